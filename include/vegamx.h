@@ -1,0 +1,232 @@
+/*
+ * vegamx.h - C ABI of the MI355X-native Vega model + chi2 engine (libvegamx.so).
+ *
+ * The engine replaces, for batches of parameter points, the per-evaluation hot path of
+ * andreicuceu/vega that sits behind
+ *     VegaInterface.compute_model / chi2 / log_lik   (reference vega/vega_interface.py:208-387)
+ *     Model.compute                                   (reference vega/model.py:157-187)
+ * i.e. PowerSpectrum.compute (vega/power_spectrum.py:87-196), PktoXi.compute
+ * (vega/pktoxi.py:99-163), CorrelationFunction.compute (vega/correlation_func.py:117-198),
+ * Metals.compute (vega/metals.py:258-367), BroadbandPolynomials.compute
+ * (vega/broadband_poly.py:74-198), the distortion-matrix product (vega/model.py:143-144)
+ * and the Gaussian chi2 (vega/vega_interface.py:295-319).
+ *
+ * The reference is pure Python and has no FFI of its own; the binding a maintainer adds is the
+ * ctypes layer shown in INTEGRATION.md (vega_amd/engine.py is that binding).
+ *
+ * Conventions
+ *   - plain C types only; all host buffers are owned by the caller; the engine owns device memory;
+ *   - every function returns 0 on success, a negative code on failure, and vmx_last_error()
+ *     then describes the failure (thread-local string);
+ *   - parameter points are rows of `theta` (row-major [B][n_params], fp64); a descriptor refers
+ *     to a parameter by its column ("slot"); slot -1 means "absent" (Python None);
+ *   - per-walker numerical failures (spline argument out of range = the reference's
+ *     VegaBoundsError, NaN/Inf in the Arinyo term = VegaArinyoError) never fail the call: they
+ *     set status[b] != 0 and chi2[b] = 1e100, the reference's sentinel
+ *     (vega/vega_interface.py:268-279);
+ *   - one engine handle = one HIP device + one stream; calls on a handle must be serialised by
+ *     the caller; distinct handles are independent.  No global mutable state.
+ */
+#ifndef VEGAMX_H
+#define VEGAMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vmx_engine vmx_engine;
+
+#define VMX_MAX_ELL 4          /* ell = 0, 2, 4, 6 (reference pktoxi.py:39,45) */
+#define VMX_MAX_SMOOTH 3       /* Gaussian-type smoothing terms per pipeline */
+
+enum { VMX_HCD_NONE = 0, VMX_HCD_ROGERS = 1, VMX_HCD_SINC = 2 };
+enum { VMX_NL_NONE = 0, VMX_NL_ARINYO = 1, VMX_NL_MCDONALD = 2 };
+enum { VMX_VD_NONE = 0, VMX_VD_GAUSS = 1, VMX_VD_LORENTZ = 2 };
+enum { VMX_SCALE_UNIT = 0, VMX_SCALE_AP_AT = 1, VMX_SCALE_AISO_EPS = 2, VMX_SCALE_PHI_ALPHA = 3 };
+enum { VMX_PKLIN_PEAK = 0, VMX_PKLIN_SMOOTH = 1, VMX_PKLIN_FULL = 2 };
+enum { VMX_EVOL_STD = 0, VMX_EVOL_CROOM = 1 };
+enum { VMX_MAT_DISTORTION = 0, VMX_MAT_INVCOV = 1, VMX_MAT_METAL = 2 };
+enum { VMX_BB_PRE_MUL = 0, VMX_BB_PRE_ADD = 1, VMX_BB_POST_MUL = 2, VMX_BB_POST_ADD = 3 };
+enum { VMX_BB_POLY = 0, VMX_BB_SKY = 1 };
+
+/* status bits written per walker */
+enum { VMX_STATUS_OK = 0, VMX_STATUS_BOUNDS = 1, VMX_STATUS_ARINYO = 2, VMX_STATUS_NONFINITE = 4 };
+
+/* A tracer's (bias, beta): two of the three slots must be present
+ * (reference vega/utils.py:45-82 _tracer_bias_beta). */
+typedef struct {
+    int32_t bias_slot;
+    int32_t bias_eta_slot;
+    int32_t beta_slot;
+    int32_t is_lya;        /* name == 'LYA': receives the UV / HCD effective bias */
+    int32_t discrete;      /* tracer type 'discrete': receives the velocity-dispersion term */
+    int32_t vd_sigma_slot; /* sigma_velo_disp_{gauss,lorentz}_<name>, -1 if not discrete */
+    int32_t evol_kind;     /* VMX_EVOL_* (reference correlation_func.py:301-370) */
+    int32_t alpha_slot;    /* alpha_<name> */
+} vmx_tracer;
+
+/* One P(k,mu) -> xi(r,mu) chain (a core peak / smooth component or one metal pair). */
+typedef struct {
+    vmx_tracer tracer[2];
+    int32_t same_tracer;            /* tracer2 is tracer1 (utils.py:103-104) */
+    int32_t growth_rate_slot;       /* 'growth_rate', -1 -> growth_rate_default */
+    double  growth_rate_default;    /* 0.970386 (utils.py:60) or a fixed override */
+    int32_t fast_metals;            /* Kaiser term without b1*b2 (power_spectrum.py:220-221) */
+    int32_t pk_lin_kind;            /* VMX_PKLIN_* (model.py:177,182,184) */
+    int32_t is_peak;                /* params['peak'] */
+
+    int32_t uvb, heii;              /* power_spectrum.py:224-261 */
+    int32_t bias_gamma_slot, bias_prim_slot, lambda_uv_slot, bias_gamma_e_slot, lambda_heii_slot;
+
+    int32_t hcd_model;              /* VMX_HCD_*  (power_spectrum.py:263-358) */
+    int32_t bias_hcd_slot, beta_hcd_slot, l0_hcd_slot;
+    double  l0_default;             /* L0_sinc default 1 (power_spectrum.py:299) */
+
+    int32_t nl_model;               /* VMX_NL_* after the skip-nl-model-in-peak rule */
+    int32_t arinyo_slot[6];         /* q1, q2, kv, av, bv, kp  (q2 may be -1 -> 0) */
+    double  arinyo_power;           /* 1 two Lya tracers, 0.5 one, 0 none (:472-477) */
+
+    int32_t gk_table;               /* id from vmx_add_gk_table, -1: no G(k) */
+
+    int32_t peak_nl;                /* apply compute_peak_nl (power_spectrum.py:382-417) */
+    int32_t sigma_nl_par_slot, sigma_nl_per_slot;
+
+    /* Gaussian smoothing terms: factor exp(-w (k_par^2 s_par^2 + k_perp^2 s_perp^2)) each
+     * (power_spectrum.py:504-553, utils.py:396-420) */
+    int32_t n_smooth;
+    int32_t smooth_par_slot[VMX_MAX_SMOOTH], smooth_per_slot[VMX_MAX_SMOOTH];
+    double  smooth_weight[VMX_MAX_SMOOTH];
+    int32_t exp_par_slot, exp_per_slot;   /* exp smoothing (power_spectrum.py:560-586), -1 none */
+
+    int32_t vd_kind;                /* VMX_VD_* (power_spectrum.py:588-636) */
+    double  damping_scale;          /* <= 0: none (power_spectrum.py:192-194) */
+    int32_t damping_power;
+
+    int32_t n_ell;                  /* multipoles 0, 2, .. 2 (n_ell - 1) */
+    int32_t scale_mode;             /* VMX_SCALE_* (scale_parameters.py:38-230) */
+    int32_t scale_slot[2];
+    int32_t drp_slot;               /* drp_<discrete tracer>, -1 none (correlation_func.py:65-69) */
+    int32_t croom_slot[2];          /* croom_par0, croom_par1 */
+    int32_t radiation;              /* QSO radiation term (correlation_func.py:446-489) */
+    int32_t rad_slot[4];            /* strength, asymmetry, lifetime, decrease */
+    double  z_eff;
+} vmx_pipe_desc;
+
+/* One metal pair's contribution: bias1*bias2*factor * M . xi_pair (metals.py:286-334). */
+typedef struct {
+    int32_t pipeline;               /* id from vmx_add_pipeline */
+    vmx_tracer tracer[2];           /* bias slots as seen by Metals.compute (after single-metal-beta) */
+    int32_t same_tracer;
+    int32_t growth_rate_slot;
+    double  growth_rate_default;
+    int32_t extra_bias_slot;        /* bias_<m1>_<m2> (separate-metal-auto-biases), -1 none */
+    int32_t apply_bias;             /* fast_metal_bias: multiply by the bias product afterwards */
+    double  multiplicity;           /* 2 for distinct metals in an auto-correlation (:238-239) */
+} vmx_metal_desc;
+
+typedef struct {
+    int32_t n_model;                /* undistorted model bins */
+    int32_t n_dist;                 /* distorted model bins (= output size) */
+    int32_t pipe_peak, pipe_smooth; /* pipeline ids */
+    int32_t bao_amp_slot;
+} vmx_item_desc;
+
+const char* vmx_last_error(void);
+
+int vmx_create(vmx_engine** out, int device);
+void vmx_destroy(vmx_engine* e);
+
+/* Template grids (vega_interface.py:690-696; power_spectrum.py:72-81; pktoxi.py:37,55).
+ * pk_peak = pk_full - pk_smooth as formed by the caller (model.py:177);
+ * delta2 = k^3 pk_fid / (2 pi^2) (power_spectrum.py:462). */
+int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* pk_peak,
+                     const double* pk_smooth, const double* pk_full, const double* delta2,
+                     int32_t n_mu);
+
+/* The linear operator P_ell(k) -> cubic-spline coefficients of xi_ell on the uniform ln r knot
+ * grid x0 + h*i: FFTLog (mcfit.P2xi call of pktoxi.py:141) followed by the not-a-knot spline of
+ * pktoxi.py:144.  op is row-major [n_coef][nk]; n_coef = n_knots + 2. */
+int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n_coef,
+                   double x0, double h, int32_t n_knots);
+
+/* G(k) binning table for one (bin_size_rp, bin_size_rt) pair (power_spectrum.py:481-502).
+ * Returns the table id (>= 0). */
+int vmx_add_gk_table(vmx_engine* e, double bin_size_rp, double bin_size_rt);
+
+/* Returns the pipeline id (>= 0).  r, mu, z, rel_z_evol, xi_growth: [n] (correlation_func.py:46-80,252). */
+int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const double* r,
+                     const double* mu, const double* z, const double* rel_z_evol,
+                     const double* xi_growth);
+
+/* Returns the item id (>= 0). */
+int vmx_add_item(vmx_engine* e, const vmx_item_desc* desc);
+int vmx_item_add_metal(vmx_engine* e, int32_t item, const vmx_metal_desc* desc);
+
+/* Broadband term (broadband_poly.py:119-198).
+ *  VMX_BB_POLY: slots[n_coef] coefficient slots, basis [n_coef][n] = r1^i r2^j per coefficient;
+ *  VMX_BB_SKY:  slots = {scale, sigma}, basis [2][n] = {rt, window(0/1)}.
+ * n = n_model for pre terms, n_dist for post terms. */
+int vmx_item_add_broadband(vmx_engine* e, int32_t item, int32_t position, int32_t func,
+                           int32_t n_coef, const int32_t* slots, const double* basis, int32_t n);
+
+/* Dense row-major matrices.  VMX_MAT_DISTORTION [n_dist][n_model] (model.py:143-144);
+ * VMX_MAT_INVCOV [n_masked][n_masked] (vega_interface.py:316); VMX_MAT_METAL [n_model][n_pair]
+ * with `index` = position of the metal in the order of vmx_item_add_metal (metals.py:338-367).
+ * A matrix that is never set is the identity (data.py:77-78, :683-684). */
+int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index, int32_t rows,
+                        int32_t cols, const double* dense);
+/* Indices (into the n_dist model bins) kept by the model mask (data.py:410). */
+int vmx_item_set_mask(vmx_engine* e, int32_t item, const int32_t* idx, int32_t n_masked);
+/* Masked data vector, or the current Monte-Carlo mock (vega_interface.py:311-315). */
+int vmx_item_set_data(vmx_engine* e, int32_t item, const double* masked_data, int32_t n_masked);
+
+/* Global-covariance mode (vega_interface.py:295-304): inverse of the masked global covariance over
+ * the concatenation of all items' masked bins, in item order. */
+int vmx_set_global_invcov(vmx_engine* e, const double* invcov, int32_t n);
+
+int vmx_add_prior(vmx_engine* e, int32_t slot, double mean, double sigma);
+
+/* Allocate the per-batch workspace.  After this the engine is immutable except for
+ * vmx_item_set_data / vmx_item_set_matrix(INVCOV) / vmx_set_global_invcov. */
+int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch);
+
+/* Total output size per walker: sum of n_dist over items, in item order. */
+int vmx_model_size(vmx_engine* e);
+
+/* Evaluate B parameter points.  theta [B][n_params] host memory.
+ * chi2 [B] (may be NULL), model [B][vmx_model_size] (may be NULL), status [B] (may be NULL).
+ * Synchronous: outputs are valid on return. */
+int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double* model,
+             int32_t* status);
+
+/* Same with theta / chi2 already in device memory (no host copies, no synchronisation: the work
+ * is enqueued on the engine stream; use vmx_sync).  d_model may be NULL. */
+int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2,
+                    double* d_model, int32_t* d_status);
+int vmx_sync(vmx_engine* e);
+
+/* Stage taps for parity tests: copy an internal buffer of the last evaluation to the host.
+ * what: 0 = P_ell(k) [n_ell_max][B*n_pipe][nk_pad]; 1 = xi per pipeline [B][n] (index = pipeline).
+ * Returns the number of doubles written (<= capacity) or a negative error. */
+int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, int64_t capacity);
+
+/* Stand-alone distortion-style product y[b] = A x[b] through the same kernels the evaluation
+ * uses (bench / roofline measurement of the distortion-matrix step).  d_A row-major [rows][cols],
+ * d_x [B][cols], d_y [B][rows], all device pointers; enqueued on the engine stream. */
+int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t cols,
+                      const double* d_x, int32_t B, double* d_y);
+
+/* Per-kernel timing with HIP events on the engine stream.  When enabled every kernel launch of
+ * vmx_eval* is bracketed by events; vmx_get_timings returns the accumulated milliseconds and
+ * launch counts per kernel class since the last reset. */
+#define VMX_N_KERNELS 12
+int vmx_set_profiling(vmx_engine* e, int32_t enabled);
+int vmx_get_timings(vmx_engine* e, double* ms, int64_t* launches, int32_t reset);
+const char* vmx_kernel_name(int32_t kernel_class);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEGAMX_H */

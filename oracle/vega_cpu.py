@@ -1,0 +1,682 @@
+"""TEST INFRASTRUCTURE (oracle) - NumPy restatement of the reference's model + chi2 hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module; nothing under ``vega_amd/`` does.  It is the checker, never the product.
+
+Every function restates, for one parameter dictionary, what the reference computes, citing the
+reference file:line it follows.  Inputs are the plain records built by ``vega_amd.setup``
+(arrays + option flags); the arithmetic below is independent of the engine.
+
+Pinning (see tests/test_oracle.py, tests/golden/make_golden.py):
+  * the P(k,mu) known answers of reference tests/test_pk.py;
+  * the 14 picca golden xi vectors of reference tests/data/picca_bench_data.fits
+    (in-repo Hamilton FFTLog path, ``old_fftlog``);
+  * the pinned log-likelihood of reference tests/test_vega.py:14 (mcfit path, through the restated
+    FFTLog of oracle/fftlog.py);
+  * stage-by-stage outputs of the unmodified reference run under import shims in the build
+    container (tests/golden/*.npz).
+"""
+import numpy as np
+from scipy import interpolate, special
+
+from .fftlog import P2xi
+
+DEFAULT_GROWTH_RATE = 0.970386   # reference vega/utils.py:60
+
+
+class OracleModelError(Exception):
+    """Stands for the reference's VegaModelError family (vega/utils.py:444-453)."""
+
+
+# --------------------------------------------------------------------------------------
+# parameters -> tracer bias / beta   (reference vega/utils.py:45-108)
+# --------------------------------------------------------------------------------------
+def tracer_bias_beta(params, name):
+    growth_rate = params.get('growth_rate', DEFAULT_GROWTH_RATE)
+    bias = params.get('bias_' + name, None)
+    bias_eta = params.get('bias_eta_' + name, None)
+    beta = params.get('beta_' + name, None)
+    if bias is None:
+        assert bias_eta is not None and beta is not None, f'Offending tracer: {name}'
+        bias = bias_eta * growth_rate / beta
+    if bias_eta is None:
+        assert bias is not None and beta is not None, f'Offending tracer: {name}'
+    if beta is None:
+        assert bias is not None and bias_eta is not None, f'Offending tracer: {name}'
+        beta = bias_eta * growth_rate / bias
+    return bias, beta
+
+
+def bias_beta(params, name1, name2):
+    b1, be1 = tracer_bias_beta(params, name1)
+    if name1 == name2:
+        return b1, be1, b1, be1
+    b2, be2 = tracer_bias_beta(params, name2)
+    return b1, be1, b2, be2
+
+
+# --------------------------------------------------------------------------------------
+# P(k, mu)   (reference vega/power_spectrum.py)
+# --------------------------------------------------------------------------------------
+class PkGrid:
+    """mu/k grids of one PowerSpectrum object (reference power_spectrum.py:76-81)."""
+
+    def __init__(self, k, n_mu):
+        self.k = np.asarray(k, dtype=float)
+        mu = (np.arange(n_mu) + 0.5) / n_mu
+        self.mu = mu[:, None]
+        self.k_par = self.k * self.mu
+        self.k_trans = self.k * np.sqrt(1 - self.mu**2)
+
+
+def sinc(x):
+    return np.sin(x) / x          # reference vega/utils.py:28-42
+
+
+def _uv_heii(opts, grid, bias, beta, params):
+    """reference power_spectrum.py:224-261"""
+    bias_eff = bias
+    if opts.uvb:
+        W = np.arctan(grid.k * params['lambda_uv']) / (grid.k * params['lambda_uv'])
+        bias_eff = bias_eff + params['bias_gamma'] * W / (1 + params['bias_prim'] * W)
+    if opts.heii:
+        W = np.arctan(grid.k * params['lambda_HeII']) / (grid.k * params['lambda_HeII'])
+        bias_eff = bias_eff + params['bias_gamma_e'] * W / (1 + params['bias_prim'] * W)
+    beta_eff = beta * bias / bias_eff
+    return bias_eff, beta_eff
+
+
+def _hcd(opts, grid, corr_name, bias, beta, params):
+    """reference power_spectrum.py:263-380"""
+    bias_hcd = params.get(f'bias_hcd_{corr_name}', None)
+    if bias_hcd is None:
+        bias_hcd = params['bias_hcd']
+    beta_hcd = params.get(f'beta_hcd_{corr_name}', None)
+    if beta_hcd is None:
+        beta_hcd = params['beta_hcd']
+
+    if opts.hcd_model == 'Rogers':
+        F = np.exp(-params['L0_hcd'] * grid.k_par)
+    elif opts.hcd_model == 'fvoigt':
+        L0 = params.get('L0_fvoigt', 1)
+        F = np.interp(L0 * grid.k_par, opts.fvoigt_table[:, 0], opts.fvoigt_table[:, 1],
+                      left=1, right=0)
+    elif opts.hcd_model == 'sinc':
+        F = sinc(grid.k_par * params.get('L0_sinc', 1))
+    else:
+        raise ValueError(opts.hcd_model)
+
+    bias_eff = bias + bias_hcd * F
+    beta_eff = (bias * beta + bias_hcd * beta_hcd * F) / (bias + bias_hcd * F)
+    return bias_eff, beta_eff
+
+
+def _arinyo(grid, pk_fid, name1, name2, params):
+    """reference power_spectrum.py:435-479 (no allclose cache: recomputed exactly)"""
+    two_lya = 'LY' in name1 and 'LY' in name2
+    one_lya = 'LY' in name1 or 'LY' in name2
+    q1 = params['dnl_arinyo_q1']
+    kv = params['dnl_arinyo_kv']
+    av = params['dnl_arinyo_av']
+    bv = params['dnl_arinyo_bv']
+    kp = params['dnl_arinyo_kp']
+    q2 = params.get('dnl_arinyo_q2', 0)
+    delta2 = grid.k**3 * pk_fid / (2 * np.pi**2)
+    growth = q1 * delta2 + q2 * delta2**2
+    pec = (grid.k / kv)**av * np.abs(grid.mu)**bv
+    pressure = (grid.k / kp) * (grid.k / kp)
+    dnl = np.exp(growth * (1 - pec) - pressure)
+    if np.any(np.isnan(dnl)) or np.any(np.isinf(dnl)):
+        raise OracleModelError('arinyo')
+    if two_lya:
+        return dnl
+    if one_lya:
+        return np.sqrt(dnl)
+    return np.ones(dnl.shape)
+
+
+def _mcdonald(grid):
+    """reference power_spectrum.py:419-433"""
+    kvel = 1.22 * (1 + grid.k / 0.923)**0.451
+    dnl = (grid.k / 6.4)**0.569 - (grid.k / 15.3)**2.01
+    dnl = dnl - (grid.k * grid.mu / kvel)**1.5
+    return np.exp(dnl)
+
+
+def _gk(opts, grid, dataset, params):
+    """reference power_spectrum.py:481-502"""
+    bs_rp = params.get(f'par binsize {dataset}', opts.bin_size_rp)
+    bs_rt = params.get(f'per binsize {dataset}', opts.bin_size_rt)
+    gk = 1.
+    if bs_rp != 0:
+        gk = gk * sinc(grid.k_par * bs_rp / 2)
+    if bs_rt != 0:
+        gk = gk * sinc(grid.k_trans * bs_rt / 2)
+    return gk
+
+
+def _peak_nl(grid, params):
+    """reference power_spectrum.py:382-417"""
+    s_par = params.get('sigmaNL_par', None)
+    s_trans = params.get('sigmaNL_per', None)
+    f = params.get('growth_rate')
+    if s_par is None and s_trans is not None:
+        s_par = s_trans * (1 + f)
+    elif s_trans is None and s_par is not None:
+        s_trans = s_par / (1 + f)
+    elif s_par is None and s_trans is None:
+        raise ValueError('No parameters for peak NL found.')
+    return np.exp(-(grid.k_par**2 * s_par**2 + grid.k_trans**2 * s_trans**2) / 2)
+
+
+def _gauss(grid, s_par, s_trans):
+    """reference vega/utils.py:396-420"""
+    return np.exp(-(grid.k_par**2 * s_par**2 + grid.k_trans**2 * s_trans**2) / 2)
+
+
+def _fullshape_gauss(grid, name1, name2, params):
+    """reference power_spectrum.py:504-553"""
+    main1 = name1 in ('LYA', 'QSO')
+    main2 = name2 in ('LYA', 'QSO')
+    if ('par_sigma_smooth' in params) or ('per_sigma_smooth' in params):
+        s_par = params.get('par_sigma_smooth', None)
+        s_trans = params.get('per_sigma_smooth', None)
+        if s_par is None:
+            s_par = s_trans
+        elif s_trans is None:
+            s_trans = s_par
+        return _gauss(grid, s_par, s_trans)**2
+    if (('par_sigma_smooth_metals' in params) and ('per_sigma_smooth_metals' in params)
+            and not (main1 and main2)):
+        return _gauss(grid, params['par_sigma_smooth_metals'],
+                      params['per_sigma_smooth_metals'])**2
+    return (_gauss(grid, params[f'par_sigma_smooth_{name1}'], params[f'per_sigma_smooth_{name1}'])
+            * _gauss(grid, params[f'par_sigma_smooth_{name2}'], params[f'per_sigma_smooth_{name2}']))
+
+
+def _fullshape_exp(grid, params):
+    """reference power_spectrum.py:560-586"""
+    g = grid.k_par**2 * params['par_sigma_smooth']**2 + grid.k_trans**2 * params['per_sigma_smooth']**2
+    e = np.abs(grid.k_par) * params['par_exp_smooth']**2 + np.abs(grid.k_trans) * params['per_exp_smooth']**2
+    return np.exp(-g / 2) * np.exp(-e)
+
+
+def _velocity_dispersion(kind, grid, tr1, tr2, params):
+    """reference power_spectrum.py:588-636"""
+    assert 'discrete' in (tr1.type, tr2.type)
+    sm = np.ones(grid.k_par.shape)
+    for tr in (tr1, tr2):
+        if tr.type != 'discrete':
+            continue
+        if kind == 'gauss':
+            sigma = params['sigma_velo_disp_gauss_' + tr.name]
+            sm *= np.exp(-0.25 * (grid.k_par * sigma)**2)
+        else:
+            sigma = params['sigma_velo_disp_lorentz_' + tr.name]
+            sm *= 1. / np.sqrt(1 + (grid.k_par * sigma)**2)
+    return sm
+
+
+def power_spectrum(pipe, grid, pk_lin, pk_fid, params, fast_metals=False):
+    """PowerSpectrum.compute (reference power_spectrum.py:87-196)."""
+    opts = pipe.pk
+    n1, n2 = pipe.tracer1.name, pipe.tracer2.name
+    bias1, beta1, bias2, beta2 = bias_beta(params, n1, n2)
+
+    if opts.uvb or opts.heii:
+        if n1 == 'LYA':
+            bias1, beta1 = _uv_heii(opts, grid, bias1, beta1, params)
+        if n2 == 'LYA':
+            bias2, beta2 = _uv_heii(opts, grid, bias2, beta2, params)
+    if opts.hcd_model is not None:
+        if n1 == 'LYA':
+            bias1, beta1 = _hcd(opts, grid, pipe.corr_name, bias1, beta1, params)
+        if n2 == 'LYA':
+            bias2, beta2 = _hcd(opts, grid, pipe.corr_name, bias2, beta2, params)
+
+    # Kaiser (reference :198-222)
+    kaiser = (1 + beta1 * grid.mu**2)
+    kaiser = kaiser * (1 + beta2 * grid.mu**2)
+    if not fast_metals:
+        kaiser = kaiser * (bias1 * bias2)
+    pk = pk_lin * kaiser
+
+    skip_nl = opts.skip_nl_in_peak and params['peak']
+    if opts.small_scale_nl is not None and not skip_nl:
+        if opts.small_scale_nl == 'arinyo':
+            pk = pk * _arinyo(grid, pk_fid, n1, n2, params)
+        else:
+            assert n1 == 'LYA' and n2 == 'LYA'
+            pk = pk * _mcdonald(grid)
+    if opts.use_gk:
+        pk = pk * _gk(opts, grid, pipe.dataset, params)
+    if params['peak']:
+        pk = pk * _peak_nl(grid, params)
+    if opts.fullshape_smoothing is not None and not skip_nl:
+        if opts.fullshape_smoothing == 'gauss':
+            pk = pk * _fullshape_gauss(grid, n1, n2, params)
+        else:
+            pk = pk * _fullshape_exp(grid, params)
+    if opts.velocity_dispersion is not None:
+        pk = pk * _velocity_dispersion(opts.velocity_dispersion, grid, pipe.tracer1,
+                                       pipe.tracer2, params)
+    if opts.damping_scale is not None:
+        pk = pk * np.exp(-opts.damping_scale**2 * grid.k**opts.damping_power / 2)
+    return pk
+
+
+# --------------------------------------------------------------------------------------
+# P(k, mu) -> xi(r, mu)   (reference vega/pktoxi.py)
+# --------------------------------------------------------------------------------------
+_LEGENDRE = {ell: special.legendre(ell) for ell in range(0, 9)}
+_P2XI_CACHE = {}
+
+
+def _p2xi(k, ell):
+    key = (k.tobytes(), ell)
+    if key not in _P2XI_CACHE:
+        _P2XI_CACHE[key] = P2xi(k, l=ell, lowring=True)
+    return _P2XI_CACHE[key]
+
+
+def pk_multipoles(grid, pk, ell_vals):
+    """reference pktoxi.py:138 - 1000-point midpoint rule on [0, 1]"""
+    dmu = 1 / len(grid.mu)
+    return np.array([np.sum(dmu * _LEGENDRE[ell](grid.mu) * pk, axis=0) * (2 * ell + 1)
+                     for ell in ell_vals])
+
+
+def hamilton_multipoles(ar, k, pk, ell_vals, muk, dmuk, tform=None):
+    """The reference's legacy in-repo FFTLog, ``PktoXi.Pk2Mp`` (reference pktoxi.py:230-279)."""
+    k0 = k[0]
+    ln_range = np.log(k.max() / k0)
+    r0 = 1.
+    N = len(k)
+    emm = N * np.fft.fftfreq(N)
+    r = r0 * np.exp(-emm * ln_range / N)
+    dr = abs(np.log(r[1] / r[0]))
+    s = np.argsort(r)
+    r = r[s]
+    xi = np.zeros([len(ell_vals), len(ar)])
+    for ell in ell_vals:
+        if tform == 'rel':
+            pk_ell, n = pk, 1.
+        elif tform == 'asy':
+            pk_ell, n = pk, 2.
+        else:
+            pk_ell = np.sum(dmuk * _LEGENDRE[ell](muk) * pk, axis=0) * (2 * ell + 1)
+            pk_ell = pk_ell * (-1)**(ell // 2) / 2 / np.pi**2
+            n = 2.
+        mu = ell + 0.5
+        q = 2 - n - 0.5
+        x = q + 2 * np.pi * 1j * emm / ln_range
+        lg1 = special.loggamma((mu + 1 + x) / 2)
+        lg2 = special.loggamma((mu + 1 - x) / 2)
+        um = (k0 * r0)**(-2 * np.pi * 1j * emm / ln_range) * 2**x * np.exp(lg1 - lg2)
+        um[0] = np.real(um[0])
+        an = np.fft.fft(pk_ell * k**n * np.sqrt(np.pi / 2))
+        an = an * um
+        xi_loc = np.fft.ifft(an)
+        xi_loc = xi_loc[s]
+        xi_loc = xi_loc / r**(3 - n)
+        xi_loc[-1] = 0
+        spline = interpolate.splrep(np.log(r) - dr / 2, np.real(xi_loc), k=3, s=0)
+        xi[ell // 2, :] = interpolate.splev(np.log(ar), spline)
+    return xi
+
+
+def pk_to_xi(pipe, grid, r_grid, mu_grid, pk, taps=None):
+    """PktoXi.compute (reference pktoxi.py:99-163) / pk_to_xi for ``old_fftlog`` (:281-319)."""
+    ell_vals = tuple(range(0, pipe.xi.ell_max + 1, 2))
+    single = pipe.xi.single_multipole
+    if single >= 0:
+        ell_vals = (single,)
+
+    if pipe.xi.old_fftlog:
+        xi = hamilton_multipoles(r_grid, grid.k, pk, ell_vals, grid.mu, 1 / len(grid.mu))
+        if single >= 0:
+            return xi[single // 2]
+        for ell in ell_vals:
+            xi[ell // 2, :] *= _LEGENDRE[ell](mu_grid)
+        return np.sum(xi, axis=0)
+
+    xi_ell_arr = np.zeros([len(ell_vals), len(r_grid)])
+    pk_ells = pk_multipoles(grid, pk, ell_vals)
+    for i, ell in enumerate(ell_vals):
+        r_fft, xi_fft = _p2xi(grid.k, ell)(pk_ells[i], extrap=False)
+        if taps is not None:
+            taps.setdefault('pk_ell', {})[ell] = pk_ells[i]
+            taps.setdefault('xi_fft', {})[ell] = (r_fft, xi_fft)
+        interp = interpolate.interp1d(np.log(r_fft), xi_fft, kind='cubic')
+        mask = r_grid != 0
+        xi_ell = np.zeros(len(r_grid))
+        try:
+            xi_ell[mask] = interp(np.log(r_grid[mask]))
+        except ValueError:
+            raise OracleModelError('bounds')
+        if single >= 0:
+            return xi_ell
+        xi_ell_arr[i, :] = xi_ell * _LEGENDRE[ell](mu_grid)
+    return np.sum(xi_ell_arr, axis=0)
+
+
+# --------------------------------------------------------------------------------------
+# scale parameters (reference vega/scale_parameters.py:38-230)
+# --------------------------------------------------------------------------------------
+def get_ap_at(scale, params, corr_name=None, metal_corr=False):
+    if metal_corr and not scale.metal_scaling:
+        return 1., 1.
+
+    def bao():
+        if scale.parametrisation == 'ap_at':
+            return params['ap'], params['at']
+        if scale.parametrisation == 'aiso_epsilon':
+            return (params['aiso'] * (1 + params['epsilon'])**2,
+                    params['aiso'] / (1 + params['epsilon']))
+        return params['alpha'] / np.sqrt(params['phi']), params['alpha'] * np.sqrt(params['phi'])
+
+    def fullshape():
+        if scale.parametrisation != 'phi_alpha' and not scale.full_shape_alpha:
+            raise ValueError('Only the "phi_alpha" parametrisation works with split full-shape.')
+        if scale.parametrisation == 'ap_at':
+            return params['ap_full'], params['at_full']
+        if scale.parametrisation == 'aiso_epsilon':
+            return (params['aiso_full'] * (1 + params['epsilon_full'])**2,
+                    params['aiso_full'] / (1 + params['epsilon_full']))
+        phi_name = 'phi_full' if scale.full_shape else 'phi_smooth'
+        if scale.full_shape_alpha:
+            alpha_name = 'alpha_full'
+        elif params['peak']:
+            alpha_name = 'alpha'
+        elif scale.two_alpha_smooth:
+            alpha_name = f'alpha_smooth_{corr_name}'
+        else:
+            alpha_name = 'alpha_smooth'
+        phi, alpha = params[phi_name], params[alpha_name]
+        return alpha / np.sqrt(phi), alpha * np.sqrt(phi)
+
+    if scale.full_shape:
+        return fullshape()
+    if params['peak']:
+        return bao()
+    if scale.smooth_scaling:
+        return fullshape()
+    return 1., 1.
+
+
+# --------------------------------------------------------------------------------------
+# xi(r, mu) on the bins (reference vega/correlation_func.py)
+# --------------------------------------------------------------------------------------
+def rescale_coords(r, mu, ap, at, delta_rp=0.):
+    """reference correlation_func.py:200-236"""
+    mask = r != 0
+    rp = r[mask] * mu[mask] + delta_rp
+    rt = r[mask] * np.sqrt(1 - mu[mask]**2)
+    rrp, rrt = ap * rp, at * rt
+    rr = np.zeros(len(r))
+    rmu = np.zeros(len(mu))
+    rr[mask] = np.sqrt(rrp**2 + rrt**2)
+    rmu[mask] = rrp / rr[mask]
+    return rr, rmu
+
+
+def _tracer_evol(pipe, params, name, z_eff):
+    """reference correlation_func.py:301-370"""
+    if pipe.xi.evol_model.get(name, 'standard') == 'croom':
+        assert name == 'QSO'
+        p0, p1 = params['croom_par0'], params['croom_par1']
+        return (p0 + p1 * (1. + pipe.z)**2) / (p0 + p1 * (1 + z_eff)**2)
+    return pipe.rel_z_evol**params[f'alpha_{name}']
+
+
+def qso_radiation(pipe, params, rescaled_r, rescaled_mu):
+    """reference correlation_func.py:446-489"""
+    delta_rp = params.get(pipe.delta_rp_name, 0.)
+    if pipe.xi.rescale_coords_systematics:
+        rp = rescaled_r * rescaled_mu + delta_rp
+        rt = rescaled_r * np.sqrt(1 - rescaled_mu**2)
+    else:
+        rp = pipe.r * pipe.mu + delta_rp
+        rt = pipe.r * np.sqrt(1 - pipe.mu**2)
+    r_shift = np.sqrt(rp**2 + rt**2)
+    mu_shift = rp / r_shift
+    xi_rad = params['qso_rad_strength'] / (r_shift**2) * (
+        1 - params['qso_rad_asymmetry'] * (1 - mu_shift**2))
+    xi_rad = xi_rad * np.exp(-r_shift * ((1 + mu_shift) / params['qso_rad_lifetime']
+                                         + 1 / params['qso_rad_decrease']))
+    return xi_rad
+
+
+def correlation_function(prob, pipe, grid, pk, pk_lin, params, taps=None):
+    """CorrelationFunction.compute (reference correlation_func.py:117-198)."""
+    delta_rp = 0.
+    if pipe.delta_rp_name is not None:
+        delta_rp = params.get(pipe.delta_rp_name, 0.)
+    ap, at = get_ap_at(prob.scale, params, corr_name=pipe.corr_name, metal_corr=pipe.metal_corr)
+    rr, rmu = rescale_coords(pipe.r, pipe.mu, ap, at, delta_rp)
+    xi = pk_to_xi(pipe, grid, rr, rmu, pk, taps)
+
+    evol = _tracer_evol(pipe, params, pipe.tracer1.name, prob.z_eff)
+    evol = evol * _tracer_evol(pipe, params, pipe.tracer2.name, prob.z_eff)
+    xi = xi * evol
+    xi = xi * pipe.xi_growth
+
+    if pipe.xi.radiation and not params['peak']:
+        xi = xi + qso_radiation(pipe, params, rr, rmu)
+
+    if pipe.xi.relativistic or pipe.xi.asymmetry:
+        # reference correlation_func.py:491-551 -> pktoxi.py:321-382 (corr_name NOT passed there)
+        ap2, at2 = get_ap_at(prob.scale, params, metal_corr=pipe.metal_corr)
+        rr2, rmu2 = rescale_coords(pipe.r, pipe.mu, ap2, at2, params.get(pipe.delta_rp_name, 0.))
+        dmu = 1 / len(grid.mu)
+        if pipe.xi.relativistic:
+            x = hamilton_multipoles(rr2, grid.k, pk_lin, [1, 3], grid.mu, dmu, tform='rel')
+            xi = xi + (params['Arel1'] * x[0, :] * _LEGENDRE[1](rmu2)
+                       + params['Arel3'] * x[1, :] * _LEGENDRE[3](rmu2))
+        if pipe.xi.asymmetry:
+            x = hamilton_multipoles(rr2, grid.k, pk_lin, [0, 2], grid.mu, dmu, tform='asy')
+            xa = (params['Aasy0'] * x[0, :] - params['Aasy2'] * x[1, :]) * rr2 * _LEGENDRE[1](rmu2)
+            xa = xa + params['Aasy3'] * x[1, :] * rr2 * _LEGENDRE[3](rmu2)
+            xi = xi + xa
+    return xi
+
+
+# --------------------------------------------------------------------------------------
+# metals (reference vega/metals.py:209-367)
+# --------------------------------------------------------------------------------------
+def metals_compute(prob, item, grid, params, pk_lin, taps=None):
+    """Metals.compute, slow (exact) mode (reference metals.py:258-336)."""
+    opts = item.metal_opts
+    local = dict(params)
+    main = (item.tracer1.name, item.tracer2.name)
+    xi_metals = np.zeros(item.model_grid.size)
+    for pair in item.metals:
+        n1, n2 = pair.names
+        if opts['single_metal_beta']:
+            if n1 not in main:
+                local[f'beta_{n1}'] = local['beta_metals']
+            if n2 not in main:
+                local[f'beta_{n2}'] = local['beta_metals']
+        b1, _, b2, _ = bias_beta(local, n1, n2)
+        bias_product = b1 * b2
+        if (not pair.cross_with_main) and opts['separate_metal_auto_biases'] and n1 != n2:
+            for cand in pair.auto_bias_names:
+                if cand in local:
+                    bias_product = b1 * b2 * local[cand]
+                    break
+            else:
+                raise ValueError(f'no separate auto bias for {pair.names}')
+
+        fast = opts['fast_metal_bias']
+        pk = power_spectrum(pair.pipeline, grid, pk_lin, prob.pk_fid, local, fast_metals=fast)
+        xi = correlation_function(prob, pair.pipeline, grid, pk, pk_lin, local)
+        if pair.double_count:
+            xi = xi * 2                                   # reference metals.py:238-239
+        if pair.matrix is not None:
+            xi = pair.matrix.dot(xi)                      # reference metals.py:338-367
+        if taps is not None:
+            taps.setdefault('xi_metal', {})[pair.names] = xi
+        xi_metals = xi_metals + (bias_product * xi if fast else xi)
+    return xi_metals
+
+
+# --------------------------------------------------------------------------------------
+# broadband (reference vega/broadband_poly.py:74-198)
+# --------------------------------------------------------------------------------------
+def broadband(item, params, pos_type):
+    pos, kind = pos_type.split('-')
+    grid = item.model_grid if pos == 'pre' else item.dist_grid
+    total = None
+    for term in item.broadband:
+        if term.pos != pos or term.kind != kind:
+            continue
+        if term.func == 'broadband_sky':
+            scale = params[term.name + '-scale-sky']
+            sigma = params[term.name + '-sigma-sky']
+            corr = scale / (sigma * np.sqrt(2. * np.pi)) * np.exp(-0.5 * (grid.rt / sigma)**2)
+            w = (grid.rp >= 0.) & (grid.rp < grid.rp_binsize)
+            corr[~w] = 0.
+        else:
+            if term.coords == 'r,mu':
+                r1, r2 = grid.r / 100., grid.mu
+            else:
+                r1 = grid.r / 100. * grid.mu
+                r2 = grid.r / 100. * np.sqrt(1 - grid.mu**2)
+            r1_min, r1_max, dr1 = term.r1
+            r2_min, r2_max, dr2 = term.r2
+            p1 = np.arange(r1_min, r1_max + 1, dr1)
+            p2 = np.arange(r2_min, r2_max + 1, dr2)
+            coef = np.array([params[f'{term.name} ({i},{j})'] for i in p1 for j in p2])
+            coef = coef.reshape(r1_max - r1_min + 1, -1)
+            corr = (coef[None, :, :] * r1[:, None, None]**p1[None, :, None]
+                    * r2[:, None, None]**p2[None, None, :]).sum(axis=(1, 2))
+        if total is None:
+            total = 1 + corr if kind == 'mul' else corr
+        elif kind == 'mul':
+            total = total * (1 + corr)
+        else:
+            total = total + corr
+    if total is None:
+        total = 1 if kind == 'mul' else 0
+    return total
+
+
+# --------------------------------------------------------------------------------------
+# model assembly (reference vega/model.py:79-187) and chi2 (vega/vega_interface.py:208-446)
+# --------------------------------------------------------------------------------------
+_GRID_CACHE = {}
+
+
+def _grid(prob, n_mu):
+    key = (id(prob), n_mu)
+    if key not in _GRID_CACHE:
+        _GRID_CACHE[key] = PkGrid(prob.k, n_mu)
+    return _GRID_CACHE[key]
+
+
+def _component(prob, item, params, pk_lin, component, xi_metals=None, taps=None):
+    """Model._compute_model (reference model.py:79-155)."""
+    grid = _grid(prob, item.core.pk.n_mu)
+    pk = power_spectrum(item.core, grid, pk_lin, prob.pk_fid, params)
+    sub = None if taps is None else taps.setdefault(component, {})
+    xi = correlation_function(prob, item.core, grid, pk, pk_lin, params, sub)
+    if sub is not None:
+        sub['pk_mean'] = float(np.mean(pk))
+        sub['xi_core'] = xi.copy()
+    if item.metals:
+        if item.metal_opts['no_metal_decomp'] and xi_metals is not None:
+            xi = xi + xi_metals
+        elif not item.metal_opts['no_metal_decomp']:
+            xi = xi + metals_compute(prob, item, grid, params, pk_lin)
+    if item.broadband:
+        xi = xi * broadband(item, params, 'pre-mul')
+        xi = xi + broadband(item, params, 'pre-add')
+    if item.distortion is not None:
+        xi = item.distortion.dot(xi)
+    if item.broadband:
+        xi = xi * broadband(item, params, 'post-mul')
+        xi = xi + broadband(item, params, 'post-add')
+    if sub is not None:
+        sub['xi_distorted'] = np.array(xi)
+    return xi
+
+
+def model_compute(prob, item, params, taps=None):
+    """Model.compute (reference model.py:157-187)."""
+    pars = dict(params)
+    pars['peak'] = True
+    xi_peak = _component(prob, item, pars, prob.pk_full - prob.pk_smooth, 'peak', taps=taps)
+    pars['peak'] = False
+    xi_metals = None
+    if item.metals and item.metal_opts['no_metal_decomp']:
+        grid = _grid(prob, item.core.pk.n_mu)
+        xi_metals = metals_compute(prob, item, grid, pars, prob.pk_full, taps)
+        if taps is not None:
+            taps['xi_metals'] = xi_metals.copy()
+    xi_smooth = _component(prob, item, pars, prob.pk_smooth, 'smooth', xi_metals=xi_metals,
+                           taps=taps)
+    return pars['bao_amp'] * xi_peak + xi_smooth
+
+
+def local_params(prob, params=None):
+    """VegaInterface._get_lcl_prms without blinding (reference vega_interface.py:389-421)."""
+    out = dict(prob.params)
+    if params is not None:
+        out.update(params)
+    return out
+
+
+def compute_model(prob, params=None, taps=None):
+    """VegaInterface.compute_model (reference vega_interface.py:208-248)."""
+    lp = local_params(prob, params)
+    return {name: model_compute(prob, item, lp, None if taps is None else taps.setdefault(name, {}))
+            for name, item in prob.items.items()}
+
+
+def prior_chi2(prob, params=None):
+    """reference vega_interface.py:423-446, :818-820"""
+    lp = local_params(prob, params)
+    chi2 = 0
+    for name, (mean, sigma) in prob.priors.items():
+        assert name in lp
+        chi2 += (lp[name] - mean)**2 / sigma**2
+    return chi2
+
+
+def chi2(prob, params=None, data_override=None):
+    """VegaInterface.chi2 (reference vega_interface.py:250-325); 1e100 on a model error."""
+    try:
+        model = compute_model(prob, params)
+    except OracleModelError:
+        return 1e100
+    if prob.global_cov is not None:
+        g = prob.global_masks()
+        data = np.concatenate([it.masked_data_vec for it in prob.items.values()]) \
+            if data_override is None else data_override
+        full = np.concatenate([model[name] for name in prob.items])
+        diff = data - full[g['model_mask']]
+        total = diff.T.dot(g['invcov'].dot(diff))
+    else:
+        total = 0
+        for name, item in prob.items.items():
+            data = item.masked_data_vec if data_override is None else data_override[name]
+            diff = data - model[name][item.model_mask]
+            total += diff.T.dot(item.inv_masked_cov.dot(diff))
+    total += prior_chi2(prob, params)
+    return float(total)
+
+
+def log_lik(prob, params=None):
+    """VegaInterface.log_lik (reference vega_interface.py:327-387)."""
+    c2 = chi2(prob, params)
+    log_norm = 0
+    for item in prob.items.values():
+        log_norm -= 0.5 * item.data_size * np.log(2 * np.pi)
+        if prob.global_cov is None:
+            log_norm -= 0.5 * item.log_cov_det
+    if prob.global_cov is not None:
+        log_norm -= 0.5 * prob.global_masks()['log_det']
+    out = log_norm - 0.5 * c2
+    for (_, sigma) in prob.priors.values():
+        out += -0.5 * np.log(2 * np.pi) - np.log(sigma)
+    return float(out)

@@ -1,0 +1,318 @@
+"""Generate the committed golden fixtures from the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference; the GPU box never runs this):
+
+    python tests/golden/make_golden.py
+
+What it does
+  1. converts the reference's test inputs (template P(k), data vectors + grids, metal grids,
+     picca benchmark vectors) into ``tests/golden/inputs/*.npz`` bundles (data, not source);
+  2. derives the test configs under ``tests/golden/configs/`` from the reference's own test
+     configs, only rewriting file names to point at those bundles;
+  3. imports the reference (``/root/reference/vega``) under the import stand-ins of
+     ``tools/refshim`` (packages absent from this image; ``mcfit`` -> ``oracle/fftlog.py``) and
+     dumps its outputs - models, chi2, log-likelihood and per-stage taps - for the fiducial
+     point and for seeded walkers into ``tests/golden/expected_*.npz``.
+
+The reference's ``allclose``-keyed grid caches are reset between walkers
+so that every dumped value is an exact recomputation.
+"""
+import configparser
+import io
+import os
+import re
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REF = Path('/root/reference')
+
+sys.path[:0] = [str(REPO / 'tools' / 'refshim'), str(REPO), str(REF), str(REF / 'tests')]
+
+from vega_amd import fitslite                       # noqa: E402
+from vega_amd.tables import Table, write_bundle     # noqa: E402
+from vega_amd import synthetic                      # noqa: E402
+
+WALKER_SEED = 20260803
+N_WALKERS = 8
+
+
+# ----------------------------------------------------------------------------- inputs
+def convert_inputs():
+    out = HERE / 'inputs'
+    out.mkdir(exist_ok=True)
+    files = {
+        'vega/models/PlanckDR16/PlanckDR16.fits': 'PlanckDR16.npz',
+        'tests/data/cf_lya-exp.fits.gz': 'cf_lya-exp.npz',
+        'tests/data/cf_lyb-exp.fits.gz': 'cf_lyb-exp.npz',
+        'tests/data/xcf_lya-exp.fits.gz': 'xcf_lya-exp.npz',
+        'tests/data/xcf_lyb-exp.fits.gz': 'xcf_lyb-exp.npz',
+        'tests/data/metal_dmat_lya.fits.gz': 'metal_dmat_lya.npz',
+        'tests/data/metal_dmat_lyb.fits.gz': 'metal_dmat_lyb.npz',
+        'tests/data/metal_xdmat_lya.fits.gz': 'metal_xdmat_lya.npz',
+        'tests/data/metal_xdmat_lyb.fits.gz': 'metal_xdmat_lyb.npz',
+        'tests/data/dr16_simple_auto.fits': 'dr16_simple_auto.npz',
+        'tests/data/dr16_simple_cross.fits': 'dr16_simple_cross.npz',
+        'tests/data/picca_bench_data.fits': 'picca_bench_data.npz',
+    }
+    for src, dst in files.items():
+        hdul = fitslite.open(REF / src)
+        tabs = []
+        for hdu in hdul[1:]:
+            cols = {}
+            for name in hdu.columns.names:
+                col = hdu.data[name]
+                # metal files carry bookkeeping columns the hot path never reads
+                if col.dtype.kind in 'US':
+                    continue
+                cols[name] = col
+            tabs.append(Table(hdu.header, cols))
+        write_bundle(out / dst, tabs)
+        print('wrote', out / dst)
+
+
+# ----------------------------------------------------------------------------- configs
+_RENAMES = [
+    (r'PlanckDR16/PlanckDR16\.fits', 'inputs/PlanckDR16.npz'),
+    (r'data/([\w\-]+)\.fits(\.gz)?', r'inputs/\1.npz'),
+]
+
+
+def _rewrite(text, ini_dir_map):
+    for pat, rep in _RENAMES:
+        text = re.sub(pat, rep, text)
+    for old, new in ini_dir_map.items():
+        text = text.replace(old, new)
+    return text
+
+
+def derive_configs():
+    cfg_out = HERE / 'configs'
+    sets = {
+        'full4': (REF / 'tests/full_configs', ['main.ini', 'lyalya_lyalya.ini', 'lyalya_lyalyb.ini',
+                                                'lyalya_qso.ini', 'lyalyb_qso.ini'],
+                  {'full_configs/': 'configs/full4/'}),
+        'picca': (REF / 'examples/picca_benchmarks/configs/vega',
+                  ['main.ini', 'main_cross.ini']
+                  + [f'auto_test_{i}.ini' for i in (0, 1, 2, 4, 5, 6, 7)]
+                  + [f'cross_test_{i}.ini' for i in (0, 1, 2, 4, 5, 6, 7)],
+                  {'examples/picca_benchmarks/configs/vega/': 'configs/picca/'}),
+    }
+    for name, (src_dir, files, dirmap) in sets.items():
+        dst = cfg_out / name
+        dst.mkdir(parents=True, exist_ok=True)
+        for f in files:
+            text = _rewrite((src_dir / f).read_text(), dirmap)
+            (dst / f).write_text(text)
+
+    # joint auto+cross (BASELINE configs 3/4) and auto-only (configs 1/2) mains, with and
+    # without the [metals] sections, derived from the full4 set
+    main = (cfg_out / 'full4' / 'main.ini').read_text()
+    for tag, items in {'joint': ['lyalya_lyalya', 'lyalya_qso'], 'auto': ['lyalya_lyalya']}.items():
+        for metals in (True, False):
+            sub = f'{tag}' + ('_metals' if metals else '')
+            d = cfg_out / sub
+            d.mkdir(exist_ok=True)
+            line = 'ini files = ' + ' '.join(f'configs/{sub}/{it}.ini' for it in items)
+            (d / 'main.ini').write_text(re.sub(r'ini files = .*', line, main))
+            for it in items:
+                text = (cfg_out / 'full4' / f'{it}.ini').read_text()
+                if not metals:
+                    text = re.sub(r'\[metals\][^\[]*', '', text)
+                (d / f'{it}.ini').write_text(text)
+    print('wrote configs under', cfg_out)
+
+
+# ----------------------------------------------------------------------------- reference runs
+def _reference():
+    import matplotlib
+    matplotlib.use('Agg')
+    from vega import VegaInterface
+    return VegaInterface
+
+
+def _reset_caches(vega):
+    """Defeat the allclose / first-call caches so each call recomputes (quirks 2, 3)."""
+    for model in vega.models.values():
+        pks = [model.Pk_core]
+        if model.metals is not None:
+            pks += list(model.metals.Pk_metal.values())
+        for pk in pks:
+            pk._arinyo_pars = None
+            pk._peak_nl_pars = None
+            pk._L0_hcd_cache = None
+            pk._F_hcd = None
+
+
+def _ref_main(tmp, items, metals):
+    """Write a reference-side main.ini selecting ``items`` of tests/full_configs."""
+    main = (REF / 'tests/full_configs/main.ini').read_text()
+    paths = []
+    for it in items:
+        text = (REF / 'tests/full_configs' / f'{it}.ini').read_text()
+        if not metals:
+            text = re.sub(r'\[metals\][^\[]*', '', text)
+        p = Path(tmp) / f'{it}.ini'
+        p.write_text(text)
+        paths.append(str(p))
+    main = re.sub(r'ini files = .*', 'ini files = ' + ' '.join(paths), main)
+    mp = Path(tmp) / 'main.ini'
+    mp.write_text(main)
+    return str(mp)
+
+
+def make_walkers(params, n, seed=WALKER_SEED):
+    """Seeded walkers around the fiducial: every parameter perturbed by 2 % (0.01 absolute for
+    zero-valued ones); the huge ``qso_rad_lifetime`` sentinel is kept."""
+    rng = np.random.default_rng(seed)
+    names = sorted(params)
+    out = []
+    for _ in range(n):
+        w = {}
+        for name in names:
+            v = params[name]
+            g = rng.standard_normal()
+            if name == 'qso_rad_lifetime':
+                w[name] = v
+            elif v == 0:
+                w[name] = 0.01 * g
+            else:
+                w[name] = v * (1 + 0.02 * g)
+        out.append(w)
+    return names, out
+
+
+def _taps_from_model(model, with_metals):
+    """Stage outputs the reference keeps when ``save-components`` is on."""
+    taps = {}
+    for comp in ('peak', 'smooth'):
+        taps[f'{comp}/pk_mean'] = np.mean(model.pk[comp]['core'])
+        taps[f'{comp}/xi_core'] = model.xi[comp]['core']
+        taps[f'{comp}/xi_distorted'] = model.xi_distorted[comp]['core']
+        taps[f'{comp}/pk_ells'] = model.PktoXi.compute_pk_ells(model.pk[comp]['core'])
+    return taps
+
+
+def dump_full4(VegaInterface):
+    os.chdir(REF / 'tests')
+    vega = VegaInterface('full_configs/main.ini')
+    out = {'log_lik': vega.log_lik(), 'chi2': vega.chi2(),
+           'pinned_log_lik': -8766.997108462287}
+    model = vega.compute_model(run_init=False)
+    for name, xi in model.items():
+        out[f'model/{name}'] = xi
+    np.savez_compressed(HERE / 'expected_full4.npz', **out)
+    print('full4: log_lik', out['log_lik'], 'chi2', out['chi2'])
+
+
+def dump_subset(VegaInterface, tag, items, metals, synth=False):
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        vega = VegaInterface(_ref_main(tmp, items, metals))
+        out = {}
+        if synth:
+            # synthetic distortion matrix + covariance (none ship with the reference)
+            from scipy.sparse import csr_array
+            for name in items:
+                data = vega.data[name]
+                grid = data.model_coordinates
+                dm = synthetic.distortion_matrix(grid.rp_grid, grid.rt_grid)
+                cov = synthetic.covariance(data.data_coordinates.rp_grid,
+                                           data.data_coordinates.rt_grid)
+                data._distortion_mat = csr_array(dm)
+                data._cov_mat = cov
+                data._inv_masked_cov = None
+                data._log_cov_det = None
+        names, walkers = make_walkers(vega.params, N_WALKERS)
+        out['param_names'] = np.array(names)
+        out['theta_fid'] = np.array([vega.params[n] for n in names])
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+
+        _reset_caches(vega)
+        out['fid/chi2'] = vega.chi2()
+        out['fid/log_lik'] = vega.log_lik()
+        model = vega.compute_model(run_init=False)
+        for name in items:
+            out[f'fid/model/{name}'] = model[name]
+
+        chi2s = []
+        for i, w in enumerate(walkers):
+            _reset_caches(vega)
+            chi2s.append(vega.chi2(w))
+            _reset_caches(vega)
+            model = vega.compute_model(w, run_init=False)
+            for name in items:
+                out[f'walker{i}/model/{name}'] = model[name]
+        out['chi2'] = np.array(chi2s)
+
+        # stage taps at the fiducial point
+        if not synth:
+            vega.fiducial['save-components'] = True
+            if metals:
+                # components cannot be saved in fast-metal-bias mode (reference metals.py:67-69,242)
+                for name in items:
+                    out[f'fid/xi_metals/{name}'] = _metals_only(vega, name)
+            with tempfile.TemporaryDirectory() as tmp2:
+                vega_t = VegaInterface(_ref_main(tmp2, items, False))
+                vega_t.fiducial['save-components'] = True
+                vega_t.compute_model(run_init=True)
+                for name in items:
+                    for key, val in _taps_from_model(vega_t.models[name], False).items():
+                        out[f'fid/taps/{name}/{key}'] = val
+                    # FFTLog outputs per multipole for the smooth component
+                    m = vega_t.models[name]
+                    pk_ells = out[f'fid/taps/{name}/smooth/pk_ells']
+                    for i, ell in enumerate(m.PktoXi.ell_vals):
+                        r_fft, xi_fft = m.PktoXi.fftlog_objects[ell](pk_ells[i], extrap=False)
+                        out[f'fid/taps/{name}/smooth/r_fft_{ell}'] = r_fft
+                        out[f'fid/taps/{name}/smooth/xi_fft_{ell}'] = xi_fft
+        np.savez_compressed(HERE / f'expected_{tag}.npz', **out)
+        print(tag, 'fid chi2', out['fid/chi2'], 'walker chi2', out['chi2'][:3])
+
+
+def _metals_only(vega, name):
+    import copy
+    pars = copy.deepcopy(vega.params)
+    pars['peak'] = False
+    _reset_caches(vega)
+    return vega.models[name].metals.compute(pars, vega.fiducial['pk_full'], 'full')
+
+
+def dump_picca(VegaInterface):
+    os.chdir(REF)
+    out = {}
+    for kind, main in (('auto', 'main.ini'), ('cross', 'main_cross.ini')):
+        vega = VegaInterface(f'examples/picca_benchmarks/configs/vega/{main}')
+        vega.fiducial['Omega_de'] = None
+        xi = vega.compute_model(run_init=True)
+        for name, vec in xi.items():
+            out[f'{kind}_{name}'] = vec
+    np.savez_compressed(HERE / 'expected_picca.npz', **out)
+    print('picca: dumped', len(out), 'vectors')
+
+
+def dump_pk_kat(VegaInterface):
+    """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
+    # The known answers themselves are constants of the reference's test and live in
+    # tests/test_oracle.py; nothing to generate here.
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca']
+    if 'inputs' in what:
+        convert_inputs()
+    if 'configs' in what:
+        derive_configs()
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca'} else None
+    if 'full4' in what:
+        dump_full4(VI)
+    if 'joint' in what:
+        dump_subset(VI, 'joint_metals', ['lyalya_lyalya', 'lyalya_qso'], True)
+        dump_subset(VI, 'joint', ['lyalya_lyalya', 'lyalya_qso'], False)
+        dump_subset(VI, 'joint_synth', ['lyalya_lyalya', 'lyalya_qso'], False, synth=True)
+    if 'picca' in what:
+        dump_picca(VI)

@@ -1,0 +1,3 @@
+class UniformPrior:
+    def __init__(self, *a, **k):
+        raise RuntimeError('placeholder')

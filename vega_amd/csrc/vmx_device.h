@@ -1,0 +1,744 @@
+// Device-side data layout and kernels of the vegamx engine (gfx950 / CDNA4 only).
+//
+// Stage map (reference file:line each kernel replaces):
+//   k_prologue        parameters -> per-(walker, pipeline) scalars        utils.py:45-108, scale_parameters.py:38-230
+//   k_gk_table        G(k,mu) binning table (static)                       power_spectrum.py:481-502
+//   k_pk_multipoles   P(k,mu) and its Legendre projection, fused           power_spectrum.py:87-196 + pktoxi.py:138
+//   k_gemm_nt / k_gemv  D = A . X for a static matrix and a batch of walker vectors:
+//                     FFTLog+spline operator (pktoxi.py:141-144), metal matrices (metals.py:338-367),
+//                     distortion matrix (model.py:143-144), inverse covariance (vega_interface.py:316)
+//   k_xi_bins         spline evaluation on rescaled bins, Legendre sum, bias evolution, growth,
+//                     QSO radiation                                         pktoxi.py:144-162, correlation_func.py:117-236,276-349,446-489
+//   k_assemble        peak/smooth/metals combination + pre-distortion broadband   model.py:119-140,186, metals.py:331-334
+//   k_post            post-distortion broadband, model output, masked residual   model.py:147-149, vega_interface.py:310-315
+//   k_chi2            diff^T C^-1 diff + priors + error sentinel                  vega_interface.py:268-279,304,316-319
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vegamx.h"
+
+#define VMX_NS 40            // scalars per (walker, pipeline)
+#define VMX_PAD 16           // leading dimensions are multiples of 16 doubles
+#define VMX_MAX_BB 32        // broadband terms per item and position
+#define VMX_MAX_METALS 64
+
+enum {
+    S_BIAS1 = 0, S_BB1, S_BIAS2, S_BB2,
+    S_UV_BG, S_UV_BP, S_UV_LAM, S_HE_BG, S_HE_LAM,
+    S_HCD_B, S_HCD_BB, S_HCD_L0,
+    S_GA, S_GB, S_EA, S_EB,
+    S_AQ1, S_AQ2, S_AKV, S_AAV, S_ABV, S_AKP,
+    S_VD1, S_VD2,
+    S_AP, S_AT, S_DRP, S_EV1A, S_EV1B, S_EV2A, S_EV2B,
+    S_RAD_S, S_RAD_A, S_RAD_L, S_RAD_D
+};
+
+static inline int vmx_pad(int n) { return (n + VMX_PAD - 1) / VMX_PAD * VMX_PAD; }
+
+struct PipeDev {
+    vmx_pipe_desc d;
+    int32_t n;            // bins
+    int64_t coord_off;    // offset into the coordinate arrays
+    int64_t xi_off;       // offset into the xi buffer (per-walker stride n)
+};
+
+struct BBTermDev {
+    int32_t func, n_coef;
+    int32_t slot[16];
+    int64_t basis_off;    // [n_coef][n] doubles in the bb basis pool
+};
+
+struct MetalDev {
+    vmx_metal_desc d;
+    int64_t mat_off;      // offset of the dense metal matrix (-1: identity)
+    int32_t mat_ld;
+    int64_t xim_off;      // offset into the metal-product buffer (per-walker stride n_model_pad)
+};
+
+struct ItemDev {
+    vmx_item_desc d;
+    int32_t n_model_pad, n_dist_pad, n_masked, n_masked_pad;
+    int32_t n_metals;
+    int32_t metal_begin;              // first index in the metal table
+    int32_t n_bb[4];
+    BBTermDev bb[4][VMX_MAX_BB];
+    int64_t model_off;                // offset of this item in the per-walker model output
+    int64_t masked_off;               // offset in the concatenated masked vector (global-cov mode)
+    // device arrays
+    const double* dm;  int32_t dm_ld;         // distortion matrix or null
+    const double* cinv; int32_t cinv_ld;      // inverse covariance or null (identity)
+    const int32_t* inv_mask;                  // [n_dist] -> masked index or -1
+    const double* data;                       // [n_masked]
+    double* vec;                              // [B][n_model_pad]   pre-distortion model
+    double* dist;                             // [S][B][n_dist_pad] distortion product slabs
+    double* res;                              // [B][n_masked_pad]  residual
+    double* z;                                // [S][B][n_masked_pad] C^-1 residual slabs
+    int32_t dist_slabs, z_slabs;
+};
+
+struct EngineDev {
+    // template
+    int32_t nk, nkp, n_mu, n_ell;
+    const double* k;            // [nkp]
+    const double* pklin;        // [3][nkp]
+    const double* delta2;       // [nkp]
+    const double* mu;           // [n_mu]
+    const double* sq1mmu2;      // [n_mu] sqrt(1 - mu^2)
+    const double* wl;           // [4][n_mu] L_ell(mu) (2 ell + 1) / n_mu
+    const double* gk;           // [tables][n_mu][nkp]
+    // fftlog / spline
+    int32_t n_coef, ncp;        // coefficients per ell, padded
+    double x0[VMX_MAX_ELL], h[VMX_MAX_ELL], xlast[VMX_MAX_ELL];
+    // pipelines
+    int32_t n_pipe;
+    const PipeDev* pipes;
+    const double* cr; const double* cmu; const double* cz; const double* crelz; const double* cgrowth;
+    // items
+    int32_t n_items;
+    const ItemDev* items;
+    const MetalDev* metals;
+    int32_t n_metals_total;
+    const double* bb_basis;
+    // priors
+    int32_t n_priors;
+    const int32_t* prior_slot; const double* prior_mean; const double* prior_sigma;
+    // batch buffers
+    int32_t n_params;
+    const double* theta;        // [B][n_params]
+    double* scal;               // [B][n_pipe][VMX_NS]
+    double* metal_bias;         // [B][n_metals_total]
+    double* pl;                 // [n_ell][B*n_pipe][nkp]
+    double* coef;               // [n_ell][B*n_pipe][ncp]
+    double* xi;                 // per pipeline [B][n]
+    double* xim;                // metal matrix products
+    double* model;              // [B][model_size]
+    double* chi2;               // [B]
+    int32_t* status;            // [B]
+    int32_t model_size;
+    // global covariance mode
+    const double* gcinv; int32_t g_n, g_ld; double* gres; double* gz; int32_t gz_slabs;
+};
+
+// ------------------------------------------------------------------------------------------------
+// prologue: parameters -> scalars
+// ------------------------------------------------------------------------------------------------
+__device__ inline double th(const double* t, int slot, double dflt) { return slot >= 0 ? t[slot] : dflt; }
+
+__device__ inline void tracer_bias_beta(const double* t, const vmx_tracer& tr, double gr,
+                                        double& bias, double& beta)
+{
+    // reference vega/utils.py:45-82
+    const bool has_bias = tr.bias_slot >= 0, has_eta = tr.bias_eta_slot >= 0, has_beta = tr.beta_slot >= 0;
+    bias = has_bias ? t[tr.bias_slot] : 0.0;
+    beta = has_beta ? t[tr.beta_slot] : 0.0;
+    const double eta = has_eta ? t[tr.bias_eta_slot] : 0.0;
+    if (!has_bias) bias = eta * gr / beta;
+    if (!has_beta) beta = eta * gr / bias;
+}
+
+__global__ void k_prologue(EngineDev D, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* t = D.theta + (size_t)b * D.n_params;
+
+    for (int p = 0; p < D.n_pipe; ++p) {
+        const vmx_pipe_desc& d = D.pipes[p].d;
+        double* s = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+        for (int i = 0; i < VMX_NS; ++i) s[i] = 0.0;
+
+        const double gr = th(t, d.growth_rate_slot, d.growth_rate_default);
+        double b1, be1, b2, be2;
+        tracer_bias_beta(t, d.tracer[0], gr, b1, be1);
+        if (d.same_tracer) { b2 = b1; be2 = be1; }
+        else tracer_bias_beta(t, d.tracer[1], gr, b2, be2);
+
+        const bool eff1 = d.tracer[0].is_lya && (d.uvb || d.heii || d.hcd_model != VMX_HCD_NONE);
+        const bool eff2 = d.tracer[1].is_lya && (d.uvb || d.heii || d.hcd_model != VMX_HCD_NONE);
+        if (d.fast_metals && !eff1) { s[S_BIAS1] = 1.0; s[S_BB1] = be1; }
+        else { s[S_BIAS1] = b1; s[S_BB1] = b1 * be1; }
+        if (d.fast_metals && !eff2) { s[S_BIAS2] = 1.0; s[S_BB2] = be2; }
+        else { s[S_BIAS2] = b2; s[S_BB2] = b2 * be2; }
+
+        if (d.uvb) { s[S_UV_BG] = t[d.bias_gamma_slot]; s[S_UV_BP] = t[d.bias_prim_slot]; s[S_UV_LAM] = t[d.lambda_uv_slot]; }
+        if (d.heii) { s[S_HE_BG] = t[d.bias_gamma_e_slot]; s[S_UV_BP] = t[d.bias_prim_slot]; s[S_HE_LAM] = t[d.lambda_heii_slot]; }
+        if (d.hcd_model != VMX_HCD_NONE) {
+            const double bh = t[d.bias_hcd_slot], beh = t[d.beta_hcd_slot];
+            s[S_HCD_B] = bh; s[S_HCD_BB] = bh * beh; s[S_HCD_L0] = th(t, d.l0_hcd_slot, d.l0_default);
+        }
+
+        double ga = 0.0, gb = 0.0;
+        if (d.peak_nl) {
+            // reference power_spectrum.py:395-402
+            double sp, st;
+            if (d.sigma_nl_par_slot >= 0 && d.sigma_nl_per_slot >= 0) { sp = t[d.sigma_nl_par_slot]; st = t[d.sigma_nl_per_slot]; }
+            else if (d.sigma_nl_par_slot >= 0) { sp = t[d.sigma_nl_par_slot]; st = sp / (1.0 + gr); }
+            else { st = t[d.sigma_nl_per_slot]; sp = st * (1.0 + gr); }
+            ga += 0.5 * sp * sp; gb += 0.5 * st * st;
+        }
+        for (int i = 0; i < d.n_smooth; ++i) {
+            const double sp = t[d.smooth_par_slot[i]], st = t[d.smooth_per_slot[i]];
+            ga += d.smooth_weight[i] * sp * sp; gb += d.smooth_weight[i] * st * st;
+        }
+        if (d.exp_par_slot >= 0) { const double a = t[d.exp_par_slot], c = t[d.exp_per_slot]; s[S_EA] = a * a; s[S_EB] = c * c; }
+        for (int q = 0; q < 2; ++q) {
+            const vmx_tracer& tr = d.tracer[q];
+            if (d.vd_kind == VMX_VD_NONE || !tr.discrete) continue;
+            const double sg = t[tr.vd_sigma_slot];
+            if (d.vd_kind == VMX_VD_GAUSS) ga += 0.25 * sg * sg;
+            else s[q == 0 ? S_VD1 : S_VD2] = sg * sg;
+        }
+        s[S_GA] = ga; s[S_GB] = gb;
+
+        if (d.nl_model == VMX_NL_ARINYO) {
+            s[S_AQ1] = t[d.arinyo_slot[0]]; s[S_AQ2] = th(t, d.arinyo_slot[1], 0.0);
+            s[S_AKV] = t[d.arinyo_slot[2]]; s[S_AAV] = t[d.arinyo_slot[3]];
+            s[S_ABV] = t[d.arinyo_slot[4]]; s[S_AKP] = t[d.arinyo_slot[5]];
+        }
+
+        // scale parameters (reference scale_parameters.py:162-230)
+        double ap = 1.0, at = 1.0;
+        if (d.scale_mode == VMX_SCALE_AP_AT) { ap = t[d.scale_slot[0]]; at = t[d.scale_slot[1]]; }
+        else if (d.scale_mode == VMX_SCALE_AISO_EPS) {
+            const double aiso = t[d.scale_slot[0]], eps = t[d.scale_slot[1]];
+            ap = aiso * (1.0 + eps) * (1.0 + eps); at = aiso / (1.0 + eps);
+        } else if (d.scale_mode == VMX_SCALE_PHI_ALPHA) {
+            const double phi = t[d.scale_slot[0]], alpha = t[d.scale_slot[1]];
+            ap = alpha / sqrt(phi); at = alpha * sqrt(phi);
+        }
+        s[S_AP] = ap; s[S_AT] = at;
+        s[S_DRP] = th(t, d.drp_slot, 0.0);
+        for (int q = 0; q < 2; ++q) {
+            const vmx_tracer& tr = d.tracer[q];
+            double a, c = 0.0;
+            if (tr.evol_kind == VMX_EVOL_CROOM) { a = t[d.croom_slot[0]]; c = t[d.croom_slot[1]]; }
+            else a = t[tr.alpha_slot];
+            s[q == 0 ? S_EV1A : S_EV2A] = a; s[q == 0 ? S_EV1B : S_EV2B] = c;
+        }
+        if (d.radiation) { for (int i = 0; i < 4; ++i) s[S_RAD_S + i] = t[d.rad_slot[i]]; }
+    }
+
+    // metal bias products (reference metals.py:295-313, :331-332)
+    for (int m = 0; m < D.n_metals_total; ++m) {
+        const vmx_metal_desc& d = D.metals[m].d;
+        double f = d.multiplicity;
+        if (d.apply_bias) {
+            const double gr = th(t, d.growth_rate_slot, d.growth_rate_default);
+            double b1, be1, b2, be2;
+            tracer_bias_beta(t, d.tracer[0], gr, b1, be1);
+            if (d.same_tracer) { b2 = b1; } else tracer_bias_beta(t, d.tracer[1], gr, b2, be2);
+            f *= b1 * b2 * th(t, d.extra_bias_slot, 1.0);
+        }
+        D.metal_bias[(size_t)b * D.n_metals_total + m] = f;
+    }
+    D.status[b] = 0;
+    D.chi2[b] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// static G(k, mu) table
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gk_table(double* out, const double* k, const double* mu, int nk, int nkp, int n_mu,
+                           double bs_rp, double bs_rt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= nkp || j >= n_mu) return;
+    double g = 0.0;
+    if (i < nk) {
+        const double kk = k[i], m = mu[j];
+        const double kpar = kk * m;
+        const double ktr = kk * sqrt(1.0 - m * m);
+        g = 1.0;
+        if (bs_rp != 0.0) { const double x = kpar * bs_rp / 2.0; g = g * (sin(x) / x); }
+        if (bs_rt != 0.0) { const double x = ktr * bs_rt / 2.0; g = g * (sin(x) / x); }
+    }
+    out[(size_t)j * nkp + i] = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P(k, mu) evaluation fused with the Legendre projection
+//   block = KT wavenumbers x MS mu-slices (KT * MS = 256); grid = (k tiles, pipelines, walkers)
+// ------------------------------------------------------------------------------------------------
+template <int KT, int MS>
+__global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D)
+{
+    extern __shared__ double smem[];
+    double* s_mubv = smem;                        // [n_mu]   mu^bv (Arinyo)
+    double* s_red = smem + D.n_mu;                // [4][256]
+
+    const int p = blockIdx.y, b = blockIdx.z;
+    const vmx_pipe_desc& d = D.pipes[p].d;
+    const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+    const int kk = threadIdx.x % KT, ms = threadIdx.x / KT;
+    const int i = blockIdx.x * KT + kk;
+    const bool valid = i < D.nk;
+    const int ic = valid ? i : D.nk - 1;
+    const int n_mu = D.n_mu;
+
+    const bool arinyo = d.nl_model == VMX_NL_ARINYO;
+    if (arinyo) {
+        const double bv = sc[S_ABV];
+        for (int j = threadIdx.x; j < n_mu; j += 256) s_mubv[j] = pow(D.mu[j], bv);
+        __syncthreads();
+    }
+
+    const double k = D.k[ic], k2 = k * k;
+    const bool hcd = d.hcd_model != VMX_HCD_NONE;
+    const bool lya1 = d.tracer[0].is_lya, lya2 = d.tracer[1].is_lya;
+
+    // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261): only the bias changes,
+    // bias * beta is invariant under that step.
+    double c0_1 = sc[S_BIAS1], c1_1 = sc[S_BB1], c0_2 = sc[S_BIAS2], c1_2 = sc[S_BB2];
+    if (d.uvb || d.heii) {
+        double add = 0.0;
+        if (d.uvb) { const double x = k * sc[S_UV_LAM]; const double W = atan(x) / x; add += sc[S_UV_BG] * W / (1.0 + sc[S_UV_BP] * W); }
+        if (d.heii) { const double x = k * sc[S_HE_LAM]; const double W = atan(x) / x; add += sc[S_HE_BG] * W / (1.0 + sc[S_UV_BP] * W); }
+        if (lya1) c0_1 += add;
+        if (lya2) c0_2 += add;
+    }
+    const double hb = sc[S_HCD_B], hbb = sc[S_HCD_BB], L0 = sc[S_HCD_L0];
+    const bool div1 = d.fast_metals && lya1 && (d.uvb || d.heii || hcd);
+    const bool div2 = d.fast_metals && lya2 && (d.uvb || d.heii || hcd);
+
+    const double ga = sc[S_GA], gb = sc[S_GB], ea = sc[S_EA], eb = sc[S_EB];
+    const bool has_exp = (ea != 0.0) || (eb != 0.0);
+    const double vd1 = sc[S_VD1], vd2 = sc[S_VD2];
+
+    double ar_g = 0.0, ar_v = 0.0, ar_p = 0.0;
+    const double apow = d.arinyo_power;
+    if (arinyo) {
+        const double d2 = D.delta2[ic];
+        ar_g = sc[S_AQ1] * d2 + sc[S_AQ2] * d2 * d2;
+        ar_v = pow(k / sc[S_AKV], sc[S_AAV]);
+        const double kp = k / sc[S_AKP];
+        ar_p = kp * kp;
+    }
+    double mc_base = 0.0, mc_kvel = 1.0;
+    const bool mcdonald = d.nl_model == VMX_NL_MCDONALD;
+    if (mcdonald) {
+        mc_kvel = 1.22 * pow(1.0 + k / 0.923, 0.451);
+        mc_base = pow(k / 6.4, 0.569) - pow(k / 15.3, 2.01);
+    }
+    const double* gk = d.gk_table >= 0 ? D.gk + (size_t)d.gk_table * n_mu * D.nkp : nullptr;
+
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    bool bad = false;
+
+    for (int j = ms; j < n_mu; j += MS) {
+        const double mu = D.mu[j];
+        const double mu2 = mu * mu;
+        const double kpar = k * mu;
+
+        double F = 0.0;
+        if (d.hcd_model == VMX_HCD_ROGERS) F = exp(-L0 * kpar);
+        else if (d.hcd_model == VMX_HCD_SINC) { const double x = kpar * L0; F = sin(x) / x; }
+
+        // tracer amplitudes b_eff (1 + beta_eff mu^2) = b + b beta mu^2 + F b_hcd (1 + beta_hcd mu^2)
+        double A1 = fma(c1_1, mu2, c0_1);
+        if (lya1 && hcd) A1 = fma(F, fma(hbb, mu2, hb), A1);
+        if (div1) A1 /= fma(F, hb, c0_1);
+        double A2;
+        if (d.same_tracer) A2 = A1;
+        else {
+            A2 = fma(c1_2, mu2, c0_2);
+            if (lya2 && hcd) A2 = fma(F, fma(hbb, mu2, hb), A2);
+            if (div2) A2 /= fma(F, hb, c0_2);
+        }
+
+        double E = -k2 * fma(mu2, ga, (1.0 - mu2) * gb);
+        if (has_exp) E -= k * fma(mu, ea, D.sq1mmu2[j] * eb);
+        if (arinyo) {
+            const double Ea = ar_g * (1.0 - ar_v * s_mubv[j]) - ar_p;
+            // VegaArinyoError: NaN or Inf in exp(Ea) (power_spectrum.py:468-469)
+            if (!(Ea < 709.0)) bad = true;
+            E = fma(apow, Ea, E);
+        }
+        if (mcdonald) { const double x = kpar / mc_kvel; E += mc_base - x * sqrt(x); }
+
+        double val = A1 * A2 * exp(E);
+        if (gk) val *= gk[(size_t)j * D.nkp + ic];
+        if (vd1 != 0.0) val *= 1.0 / sqrt(fma(kpar * kpar, vd1, 1.0));
+        if (vd2 != 0.0) val *= 1.0 / sqrt(fma(kpar * kpar, vd2, 1.0));
+
+        acc0 = fma(D.wl[j], val, acc0);
+        acc1 = fma(D.wl[n_mu + j], val, acc1);
+        acc2 = fma(D.wl[2 * n_mu + j], val, acc2);
+        acc3 = fma(D.wl[3 * n_mu + j], val, acc3);
+    }
+
+    s_red[threadIdx.x] = acc0;
+    s_red[256 + threadIdx.x] = acc1;
+    s_red[512 + threadIdx.x] = acc2;
+    s_red[768 + threadIdx.x] = acc3;
+    __syncthreads();
+    if (bad && valid) atomicOr(&D.status[b], VMX_STATUS_ARINYO);
+
+    if (ms == 0 && valid) {
+        double pk = D.pklin[(size_t)d.pk_lin_kind * D.nkp + i];
+        if (d.damping_scale > 0.0) pk *= exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
+        const size_t ncols = (size_t)gridDim.z * D.n_pipe;
+        const size_t col = (size_t)b * D.n_pipe + p;
+        for (int e = 0; e < D.n_ell; ++e) {
+            double sum = 0.0;
+            for (int q = 0; q < MS; ++q) sum += s_red[e * 256 + q * KT + kk];
+            D.pl[((size_t)e * ncols + col) * D.nkp + i] = pk * sum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// D^T[n][m] = sum_k A[m][k] * X[n][k]      (A static matrix, X / D one vector per walker)
+//   fp64 MFMA 16x16x4; block tile 64 x 64 x 16, 4 waves each owning a 32 x 32 quadrant.
+//   blockIdx.z = batch * nsplit + split; split-K partial sums go to separate slabs of D
+//   (summed in fixed order by the consumer: results are bitwise reproducible).
+// ------------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define GEMM_BM 64
+#define GEMM_BN 64
+#define GEMM_BK 16
+#define GEMM_LDS_LD 18      // 16 + 2: conflict-free ds_read_b64 for the 16x4 operand pattern
+
+struct GemmArgs {
+    const double* A; int lda; int64_t a_batch;
+    const double* X; int ldx; int64_t x_batch;
+    double* D; int ldd; int64_t d_batch; int64_t d_slab;
+    int M, N, K;            // K already padded to a multiple of 16 (zero padded operands)
+    int nsplit, klen;       // klen multiple of 16
+};
+
+__global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
+{
+    __shared__ double sA[2][GEMM_BM * GEMM_LDS_LD];
+    __shared__ double sX[2][GEMM_BN * GEMM_LDS_LD];
+
+    const int batch = blockIdx.z / g.nsplit, split = blockIdx.z % g.nsplit;
+    const double* A = g.A + batch * g.a_batch;
+    const double* X = g.X + batch * g.x_batch;
+    double* Dp = g.D + batch * g.d_batch + split * g.d_slab;
+
+    const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * GEMM_BN;
+    const int kbeg = split * g.klen;
+    int kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+
+    // staging: each thread moves 2 x double2 of A and of X per K step
+    const int lrow = tid >> 3;            // 0..31
+    const int lk = (tid & 7) * 2;         // 0,2,..14
+    int ar0 = m0 + lrow, ar1 = m0 + lrow + 32;
+    if (ar0 >= g.M) ar0 = g.M - 1;
+    if (ar1 >= g.M) ar1 = g.M - 1;
+    int xr0 = n0 + lrow, xr1 = n0 + lrow + 32;
+    if (xr0 >= g.N) xr0 = g.N - 1;
+    if (xr1 >= g.N) xr1 = g.N - 1;
+    const double* pa0 = A + (size_t)ar0 * g.lda + lk;
+    const double* pa1 = A + (size_t)ar1 * g.lda + lk;
+    const double* px0 = X + (size_t)xr0 * g.ldx + lk;
+    const double* px1 = X + (size_t)xr1 * g.ldx + lk;
+
+    v4d acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    v2d ra0, ra1, rx0, rx1;
+    if (kbeg < kend) {
+        ra0 = *(const v2d*)(pa0 + kbeg); ra1 = *(const v2d*)(pa1 + kbeg);
+        rx0 = *(const v2d*)(px0 + kbeg); rx1 = *(const v2d*)(px1 + kbeg);
+    }
+    int buf = 0;
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+        *(v2d*)&sA[buf][lrow * GEMM_LDS_LD + lk] = ra0;
+        *(v2d*)&sA[buf][(lrow + 32) * GEMM_LDS_LD + lk] = ra1;
+        *(v2d*)&sX[buf][lrow * GEMM_LDS_LD + lk] = rx0;
+        *(v2d*)&sX[buf][(lrow + 32) * GEMM_LDS_LD + lk] = rx1;
+        __syncthreads();
+        const int kn = k0 + GEMM_BK;
+        if (kn < kend) {
+            ra0 = *(const v2d*)(pa0 + kn); ra1 = *(const v2d*)(pa1 + kn);
+            rx0 = *(const v2d*)(px0 + kn); rx1 = *(const v2d*)(px1 + kn);
+        }
+        const double* a = &sA[buf][0];
+        const double* x = &sX[buf][0];
+#pragma unroll
+        for (int ks = 0; ks < GEMM_BK; ks += 4) {
+            const double a0 = a[(wm + frow) * GEMM_LDS_LD + ks + fk];
+            const double a1 = a[(wm + 16 + frow) * GEMM_LDS_LD + ks + fk];
+            const double x0 = x[(wn + frow) * GEMM_LDS_LD + ks + fk];
+            const double x1 = x[(wn + 16 + frow) * GEMM_LDS_LD + ks + fk];
+            // MFMA computes C[i][j] += sum_k Aop[i][k] Bop[k][j]; rows i <- walkers (X), cols j <- matrix rows (A):
+            // the result tile is D^T[n][m], whose register layout (row = (lane>>4) + 4 r, col = lane & 15)
+            // stores 16 consecutive m per 16 lanes -> coalesced along m.
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, acc[1][1], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+    // store: acc[i][j] covers walkers n0 + wn + 16 i + (lane>>4) + 4 r, matrix rows m0 + wm + 16 j + (lane & 15)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn + 16 * i + (lane >> 4) + 4 * r;
+                const int m = m0 + wm + 16 * j + (lane & 15);
+                if (n < g.N && m < g.M) Dp[(size_t)n * g.ldd + m] = acc[i][j][r];
+            }
+}
+
+// Small-batch product (NB <= 8 walkers): HBM-bound streaming of A, one wave per matrix row.
+template <int NB>
+__global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
+{
+    const int batch = blockIdx.z;
+    const double* A = g.A + batch * g.a_batch;
+    const double* X = g.X + batch * g.x_batch;
+    double* Dp = g.D + batch * g.d_batch;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= g.M) return;
+    const double* a = A + (size_t)row * g.lda;
+    double acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.0;
+    // K is a multiple of 16; each lane consumes double2 chunks, 128 doubles per wave step, 4 steps in flight
+    int k = lane * 2;
+    for (; k + 384 < g.K; k += 512) {
+        const v2d a0 = *(const v2d*)(a + k), a1 = *(const v2d*)(a + k + 128);
+        const v2d a2 = *(const v2d*)(a + k + 256), a3 = *(const v2d*)(a + k + 384);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double* x = X + (size_t)b * g.ldx + k;
+            const v2d x0 = *(const v2d*)(x), x1 = *(const v2d*)(x + 128), x2 = *(const v2d*)(x + 256), x3 = *(const v2d*)(x + 384);
+            acc[b] += a0.x * x0.x + a0.y * x0.y + a1.x * x1.x + a1.y * x1.y
+                    + a2.x * x2.x + a2.y * x2.y + a3.x * x3.x + a3.y * x3.y;
+        }
+    }
+    for (; k < g.K; k += 128) {
+        const v2d a0 = *(const v2d*)(a + k);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const v2d x0 = *(const v2d*)(X + (size_t)b * g.ldx + k);
+            acc[b] += a0.x * x0.x + a0.y * x0.y;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double v = acc[b];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && b < g.N) Dp[(size_t)b * g.ldd + row] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// xi on the (rescaled) bins of every pipeline
+// ------------------------------------------------------------------------------------------------
+__device__ inline double legendre_even(int e, double x)
+{
+    const double x2 = x * x;
+    switch (e) {
+        case 0: return 1.0;
+        case 1: return 0.5 * (3.0 * x2 - 1.0);
+        case 2: return 0.125 * ((35.0 * x2 - 30.0) * x2 + 3.0);
+        default: return 0.0625 * (((231.0 * x2 - 315.0) * x2 + 105.0) * x2 - 5.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
+{
+    const int p = blockIdx.y, b = blockIdx.z;
+    const PipeDev& P = D.pipes[p];
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= P.n) return;
+    const vmx_pipe_desc& d = P.d;
+    const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+    const size_t c = P.coord_off + bin;
+    const double r = D.cr[c], mu = D.cmu[c];
+    const double drp = sc[S_DRP];
+
+    // reference correlation_func.py:200-236
+    double rr = 0.0, rmu = 0.0;
+    if (r != 0.0) {
+        const double rp = r * mu + drp;
+        const double rt = r * sqrt(1.0 - mu * mu);
+        const double rrp = sc[S_AP] * rp, rrt = sc[S_AT] * rt;
+        rr = sqrt(rrp * rrp + rrt * rrt);
+        rmu = rrp / rr;
+    }
+
+    double xi = 0.0;
+    if (rr != 0.0) {
+        const double x = log(rr);
+        const size_t ncols = (size_t)gridDim.z * D.n_pipe;
+        const size_t col = (size_t)b * D.n_pipe + p;
+        bool oob = false;
+        for (int e = 0; e < d.n_ell; ++e) {
+            if (x < D.x0[e] || x > D.xlast[e]) { oob = true; continue; }   // VegaBoundsError (pktoxi.py:149-152)
+            const double u = (x - D.x0[e]) / D.h[e];
+            int j = (int)floor(u);
+            if (j < 0) j = 0;
+            if (j > D.n_coef - 4) j = D.n_coef - 4;
+            const double t = u - (double)j, t2 = t * t, t3 = t2 * t;
+            const double omt = 1.0 - t;
+            const double* cf = D.coef + ((size_t)e * ncols + col) * D.ncp + j;
+            const double w0 = omt * omt * omt;
+            const double w1 = 3.0 * t3 - 6.0 * t2 + 4.0;
+            const double w2 = -3.0 * t3 + 3.0 * t2 + 3.0 * t + 1.0;
+            const double s = (cf[0] * w0 + cf[1] * w1 + cf[2] * w2 + cf[3] * t3) * (1.0 / 6.0);
+            xi += s * legendre_even(e, rmu);
+        }
+        if (oob) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
+    }
+
+    // bias evolution (correlation_func.py:276-370) and growth (:143)
+    const double relz = D.crelz[c];
+    double ev = 1.0;
+    for (int q = 0; q < 2; ++q) {
+        const double a = sc[q == 0 ? S_EV1A : S_EV2A], cc = sc[q == 0 ? S_EV1B : S_EV2B];
+        if (d.tracer[q].evol_kind == VMX_EVOL_CROOM) {
+            const double z1 = 1.0 + D.cz[c], ze = 1.0 + d.z_eff;
+            ev *= (a + cc * z1 * z1) / (a + cc * ze * ze);
+        } else ev *= pow(relz, a);
+    }
+    xi *= ev;
+    xi *= D.cgrowth[c];
+
+    if (d.radiation && !d.is_peak) {
+        // reference correlation_func.py:446-489 (unrescaled coordinates, shifted by delta_rp)
+        const double rp = r * mu + drp;
+        const double rt = r * sqrt(1.0 - mu * mu);
+        const double rs = sqrt(rp * rp + rt * rt);
+        const double ms = rp / rs;
+        double xr = sc[S_RAD_S] / (rs * rs) * (1.0 - sc[S_RAD_A] * (1.0 - ms * ms));
+        xr *= exp(-rs * ((1.0 + ms) / sc[S_RAD_L] + 1.0 / sc[S_RAD_D]));
+        xi += xr;
+    }
+    D.xi[P.xi_off + (size_t)b * P.n + bin] = xi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// broadband helpers
+// ------------------------------------------------------------------------------------------------
+__device__ inline double bb_total(const EngineDev& D, const ItemDev& it, int pos, const double* t, int bin, int n)
+{
+    const bool mul = (pos == VMX_BB_PRE_MUL || pos == VMX_BB_POST_MUL);
+    double total = mul ? 1.0 : 0.0;
+    for (int q = 0; q < it.n_bb[pos]; ++q) {
+        const BBTermDev& term = it.bb[pos][q];
+        const double* basis = D.bb_basis + term.basis_off;
+        double corr = 0.0;
+        if (term.func == VMX_BB_SKY) {
+            const double scale = t[term.slot[0]], sigma = t[term.slot[1]];
+            const double rt = basis[bin], w = basis[(size_t)n + bin];
+            if (w != 0.0) {
+                const double q2 = rt / sigma;
+                corr = scale / (sigma * sqrt(2.0 * M_PI)) * exp(-0.5 * q2 * q2);
+            }
+        } else {
+            for (int cidx = 0; cidx < term.n_coef; ++cidx) corr = fma(t[term.slot[cidx]], basis[(size_t)cidx * n + bin], corr);
+        }
+        if (mul) total *= (1.0 + corr); else total += corr;
+    }
+    return total;
+}
+
+// combine components, add metals, apply pre-distortion broadband (model.py:119-140,186)
+__global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item, const double* xim_or_null)
+{
+    const ItemDev& it = D.items[item];
+    const int b = blockIdx.y;
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= it.d.n_model) return;
+    const double* t = D.theta + (size_t)b * D.n_params;
+    const double bao = t[it.d.bao_amp_slot];
+    const PipeDev& Pp = D.pipes[it.d.pipe_peak];
+    const PipeDev& Ps = D.pipes[it.d.pipe_smooth];
+    double v = bao * D.xi[Pp.xi_off + (size_t)b * Pp.n + bin] + D.xi[Ps.xi_off + (size_t)b * Ps.n + bin];
+    for (int m = 0; m < it.n_metals; ++m) {
+        const MetalDev& md = D.metals[it.metal_begin + m];
+        const double f = D.metal_bias[(size_t)b * D.n_metals_total + it.metal_begin + m];
+        double x;
+        if (md.mat_off >= 0) x = D.xim[md.xim_off + (size_t)b * it.n_model_pad + bin];
+        else { const PipeDev& Pm = D.pipes[md.d.pipeline]; x = D.xi[Pm.xi_off + (size_t)b * Pm.n + bin]; }
+        v = fma(f, x, v);
+    }
+    if (it.n_bb[VMX_BB_PRE_MUL]) v *= bb_total(D, it, VMX_BB_PRE_MUL, t, bin, it.d.n_model);
+    if (it.n_bb[VMX_BB_PRE_ADD]) v += (1.0 + bao) * bb_total(D, it, VMX_BB_PRE_ADD, t, bin, it.d.n_model);
+    it.vec[(size_t)b * it.n_model_pad + bin] = v;
+}
+
+// post-distortion broadband, model output and masked residual (model.py:147-149; vega_interface.py:310-315)
+__global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B)
+{
+    const ItemDev& it = D.items[item];
+    const int b = blockIdx.y;
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= it.d.n_dist) return;
+    const double* t = D.theta + (size_t)b * D.n_params;
+    double v;
+    if (it.dm) {
+        v = 0.0;
+        for (int s = 0; s < it.dist_slabs; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
+    } else v = it.vec[(size_t)b * it.n_model_pad + bin];
+    if (it.n_bb[VMX_BB_POST_MUL]) v *= bb_total(D, it, VMX_BB_POST_MUL, t, bin, it.d.n_dist);
+    if (it.n_bb[VMX_BB_POST_ADD]) v += (1.0 + t[it.d.bao_amp_slot]) * bb_total(D, it, VMX_BB_POST_ADD, t, bin, it.d.n_dist);
+    D.model[(size_t)b * D.model_size + it.model_off + bin] = v;
+    const int mi = it.inv_mask[bin];
+    if (mi >= 0) {
+        const double diff = it.data[mi] - v;
+        it.res[(size_t)b * it.n_masked_pad + mi] = diff;
+        if (D.gres) D.gres[(size_t)b * D.g_ld + it.masked_off + mi] = diff;
+    }
+}
+
+// chi2 = sum_items diff^T (C^-1 diff) + priors; sentinel on failure
+__global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B)
+{
+    __shared__ double red[256];
+    const int b = blockIdx.x;
+    double acc = 0.0;
+    if (D.gcinv) {
+        for (int i = threadIdx.x; i < D.g_n; i += 256) {
+            double z = 0.0;
+            for (int s = 0; s < D.gz_slabs; ++s) z += D.gz[((size_t)s * B + b) * D.g_ld + i];
+            acc = fma(D.gres[(size_t)b * D.g_ld + i], z, acc);
+        }
+    } else {
+        for (int q = 0; q < D.n_items; ++q) {
+            const ItemDev& it = D.items[q];
+            for (int i = threadIdx.x; i < it.n_masked; i += 256) {
+                const double rres = it.res[(size_t)b * it.n_masked_pad + i];
+                double z;
+                if (it.cinv) {
+                    z = 0.0;
+                    for (int s = 0; s < it.z_slabs; ++s) z += it.z[((size_t)s * B + b) * it.n_masked_pad + i];
+                } else z = rres;
+                acc = fma(rres, z, acc);
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double c = red[0];
+        const double* t = D.theta + (size_t)b * D.n_params;
+        for (int q = 0; q < D.n_priors; ++q) {
+            const double dlt = t[D.prior_slot[q]] - D.prior_mean[q];
+            c += dlt * dlt / (D.prior_sigma[q] * D.prior_sigma[q]);
+        }
+        int st = D.status[b];
+        if (!(c == c) || c > 1e300 || c < -1e300) { st |= VMX_STATUS_NONFINITE; D.status[b] = st; }
+        D.chi2[b] = st ? 1e100 : c;
+    }
+}

@@ -1,0 +1,70 @@
+"""Deterministic synthetic tensors for the BASELINE configs.
+
+The reference ships no distortion matrix, covariance or metal matrices with its test data
+(the reference substitutes ``np.eye``: vega/data.py:77-80).  The
+benchmark configs therefore use the seeded generators below; the same arrays are injected into
+the reference when the golden fixtures are made (tests/golden/make_golden.py) so that engine,
+oracle and reference all see identical inputs.
+"""
+import numpy as np
+
+SEED = 20260803
+
+
+def distortion_matrix(rp, rt, seed=SEED, dense_fraction=0.65):
+    """``DM = I - W``: W couples bins at similar rt, falls off with |d rp|; rows of W sum to 0.3;
+    35 % of the far-off-band (|d rt| > 24) entries are zeroed so a CSR twin is meaningfully
+    sparse."""
+    rp = np.asarray(rp, dtype=float)
+    rt = np.asarray(rt, dtype=float)
+    n = rp.size
+    rng = np.random.default_rng(seed + n)
+    w_col = rng.uniform(0.5, 1.5, size=n)
+    d_rt = rt[:, None] - rt[None, :]
+    W = np.exp(-d_rt**2 / (2 * 8.**2))
+    off_band = np.abs(d_rt) > 24
+    del d_rt
+    W /= 1 + np.abs(rp[:, None] - rp[None, :]) / 20.
+    W *= w_col[None, :]
+    drop = off_band & (rng.random((n, n)) > dense_fraction)
+    W[drop] = 0.
+    del drop, off_band
+    W *= 0.3 / W.sum(axis=1, keepdims=True)
+    dm = -W
+    dm[np.arange(n), np.arange(n)] += 1.
+    return dm
+
+
+def covariance(rp, rt):
+    """SPD covariance: variance ~ 1/r^2, Kronecker-exponential correlations in (rp, rt)."""
+    rp = np.asarray(rp, dtype=float)
+    rt = np.asarray(rt, dtype=float)
+    r = np.sqrt(rp**2 + rt**2)
+    sigma = 2e-4 * 50. / np.maximum(r, 5.)
+    corr = 0.25**(np.abs(rp[:, None] - rp[None, :]) / 4.)
+    corr *= 0.15**(np.abs(rt[:, None] - rt[None, :]) / 4.)
+    corr *= sigma[:, None]
+    corr *= sigma[None, :]
+    return corr
+
+
+def walkers(theta_fid, names, n, varied=None, seed=SEED, scale=0.02, limits=None):
+    """``theta_b = theta_fid + scale * |theta_fid| * N(0, 1)`` on the ``varied`` names
+    (all non-sentinel parameters when None), clipped to ``limits`` = {name: (lo, hi)}."""
+    rng = np.random.default_rng(seed)
+    theta_fid = np.asarray(theta_fid, dtype=float)
+    theta = np.tile(theta_fid, (n, 1))
+    for j, name in enumerate(names):
+        if varied is not None and name not in varied:
+            continue
+        if name == 'qso_rad_lifetime':
+            continue
+        g = rng.standard_normal(n)
+        if theta_fid[j] == 0:
+            theta[:, j] = 0.01 * scale / 0.02 * g
+        else:
+            theta[:, j] = theta_fid[j] + scale * abs(theta_fid[j]) * g
+        if limits is not None and name in limits:
+            lo, hi = limits[name]
+            theta[:, j] = np.clip(theta[:, j], lo, hi)
+    return theta
