@@ -134,6 +134,9 @@ typedef struct {
 } vmx_item_desc;
 
 const char* vmx_last_error(void);
+/* sizeof() of the descriptor structs as compiled (0 tracer, 1 pipe, 2 metal, 3 item): lets a foreign
+ * binding verify its struct layout at load time. */
+int vmx_struct_size(int32_t which);
 
 int vmx_create(vmx_engine** out, int device);
 void vmx_destroy(vmx_engine* e);

@@ -1,0 +1,64 @@
+"""Stage-by-stage comparison of the engine with the oracle on the GPU box (development aid)."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+import __graft_entry__ as g  # noqa: E402
+g.build()
+from vega_amd import VegaInterface  # noqa: E402
+from oracle import vega_cpu as oc  # noqa: E402
+
+GOLD = REPO / 'tests' / 'golden'
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'joint'
+t0 = time.time()
+vega = VegaInterface(f'configs/{cfg}/main.ini', search_dirs=[GOLD], max_batch=16)
+print('engine build', time.time() - t0)
+prob = vega.problem
+eng = vega.engine
+
+taps = {}
+ref_model = oc.compute_model(prob, taps=taps)
+ref_chi2 = oc.chi2(prob)
+
+chi2, status, model = eng.eval(eng.theta_from_params()[None, :], want_model=True)
+print('status', status, 'chi2', chi2[0], 'ref', ref_chi2, 'rel', abs(chi2[0] - ref_chi2) / abs(ref_chi2))
+
+n_pipe = len(eng.pipe_index)
+nkp = 816
+pl = eng.debug_read(0, 0, 4 * 1 * n_pipe * nkp).reshape(4, n_pipe, nkp)
+for (name, comp), pid in eng.pipe_index.items():
+    if comp in ('peak', 'smooth'):
+        for i, ell in enumerate((0, 2, 4, 6)):
+            ref = taps[name][comp]['pk_ell'][ell]
+            got = pl[i, pid, :814]
+            print(f'pk_ell {name} {comp} ell={ell}: max abs err {np.abs(got - ref).max():.3e} scale {np.abs(ref).max():.3e}')
+        n = prob.items[name].model_grid.size
+        npad = (n + 15) // 16 * 16
+        xi = eng.debug_read(1, pid, npad)[:n]
+        ref = taps[name][comp]['xi_core']
+        print(f'xi_core {name} {comp}: max abs err {np.abs(xi - ref).max():.3e} scale {np.abs(ref).max():.3e}')
+for name, sl in eng.model_slices.items():
+    ref = ref_model[name]
+    print(f'model {name}: max abs err {np.abs(model[0, sl] - ref).max():.3e} scale {np.abs(ref).max():.3e}')
+
+# walkers from the golden file
+exp = np.load(GOLD / f'expected_{cfg}.npz')
+names = [str(n) for n in exp['param_names']]
+theta = np.stack([eng.theta_from_params(dict(zip(names, row))) for row in exp['theta']])
+chi2, status, model = eng.eval(theta, want_model=True)
+print('walker status', status)
+print('walker chi2 rel err', np.abs(chi2 - exp['chi2']) / np.abs(exp['chi2']))
+for i in range(theta.shape[0]):
+    for name, sl in eng.model_slices.items():
+        ref = exp[f'walker{i}/model/{name}']
+        err = np.abs(model[i, sl] - ref).max() / np.abs(ref).max()
+        if i < 2:
+            print(f'walker{i} model {name}: scaled max err {err:.3e}')
+eng.set_profiling(True)
+for _ in range(3):
+    eng.eval(theta)
+print({k: v for k, v in eng.timings().items() if v[1]})

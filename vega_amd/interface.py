@@ -1,0 +1,163 @@
+"""Drop-in host interface: the reference's ``VegaInterface`` surface over the vegamx engine.
+
+Mirrors the call signatures, return types and error behaviour of
+``VegaInterface.compute_model / chi2 / log_lik`` (reference vega/vega_interface.py:208-387) so
+that a minimiser or sampler written against the reference keeps working, and adds the batched
+entry points ``chi2_batch`` / ``compute_model_batch`` the GPU is built for.  All arithmetic of the
+per-evaluation hot path runs in libvegamx.so; this module only marshals parameters.
+"""
+import copy
+
+import numpy as np
+
+from .engine import Engine
+from .setup import build_problem
+
+
+class _DataView:
+    """The attributes of the reference's ``Data`` object that its callers read
+    (reference vega/data.py:169-250, :397, :410)."""
+
+    def __init__(self, item):
+        self._item = item
+        self.masked_mc_mock = None
+        self.scaled_inv_masked_cov = None
+        self.scaled_log_cov_det = None
+
+    data_vec = property(lambda self: self._item.data_vec)
+    masked_data_vec = property(lambda self: self._item.masked_data_vec)
+    data_mask = property(lambda self: self._item.data_mask)
+    model_mask = property(lambda self: self._item.model_mask)
+    inv_masked_cov = property(lambda self: self._item.inv_masked_cov)
+    log_cov_det = property(lambda self: self._item.log_cov_det)
+    data_size = property(lambda self: self._item.data_size)
+    full_data_size = property(lambda self: self._item.data_vec.size)
+
+
+class VegaInterface:
+    """GPU-backed stand-in for ``vega.VegaInterface`` restricted to the model + chi2 hot path."""
+
+    def __init__(self, main_path, search_dirs=(), max_batch=256, device=0, problem=None,
+                 extra_names=()):
+        self.problem = problem if problem is not None else build_problem(main_path, search_dirs)
+        self.main_config = self.problem.main_config
+        self.params = self.problem.params
+        self.sample_params = self.problem.sample_params
+        self.priors = self.problem.priors
+        self.corr_items = self.problem.items
+        self.data = {name: _DataView(item) for name, item in self.problem.items.items()}
+        self.fiducial = {'k': self.problem.k, 'pk_full': self.problem.pk_full,
+                         'pk_smooth': self.problem.pk_smooth, 'z_eff': self.problem.z_eff,
+                         'z_fiducial': self.problem.z_fid, 'Omega_m': self.problem.omega_m,
+                         'Omega_de': self.problem.omega_de, 'growth_rate': self.problem.growth_rate}
+        self._use_global_cov = self.problem.global_cov is not None
+        self.monte_carlo = False
+        self._mc_active = False
+        self.engine = Engine(self.problem, max_batch=max_batch, device=device, extra_names=extra_names)
+        self.param_names = self.engine.names
+
+    # ------------------------------------------------------------------ parameter marshalling
+    def _theta(self, params=None):
+        return self.engine.theta_from_params(params)
+
+    def theta_matrix(self, params_list):
+        """Stack parameter dictionaries (or pass through a [B, n_params] array)."""
+        if isinstance(params_list, np.ndarray):
+            return np.atleast_2d(params_list)
+        return np.stack([self._theta(p) for p in params_list])
+
+    def _sync_monte_carlo(self):
+        """chi2 reads the current mock and the scaled inverse covariance in Monte-Carlo mode
+        (reference vega/vega_interface.py:296-297, :311-313)."""
+        if self.monte_carlo == self._mc_active and not self.monte_carlo:
+            return
+        for name, view in self.data.items():
+            if self.monte_carlo:
+                if view.masked_mc_mock is None:
+                    raise ValueError(f'monte_carlo is set but data[{name!r}].masked_mc_mock is None')
+                self.engine.set_data(name, view.masked_mc_mock)
+                if view.scaled_inv_masked_cov is not None and not self._use_global_cov:
+                    self.engine.set_invcov(name, view.scaled_inv_masked_cov)
+            else:
+                self.engine.set_data(name, view.masked_data_vec)
+                if self.problem.items[name].cov is not None and not self._use_global_cov:
+                    self.engine.set_invcov(name, view.inv_masked_cov)
+        self._mc_active = self.monte_carlo
+
+    # ------------------------------------------------------------------ reference surface
+    def compute_model(self, params=None, run_init=True, direct_pk=None, marg_coeff=None):
+        """dict name -> model correlation function (distorted grid), as the reference returns."""
+        if direct_pk is not None:
+            raise NotImplementedError('direct_pk is not accelerated')
+        if marg_coeff is not None:
+            raise NotImplementedError('marginalisation templates are not accelerated')
+        _, status, model = self.engine.eval(self._theta(params)[None, :], want_model=True)
+        if status[0]:
+            from .errors import VegaModelError
+            raise VegaModelError(f'model evaluation failed (status {int(status[0])})')
+        return {name: model[0, sl].copy() for name, sl in self.engine.model_slices.items()}
+
+    def chi2(self, params=None, direct_pk=None, return_marg_coeff=False):
+        """float chi2; 1e100 when the model cannot be evaluated (reference :268-279)."""
+        if direct_pk is not None or return_marg_coeff:
+            raise NotImplementedError('direct_pk / marginalisation coefficients are not accelerated')
+        self._sync_monte_carlo()
+        chi2, _, _ = self.engine.eval(self._theta(params)[None, :])
+        return float(chi2[0])
+
+    def log_lik(self, params=None, direct_pk=None, return_marg_coeff=False):
+        """Gaussian log-likelihood with its normalisation (reference :327-387)."""
+        chi2 = self.chi2(params, direct_pk, return_marg_coeff)
+        return float(self._log_norm() - 0.5 * chi2)
+
+    def _log_norm(self):
+        log_norm = 0.
+        for name, item in self.problem.items.items():
+            log_norm -= 0.5 * item.data_size * np.log(2 * np.pi)
+            if not self._use_global_cov:
+                if self.monte_carlo and self.data[name].scaled_log_cov_det is not None:
+                    log_norm -= 0.5 * self.data[name].scaled_log_cov_det
+                else:
+                    log_norm -= 0.5 * item.log_cov_det
+        if self._use_global_cov:
+            log_norm -= 0.5 * self.problem.global_masks()['log_det']
+        for (_, sigma) in self.priors.values():
+            log_norm += -0.5 * np.log(2 * np.pi) - np.log(sigma)
+        return log_norm
+
+    def compute_prior_chi2(self, params=None):
+        theta = self._theta(params)
+        total = 0.
+        for name, (mean, sigma) in self.priors.items():
+            total += (theta[self.engine.low.slot[name]] - mean)**2 / sigma**2
+        return total
+
+    # ------------------------------------------------------------------ batched surface
+    def chi2_batch(self, params_list, return_status=False):
+        """chi2 for many parameter points: list of dicts or [B, n_params] array (column order
+        ``self.param_names``).  Points are evaluated in chunks of ``max_batch``."""
+        self._sync_monte_carlo()
+        theta = self.theta_matrix(params_list)
+        out = np.empty(theta.shape[0])
+        status = np.empty(theta.shape[0], dtype=np.int32)
+        mb = self.engine.max_batch
+        for lo in range(0, theta.shape[0], mb):
+            c, s, _ = self.engine.eval(theta[lo:lo + mb])
+            out[lo:lo + mb] = c
+            status[lo:lo + mb] = s
+        return (out, status) if return_status else out
+
+    def log_lik_batch(self, params_list):
+        return self._log_norm() - 0.5 * self.chi2_batch(params_list)
+
+    def compute_model_batch(self, params_list):
+        theta = self.theta_matrix(params_list)
+        blocks = []
+        mb = self.engine.max_batch
+        for lo in range(0, theta.shape[0], mb):
+            blocks.append(self.engine.eval(theta[lo:lo + mb], want_model=True)[2])
+        model = np.concatenate(blocks)
+        return {name: model[:, sl] for name, sl in self.engine.model_slices.items()}
+
+    def close(self):
+        self.engine.close()
