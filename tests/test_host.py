@@ -1,0 +1,104 @@
+"""CPU tests of the host logic: config lowering, static operators, synthetic tensors, sharding."""
+import numpy as np
+import pytest
+from scipy import interpolate
+
+from conftest import load_problem, GOLDEN
+
+
+class _FakeEngine:
+    def __init__(self):
+        self.tables = {}
+
+    def _gk_table(self, a, b):
+        return self.tables.setdefault((a, b), len(self.tables))
+
+
+def test_lowering_resolves_the_reference_lookups():
+    from vega_amd import engine as E
+    prob = load_problem('joint_metals')
+    low = E.Lowering(prob)
+    fake = _FakeEngine()
+    auto = prob.items['lyalya_lyalya']
+    peak = low.pipeline(fake, auto.core, 'peak')
+    smooth = low.pipeline(fake, auto.core, 'smooth')
+    assert peak.scale_mode == E.SCALE_AP_AT and smooth.scale_mode == E.SCALE_UNIT
+    assert peak.peak_nl == 1 and smooth.peak_nl == 0
+    assert peak.hcd_model == E.HCD['Rogers'] and peak.uvb == 1 and peak.nl_model == E.NL['arinyo']
+    assert peak.arinyo_power == 1.0 and peak.n_ell == 4 and peak.same_tracer == 1
+    # bias_eta + beta given -> bias derived (reference utils.py:71-73)
+    assert peak.tracer[0].bias_slot == -1 and peak.tracer[0].bias_eta_slot >= 0
+    # 'par_sigma_smooth' present -> one squared Gaussian term (reference power_spectrum.py:520-535)
+    assert peak.n_smooth == 1 and peak.smooth_weight[0] == 1.0
+    cross = prob.items['lyalya_qso']
+    xs = low.pipeline(fake, cross.core, 'smooth')
+    assert xs.arinyo_power == 0.5 and xs.vd_kind == E.VD['lorentz'] and xs.radiation == 1
+    assert xs.drp_slot == low.slot['drp_QSO'] and xs.tracer[1].discrete == 1
+    assert len(fake.tables) == 1
+    # metal pairs: no HCD / UV / NL, unit scaling, Kaiser without biases
+    m = auto.metals[0]
+    md = low.pipeline(fake, m.pipeline, 'full', fast_metals=True)
+    assert md.scale_mode == E.SCALE_UNIT and md.hcd_model == 0 and md.nl_model == 0 and md.fast_metals == 1
+    assert [p.names for p in auto.metals][:5] == [('SiII(1190)', 'LYA'), ('SiII(1193)', 'LYA'),
+                                                  ('SiIII(1207)', 'LYA'), ('SiII(1260)', 'LYA'),
+                                                  ('SiII(1190)', 'SiII(1190)')]
+    assert len(auto.metals) == 15 and len(cross.metals) == 4
+    assert sum(p.double_count for p in auto.metals) == 6 + 4
+
+
+def test_unsupported_options_fail_loudly():
+    from vega_amd import engine as E
+    prob = load_problem('configs/picca/main_cross.ini')
+    low = E.Lowering(prob)
+    with pytest.raises(NotImplementedError):
+        low.pipeline(_FakeEngine(), prob.items['test_7'].core, 'smooth')
+
+
+def test_masks_and_sizes_match_the_reference_fixture_facts():
+    prob = load_problem('full4')
+    sizes = {n: (it.model_grid.size, it.data_size) for n, it in prob.items.items()}
+    assert sizes['lyalya_lyalya'] == (2500, 1590) and sizes['lyalya_qso'] == (5000, 3180)
+
+
+def test_xi_operator_reproduces_fftlog_plus_cubic_spline():
+    """OP_ell . P_ell evaluated with four B-spline taps == scipy interp1d(cubic) of the FFTLog."""
+    from vega_amd.fftlog_op import xi_operator
+    from oracle.fftlog import P2xi
+    prob = load_problem('auto')
+    f = prob.pk_smooth * np.exp(-prob.k**2 * 4) * 0.02
+    xs = np.log(np.linspace(1.5, 700., 4001))
+    for ell in (0, 2, 4, 6):
+        op, x0, h, n = xi_operator(prob.k, ell)
+        assert op.shape == (n + 2, n)
+        r, xi = P2xi(prob.k, l=ell)(f)
+        ref = interpolate.interp1d(np.log(r), xi, kind='cubic')(xs)
+        c = op @ f
+        u = (xs - x0) / h
+        j = np.floor(u).astype(int)
+        t = u - j
+        s = (c[j] * (1 - t)**3 + c[j + 1] * (3 * t**3 - 6 * t**2 + 4)
+             + c[j + 2] * (-3 * t**3 + 3 * t**2 + 3 * t + 1) + c[j + 3] * t**3) / 6
+        assert np.abs(s - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_synthetic_tensors_are_deterministic_and_well_formed():
+    from vega_amd import synthetic
+    prob = load_problem('auto')
+    grid = prob.items['lyalya_lyalya'].model_grid
+    dm = synthetic.distortion_matrix(grid.rp[:400], grid.rt[:400])
+    assert np.array_equal(dm, synthetic.distortion_matrix(grid.rp[:400], grid.rt[:400]))
+    np.testing.assert_allclose(dm.sum(axis=1), 0.7, rtol=1e-12)
+    assert 0.2 < (dm == 0).mean() < 0.6
+    cov = synthetic.covariance(grid.rp[:300], grid.rt[:300])
+    assert np.allclose(cov, cov.T) and np.linalg.eigvalsh(cov).min() > 0
+    theta = synthetic.walkers(np.array([1.0, 0.0, 9e99]), ['ap', 'x', 'qso_rad_lifetime'], 5)
+    assert theta.shape == (5, 3) and np.all(theta[:, 2] == 9e99) and np.ptp(theta[:, 0]) > 0
+
+
+def test_table_bundle_round_trip(tmp_path):
+    from vega_amd.tables import Table, write_bundle, read_tables
+    t = Table({'RPMIN': 0.0, 'NP': 50, 'NAXIS1': 8}, {'RP': np.arange(5.), 'DM': np.eye(3)})
+    write_bundle(tmp_path / 'x.npz', [t])
+    back = read_tables(tmp_path / 'x.npz')[0]
+    assert back.header == {'RPMIN': 0.0, 'NP': 50} and back.names == ['RP', 'DM']
+    np.testing.assert_array_equal(back.data['DM'], np.eye(3))
