@@ -1,0 +1,258 @@
+"""Benchmark of the model + chi2 hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" evaluates one batch of B synthetic walkers (parameter points) of BASELINE.json configs[2]:
+the joint Lya x Lya + QSO x Lya fit (two correlation items, shared parameters, 4 P(k)->xi pipelines
+per evaluation, ell = 0,2,4,6), with the seeded dense synthetic distortion matrices (2500^2 and
+5000^2) and covariances of SURVEY.md section 8d.  Walkers are resident in HBM before the timed
+region.  With N ranks each rank evaluates its own B walkers per step (weak scaling) and the chi2
+vectors are exchanged with ONE all-gather per step (RCCL over xGMI).
+
+Rank 0 prints one JSON line.  Extra objects:
+  roofline      dominant kernel of the timed region (HIP-event time on the engine stream)
+  distortion    the B = 1 distortion-matrix product of configs[1] (2500^2 fp64): GB/s vs HBM
+  cpu_baseline  the CPU oracle (NumPy restatement of the reference) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP64_VALU_PEAK_TF = 78.6       # MI355X FP64 vector peak (spec; 256 CU x 128 flop/clk x 2.4 GHz)
+FP64_MFMA_PEAK_TF = 78.6       # MI355X FP64 matrix peak (spec)
+
+# Algorithmic flops per P(k,mu) grid point (DESIGN.md section "Flop model"): elementary operations
+# of the reference's formulas, transcendental calls counted once each.
+FLOPS_PER_POINT = {'auto': 58, 'cross': 52}
+
+
+def build_problem(workload):
+    from vega_amd.setup import build_problem as bp
+    from vega_amd import synthetic
+    cfg = {'joint': 'configs/joint/main.ini', 'auto': 'configs/auto/main.ini',
+           'joint_metals': 'configs/joint_metals/main.ini'}[workload]
+    prob = bp(cfg, search_dirs=[REPO / 'tests' / 'golden'])
+    for item in prob.items.values():
+        item.distortion = synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt)
+        item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt))
+    return prob
+
+
+VARIED = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO', 'drp_QSO',
+          'bias_hcd', 'beta_hcd', 'L0_hcd', 'bias_eta_SiII(1190)', 'bias_eta_SiII(1193)',
+          'bias_eta_SiIII(1207)', 'bias_eta_SiII(1260)', 'bias_eta_CIV(eff)']
+
+
+def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
+    """B = 1 product y = DM x with 8 distinct matrices (400 MB > Infinity Cache) round-robin, so
+    every launch streams its matrix from HBM; HIP-event timed on the engine stream."""
+    ld = (n + 15) // 16 * 16
+    dev = torch.device('cuda', torch.cuda.current_device())
+    mats = [torch.zeros(n, ld, dtype=torch.float64, device=dev) for _ in range(copies)]
+    for m in mats:
+        m[:, :n] = torch.rand(n, n, dtype=torch.float64, device=dev)
+    x = torch.zeros(1, ld, dtype=torch.float64, device=dev)
+    x[0, :n] = torch.rand(n, dtype=torch.float64, device=dev)
+    y = torch.zeros(1, ld, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    for m in mats:
+        engine.matvec_device(m.data_ptr(), n, ld, x.data_ptr(), 1, y.data_ptr())
+    engine.sync()
+    ref = (mats[-1][:, :n] @ x[0, :n])
+    err = float((y[0, :n] - ref).abs().max() / ref.abs().max())
+    engine.timings(reset=True)
+    engine.set_profiling(True)
+    for i in range(reps):
+        engine.matvec_device(mats[i % copies].data_ptr(), n, ld, x.data_ptr(), 1, y.data_ptr())
+    engine.sync()
+    ms, launches = engine.timings(reset=True)['matvec_api']
+    engine.set_profiling(False)
+    # one hot-cache variant: same matrix every launch (50 MB, Infinity-Cache resident)
+    engine.set_profiling(True)
+    for i in range(reps):
+        engine.matvec_device(mats[0].data_ptr(), n, ld, x.data_ptr(), 1, y.data_ptr())
+    engine.sync()
+    ms_hot, launches_hot = engine.timings(reset=True)['matvec_api']
+    engine.set_profiling(False)
+    algo_bytes = 8.0 * (n * n + n + n)          # 8 (N_out N_in + B N_in + B N_out)
+    cold = algo_bytes / (ms / launches * 1e-3) / 1e9
+    hot = algo_bytes / (ms_hot / launches_hot * 1e-3) / 1e9
+    return {'shape': [n, n], 'batch': 1, 'bound': 'hbm', 'algorithmic_bytes': algo_bytes,
+            'us_per_launch': ms / launches * 1e3, 'achieved': cold, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': cold / HBM_PEAK_GBS, 'achieved_cache_resident': hot, 'max_rel_err': err,
+            'note': '8 distinct 50 MB matrices round-robin (HBM); cache_resident = one matrix reused'}
+
+
+def cpu_baseline(prob, names, theta, seconds=15.0):
+    """The oracle (CPU restatement of the reference) on a bounded sample of the same walkers."""
+    from contextlib import nullcontext
+    from oracle import vega_cpu as oracle
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:       # pragma: no cover
+        ctx = nullcontext()
+    with ctx:
+        oracle.chi2(prob)       # warm caches (grids, FFTLog objects)
+        t0 = time.perf_counter()
+        done = 0
+        vals = []
+        while done < theta.shape[0] and (time.perf_counter() - t0) < seconds:
+            vals.append(oracle.chi2(prob, dict(zip(names, theta[done]))))
+            done += 1
+        dt = time.perf_counter() - t0
+    return {'value': done / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{done} walkers of the same workload, oracle/vega_cpu.py chi2, 1 thread, {dt:.1f} s'}, vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--workload', default='joint', choices=['joint', 'auto', 'joint_metals'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the vegamx engine has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from vega_amd import VegaInterface, synthetic
+
+    B = args.batch
+    prob = build_problem(args.workload)
+    vega = VegaInterface(None, problem=prob, max_batch=B, device=local_rank)
+    eng = vega.engine
+    dev = torch.device('cuda', local_rank)
+
+    # distinct walker batches per step and per rank, resident in HBM before timing
+    n_pool = min(args.steps, 8)
+    pools = []
+    host_theta = None
+    for i in range(n_pool):
+        th = synthetic.walkers(eng.low.theta0, eng.names, B, varied=VARIED, seed=synthetic.SEED + 1000 * rank + i)
+        if i == 0:
+            host_theta = th
+        pools.append(torch.from_numpy(th).to(dev))
+    chi2_dev = torch.zeros(B, dtype=torch.float64, device=dev)
+    gathered = torch.zeros(world * B, dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step(i):
+        eng.eval_device(pools[i % n_pool].data_ptr(), B, chi2_dev.data_ptr())
+        if world > 1:
+            eng.sync()      # the engine runs on its own stream
+            dist.all_gather_into_tensor(gathered, chi2_dev)
+
+    for i in range(args.warmup):
+        step(i)
+    eng.sync()
+    torch.cuda.synchronize()
+    eng.timings(reset=True)
+    eng.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(False)
+    timings = eng.timings(reset=True)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_evals = B * args.steps * world
+        value = total_evals / elapsed
+        kernels = {k: {'ms_per_launch': v[0] / v[1], 'launches': v[1], 'ms_total': v[0]}
+                   for k, v in timings.items() if v[1]}
+        dominant = max(kernels, key=lambda k: kernels[k]['ms_total'])
+        n_items = len(prob.items)
+        roofline = None
+        if dominant == 'pk_multipoles':
+            nk, n_mu = prob.k.size, 1000
+            flops = 0.0
+            for item in prob.items.values():
+                kind = 'auto' if item.tracer1.name == item.tracer2.name else 'cross'
+                flops += 2 * B * nk * n_mu * FLOPS_PER_POINT[kind]       # peak + smooth components
+            tf = flops / (kernels[dominant]['ms_per_launch'] * 1e-3) / 1e12
+            roofline = {'kernel': dominant, 'bound': 'valu-fp64', 'achieved': tf, 'peak': FP64_VALU_PEAK_TF,
+                        'unit': 'TFLOP/s', 'frac': tf / FP64_VALU_PEAK_TF, 'traffic': None,
+                        'algorithmic_flops_per_launch': flops}
+        elif dominant in ('distortion_product', 'invcov_product', 'fftlog_spline_product'):
+            if dominant == 'distortion_product':
+                shapes = [(it.dist_grid.size, it.model_grid.size) for it in prob.items.values()]
+            elif dominant == 'invcov_product':
+                shapes = [(it.data_size, it.data_size) for it in prob.items.values()]
+            else:
+                shapes = [(816, 814)] * 4
+            n_vec = B * (4 * n_items // 2 if dominant == 'fftlog_spline_product' else 1)
+            flops = sum(2.0 * m * n * n_vec for m, n in shapes) / len(shapes)
+            tf = flops / (kernels[dominant]['ms_per_launch'] * 1e-3) / 1e12
+            roofline = {'kernel': dominant, 'bound': 'mfma', 'achieved': tf, 'peak': FP64_MFMA_PEAK_TF,
+                        'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TF, 'traffic': None,
+                        'algorithmic_flops_per_launch': flops}
+        distortion = distortion_microbench(eng, torch)
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu, ref_vals = cpu_baseline(prob, eng.names, host_theta)
+            got = chi2_check = vega.chi2_batch(host_theta[:len(ref_vals)])
+            rel = float(np.max(np.abs(got - np.array(ref_vals)) / np.abs(ref_vals)))
+            cpu['max_rel_chi2_diff_vs_gpu'] = rel
+            del chi2_check
+        out = {
+            'metric': 'model+chi2 evals/sec (Lya auto+cross)', 'value': value, 'unit': 'evals/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: Lya x Lya + QSO x Lya joint fit, B={B} walkers/GPU/step, '
+                                   'ell=0,2,4,6, dense synthetic 2500^2 + 5000^2 distortion matrices and '
+                                   '1590^2 + 3180^2 inverse covariances (BASELINE configs[2])'
+                       if args.workload == 'joint' else args.workload,
+                       'batch_per_gpu': B, 'pipelines_per_eval': len(eng.pipe_index),
+                       'collective': 'one all_gather of chi2 per step' if world > 1 else 'none'},
+            'roofline': roofline, 'distortion': distortion, 'cpu_baseline': cpu, 'kernels': kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    vega.close()
+
+
+if __name__ == '__main__':
+    main()
