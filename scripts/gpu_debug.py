@@ -62,3 +62,30 @@ eng.set_profiling(True)
 for _ in range(3):
     eng.eval(theta)
 print({k: v for k, v in eng.timings().items() if v[1]})
+
+# ---- timing at B = 256
+from vega_amd import synthetic  # noqa: E402
+vega.close()
+vega = VegaInterface(f'configs/{cfg}/main.ini', search_dirs=[GOLD], max_batch=256)
+eng = vega.engine
+theta = synthetic.walkers(eng.low.theta0, eng.names, 256, seed=3,
+                          varied=['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO',
+                                  'drp_QSO', 'bias_hcd', 'beta_hcd', 'L0_hcd'])
+for _ in range(2):
+    eng.eval(theta)
+eng.set_profiling(True)
+t0 = time.time()
+for _ in range(5):
+    eng.eval(theta)
+dt = (time.time() - t0) / 5
+print(f'B=256: {dt*1e3:.3f} ms/step, {256/dt:.0f} evals/s')
+print({k: round(v[0] / v[1], 4) for k, v in eng.timings().items() if v[1]})
+eng.set_profiling(False)
+for B in (1, 4, 16, 64):
+    for _ in range(2):
+        eng.eval(theta[:B])
+    t0 = time.time()
+    for _ in range(20):
+        eng.eval(theta[:B])
+    dt = (time.time() - t0) / 20
+    print(f'B={B}: {dt*1e6:.1f} us/step, {B/dt:.0f} evals/s')

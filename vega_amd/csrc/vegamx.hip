@@ -110,6 +110,8 @@ struct vmx_engine {
     std::vector<double> h_r, h_mu_c, h_z, h_relz, h_growth;
     DevBuf<double> cr, cmu, cz, crelz, cgrowth;
     DevBuf<PipeDev> d_pipes;
+    std::vector<PkGroup> pk_groups;
+    DevBuf<PkGroup> d_pk_groups;
 
     std::vector<ItemHost*> items;
     std::vector<MetalHost*> metals;
@@ -177,6 +179,20 @@ static void collect_spans(vmx_engine* e)
         }
     }
     e->span_used = 0;
+}
+
+// true when `peak` evaluates the same P(k,mu) factors as `smooth` apart from the peak-only Gaussian
+// broadening (and the k-only linear spectrum): then both are produced by one pass of k_pk_multipoles
+static bool pk_stage_compatible(const vmx_pipe_desc& smooth, const vmx_pipe_desc& peak)
+{
+    vmx_pipe_desc a = smooth, b = peak;
+    if (a.is_peak || !b.is_peak || a.peak_nl || !b.peak_nl) return false;
+    // neutralise the fields that are allowed to differ, then compare everything the P(k) stage reads
+    b.is_peak = a.is_peak; b.pk_lin_kind = a.pk_lin_kind; b.peak_nl = a.peak_nl;
+    b.sigma_nl_par_slot = a.sigma_nl_par_slot; b.sigma_nl_per_slot = a.sigma_nl_per_slot;
+    b.scale_mode = a.scale_mode; b.scale_slot[0] = a.scale_slot[0]; b.scale_slot[1] = a.scale_slot[1];
+    b.radiation = a.radiation;
+    return std::memcmp(&a, &b, sizeof(vmx_pipe_desc)) == 0;
 }
 
 // D[n][m] = sum_k A[m][k] X[n][k]; returns the number of K slabs written (consumer sums them).
@@ -582,6 +598,23 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     const int n_pipe = (int)e->pipes.size();
     if (e->d_pipes.upload(e->pipes.data(), e->pipes.size())) return -2;
 
+    // P(k,mu) work groups: an item's peak component rides along with its smooth component when the two
+    // differ only by the peak broadening
+    {
+        std::vector<char> taken(e->pipes.size(), 0);
+        e->pk_groups.clear();
+        for (auto* it : e->items) {
+            const int ps = it->dev.d.pipe_smooth, pk = it->dev.d.pipe_peak;
+            if (ps != pk && !taken[ps] && !taken[pk] && pk_stage_compatible(e->pipes[ps].d, e->pipes[pk].d)) {
+                e->pk_groups.push_back({ps, pk});
+                taken[ps] = taken[pk] = 1;
+            }
+        }
+        for (int p = 0; p < (int)e->pipes.size(); ++p)
+            if (!taken[p]) e->pk_groups.push_back({p, -1});
+        if (e->d_pk_groups.upload(e->pk_groups.data(), e->pk_groups.size())) return -2;
+    }
+
     // metals
     int64_t xim_off = 0;
     std::vector<MetalDev> metals;
@@ -676,11 +709,14 @@ static int run_chain(vmx_engine* e, int B)
     }
     {
         ScopedTimer t(e, KC_PK);
-        const size_t shmem = ((size_t)e->n_mu + 1024) * sizeof(double);
-        if ((int64_t)B * n_pipe >= 48)
-            hipLaunchKernelGGL((k_pk_multipoles<64, 4>), dim3((e->nk + 63) / 64, n_pipe, B), dim3(256), shmem, e->stream, D);
+        const size_t shmem = ((size_t)e->n_mu + 2048) * sizeof(double);
+        const int n_groups = (int)e->pk_groups.size();
+        if ((int64_t)B * n_groups >= 24)
+            hipLaunchKernelGGL((k_pk_multipoles<64, 4>), dim3(B, n_groups, (e->nk + 63) / 64), dim3(256), shmem, e->stream, D,
+                               e->d_pk_groups.p);
         else
-            hipLaunchKernelGGL((k_pk_multipoles<16, 16>), dim3((e->nk + 15) / 16, n_pipe, B), dim3(256), shmem, e->stream, D);
+            hipLaunchKernelGGL((k_pk_multipoles<16, 16>), dim3(B, n_groups, (e->nk + 15) / 16), dim3(256), shmem, e->stream, D,
+                               e->d_pk_groups.p);
     }
     {
         const int64_t ncols = (int64_t)B * n_pipe;

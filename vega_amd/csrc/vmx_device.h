@@ -260,131 +260,273 @@ __global__ void k_gk_table(double* out, const double* k, const double* mu, int n
 
 // ------------------------------------------------------------------------------------------------
 // P(k, mu) evaluation fused with the Legendre projection
-//   block = KT wavenumbers x MS mu-slices (KT * MS = 256); grid = (k tiles, pipelines, walkers)
+//   block = KT wavenumbers x MS mu-slices (KT * MS = 256); grid = (walkers, pipelines, k tiles):
+//   walkers vary fastest so that co-resident blocks read the same slice of the G(k,mu) table from L2.
+//   Each thread owns one k and walks mu_j = (j + 1/2)/n_mu for j = ms, ms + MS, ...; every factor of
+//   the reference's product is rebuilt per walker (no allclose-keyed caches).
 // ------------------------------------------------------------------------------------------------
+
+// d = a * b + c as one v_fma_f64.  hipcc otherwise lowers a Horner step with a constant addend to
+// v_mov_b64 + v_fmac_f64 (two VALU slots); plain VALU results are interlocked in hardware, so the
+// statement needs no wait states of its own.
+__device__ __forceinline__ double vmx_fma(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// exp(x) for x <= 709, |relative error| ~ 2e-16: n = rint(x log2 e), r = x - n ln 2 in two pieces,
+// degree-12 Taylor polynomial on |r| <= ln(2)/2, scaled by 2^n.  Very negative arguments give 0
+// (v_cvt_i32_f64 saturates and v_ldexp_f64 underflows to zero).
+__device__ __forceinline__ double vmx_exp(double x)
+{
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;            // 1/12!
+    p = vmx_fma(p, r, 2.50521083854417187751e-08);    // 1/11!
+    p = vmx_fma(p, r, 2.75573192239858906526e-07);    // 1/10!
+    p = vmx_fma(p, r, 2.75573192239858906526e-06);    // 1/9!
+    p = vmx_fma(p, r, 2.48015873015873015873e-05);    // 1/8!
+    p = vmx_fma(p, r, 1.98412698412698412698e-04);    // 1/7!
+    p = vmx_fma(p, r, 1.38888888888888888889e-03);    // 1/6!
+    p = vmx_fma(p, r, 8.33333333333333333333e-03);    // 1/5!
+    p = vmx_fma(p, r, 4.16666666666666666667e-02);    // 1/4!
+    p = vmx_fma(p, r, 1.66666666666666666667e-01);    // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// 1/sqrt(x) for x >= 1: hardware estimate plus one third-order correction (no special cases arise)
+__device__ __forceinline__ double vmx_rsqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+#define PK_REANCHOR 64      // steps between exact re-evaluations of the exponential recurrences
+
+// One work group of the P(k,mu) stage: a pipeline and, when the item's peak component differs from its
+// smooth component only by the peak non-linear broadening (power_spectrum.py:163-164), that peak
+// pipeline as a partner evaluated in the same pass.
+struct PkGroup { int32_t pipe; int32_t peak_partner; };
+
+struct PkThread {
+    // per-thread (one wavenumber) constants of the mu loop
+    double k, c0_1, c1_1, c0_2, c1_2, hb, hbb, L0, e0, e1, e2, ar_gv, ar_gp, vd1, vd2, ea, eb, mc_kvel;
+    double p0, p1, pq, Fq;
+    const double* gk;
+    size_t gk_stride;
+    bool hcd1, hcd2, div1, div2, same, arinyo, rogers, sinc, has_exp, mcdonald, paired, has_vd1, has_vd2;
+};
+
+// mu loop of one thread.  RARE = false covers the production model set (Kaiser, UV, Rogers HCD, Arinyo,
+// G(k), Gaussian smoothing / peak broadening, Lorentz or Gaussian velocity dispersion); RARE = true adds
+// sinc HCD, McDonald NL, exponential smoothing and the fast-metals division.
+template <int MS, bool RARE>
+__device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mubv, int ms, int n_mu,
+                                           double inv_nmu, double* s, double* q, bool& bad)
+{
+    const double w2a = 7.5 * inv_nmu, w2b = -2.5 * inv_nmu;
+    const double w4a = 39.375 * inv_nmu, w4b = -33.75 * inv_nmu, w4c = 3.375 * inv_nmu;
+    const double w6a = 187.6875 * inv_nmu, w6b = -255.9375 * inv_nmu, w6c = 85.3125 * inv_nmu, w6d = -4.0625 * inv_nmu;
+    const double dmu = (double)MS * inv_nmu;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    const double* gk = T.gk;
+
+    for (int j0 = ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
+        // exact anchors of the three geometric progressions along this thread's mu sequence
+        const double mu_a = ((double)j0 + 0.5) * inv_nmu;
+        double F = 0.0, pg = 1.0, pr = 1.0;
+        if (T.rogers) F = vmx_exp(-T.L0 * T.k * mu_a);
+        if (T.paired) {
+            pg = vmx_exp(fma(T.p1, mu_a * mu_a, T.p0));
+            pr = vmx_exp(T.p1 * fma(2.0 * mu_a, dmu, dmu * dmu));
+        }
+        int jend = j0 + MS * PK_REANCHOR;
+        if (jend > n_mu) jend = n_mu;
+        for (int j = j0; j < jend; j += MS) {
+            const double mu = ((double)j + 0.5) * inv_nmu;
+            const double mu2 = mu * mu;
+            const double kpar = T.k * mu;
+            if (RARE && T.sinc) { const double x = kpar * T.L0; F = sin(x) / x; }
+
+            // tracer amplitudes b_eff (1 + beta_eff mu^2) = b + b beta mu^2 + F b_hcd (1 + beta_hcd mu^2)
+            const double hmu = fma(T.hbb, mu2, T.hb);
+            double A1 = fma(T.c1_1, mu2, T.c0_1);
+            if (T.hcd1) A1 = fma(F, hmu, A1);
+            if (RARE && T.div1) A1 /= fma(F, T.hb, T.c0_1);
+            double A2;
+            if (T.same) A2 = A1;
+            else {
+                A2 = fma(T.c1_2, mu2, T.c0_2);
+                if (T.hcd2) A2 = fma(F, hmu, A2);
+                if (RARE && T.div2) A2 /= fma(F, T.hb, T.c0_2);
+            }
+
+            double E = fma(T.e1, mu2, T.e0);
+            if (T.arinyo) {
+                const double m = s_mubv[j];
+                // VegaArinyoError: NaN or Inf in exp(growth (1 - pec) - pressure) (power_spectrum.py:466-469)
+                if (!(fma(-T.ar_gv, m, T.ar_gp) < 709.0)) bad = true;
+                E = fma(T.e2, m, E);
+            }
+            if (RARE) {
+                if (T.has_exp) E -= T.k * fma(mu, T.ea, sqrt(1.0 - mu2) * T.eb);
+                if (T.mcdonald) { const double x = kpar / T.mc_kvel; E -= x * sqrt(x); }
+                E = fmin(E, 709.0);
+            }
+
+            double val = A1 * A2 * vmx_exp(E);
+            if (gk) { val *= *gk; gk += T.gk_stride; }
+            if (T.has_vd1) val *= vmx_rsqrt(fma(kpar * kpar, T.vd1, 1.0));
+            if (T.has_vd2) val *= vmx_rsqrt(fma(kpar * kpar, T.vd2, 1.0));
+
+            const double w2 = fma(w2a, mu2, w2b);
+            const double w4 = fma(fma(w4a, mu2, w4b), mu2, w4c);
+            const double w6 = fma(fma(fma(w6a, mu2, w6b), mu2, w6c), mu2, w6d);
+            s0 += val;
+            s1 = fma(w2, val, s1);
+            s2 = fma(w4, val, s2);
+            s3 = fma(w6, val, s3);
+            if (T.paired) {
+                const double vp = val * pg;
+                q0 += vp;
+                q1 = fma(w2, vp, q1);
+                q2 = fma(w4, vp, q2);
+                q3 = fma(w6, vp, q3);
+                pg *= pr;
+                pr *= T.pq;
+            }
+            F *= T.Fq;
+        }
+    }
+    s[0] = s0 * inv_nmu; s[1] = s1; s[2] = s2; s[3] = s3;
+    q[0] = q0 * inv_nmu; q[1] = q1; q[2] = q2; q[3] = q3;
+}
+
 template <int KT, int MS>
-__global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D)
+__global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGroup* groups)
 {
     extern __shared__ double smem[];
     double* s_mubv = smem;                        // [n_mu]   mu^bv (Arinyo)
-    double* s_red = smem + D.n_mu;                // [4][256]
+    double* s_red = smem + D.n_mu;                // [8][256]
 
-    const int p = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.x;
+    const int p = groups[blockIdx.y].pipe, pp = groups[blockIdx.y].peak_partner;
     const vmx_pipe_desc& d = D.pipes[p].d;
     const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
-    const int kk = threadIdx.x % KT, ms = threadIdx.x / KT;
-    const int i = blockIdx.x * KT + kk;
+    const int kk = threadIdx.x % KT;
+    // with KT = 64 a wave shares its mu slice: keep the slice index in a scalar register
+    const int ms = (KT == 64) ? __builtin_amdgcn_readfirstlane(threadIdx.x / KT) : (int)(threadIdx.x / KT);
+    const int i = blockIdx.z * KT + kk;
     const bool valid = i < D.nk;
     const int ic = valid ? i : D.nk - 1;
     const int n_mu = D.n_mu;
+    const double inv_nmu = 1.0 / (double)n_mu;
 
-    const bool arinyo = d.nl_model == VMX_NL_ARINYO;
-    if (arinyo) {
+    PkThread T;
+    T.paired = pp >= 0;
+    T.arinyo = d.nl_model == VMX_NL_ARINYO;
+    if (T.arinyo) {
         const double bv = sc[S_ABV];
-        for (int j = threadIdx.x; j < n_mu; j += 256) s_mubv[j] = pow(D.mu[j], bv);
+        for (int j = threadIdx.x; j < n_mu; j += 256) s_mubv[j] = pow(((double)j + 0.5) * inv_nmu, bv);
         __syncthreads();
     }
 
     const double k = D.k[ic], k2 = k * k;
+    T.k = k;
     const bool hcd = d.hcd_model != VMX_HCD_NONE;
     const bool lya1 = d.tracer[0].is_lya, lya2 = d.tracer[1].is_lya;
+    T.same = d.same_tracer;
+    T.rogers = d.hcd_model == VMX_HCD_ROGERS;
+    T.sinc = d.hcd_model == VMX_HCD_SINC;
 
     // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261): only the bias changes,
     // bias * beta is invariant under that step.
-    double c0_1 = sc[S_BIAS1], c1_1 = sc[S_BB1], c0_2 = sc[S_BIAS2], c1_2 = sc[S_BB2];
+    T.c0_1 = sc[S_BIAS1]; T.c0_2 = sc[S_BIAS2]; T.c1_1 = sc[S_BB1]; T.c1_2 = sc[S_BB2];
     if (d.uvb || d.heii) {
         double add = 0.0;
         if (d.uvb) { const double x = k * sc[S_UV_LAM]; const double W = atan(x) / x; add += sc[S_UV_BG] * W / (1.0 + sc[S_UV_BP] * W); }
         if (d.heii) { const double x = k * sc[S_HE_LAM]; const double W = atan(x) / x; add += sc[S_HE_BG] * W / (1.0 + sc[S_UV_BP] * W); }
-        if (lya1) c0_1 += add;
-        if (lya2) c0_2 += add;
+        if (lya1) T.c0_1 += add;
+        if (lya2) T.c0_2 += add;
     }
-    const double hb = sc[S_HCD_B], hbb = sc[S_HCD_BB], L0 = sc[S_HCD_L0];
-    const bool div1 = d.fast_metals && lya1 && (d.uvb || d.heii || hcd);
-    const bool div2 = d.fast_metals && lya2 && (d.uvb || d.heii || hcd);
+    T.hb = sc[S_HCD_B]; T.hbb = sc[S_HCD_BB]; T.L0 = sc[S_HCD_L0];
+    T.hcd1 = lya1 && hcd; T.hcd2 = lya2 && hcd;
+    T.div1 = d.fast_metals && lya1 && (d.uvb || d.heii || hcd);
+    T.div2 = d.fast_metals && lya2 && (d.uvb || d.heii || hcd);
 
-    const double ga = sc[S_GA], gb = sc[S_GB], ea = sc[S_EA], eb = sc[S_EB];
-    const bool has_exp = (ea != 0.0) || (eb != 0.0);
-    const double vd1 = sc[S_VD1], vd2 = sc[S_VD2];
-
-    double ar_g = 0.0, ar_v = 0.0, ar_p = 0.0;
-    const double apow = d.arinyo_power;
-    if (arinyo) {
+    // exponent  E = e0 + e1 mu^2 + e2 mu^bv  (+ rarely used extra terms)
+    const double ga = sc[S_GA], gb = sc[S_GB];
+    T.ea = sc[S_EA]; T.eb = sc[S_EB];
+    T.has_exp = (T.ea != 0.0) || (T.eb != 0.0);
+    T.vd1 = sc[S_VD1]; T.vd2 = sc[S_VD2];
+    T.has_vd1 = T.vd1 != 0.0; T.has_vd2 = T.vd2 != 0.0;
+    T.e0 = -k2 * gb; T.e1 = -k2 * (ga - gb); T.e2 = 0.0;
+    T.ar_gv = 0.0; T.ar_gp = 0.0;
+    if (T.arinyo) {
+        const double apow = d.arinyo_power;
         const double d2 = D.delta2[ic];
-        ar_g = sc[S_AQ1] * d2 + sc[S_AQ2] * d2 * d2;
-        ar_v = pow(k / sc[S_AKV], sc[S_AAV]);
+        const double ar_g = sc[S_AQ1] * d2 + sc[S_AQ2] * d2 * d2;
+        T.ar_gv = ar_g * pow(k / sc[S_AKV], sc[S_AAV]);
         const double kp = k / sc[S_AKP];
-        ar_p = kp * kp;
+        T.ar_gp = ar_g - kp * kp;
+        T.e0 = fma(apow, T.ar_gp, T.e0);
+        T.e2 = -apow * T.ar_gv;
     }
-    double mc_base = 0.0, mc_kvel = 1.0;
-    const bool mcdonald = d.nl_model == VMX_NL_MCDONALD;
-    if (mcdonald) {
-        mc_kvel = 1.22 * pow(1.0 + k / 0.923, 0.451);
-        mc_base = pow(k / 6.4, 0.569) - pow(k / 15.3, 2.01);
+    T.mc_kvel = 1.0;
+    T.mcdonald = d.nl_model == VMX_NL_MCDONALD;
+    if (T.mcdonald) {
+        T.mc_kvel = 1.22 * pow(1.0 + k / 0.923, 0.451);
+        T.e0 += pow(k / 6.4, 0.569) - pow(k / 15.3, 2.01);
     }
-    const double* gk = d.gk_table >= 0 ? D.gk + (size_t)d.gk_table * n_mu * D.nkp : nullptr;
+    T.gk_stride = (size_t)MS * D.nkp;
+    T.gk = d.gk_table >= 0 ? D.gk + (size_t)d.gk_table * n_mu * D.nkp + (size_t)ms * D.nkp + ic : nullptr;
 
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    // peak partner: extra factor exp(p0 + p1 mu^2) from the additional Gaussian broadening
+    const double dmu = (double)MS * inv_nmu;
+    T.p0 = 0.0; T.p1 = 0.0; T.pq = 1.0;
+    if (T.paired) {
+        const double* scp = D.scal + ((size_t)b * D.n_pipe + pp) * VMX_NS;
+        const double dga = scp[S_GA] - ga, dgb = scp[S_GB] - gb;
+        T.p0 = -k2 * dgb;
+        T.p1 = -k2 * (dga - dgb);
+        T.pq = vmx_exp(2.0 * T.p1 * dmu * dmu);
+    }
+    // F = exp(-L0 k mu_j) along this thread's mu sequence is a geometric progression
+    T.Fq = T.rogers ? vmx_exp(-T.L0 * k * dmu) : 0.0;
+
+    double s[4], q[4];
     bool bad = false;
+    const bool rare = T.sinc || T.has_exp || T.mcdonald || T.div1 || T.div2;
+    if (rare) pk_mu_loop<MS, true>(T, s_mubv, ms, n_mu, inv_nmu, s, q, bad);
+    else pk_mu_loop<MS, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q, bad);
 
-    for (int j = ms; j < n_mu; j += MS) {
-        const double mu = D.mu[j];
-        const double mu2 = mu * mu;
-        const double kpar = k * mu;
-
-        double F = 0.0;
-        if (d.hcd_model == VMX_HCD_ROGERS) F = exp(-L0 * kpar);
-        else if (d.hcd_model == VMX_HCD_SINC) { const double x = kpar * L0; F = sin(x) / x; }
-
-        // tracer amplitudes b_eff (1 + beta_eff mu^2) = b + b beta mu^2 + F b_hcd (1 + beta_hcd mu^2)
-        double A1 = fma(c1_1, mu2, c0_1);
-        if (lya1 && hcd) A1 = fma(F, fma(hbb, mu2, hb), A1);
-        if (div1) A1 /= fma(F, hb, c0_1);
-        double A2;
-        if (d.same_tracer) A2 = A1;
-        else {
-            A2 = fma(c1_2, mu2, c0_2);
-            if (lya2 && hcd) A2 = fma(F, fma(hbb, mu2, hb), A2);
-            if (div2) A2 /= fma(F, hb, c0_2);
-        }
-
-        double E = -k2 * fma(mu2, ga, (1.0 - mu2) * gb);
-        if (has_exp) E -= k * fma(mu, ea, D.sq1mmu2[j] * eb);
-        if (arinyo) {
-            const double Ea = ar_g * (1.0 - ar_v * s_mubv[j]) - ar_p;
-            // VegaArinyoError: NaN or Inf in exp(Ea) (power_spectrum.py:468-469)
-            if (!(Ea < 709.0)) bad = true;
-            E = fma(apow, Ea, E);
-        }
-        if (mcdonald) { const double x = kpar / mc_kvel; E += mc_base - x * sqrt(x); }
-
-        double val = A1 * A2 * exp(E);
-        if (gk) val *= gk[(size_t)j * D.nkp + ic];
-        if (vd1 != 0.0) val *= 1.0 / sqrt(fma(kpar * kpar, vd1, 1.0));
-        if (vd2 != 0.0) val *= 1.0 / sqrt(fma(kpar * kpar, vd2, 1.0));
-
-        acc0 = fma(D.wl[j], val, acc0);
-        acc1 = fma(D.wl[n_mu + j], val, acc1);
-        acc2 = fma(D.wl[2 * n_mu + j], val, acc2);
-        acc3 = fma(D.wl[3 * n_mu + j], val, acc3);
+    for (int e = 0; e < 4; ++e) {
+        s_red[e * 256 + threadIdx.x] = s[e];
+        s_red[(4 + e) * 256 + threadIdx.x] = q[e];
     }
-
-    s_red[threadIdx.x] = acc0;
-    s_red[256 + threadIdx.x] = acc1;
-    s_red[512 + threadIdx.x] = acc2;
-    s_red[768 + threadIdx.x] = acc3;
     __syncthreads();
     if (bad && valid) atomicOr(&D.status[b], VMX_STATUS_ARINYO);
 
-    if (ms == 0 && valid) {
-        double pk = D.pklin[(size_t)d.pk_lin_kind * D.nkp + i];
-        if (d.damping_scale > 0.0) pk *= exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
-        const size_t ncols = (size_t)gridDim.z * D.n_pipe;
-        const size_t col = (size_t)b * D.n_pipe + p;
-        for (int e = 0; e < D.n_ell; ++e) {
-            double sum = 0.0;
-            for (int q = 0; q < MS; ++q) sum += s_red[e * 256 + q * KT + kk];
-            D.pl[((size_t)e * ncols + col) * D.nkp + i] = pk * sum;
+    if (threadIdx.x < KT && valid) {
+        double damp = 1.0;
+        if (d.damping_scale > 0.0) damp = exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
+        const size_t ncols = (size_t)gridDim.x * D.n_pipe;
+        for (int half = 0; half < (T.paired ? 2 : 1); ++half) {
+            const int pipe = half ? pp : p;
+            const double pk = damp * D.pklin[(size_t)D.pipes[pipe].d.pk_lin_kind * D.nkp + i];
+            const size_t col = (size_t)b * D.n_pipe + pipe;
+            for (int e = 0; e < D.n_ell; ++e) {
+                double sum = 0.0;
+                for (int qq = 0; qq < MS; ++qq) sum += s_red[(half * 4 + e) * 256 + qq * KT + kk];
+                D.pl[((size_t)e * ncols + col) * D.nkp + i] = pk * sum;
+            }
         }
     }
 }
