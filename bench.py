@@ -94,6 +94,33 @@ def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
             'note': '8 distinct 50 MB matrices round-robin (HBM); cache_resident = one matrix reused'}
 
 
+def single_point_latency(device, reps=200):
+    """BASELINE configs[1]: Lya x Lya auto only, ell = 0,2,4, dense 2500^2 distortion matrix, B = 1:
+    wall-clock chi2 evaluations per second through the host interface (host theta in, host chi2 out)."""
+    from vega_amd import VegaInterface
+    prob = build_problem('auto')
+    for item in prob.items.values():
+        item.core.xi.ell_max = 4
+    vega = VegaInterface(None, problem=prob, max_batch=1, device=device)
+    theta = vega.engine.theta_from_params()[None, :]
+    for _ in range(10):
+        vega.engine.eval(theta)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vega.engine.eval(theta)
+    dt = (time.perf_counter() - t0) / reps
+    vega.engine.set_profiling(True)
+    for _ in range(5):
+        vega.engine.eval(theta)
+    vega.engine.timings(reset=True)
+    for _ in range(50):
+        vega.engine.eval(theta)
+    kern = {k: round(v[0] / v[1] * 1e3, 2) for k, v in vega.engine.timings().items() if v[1]}
+    vega.close()
+    return {'workload': 'configs[1]: Lya x Lya auto, ell<=4, dense 2500^2 distortion, B=1', 'evals_per_s': 1.0 / dt,
+            'us_per_eval': dt * 1e6, 'kernel_us_per_launch': kern}
+
+
 def cpu_baseline(prob, names, theta, seconds=15.0):
     """The oracle (CPU restatement of the reference) on a bounded sample of the same walkers."""
     from contextlib import nullcontext
@@ -170,12 +197,12 @@ def main():
             eng.sync()      # the engine runs on its own stream
             dist.all_gather_into_tensor(gathered, chi2_dev)
 
-    for i in range(args.warmup):
+    eng.set_profiling(True)         # per-kernel HIP events on the engine stream (first use of an event is slow:
+    for i in range(args.warmup):    # warm them up together with the kernels)
         step(i)
     eng.sync()
     torch.cuda.synchronize()
     eng.timings(reset=True)
-    eng.set_profiling(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -227,6 +254,7 @@ def main():
                         'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TF, 'traffic': None,
                         'algorithmic_flops_per_launch': flops}
         distortion = distortion_microbench(eng, torch)
+        single = single_point_latency(local_rank)
         cpu = None
         if not args.no_cpu_baseline:
             cpu, ref_vals = cpu_baseline(prob, eng.names, host_theta)
@@ -245,7 +273,8 @@ def main():
                        if args.workload == 'joint' else args.workload,
                        'batch_per_gpu': B, 'pipelines_per_eval': len(eng.pipe_index),
                        'collective': 'one all_gather of chi2 per step' if world > 1 else 'none'},
-            'roofline': roofline, 'distortion': distortion, 'cpu_baseline': cpu, 'kernels': kernels,
+            'roofline': roofline, 'distortion': distortion, 'single_point': single, 'cpu_baseline': cpu,
+            'kernels': kernels,
         }
         print(json.dumps(out))
     if world > 1:

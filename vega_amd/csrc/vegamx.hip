@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -195,6 +196,32 @@ static bool pk_stage_compatible(const vmx_pipe_desc& smooth, const vmx_pipe_desc
     return std::memcmp(&a, &b, sizeof(vmx_pipe_desc)) == 0;
 }
 
+// compile-time specialisation of the mu loop that matches a pipeline (PKV_GENERIC when none does)
+static int pk_variant(const vmx_pipe_desc& d, bool paired)
+{
+    const bool rare = d.hcd_model == VMX_HCD_SINC || d.nl_model == VMX_NL_MCDONALD || d.exp_par_slot >= 0 ||
+                      (d.fast_metals && (d.tracer[0].is_lya || d.tracer[1].is_lya) &&
+                       (d.uvb || d.heii || d.hcd_model != VMX_HCD_NONE));
+    if (rare || d.gk_table < 0 || d.vd_kind == VMX_VD_GAUSS) {
+        // a Gaussian velocity dispersion only changes the exponent coefficients: still specialisable
+        if (rare || d.gk_table < 0) return PKV_GENERIC;
+    }
+    const bool rogers = d.hcd_model == VMX_HCD_ROGERS;
+    const bool hcd1 = rogers && d.tracer[0].is_lya, hcd2 = rogers && d.tracer[1].is_lya;
+    const bool arinyo = d.nl_model == VMX_NL_ARINYO;
+    const bool lorentz = d.vd_kind == VMX_VD_LORENTZ;
+    const bool vd1 = lorentz && d.tracer[0].discrete, vd2 = lorentz && d.tracer[1].discrete;
+    if (vd1) return PKV_GENERIC;
+    if (d.same_tracer) {
+        if (hcd1 && arinyo && paired && !vd2) return PKV_AUTO_CORE;
+        if (!hcd1 && !arinyo && !paired && !vd2) return PKV_PLAIN_SAME;
+        return PKV_GENERIC;
+    }
+    if (hcd1 && !hcd2 && arinyo && paired && vd2) return PKV_CROSS_CORE;
+    if (!hcd1 && !hcd2 && !arinyo && !paired) return vd2 ? PKV_PLAIN_PAIR_VD : PKV_PLAIN_PAIR;
+    return PKV_GENERIC;
+}
+
 // D[n][m] = sum_k A[m][k] X[n][k]; returns the number of K slabs written (consumer sums them).
 static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64_t a_batch, int M, int K,
                           const double* X, int ldx, int64_t x_batch, int N, double* D, int ldd,
@@ -347,6 +374,12 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     if (desc->n_smooth < 0 || desc->n_smooth > VMX_MAX_SMOOTH) return fail(-1, "invalid argument: n_smooth");
     PipeDev p{};
     p.d = *desc;
+    // The P(k) stage is symmetric in the two tracers: keep the Lya-like tracer first (and a discrete
+    // tracer last) so that the specialised mu loops see one canonical order.
+    if (!p.d.same_tracer && ((!p.d.tracer[0].is_lya && p.d.tracer[1].is_lya) ||
+                             (p.d.tracer[0].is_lya == p.d.tracer[1].is_lya && p.d.tracer[0].discrete &&
+                              !p.d.tracer[1].discrete)))
+        std::swap(p.d.tracer[0], p.d.tracer[1]);
     p.n = n;
     p.coord_off = (int64_t)e->h_r.size();
     e->h_r.insert(e->h_r.end(), r, r + n);
@@ -606,12 +639,13 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         for (auto* it : e->items) {
             const int ps = it->dev.d.pipe_smooth, pk = it->dev.d.pipe_peak;
             if (ps != pk && !taken[ps] && !taken[pk] && pk_stage_compatible(e->pipes[ps].d, e->pipes[pk].d)) {
-                e->pk_groups.push_back({ps, pk});
+                e->pk_groups.push_back({ps, pk, 0});
                 taken[ps] = taken[pk] = 1;
             }
         }
         for (int p = 0; p < (int)e->pipes.size(); ++p)
-            if (!taken[p]) e->pk_groups.push_back({p, -1});
+            if (!taken[p]) e->pk_groups.push_back({p, -1, 0});
+        for (auto& g : e->pk_groups) g.variant = pk_variant(e->pipes[g.pipe].d, g.peak_partner >= 0);
         if (e->d_pk_groups.upload(e->pk_groups.data(), e->pk_groups.size())) return -2;
     }
 
@@ -843,6 +877,13 @@ int vmx_set_profiling(vmx_engine* e, int32_t enabled)
     HIP_OK(hipStreamSynchronize(e->stream));
     if (e->profiling) collect_spans(e);
     e->profiling = enabled != 0;
+    // create the event pool up front so that no event is created between two launches of a timed run
+    while (e->profiling && e->spans.size() < 96) {
+        vmx_engine::Span s{};
+        HIP_OK(hipEventCreate(&s.a));
+        HIP_OK(hipEventCreate(&s.b));
+        e->spans.push_back(s);
+    }
     return 0;
 }
 

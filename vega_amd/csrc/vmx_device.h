@@ -312,101 +312,119 @@ __device__ __forceinline__ double vmx_rsqrt(double x)
 
 // One work group of the P(k,mu) stage: a pipeline and, when the item's peak component differs from its
 // smooth component only by the peak non-linear broadening (power_spectrum.py:163-164), that peak
-// pipeline as a partner evaluated in the same pass.
-struct PkGroup { int32_t pipe; int32_t peak_partner; };
+// pipeline as a partner evaluated in the same pass.  `variant` selects a compile-time specialisation
+// of the mu loop (0 = generic).
+struct PkGroup { int32_t pipe; int32_t peak_partner; int32_t variant; };
+
+enum { PKV_GENERIC = 0, PKV_AUTO_CORE = 1, PKV_CROSS_CORE = 2, PKV_PLAIN_SAME = 3, PKV_PLAIN_PAIR = 4, PKV_PLAIN_PAIR_VD = 5 };
+// Kaiser-term modes of the specialised loops
+enum { KM_SAME_HCD = 0, KM_SAME_PLAIN = 1, KM_FIRST_HCD = 2, KM_BOTH_PLAIN = 3 };
 
 struct PkThread {
     // per-thread (one wavenumber) constants of the mu loop
-    double k, c0_1, c1_1, c0_2, c1_2, hb, hbb, L0, e0, e1, e2, ar_gv, ar_gp, vd1, vd2, ea, eb, mc_kvel;
+    double k, c0_1, c1_1, c0_2, c1_2, hb, hbb, L0, e0, e1, e2, vd1, vd2, ea, eb, mc_kvel;
     double p0, p1, pq, Fq;
     const double* gk;
     size_t gk_stride;
     bool hcd1, hcd2, div1, div2, same, arinyo, rogers, sinc, has_exp, mcdonald, paired, has_vd1, has_vd2;
 };
 
-// mu loop of one thread.  RARE = false covers the production model set (Kaiser, UV, Rogers HCD, Arinyo,
-// G(k), Gaussian smoothing / peak broadening, Lorentz or Gaussian velocity dispersion); RARE = true adds
-// sinc HCD, McDonald NL, exponential smoothing and the fast-metals division.
-template <int MS, bool RARE>
+// mu loop of one thread: accumulates the even moments  M_n = sum_j mu_j^(2n) P(k, mu_j), n = 0..3, of this
+// pipeline (s) and of its peak partner (q).
+//   SPEC = true : KM / ARINYO / PAIRED / NVD are compile-time (production model set: Kaiser, UV, Rogers HCD,
+//                 Arinyo, G(k), Gaussian smoothing / peak broadening, Lorentz velocity dispersion on tracer 2);
+//   SPEC = false: every switch is read from T at run time; RARE adds sinc HCD, McDonald NL, exponential
+//                 smoothing and the fast-metals division.
+template <int MS, bool SPEC, int KM, bool ARINYO, bool PAIRED, int NVD, bool RARE>
 __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mubv, int ms, int n_mu,
-                                           double inv_nmu, double* s, double* q, bool& bad)
+                                           double inv_nmu, double* s, double* q)
 {
-    const double w2a = 7.5 * inv_nmu, w2b = -2.5 * inv_nmu;
-    const double w4a = 39.375 * inv_nmu, w4b = -33.75 * inv_nmu, w4c = 3.375 * inv_nmu;
-    const double w6a = 187.6875 * inv_nmu, w6b = -255.9375 * inv_nmu, w6c = 85.3125 * inv_nmu, w6d = -4.0625 * inv_nmu;
+    const bool same = SPEC ? (KM == KM_SAME_HCD || KM == KM_SAME_PLAIN) : T.same;
+    const bool hcd1 = SPEC ? (KM == KM_SAME_HCD || KM == KM_FIRST_HCD) : T.hcd1;
+    const bool hcd2 = SPEC ? false : T.hcd2;
+    const bool arinyo = SPEC ? ARINYO : T.arinyo;
+    const bool paired = SPEC ? PAIRED : T.paired;
+    const bool has_vd1 = SPEC ? false : T.has_vd1;
+    const bool has_vd2 = SPEC ? (NVD == 1) : T.has_vd2;
+    const bool rogers = SPEC ? hcd1 : T.rogers;
+
     const double dmu = (double)MS * inv_nmu;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
     const double* gk = T.gk;
+    double g_next = (gk != nullptr) ? *gk : 1.0;
+    double m_next = arinyo ? s_mubv[ms] : 0.0;
 
     for (int j0 = ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
-        // exact anchors of the three geometric progressions along this thread's mu sequence
-        const double mu_a = ((double)j0 + 0.5) * inv_nmu;
+        // exact anchors of the progressions along this thread's mu sequence
+        double mu = ((double)j0 + 0.5) * inv_nmu;
         double F = 0.0, pg = 1.0, pr = 1.0;
-        if (T.rogers) F = vmx_exp(-T.L0 * T.k * mu_a);
-        if (T.paired) {
-            pg = vmx_exp(fma(T.p1, mu_a * mu_a, T.p0));
-            pr = vmx_exp(T.p1 * fma(2.0 * mu_a, dmu, dmu * dmu));
+        if (rogers) F = vmx_exp(-T.L0 * T.k * mu);
+        if (paired) {
+            pg = vmx_exp(fma(T.p1, mu * mu, T.p0));
+            pr = vmx_exp(T.p1 * fma(2.0 * mu, dmu, dmu * dmu));
         }
         int jend = j0 + MS * PK_REANCHOR;
         if (jend > n_mu) jend = n_mu;
         for (int j = j0; j < jend; j += MS) {
-            const double mu = ((double)j + 0.5) * inv_nmu;
             const double mu2 = mu * mu;
-            const double kpar = T.k * mu;
-            if (RARE && T.sinc) { const double x = kpar * T.L0; F = sin(x) / x; }
+            const double g = g_next;
+            const double m = m_next;
+            if (j + MS < n_mu) {            // prefetch the next step's table entries
+                if (gk != nullptr) { gk += T.gk_stride; g_next = *gk; }
+                if (arinyo) m_next = s_mubv[j + MS];
+            }
+            if (!SPEC && RARE && T.sinc) { const double x = T.k * mu * T.L0; F = sin(x) / x; }
 
             // tracer amplitudes b_eff (1 + beta_eff mu^2) = b + b beta mu^2 + F b_hcd (1 + beta_hcd mu^2)
             const double hmu = fma(T.hbb, mu2, T.hb);
             double A1 = fma(T.c1_1, mu2, T.c0_1);
-            if (T.hcd1) A1 = fma(F, hmu, A1);
-            if (RARE && T.div1) A1 /= fma(F, T.hb, T.c0_1);
-            double A2;
-            if (T.same) A2 = A1;
+            if (hcd1) A1 = fma(F, hmu, A1);
+            if (!SPEC && RARE && T.div1) A1 /= fma(F, T.hb, T.c0_1);
+            double AA;
+            if (same) AA = A1 * A1;
             else {
-                A2 = fma(T.c1_2, mu2, T.c0_2);
-                if (T.hcd2) A2 = fma(F, hmu, A2);
-                if (RARE && T.div2) A2 /= fma(F, T.hb, T.c0_2);
+                double A2 = fma(T.c1_2, mu2, T.c0_2);
+                if (hcd2) A2 = fma(F, hmu, A2);
+                if (!SPEC && RARE && T.div2) A2 /= fma(F, T.hb, T.c0_2);
+                AA = A1 * A2;
             }
 
             double E = fma(T.e1, mu2, T.e0);
-            if (T.arinyo) {
-                const double m = s_mubv[j];
-                // VegaArinyoError: NaN or Inf in exp(growth (1 - pec) - pressure) (power_spectrum.py:466-469)
-                if (!(fma(-T.ar_gv, m, T.ar_gp) < 709.0)) bad = true;
-                E = fma(T.e2, m, E);
-            }
-            if (RARE) {
+            if (arinyo) E = fma(T.e2, m, E);
+            if (!SPEC && RARE) {
                 if (T.has_exp) E -= T.k * fma(mu, T.ea, sqrt(1.0 - mu2) * T.eb);
-                if (T.mcdonald) { const double x = kpar / T.mc_kvel; E -= x * sqrt(x); }
+                if (T.mcdonald) { const double x = T.k * mu / T.mc_kvel; E -= x * sqrt(x); }
                 E = fmin(E, 709.0);
             }
 
-            double val = A1 * A2 * vmx_exp(E);
-            if (gk) { val *= *gk; gk += T.gk_stride; }
-            if (T.has_vd1) val *= vmx_rsqrt(fma(kpar * kpar, T.vd1, 1.0));
-            if (T.has_vd2) val *= vmx_rsqrt(fma(kpar * kpar, T.vd2, 1.0));
+            double val = AA * vmx_exp(E) * g;
+            if (has_vd1 || has_vd2) {
+                const double kpar = T.k * mu;
+                const double kp2 = kpar * kpar;
+                if (has_vd1) val *= vmx_rsqrt(fma(kp2, T.vd1, 1.0));
+                if (has_vd2) val *= vmx_rsqrt(fma(kp2, T.vd2, 1.0));
+            }
 
-            const double w2 = fma(w2a, mu2, w2b);
-            const double w4 = fma(fma(w4a, mu2, w4b), mu2, w4c);
-            const double w6 = fma(fma(fma(w6a, mu2, w6b), mu2, w6c), mu2, w6d);
+            const double mu4 = mu2 * mu2, mu6 = mu4 * mu2;
             s0 += val;
-            s1 = fma(w2, val, s1);
-            s2 = fma(w4, val, s2);
-            s3 = fma(w6, val, s3);
-            if (T.paired) {
+            s1 = fma(mu2, val, s1);
+            s2 = fma(mu4, val, s2);
+            s3 = fma(mu6, val, s3);
+            if (paired) {
                 const double vp = val * pg;
                 q0 += vp;
-                q1 = fma(w2, vp, q1);
-                q2 = fma(w4, vp, q2);
-                q3 = fma(w6, vp, q3);
+                q1 = fma(mu2, vp, q1);
+                q2 = fma(mu4, vp, q2);
+                q3 = fma(mu6, vp, q3);
                 pg *= pr;
                 pr *= T.pq;
             }
             F *= T.Fq;
+            mu += dmu;
         }
     }
-    s[0] = s0 * inv_nmu; s[1] = s1; s[2] = s2; s[3] = s3;
-    q[0] = q0 * inv_nmu; q[1] = q1; q[2] = q2; q[3] = q3;
+    s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3;
+    q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
 }
 
 template <int KT, int MS>
@@ -418,6 +436,7 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
 
     const int b = blockIdx.x;
     const int p = groups[blockIdx.y].pipe, pp = groups[blockIdx.y].peak_partner;
+    const int variant = groups[blockIdx.y].variant;
     const vmx_pipe_desc& d = D.pipes[p].d;
     const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
     const int kk = threadIdx.x % KT;
@@ -468,16 +487,21 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     T.vd1 = sc[S_VD1]; T.vd2 = sc[S_VD2];
     T.has_vd1 = T.vd1 != 0.0; T.has_vd2 = T.vd2 != 0.0;
     T.e0 = -k2 * gb; T.e1 = -k2 * (ga - gb); T.e2 = 0.0;
-    T.ar_gv = 0.0; T.ar_gp = 0.0;
+    bool bad = false;
     if (T.arinyo) {
         const double apow = d.arinyo_power;
         const double d2 = D.delta2[ic];
         const double ar_g = sc[S_AQ1] * d2 + sc[S_AQ2] * d2 * d2;
-        T.ar_gv = ar_g * pow(k / sc[S_AKV], sc[S_AAV]);
+        const double ar_gv = ar_g * pow(k / sc[S_AKV], sc[S_AAV]);
         const double kp = k / sc[S_AKP];
-        T.ar_gp = ar_g - kp * kp;
-        T.e0 = fma(apow, T.ar_gp, T.e0);
-        T.e2 = -apow * T.ar_gv;
+        const double ar_gp = ar_g - kp * kp;
+        T.e0 = fma(apow, ar_gp, T.e0);
+        T.e2 = -apow * ar_gv;
+        // VegaArinyoError: NaN or Inf in exp(growth (1 - pec) - pressure) anywhere on the grid
+        // (power_spectrum.py:466-469).  The exponent is monotonic in mu^bv, so its extremes sit at the two
+        // ends of the mu grid.
+        const double lo = fma(-ar_gv, s_mubv[0], ar_gp), hi = fma(-ar_gv, s_mubv[n_mu - 1], ar_gp);
+        if (!(lo < 709.0) || !(hi < 709.0)) bad = true;
     }
     T.mc_kvel = 1.0;
     T.mcdonald = d.nl_model == VMX_NL_MCDONALD;
@@ -502,14 +526,26 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     T.Fq = T.rogers ? vmx_exp(-T.L0 * k * dmu) : 0.0;
 
     double s[4], q[4];
-    bool bad = false;
-    const bool rare = T.sinc || T.has_exp || T.mcdonald || T.div1 || T.div2;
-    if (rare) pk_mu_loop<MS, true>(T, s_mubv, ms, n_mu, inv_nmu, s, q, bad);
-    else pk_mu_loop<MS, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q, bad);
+    switch (variant) {
+        case PKV_AUTO_CORE: pk_mu_loop<MS, true, KM_SAME_HCD, true, true, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_CROSS_CORE: pk_mu_loop<MS, true, KM_FIRST_HCD, true, true, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_PLAIN_SAME: pk_mu_loop<MS, true, KM_SAME_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_PLAIN_PAIR: pk_mu_loop<MS, true, KM_BOTH_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_PLAIN_PAIR_VD: pk_mu_loop<MS, true, KM_BOTH_PLAIN, false, false, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        default:
+            if (T.sinc || T.has_exp || T.mcdonald || T.div1 || T.div2)
+                pk_mu_loop<MS, false, 0, false, false, 0, true>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
+            else
+                pk_mu_loop<MS, false, 0, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
+    }
 
-    for (int e = 0; e < 4; ++e) {
-        s_red[e * 256 + threadIdx.x] = s[e];
-        s_red[(4 + e) * 256 + threadIdx.x] = q[e];
+    // moments -> Legendre multipoles  P_ell = (2 ell + 1) / n_mu * sum_n c_{ell n} M_n  (pktoxi.py:37,55,138)
+    for (int half = 0; half < 2; ++half) {
+        const double* m = half ? q : s;
+        s_red[(half * 4 + 0) * 256 + threadIdx.x] = m[0] * inv_nmu;
+        s_red[(half * 4 + 1) * 256 + threadIdx.x] = (7.5 * m[1] - 2.5 * m[0]) * inv_nmu;
+        s_red[(half * 4 + 2) * 256 + threadIdx.x] = (39.375 * m[2] - 33.75 * m[1] + 3.375 * m[0]) * inv_nmu;
+        s_red[(half * 4 + 3) * 256 + threadIdx.x] = (187.6875 * m[3] - 255.9375 * m[2] + 85.3125 * m[1] - 4.0625 * m[0]) * inv_nmu;
     }
     __syncthreads();
     if (bad && valid) atomicOr(&D.status[b], VMX_STATUS_ARINYO);
