@@ -32,9 +32,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 FP64_VALU_PEAK_TF = 78.6       # MI355X FP64 vector peak (spec; 256 CU x 128 flop/clk x 2.4 GHz)
 FP64_MFMA_PEAK_TF = 78.6       # MI355X FP64 matrix peak (spec)
 
-# Algorithmic flops per P(k,mu) grid point (DESIGN.md section "Flop model"): elementary operations
-# of the reference's formulas, transcendental calls counted once each.
-FLOPS_PER_POINT = {'auto': 58, 'cross': 52}
+# Algorithmic flops per (k, mu) grid point of a paired peak+smooth group:
+# + - x count 1, FMA 2, every transcendental / rsqrt 1.
+FLOPS_PER_POINT = {'auto': 35, 'cross': 43}
 
 
 def build_problem(workload):
@@ -235,7 +235,7 @@ def main():
             flops = 0.0
             for item in prob.items.values():
                 kind = 'auto' if item.tracer1.name == item.tracer2.name else 'cross'
-                flops += 2 * B * nk * n_mu * FLOPS_PER_POINT[kind]       # peak + smooth components
+                flops += B * nk * n_mu * FLOPS_PER_POINT[kind]          # one paired pass per item
             tf = flops / (kernels[dominant]['ms_per_launch'] * 1e-3) / 1e12
             roofline = {'kernel': dominant, 'bound': 'valu-fp64', 'achieved': tf, 'peak': FP64_VALU_PEAK_TF,
                         'unit': 'TFLOP/s', 'frac': tf / FP64_VALU_PEAK_TF, 'traffic': None,
