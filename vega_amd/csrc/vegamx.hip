@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <utility>
 #include <string>
 #include <vector>
@@ -108,8 +109,8 @@ struct vmx_engine {
     double x0[VMX_MAX_ELL] = {0}, h[VMX_MAX_ELL] = {0};
 
     std::vector<PipeDev> pipes;
-    std::vector<double> h_r, h_mu_c, h_z, h_relz, h_growth;
-    DevBuf<double> cr, cmu, cz, crelz, cgrowth;
+    std::vector<double> h_r, h_mu_c, h_z, h_relz, h_lnrelz, h_growth;
+    DevBuf<double> cr, cmu, cz, crelz, clnrelz, cgrowth;
     DevBuf<PipeDev> d_pipes;
     std::vector<PkGroup> pk_groups;
     DevBuf<PkGroup> d_pk_groups;
@@ -136,6 +137,11 @@ struct vmx_engine {
     int last_B = 0;
     EngineDev dev{};
 
+    // host path: pinned staging buffers and one captured graph per batch size
+    double* pin_theta = nullptr; double* pin_chi2 = nullptr; int32_t* pin_status = nullptr;
+    std::map<int, hipGraphExec_t> graphs;
+    bool use_graphs = true;
+
     // profiling
     bool profiling = false;
     struct Span { hipEvent_t a, b; int kc; };
@@ -148,6 +154,10 @@ struct vmx_engine {
         for (auto* it : items) delete it;
         for (auto* m : metals) delete m;
         for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+        if (pin_theta) (void)hipHostFree(pin_theta);
+        if (pin_chi2) (void)hipHostFree(pin_chi2);
+        if (pin_status) (void)hipHostFree(pin_status);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -386,6 +396,7 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     e->h_mu_c.insert(e->h_mu_c.end(), mu, mu + n);
     e->h_z.insert(e->h_z.end(), z, z + n);
     e->h_relz.insert(e->h_relz.end(), rel_z_evol, rel_z_evol + n);
+    for (int i = 0; i < n; ++i) e->h_lnrelz.push_back(std::log(rel_z_evol[i]));
     e->h_growth.insert(e->h_growth.end(), xi_growth, xi_growth + n);
     e->pipes.push_back(p);
     return (int)e->pipes.size() - 1;
@@ -624,6 +635,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     // coordinates and pipelines
     if (e->cr.upload(e->h_r.data(), e->h_r.size()) || e->cmu.upload(e->h_mu_c.data(), e->h_mu_c.size()) ||
         e->cz.upload(e->h_z.data(), e->h_z.size()) || e->crelz.upload(e->h_relz.data(), e->h_relz.size()) ||
+        e->clnrelz.upload(e->h_lnrelz.data(), e->h_lnrelz.size()) ||
         e->cgrowth.upload(e->h_growth.data(), e->h_growth.size())) return -2;
     int64_t xi_off = 0;
     for (auto& p : e->pipes) { p.n_pad = vmx_pad(p.n); p.xi_off = xi_off; xi_off += (int64_t)Bm * p.n_pad; }
@@ -713,7 +725,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
     }
     D.n_pipe = n_pipe; D.pipes = e->d_pipes.p;
-    D.cr = e->cr.p; D.cmu = e->cmu.p; D.cz = e->cz.p; D.crelz = e->crelz.p; D.cgrowth = e->cgrowth.p;
+    D.cr = e->cr.p; D.cmu = e->cmu.p; D.cz = e->cz.p; D.crelz = e->crelz.p; D.clnrelz = e->clnrelz.p; D.cgrowth = e->cgrowth.p;
     D.n_items = (int)e->items.size(); D.items = e->d_items.p;
     D.metals = e->d_metals.p; D.n_metals_total = (int)e->metals.size();
     D.bb_basis = e->bb_basis.p;
@@ -724,6 +736,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p;
     D.model_size = e->model_size;
     D.gcinv = e->gcinv.p; D.g_n = e->g_n; D.g_ld = e->g_ld; D.gres = e->gres.p; D.gz = e->gz.p;
+
+    HIP_OK(hipHostMalloc((void**)&e->pin_theta, (size_t)Bm * n_params * sizeof(double), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&e->pin_chi2, (size_t)Bm * sizeof(double), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&e->pin_status, (size_t)Bm * sizeof(int32_t), hipHostMallocDefault));
 
     HIP_OK(hipStreamSynchronize(e->stream));
     e->finalized = true;
@@ -805,6 +821,33 @@ static int run_chain(vmx_engine* e, int B)
     return 0;
 }
 
+// run the chain for B walkers: replay a captured graph when one exists (or can be captured), else launch eagerly
+static int run_chain_cached(vmx_engine* e, int B)
+{
+    if (!e->use_graphs || e->profiling) return run_chain(e, B);
+    auto it = e->graphs.find(B);
+    if (it == e->graphs.end()) {
+        if (e->graphs.size() >= 64) return run_chain(e, B);
+        hipGraph_t graph = nullptr;
+        HIP_OK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = run_chain(e, B);
+        hipError_t err = hipStreamEndCapture(e->stream, &graph);
+        if (rc || err != hipSuccess || graph == nullptr) {
+            if (graph) (void)hipGraphDestroy(graph);
+            e->use_graphs = false;      // capture is not available: stay on eager launches
+            return run_chain(e, B);
+        }
+        hipGraphExec_t exec = nullptr;
+        err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (err != hipSuccess) { e->use_graphs = false; return run_chain(e, B); }
+        it = e->graphs.emplace(B, exec).first;
+    }
+    HIP_OK(hipGraphLaunch(it->second, e->stream));
+    e->last_B = B;
+    return 0;
+}
+
 int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2, double* d_model,
                     int32_t* d_status)
 {
@@ -812,7 +855,7 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    if (run_chain(e, B)) return -2;
+    if (run_chain_cached(e, B)) return -2;
     if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
     if (d_model) HIP_OK(hipMemcpyAsync(d_model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
@@ -833,12 +876,16 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     REQUIRE(e && e->finalized && theta, "vmx_eval");
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
-    HIP_OK(hipMemcpyAsync(e->theta.p, theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    if (run_chain(e, B)) return -2;
-    if (chi2) HIP_OK(hipMemcpyAsync(chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    if (status) HIP_OK(hipMemcpyAsync(status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    std::memcpy(e->pin_theta, theta, (size_t)B * e->n_params * sizeof(double));
+    HIP_OK(hipMemcpyAsync(e->theta.p, e->pin_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    if (run_chain_cached(e, B)) return -2;
+    if (chi2) HIP_OK(hipMemcpyAsync(e->pin_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (status) HIP_OK(hipMemcpyAsync(e->pin_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (model) HIP_OK(hipMemcpyAsync(model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    return vmx_sync(e);
+    if (vmx_sync(e)) return -2;
+    if (chi2) std::memcpy(chi2, e->pin_chi2, (size_t)B * sizeof(double));
+    if (status) std::memcpy(status, e->pin_status, (size_t)B * sizeof(int32_t));
+    return 0;
 }
 
 int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, int64_t capacity)

@@ -94,7 +94,7 @@ struct EngineDev {
     // pipelines
     int32_t n_pipe;
     const PipeDev* pipes;
-    const double* cr; const double* cmu; const double* cz; const double* crelz; const double* cgrowth;
+    const double* cr; const double* cmu; const double* cz; const double* crelz; const double* clnrelz; const double* cgrowth;
     // items
     int32_t n_items;
     const ItemDev* items;
@@ -525,7 +525,14 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     // F = exp(-L0 k mu_j) along this thread's mu sequence is a geometric progression
     T.Fq = T.rogers ? vmx_exp(-T.L0 * k * dmu) : 0.0;
 
-    double s[4], q[4];
+    // Wavenumbers whose every (k, mu) value underflows the double range of the multipole sums contribute
+    // exactly nothing: bound the exponent over mu in (0, 1] (mu^2 and mu^bv lie in (0, 1]) and skip the mu loop
+    // when a whole wave is past that bound.  exp(-200) ~ 1e-87 leaves > 60 decades of margin for the amplitudes.
+    double e_max = T.e0 + fmax(T.e1, 0.0) + fmax(T.e2, 0.0);
+    if (T.paired) e_max += fmax(T.p0 + fmax(T.p1, 0.0), 0.0);
+    const bool live = !(e_max < -200.0);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (__ballot(live) != 0ull)
     switch (variant) {
         case PKV_AUTO_CORE: pk_mu_loop<MS, true, KM_SAME_HCD, true, true, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
         case PKV_CROSS_CORE: pk_mu_loop<MS, true, KM_FIRST_HCD, true, true, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
@@ -778,14 +785,19 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
     }
 
     // bias evolution (correlation_func.py:276-370) and growth (:143)
-    const double relz = D.crelz[c];
-    double ev = 1.0;
-    for (int q = 0; q < 2; ++q) {
-        const double a = sc[q == 0 ? S_EV1A : S_EV2A], cc = sc[q == 0 ? S_EV1B : S_EV2B];
-        if (d.tracer[q].evol_kind == VMX_EVOL_CROOM) {
-            const double z1 = 1.0 + D.cz[c], ze = 1.0 + d.z_eff;
-            ev *= (a + cc * z1 * z1) / (a + cc * ze * ze);
-        } else ev *= pow(relz, a);
+    double ev;
+    if (d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD) {
+        // relz^a1 * relz^a2 = exp((a1 + a2) ln relz), ln relz tabulated at upload
+        ev = vmx_exp((sc[S_EV1A] + sc[S_EV2A]) * D.clnrelz[c]);
+    } else {
+        ev = 1.0;
+        for (int q = 0; q < 2; ++q) {
+            const double a = sc[q == 0 ? S_EV1A : S_EV2A], cc = sc[q == 0 ? S_EV1B : S_EV2B];
+            if (d.tracer[q].evol_kind == VMX_EVOL_CROOM) {
+                const double z1 = 1.0 + D.cz[c], ze = 1.0 + d.z_eff;
+                ev *= (a + cc * z1 * z1) / (a + cc * ze * ze);
+            } else ev *= pow(D.crelz[c], a);
+        }
     }
     xi *= ev;
     xi *= D.cgrowth[c];
