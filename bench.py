@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--workload', default='joint', choices=['joint', 'auto', 'joint_metals'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='run the collective path even with one rank')
     args = ap.parse_args()
 
     import torch
@@ -162,14 +163,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the vegamx engine has no CPU fallback')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from vega_amd import VegaInterface, synthetic
 
@@ -189,11 +192,11 @@ def main():
             host_theta = th
         pools.append(torch.from_numpy(th).to(dev))
     chi2_dev = torch.zeros(B, dtype=torch.float64, device=dev)
-    gathered = torch.zeros(world * B, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros(world * B, dtype=torch.float64, device=dev) if use_dist else None
 
     def step(i):
         eng.eval_device(pools[i % n_pool].data_ptr(), B, chi2_dev.data_ptr())
-        if world > 1:
+        if use_dist:
             eng.sync()      # the engine runs on its own stream
             dist.all_gather_into_tensor(gathered, chi2_dev)
 
@@ -203,7 +206,7 @@ def main():
     eng.sync()
     torch.cuda.synchronize()
     eng.timings(reset=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -211,14 +214,14 @@ def main():
         step(i)
     eng.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
     timings = eng.timings(reset=True)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -272,12 +275,12 @@ def main():
                                    '1590^2 + 3180^2 inverse covariances (BASELINE configs[2])'
                        if args.workload == 'joint' else args.workload,
                        'batch_per_gpu': B, 'pipelines_per_eval': len(eng.pipe_index),
-                       'collective': 'one all_gather of chi2 per step' if world > 1 else 'none'},
+                       'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
             'roofline': roofline, 'distortion': distortion, 'single_point': single, 'cpu_baseline': cpu,
             'kernels': kernels,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     vega.close()
