@@ -99,7 +99,7 @@ struct vmx_engine {
     bool finalized = false;
 
     int nk = 0, nkp = 0, n_mu = 0;
-    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, wl, gk;
+    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, wl, gk, gk_mom;
     std::vector<std::pair<double, double>> gk_tables;
     std::vector<double> h_k, h_mu;
 
@@ -114,6 +114,8 @@ struct vmx_engine {
     DevBuf<PipeDev> d_pipes;
     std::vector<PkGroup> pk_groups;
     DevBuf<PkGroup> d_pk_groups;
+    std::vector<int32_t> pk_members, pk_poly;
+    DevBuf<int32_t> d_pk_members, d_pk_poly;
 
     std::vector<ItemHost*> items;
     std::vector<MetalHost*> metals;
@@ -206,22 +208,44 @@ static bool pk_stage_compatible(const vmx_pipe_desc& smooth, const vmx_pipe_desc
     return std::memcmp(&a, &b, sizeof(vmx_pipe_desc)) == 0;
 }
 
+// true when two pipelines without amplitude-dependent mu structure share the factor W(k, mu) (G table, Gaussian
+// exponent, velocity dispersion): they may differ in the tracers' bias / beta, the linear spectrum and the xi stage
+static bool w_stage_compatible(const vmx_pipe_desc& a, const vmx_pipe_desc& b)
+{
+    if (a.gk_table != b.gk_table || a.is_peak != b.is_peak || a.peak_nl != b.peak_nl) return false;
+    if (a.peak_nl && (a.sigma_nl_par_slot != b.sigma_nl_par_slot || a.sigma_nl_per_slot != b.sigma_nl_per_slot ||
+                      a.growth_rate_slot != b.growth_rate_slot || a.growth_rate_default != b.growth_rate_default))
+        return false;
+    if (a.n_smooth != b.n_smooth || a.exp_par_slot != b.exp_par_slot || a.exp_per_slot != b.exp_per_slot) return false;
+    for (int i = 0; i < a.n_smooth; ++i)
+        if (a.smooth_par_slot[i] != b.smooth_par_slot[i] || a.smooth_per_slot[i] != b.smooth_per_slot[i] ||
+            a.smooth_weight[i] != b.smooth_weight[i]) return false;
+    if (a.vd_kind != b.vd_kind) return false;
+    for (int q = 0; q < 2; ++q)
+        if (a.vd_kind != VMX_VD_NONE && (a.tracer[q].discrete != b.tracer[q].discrete ||
+                                         (a.tracer[q].discrete && a.tracer[q].vd_sigma_slot != b.tracer[q].vd_sigma_slot)))
+            return false;
+    return a.hcd_model == VMX_HCD_NONE && b.hcd_model == VMX_HCD_NONE && a.nl_model == VMX_NL_NONE &&
+           b.nl_model == VMX_NL_NONE;
+}
+
 // compile-time specialisation of the mu loop that matches a pipeline (PKV_GENERIC when none does)
 static int pk_variant(const vmx_pipe_desc& d, bool paired)
 {
     const bool rare = d.hcd_model == VMX_HCD_SINC || d.nl_model == VMX_NL_MCDONALD || d.exp_par_slot >= 0 ||
                       (d.fast_metals && (d.tracer[0].is_lya || d.tracer[1].is_lya) &&
                        (d.uvb || d.heii || d.hcd_model != VMX_HCD_NONE));
-    if (rare || d.gk_table < 0 || d.vd_kind == VMX_VD_GAUSS) {
-        // a Gaussian velocity dispersion only changes the exponent coefficients: still specialisable
-        if (rare || d.gk_table < 0) return PKV_GENERIC;
-    }
+    if (rare) return PKV_GENERIC;
+    // no mu-dependent factor besides the Kaiser polynomial and the static G table: closed form in the moments
+    if (!rare && !paired && !d.is_peak && !d.peak_nl && d.hcd_model == VMX_HCD_NONE && d.nl_model == VMX_NL_NONE &&
+        d.n_smooth == 0 && d.exp_par_slot < 0 && d.vd_kind == VMX_VD_NONE)
+        return PKV_POLY;
     const bool rogers = d.hcd_model == VMX_HCD_ROGERS;
     const bool hcd1 = rogers && d.tracer[0].is_lya, hcd2 = rogers && d.tracer[1].is_lya;
     const bool arinyo = d.nl_model == VMX_NL_ARINYO;
     const bool lorentz = d.vd_kind == VMX_VD_LORENTZ;
     const bool vd1 = lorentz && d.tracer[0].discrete, vd2 = lorentz && d.tracer[1].discrete;
-    if (vd1) return PKV_GENERIC;
+    if (vd1 || d.gk_table < 0) return PKV_GENERIC;
     if (d.same_tracer) {
         if (hcd1 && arinyo && paired && !vd2) return PKV_AUTO_CORE;
         if (!hcd1 && !arinyo && !paired && !vd2) return PKV_PLAIN_SAME;
@@ -243,6 +267,18 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
     g.D = D; g.ldd = ldd; g.d_batch = d_batch;
     g.M = M; g.N = N; g.K = K;
     ScopedTimer timer(e, kc);
+    if (N == 1 && K <= 5120 && (size_t)K * sizeof(double) <= 48 * 1024) {
+        // persistent streaming kernel: 2 blocks per CU, rows strided over blocks
+        g.nsplit = 1; g.klen = K; g.d_slab = 0;
+        int blocks = 512;
+        while ((M + blocks - 1) / blocks > GEMV1_MAX_ROWS) blocks *= 2;
+        if (blocks > M) blocks = M;
+        dim3 grid(blocks, 1, nbatch), block(256);
+        const size_t shmem = (size_t)K * sizeof(double);
+        if (K <= 2560) hipLaunchKernelGGL(k_gemv1<5>, grid, block, shmem, e->stream, g);
+        else hipLaunchKernelGGL(k_gemv1<10>, grid, block, shmem, e->stream, g);
+        return 1;
+    }
     if (N <= 8) {
         g.nsplit = 1; g.klen = K; g.d_slab = 0;
         dim3 grid((M + 3) / 4, 1, nbatch), block(256);
@@ -255,8 +291,9 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
         return 1;
     }
     const int tm = (M + GEMM_BM - 1) / GEMM_BM, tn = (N + GEMM_BN - 1) / GEMM_BN;
-    int nsplit = 1;
     const int tiles = tm * tn * nbatch;
+    // split K until at least 512 blocks exist (2 per CU); partial sums go to separate slabs
+    int nsplit = 1;
     if (tiles < 512) nsplit = (512 + tiles - 1) / tiles;
     if (nsplit > 8) nsplit = 8;
     while (nsplit > 1 && (int64_t)nsplit * N > slab_rows_avail) --nsplit;
@@ -631,6 +668,15 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         }
         HIP_OK(hipGetLastError());
     }
+    {
+        const size_t nt = e->gk_tables.size();
+        if (e->gk_mom.alloc((nt + 1) * 6 * (size_t)e->nkp, true)) return -2;
+        for (size_t t = 0; t <= nt; ++t)
+            hipLaunchKernelGGL(k_gk_moments, dim3((e->nkp + 63) / 64), dim3(64), 0, e->stream,
+                               e->gk_mom.p + t * 6 * (size_t)e->nkp, t < nt ? e->gk.p + t * gk_stride : nullptr,
+                               e->mu.p, e->nkp, e->n_mu);
+        HIP_OK(hipGetLastError());
+    }
 
     // coordinates and pipelines
     if (e->cr.upload(e->h_r.data(), e->h_r.size()) || e->cmu.upload(e->h_mu_c.data(), e->h_mu_c.size()) ||
@@ -651,13 +697,38 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         for (auto* it : e->items) {
             const int ps = it->dev.d.pipe_smooth, pk = it->dev.d.pipe_peak;
             if (ps != pk && !taken[ps] && !taken[pk] && pk_stage_compatible(e->pipes[ps].d, e->pipes[pk].d)) {
-                e->pk_groups.push_back({ps, pk, 0});
+                e->pk_groups.push_back({ps, pk, 0, 0, 0});
                 taken[ps] = taken[pk] = 1;
             }
         }
-        for (int p = 0; p < (int)e->pipes.size(); ++p)
-            if (!taken[p]) e->pk_groups.push_back({p, -1, 0});
-        for (auto& g : e->pk_groups) g.variant = pk_variant(e->pipes[g.pipe].d, g.peak_partner >= 0);
+        // unpaired pipelines: those without any amplitude-dependent mu structure (no HCD / UV-in-the-loop / NL)
+        // that share the amplitude-free factor W are evaluated by one mu loop per shared-W group
+        e->pk_members.clear();
+        e->pk_poly.clear();
+        for (int p = 0; p < (int)e->pipes.size(); ++p) {
+            if (taken[p]) continue;
+            const int variant = pk_variant(e->pipes[p].d, false);
+            const bool plain = variant == PKV_PLAIN_SAME || variant == PKV_PLAIN_PAIR || variant == PKV_PLAIN_PAIR_VD;
+            if (variant == PKV_POLY) { e->pk_poly.push_back(p); taken[p] = 1; continue; }
+            if (!plain) { e->pk_groups.push_back({p, -1, variant, 0, 0}); taken[p] = 1; continue; }
+            PkGroup g{p, -1, PKV_SHARED_W, 0, (int32_t)e->pk_members.size()};
+            for (int q = p; q < (int)e->pipes.size(); ++q) {
+                if (taken[q]) continue;
+                const int vq = pk_variant(e->pipes[q].d, false);
+                const bool plain_q = vq == PKV_PLAIN_SAME || vq == PKV_PLAIN_PAIR || vq == PKV_PLAIN_PAIR_VD;
+                if (plain_q && w_stage_compatible(e->pipes[p].d, e->pipes[q].d)) {
+                    e->pk_members.push_back(q); taken[q] = 1; ++g.n_members;
+                }
+            }
+            e->pk_groups.push_back(g);
+        }
+        for (auto& g : e->pk_groups)
+            if (g.peak_partner >= 0) g.variant = pk_variant(e->pipes[g.pipe].d, true);
+        e->pk_members.push_back(-1);
+        if (e->d_pk_members.upload(e->pk_members.data(), e->pk_members.size())) return -2;
+        e->pk_poly.push_back(-1);
+        if (e->d_pk_poly.upload(e->pk_poly.data(), e->pk_poly.size())) return -2;
+        e->pk_poly.pop_back();
         if (e->d_pk_groups.upload(e->pk_groups.data(), e->pk_groups.size())) return -2;
     }
 
@@ -719,7 +790,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
     D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p;
-    D.wl = e->wl.p; D.gk = e->gk.p;
+    D.wl = e->wl.p; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp;
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
@@ -761,12 +832,15 @@ static int run_chain(vmx_engine* e, int B)
         ScopedTimer t(e, KC_PK);
         const size_t shmem = ((size_t)e->n_mu + 2048) * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
-        if ((int64_t)B * n_groups >= 24)
+        if (!e->pk_poly.empty())
+            hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
+        if (n_groups == 0) {}
+        else if ((int64_t)B * n_groups >= 24)
             hipLaunchKernelGGL((k_pk_multipoles<64, 4>), dim3(B, n_groups, (e->nk + 63) / 64), dim3(256), shmem, e->stream, D,
-                               e->d_pk_groups.p);
+                               e->d_pk_groups.p, e->d_pk_members.p);
         else
             hipLaunchKernelGGL((k_pk_multipoles<16, 16>), dim3(B, n_groups, (e->nk + 15) / 16), dim3(256), shmem, e->stream, D,
-                               e->d_pk_groups.p);
+                               e->d_pk_groups.p, e->d_pk_members.p);
     }
     {
         const int64_t ncols = (int64_t)B * n_pipe;
@@ -834,13 +908,20 @@ static int run_chain_cached(vmx_engine* e, int B)
         hipError_t err = hipStreamEndCapture(e->stream, &graph);
         if (rc || err != hipSuccess || graph == nullptr) {
             if (graph) (void)hipGraphDestroy(graph);
+            std::fprintf(stderr, "[vegamx] stream capture failed (%s): falling back to eager launches\n",
+                         err != hipSuccess ? hipGetErrorString(err) : "launch error");
+            (void)hipGetLastError();
             e->use_graphs = false;      // capture is not available: stay on eager launches
             return run_chain(e, B);
         }
         hipGraphExec_t exec = nullptr;
         err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
-        if (err != hipSuccess) { e->use_graphs = false; return run_chain(e, B); }
+        if (err != hipSuccess) {
+            std::fprintf(stderr, "[vegamx] graph instantiation failed (%s): falling back to eager launches\n", hipGetErrorString(err));
+            e->use_graphs = false;
+            return run_chain(e, B);
+        }
         it = e->graphs.emplace(B, exec).first;
     }
     HIP_OK(hipGraphLaunch(it->second, e->stream));

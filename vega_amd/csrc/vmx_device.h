@@ -88,6 +88,8 @@ struct EngineDev {
     const double* sq1mmu2;      // [n_mu] sqrt(1 - mu^2)
     const double* wl;           // [4][n_mu] L_ell(mu) (2 ell + 1) / n_mu
     const double* gk;           // [tables][n_mu][nkp]
+    const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
+    int32_t n_gk;
     // fftlog / spline
     int32_t n_coef, ncp;        // coefficients per ell, padded
     double x0[VMX_MAX_ELL], h[VMX_MAX_ELL], xlast[VMX_MAX_ELL];
@@ -258,6 +260,20 @@ __global__ void k_gk_table(double* out, const double* k, const double* mu, int n
     out[(size_t)j * nkp + i] = g;
 }
 
+// even mu-moments of a G(k, mu) table (or of 1 when table == nullptr): out[n][i] = sum_j mu_j^(2n) G[j][i]
+__global__ void k_gk_moments(double* out, const double* table, const double* mu, int nkp, int n_mu)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nkp) return;
+    double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < n_mu; ++j) {
+        const double mu2 = mu[j] * mu[j];
+        double v = table ? table[(size_t)j * nkp + i] : 1.0;
+        for (int n = 0; n < 6; ++n) { m[n] += v; v *= mu2; }
+    }
+    for (int n = 0; n < 6; ++n) out[(size_t)n * nkp + i] = m[n];
+}
+
 // ------------------------------------------------------------------------------------------------
 // P(k, mu) evaluation fused with the Legendre projection
 //   block = KT wavenumbers x MS mu-slices (KT * MS = 256); grid = (walkers, pipelines, k tiles):
@@ -314,9 +330,10 @@ __device__ __forceinline__ double vmx_rsqrt(double x)
 // smooth component only by the peak non-linear broadening (power_spectrum.py:163-164), that peak
 // pipeline as a partner evaluated in the same pass.  `variant` selects a compile-time specialisation
 // of the mu loop (0 = generic).
-struct PkGroup { int32_t pipe; int32_t peak_partner; int32_t variant; };
+struct PkGroup { int32_t pipe; int32_t peak_partner; int32_t variant; int32_t n_members; int32_t member_off; };
 
-enum { PKV_GENERIC = 0, PKV_AUTO_CORE = 1, PKV_CROSS_CORE = 2, PKV_PLAIN_SAME = 3, PKV_PLAIN_PAIR = 4, PKV_PLAIN_PAIR_VD = 5 };
+enum { PKV_GENERIC = 0, PKV_AUTO_CORE = 1, PKV_CROSS_CORE = 2, PKV_PLAIN_SAME = 3, PKV_PLAIN_PAIR = 4, PKV_PLAIN_PAIR_VD = 5,
+       PKV_POLY = 6, PKV_SHARED_W = 7 };
 // Kaiser-term modes of the specialised loops
 enum { KM_SAME_HCD = 0, KM_SAME_PLAIN = 1, KM_FIRST_HCD = 2, KM_BOTH_PLAIN = 3 };
 
@@ -326,7 +343,7 @@ struct PkThread {
     double p0, p1, pq, Fq;
     const double* gk;
     size_t gk_stride;
-    bool hcd1, hcd2, div1, div2, same, arinyo, rogers, sinc, has_exp, mcdonald, paired, has_vd1, has_vd2;
+    bool hcd1, hcd2, div1, div2, same, arinyo, rogers, sinc, has_exp, mcdonald, paired, has_vd1, has_vd2, noexp;
 };
 
 // mu loop of one thread: accumulates the even moments  M_n = sum_j mu_j^(2n) P(k, mu_j), n = 0..3, of this
@@ -427,8 +444,45 @@ __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mu
     q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
 }
 
+// mu loop of a shared-W group: six even moments of the amplitude-free factor
+//   W(k, mu) = G(k, mu) exp(e0 + e1 mu^2) / sqrt((1 + (k mu s1)^2)(1 + (k mu s2)^2)),
+// from which every member pipeline P = P_lin (c0_1 + c1_1 mu^2)(c0_2 + c1_2 mu^2) W forms its own moments.
+template <int MS>
+__device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, double inv_nmu, double* wm)
+{
+    const double dmu = (double)MS * inv_nmu;
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
+    const double* gk = T.gk;
+    double g_next = (gk != nullptr) ? *gk : 1.0;
+    double mu = ((double)ms + 0.5) * inv_nmu;
+    for (int j = ms; j < n_mu; j += MS) {
+        const double mu2 = mu * mu;
+        const double g = g_next;
+        if (j + MS < n_mu && gk != nullptr) { gk += T.gk_stride; g_next = *gk; }
+        double val = g;
+        if (!T.noexp) val *= vmx_exp(fma(T.e1, mu2, T.e0));
+        if (T.has_vd1 || T.has_vd2) {
+            const double kpar = T.k * mu;
+            const double kp2 = kpar * kpar;
+            if (T.has_vd1) val *= vmx_rsqrt(fma(kp2, T.vd1, 1.0));
+            if (T.has_vd2) val *= vmx_rsqrt(fma(kp2, T.vd2, 1.0));
+        }
+        const double mu4 = mu2 * mu2;
+        m0 += val;
+        m1 = fma(mu2, val, m1);
+        m2 = fma(mu4, val, m2);
+        const double v6 = val * (mu4 * mu2);
+        m3 += v6;
+        m4 = fma(mu2, v6, m4);
+        m5 = fma(mu4, v6, m5);
+        mu = ((double)(j + MS) + 0.5) * inv_nmu;
+    }
+    (void)dmu;
+    wm[0] = m0; wm[1] = m1; wm[2] = m2; wm[3] = m3; wm[4] = m4; wm[5] = m5;
+}
+
 template <int KT, int MS>
-__global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGroup* groups)
+__global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGroup* groups, const int32_t* members)
 {
     extern __shared__ double smem[];
     double* s_mubv = smem;                        // [n_mu]   mu^bv (Arinyo)
@@ -487,6 +541,7 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     T.vd1 = sc[S_VD1]; T.vd2 = sc[S_VD2];
     T.has_vd1 = T.vd1 != 0.0; T.has_vd2 = T.vd2 != 0.0;
     T.e0 = -k2 * gb; T.e1 = -k2 * (ga - gb); T.e2 = 0.0;
+    T.noexp = (ga == 0.0) && (gb == 0.0);
     bool bad = false;
     if (T.arinyo) {
         const double apow = d.arinyo_power;
@@ -532,6 +587,51 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     if (T.paired) e_max += fmax(T.p0 + fmax(T.p1, 0.0), 0.0);
     const bool live = !(e_max < -200.0);
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (variant == PKV_SHARED_W) {
+        // one mu loop for all member pipelines (e.g. QSO x each metal line): they share W and differ only in
+        // the Kaiser polynomials
+        double wm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (__ballot(live) != 0ull) pk_w_loop<MS>(T, ms, n_mu, inv_nmu, wm);
+        for (int n = 0; n < 6; ++n) s_red[n * 256 + threadIdx.x] = wm[n];
+        __syncthreads();
+        if (threadIdx.x < KT && valid) {
+            for (int n = 0; n < 6; ++n) {
+                double sum = 0.0;
+                for (int qq = 0; qq < MS; ++qq) sum += s_red[n * 256 + qq * KT + kk];
+                wm[n] = sum;
+            }
+            const PkGroup& G = groups[blockIdx.y];
+            const size_t ncols = (size_t)gridDim.x * D.n_pipe;
+            for (int mi = 0; mi < G.n_members; ++mi) {
+                const int pm = members[G.member_off + mi];
+                const vmx_pipe_desc& dm = D.pipes[pm].d;
+                const double* scm = D.scal + ((size_t)b * D.n_pipe + pm) * VMX_NS;
+                double c01 = scm[S_BIAS1], c02 = scm[S_BIAS2];
+                const double c11 = scm[S_BB1], c12 = scm[S_BB2];
+                if (dm.uvb || dm.heii) {
+                    double add = 0.0;
+                    if (dm.uvb) { const double x = k * scm[S_UV_LAM]; const double W = atan(x) / x; add += scm[S_UV_BG] * W / (1.0 + scm[S_UV_BP] * W); }
+                    if (dm.heii) { const double x = k * scm[S_HE_LAM]; const double W = atan(x) / x; add += scm[S_HE_BG] * W / (1.0 + scm[S_UV_BP] * W); }
+                    if (dm.tracer[0].is_lya) c01 += add;
+                    if (dm.tracer[1].is_lya) c02 += add;
+                }
+                if (dm.same_tracer) c02 = c01;
+                const double c12e = dm.same_tracer ? c11 : c12;
+                const double a0 = c01 * c02, a1 = fma(c01, c12e, c11 * c02), a2 = c11 * c12e;
+                double mm[4];
+                for (int m = 0; m < 4; ++m) mm[m] = fma(a2, wm[m + 2], fma(a1, wm[m + 1], a0 * wm[m]));
+                double damp = 1.0;
+                if (dm.damping_scale > 0.0) damp = exp(-dm.damping_scale * dm.damping_scale * pow(k, (double)dm.damping_power) / 2.0);
+                const double pk = damp * D.pklin[(size_t)dm.pk_lin_kind * D.nkp + i] * inv_nmu;
+                const size_t col = (size_t)b * D.n_pipe + pm;
+                D.pl[((size_t)0 * ncols + col) * D.nkp + i] = pk * mm[0];
+                D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
+                D.pl[((size_t)2 * ncols + col) * D.nkp + i] = pk * (39.375 * mm[2] - 33.75 * mm[1] + 3.375 * mm[0]);
+                D.pl[((size_t)3 * ncols + col) * D.nkp + i] = pk * (187.6875 * mm[3] - 255.9375 * mm[2] + 85.3125 * mm[1] - 4.0625 * mm[0]);
+            }
+        }
+        return;
+    }
     if (__ballot(live) != 0ull)
     switch (variant) {
         case PKV_AUTO_CORE: pk_mu_loop<MS, true, KM_SAME_HCD, true, true, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
@@ -571,6 +671,44 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
                 D.pl[((size_t)e * ncols + col) * D.nkp + i] = pk * sum;
             }
         }
+    }
+}
+
+// Pipelines whose only mu dependence is the Kaiser polynomial times the static G table (metal pairs without
+// HCD / NL / smoothing / velocity dispersion): P(k,mu) = P_lin(k) (c0_1 + c1_1 mu^2)(c0_2 + c1_2 mu^2) G(k,mu), so
+// the mu-moments are combinations of the table's own moments - no mu loop.  grid = (walkers, poly pipelines).
+__global__ __launch_bounds__(256) void k_pk_poly(EngineDev D, const int32_t* poly_pipes, int B)
+{
+    const int b = blockIdx.x, p = poly_pipes[blockIdx.y];
+    const vmx_pipe_desc& d = D.pipes[p].d;
+    const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+    const double inv_nmu = 1.0 / (double)D.n_mu;
+    const size_t ncols = (size_t)B * D.n_pipe, col = (size_t)b * D.n_pipe + p;
+    const double* mg0 = D.gk_mom + (size_t)(d.gk_table >= 0 ? d.gk_table : D.n_gk) * 6 * D.nkp;
+    for (int i = threadIdx.x; i < D.nk; i += 256) {
+        const double k = D.k[i];
+        double c01 = sc[S_BIAS1], c02 = sc[S_BIAS2];
+        const double c11 = sc[S_BB1], c12 = d.same_tracer ? sc[S_BB1] : sc[S_BB2];
+        if (d.uvb || d.heii) {
+            double add = 0.0;
+            if (d.uvb) { const double x = k * sc[S_UV_LAM]; const double W = atan(x) / x; add += sc[S_UV_BG] * W / (1.0 + sc[S_UV_BP] * W); }
+            if (d.heii) { const double x = k * sc[S_HE_LAM]; const double W = atan(x) / x; add += sc[S_HE_BG] * W / (1.0 + sc[S_UV_BP] * W); }
+            if (d.tracer[0].is_lya) c01 += add;
+            if (d.tracer[1].is_lya) c02 += add;
+        }
+        if (d.same_tracer) c02 = c01;
+        const double a0 = c01 * c02, a1 = fma(c01, c12, c11 * c02), a2 = c11 * c12;
+        const double* mg = mg0 + i;
+        double mm[4];
+        for (int m = 0; m < 4; ++m)
+            mm[m] = fma(a2, mg[(size_t)(m + 2) * D.nkp], fma(a1, mg[(size_t)(m + 1) * D.nkp], a0 * mg[(size_t)m * D.nkp]));
+        double damp = 1.0;
+        if (d.damping_scale > 0.0) damp = exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
+        const double pk = damp * D.pklin[(size_t)d.pk_lin_kind * D.nkp + i] * inv_nmu;
+        D.pl[((size_t)0 * ncols + col) * D.nkp + i] = pk * mm[0];
+        D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
+        D.pl[((size_t)2 * ncols + col) * D.nkp + i] = pk * (39.375 * mm[2] - 33.75 * mm[1] + 3.375 * mm[0]);
+        D.pl[((size_t)3 * ncols + col) * D.nkp + i] = pk * (187.6875 * mm[3] - 255.9375 * mm[2] + 85.3125 * mm[1] - 4.0625 * mm[0]);
     }
 }
 
@@ -721,6 +859,65 @@ __global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
         double v = acc[b];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0 && b < g.N) Dp[(size_t)b * g.ldd + row] = v;
+    }
+}
+
+// Single-walker product y = A x, the HBM-bound case (B = 1: one chi2 evaluation inside a minimiser).
+//   Persistent blocks (2 per CU): x is staged once per block in LDS; a block owns rows blockIdx.x + t gridDim.x
+//   and its four waves split every row into interleaved 1 KiB chunks, so each wave keeps CPW x 16 B per lane in
+//   flight per row and the next row is requested before the current one is reduced.  Partial sums of the four
+//   waves meet in LDS once at the end (fixed order: bitwise reproducible).
+#define GEMV1_MAX_ROWS 24
+template <int CPW>
+__global__ __launch_bounds__(256) void k_gemv1(GemmArgs g)
+{
+    extern __shared__ double sx[];                 // [K]
+    __shared__ double part[GEMV1_MAX_ROWS][4];
+    const int batch = blockIdx.z;
+    const double* A = g.A + batch * g.a_batch;
+    const double* X = g.X + batch * g.x_batch;
+    double* Dp = g.D + batch * g.d_batch;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    int koff[CPW];
+    bool kval[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) { koff[c] = (w + 4 * c) * 128 + lane * 2; kval[c] = koff[c] < g.K; if (!kval[c]) koff[c] = 0; }
+
+    // request the first row of the matrix stream before staging x, so both latencies overlap
+    v2d cur[CPW], nxt[CPW];
+    int row = blockIdx.x;
+    if (row < g.M) {
+        const double* a = A + (size_t)row * g.lda;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) cur[c] = __builtin_nontemporal_load((const v2d*)(a + koff[c]));
+    }
+    for (int k = tid * 2; k < g.K; k += 512) *(v2d*)&sx[k] = *(const v2d*)(X + k);
+    __syncthreads();
+    int t = 0;
+    for (; row < g.M; row += gridDim.x, ++t) {
+        const int next = row + gridDim.x;
+        if (next < g.M) {
+            const double* a = A + (size_t)next * g.lda;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) nxt[c] = __builtin_nontemporal_load((const v2d*)(a + koff[c]));
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const v2d x = *(const v2d*)&sx[koff[c]];
+            const double term = cur[c].x * x.x + cur[c].y * x.y;
+            acc += kval[c] ? term : 0.0;
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) part[t][w] = acc;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) cur[c] = nxt[c];
+    }
+    __syncthreads();
+    if (tid < t) {
+        const int r = blockIdx.x + tid * gridDim.x;
+        Dp[r] = (part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]);
     }
 }
 
