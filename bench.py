@@ -57,7 +57,7 @@ VARIED = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_l
 def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
     """B = 1 product y = DM x with 8 distinct matrices (400 MB > Infinity Cache) round-robin, so
     every launch streams its matrix from HBM; HIP-event timed on the engine stream."""
-    ld = (n + 15) // 16 * 16
+    ld = (n + 31) // 32 * 32
     dev = torch.device('cuda', torch.cuda.current_device())
     mats = [torch.zeros(n, ld, dtype=torch.float64, device=dev) for _ in range(copies)]
     for m in mats:

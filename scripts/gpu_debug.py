@@ -28,7 +28,7 @@ chi2, status, model = eng.eval(eng.theta_from_params()[None, :], want_model=True
 print('status', status, 'chi2', chi2[0], 'ref', ref_chi2, 'rel', abs(chi2[0] - ref_chi2) / abs(ref_chi2))
 
 n_pipe = len(eng.pipe_index)
-nkp = 816
+nkp = 832
 pl = eng.debug_read(0, 0, 4 * 1 * n_pipe * nkp).reshape(4, n_pipe, nkp)
 for (name, comp), pid in eng.pipe_index.items():
     if comp in ('peak', 'smooth'):
@@ -37,7 +37,7 @@ for (name, comp), pid in eng.pipe_index.items():
             got = pl[i, pid, :814]
             print(f'pk_ell {name} {comp} ell={ell}: max abs err {np.abs(got - ref).max():.3e} scale {np.abs(ref).max():.3e}')
         n = prob.items[name].model_grid.size
-        npad = (n + 15) // 16 * 16
+        npad = (n + 31) // 32 * 32
         xi = eng.debug_read(1, pid, npad)[:n]
         ref = taps[name][comp]['xi_core']
         print(f'xi_core {name} {comp}: max abs err {np.abs(xi - ref).max():.3e} scale {np.abs(ref).max():.3e}')

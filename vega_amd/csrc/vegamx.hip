@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <utility>
@@ -290,18 +291,19 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
         }
         return 1;
     }
-    const int tm = (M + GEMM_BM - 1) / GEMM_BM, tn = (N + GEMM_BN - 1) / GEMM_BN;
+    constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const int tiles = tm * tn * nbatch;
     // split K until at least 512 blocks exist (2 per CU); partial sums go to separate slabs
     int nsplit = 1;
     if (tiles < 512) nsplit = (512 + tiles - 1) / tiles;
     if (nsplit > 8) nsplit = 8;
     while (nsplit > 1 && (int64_t)nsplit * N > slab_rows_avail) --nsplit;
-    int klen = ((K + nsplit - 1) / nsplit + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    int klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
     nsplit = (K + klen - 1) / klen;
     g.nsplit = nsplit; g.klen = klen; g.d_slab = (int64_t)N * ldd;
     dim3 grid(tm, tn, nbatch * nsplit), block(256);
-    hipLaunchKernelGGL(k_gemm_nt, grid, block, 0, e->stream, g);
+    hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK>), grid, block, 0, e->stream, g);
     return nsplit;
 }
 
@@ -990,7 +992,7 @@ int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t co
                       double* d_y)
 {
     REQUIRE(e && d_A && d_x && d_y, "vmx_matvec_device");
-    REQUIRE(rows > 0 && cols > 0 && cols % VMX_PAD == 0, "cols (leading dimension) must be a multiple of 16, zero padded");
+    REQUIRE(rows > 0 && cols > 0 && cols % VMX_PAD == 0, "cols (leading dimension) must be a multiple of 32, zero padded");
     REQUIRE(B > 0 && B <= 8, "vmx_matvec_device streams the matrix once: B <= 8");
     HIP_OK(hipSetDevice(e->device));
     launch_product(e, KC_MATVEC, d_A, cols, 0, rows, cols, d_x, cols, 0, B, d_y, vmx_pad(rows), 0, 1, 0);

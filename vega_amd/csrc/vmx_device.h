@@ -18,7 +18,7 @@
 #include "../../include/vegamx.h"
 
 #define VMX_NS 40            // scalars per (walker, pipeline)
-#define VMX_PAD 16           // leading dimensions are multiples of 16 doubles
+#define VMX_PAD 32           // leading dimensions are multiples of 32 doubles
 #define VMX_MAX_BB 32        // broadband terms per item and position
 #define VMX_MAX_METALS 64
 
@@ -723,93 +723,104 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define GEMM_BM 64
 #define GEMM_BN 64
-#define GEMM_BK 16
-#define GEMM_LDS_LD 18      // 16 + 2: conflict-free ds_read_b64 for the 16x4 operand pattern
+#define GEMM_BK 32
 
 struct GemmArgs {
     const double* A; int lda; int64_t a_batch;
     const double* X; int ldx; int64_t x_batch;
     double* D; int ldd; int64_t d_batch; int64_t d_slab;
-    int M, N, K;            // K already padded to a multiple of 16 (zero padded operands)
-    int nsplit, klen;       // klen multiple of 16
+    int M, N, K;            // K already padded to a multiple of 32 (zero padded operands)
+    int nsplit, klen;       // klen multiple of the K step
 };
 
+// Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
+// (BM/2) x (BN/2) sub-tile as (BN/32) x (BM/32) MFMA tiles.  LDS rows are padded to BK + 2 doubles, which
+// makes the 16-row x 4-k operand read pattern of v_mfma_f64_16x16x4 conflict-free for ds_read_b64.
+template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
 {
-    __shared__ double sA[2][GEMM_BM * GEMM_LDS_LD];
-    __shared__ double sX[2][GEMM_BN * GEMM_LDS_LD];
+    constexpr int LD = BK + 2;
+    constexpr int TI = BN / 32;        // MFMA tiles per wave along walkers
+    constexpr int TJ = BM / 32;        // MFMA tiles per wave along matrix rows
+    constexpr int RPP = 512 / BK;      // rows staged per pass (256 threads x 2 doubles)
+    constexpr int PA = BM / RPP, PX = BN / RPP;
+    __shared__ double sA[2][BM * LD];
+    __shared__ double sX[2][BN * LD];
 
     const int batch = blockIdx.z / g.nsplit, split = blockIdx.z % g.nsplit;
     const double* A = g.A + batch * g.a_batch;
     const double* X = g.X + batch * g.x_batch;
     double* Dp = g.D + batch * g.d_batch + split * g.d_slab;
 
-    const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * GEMM_BN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = split * g.klen;
     int kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const int wm = (wave & 1) * (BM / 2), wn = (wave >> 1) * (BN / 2);
 
-    // staging: each thread moves 2 x double2 of A and of X per K step
-    const int lrow = tid >> 3;            // 0..31
-    const int lk = (tid & 7) * 2;         // 0,2,..14
-    int ar0 = m0 + lrow, ar1 = m0 + lrow + 32;
-    if (ar0 >= g.M) ar0 = g.M - 1;
-    if (ar1 >= g.M) ar1 = g.M - 1;
-    int xr0 = n0 + lrow, xr1 = n0 + lrow + 32;
-    if (xr0 >= g.N) xr0 = g.N - 1;
-    if (xr1 >= g.N) xr1 = g.N - 1;
-    const double* pa0 = A + (size_t)ar0 * g.lda + lk;
-    const double* pa1 = A + (size_t)ar1 * g.lda + lk;
-    const double* px0 = X + (size_t)xr0 * g.ldx + lk;
-    const double* px1 = X + (size_t)xr1 * g.ldx + lk;
+    const int lrow = tid / (BK / 2);
+    const int lk = (tid % (BK / 2)) * 2;
+    const double* pa[PA];
+    const double* px[PX];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) { int r = m0 + lrow + p * RPP; if (r >= g.M) r = g.M - 1; pa[p] = A + (size_t)r * g.lda + lk; }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) { int r = n0 + lrow + p * RPP; if (r >= g.N) r = g.N - 1; px[p] = X + (size_t)r * g.ldx + lk; }
 
-    v4d acc[2][2];
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    v4d acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    v2d ra0, ra1, rx0, rx1;
+    v2d ra[PA], rx[PX];
     if (kbeg < kend) {
-        ra0 = *(const v2d*)(pa0 + kbeg); ra1 = *(const v2d*)(pa1 + kbeg);
-        rx0 = *(const v2d*)(px0 + kbeg); rx1 = *(const v2d*)(px1 + kbeg);
+#pragma unroll
+        for (int p = 0; p < PA; ++p) ra[p] = *(const v2d*)(pa[p] + kbeg);
+#pragma unroll
+        for (int p = 0; p < PX; ++p) rx[p] = *(const v2d*)(px[p] + kbeg);
     }
     int buf = 0;
     const int frow = lane & 15, fk = lane >> 4;
-    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-        *(v2d*)&sA[buf][lrow * GEMM_LDS_LD + lk] = ra0;
-        *(v2d*)&sA[buf][(lrow + 32) * GEMM_LDS_LD + lk] = ra1;
-        *(v2d*)&sX[buf][lrow * GEMM_LDS_LD + lk] = rx0;
-        *(v2d*)&sX[buf][(lrow + 32) * GEMM_LDS_LD + lk] = rx1;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) *(v2d*)&sA[buf][(lrow + p * RPP) * LD + lk] = ra[p];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) *(v2d*)&sX[buf][(lrow + p * RPP) * LD + lk] = rx[p];
         __syncthreads();
-        const int kn = k0 + GEMM_BK;
+        const int kn = k0 + BK;
         if (kn < kend) {
-            ra0 = *(const v2d*)(pa0 + kn); ra1 = *(const v2d*)(pa1 + kn);
-            rx0 = *(const v2d*)(px0 + kn); rx1 = *(const v2d*)(px1 + kn);
+#pragma unroll
+            for (int p = 0; p < PA; ++p) ra[p] = *(const v2d*)(pa[p] + kn);
+#pragma unroll
+            for (int p = 0; p < PX; ++p) rx[p] = *(const v2d*)(px[p] + kn);
         }
         const double* a = &sA[buf][0];
         const double* x = &sX[buf][0];
 #pragma unroll
-        for (int ks = 0; ks < GEMM_BK; ks += 4) {
-            const double a0 = a[(wm + frow) * GEMM_LDS_LD + ks + fk];
-            const double a1 = a[(wm + 16 + frow) * GEMM_LDS_LD + ks + fk];
-            const double x0 = x[(wn + frow) * GEMM_LDS_LD + ks + fk];
-            const double x1 = x[(wn + 16 + frow) * GEMM_LDS_LD + ks + fk];
-            // MFMA computes C[i][j] += sum_k Aop[i][k] Bop[k][j]; rows i <- walkers (X), cols j <- matrix rows (A):
+        for (int ks = 0; ks < BK; ks += 4) {
+            double av[TJ], xv[TI];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) av[j] = a[(wm + 16 * j + frow) * LD + ks + fk];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) xv[i] = x[(wn + 16 * i + frow) * LD + ks + fk];
+            // MFMA computes C[i][j] += sum_k Aop[i][k] Bop[k][j]; rows <- walkers (X), cols <- matrix rows (A):
             // the result tile is D^T[n][m], whose register layout (row = (lane>>4) + 4 r, col = lane & 15)
             // stores 16 consecutive m per 16 lanes -> coalesced along m.
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[i], av[j], acc[i][j], 0, 0, 0);
         }
         buf ^= 1;
     }
 
-    // store: acc[i][j] covers walkers n0 + wn + 16 i + (lane>>4) + 4 r, matrix rows m0 + wm + 16 j + (lane & 15)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wn + 16 * i + (lane >> 4) + 4 * r;
