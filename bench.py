@@ -123,6 +123,26 @@ def single_point_latency(device, reps=200):
             'us_per_eval': dt * 1e6, 'kernel_us_per_launch': kern}
 
 
+def monte_carlo_fits(vega, n_mocks=128):
+    """BASELINE configs[4] in miniature: n_mocks Monte-Carlo realisations of the bench workload, each fitted over
+    (ap, at, bias_eta_LYA, beta_LYA, beta_QSO, bias_hcd) by the batched minimiser, all in lock-step."""
+    names = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'bias_hcd']
+    limits = {'ap': (0.5, 1.5), 'at': (0.5, 1.5), 'bias_eta_LYA': (-2., 0.), 'beta_LYA': (0., 5.),
+              'beta_QSO': (0., 1.), 'bias_hcd': (-0.5, 0.)}
+    errors = {'ap': 0.01, 'at': 0.01, 'bias_eta_LYA': 0.01, 'beta_LYA': 0.1, 'beta_QSO': 0.1, 'bias_hcd': 0.01}
+    sample = {'limits': limits, 'values': {n: vega.params[n] for n in names}, 'errors': errors,
+              'fix': {n: False for n in names}}
+    t0 = time.perf_counter()
+    res = vega.run_monte_carlo(num_mocks=n_mocks, seed=11, sample_params=sample)
+    dt = time.perf_counter() - t0
+    truth = np.array([vega.params[n] for n in names])
+    pulls = (res.values - truth) / res.errors
+    return {'workload': f'{n_mocks} mocks x {len(names)}-parameter fits (mock generation + minimisation + Hessian)',
+            'fits_per_s': n_mocks / dt, 'seconds': dt, 'chi2_evaluations': int(res.nfcn.sum()),
+            'evals_per_fit': float(res.nfcn.mean()), 'valid_fraction': float(res.is_valid.mean()),
+            'pull_rms': [float(v) for v in pulls.std(axis=0)]}
+
+
 def cpu_baseline(prob, names, theta, seconds=15.0):
     """The oracle (CPU restatement of the reference) on a bounded sample of the same walkers."""
     from contextlib import nullcontext
@@ -260,6 +280,7 @@ def main():
                         'algorithmic_flops_per_launch': flops}
         distortion = distortion_microbench(eng, torch)
         single = single_point_latency(local_rank)
+        mc_fits = monte_carlo_fits(vega) if args.workload == 'joint' else None
         cpu = None
         if not args.no_cpu_baseline:
             cpu, ref_vals = cpu_baseline(prob, eng.names, host_theta)
@@ -278,7 +299,7 @@ def main():
                        if args.workload == 'joint' else args.workload,
                        'batch_per_gpu': B, 'pipelines_per_eval': len(eng.pipe_index),
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
-            'roofline': roofline, 'distortion': distortion, 'single_point': single, 'cpu_baseline': cpu,
+            'roofline': roofline, 'distortion': distortion, 'single_point': single, 'monte_carlo_fits': mc_fits, 'cpu_baseline': cpu,
             'kernels': kernels,
         }
         print(json.dumps(out))

@@ -185,6 +185,13 @@ int vmx_item_set_mask(vmx_engine* e, int32_t item, const int32_t* idx, int32_t n
 /* Masked data vector, or the current Monte-Carlo mock (vega_interface.py:311-315). */
 int vmx_item_set_data(vmx_engine* e, int32_t item, const double* masked_data, int32_t n_masked);
 
+/* Monte-Carlo fits of many mocks at once (vega/analysis.py:224-302 evaluates one mock at a time): a pool of
+ * masked mock data vectors [n_mocks][n_masked] per item, and per walker the pool row it is compared with
+ * (vmx_set_mock_index; -1 or a NULL index array = the item's own data vector).  Both may be called after
+ * vmx_finalize; the index array applies to the following vmx_eval* calls. */
+int vmx_item_set_mock_pool(vmx_engine* e, int32_t item, const double* pool, int32_t n_mocks, int32_t n_masked);
+int vmx_set_mock_index(vmx_engine* e, const int32_t* index, int32_t B);
+
 /* Global-covariance mode (vega_interface.py:295-304): inverse of the masked global covariance over
  * the concatenation of all items' masked bins, in item order. */
 int vmx_set_global_invcov(vmx_engine* e, const double* invcov, int32_t n);

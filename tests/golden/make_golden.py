@@ -295,6 +295,36 @@ def dump_picca(VegaInterface):
     print('picca: dumped', len(out), 'vectors')
 
 
+def dump_mc(VegaInterface):
+    """Two Monte-Carlo mocks of the joint config with the synthetic covariance, drawn exactly as
+    Analysis.run_monte_carlo does (np.random.seed once, then create_monte_carlo_sim per mock), plus the chi2 of
+    the fiducial parameters against each mock through the reference's monte_carlo switch."""
+    from scipy.sparse import csr_array
+    os.chdir(REF / 'tests')
+    items = ['lyalya_lyalya', 'lyalya_qso']
+    with tempfile.TemporaryDirectory() as tmp:
+        vega = VegaInterface(_ref_main(tmp, items, False))
+        for name in items:
+            data = vega.data[name]
+            data._distortion_mat = csr_array(synthetic.distortion_matrix(data.model_coordinates.rp_grid,
+                                                                          data.model_coordinates.rt_grid))
+            data._cov_mat = synthetic.covariance(data.data_coordinates.rp_grid, data.data_coordinates.rt_grid)
+            data._inv_masked_cov = None
+            data._log_cov_det = None
+        fid = vega.compute_model(run_init=False)
+        out = {}
+        np.random.seed(7)
+        vega.monte_carlo = True
+        for i in range(2):
+            vega.analysis.create_monte_carlo_sim(fid, seed=None, scale=None)
+            for name in items:
+                out[f'mock{i}/{name}'] = vega.data[name].masked_mc_mock.copy()
+            _reset_caches(vega)
+            out[f'mock{i}/chi2_fid'] = vega.chi2()
+        np.savez_compressed(HERE / 'expected_mc.npz', **out)
+        print('mc: chi2 of the fiducial against the two mocks', out['mock0/chi2_fid'], out['mock1/chi2_fid'])
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -302,12 +332,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -316,3 +346,5 @@ if __name__ == '__main__':
         dump_subset(VI, 'joint_synth', ['lyalya_lyalya', 'lyalya_qso'], False, synth=True)
     if 'picca' in what:
         dump_picca(VI)
+    if 'mc' in what:
+        dump_mc(VI)

@@ -86,7 +86,8 @@ struct MetalHost {
 struct ItemHost {
     ItemDev dev{};
     std::vector<MetalHost*> metals;
-    DevBuf<double> dm, cinv, data, vec, dist, res, z;
+    DevBuf<double> dm, cinv, data, vec, dist, res, z, mock_pool;
+    int n_mocks = 0;
     DevBuf<int32_t> inv_mask;
     std::vector<int32_t> mask_idx;
     bool has_dm = false, has_cinv = false, has_mask = false, has_data = false;
@@ -136,7 +137,8 @@ struct vmx_engine {
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
     int64_t xi_total = 0, xim_total = 0;
     DevBuf<double> theta, scal, metal_bias, pl, coef, xi, xim, model, chi2;
-    DevBuf<int32_t> status;
+    DevBuf<int32_t> status, mock_index;
+    std::vector<int32_t> h_mock_index;
     int last_B = 0;
     EngineDev dev{};
 
@@ -571,6 +573,39 @@ int vmx_item_set_data(vmx_engine* e, int32_t item, const double* masked_data, in
     return 0;
 }
 
+int vmx_item_set_mock_pool(vmx_engine* e, int32_t item, const double* pool, int32_t n_mocks, int32_t n_masked)
+{
+    REQUIRE(e && e->finalized && pool, "vmx_item_set_mock_pool (after vmx_finalize)");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(n_mocks > 0 && n_masked == it->dev.n_masked, "mock pool shape");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (it->mock_pool.upload(pool, (size_t)n_mocks * n_masked)) return -2;
+    it->n_mocks = n_mocks;
+    it->dev.mock_pool = it->mock_pool.p;
+    // the item table lives in device memory: patch this item's entry
+    HIP_OK(hipMemcpy(e->d_items.p + item, &it->dev, sizeof(ItemDev), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int vmx_set_mock_index(vmx_engine* e, const int32_t* index, int32_t B)
+{
+    REQUIRE(e && e->finalized, "vmx_set_mock_index (after vmx_finalize)");
+    REQUIRE(B >= 0 && B <= e->max_batch, "batch exceeds max_batch");
+    HIP_OK(hipSetDevice(e->device));
+    for (int b = 0; b < e->max_batch; ++b) e->h_mock_index[b] = -1;
+    if (index) {
+        for (int b = 0; b < B; ++b) {
+            for (auto* it : e->items) REQUIRE(index[b] < 0 || index[b] < it->n_mocks, "mock index exceeds the pool");
+            e->h_mock_index[b] = index[b];
+        }
+    }
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipMemcpy(e->mock_index.p, e->h_mock_index.data(), (size_t)e->max_batch * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int vmx_set_global_invcov(vmx_engine* e, const double* invcov, int32_t n)
 {
     REQUIRE(e && invcov && n > 0, "vmx_set_global_invcov");
@@ -787,6 +822,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->pl.alloc((size_t)VMX_MAX_ELL * ncols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * ncols * e->ncp) ||
         e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
         e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm)) return -2;
+    e->h_mock_index.assign(Bm, -1);
+    if (e->mock_index.upload(e->h_mock_index.data(), Bm)) return -2;
 
     EngineDev& D = e->dev;
     D = EngineDev{};
@@ -806,7 +843,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.prior_slot = e->d_prior_slot.p; D.prior_mean = e->d_prior_mean.p; D.prior_sigma = e->d_prior_sigma.p;
     D.n_params = n_params;
     D.theta = e->theta.p; D.scal = e->scal.p; D.metal_bias = e->metal_bias.p; D.pl = e->pl.p; D.coef = e->coef.p;
-    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p;
+    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p; D.mock_index = e->mock_index.p;
     D.model_size = e->model_size;
     D.gcinv = e->gcinv.p; D.g_n = e->g_n; D.g_ld = e->g_ld; D.gres = e->gres.p; D.gz = e->gz.p;
 

@@ -70,6 +70,7 @@ struct ItemDev {
     const double* cinv; int32_t cinv_ld;      // inverse covariance or null (identity)
     const int32_t* inv_mask;                  // [n_dist] -> masked index or -1
     const double* data;                       // [n_masked]
+    const double* mock_pool;                  // [n_mocks][n_masked] per-walker data vectors, or null
     double* vec;                              // [B][n_model_pad]   pre-distortion model
     double* dist;                             // [S][B][n_dist_pad] distortion product slabs
     double* res;                              // [B][n_masked_pad]  residual
@@ -118,6 +119,7 @@ struct EngineDev {
     double* model;              // [B][model_size]
     double* chi2;               // [B]
     int32_t* status;            // [B]
+    const int32_t* mock_index;  // [B] row of the mock pool used as data by walker b, -1: the item's data vector
     int32_t model_size;
     // global covariance mode
     const double* gcinv; int32_t g_n, g_ld; double* gres; double* gz;
@@ -1092,7 +1094,9 @@ __global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B, int 
     D.model[(size_t)b * D.model_size + it.model_off + bin] = v;
     const int mi = it.inv_mask[bin];
     if (mi >= 0) {
-        const double diff = it.data[mi] - v;
+        const int mock = D.mock_index[b];
+        const double dat = (mock >= 0 && it.mock_pool) ? it.mock_pool[(size_t)mock * it.n_masked + mi] : it.data[mi];
+        const double diff = dat - v;
         it.res[(size_t)b * it.n_masked_pad + mi] = diff;
         if (D.gres) D.gres[(size_t)b * D.g_ld + it.masked_off + mi] = diff;
     }

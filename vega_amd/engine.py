@@ -115,6 +115,8 @@ def load_library():
     lib.vmx_item_set_mask.argtypes = [C.c_void_p, C.c_int32, iptr, C.c_int32]
     lib.vmx_item_set_data.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_global_invcov.argtypes = [C.c_void_p, dptr, C.c_int32]
+    lib.vmx_item_set_mock_pool.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32]
+    lib.vmx_set_mock_index.argtypes = [C.c_void_p, iptr, C.c_int32]
     lib.vmx_add_prior.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double]
     lib.vmx_finalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.vmx_model_size.argtypes = [C.c_void_p]
@@ -139,7 +141,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_add_gk_table',
     'vmx_add_pipeline', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
-    'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
+    'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_debug_read', 'vmx_matvec_device',
     'vmx_set_profiling', 'vmx_get_timings', 'vmx_kernel_name']
 
@@ -576,6 +578,20 @@ class Engine:
         qi = self.item_names.index(name)
         d = _f64(masked_data)
         self._check(self.lib.vmx_item_set_data(self._h, qi, _dp(d), d.size))
+
+    def set_mock_pool(self, name, pool):
+        """Masked mock data vectors [n_mocks, n_masked] of item ``name`` (Monte-Carlo fits)."""
+        qi = self.item_names.index(name)
+        pool = _f64(np.atleast_2d(pool))
+        self._check(self.lib.vmx_item_set_mock_pool(self._h, qi, _dp(pool), pool.shape[0], pool.shape[1]))
+
+    def set_mock_index(self, index=None):
+        """Per-walker pool row used as data in the following evaluations (None: the items' own data)."""
+        if index is None:
+            self._check(self.lib.vmx_set_mock_index(self._h, None, 0))
+        else:
+            idx = np.ascontiguousarray(index, dtype=np.int32)
+            self._check(self.lib.vmx_set_mock_index(self._h, _ip(idx), idx.size))
 
     def set_invcov(self, name, invcov):
         qi = self.item_names.index(name)

@@ -159,5 +159,31 @@ class VegaInterface:
         model = np.concatenate(blocks)
         return {name: model[:, sl] for name, sl in self.engine.model_slices.items()}
 
+    # ------------------------------------------------------------------ fits (SURVEY section 8f "next" #1, #2)
+    def minimize(self, params=None, tol=0.1):
+        """Fit the sampled parameters to the data (reference VegaInterface.minimize -> Minimizer.minimize,
+        vega/vega_interface.py:581, vega/minimizer.py:39-103).  Returns a FitResult with one fit; the best fit
+        is also kept in ``self.bestfit``."""
+        from .montecarlo import MonteCarlo
+        self._sync_monte_carlo()
+        fitter = MonteCarlo(self).minimizer(tol=tol)
+        start = None
+        if params is not None and 'values' in params:
+            start = [[params['values'].get(n, v) for n, v in zip(fitter.names, fitter.start)]]
+        self.bestfit = fitter.minimize(n_fits=1, start=start)
+        return self.bestfit
+
+    def run_monte_carlo(self, fiducial_model=None, num_mocks=1, seed=0, scale=None, forecast=False,
+                        run_mc_fits=True, sample_params=None):
+        """Create ``num_mocks`` mocks around ``fiducial_model`` (default: the model at the current parameters)
+        and fit them all in lock-step (reference Analysis.run_monte_carlo, vega/analysis.py:224-308)."""
+        from .montecarlo import MonteCarlo
+        if fiducial_model is None:
+            fiducial_model = self.compute_model()
+        self.analysis = MonteCarlo(self)
+        return self.analysis.run_monte_carlo(fiducial_model, num_mocks=num_mocks, seed=seed, scale=scale,
+                                             forecast=forecast, run_mc_fits=run_mc_fits,
+                                             sample_params=sample_params)
+
     def close(self):
         self.engine.close()

@@ -272,6 +272,7 @@ class Problem:
     items: dict
     global_cov: np.ndarray = None
     main_config: object = None
+    mc_config: dict = None
 
     _global = None
 
@@ -657,9 +658,19 @@ def _build_item(cfg, consts, search_dirs):
 # --------------------------------------------------------------------------------------
 def _read_sample(section, params):
     """reference vega/vega_interface.py:738-816"""
+    from .defaults import DEFAULT_VALUES
     out = {'limits': {}, 'values': {}, 'errors': {}, 'fix': {}}
+
+    def default(param):
+        if param not in DEFAULT_VALUES:
+            raise ValueError(f'Default values not found for: {param}. Please provide the full sampling '
+                             'specification.')
+        return DEFAULT_VALUES[param]
+
     for param, values in section.items():
         if param not in params:
+            print(f'Warning: You tried sampling the parameter: {param}. As this parameter was not specified '
+                  'under [parameters], it will be skipped.')
             continue
         vals = values.split()
         if len(vals) > 1:
@@ -669,10 +680,13 @@ def _read_sample(section, params):
         else:
             if vals[0] not in TRUE_WORDS:
                 continue
-            out['limits'][param] = (None, None)
+            out['limits'][param] = default(param)[0]
         out['values'][param] = float(vals[2]) if len(vals) > 2 else params[param]
-        out['errors'][param] = float(vals[3]) if len(vals) > 3 else \
-            max(abs(params[param]) * 0.1, 1e-3)
+        if len(vals) > 3:
+            assert len(vals) == 4
+            out['errors'][param] = float(vals[3])
+        else:
+            out['errors'][param] = default(param)[1]
         out['fix'][param] = False
     return out
 
@@ -766,6 +780,11 @@ def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
     if scale.metal_scaling and scale.two_alpha_smooth:
         raise ValueError('The "metal-scaling" and "two-alpha-smooth" options are incompatible.')
 
+    mc_config = None
+    if 'monte carlo' in main:
+        mc_config = {'params': {p: float(v) for p, v in main['mc parameters'].items()} if 'mc parameters' in main else {},
+                     'sample': _read_sample(main['monte carlo'], params)}
+
     global_cov = None
     gc_file = main['data sets'].get('global-cov-file', None)
     if gc_file is not None:
@@ -777,4 +796,4 @@ def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
     return Problem(k=k, pk_full=pk_full, pk_smooth=pk_smooth, z_fid=z_fid, z_eff=z_eff,
                    omega_m=om, omega_de=ode, growth_rate=growth_rate, scale=scale,
                    params=params, sample_params=sample, priors=priors, items=items,
-                   global_cov=global_cov, main_config=main)
+                   global_cov=global_cov, main_config=main, mc_config=mc_config)
