@@ -216,11 +216,14 @@ def main():
     chi2_dev = torch.zeros(B, dtype=torch.float64, device=dev)
     gathered = torch.zeros(world * B, dtype=torch.float64, device=dev) if use_dist else None
 
+    # the collective is ordered after the evaluation on the engine's own stream: no host synchronisation per step
+    eng_stream = torch.cuda.ExternalStream(eng.stream_handle(), device=dev)
+
     def step(i):
         eng.eval_device(pools[i % n_pool].data_ptr(), B, chi2_dev.data_ptr())
         if use_dist:
-            eng.sync()      # the engine runs on its own stream
-            dist.all_gather_into_tensor(gathered, chi2_dev)
+            with torch.cuda.stream(eng_stream):
+                dist.all_gather_into_tensor(gathered, chi2_dev)
 
     eng.set_profiling(True)         # per-kernel HIP events on the engine stream (first use of an event is slow:
     for i in range(args.warmup):    # warm them up together with the kernels)

@@ -216,6 +216,9 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
 int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2,
                     double* d_model, int32_t* d_status);
 int vmx_sync(vmx_engine* e);
+/* The engine's HIP stream (hipStream_t as an opaque pointer), so that a caller can order its own work - e.g. an
+ * RCCL collective on the chi2 buffer - after vmx_eval_device without a host synchronisation. */
+void* vmx_stream(vmx_engine* e);
 
 /* Stage taps for parity tests: copy an internal buffer of the last evaluation to the host.
  * what: 0 = P_ell(k) [n_ell_max][B*n_pipe][nk_pad]; 1 = xi per pipeline [B][n] (index = pipeline).

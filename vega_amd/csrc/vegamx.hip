@@ -101,7 +101,7 @@ struct vmx_engine {
     bool finalized = false;
 
     int nk = 0, nkp = 0, n_mu = 0;
-    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, wl, gk, gk_mom;
+    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom;
     std::vector<std::pair<double, double>> gk_tables;
     std::vector<double> h_k, h_mu;
 
@@ -372,10 +372,10 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
 
     // mu grid: midpoint rule on [0, 1] (power_spectrum.py:76-77); Legendre weights
     // L_ell(mu) (2 ell + 1) / n_mu (pktoxi.py:37,55,138)
-    std::vector<double> mu(n_mu), sq(n_mu), wl(4 * (size_t)n_mu);
+    std::vector<double> mu(n_mu), sq(n_mu), lnm(n_mu), wl(4 * (size_t)n_mu);
     for (int j = 0; j < n_mu; ++j) {
         const double m = (j + 0.5) / n_mu, m2 = m * m;
-        mu[j] = m; sq[j] = std::sqrt(1.0 - m2);
+        mu[j] = m; sq[j] = std::sqrt(1.0 - m2); lnm[j] = std::log(m);
         const double dmu = 1.0 / n_mu;
         wl[j] = dmu * 1.0 * 1.0;
         wl[n_mu + j] = dmu * (0.5 * (3.0 * m2 - 1.0)) * 5.0;
@@ -383,7 +383,7 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
         wl[3 * (size_t)n_mu + j] = dmu * (0.0625 * (((231.0 * m2 - 315.0) * m2 + 105.0) * m2 - 5.0)) * 13.0;
     }
     e->h_mu = mu;
-    if (e->mu.upload(mu.data(), n_mu) || e->sq1mmu2.upload(sq.data(), n_mu) || e->wl.upload(wl.data(), wl.size())) return -2;
+    if (e->mu.upload(mu.data(), n_mu) || e->sq1mmu2.upload(sq.data(), n_mu) || e->lnmu.upload(lnm.data(), n_mu) || e->wl.upload(wl.data(), wl.size())) return -2;
     return 0;
 }
 
@@ -828,7 +828,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     EngineDev& D = e->dev;
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
-    D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p;
+    D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p; D.lnmu = e->lnmu.p;
     D.wl = e->wl.p; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp;
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
@@ -865,7 +865,8 @@ static int run_chain(vmx_engine* e, int B)
     const int n_pipe = D.n_pipe;
     {
         ScopedTimer t(e, KC_PROLOGUE);
-        hipLaunchKernelGGL(k_prologue, dim3((B + 63) / 64), dim3(64), 0, e->stream, D, B);
+        const int n_thr = B * (n_pipe + 1);
+        hipLaunchKernelGGL(k_prologue, dim3((n_thr + 63) / 64), dim3(64), 0, e->stream, D, B);
     }
     {
         ScopedTimer t(e, KC_PK);
@@ -877,8 +878,11 @@ static int run_chain(vmx_engine* e, int B)
         else if ((int64_t)B * n_groups >= 24)
             hipLaunchKernelGGL((k_pk_multipoles<64, 4>), dim3(B, n_groups, (e->nk + 63) / 64), dim3(256), shmem, e->stream, D,
                                e->d_pk_groups.p, e->d_pk_members.p);
-        else
+        else if ((int64_t)B * n_groups >= 4)
             hipLaunchKernelGGL((k_pk_multipoles<16, 16>), dim3(B, n_groups, (e->nk + 15) / 16), dim3(256), shmem, e->stream, D,
+                               e->d_pk_groups.p, e->d_pk_members.p);
+        else
+            hipLaunchKernelGGL((k_pk_multipoles<8, 32>), dim3(B, n_groups, (e->nk + 7) / 8), dim3(256), shmem, e->stream, D,
                                e->d_pk_groups.p, e->d_pk_members.p);
     }
     {
@@ -981,6 +985,8 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     if (d_model) HIP_OK(hipMemcpyAsync(d_model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     return 0;
 }
+
+void* vmx_stream(vmx_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int vmx_sync(vmx_engine* e)
 {

@@ -87,6 +87,7 @@ struct EngineDev {
     const double* delta2;       // [nkp]
     const double* mu;           // [n_mu]
     const double* sq1mmu2;      // [n_mu] sqrt(1 - mu^2)
+    const double* lnmu;         // [n_mu] ln(mu)
     const double* wl;           // [4][n_mu] L_ell(mu) (2 ell + 1) / n_mu
     const double* gk;           // [tables][n_mu][nkp]
     const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
@@ -144,11 +145,14 @@ __device__ inline void tracer_bias_beta(const double* t, const vmx_tracer& tr, d
 
 __global__ void k_prologue(EngineDev D, int B)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // thread = (walker, slot): slots 0 .. n_pipe-1 fill one pipeline's scalars, slot n_pipe the walker-level values
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gid / (D.n_pipe + 1), slot = gid % (D.n_pipe + 1);
     if (b >= B) return;
     const double* t = D.theta + (size_t)b * D.n_params;
 
-    for (int p = 0; p < D.n_pipe; ++p) {
+    if (slot < D.n_pipe) {
+        const int p = slot;
         const vmx_pipe_desc& d = D.pipes[p].d;
         double* s = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
         for (int i = 0; i < VMX_NS; ++i) s[i] = 0.0;
@@ -222,6 +226,7 @@ __global__ void k_prologue(EngineDev D, int B)
             s[q == 0 ? S_EV1A : S_EV2A] = a; s[q == 0 ? S_EV1B : S_EV2B] = c;
         }
         if (d.radiation) { for (int i = 0; i < 4; ++i) s[S_RAD_S + i] = t[d.rad_slot[i]]; }
+        return;
     }
 
     // metal bias products (reference metals.py:295-313, :331-332)
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     T.arinyo = d.nl_model == VMX_NL_ARINYO;
     if (T.arinyo) {
         const double bv = sc[S_ABV];
-        for (int j = threadIdx.x; j < n_mu; j += 256) s_mubv[j] = pow(((double)j + 0.5) * inv_nmu, bv);
+        for (int j = threadIdx.x; j < n_mu; j += 256) s_mubv[j] = vmx_exp(bv * D.lnmu[j]);     // mu^bv
         __syncthreads();
     }
 

@@ -123,6 +123,8 @@ def load_library():
     lib.vmx_eval.argtypes = [C.c_void_p, dptr, C.c_int32, dptr, dptr, iptr]
     lib.vmx_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vmx_sync.argtypes = [C.c_void_p]
+    lib.vmx_stream.argtypes = [C.c_void_p]
+    lib.vmx_stream.restype = C.c_void_p
     lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
     lib.vmx_debug_read.restype = C.c_int64
     lib.vmx_matvec_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -142,7 +144,7 @@ EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_add_gk_table',
     'vmx_add_pipeline', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_debug_read', 'vmx_matvec_device',
+    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
     'vmx_set_profiling', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -573,6 +575,10 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.vmx_sync(self._h))
+
+    def stream_handle(self):
+        """hipStream_t of the engine as an integer (for ``torch.cuda.ExternalStream``)."""
+        return int(self.lib.vmx_stream(self._h))
 
     def set_data(self, name, masked_data):
         qi = self.item_names.index(name)
