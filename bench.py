@@ -250,6 +250,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    if use_dist:
+        # the gathered vector holds every rank's chi2 of the last step, rank-major
+        torch.cuda.synchronize()
+        mine = gathered[rank * B:(rank + 1) * B]
+        if not torch.equal(mine, chi2_dev) or not bool(torch.isfinite(gathered).all()):
+            raise SystemExit('all_gather of chi2 returned unexpected values')
     if rank == 0:
         total_evals = B * args.steps * world
         value = total_evals / elapsed
