@@ -41,7 +41,7 @@ typedef struct vmx_engine vmx_engine;
 #define VMX_MAX_ELL 4          /* ell = 0, 2, 4, 6 (reference pktoxi.py:39,45) */
 #define VMX_MAX_SMOOTH 3       /* Gaussian-type smoothing terms per pipeline */
 
-enum { VMX_HCD_NONE = 0, VMX_HCD_ROGERS = 1, VMX_HCD_SINC = 2 };
+enum { VMX_HCD_NONE = 0, VMX_HCD_ROGERS = 1, VMX_HCD_SINC = 2, VMX_HCD_FVOIGT = 3 };
 enum { VMX_NL_NONE = 0, VMX_NL_ARINYO = 1, VMX_NL_MCDONALD = 2 };
 enum { VMX_VD_NONE = 0, VMX_VD_GAUSS = 1, VMX_VD_LORENTZ = 2 };
 enum { VMX_SCALE_UNIT = 0, VMX_SCALE_AP_AT = 1, VMX_SCALE_AISO_EPS = 2, VMX_SCALE_PHI_ALPHA = 3 };
@@ -153,6 +153,10 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
  * pktoxi.py:144.  op is row-major [n_coef][nk]; n_coef = n_knots + 2. */
 int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n_coef,
                    double x0, double h, int32_t n_knots);
+
+/* Voigt-profile table of model-hcd = fvoigt: F(L0 k_par) by linear interpolation in (x, f), 1 below the table and
+ * 0 above it (np.interp(..., left=1, right=0), power_spectrum.py:360-380).  x must be increasing. */
+int vmx_set_fvoigt_table(vmx_engine* e, const double* x, const double* f, int32_t n);
 
 /* G(k) binning table for one (bin_size_rp, bin_size_rt) pair (power_spectrum.py:481-502).
  * Returns the table id (>= 0). */

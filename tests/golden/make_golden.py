@@ -73,6 +73,9 @@ def convert_inputs():
             tabs.append(Table(hdu.header, cols))
         write_bundle(out / dst, tabs)
         print('wrote', out / dst)
+    # HCD Voigt-profile table (data) used by model-hcd = fvoigt
+    (out / 'fvoigt_models').mkdir(exist_ok=True)
+    np.save(out / 'fvoigt_models' / 'Fvoigt_exp.npy', np.loadtxt(REF / 'vega/models/fvoigt_models/Fvoigt_exp.txt'))
 
 
 # ----------------------------------------------------------------------------- configs

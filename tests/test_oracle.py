@@ -167,6 +167,11 @@ def test_pk_known_answers():
     hcd = {'bias_hcd': -0.05, 'beta_hcd': 0.5, 'L0_hcd': 10}
     b_e, be_e = oc._hcd(full.pk, grid, 'LYAxLYA', -0.12, 1.6, hcd)
     assert np.sum(b_e) == approx(-116031.686) and np.sum(be_e) == approx(1179867.64849)
+    from vega_amd.setup import load_fvoigt_table
+    voigt = pipe(lya, lya, 'lyaxlya', hcd_model='fvoigt',
+                 fvoigt_table=load_fvoigt_table('fvoigt_models/Fvoigt_exp.txt', [GOLDEN / 'inputs']))
+    b_e, be_e = oc._hcd(voigt.pk, grid, 'LYAxLYA', -0.12, 1.6, hcd)
+    assert np.sum(b_e) == approx(-121782.768388) and np.sum(be_e) == approx(1142662.6535)
     sinc = pipe(lya, lya, 'lyaxlya', hcd_model='sinc')
     b_e, be_e = oc._hcd(sinc.pk, grid, 'LYAxLYA', -0.12, 1.6, dict(hcd, L0_sinc=10))
     assert np.sum(b_e) == approx(-118530.3944) and np.sum(be_e) == approx(1166657.39777)

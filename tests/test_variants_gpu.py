@@ -53,6 +53,17 @@ def test_sinc_hcd_and_mcdonald():
     _check(prob)
 
 
+def test_fvoigt_hcd():
+    from vega_amd.setup import load_fvoigt_table
+    prob = _fresh('joint')
+    table = load_fvoigt_table('fvoigt_models/Fvoigt_exp.txt', [GOLDEN / 'inputs'])
+    for item in prob.items.values():
+        item.core.pk.hcd_model = 'fvoigt'
+        item.core.pk.fvoigt_table = table
+    prob.params['L0_fvoigt'] = 0.8
+    _check(prob, n_walkers=2)
+
+
 def test_exp_smoothing_gauss_velocity_dispersion_croom():
     prob = _fresh('joint')
     cross = prob.items['lyalya_qso'].core

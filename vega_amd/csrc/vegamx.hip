@@ -101,7 +101,8 @@ struct vmx_engine {
     bool finalized = false;
 
     int nk = 0, nkp = 0, n_mu = 0;
-    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom;
+    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom, fv_x, fv_f;
+    int fv_n = 0;
     std::vector<std::pair<double, double>> gk_tables;
     std::vector<double> h_k, h_mu;
 
@@ -235,7 +236,7 @@ static bool w_stage_compatible(const vmx_pipe_desc& a, const vmx_pipe_desc& b)
 // compile-time specialisation of the mu loop that matches a pipeline (PKV_GENERIC when none does)
 static int pk_variant(const vmx_pipe_desc& d, bool paired)
 {
-    const bool rare = d.hcd_model == VMX_HCD_SINC || d.nl_model == VMX_NL_MCDONALD || d.exp_par_slot >= 0 ||
+    const bool rare = d.hcd_model == VMX_HCD_SINC || d.hcd_model == VMX_HCD_FVOIGT || d.nl_model == VMX_NL_MCDONALD || d.exp_par_slot >= 0 ||
                       (d.fast_metals && (d.tracer[0].is_lya || d.tracer[1].is_lya) &&
                        (d.uvb || d.heii || d.hcd_model != VMX_HCD_NONE));
     if (rare) return PKV_GENERIC;
@@ -404,6 +405,16 @@ int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n
                        (size_t)e->nk * sizeof(double), (size_t)e->nk * sizeof(double), n_coef,
                        hipMemcpyHostToDevice));
     e->x0[ell_index] = x0; e->h[ell_index] = h; e->op_set[ell_index] = true;
+    return 0;
+}
+
+int vmx_set_fvoigt_table(vmx_engine* e, const double* x, const double* f, int32_t n)
+{
+    REQUIRE(e && !e->finalized && x && f && n >= 2, "vmx_set_fvoigt_table");
+    for (int i = 1; i < n; ++i) REQUIRE(x[i] > x[i - 1], "the fvoigt table abscissae must be increasing");
+    HIP_OK(hipSetDevice(e->device));
+    if (e->fv_x.upload(x, n) || e->fv_f.upload(f, n)) return -2;
+    e->fv_n = n;
     return 0;
 }
 
@@ -669,6 +680,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         REQUIRE(!d.heii || (d.bias_gamma_e_slot >= 0 && d.bias_prim_slot >= 0 && d.lambda_heii_slot >= 0), "HeII slots");
         REQUIRE(d.hcd_model == VMX_HCD_NONE || (d.bias_hcd_slot >= 0 && d.beta_hcd_slot >= 0), "HCD slots");
         REQUIRE(d.hcd_model != VMX_HCD_ROGERS || d.l0_hcd_slot >= 0, "L0_hcd slot");
+        REQUIRE(d.hcd_model != VMX_HCD_FVOIGT || e->fv_n >= 2, "model-hcd = fvoigt needs vmx_set_fvoigt_table");
         REQUIRE(d.nl_model != VMX_NL_ARINYO || (d.arinyo_slot[0] >= 0 && d.arinyo_slot[2] >= 0 && d.arinyo_slot[3] >= 0 &&
                                                 d.arinyo_slot[4] >= 0 && d.arinyo_slot[5] >= 0), "Arinyo slots");
         REQUIRE(!d.peak_nl || d.sigma_nl_par_slot >= 0 || d.sigma_nl_per_slot >= 0, "sigmaNL slots");
@@ -829,7 +841,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
     D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p; D.lnmu = e->lnmu.p;
-    D.wl = e->wl.p; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.n_gk = (int)e->gk_tables.size();
+    D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp;
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);

@@ -89,6 +89,7 @@ struct EngineDev {
     const double* sq1mmu2;      // [n_mu] sqrt(1 - mu^2)
     const double* lnmu;         // [n_mu] ln(mu)
     const double* wl;           // [4][n_mu] L_ell(mu) (2 ell + 1) / n_mu
+    const double* fv_x; const double* fv_f; int32_t fv_n;   // Voigt-profile HCD table
     const double* gk;           // [tables][n_mu][nkp]
     const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
     int32_t n_gk;
@@ -350,8 +351,20 @@ struct PkThread {
     double p0, p1, pq, Fq;
     const double* gk;
     size_t gk_stride;
-    bool hcd1, hcd2, div1, div2, same, arinyo, rogers, sinc, has_exp, mcdonald, paired, has_vd1, has_vd2, noexp;
+    bool hcd1, hcd2, div1, div2, same, arinyo, rogers, sinc, fvoigt, has_exp, mcdonald, paired, has_vd1, has_vd2, noexp;
+    const double* fv_x; const double* fv_f; int fv_n;
 };
+
+// np.interp(x, xp, fp, left=1, right=0) on an increasing table (power_spectrum.py:378)
+__device__ inline double fvoigt_interp(double x, const double* xp, const double* fp, int n)
+{
+    if (x < xp[0]) return 1.0;
+    if (x > xp[n - 1]) return 0.0;
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= x) lo = mid; else hi = mid; }
+    const double slope = (fp[hi] - fp[lo]) / (xp[hi] - xp[lo]);
+    return slope * (x - xp[lo]) + fp[lo];
+}
 
 // mu loop of one thread: accumulates the even moments  M_n = sum_j mu_j^(2n) P(k, mu_j), n = 0..3, of this
 // pipeline (s) and of its peak partner (q).
@@ -398,6 +411,7 @@ __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mu
                 if (arinyo) m_next = s_mubv[j + MS];
             }
             if (!SPEC && RARE && T.sinc) { const double x = T.k * mu * T.L0; F = sin(x) / x; }
+            if (!SPEC && RARE && T.fvoigt) F = fvoigt_interp(T.L0 * (T.k * mu), T.fv_x, T.fv_f, T.fv_n);
 
             // tracer amplitudes b_eff (1 + beta_eff mu^2) = b + b beta mu^2 + F b_hcd (1 + beta_hcd mu^2)
             const double hmu = fma(T.hbb, mu2, T.hb);
@@ -525,6 +539,8 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     T.same = d.same_tracer;
     T.rogers = d.hcd_model == VMX_HCD_ROGERS;
     T.sinc = d.hcd_model == VMX_HCD_SINC;
+    T.fvoigt = d.hcd_model == VMX_HCD_FVOIGT;
+    T.fv_x = D.fv_x; T.fv_f = D.fv_f; T.fv_n = D.fv_n;
 
     // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261): only the bias changes,
     // bias * beta is invariant under that step.
@@ -647,7 +663,7 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
         case PKV_PLAIN_PAIR: pk_mu_loop<MS, true, KM_BOTH_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
         case PKV_PLAIN_PAIR_VD: pk_mu_loop<MS, true, KM_BOTH_PLAIN, false, false, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
         default:
-            if (T.sinc || T.has_exp || T.mcdonald || T.div1 || T.div2)
+            if (T.sinc || T.fvoigt || T.has_exp || T.mcdonald || T.div1 || T.div2)
                 pk_mu_loop<MS, false, 0, false, false, 0, true>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
             else
                 pk_mu_loop<MS, false, 0, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q);

@@ -18,7 +18,7 @@ _lib = None
 VMX_MAX_ELL = 4
 VMX_MAX_SMOOTH = 3
 VMX_N_KERNELS = 12
-HCD = {'none': 0, 'Rogers': 1, 'sinc': 2}
+HCD = {'none': 0, 'Rogers': 1, 'sinc': 2, 'fvoigt': 3}
 NL = {'none': 0, 'arinyo': 1, 'mcdonald': 2}
 VD = {None: 0, 'gauss': 1, 'lorentz': 2}
 SCALE_UNIT, SCALE_AP_AT, SCALE_AISO_EPS, SCALE_PHI_ALPHA = 0, 1, 2, 3
@@ -106,6 +106,7 @@ def load_library():
     lib.vmx_set_template.argtypes = [C.c_void_p, C.c_int32, dptr, dptr, dptr, dptr, dptr, C.c_int32]
     lib.vmx_set_fftlog.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_double, C.c_double, C.c_int32]
     lib.vmx_add_gk_table.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.vmx_set_fvoigt_table.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_add_pipeline.argtypes = [C.c_void_p, C.POINTER(PipeDesc), C.c_int32, dptr, dptr, dptr, dptr, dptr]
     lib.vmx_add_item.argtypes = [C.c_void_p, C.POINTER(ItemDesc)]
     lib.vmx_item_add_metal.argtypes = [C.c_void_p, C.c_int32, C.POINTER(MetalDesc)]
@@ -141,7 +142,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_add_gk_table',
+    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_fvoigt_table', 'vmx_add_gk_table',
     'vmx_add_pipeline', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
@@ -245,8 +246,6 @@ class Lowering:
             raise NotImplementedError('single_multipole is not accelerated')
         if xi.relativistic or xi.asymmetry:
             raise NotImplementedError('relativistic / asymmetry odd multipoles are not accelerated')
-        if pk.hcd_model == 'fvoigt':
-            raise NotImplementedError('model-hcd = fvoigt is not accelerated')
         if xi.ell_max not in (0, 2, 4, 6):
             raise NotImplementedError(f'ell_max = {xi.ell_max} is not supported (even, <= 6)')
         is_peak = component == 'peak'
@@ -287,7 +286,10 @@ class Lowering:
             d.bias_hcd_slot = self.slot[name] if name in self.slot else self.need('bias_hcd')
             name = f'beta_hcd_{pipe.corr_name}'
             d.beta_hcd_slot = self.slot[name] if name in self.slot else self.need('beta_hcd')
-            d.l0_hcd_slot = self.need('L0_hcd') if pk.hcd_model == 'Rogers' else self.s('L0_sinc')
+            d.l0_hcd_slot = (self.need('L0_hcd') if pk.hcd_model == 'Rogers' else
+                             self.s('L0_sinc') if pk.hcd_model == 'sinc' else self.s('L0_fvoigt'))
+            if pk.hcd_model == 'fvoigt':
+                engine._set_fvoigt(pk.fvoigt_table)
 
         skip_nl = pk.skip_nl_in_peak and is_peak
         nl = 'none' if (pk.small_scale_nl is None or skip_nl) else pk.small_scale_nl
@@ -395,6 +397,16 @@ class Engine:
         if key not in self._gk:
             self._gk[key] = self._check(self.lib.vmx_add_gk_table(self._h, bs_rp, bs_rt))
         return self._gk[key]
+
+    def _set_fvoigt(self, table):
+        key = hash(np.ascontiguousarray(table).tobytes())
+        if getattr(self, '_fvoigt_key', None) == key:
+            return
+        if getattr(self, '_fvoigt_key', None) is not None:
+            raise NotImplementedError('all correlations must share one fvoigt table')
+        x, f = _f64(table[:, 0]), _f64(table[:, 1])
+        self._check(self.lib.vmx_set_fvoigt_table(self._h, _dp(x), _dp(f), x.size))
+        self._fvoigt_key = key
 
     def close(self):
         if self._h:

@@ -307,6 +307,15 @@ def _parser(path):
     return cfg
 
 
+def load_fvoigt_table(path, search_dirs=()):
+    """(k, F) table of the Voigt-profile HCD model: the reference's text file or its ``.npy`` twin."""
+    try:
+        return np.loadtxt(find_file(path, search_dirs))
+    except RuntimeError:
+        alt = str(path)[:-4] + '.npy' if str(path).endswith('.txt') else str(path) + '.npy'
+        return np.load(find_file(alt, [*search_dirs, *[Path(d) / 'inputs' for d in search_dirs]]))
+
+
 def _pk_options(section, bin_size_rp, bin_size_rt, search_dirs):
     opts = PkOptions(bin_size_rp=bin_size_rp, bin_size_rt=bin_size_rt)
     opts.use_gk = section.getboolean('model binning', True)
@@ -328,7 +337,7 @@ def _pk_options(section, bin_size_rp, bin_size_rt, search_dirs):
             if model is None:
                 raise ValueError('No fvoigt_model specified in config')
             path = model if '/' in model else f'fvoigt_models/Fvoigt_{model}.txt'
-            opts.fvoigt_table = np.loadtxt(find_file(path, search_dirs))
+            opts.fvoigt_table = load_fvoigt_table(path, search_dirs)
         elif 'sinc' in hcd:
             opts.hcd_model = 'sinc'
         else:
