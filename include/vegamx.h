@@ -167,6 +167,13 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
                      const double* mu, const double* z, const double* rel_z_evol,
                      const double* xi_growth);
 
+/* Odd-multipole terms of a cross-correlation component (correlation_func.py:150-155, pktoxi.py:321-382):
+ * coef [4][n_coef] = cubic B-spline coefficients (knots x0 + h i in ln r) of the Hamilton-FFTLog transforms of the
+ * component's isotropic linear spectrum, in the order rel ell=1, rel ell=3, asy ell=0, asy ell=2;
+ * slots = {Arel1, Arel3, Aasy0, Aasy2, Aasy3}. */
+int vmx_pipeline_set_odd_terms(vmx_engine* e, int32_t pipeline, const double* coef, int32_t n_coef, double x0,
+                               double h, int32_t relativistic, int32_t asymmetry, const int32_t* slots);
+
 /* Returns the item id (>= 0). */
 int vmx_add_item(vmx_engine* e, const vmx_item_desc* desc);
 int vmx_item_add_metal(vmx_engine* e, int32_t item, const vmx_metal_desc* desc);

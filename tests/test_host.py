@@ -50,7 +50,7 @@ def test_unsupported_options_fail_loudly():
     from vega_amd import engine as E
     prob = load_problem('configs/picca/main_cross.ini')
     low = E.Lowering(prob)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):        # old_fftlog = True: the legacy transform is not accelerated
         low.pipeline(_FakeEngine(), prob.items['test_7'].core, 'smooth')
 
 

@@ -64,6 +64,14 @@ def test_fvoigt_hcd():
     _check(prob, n_walkers=2)
 
 
+def test_relativistic_and_asymmetry_odd_multipoles():
+    prob = _fresh('joint')
+    cross = prob.items['lyalya_qso'].core
+    cross.xi.relativistic = cross.xi.asymmetry = True
+    prob.params.update({'Arel1': -13.5, 'Arel3': 1.0, 'Aasy0': 1.0, 'Aasy2': 1.0, 'Aasy3': 1.0})
+    _check(prob, n_walkers=2)
+
+
 def test_exp_smoothing_gauss_velocity_dispersion_croom():
     prob = _fresh('joint')
     cross = prob.items['lyalya_qso'].core

@@ -124,8 +124,8 @@ struct vmx_engine {
     std::vector<MetalHost*> metals;
     DevBuf<ItemDev> d_items;
     DevBuf<MetalDev> d_metals;
-    std::vector<double> h_bb;
-    DevBuf<double> bb_basis;
+    std::vector<double> h_bb, h_odd;
+    DevBuf<double> bb_basis, odd_coef;
 
     std::vector<int32_t> prior_slot;
     std::vector<double> prior_mean, prior_sigma;
@@ -452,6 +452,25 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     e->h_growth.insert(e->h_growth.end(), xi_growth, xi_growth + n);
     e->pipes.push_back(p);
     return (int)e->pipes.size() - 1;
+}
+
+int vmx_pipeline_set_odd_terms(vmx_engine* e, int32_t pipeline, const double* coef, int32_t n_coef, double x0,
+                               double h, int32_t relativistic, int32_t asymmetry, const int32_t* slots)
+{
+    REQUIRE(e && !e->finalized && coef && slots, "vmx_pipeline_set_odd_terms");
+    REQUIRE(pipeline >= 0 && pipeline < (int)e->pipes.size(), "pipeline id");
+    REQUIRE(n_coef >= 4 && h > 0.0, "spline description");
+    PipeDev& p = e->pipes[pipeline];
+    p.odd_rel = relativistic != 0; p.odd_asy = asymmetry != 0; p.odd_ncoef = n_coef;
+    p.odd_x0 = x0; p.odd_h = h;
+    for (int i = 0; i < 5; ++i) {
+        const bool needed = (i < 2) ? p.odd_rel : p.odd_asy;
+        REQUIRE(!needed || slots[i] >= 0, "amplitude slot of an odd-multipole term");
+        p.odd_slot[i] = slots[i];
+    }
+    p.odd_off = (int64_t)e->h_odd.size();
+    e->h_odd.insert(e->h_odd.end(), coef, coef + (size_t)4 * n_coef);
+    return 0;
 }
 
 int vmx_add_item(vmx_engine* e, const vmx_item_desc* desc)
@@ -820,6 +839,9 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     }
 
     if (e->bb_basis.upload(e->h_bb.data(), e->h_bb.size() ? e->h_bb.size() : 0)) return -2;
+    if (e->odd_coef.upload(e->h_odd.data(), e->h_odd.size())) return -2;
+    for (auto& p : e->pipes)
+        for (int i = 0; i < 5; ++i) REQUIRE(p.odd_slot[i] < n_params, "odd-multipole slot exceeds n_params");
     if (!e->prior_slot.empty()) {
         for (int s : e->prior_slot) REQUIRE(s < n_params, "prior slot exceeds n_params");
         if (e->d_prior_slot.upload(e->prior_slot.data(), e->prior_slot.size()) ||
@@ -851,6 +873,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.n_items = (int)e->items.size(); D.items = e->d_items.p;
     D.metals = e->d_metals.p; D.n_metals_total = (int)e->metals.size();
     D.bb_basis = e->bb_basis.p;
+    D.odd_coef = e->odd_coef.p;
     D.n_priors = (int)e->prior_slot.size();
     D.prior_slot = e->d_prior_slot.p; D.prior_mean = e->d_prior_mean.p; D.prior_sigma = e->d_prior_sigma.p;
     D.n_params = n_params;

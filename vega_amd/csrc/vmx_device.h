@@ -41,6 +41,11 @@ struct PipeDev {
     int32_t n_pad;        // per-walker stride of the xi buffer (zero tail)
     int64_t coord_off;    // offset into the coordinate arrays
     int64_t xi_off;       // offset into the xi buffer
+    // odd-multipole (relativistic / asymmetry) terms: static spline coefficients + amplitude slots
+    int32_t odd_rel, odd_asy, odd_ncoef;
+    int32_t odd_slot[5];
+    int64_t odd_off;
+    double odd_x0, odd_h;
 };
 
 struct BBTermDev {
@@ -106,6 +111,7 @@ struct EngineDev {
     const MetalDev* metals;
     int32_t n_metals_total;
     const double* bb_basis;
+    const double* odd_coef;
     // priors
     int32_t n_priors;
     const int32_t* prior_slot; const double* prior_mean; const double* prior_sigma;
@@ -1042,6 +1048,25 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
         double xr = sc[S_RAD_S] / (rs * rs) * (1.0 - sc[S_RAD_A] * (1.0 - ms * ms));
         xr *= exp(-rs * ((1.0 + ms) / sc[S_RAD_L] + 1.0 / sc[S_RAD_D]));
         xi += xr;
+    }
+    if (P.odd_rel || P.odd_asy) {
+        // reference pktoxi.py:321-382 on the rescaled coordinates (correlation_func.py:491-551)
+        const double* t = D.theta + (size_t)b * D.n_params;
+        const double x = log(rr);
+        const double u = (x - P.odd_x0) / P.odd_h;
+        int j = (int)floor(u);
+        if (j < 0) j = 0;
+        if (j > P.odd_ncoef - 4) j = P.odd_ncoef - 4;
+        const double tt = u - (double)j, t2 = tt * tt, t3 = t2 * tt, omt = 1.0 - tt;
+        const double w0 = omt * omt * omt, w1 = 3.0 * t3 - 6.0 * t2 + 4.0, w2 = -3.0 * t3 + 3.0 * t2 + 3.0 * tt + 1.0;
+        double sp[4];
+        for (int q = 0; q < 4; ++q) {
+            const double* cf = D.odd_coef + P.odd_off + (size_t)q * P.odd_ncoef + j;
+            sp[q] = (cf[0] * w0 + cf[1] * w1 + cf[2] * w2 + cf[3] * t3) * (1.0 / 6.0);
+        }
+        const double l1 = rmu, l3 = 0.5 * (5.0 * rmu * rmu - 3.0) * rmu;
+        if (P.odd_rel) xi += t[P.odd_slot[0]] * sp[0] * l1 + t[P.odd_slot[1]] * sp[1] * l3;
+        if (P.odd_asy) xi += (t[P.odd_slot[2]] * sp[2] - t[P.odd_slot[3]] * sp[3]) * rr * l1 + t[P.odd_slot[4]] * sp[3] * rr * l3;
     }
     D.xi[P.xi_off + (size_t)b * P.n_pad + bin] = xi;
 }

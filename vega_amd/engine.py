@@ -109,6 +109,8 @@ def load_library():
     lib.vmx_set_fvoigt_table.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_add_pipeline.argtypes = [C.c_void_p, C.POINTER(PipeDesc), C.c_int32, dptr, dptr, dptr, dptr, dptr]
     lib.vmx_add_item.argtypes = [C.c_void_p, C.POINTER(ItemDesc)]
+    lib.vmx_pipeline_set_odd_terms.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_double, C.c_double,
+                                               C.c_int32, C.c_int32, iptr]
     lib.vmx_item_add_metal.argtypes = [C.c_void_p, C.c_int32, C.POINTER(MetalDesc)]
     lib.vmx_item_add_broadband.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, iptr, dptr,
                                            C.c_int32]
@@ -143,7 +145,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_fvoigt_table', 'vmx_add_gk_table',
-    'vmx_add_pipeline', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
+    'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
     'vmx_set_profiling', 'vmx_get_timings', 'vmx_kernel_name']
@@ -244,8 +246,8 @@ class Lowering:
             raise NotImplementedError('old_fftlog (legacy Hamilton FFTLog) is not accelerated')
         if xi.single_multipole >= 0:
             raise NotImplementedError('single_multipole is not accelerated')
-        if xi.relativistic or xi.asymmetry:
-            raise NotImplementedError('relativistic / asymmetry odd multipoles are not accelerated')
+        if (xi.relativistic or xi.asymmetry) and self.prob.scale.two_alpha_smooth:
+            raise NotImplementedError('odd multipoles with two-alpha-smooth are not accelerated')
         if xi.ell_max not in (0, 2, 4, 6):
             raise NotImplementedError(f'ell_max = {xi.ell_max} is not supported (even, <= 6)')
         is_peak = component == 'peak'
@@ -420,11 +422,24 @@ class Engine:
             pass
 
     # ---- construction
-    def _add_pipeline(self, desc, pipe):
+    def _add_pipeline(self, desc, pipe, pk_lin=None):
         n = pipe.r.size
-        return self._check(self.lib.vmx_add_pipeline(
+        pid = self._check(self.lib.vmx_add_pipeline(
             self._h, C.byref(desc), n, _dp(_f64(pipe.r)), _dp(_f64(pipe.mu)), _dp(_f64(pipe.z)),
             _dp(_f64(pipe.rel_z_evol)), _dp(_f64(pipe.xi_growth))))
+        if pipe.xi.relativistic or pipe.xi.asymmetry:
+            # static splines of the odd-multipole terms of this component's linear spectrum
+            low, k = self.low, self.prob.k
+            rows = [fftlog_op.hamilton_spline(k, pk_lin, ell, kind)
+                    for kind, ell in (('rel', 1), ('rel', 3), ('asy', 0), ('asy', 2))]
+            coef = _f64(np.stack([r[0] for r in rows]))
+            slots = np.array([low.need(n_) if use else -1 for n_, use in (
+                ('Arel1', pipe.xi.relativistic), ('Arel3', pipe.xi.relativistic), ('Aasy0', pipe.xi.asymmetry),
+                ('Aasy2', pipe.xi.asymmetry), ('Aasy3', pipe.xi.asymmetry))], dtype=np.int32)
+            self._check(self.lib.vmx_pipeline_set_odd_terms(self._h, pid, _dp(coef), coef.shape[1], rows[0][1],
+                                                            rows[0][2], int(pipe.xi.relativistic),
+                                                            int(pipe.xi.asymmetry), _ip(slots)))
+        return pid
 
     def _build(self):
         prob, low, lib = self.prob, self.low, self.lib
@@ -448,8 +463,8 @@ class Engine:
         off = 0
         self.pipe_index = {}
         for qi, (name, item) in enumerate(prob.items.items()):
-            peak = self._add_pipeline(low.pipeline(self, item.core, 'peak'), item.core)
-            smooth = self._add_pipeline(low.pipeline(self, item.core, 'smooth'), item.core)
+            peak = self._add_pipeline(low.pipeline(self, item.core, 'peak'), item.core, pk_peak)
+            smooth = self._add_pipeline(low.pipeline(self, item.core, 'smooth'), item.core, prob.pk_smooth)
             self.pipe_index[(name, 'peak')] = peak
             self.pipe_index[(name, 'smooth')] = smooth
             idesc = ItemDesc(item.model_grid.size, item.dist_grid.size, peak, smooth, low.need('bao_amp'))
@@ -476,7 +491,7 @@ class Engine:
                     fast = bool(opts['fast_metal_bias'])
                     pid = self._add_pipeline(
                         low.pipeline(self, pair.pipeline, 'full', fast_metals=fast, beta_names=betas,
-                                     growth_rate_override=override), pair.pipeline)
+                                     growth_rate_override=override), pair.pipeline, prob.pk_full)
                     self.pipe_index[(name, pair.names)] = pid
                     md = MetalDesc()
                     md.pipeline = pid

@@ -75,3 +75,34 @@ def xi_operator(k, ell):
     if np.max(np.abs(np.diff(ln_r) - h)) > 1e-10 * h:
         raise ValueError('the template k grid is not log-uniform; the engine needs uniform ln r knots')
     return notaknot_bspline_matrix(n) @ H, float(ln_r[0]), float(h), n
+
+
+def hamilton_spline(k, pk, ell, kind):
+    """B-spline coefficients of the odd-multipole terms of the cross-correlation.
+
+    The reference computes the relativistic (``kind='rel'``, ell = 1, 3) and standard-asymmetry
+    (``kind='asy'``, ell = 0, 2) contributions with its legacy in-repo FFTLog (Hamilton 2000) applied to the
+    isotropic linear spectrum, followed by a cubic interpolating spline in ln r on knots shifted by half a step
+    (reference vega/pktoxi.py:230-279, :321-382).  The linear spectrum is static, so the whole chain collapses
+    to one coefficient vector per (component, ell).  Returns (coef [n + 2], x0, h).
+    """
+    k = np.asarray(k, dtype=float)
+    pk = np.asarray(pk, dtype=float)
+    n_pts = k.size
+    span = np.log(k.max() / k[0])
+    m = n_pts * np.fft.fftfreq(n_pts)
+    n_pow = 1.0 if kind == 'rel' else 2.0
+    q = 2 - n_pow - 0.5
+    z = q + 2j * np.pi * m / span
+    mu = ell + 0.5
+    um = k[0] ** (-2j * np.pi * m / span) * 2 ** z * np.exp(loggamma((mu + 1 + z) / 2) - loggamma((mu + 1 - z) / 2))
+    um[0] = um[0].real
+    spec = np.fft.ifft(np.fft.fft(pk * k ** n_pow * np.sqrt(np.pi / 2)) * um)
+    r = np.exp(-m * span / n_pts)
+    order = np.argsort(r)
+    r = r[order]
+    xi = (spec[order] / r ** (3 - n_pow)).real
+    xi[-1] = 0.0                                    # reference pktoxi.py:275
+    h = span / n_pts
+    x0 = np.log(r[0]) - h / 2                       # knots at ln r - dr/2 (reference pktoxi.py:276)
+    return notaknot_bspline_matrix(n_pts) @ xi, float(x0), float(h)
