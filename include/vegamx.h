@@ -153,6 +153,9 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
  * pktoxi.py:144.  op is row-major [n_coef][nk]; n_coef = n_knots + 2. */
 int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n_coef,
                    double x0, double h, int32_t n_knots);
+/* Evaluate the xi splines outside their knot range by polynomial extension instead of flagging the walker
+ * (the reference's legacy old_fftlog path uses splev, which extrapolates; pktoxi.py:276-277). */
+int vmx_set_spline_extrapolation(vmx_engine* e, int32_t enabled);
 
 /* Voigt-profile table of model-hcd = fvoigt: F(L0 k_par) by linear interpolation in (x, f), 1 below the table and
  * 0 above it (np.interp(..., left=1, right=0), power_spectrum.py:360-380).  x must be increasing. */

@@ -72,6 +72,21 @@ def test_pinned_log_likelihood_four_correlations():
     vega.close()
 
 
+def test_picca_golden_vectors_through_the_engine():
+    """reference tests/test_vega.py:21-44: the 7 auto + 7 cross picca benchmark vectors (np.allclose defaults),
+    here produced by the HIP engine with the legacy transform as a static operator."""
+    from vega_amd import VegaInterface
+    bench = np.load(GOLDEN / 'inputs' / 'picca_bench_data.npz')
+    for kind, main, hdu in (('auto', 'configs/picca/main.ini', 1), ('cross', 'configs/picca/main_cross.ini', 2)):
+        prob = load_problem(main, fiducial_overrides=(('Omega_de', None),))
+        vega = VegaInterface(None, problem=prob, max_batch=1)
+        model = vega.compute_model()
+        assert len(model) == 7
+        for name, xi in model.items():
+            assert np.allclose(xi, bench[f'{hdu}/{kind}_{name}']), (kind, name)
+        vega.close()
+
+
 def test_synthetic_distortion_and_covariance():
     """Dense distortion matrix + dense inverse covariance: the MFMA / streaming products."""
     from vega_amd import VegaInterface, synthetic

@@ -48,10 +48,36 @@ def test_lowering_resolves_the_reference_lookups():
 
 def test_unsupported_options_fail_loudly():
     from vega_amd import engine as E
-    prob = load_problem('configs/picca/main_cross.ini')
+    prob = load_problem('auto')
     low = E.Lowering(prob)
-    with pytest.raises(NotImplementedError):        # old_fftlog = True: the legacy transform is not accelerated
-        low.pipeline(_FakeEngine(), prob.items['test_7'].core, 'smooth')
+    core = prob.items['lyalya_lyalya'].core
+    core.xi.single_multipole = 2
+    try:
+        with pytest.raises(NotImplementedError):
+            low.pipeline(_FakeEngine(), core, 'smooth')
+    finally:
+        core.xi.single_multipole = -1
+
+
+def test_hamilton_operator_is_the_legacy_transform():
+    from vega_amd.fftlog_op import hamilton_xi_operator
+    from oracle.vega_cpu import hamilton_multipoles, PkGrid
+    prob = load_problem('auto')
+    grid = PkGrid(prob.k, 1000)
+    pk2d = prob.pk_smooth * (1 + 1.5 * grid.mu**2)**2 * np.exp(-(prob.k * grid.mu)**2)
+    ar = np.linspace(4., 300., 500)
+    ref = hamilton_multipoles(ar, prob.k, pk2d, (0, 2, 4), grid.mu, 1e-3)
+    for i, ell in enumerate((0, 2, 4)):
+        from scipy import special
+        pk_ell = np.sum(1e-3 * special.legendre(ell)(grid.mu) * pk2d, axis=0) * (2 * ell + 1)
+        op, x0, h, n = hamilton_xi_operator(prob.k, ell)
+        c = op @ pk_ell
+        u = (np.log(ar) - x0) / h
+        j = np.floor(u).astype(int)
+        t = u - j
+        s = (c[j] * (1 - t)**3 + c[j + 1] * (3 * t**3 - 6 * t**2 + 4)
+             + c[j + 2] * (-3 * t**3 + 3 * t**2 + 3 * t + 1) + c[j + 3] * t**3) / 6
+        assert np.abs(s - ref[i]).max() <= 1e-12 * np.abs(ref[i]).max()
 
 
 def test_masks_and_sizes_match_the_reference_fixture_facts():

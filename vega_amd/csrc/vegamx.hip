@@ -109,6 +109,7 @@ struct vmx_engine {
     int n_coef = 0, ncp = 0, n_knots = 0;
     DevBuf<double> op;          // [VMX_MAX_ELL][ncp][nkp]
     bool op_set[VMX_MAX_ELL] = {false, false, false, false};
+    bool extrapolate = false;
     double x0[VMX_MAX_ELL] = {0}, h[VMX_MAX_ELL] = {0};
 
     std::vector<PipeDev> pipes;
@@ -405,6 +406,13 @@ int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n
                        (size_t)e->nk * sizeof(double), (size_t)e->nk * sizeof(double), n_coef,
                        hipMemcpyHostToDevice));
     e->x0[ell_index] = x0; e->h[ell_index] = h; e->op_set[ell_index] = true;
+    return 0;
+}
+
+int vmx_set_spline_extrapolation(vmx_engine* e, int32_t enabled)
+{
+    REQUIRE(e && !e->finalized, "vmx_set_spline_extrapolation");
+    e->extrapolate = enabled != 0;
     return 0;
 }
 
@@ -864,7 +872,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
     D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p; D.lnmu = e->lnmu.p;
     D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.n_gk = (int)e->gk_tables.size();
-    D.n_coef = e->n_coef; D.ncp = e->ncp;
+    D.n_coef = e->n_coef; D.ncp = e->ncp; D.extrapolate = e->extrapolate ? 1 : 0;
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
     }

@@ -100,6 +100,7 @@ struct EngineDev {
     int32_t n_gk;
     // fftlog / spline
     int32_t n_coef, ncp;        // coefficients per ell, padded
+    int32_t extrapolate;        // splines extend beyond their knots (legacy transform) instead of flagging
     double x0[VMX_MAX_ELL], h[VMX_MAX_ELL], xlast[VMX_MAX_ELL];
     // pipelines
     int32_t n_pipe;
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
         const size_t col = (size_t)b * D.n_pipe + p;
         bool oob = false;
         for (int e = 0; e < d.n_ell; ++e) {
-            if (x < D.x0[e] || x > D.xlast[e]) { oob = true; continue; }   // VegaBoundsError (pktoxi.py:149-152)
+            if (!D.extrapolate && (x < D.x0[e] || x > D.xlast[e])) { oob = true; continue; }   // VegaBoundsError (pktoxi.py:149-152)
             const double u = (x - D.x0[e]) / D.h[e];
             int j = (int)floor(u);
             if (j < 0) j = 0;

@@ -106,6 +106,7 @@ def load_library():
     lib.vmx_set_template.argtypes = [C.c_void_p, C.c_int32, dptr, dptr, dptr, dptr, dptr, C.c_int32]
     lib.vmx_set_fftlog.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_double, C.c_double, C.c_int32]
     lib.vmx_add_gk_table.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.vmx_set_spline_extrapolation.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_fvoigt_table.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_add_pipeline.argtypes = [C.c_void_p, C.POINTER(PipeDesc), C.c_int32, dptr, dptr, dptr, dptr, dptr]
     lib.vmx_add_item.argtypes = [C.c_void_p, C.POINTER(ItemDesc)]
@@ -144,7 +145,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_fvoigt_table', 'vmx_add_gk_table',
+    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table',
     'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
@@ -242,8 +243,6 @@ class Lowering:
     def pipeline(self, engine, pipe, component, fast_metals=False, beta_names=(None, None),
                  growth_rate_override=None):
         pk, xi = pipe.pk, pipe.xi
-        if xi.old_fftlog:
-            raise NotImplementedError('old_fftlog (legacy Hamilton FFTLog) is not accelerated')
         if xi.single_multipole >= 0:
             raise NotImplementedError('single_multipole is not accelerated')
         if (xi.relativistic or xi.asymmetry) and self.prob.scale.two_alpha_smooth:
@@ -453,8 +452,14 @@ class Engine:
             raise NotImplementedError('all correlations must share num_bins_muk')
         self._check(lib.vmx_set_template(self._h, k.size, _dp(k), _dp(pk_peak), _dp(_f64(prob.pk_smooth)),
                                          _dp(_f64(prob.pk_full)), _dp(delta2), n_mu.pop()))
+        old = {p.xi.old_fftlog for it in prob.items.values() for p in [it.core] + [m.pipeline for m in it.metals]}
+        if len(old) != 1:
+            raise NotImplementedError('old_fftlog must be the same for every correlation')
+        self.old_fftlog = old.pop()
+        if self.old_fftlog:
+            self._check(lib.vmx_set_spline_extrapolation(self._h, 1))
         for i, ell in enumerate((0, 2, 4, 6)):
-            op, x0, h, n_knots = fftlog_op.xi_operator(k, ell)
+            op, x0, h, n_knots = (fftlog_op.hamilton_xi_operator if self.old_fftlog else fftlog_op.xi_operator)(k, ell)
             op = _f64(op)
             self._check(lib.vmx_set_fftlog(self._h, i, _dp(op), op.shape[0], x0, h, n_knots))
 

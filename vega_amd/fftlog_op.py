@@ -106,3 +106,28 @@ def hamilton_spline(k, pk, ell, kind):
     h = span / n_pts
     x0 = np.log(r[0]) - h / 2                       # knots at ln r - dr/2 (reference pktoxi.py:276)
     return notaknot_bspline_matrix(n_pts) @ xi, float(x0), float(h)
+
+
+def hamilton_xi_operator(k, ell):
+    """(OP, x0, h, n_knots) for the reference's legacy transform (``old_fftlog = True``): the Hamilton FFTLog of
+    ``PktoXi.Pk2Mp`` (reference vega/pktoxi.py:230-279) applied to a multipole P_ell(k), followed by its cubic
+    spline on the half-step-shifted ln r knots.  Like :func:`xi_operator` it is linear in P_ell; unlike the
+    mcfit path its spline is evaluated outside the knot range by polynomial extension (``splev``), without error.
+    """
+    k = np.asarray(k, dtype=float)
+    n_pts = k.size
+    span = np.log(k.max() / k[0])
+    m = n_pts * np.fft.fftfreq(n_pts)
+    z = -0.5 + 2j * np.pi * m / span                 # q = 2 - n - 1/2 with n = 2
+    mu = ell + 0.5
+    um = k[0] ** (-2j * np.pi * m / span) * 2 ** z * np.exp(loggamma((mu + 1 + z) / 2) - loggamma((mu + 1 - z) / 2))
+    um[0] = um[0].real
+    pre = (-1.0) ** (ell // 2) / 2 / np.pi ** 2 * k ** 2 * np.sqrt(np.pi / 2)
+    spec = np.fft.ifft(np.fft.fft(np.diag(pre), axis=0) * um[:, None], axis=0)
+    r = np.exp(-m * span / n_pts)
+    order = np.argsort(r)
+    r = r[order]
+    H = (spec[order] / r[:, None]).real              # / r^(3 - n)
+    H[-1, :] = 0.0                                   # xi_loc[-1] = 0 (reference pktoxi.py:275)
+    h = span / n_pts
+    return notaknot_bspline_matrix(n_pts) @ H, float(np.log(r[0]) - h / 2), float(h), n_pts
