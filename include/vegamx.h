@@ -111,6 +111,8 @@ typedef struct {
     int32_t croom_slot[2];          /* croom_par0, croom_par1 */
     int32_t radiation;              /* QSO radiation term (correlation_func.py:446-489) */
     int32_t rad_slot[4];            /* strength, asymmetry, lifetime, decrease */
+    int32_t uv_shotnoise;           /* UV-background shot noise (correlation_func.py:649-686) */
+    int32_t uvsn_slot[3];           /* uv_shotnoise_amp, lambda_uv, bias_gamma (or bias_gamma_e) */
     double  z_eff;
 } vmx_pipe_desc;
 
@@ -177,9 +179,19 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
 int vmx_pipeline_set_odd_terms(vmx_engine* e, int32_t pipeline, const double* coef, int32_t n_coef, double x0,
                                double h, int32_t relativistic, int32_t asymmetry, const int32_t* slots);
 
+/* A(tau) table of the UV shot-noise term on the uniform grid tau0 + dtau i (correlation_func.py:597-647):
+ * np.interp with left = a[0], right = 0. */
+int vmx_set_shotnoise_table(vmx_engine* e, const double* a, int32_t n, double tau0, double dtau);
+
 /* Returns the item id (>= 0). */
 int vmx_add_item(vmx_engine* e, const vmx_item_desc* desc);
 int vmx_item_add_metal(vmx_engine* e, int32_t item, const vmx_metal_desc* desc);
+
+/* Additive template of the non-peak component: v += amp * vec[bin] before the pre-distortion broadband
+ * (DESI instrumental systematics, model.py:133-135, correlation_func.py:553-595).  amp = theta[slot], or
+ * default_amp when slot = -1. */
+int vmx_item_set_additive_template(vmx_engine* e, int32_t item, const double* vec, int32_t n_model,
+                                   int32_t slot, double default_amp);
 
 /* Broadband term (broadband_poly.py:119-198).
  *  VMX_BB_POLY: slots[n_coef] coefficient slots, basis [n_coef][n] = r1^i r2^j per coefficient;

@@ -447,6 +447,53 @@ def qso_radiation(pipe, params, rescaled_r, rescaled_mu):
     return xi_rad
 
 
+_SHOTNOISE_A = {}
+
+
+def shotnoise_A(ntau=100, nrho=10000):
+    """A(tau) of Gontcho A Gontcho et al. 2014, eq. 19 (reference correlation_func.py:597-626)."""
+    key = (ntau, nrho)
+    if key not in _SHOTNOISE_A:
+        from scipy.special import expn
+        tau = np.linspace(0.01, 5, ntau)
+        a = np.zeros(tau.size)
+        rho = np.linspace(0.0001, 10, nrho)
+        drho = rho[1] - rho[0]
+        for i, t in enumerate(tau):
+            a[i] = -np.sum(drho * np.exp(-rho) / rho * (
+                expn(1, rho * np.sqrt(1 + (t / rho)**2)) - expn(1, rho * np.abs(1 - t / rho))))
+        _SHOTNOISE_A[key] = (tau, a)
+    return _SHOTNOISE_A[key]
+
+
+def uv_shotnoise(pipe, params):
+    """reference correlation_func.py:649-686 (unrescaled coordinates)"""
+    amp = params['uv_shotnoise_amp']
+    lam = params['lambda_uv']
+    if 'bias_gamma' in params:
+        bg = params['bias_gamma']
+    elif 'bias_gamma_e' in params:
+        bg = params['bias_gamma_e']
+    else:
+        raise ValueError('UV shotnoise needs bias_gamma or bias_gamma_e')
+    tau, a = shotnoise_A()
+    r = pipe.r
+    return bg**2 * amp * lam / r * np.interp(r / lam, tau, a, left=a[0], right=0)
+
+
+def desi_instrumental_systematics(item, params):
+    """reference correlation_func.py:553-595 (auto-correlations only; applied to the non-peak component)"""
+    pipe = item.core
+    rp = pipe.r * pipe.mu
+    rt = pipe.r * np.sqrt(1 - pipe.mu**2)
+    b = params.get('desi_inst_sys_amp', 0.0003189935987295203)
+    w = (rp > 0) & (rp < item.rp_binsize)
+    corr = np.zeros(rt.shape)
+    table = item.inst_sys_table
+    corr[w] = b * interpolate.interp1d(table[:, 0], table[:, 1], kind='linear')(rt[w])
+    return corr
+
+
 def correlation_function(prob, pipe, grid, pk, pk_lin, params, taps=None):
     """CorrelationFunction.compute (reference correlation_func.py:117-198)."""
     delta_rp = 0.
@@ -478,6 +525,8 @@ def correlation_function(prob, pipe, grid, pk, pk_lin, params, taps=None):
             xa = (params['Aasy0'] * x[0, :] - params['Aasy2'] * x[1, :]) * rr2 * _LEGENDRE[1](rmu2)
             xa = xa + params['Aasy3'] * x[1, :] * rr2 * _LEGENDRE[3](rmu2)
             xi = xi + xa
+    if pipe.xi.uv_shotnoise:
+        xi = xi + uv_shotnoise(pipe, params)
     return xi
 
 
@@ -588,6 +637,8 @@ def _component(prob, item, params, pk_lin, component, xi_metals=None, taps=None)
             xi = xi + xi_metals
         elif not item.metal_opts['no_metal_decomp']:
             xi = xi + metals_compute(prob, item, grid, params, pk_lin)
+    if item.inst_sys_table is not None and component != 'peak':
+        xi = xi + desi_instrumental_systematics(item, params)     # reference model.py:133-135
     if item.broadband:
         xi = xi * broadband(item, params, 'pre-mul')
         xi = xi + broadband(item, params, 'pre-add')

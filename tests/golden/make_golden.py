@@ -76,6 +76,11 @@ def convert_inputs():
     # HCD Voigt-profile table (data) used by model-hcd = fvoigt
     (out / 'fvoigt_models').mkdir(exist_ok=True)
     np.save(out / 'fvoigt_models' / 'Fvoigt_exp.npy', np.loadtxt(REF / 'vega/models/fvoigt_models/Fvoigt_exp.txt'))
+    # DESI instrumental-systematics table (data)
+    import shutil
+    (out / 'instrumental_systematics').mkdir(exist_ok=True)
+    shutil.copy(REF / 'vega/models/instrumental_systematics/desi-instrument-syst-for-forest-auto-correlation.csv',
+                out / 'instrumental_systematics')
 
 
 # ----------------------------------------------------------------------------- configs
@@ -127,6 +132,14 @@ def derive_configs():
                 if not metals:
                     text = re.sub(r'\[metals\][^\[]*', '', text)
                 (d / f'{it}.ini').write_text(text)
+    # auto-correlation with the UV shot-noise and DESI instrumental-systematics terms switched on
+    d = cfg_out / 'auto_extras'
+    d.mkdir(exist_ok=True)
+    (d / 'main.ini').write_text(re.sub(r'ini files = .*', 'ini files = configs/auto_extras/lyalya_lyalya.ini', main)
+                                .replace('[parameters]', '[parameters]\nuv_shotnoise_amp = 0.02\ndesi_inst_sys_amp = 0.0004'))
+    text = re.sub(r'\[metals\][^\[]*', '', (cfg_out / 'full4' / 'lyalya_lyalya.ini').read_text())
+    (d / 'lyalya_lyalya.ini').write_text(text.replace('[model]', '[model]\nUVB-shotnoise = True\n'
+                                                      'desi-instrumental-systematics = True'))
     print('wrote configs under', cfg_out)
 
 
@@ -328,6 +341,31 @@ def dump_mc(VegaInterface):
         print('mc: chi2 of the fiducial against the two mocks', out['mock0/chi2_fid'], out['mock1/chi2_fid'])
 
 
+def dump_extras(VegaInterface):
+    """Additive terms outside the default test configuration: UV-background shot noise and the DESI
+    instrumental-systematics model, both switched on for the auto-correlation (fiducial point + one walker)."""
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_lyalya'], False)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(item.read_text().replace('[model]', '[model]\nUVB-shotnoise = True\n'
+                                                 'desi-instrumental-systematics = True'))
+        mp = Path(main)
+        mp.write_text(mp.read_text().replace('[parameters]', '[parameters]\nuv_shotnoise_amp = 0.02\n'
+                                             'desi_inst_sys_amp = 0.0004'))
+        vega = VegaInterface(main)
+        out = {'fid/chi2': vega.chi2(), 'fid/model': vega.compute_model(run_init=False)['lyalya_lyalya']}
+        names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 5)
+        _reset_caches(vega)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[walkers[0][n] for n in names]])
+        out['walker0/chi2'] = vega.chi2(walkers[0])
+        _reset_caches(vega)
+        out['walker0/model'] = vega.compute_model(walkers[0], run_init=False)['lyalya_lyalya']
+        np.savez_compressed(HERE / 'expected_extras.npz', **out)
+        print('extras: chi2', out['fid/chi2'], out['walker0/chi2'])
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -335,12 +373,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -351,3 +389,5 @@ if __name__ == '__main__':
         dump_picca(VI)
     if 'mc' in what:
         dump_mc(VI)
+    if 'extras' in what:
+        dump_extras(VI)

@@ -227,3 +227,15 @@ def test_fftlog_matrix_is_the_transform():
         r, xi = t(f)
         sel = (r > 0.5) & (r < 1000.)      # the bins only ever ask for separations of a few to ~600 Mpc/h
         np.testing.assert_allclose((t.matrix() @ f)[sel], xi[sel], rtol=0, atol=1e-12 * np.abs(xi[sel]).max())
+
+
+def test_uv_shotnoise_and_instrumental_systematics_match_reference():
+    """Additive terms pinned by the unmodified reference (tests/golden/expected_extras.npz)."""
+    prob = load_problem('auto_extras')
+    exp = np.load(GOLDEN / 'expected_extras.npz')
+    assert oc.chi2(prob) == pytest.approx(float(exp['fid/chi2']), rel=1e-12)
+    np.testing.assert_allclose(oc.compute_model(prob)['lyalya_lyalya'], exp['fid/model'], rtol=1e-11, atol=1e-16)
+    pars = _params(exp['param_names'], exp['theta'][0])
+    assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-12)
+    np.testing.assert_allclose(oc.compute_model(prob, pars)['lyalya_lyalya'], exp['walker0/model'],
+                               rtol=1e-11, atol=1e-16)

@@ -177,3 +177,18 @@ def test_metals_with_biases_inside_pk_and_hcd_division():
         pair.pipeline.pk.hcd_model = 'Rogers'
         pair.pipeline.pk.uvb = True
     _check(prob, n_walkers=1)
+
+
+def test_uv_shotnoise_and_instrumental_systematics():
+    """Against the oracle and against the reference's own output (tests/golden/expected_extras.npz)."""
+    from vega_amd import VegaInterface
+    prob = _fresh('auto_extras')
+    exp = np.load(GOLDEN / 'expected_extras.npz')
+    vega = VegaInterface(None, problem=prob, max_batch=2)
+    assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert vega.chi2(pars) == pytest.approx(float(exp['walker0/chi2']), rel=CHI2_RTOL)
+    got = vega.compute_model(pars)['lyalya_lyalya']
+    assert np.abs(got - exp['walker0/model']).max() <= XI_RTOL * np.abs(exp['walker0/model']).max()
+    vega.close()
+    _check(prob, n_walkers=2)

@@ -86,7 +86,7 @@ struct MetalHost {
 struct ItemHost {
     ItemDev dev{};
     std::vector<MetalHost*> metals;
-    DevBuf<double> dm, cinv, data, vec, dist, res, z, mock_pool;
+    DevBuf<double> dm, cinv, data, vec, dist, res, z, mock_pool, add_vec;
     int n_mocks = 0;
     DevBuf<int32_t> inv_mask;
     std::vector<int32_t> mask_idx;
@@ -126,7 +126,8 @@ struct vmx_engine {
     DevBuf<ItemDev> d_items;
     DevBuf<MetalDev> d_metals;
     std::vector<double> h_bb, h_odd;
-    DevBuf<double> bb_basis, odd_coef;
+    DevBuf<double> bb_basis, odd_coef, sn_a;
+    int sn_n = 0; double sn_tau0 = 0.0, sn_dtau = 1.0;
 
     std::vector<int32_t> prior_slot;
     std::vector<double> prior_mean, prior_sigma;
@@ -481,6 +482,28 @@ int vmx_pipeline_set_odd_terms(vmx_engine* e, int32_t pipeline, const double* co
     return 0;
 }
 
+int vmx_set_shotnoise_table(vmx_engine* e, const double* a, int32_t n, double tau0, double dtau)
+{
+    REQUIRE(e && !e->finalized && a && n >= 2 && dtau > 0.0, "vmx_set_shotnoise_table");
+    HIP_OK(hipSetDevice(e->device));
+    if (e->sn_a.upload(a, n)) return -2;
+    e->sn_n = n; e->sn_tau0 = tau0; e->sn_dtau = dtau;
+    return 0;
+}
+
+int vmx_item_set_additive_template(vmx_engine* e, int32_t item, const double* vec, int32_t n_model, int32_t slot,
+                                   double default_amp)
+{
+    REQUIRE(e && !e->finalized && vec, "vmx_item_set_additive_template");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(n_model == it->dev.d.n_model, "template size");
+    HIP_OK(hipSetDevice(e->device));
+    if (it->add_vec.upload(vec, n_model)) return -2;
+    it->dev.add_vec = it->add_vec.p; it->dev.add_slot = slot; it->dev.add_default = default_amp;
+    return 0;
+}
+
 int vmx_add_item(vmx_engine* e, const vmx_item_desc* desc)
 {
     if (!e || e->finalized || !desc) return fail(-1, "invalid argument: vmx_add_item");
@@ -495,6 +518,7 @@ int vmx_add_item(vmx_engine* e, const vmx_item_desc* desc)
     it->dev.n_model_pad = vmx_pad(desc->n_model);
     it->dev.n_dist_pad = vmx_pad(desc->n_dist);
     it->dev.metal_begin = (int)e->metals.size();
+    it->dev.add_vec = nullptr; it->dev.add_slot = -1; it->dev.add_default = 0.0;
     e->items.push_back(it);
     return (int)e->items.size() - 1;
 }
@@ -714,6 +738,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         REQUIRE((d.exp_par_slot >= 0) == (d.exp_per_slot >= 0), "exp smoothing slots");
         REQUIRE(d.scale_mode == VMX_SCALE_UNIT || (d.scale_slot[0] >= 0 && d.scale_slot[1] >= 0), "scale slots");
         if (d.radiation) for (int i = 0; i < 4; ++i) REQUIRE(d.rad_slot[i] >= 0 && slot_ok(d.rad_slot[i]), "radiation slots");
+        if (d.uv_shotnoise) {
+            for (int i = 0; i < 3; ++i) REQUIRE(d.uvsn_slot[i] >= 0 && slot_ok(d.uvsn_slot[i]), "UV shot-noise slots");
+            REQUIRE(e->sn_n >= 2, "UV shot noise needs vmx_set_shotnoise_table");
+        }
     }
     for (auto* m : e->metals) {
         const vmx_metal_desc& d = m->dev.d;
@@ -727,6 +755,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     }
     for (auto* it : e->items) {
         REQUIRE(slot_ok(it->dev.d.bao_amp_slot), "bao_amp slot exceeds n_params");
+        REQUIRE(slot_ok(it->dev.add_slot), "additive-template slot exceeds n_params");
         for (int pos = 0; pos < 4; ++pos)
             for (int q = 0; q < it->dev.n_bb[pos]; ++q)
                 for (int c = 0; c < it->dev.bb[pos][q].n_coef; ++c)
@@ -882,6 +911,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.metals = e->d_metals.p; D.n_metals_total = (int)e->metals.size();
     D.bb_basis = e->bb_basis.p;
     D.odd_coef = e->odd_coef.p;
+    D.sn_a = e->sn_a.p; D.sn_n = e->sn_n; D.sn_tau0 = e->sn_tau0; D.sn_dtau = e->sn_dtau;
     D.n_priors = (int)e->prior_slot.size();
     D.prior_slot = e->d_prior_slot.p; D.prior_mean = e->d_prior_mean.p; D.prior_sigma = e->d_prior_sigma.p;
     D.n_params = n_params;

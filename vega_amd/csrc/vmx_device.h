@@ -69,6 +69,7 @@ struct ItemDev {
     int32_t n_bb[4];
     BBTermDev bb[4][VMX_MAX_BB];
     int64_t model_off;                // offset of this item in the per-walker model output
+    const double* add_vec; int32_t add_slot; double add_default;   // additive template of the smooth component
     int64_t masked_off;               // offset in the concatenated masked vector (global-cov mode)
     // device arrays
     const double* dm;  int32_t dm_ld;         // distortion matrix or null
@@ -113,6 +114,7 @@ struct EngineDev {
     int32_t n_metals_total;
     const double* bb_basis;
     const double* odd_coef;
+    const double* sn_a; int32_t sn_n; double sn_tau0, sn_dtau;     // UV shot-noise A(tau) table
     // priors
     int32_t n_priors;
     const int32_t* prior_slot; const double* prior_mean; const double* prior_sigma;
@@ -1050,6 +1052,18 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
         xr *= exp(-rs * ((1.0 + ms) / sc[S_RAD_L] + 1.0 / sc[S_RAD_D]));
         xi += xr;
     }
+    if (d.uv_shotnoise) {
+        // reference correlation_func.py:649-686 on the unrescaled separation
+        const double* t = D.theta + (size_t)b * D.n_params;
+        const double amp = t[d.uvsn_slot[0]], lam = t[d.uvsn_slot[1]], bg = t[d.uvsn_slot[2]];
+        const double tau = r / lam;
+        double a;
+        const double pos = (tau - D.sn_tau0) / D.sn_dtau;
+        if (pos <= 0.0) a = D.sn_a[0];
+        else if (pos >= (double)(D.sn_n - 1)) a = (pos == (double)(D.sn_n - 1)) ? D.sn_a[D.sn_n - 1] : 0.0;
+        else { const int j = (int)pos; const double f = pos - (double)j; a = D.sn_a[j] + f * (D.sn_a[j + 1] - D.sn_a[j]); }
+        xi += bg * bg * amp * lam / r * a;
+    }
     if (P.odd_rel || P.odd_asy) {
         // reference pktoxi.py:321-382 on the rescaled coordinates (correlation_func.py:491-551)
         const double* t = D.theta + (size_t)b * D.n_params;
@@ -1118,6 +1132,7 @@ __global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item)
         else { const PipeDev& Pm = D.pipes[md.d.pipeline]; x = D.xi[Pm.xi_off + (size_t)b * Pm.n_pad + bin]; }
         v = fma(f, x, v);
     }
+    if (it.add_vec) v = fma(it.add_slot >= 0 ? t[it.add_slot] : it.add_default, it.add_vec[bin], v);
     if (it.n_bb[VMX_BB_PRE_MUL]) v *= bb_total(D, it, VMX_BB_PRE_MUL, t, bin, it.d.n_model);
     if (it.n_bb[VMX_BB_PRE_ADD]) v += (1.0 + bao) * bb_total(D, it, VMX_BB_PRE_ADD, t, bin, it.d.n_model);
     it.vec[(size_t)b * it.n_model_pad + bin] = v;

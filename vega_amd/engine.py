@@ -10,7 +10,7 @@ from pathlib import Path
 
 import numpy as np
 
-from . import fftlog_op
+from . import fftlog_op, static_terms
 
 _LIB_PATH = Path(__file__).resolve().parent / 'libvegamx.so'
 _lib = None
@@ -60,7 +60,8 @@ class PipeDesc(C.Structure):
         ('vd_kind', C.c_int32), ('damping_scale', C.c_double), ('damping_power', C.c_int32),
         ('n_ell', C.c_int32), ('scale_mode', C.c_int32), ('scale_slot', C.c_int32 * 2),
         ('drp_slot', C.c_int32), ('croom_slot', C.c_int32 * 2), ('radiation', C.c_int32),
-        ('rad_slot', C.c_int32 * 4), ('z_eff', C.c_double)]
+        ('rad_slot', C.c_int32 * 4), ('uv_shotnoise', C.c_int32), ('uvsn_slot', C.c_int32 * 3),
+        ('z_eff', C.c_double)]
 
 
 class MetalDesc(C.Structure):
@@ -110,6 +111,8 @@ def load_library():
     lib.vmx_set_fvoigt_table.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_add_pipeline.argtypes = [C.c_void_p, C.POINTER(PipeDesc), C.c_int32, dptr, dptr, dptr, dptr, dptr]
     lib.vmx_add_item.argtypes = [C.c_void_p, C.POINTER(ItemDesc)]
+    lib.vmx_set_shotnoise_table.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_double, C.c_double]
+    lib.vmx_item_set_additive_template.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32, C.c_double]
     lib.vmx_pipeline_set_odd_terms.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_double, C.c_double,
                                                C.c_int32, C.c_int32, iptr]
     lib.vmx_item_add_metal.argtypes = [C.c_void_p, C.c_int32, C.POINTER(MetalDesc)]
@@ -146,7 +149,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table',
-    'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
+    'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
+    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
     'vmx_set_profiling', 'vmx_get_timings', 'vmx_kernel_name']
@@ -364,6 +368,14 @@ class Lowering:
             d.rad_slot[i] = self.need('qso_rad_' + key) if xi.radiation else -1
         if xi.radiation and xi.rescale_coords_systematics:
             raise NotImplementedError('rescale-coords-systematics is not accelerated')
+        d.uv_shotnoise = int(xi.uv_shotnoise)
+        for i in range(3):
+            d.uvsn_slot[i] = -1
+        if xi.uv_shotnoise:
+            gamma = 'bias_gamma' if 'bias_gamma' in self.slot else 'bias_gamma_e'
+            d.uvsn_slot[0], d.uvsn_slot[1] = self.need('uv_shotnoise_amp'), self.need('lambda_uv')
+            d.uvsn_slot[2] = self.need(gamma)
+            engine._set_shotnoise_table()
         d.z_eff = self.prob.z_eff
         return d
 
@@ -398,6 +410,14 @@ class Engine:
         if key not in self._gk:
             self._gk[key] = self._check(self.lib.vmx_add_gk_table(self._h, bs_rp, bs_rt))
         return self._gk[key]
+
+    def _set_shotnoise_table(self):
+        if getattr(self, '_shotnoise_set', False):
+            return
+        tau, a = static_terms.shotnoise_a()
+        a = _f64(a)
+        self._check(self.lib.vmx_set_shotnoise_table(self._h, _dp(a), a.size, float(tau[0]), float(tau[1] - tau[0])))
+        self._shotnoise_set = True
 
     def _set_fvoigt(self, table):
         key = hash(np.ascontiguousarray(table).tobytes())
@@ -522,6 +542,11 @@ class Engine:
                         self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_METAL, mi, dense.shape[0],
                                                             dense.shape[1], _dp(dense)))
 
+            if item.inst_sys_table is not None:
+                vec = _f64(static_terms.instrumental_systematics_template(item))
+                self._check(lib.vmx_item_set_additive_template(self._h, iid, _dp(vec), vec.size,
+                                                               low.s('desi_inst_sys_amp'),
+                                                               static_terms.DESI_INST_SYS_DEFAULT_AMP))
             for term in item.broadband:
                 grid = item.model_grid if term.pos == 'pre' else item.dist_grid
                 pos = BB_POS[(term.pos, term.kind)]

@@ -141,6 +141,7 @@ class XiOptions:
     radiation: bool = False
     relativistic: bool = False
     asymmetry: bool = False
+    uv_shotnoise: bool = False
     rescale_coords_systematics: bool = False
 
 
@@ -204,6 +205,7 @@ class CorrItem:
     model_mask: np.ndarray
     cov: np.ndarray              # full covariance or None (identity)
     rp_binsize: float = 4.0
+    inst_sys_table: np.ndarray = None   # (rt, xi) table of the DESI instrumental-systematics model, or None
 
     _inv_masked_cov: np.ndarray = None
     _log_cov_det: float = None
@@ -400,8 +402,9 @@ def _xi_options(model_section, xi_section, tracers):
         if 'relativistic correction' in xi_section else False
     opts.asymmetry = xi_section.getboolean('standard asymmetry', False) \
         if 'standard asymmetry' in xi_section else False
-    if xi_section.getboolean('UVB-shotnoise', False) if 'UVB-shotnoise' in xi_section else False:
-        raise NotImplementedError('UVB-shotnoise is outside the accelerated hot path')
+    opts.uv_shotnoise = xi_section.getboolean('UVB-shotnoise', False) if 'UVB-shotnoise' in xi_section else False
+    if opts.uv_shotnoise and opts.rescale_coords_systematics:
+        raise NotImplementedError('UVB-shotnoise with rescale-coords-systematics is not supported')
     if xi_section.getboolean('new-bias-evolution', False):
         raise NotImplementedError('new-bias-evolution needs a picca cosmology (not supported)')
     if xi_section.getboolean('old_growth_func', False):
@@ -496,8 +499,6 @@ def _build_item(cfg, consts, search_dirs):
         raise NotImplementedError('small-scale marginalisation is outside the hot path')
     if model_sec.getboolean('new_metals', False):
         raise NotImplementedError('new_metals (metal-matrix construction) is outside the hot path')
-    if model_sec.getboolean('desi-instrumental-systematics', False):
-        raise NotImplementedError('desi-instrumental-systematics is outside the hot path')
     if 'filename' not in d or not d.getboolean('has_datafile', True):
         raise NotImplementedError('correlation items without a data file are not supported')
 
@@ -654,11 +655,20 @@ def _build_item(cfg, consts, search_dirs):
 
     broadband = _parse_broadband(cfg['broadband'], name) if 'broadband' in cfg else []
 
+    inst_sys_table = None
+    if model_sec.getboolean('desi-instrumental-systematics', False):
+        # reference correlation_func.py:569-591: auto-correlations only; (RT, XI) table, linear interpolation
+        if tr1.type != tr2.type:
+            raise ValueError('DESI instrumental systematics model only applies to auto-correlation functions.')
+        path = find_file('instrumental_systematics/desi-instrument-syst-for-forest-auto-correlation.csv',
+                         [*search_dirs, *[Path(d) / 'inputs' for d in search_dirs]])
+        inst_sys_table = np.loadtxt(path, delimiter=',', skiprows=1)
+
     return CorrItem(name=name, tracer1=tr1, tracer2=tr2, core=core, model_grid=model_grid,
                     dist_grid=dist_grid, data_grid=data_grid, metals=metals, metal_opts=metal_opts,
                     broadband=broadband, distortion=distortion, data_vec=data_vec,
                     data_mask=data_mask, model_mask=model_mask, cov=cov,
-                    rp_binsize=data_grid.rp_binsize)
+                    rp_binsize=data_grid.rp_binsize, inst_sys_table=inst_sys_table)
 
 
 # --------------------------------------------------------------------------------------
