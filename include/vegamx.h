@@ -52,7 +52,8 @@ enum { VMX_BB_PRE_MUL = 0, VMX_BB_PRE_ADD = 1, VMX_BB_POST_MUL = 2, VMX_BB_POST_
 enum { VMX_BB_POLY = 0, VMX_BB_SKY = 1 };
 
 /* status bits written per walker */
-enum { VMX_STATUS_OK = 0, VMX_STATUS_BOUNDS = 1, VMX_STATUS_ARINYO = 2, VMX_STATUS_NONFINITE = 4 };
+enum { VMX_STATUS_OK = 0, VMX_STATUS_BOUNDS = 1, VMX_STATUS_ARINYO = 2, VMX_STATUS_NONFINITE = 4,
+       VMX_STATUS_NOT_CONSTANT = 8 };
 
 /* A tracer's (bias, beta): two of the three slots must be present
  * (reference vega/utils.py:45-82 _tracer_bias_beta). */
@@ -242,6 +243,12 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
 int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2,
                     double* d_model, int32_t* d_status);
 int vmx_sync(vmx_engine* e);
+/* Samplers usually keep the Arinyo non-linear parameters fixed.  When they are identical for every walker of a
+ * batch the factor D_NL(k,mu) G(k,mu) is tabulated once per batch instead of being exponentiated per walker and
+ * grid point.  vmx_eval (host theta) detects this by itself; for vmx_eval_device the caller states it here.
+ * A walker whose Arinyo parameters differ from the first walker's while the hint is on gets
+ * status VMX_STATUS_NOT_CONSTANT and chi2 = 1e100 - never a silently wrong value. */
+int vmx_set_constant_nl_hint(vmx_engine* e, int32_t enabled);
 /* The engine's HIP stream (hipStream_t as an opaque pointer), so that a caller can order its own work - e.g. an
  * RCCL collective on the chi2 buffer - after vmx_eval_device without a host synchronisation. */
 void* vmx_stream(vmx_engine* e);

@@ -12,6 +12,15 @@ if str(REPO) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # torch bundles its own HIP runtime: when a test uses both torch device tensors and libvegamx.so, torch must
+    # bring the runtime up first (as bench.py does), otherwise it finds no device in a process that already loaded
+    # the system runtime through the engine.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:       # pragma: no cover - CPU-only container
+        pass
 
 
 @pytest.fixture(scope='session')

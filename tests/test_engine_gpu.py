@@ -181,3 +181,41 @@ def test_monte_carlo_mock_swap():
     vega.monte_carlo = False
     assert vega.chi2() == pytest.approx(base, rel=1e-14)
     vega.close()
+
+
+def test_constant_nl_table_mode():
+    """Batches whose walkers share the Arinyo parameters run against a per-batch D_NL * G table (no exponential in
+    the mu loop): same chi2 as the per-walker path to rounding, equal to the oracle, and a violated device-side
+    hint is flagged per walker instead of producing a wrong value."""
+    import torch
+    from oracle import vega_cpu as oc
+    from vega_amd import synthetic
+    from vega_amd.engine import STATUS_NOT_CONSTANT
+    vega = _engine('joint', max_batch=64)
+    eng = vega.engine
+    varied = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO', 'drp_QSO',
+              'bias_hcd', 'beta_hcd', 'L0_hcd', 'bao_amp', 'sigmaNL_par', 'par_sigma_smooth', 'per_sigma_smooth']
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 48, varied=varied, seed=21)
+    tab = eng.eval(theta)[0]                                             # 48 >= 16 and constant: table mode
+    plain = np.concatenate([eng.eval(theta[lo:lo + 8])[0] for lo in range(0, 48, 8)])    # < 16: per-walker path
+    np.testing.assert_allclose(tab, plain, rtol=1e-11)
+    for i in (0, 17, 47):
+        assert tab[i] == pytest.approx(oc.chi2(vega.problem, dict(zip(eng.names, theta[i]))), rel=CHI2_RTOL)
+    # device entry point with the hint on, one walker violating it
+    bad = theta.copy()
+    bad[5, eng.low.slot['dnl_arinyo_q1']] *= 1.01
+    dev = torch.device('cuda', 0)
+    d_theta = torch.from_numpy(bad).to(dev)
+    d_chi2 = torch.zeros(48, dtype=torch.float64, device=dev)
+    d_status = torch.zeros(48, dtype=torch.int32, device=dev)
+    eng.set_constant_nl_hint(True)
+    eng.eval_device(d_theta.data_ptr(), 48, d_chi2.data_ptr(), None, d_status.data_ptr())
+    eng.sync()
+    eng.set_constant_nl_hint(False)
+    status = d_status.cpu().numpy()
+    chi2 = d_chi2.cpu().numpy()
+    assert status[5] & STATUS_NOT_CONSTANT and chi2[5] == 1e100
+    ok = np.arange(48) != 5
+    assert not status[ok].any()
+    np.testing.assert_allclose(chi2[ok], tab[ok], rtol=1e-11)
+    vega.close()

@@ -7,6 +7,7 @@
 #include "vmx_device.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -101,7 +102,11 @@ struct vmx_engine {
     bool finalized = false;
 
     int nk = 0, nkp = 0, n_mu = 0;
-    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom, fv_x, fv_f;
+    DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom, fv_x, fv_f, xtab;
+    std::vector<int32_t> const_slots;
+    DevBuf<int32_t> d_const_slots;
+    int n_xtab = 0;
+    bool const_hint = false;
     int fv_n = 0;
     std::vector<std::pair<double, double>> gk_tables;
     std::vector<double> h_k, h_mu;
@@ -802,7 +807,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         for (auto* it : e->items) {
             const int ps = it->dev.d.pipe_smooth, pk = it->dev.d.pipe_peak;
             if (ps != pk && !taken[ps] && !taken[pk] && pk_stage_compatible(e->pipes[ps].d, e->pipes[pk].d)) {
-                e->pk_groups.push_back({ps, pk, 0, 0, 0});
+                e->pk_groups.push_back({ps, pk, 0, 0, 0, -1});
                 taken[ps] = taken[pk] = 1;
             }
         }
@@ -815,8 +820,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             const int variant = pk_variant(e->pipes[p].d, false);
             const bool plain = variant == PKV_PLAIN_SAME || variant == PKV_PLAIN_PAIR || variant == PKV_PLAIN_PAIR_VD;
             if (variant == PKV_POLY) { e->pk_poly.push_back(p); taken[p] = 1; continue; }
-            if (!plain) { e->pk_groups.push_back({p, -1, variant, 0, 0}); taken[p] = 1; continue; }
-            PkGroup g{p, -1, PKV_SHARED_W, 0, (int32_t)e->pk_members.size()};
+            if (!plain) { e->pk_groups.push_back({p, -1, variant, 0, 0, -1}); taken[p] = 1; continue; }
+            PkGroup g{p, -1, PKV_SHARED_W, 0, (int32_t)e->pk_members.size(), -1};
             for (int q = p; q < (int)e->pipes.size(); ++q) {
                 if (taken[q]) continue;
                 const int vq = pk_variant(e->pipes[q].d, false);
@@ -827,8 +832,24 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             }
             e->pk_groups.push_back(g);
         }
-        for (auto& g : e->pk_groups)
+        e->n_xtab = 0;
+        e->const_slots.clear();
+        for (auto& g : e->pk_groups) {
             if (g.peak_partner >= 0) g.variant = pk_variant(e->pipes[g.pipe].d, true);
+            // core groups with the Arinyo term can run against a per-batch D_NL * G table
+            if (g.variant == PKV_AUTO_CORE || g.variant == PKV_CROSS_CORE) {
+                g.xtab = e->n_xtab++;
+                for (int i = 0; i < 6; ++i) {
+                    const int slot = e->pipes[g.pipe].d.arinyo_slot[i];
+                    if (slot >= 0 && std::find(e->const_slots.begin(), e->const_slots.end(), slot) == e->const_slots.end())
+                        e->const_slots.push_back(slot);
+                }
+            }
+        }
+        if (e->n_xtab > 0 && e->xtab.alloc((size_t)e->n_xtab * e->n_mu * e->nkp, true)) return -2;
+        e->const_slots.push_back(-1);
+        if (e->d_const_slots.upload(e->const_slots.data(), e->const_slots.size())) return -2;
+        e->const_slots.pop_back();
         e->pk_members.push_back(-1);
         if (e->d_pk_members.upload(e->pk_members.data(), e->pk_members.size())) return -2;
         e->pk_poly.push_back(-1);
@@ -900,7 +921,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
     D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p; D.lnmu = e->lnmu.p;
-    D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.n_gk = (int)e->gk_tables.size();
+    D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.xtab = e->xtab.p; D.const_slots = e->d_const_slots.p; D.n_const_slots = 0; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp; D.extrapolate = e->extrapolate ? 1 : 0;
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
@@ -932,9 +953,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 int vmx_model_size(vmx_engine* e) { return e ? e->model_size : -1; }
 
 // enqueue the whole kernel chain for the B parameter points already in e->theta
-static int run_chain(vmx_engine* e, int B)
+static int run_chain(vmx_engine* e, int B, bool tab_mode)
 {
-    const EngineDev& D = e->dev;
+    EngineDev D = e->dev;
+    D.n_const_slots = tab_mode ? (int)e->const_slots.size() : 0;
     const int n_pipe = D.n_pipe;
     {
         ScopedTimer t(e, KC_PROLOGUE);
@@ -943,20 +965,38 @@ static int run_chain(vmx_engine* e, int B)
     }
     {
         ScopedTimer t(e, KC_PK);
-        const size_t shmem = ((size_t)e->n_mu + 2048) * sizeof(double);
+        // reduction scratch + (unless every looping group runs against its D_NL table) the mu^bv tables
+        bool need_mubv = false;
+        for (auto& g : e->pk_groups)
+            if (e->pipes[g.pipe].d.nl_model == VMX_NL_ARINYO && !(tab_mode && g.xtab >= 0)) need_mubv = true;
+        const size_t shmem = ((need_mubv ? (size_t)e->n_mu : 0) + 2048) * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
+        if (tab_mode)
+            for (auto& g : e->pk_groups)
+                if (g.xtab >= 0)
+                    hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, e->n_mu), dim3(256), 0, e->stream, D, g.pipe, g.xtab);
         if (!e->pk_poly.empty())
             hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
+        const int tm = tab_mode ? 1 : 0;
         if (n_groups == 0) {}
-        else if ((int64_t)B * n_groups >= 24)
-            hipLaunchKernelGGL((k_pk_multipoles<64, 4>), dim3(B, n_groups, (e->nk + 63) / 64), dim3(256), shmem, e->stream, D,
-                               e->d_pk_groups.p, e->d_pk_members.p);
-        else if ((int64_t)B * n_groups >= 4)
-            hipLaunchKernelGGL((k_pk_multipoles<16, 16>), dim3(B, n_groups, (e->nk + 15) / 16), dim3(256), shmem, e->stream, D,
-                               e->d_pk_groups.p, e->d_pk_members.p);
-        else
-            hipLaunchKernelGGL((k_pk_multipoles<8, 32>), dim3(B, n_groups, (e->nk + 7) / 8), dim3(256), shmem, e->stream, D,
-                               e->d_pk_groups.p, e->d_pk_members.p);
+        else {
+            // the instantiation without the run-time-switched loops needs fewer registers (4 instead of 3 waves per
+            // SIMD): use it whenever every group has a specialised loop
+            bool generic = false;
+            for (auto& g : e->pk_groups) if (g.variant == PKV_GENERIC) generic = true;
+            const PkGroup* gp = e->d_pk_groups.p;
+            const int32_t* mp = e->d_pk_members.p;
+#define VMX_LAUNCH_PK(KT, MS)                                                                                        \
+            do {                                                                                                     \
+                const dim3 grid(B, n_groups, (e->nk + (KT) - 1) / (KT));                                             \
+                if (generic) hipLaunchKernelGGL((k_pk_multipoles<KT, MS, 1, true>), grid, dim3(256), shmem, e->stream, D, gp, mp, tm, B);   \
+                else hipLaunchKernelGGL((k_pk_multipoles<KT, MS, 1, false>), grid, dim3(256), shmem, e->stream, D, gp, mp, tm, B);         \
+            } while (0)
+            if ((int64_t)B * n_groups >= 24) VMX_LAUNCH_PK(64, 4);
+            else if ((int64_t)B * n_groups >= 4) VMX_LAUNCH_PK(16, 16);
+            else VMX_LAUNCH_PK(8, 32);
+#undef VMX_LAUNCH_PK
+        }
     }
     {
         const int64_t ncols = (int64_t)B * n_pipe;
@@ -1012,15 +1052,17 @@ static int run_chain(vmx_engine* e, int B)
 }
 
 // run the chain for B walkers: replay a captured graph when one exists (or can be captured), else launch eagerly
-static int run_chain_cached(vmx_engine* e, int B)
+static int run_chain_cached(vmx_engine* e, int B, bool tab_mode)
 {
-    if (!e->use_graphs || e->profiling) return run_chain(e, B);
-    auto it = e->graphs.find(B);
+    tab_mode = tab_mode && e->n_xtab > 0;
+    if (!e->use_graphs || e->profiling) return run_chain(e, B, tab_mode);
+    const int key = B * 2 + (tab_mode ? 1 : 0);
+    auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
-        if (e->graphs.size() >= 64) return run_chain(e, B);
+        if (e->graphs.size() >= 64) return run_chain(e, B, tab_mode);
         hipGraph_t graph = nullptr;
         HIP_OK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = run_chain(e, B);
+        const int rc = run_chain(e, B, tab_mode);
         hipError_t err = hipStreamEndCapture(e->stream, &graph);
         if (rc || err != hipSuccess || graph == nullptr) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -1028,7 +1070,7 @@ static int run_chain_cached(vmx_engine* e, int B)
                          err != hipSuccess ? hipGetErrorString(err) : "launch error");
             (void)hipGetLastError();
             e->use_graphs = false;      // capture is not available: stay on eager launches
-            return run_chain(e, B);
+            return run_chain(e, B, tab_mode);
         }
         hipGraphExec_t exec = nullptr;
         err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1036,9 +1078,9 @@ static int run_chain_cached(vmx_engine* e, int B)
         if (err != hipSuccess) {
             std::fprintf(stderr, "[vegamx] graph instantiation failed (%s): falling back to eager launches\n", hipGetErrorString(err));
             e->use_graphs = false;
-            return run_chain(e, B);
+            return run_chain(e, B, tab_mode);
         }
-        it = e->graphs.emplace(B, exec).first;
+        it = e->graphs.emplace(key, exec).first;
     }
     HIP_OK(hipGraphLaunch(it->second, e->stream));
     e->last_B = B;
@@ -1052,7 +1094,7 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    if (run_chain_cached(e, B)) return -2;
+    if (run_chain_cached(e, B, e->const_hint && B >= 16)) return -2;
     if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
     if (d_model) HIP_OK(hipMemcpyAsync(d_model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
@@ -1060,6 +1102,13 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
 }
 
 void* vmx_stream(vmx_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int vmx_set_constant_nl_hint(vmx_engine* e, int32_t enabled)
+{
+    REQUIRE(e, "vmx_set_constant_nl_hint");
+    e->const_hint = enabled != 0;
+    return 0;
+}
 
 int vmx_sync(vmx_engine* e)
 {
@@ -1077,7 +1126,12 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     HIP_OK(hipSetDevice(e->device));
     std::memcpy(e->pin_theta, theta, (size_t)B * e->n_params * sizeof(double));
     HIP_OK(hipMemcpyAsync(e->theta.p, e->pin_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    if (run_chain_cached(e, B)) return -2;
+    // the D_NL * G table pays off once a batch shares its Arinyo parameters (checked here, on the host copy)
+    bool tab_mode = B >= 16 && e->n_xtab > 0;
+    for (int b = 1; b < B && tab_mode; ++b)
+        for (int slot : e->const_slots)
+            if (theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = false; break; }
+    if (run_chain_cached(e, B, tab_mode)) return -2;
     if (chi2) HIP_OK(hipMemcpyAsync(e->pin_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if (status) HIP_OK(hipMemcpyAsync(e->pin_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (model) HIP_OK(hipMemcpyAsync(model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToHost, e->stream));

@@ -97,6 +97,8 @@ struct EngineDev {
     const double* wl;           // [4][n_mu] L_ell(mu) (2 ell + 1) / n_mu
     const double* fv_x; const double* fv_f; int32_t fv_n;   // Voigt-profile HCD table
     const double* gk;           // [tables][n_mu][nkp]
+    double* xtab;               // [arinyo groups][n_mu][nkp]  D_NL(k,mu)^power * G(k,mu) of the batch's first walker
+    const int32_t* const_slots; int32_t n_const_slots;   // parameters asserted constant across the batch
     const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
     int32_t n_gk;
     // fftlog / spline
@@ -252,7 +254,10 @@ __global__ void k_prologue(EngineDev D, int B)
         }
         D.metal_bias[(size_t)b * D.n_metals_total + m] = f;
     }
-    D.status[b] = 0;
+    int st = 0;
+    for (int q = 0; q < D.n_const_slots; ++q)
+        if (t[D.const_slots[q]] != D.theta[D.const_slots[q]]) st = VMX_STATUS_NOT_CONSTANT;
+    D.status[b] = st;
     D.chi2[b] = 0.0;
 }
 
@@ -347,7 +352,8 @@ __device__ __forceinline__ double vmx_rsqrt(double x)
 // smooth component only by the peak non-linear broadening (power_spectrum.py:163-164), that peak
 // pipeline as a partner evaluated in the same pass.  `variant` selects a compile-time specialisation
 // of the mu loop (0 = generic).
-struct PkGroup { int32_t pipe; int32_t peak_partner; int32_t variant; int32_t n_members; int32_t member_off; };
+struct PkGroup { int32_t pipe; int32_t peak_partner; int32_t variant; int32_t n_members; int32_t member_off;
+                 int32_t xtab; };     // xtab: index of this group's D_NL * G table (-1: none)
 
 enum { PKV_GENERIC = 0, PKV_AUTO_CORE = 1, PKV_CROSS_CORE = 2, PKV_PLAIN_SAME = 3, PKV_PLAIN_PAIR = 4, PKV_PLAIN_PAIR_VD = 5,
        PKV_POLY = 6, PKV_SHARED_W = 7 };
@@ -381,7 +387,7 @@ __device__ inline double fvoigt_interp(double x, const double* xp, const double*
 //                 Arinyo, G(k), Gaussian smoothing / peak broadening, Lorentz velocity dispersion on tracer 2);
 //   SPEC = false: every switch is read from T at run time; RARE adds sinc HCD, McDonald NL, exponential
 //                 smoothing and the fast-metals division.
-template <int MS, bool SPEC, int KM, bool ARINYO, bool PAIRED, int NVD, bool RARE>
+template <int MS, int WB, bool SPEC, int KM, bool ARINYO, bool PAIRED, int NVD, bool RARE>
 __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mubv, int ms, int n_mu,
                                            double inv_nmu, double* s, double* q)
 {
@@ -401,6 +407,7 @@ __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mu
     double m_next = arinyo ? s_mubv[ms] : 0.0;
 
     for (int j0 = ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
+        if (WB > 1) __syncthreads();       // keep the walkers of a block on the same table rows (L1 reuse)
         // exact anchors of the progressions along this thread's mu sequence
         double mu = ((double)j0 + 0.5) * inv_nmu;
         double F = 0.0, pg = 1.0, pr = 1.0;
@@ -477,7 +484,7 @@ __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mu
 // mu loop of a shared-W group: six even moments of the amplitude-free factor
 //   W(k, mu) = G(k, mu) exp(e0 + e1 mu^2) / sqrt((1 + (k mu s1)^2)(1 + (k mu s2)^2)),
 // from which every member pipeline P = P_lin (c0_1 + c1_1 mu^2)(c0_2 + c1_2 mu^2) W forms its own moments.
-template <int MS>
+template <int MS, int WB>
 __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, double inv_nmu, double* wm)
 {
     const double dmu = (double)MS * inv_nmu;
@@ -511,21 +518,124 @@ __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, d
     wm[0] = m0; wm[1] = m1; wm[2] = m2; wm[3] = m3; wm[4] = m4; wm[5] = m5;
 }
 
-template <int KT, int MS>
-__global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGroup* groups, const int32_t* members)
+// D_NL(k,mu)^power * G(k,mu) from the Arinyo parameters of the batch's first walker (power_spectrum.py:435-479)
+__global__ __launch_bounds__(256) void k_xtab(EngineDev D, int pipe, int xtab)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= D.nkp) return;
+    double val = 0.0;
+    if (i < D.nk) {
+        const vmx_pipe_desc& d = D.pipes[pipe].d;
+        const double* t = D.theta;
+        const double k = D.k[i], d2 = D.delta2[i];
+        const double q1 = t[d.arinyo_slot[0]], q2 = d.arinyo_slot[1] >= 0 ? t[d.arinyo_slot[1]] : 0.0;
+        const double g = q1 * d2 + q2 * d2 * d2;
+        const double v = pow(k / t[d.arinyo_slot[2]], t[d.arinyo_slot[3]]);
+        const double kp = k / t[d.arinyo_slot[5]];
+        const double m = vmx_exp(t[d.arinyo_slot[4]] * D.lnmu[j]);
+        val = exp(fmin(d.arinyo_power * (g * (1.0 - v * m) - kp * kp), 709.0));
+        if (d.gk_table >= 0) val *= D.gk[((size_t)d.gk_table * D.n_mu + j) * D.nkp + i];
+    }
+    D.xtab[((size_t)xtab * D.n_mu + j) * D.nkp + i] = val;
+}
+
+// mu loop against the tabulated D_NL * G: no exponential is left in the loop - the HCD factor, the Gaussian
+// smoothing exp(e0 + e1 mu^2) and the peak broadening all advance as geometric progressions (re-anchored exactly
+// every PK_REANCHOR steps).
+template <int MS, int WB, int KM, bool PAIRED, int NVD>
+__device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int ms, int n_mu, double inv_nmu,
+                                            double* s, double* q)
+{
+    const bool same = (KM == KM_SAME_HCD);
+    const double dmu = (double)MS * inv_nmu;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    // the table stream runs three steps ahead of its use (one outstanding load per step covers the L2 latency)
+    const double* tab = T.gk;
+    const int n_steps = (n_mu - ms + MS - 1) / MS;
+    double g_a = *tab;
+    double g_b = (n_steps > 1) ? tab[T.gk_stride] : 0.0;
+    double g_c = (n_steps > 2) ? tab[2 * T.gk_stride] : 0.0;
+    tab += 3 * T.gk_stride;
+    int step = 0;
+    const double gq = vmx_exp(2.0 * T.e1 * dmu * dmu);
+    for (int j0 = ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
+        if (WB > 1) __syncthreads();       // keep the walkers of a block on the same table rows (L1 reuse)
+        double mu = ((double)j0 + 0.5) * inv_nmu;
+        double F = vmx_exp(-T.L0 * T.k * mu);
+        double gs = vmx_exp(fma(T.e1, mu * mu, e0g));
+        double gr = vmx_exp(T.e1 * fma(2.0 * mu, dmu, dmu * dmu));
+        double pg = 1.0, pr = 1.0;
+        if (PAIRED) {
+            pg = vmx_exp(fma(T.p1, mu * mu, T.p0));
+            pr = vmx_exp(T.p1 * fma(2.0 * mu, dmu, dmu * dmu));
+        }
+        int jend = j0 + MS * PK_REANCHOR;
+        if (jend > n_mu) jend = n_mu;
+        for (int j = j0; j < jend; j += MS) {
+            const double mu2 = mu * mu;
+            const double g = g_a;
+            g_a = g_b; g_b = g_c;
+            if (step + 3 < n_steps) { g_c = *tab; tab += T.gk_stride; }
+            ++step;
+            const double hmu = fma(T.hbb, mu2, T.hb);
+            const double A1 = fma(F, hmu, fma(T.c1_1, mu2, T.c0_1));
+            const double AA = same ? A1 * A1 : A1 * fma(T.c1_2, mu2, T.c0_2);
+            double val = AA * (g * gs);
+            if (NVD == 1) { const double kpar = T.k * mu; val *= vmx_rsqrt(fma(kpar * kpar, T.vd2, 1.0)); }
+            const double mu4 = mu2 * mu2, mu6 = mu4 * mu2;
+            s0 += val;
+            s1 = fma(mu2, val, s1);
+            s2 = fma(mu4, val, s2);
+            s3 = fma(mu6, val, s3);
+            if (PAIRED) {
+                const double vp = val * pg;
+                q0 += vp;
+                q1 = fma(mu2, vp, q1);
+                q2 = fma(mu4, vp, q2);
+                q3 = fma(mu6, vp, q3);
+                pg *= pr;
+                pr *= T.pq;
+            }
+            gs *= gr;
+            gr *= gq;
+            F *= T.Fq;
+            mu += dmu;
+        }
+    }
+    s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3;
+    q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
+}
+
+// Block = KT wavenumbers x MS mu-slices x WB walkers (KT * MS * WB = 256).  WB > 1 lets the waves of a block share the
+// rows of the static table through the CU's L1 (94 % L1 hit rate measured with WB = 4); it did not shorten the kernel
+// on MI355X (L2 was not the limiter), so the engine launches WB = 1 shapes only.
+#ifndef VMX_PK_WAVES
+#define VMX_PK_WAVES 4
+#endif
+template <int KT, int MS, int WB, bool GENERIC>
+__global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipoles(EngineDev D, const PkGroup* groups, const int32_t* members,
+                                                       int tab_mode, int B)
 {
     extern __shared__ double smem[];
-    double* s_mubv = smem;                        // [n_mu]   mu^bv (Arinyo)
-    double* s_red = smem + D.n_mu;                // [8][256]
+    const int wb = (WB > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x / (KT * MS)) : 0;
+    // LDS: [8][256] reduction scratch first; the per-walker mu^bv tables follow only when the launch needs them
+    // (the tabulated-D_NL mode does not: a smaller footprint lets more blocks share a CU)
+    double* s_red = smem;
+    double* s_mubv = smem + 2048 + (size_t)wb * D.n_mu;       // [WB][n_mu]   mu^bv (Arinyo), one table per walker
+    const bool use_tab = tab_mode && groups[blockIdx.y].xtab >= 0 &&
+                         (groups[blockIdx.y].variant == PKV_AUTO_CORE || groups[blockIdx.y].variant == PKV_CROSS_CORE);
 
-    const int b = blockIdx.x;
+    int b = blockIdx.x * WB + wb;
+    const bool walker_ok = b < B;
+    if (!walker_ok) b = B - 1;                        // surplus waves shadow the last walker and store nothing
     const int p = groups[blockIdx.y].pipe, pp = groups[blockIdx.y].peak_partner;
     const int variant = groups[blockIdx.y].variant;
     const vmx_pipe_desc& d = D.pipes[p].d;
     const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
     const int kk = threadIdx.x % KT;
+    const int lt = threadIdx.x % (KT * MS);           // thread index within this walker's sub-block
     // with KT = 64 a wave shares its mu slice: keep the slice index in a scalar register
-    const int ms = (KT == 64) ? __builtin_amdgcn_readfirstlane(threadIdx.x / KT) : (int)(threadIdx.x / KT);
+    const int ms = (KT == 64) ? __builtin_amdgcn_readfirstlane((threadIdx.x / KT) % MS) : (int)((threadIdx.x / KT) % MS);
     const int i = blockIdx.z * KT + kk;
     const bool valid = i < D.nk;
     const int ic = valid ? i : D.nk - 1;
@@ -535,12 +645,12 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     PkThread T;
     T.paired = pp >= 0;
     T.arinyo = d.nl_model == VMX_NL_ARINYO;
-    if (T.arinyo) {
+    if (T.arinyo && !use_tab) {
         const double bv = sc[S_ABV];
-        for (int j = threadIdx.x; j < n_mu; j += 256) s_mubv[j] = vmx_exp(bv * D.lnmu[j]);     // mu^bv
-        __syncthreads();
+        for (int j = lt; j < n_mu; j += KT * MS) s_mubv[j] = vmx_exp(bv * D.lnmu[j]);     // mu^bv
     }
 
+    __syncthreads();
     const double k = D.k[ic], k2 = k * k;
     T.k = k;
     const bool hcd = d.hcd_model != VMX_HCD_NONE;
@@ -587,7 +697,8 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
         // VegaArinyoError: NaN or Inf in exp(growth (1 - pec) - pressure) anywhere on the grid
         // (power_spectrum.py:466-469).  The exponent is monotonic in mu^bv, so its extremes sit at the two
         // ends of the mu grid.
-        const double lo = fma(-ar_gv, s_mubv[0], ar_gp), hi = fma(-ar_gv, s_mubv[n_mu - 1], ar_gp);
+        const double bv = sc[S_ABV];
+        const double lo = fma(-ar_gv, vmx_exp(bv * D.lnmu[0]), ar_gp), hi = fma(-ar_gv, vmx_exp(bv * D.lnmu[n_mu - 1]), ar_gp);
         if (!(lo < 709.0) || !(hi < 709.0)) bad = true;
     }
     T.mc_kvel = 1.0;
@@ -617,23 +728,23 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
     // when a whole wave is past that bound.  exp(-200) ~ 1e-87 leaves > 60 decades of margin for the amplitudes.
     double e_max = T.e0 + fmax(T.e1, 0.0) + fmax(T.e2, 0.0);
     if (T.paired) e_max += fmax(T.p0 + fmax(T.p1, 0.0), 0.0);
-    const bool live = !(e_max < -200.0);
+    const bool live_block = __syncthreads_or(!(e_max < -200.0)) != 0;     // block-uniform: the mu loops contain barriers
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
     if (variant == PKV_SHARED_W) {
         // one mu loop for all member pipelines (e.g. QSO x each metal line): they share W and differ only in
         // the Kaiser polynomials
         double wm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (__ballot(live) != 0ull) pk_w_loop<MS>(T, ms, n_mu, inv_nmu, wm);
+        if (live_block) pk_w_loop<MS, WB>(T, ms, n_mu, inv_nmu, wm);
         for (int n = 0; n < 6; ++n) s_red[n * 256 + threadIdx.x] = wm[n];
         __syncthreads();
-        if (threadIdx.x < KT && valid) {
+        if (lt < KT && valid && walker_ok) {
             for (int n = 0; n < 6; ++n) {
                 double sum = 0.0;
-                for (int qq = 0; qq < MS; ++qq) sum += s_red[n * 256 + qq * KT + kk];
+                for (int qq = 0; qq < MS; ++qq) sum += s_red[n * 256 + (wb * MS + qq) * KT + kk];
                 wm[n] = sum;
             }
             const PkGroup& G = groups[blockIdx.y];
-            const size_t ncols = (size_t)gridDim.x * D.n_pipe;
+            const size_t ncols = (size_t)B * D.n_pipe;
             for (int mi = 0; mi < G.n_members; ++mi) {
                 const int pm = members[G.member_off + mi];
                 const vmx_pipe_desc& dm = D.pipes[pm].d;
@@ -664,18 +775,29 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
         }
         return;
     }
-    if (__ballot(live) != 0ull)
+    const int xt = groups[blockIdx.y].xtab;
+    if (use_tab) {
+        if (live_block) {
+            T.gk = D.xtab + ((size_t)xt * n_mu + ms) * D.nkp + ic;
+            if (variant == PKV_AUTO_CORE) pk_tab_loop<MS, WB, KM_SAME_HCD, true, 0>(T, -k2 * gb, ms, n_mu, inv_nmu, s, q);
+            else pk_tab_loop<MS, WB, KM_FIRST_HCD, true, 1>(T, -k2 * gb, ms, n_mu, inv_nmu, s, q);
+        }
+    } else if (live_block)
     switch (variant) {
-        case PKV_AUTO_CORE: pk_mu_loop<MS, true, KM_SAME_HCD, true, true, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
-        case PKV_CROSS_CORE: pk_mu_loop<MS, true, KM_FIRST_HCD, true, true, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
-        case PKV_PLAIN_SAME: pk_mu_loop<MS, true, KM_SAME_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
-        case PKV_PLAIN_PAIR: pk_mu_loop<MS, true, KM_BOTH_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
-        case PKV_PLAIN_PAIR_VD: pk_mu_loop<MS, true, KM_BOTH_PLAIN, false, false, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_AUTO_CORE: pk_mu_loop<MS, WB, true, KM_SAME_HCD, true, true, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_CROSS_CORE: pk_mu_loop<MS, WB, true, KM_FIRST_HCD, true, true, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_PLAIN_SAME: pk_mu_loop<MS, WB, true, KM_SAME_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_PLAIN_PAIR: pk_mu_loop<MS, WB, true, KM_BOTH_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_PLAIN_PAIR_VD: pk_mu_loop<MS, WB, true, KM_BOTH_PLAIN, false, false, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
         default:
-            if (T.sinc || T.fvoigt || T.has_exp || T.mcdonald || T.div1 || T.div2)
-                pk_mu_loop<MS, false, 0, false, false, 0, true>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
-            else
-                pk_mu_loop<MS, false, 0, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
+            // the run-time-switched loops (rare model options) live in the GENERIC instantiation only: their register
+            // footprint would otherwise cap the occupancy of the production loops
+            if constexpr (GENERIC) {
+                if (T.sinc || T.fvoigt || T.has_exp || T.mcdonald || T.div1 || T.div2)
+                    pk_mu_loop<MS, WB, false, 0, false, false, 0, true>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
+                else
+                    pk_mu_loop<MS, WB, false, 0, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
+            }
     }
 
     // moments -> Legendre multipoles  P_ell = (2 ell + 1) / n_mu * sum_n c_{ell n} M_n  (pktoxi.py:37,55,138)
@@ -687,19 +809,19 @@ __global__ __launch_bounds__(256) void k_pk_multipoles(EngineDev D, const PkGrou
         s_red[(half * 4 + 3) * 256 + threadIdx.x] = (187.6875 * m[3] - 255.9375 * m[2] + 85.3125 * m[1] - 4.0625 * m[0]) * inv_nmu;
     }
     __syncthreads();
-    if (bad && valid) atomicOr(&D.status[b], VMX_STATUS_ARINYO);
+    if (bad && valid && walker_ok) atomicOr(&D.status[b], VMX_STATUS_ARINYO);
 
-    if (threadIdx.x < KT && valid) {
+    if (lt < KT && valid && walker_ok) {
         double damp = 1.0;
         if (d.damping_scale > 0.0) damp = exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
-        const size_t ncols = (size_t)gridDim.x * D.n_pipe;
+        const size_t ncols = (size_t)B * D.n_pipe;
         for (int half = 0; half < (T.paired ? 2 : 1); ++half) {
             const int pipe = half ? pp : p;
             const double pk = damp * D.pklin[(size_t)D.pipes[pipe].d.pk_lin_kind * D.nkp + i];
             const size_t col = (size_t)b * D.n_pipe + pipe;
             for (int e = 0; e < D.n_ell; ++e) {
                 double sum = 0.0;
-                for (int qq = 0; qq < MS; ++qq) sum += s_red[(half * 4 + e) * 256 + qq * KT + kk];
+                for (int qq = 0; qq < MS; ++qq) sum += s_red[(half * 4 + e) * 256 + (wb * MS + qq) * KT + kk];
                 D.pl[((size_t)e * ncols + col) * D.nkp + i] = pk * sum;
             }
         }

@@ -28,7 +28,7 @@ BB_POS = {('pre', 'mul'): 0, ('pre', 'add'): 1, ('post', 'mul'): 2, ('post', 'ad
 BB_POLY, BB_SKY = 0, 1
 DEFAULT_GROWTH_RATE = 0.970386   # reference vega/utils.py:60
 
-STATUS_BOUNDS, STATUS_ARINYO, STATUS_NONFINITE = 1, 2, 4
+STATUS_BOUNDS, STATUS_ARINYO, STATUS_NONFINITE, STATUS_NOT_CONSTANT = 1, 2, 4, 8
 
 
 class EngineError(RuntimeError):
@@ -130,6 +130,7 @@ def load_library():
     lib.vmx_eval.argtypes = [C.c_void_p, dptr, C.c_int32, dptr, dptr, iptr]
     lib.vmx_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vmx_sync.argtypes = [C.c_void_p]
+    lib.vmx_set_constant_nl_hint.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_stream.argtypes = [C.c_void_p]
     lib.vmx_stream.restype = C.c_void_p
     lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
@@ -152,7 +153,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
+    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
     'vmx_set_profiling', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -632,6 +633,11 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.vmx_sync(self._h))
+
+    def set_constant_nl_hint(self, on=True):
+        """For ``eval_device``: the caller asserts that the Arinyo parameters are identical for all walkers of a
+        batch (violations are flagged per walker, never silently wrong)."""
+        self._check(self.lib.vmx_set_constant_nl_hint(self._h, int(bool(on))))
 
     def stream_handle(self):
         """hipStream_t of the engine as an integer (for ``torch.cuda.ExternalStream``)."""
