@@ -203,6 +203,9 @@ def main():
     vega = VegaInterface(None, problem=prob, max_batch=B, device=local_rank)
     eng = vega.engine
     dev = torch.device('cuda', local_rank)
+    # the walkers of SURVEY 8d vary biases, betas, alphas, HCD and velocity-dispersion parameters; the Arinyo
+    # non-linear parameters are shared by a batch, which the device entry point is told (violations are flagged)
+    eng.set_constant_nl_hint(True)
 
     # distinct walker batches per step and per rank, resident in HBM before timing
     n_pool = min(args.steps, 8)
@@ -307,6 +310,7 @@ def main():
                                    '1590^2 + 3180^2 inverse covariances (BASELINE configs[2])'
                        if args.workload == 'joint' else args.workload,
                        'batch_per_gpu': B, 'pipelines_per_eval': len(eng.pipe_index),
+                       'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
             'roofline': roofline, 'distortion': distortion, 'single_point': single, 'monte_carlo_fits': mc_fits, 'cpu_baseline': cpu,
             'kernels': kernels,
