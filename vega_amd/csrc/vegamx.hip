@@ -99,6 +99,11 @@ struct ItemHost {
 struct vmx_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    // correlation items are independent between xi_bins and chi2: item q > 0 runs on aux[q-1] (fork / join events)
+    hipStream_t cur = nullptr;
+    std::vector<hipStream_t> aux;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
     bool finalized = false;
 
     int nk = 0, nkp = 0, n_mu = 0;
@@ -171,6 +176,9 @@ struct vmx_engine {
         if (pin_theta) (void)hipHostFree(pin_theta);
         if (pin_chi2) (void)hipHostFree(pin_chi2);
         if (pin_status) (void)hipHostFree(pin_status);
+        for (auto& a : aux) (void)hipStreamDestroy(a);
+        for (auto& ev : ev_join) (void)hipEventDestroy(ev);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -188,9 +196,9 @@ struct ScopedTimer {
         }
         idx = (int)e->span_used++;
         e->spans[idx].kc = kc;
-        (void)hipEventRecord(e->spans[idx].a, e->stream);
+        (void)hipEventRecord(e->spans[idx].a, e->cur);
     }
-    ~ScopedTimer() { if (idx >= 0) (void)hipEventRecord(e->spans[idx].b, e->stream); }
+    ~ScopedTimer() { if (idx >= 0) (void)hipEventRecord(e->spans[idx].b, e->cur); }
 };
 
 static void collect_spans(vmx_engine* e)
@@ -286,18 +294,18 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
         if (blocks > M) blocks = M;
         dim3 grid(blocks, 1, nbatch), block(256);
         const size_t shmem = (size_t)K * sizeof(double);
-        if (K <= 2560) hipLaunchKernelGGL(k_gemv1<5>, grid, block, shmem, e->stream, g);
-        else hipLaunchKernelGGL(k_gemv1<10>, grid, block, shmem, e->stream, g);
+        if (K <= 2560) hipLaunchKernelGGL(k_gemv1<5>, grid, block, shmem, e->cur, g);
+        else hipLaunchKernelGGL(k_gemv1<10>, grid, block, shmem, e->cur, g);
         return 1;
     }
     if (N <= 8) {
         g.nsplit = 1; g.klen = K; g.d_slab = 0;
         dim3 grid((M + 3) / 4, 1, nbatch), block(256);
         switch (N) {
-            case 1: hipLaunchKernelGGL(k_gemv<1>, grid, block, 0, e->stream, g); break;
-            case 2: hipLaunchKernelGGL(k_gemv<2>, grid, block, 0, e->stream, g); break;
-            case 3: case 4: hipLaunchKernelGGL(k_gemv<4>, grid, block, 0, e->stream, g); break;
-            default: hipLaunchKernelGGL(k_gemv<8>, grid, block, 0, e->stream, g); break;
+            case 1: hipLaunchKernelGGL(k_gemv<1>, grid, block, 0, e->cur, g); break;
+            case 2: hipLaunchKernelGGL(k_gemv<2>, grid, block, 0, e->cur, g); break;
+            case 3: case 4: hipLaunchKernelGGL(k_gemv<4>, grid, block, 0, e->cur, g); break;
+            default: hipLaunchKernelGGL(k_gemv<8>, grid, block, 0, e->cur, g); break;
         }
         return 1;
     }
@@ -313,7 +321,7 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
     nsplit = (K + klen - 1) / klen;
     g.nsplit = nsplit; g.klen = klen; g.d_slab = (int64_t)N * ldd;
     dim3 grid(tm, tn, nbatch * nsplit), block(256);
-    hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK>), grid, block, 0, e->stream, g);
+    hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK>), grid, block, 0, e->cur, g);
     return nsplit;
 }
 
@@ -344,6 +352,7 @@ int vmx_create(vmx_engine** out, int device)
     e->device = device;
     hipError_t err = hipStreamCreate(&e->stream);
     if (err != hipSuccess) { delete e; return fail(-2, std::string("hipStreamCreate: ") + hipGetErrorString(err)); }
+    e->cur = e->stream;
     *out = e;
     return 0;
 }
@@ -941,6 +950,14 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.model_size = e->model_size;
     D.gcinv = e->gcinv.p; D.g_n = e->g_n; D.g_ld = e->g_ld; D.gres = e->gres.p; D.gz = e->gz.p;
 
+    for (size_t q = 1; q < e->items.size(); ++q) {
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        HIP_OK(hipStreamCreate(&st));
+        HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->aux.push_back(st); e->ev_join.push_back(ev);
+    }
+    HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+
     HIP_OK(hipHostMalloc((void**)&e->pin_theta, (size_t)Bm * n_params * sizeof(double), hipHostMallocDefault));
     HIP_OK(hipHostMalloc((void**)&e->pin_chi2, (size_t)Bm * sizeof(double), hipHostMallocDefault));
     HIP_OK(hipHostMalloc((void**)&e->pin_status, (size_t)Bm * sizeof(int32_t), hipHostMallocDefault));
@@ -1011,9 +1028,12 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode)
         hipLaunchKernelGGL(k_xi_bins, dim3((max_n + 255) / 256, n_pipe, B), dim3(256), 0, e->stream, D);
     }
     SlabInfo slabs{};
+    if (e->items.size() > 1) HIP_OK(hipEventRecord(e->ev_fork, e->stream));
     for (size_t q = 0; q < e->items.size(); ++q) {
         ItemHost* it = e->items[q];
         const ItemDev& d = it->dev;
+        e->cur = q == 0 ? e->stream : e->aux[q - 1];
+        if (q > 0) HIP_OK(hipStreamWaitEvent(e->cur, e->ev_fork, 0));
         // metal matrix products (no split-K: the consumer reads one slab)
         for (auto* m : it->metals) {
             if (m->dev.mat_off < 0) continue;
@@ -1023,7 +1043,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode)
         }
         {
             ScopedTimer t(e, KC_ASSEMBLE);
-            hipLaunchKernelGGL(k_assemble, dim3((d.d.n_model + 255) / 256, B), dim3(256), 0, e->stream, D, (int)q);
+            hipLaunchKernelGGL(k_assemble, dim3((d.d.n_model + 255) / 256, B), dim3(256), 0, e->cur, D, (int)q);
         }
         int dist_slabs = 1;
         if (it->has_dm)
@@ -1031,13 +1051,16 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode)
                                         it->vec.p, d.n_model_pad, 0, B, it->dist.p, d.n_dist_pad, 0, 1, e->slab_rows);
         {
             ScopedTimer t(e, KC_POST);
-            hipLaunchKernelGGL(k_post, dim3((d.d.n_dist + 255) / 256, B), dim3(256), 0, e->stream, D, (int)q, B, dist_slabs);
+            hipLaunchKernelGGL(k_post, dim3((d.d.n_dist + 255) / 256, B), dim3(256), 0, e->cur, D, (int)q, B, dist_slabs);
         }
         slabs.z[q] = 1;
         if (it->has_cinv && !e->gcinv.p)
             slabs.z[q] = launch_product(e, KC_INVCOV, it->cinv.p, d.n_masked_pad, 0, d.n_masked, d.n_masked_pad,
                                         it->res.p, d.n_masked_pad, 0, B, it->z.p, d.n_masked_pad, 0, 1, e->slab_rows);
+        if (q > 0) HIP_OK(hipEventRecord(e->ev_join[q - 1], e->cur));
     }
+    e->cur = e->stream;
+    for (size_t q = 1; q < e->items.size(); ++q) HIP_OK(hipStreamWaitEvent(e->stream, e->ev_join[q - 1], 0));
     slabs.g = 1;
     if (e->gcinv.p)
         slabs.g = launch_product(e, KC_INVCOV, e->gcinv.p, e->g_ld, 0, e->g_n, e->g_ld, e->gres.p, e->g_ld, 0, B,
