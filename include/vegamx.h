@@ -260,7 +260,8 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
 
 /* Stand-alone distortion-style product y[b] = A x[b] through the same kernels the evaluation
  * uses (bench / roofline measurement of the distortion-matrix step).  d_A row-major [rows][cols] with
- * cols a multiple of 32 (zero padded), d_x [B][cols], d_y [B][pad32(rows)], B <= 8, all device pointers;
+ * cols a multiple of 32 (zero padded), d_x [B][cols], d_y [B][pad32(rows)], all device pointers (B <= 8 streams
+ * the matrix once; larger B takes the MFMA path, split-K partial sums added in fixed order);
  * enqueued on the engine stream. */
 int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t cols,
                       const double* d_x, int32_t B, double* d_y);

@@ -148,6 +148,8 @@ struct vmx_engine {
     int g_n = 0, g_ld = 0;
 
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
+    int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
+    DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
     int64_t xi_total = 0, xim_total = 0;
     DevBuf<double> theta, scal, metal_bias, pl, coef, xi, xim, model, chi2;
     DevBuf<int32_t> status, mock_index;
@@ -312,15 +314,19 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
     constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     const int tiles = tm * tn * nbatch;
-    // split K until at least 512 blocks exist (2 per CU); partial sums go to separate slabs
+    // split K (1, 2, 4 or 8 ways: a split belongs to whole XCDs) until at least 512 blocks exist (
+    // 2 per CU); partial sums go to separate slabs, which the consumer kernels re-read: more splits cost there
     int nsplit = 1;
-    if (tiles < 512) nsplit = (512 + tiles - 1) / tiles;
-    if (nsplit > 8) nsplit = 8;
-    while (nsplit > 1 && (int64_t)nsplit * N > slab_rows_avail) --nsplit;
+    while (nsplit < 8 && tiles * nsplit < 512) nsplit *= 2;
+    if (e->gemm_split_override > 0) nsplit = e->gemm_split_override;
+    while (nsplit > 1 && (int64_t)nsplit * N > slab_rows_avail) nsplit /= 2;
     int klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
-    nsplit = (K + klen - 1) / klen;
+    while (nsplit > 1 && (int64_t)klen * (nsplit - 1) >= K) { nsplit /= 2; klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK; }
     g.nsplit = nsplit; g.klen = klen; g.d_slab = (int64_t)N * ldd;
-    dim3 grid(tm, tn, nbatch * nsplit), block(256);
+    g.tm = tm; g.tn = tn;
+    const int ngroups = 8 / nsplit;
+    const int per_xcd = ((tm + ngroups - 1) / ngroups) * tn;
+    dim3 grid(8 * per_xcd, nbatch), block(256);
     hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK>), grid, block, 0, e->cur, g);
     return nsplit;
 }
@@ -714,7 +720,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     HIP_OK(hipSetDevice(e->device));
     const int Bm = max_batch;
     e->n_params = n_params; e->max_batch = Bm;
+    // split-K slabs are re-read by the consumer kernels: at most 512 walker rows of slabs per product (measured
+    // best in the full chain, where the items overlap on separate streams and fill the chip anyway)
     e->slab_rows = Bm > 512 ? Bm : 512;
+    if (const char* ov = getenv("VMX_GEMM_SPLIT")) e->gemm_split_override = atoi(ov);
 
     // every slot must index a theta column and the combinations the kernels rely on must be present
     auto slot_ok = [&](int s) { return s < n_params; };
@@ -1186,9 +1195,21 @@ int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t co
 {
     REQUIRE(e && d_A && d_x && d_y, "vmx_matvec_device");
     REQUIRE(rows > 0 && cols > 0 && cols % VMX_PAD == 0, "cols (leading dimension) must be a multiple of 32, zero padded");
-    REQUIRE(B > 0 && B <= 8, "vmx_matvec_device streams the matrix once: B <= 8");
+    REQUIRE(B > 0, "vmx_matvec_device: B > 0");
     HIP_OK(hipSetDevice(e->device));
-    launch_product(e, KC_MATVEC, d_A, cols, 0, rows, cols, d_x, cols, 0, B, d_y, vmx_pad(rows), 0, 1, 0);
+    const int ldy = vmx_pad(rows);
+    if (B <= 8) {
+        launch_product(e, KC_MATVEC, d_A, cols, 0, rows, cols, d_x, cols, 0, B, d_y, ldy, 0, 1, 0);
+    } else {
+        const size_t need = (size_t)8 * B * ldy;
+        if (e->mv_part.n < need) {
+            HIP_OK(hipStreamSynchronize(e->stream));
+            if (e->mv_part.alloc(need, false)) return -2;
+        }
+        const int ns = launch_product(e, KC_MATVEC, d_A, cols, 0, rows, cols, d_x, cols, 0, B, e->mv_part.p, ldy, 0, 1, 8 * B);
+        const int64_t count = (int64_t)B * ldy;
+        hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->cur, e->mv_part.p, d_y, count, ns);
+    }
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void k_pk_poly(EngineDev D, const int32_t* pol
 // ------------------------------------------------------------------------------------------------
 // D^T[n][m] = sum_k A[m][k] * X[n][k]      (A static matrix, X / D one vector per walker)
 //   fp64 MFMA 16x16x4; block tile 64 x 64 x 16, 4 waves each owning a 32 x 32 quadrant.
-//   blockIdx.z = batch * nsplit + split; split-K partial sums go to separate slabs of D
+//   split-K partial sums go to separate slabs of D
 //   (summed in fixed order by the consumer: results are bitwise reproducible).
 // ------------------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -884,7 +884,8 @@ struct GemmArgs {
     const double* X; int ldx; int64_t x_batch;
     double* D; int ldd; int64_t d_batch; int64_t d_slab;
     int M, N, K;            // K already padded to a multiple of 32 (zero padded operands)
-    int nsplit, klen;       // klen multiple of the K step
+    int nsplit, klen;       // klen multiple of the K step; nsplit in {1, 2, 4, 8} for the MFMA kernel
+    int tm, tn;             // block tiles along matrix rows / walkers (MFMA kernel)
 };
 
 // Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
@@ -901,12 +902,20 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
     __shared__ double sA[2][BM * LD];
     __shared__ double sX[2][BN * LD];
 
-    const int batch = blockIdx.z / g.nsplit, split = blockIdx.z % g.nsplit;
+    // Workgroups are handed to the 8 XCDs round-robin on the linear block index, and every XCD has its own L2.
+    // XCD x works on K split (x % nsplit) only, so the walker operand it touches (N x klen doubles) stays in its
+    // L2, and it visits the walker tiles of one matrix-row tile back to back, so the matrix tile is fetched from
+    // HBM once and found in L2 by the other walker tiles.  gridDim.x = 8 * blocks per XCD.
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int split = xcd % g.nsplit, group = xcd / g.nsplit, ngroups = 8 / g.nsplit;
+    const int mt = (seq / g.tn) * ngroups + group, nt = seq % g.tn;
+    if (mt >= g.tm) return;
+    const int batch = blockIdx.y;
     const double* A = g.A + batch * g.a_batch;
     const double* X = g.X + batch * g.x_batch;
     double* Dp = g.D + batch * g.d_batch + split * g.d_slab;
 
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = mt * BM, n0 = nt * BN;
     const int kbeg = split * g.klen;
     int kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
 
@@ -981,6 +990,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
                 const int m = m0 + wm + 16 * j + (lane & 15);
                 if (n < g.N && m < g.M) Dp[(size_t)n * g.ldd + m] = acc[i][j][r];
             }
+}
+
+// y[n][m] = sum over slabs (fixed order) - used by the stand-alone product entry point
+__global__ void k_sum_slabs(const double* __restrict__ part, double* __restrict__ y, int64_t count, int nslab)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double v = part[i];
+    for (int s = 1; s < nslab; ++s) v += part[(int64_t)s * count + i];
+    y[i] = v;
 }
 
 // Small-batch product (NB <= 8 walkers): HBM-bound streaming of A, one wave per matrix row.
