@@ -266,6 +266,11 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
 int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t cols,
                       const double* d_x, int32_t B, double* d_y);
 
+/* Restrict the event pairs of vmx_set_profiling to the kernel classes whose bit (1 << class index, the index
+ * vmx_kernel_name enumerates) is set: timing one class perturbs a timed run far less than timing all of them.
+ * vmx_set_profiling(e, 1) resets the mask to all classes. */
+int vmx_set_profiling_mask(vmx_engine* e, uint32_t kernel_class_mask);
+
 /* Per-kernel timing with HIP events on the engine stream.  When enabled every kernel launch of
  * vmx_eval* is bracketed by events; vmx_get_timings returns the accumulated milliseconds and
  * launch counts per kernel class since the last reset. */

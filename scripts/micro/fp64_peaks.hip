@@ -59,11 +59,40 @@ void run(const char* name, F kernel, int blocks, int iters, double flop_per_wave
     CK(hipFree(out)); CK(hipFree(clk));
 }
 
+// both pipes at once: MFMA waves and FMA waves resident on the same SIMDs (two streams)
+void coexec(int mfma_blocks, int mfma_iters, int fma_blocks, int fma_iters)
+{
+    double* out; long long* clk;
+    CK(hipMalloc(&out, 8)); CK(hipMalloc(&clk, 16));
+    hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    float ms[3] = {0, 0, 0};
+    for (int mode = 0; mode < 3; ++mode) {      // 0: mfma alone, 1: fma alone, 2: together
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            CK(hipStreamWaitEvent(s1, e0, 0)); CK(hipStreamWaitEvent(s2, e0, 0));
+            if (mode != 1) hipLaunchKernelGGL(k_mfma, dim3(mfma_blocks), dim3(256), 0, s1, out, clk, mfma_iters, 1e-9);
+            if (mode != 0) hipLaunchKernelGGL(k_fma, dim3(fma_blocks), dim3(256), 0, s2, out, clk, fma_iters, 1e-9);
+            CK(hipEventRecord(e1, s1)); CK(hipEventRecord(e2, s2));
+            CK(hipStreamWaitEvent(0, e1, 0)); CK(hipStreamWaitEvent(0, e2, 0));
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms[mode], e0, e1));
+        }
+    }
+    const double tf_m = (double)mfma_blocks * 4 * mfma_iters * 4 * 2048.0, tf_f = (double)fma_blocks * 4 * fma_iters * 8 * 128.0;
+    printf("coexec mfma %d blocks + fma %d blocks: mfma alone %.3f ms (%.1f TF), fma alone %.3f ms (%.1f TF), together %.3f ms (%.1f TF total)\n",
+           mfma_blocks, fma_blocks, ms[0], tf_m / ms[0] / 1e9, ms[1], tf_f / ms[1] / 1e9, ms[2], (tf_m + tf_f) / ms[2] / 1e9);
+}
+
 int main()
 {
     for (int bpc : {1, 2, 4, 8}) run("mfma", k_mfma, 256 * bpc, 40000 / bpc, 4 * 2048.0);
     for (int bpc : {1, 2, 4, 8}) run("fma", k_fma, 256 * bpc, 400000 / bpc, 8 * 128.0);
     run("mfma", k_mfma, 512, 400000, 4 * 2048.0);
     run("fma", k_fma, 1024, 2000000, 8 * 128.0);
+    coexec(512, 40000, 1024, 200000);
+    coexec(512, 40000, 512, 400000);
+    coexec(256, 80000, 1024, 200000);
     return 0;
 }

@@ -164,6 +164,7 @@ struct vmx_engine {
 
     // profiling
     bool profiling = false;
+    uint32_t prof_mask = 0xffffffffu;     // kernel classes that get event pairs while profiling
     struct Span { hipEvent_t a, b; int kc; };
     std::vector<Span> spans;
     size_t span_used = 0;
@@ -190,7 +191,7 @@ namespace {
 struct ScopedTimer {
     vmx_engine* e; int idx = -1;
     ScopedTimer(vmx_engine* eng, int kc) : e(eng) {
-        if (!e->profiling) return;
+        if (!e->profiling || !((e->prof_mask >> kc) & 1u)) return;
         if (e->span_used == e->spans.size()) {
             vmx_engine::Span s{};
             if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
@@ -724,6 +725,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     // best in the full chain, where the items overlap on separate streams and fill the chip anyway)
     e->slab_rows = Bm > 512 ? Bm : 512;
     if (const char* ov = getenv("VMX_GEMM_SPLIT")) e->gemm_split_override = atoi(ov);
+    if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
 
     // every slot must index a theta column and the combinations the kernels rely on must be present
     auto slot_ok = [&](int s) { return s < n_params; };
@@ -1221,6 +1223,7 @@ int vmx_set_profiling(vmx_engine* e, int32_t enabled)
     HIP_OK(hipStreamSynchronize(e->stream));
     if (e->profiling) collect_spans(e);
     e->profiling = enabled != 0;
+    e->prof_mask = 0xffffffffu;
     // create the event pool up front so that no event is created between two launches of a timed run
     while (e->profiling && e->spans.size() < 96) {
         vmx_engine::Span s{};
@@ -1228,6 +1231,16 @@ int vmx_set_profiling(vmx_engine* e, int32_t enabled)
         HIP_OK(hipEventCreate(&s.b));
         e->spans.push_back(s);
     }
+    return 0;
+}
+
+int vmx_set_profiling_mask(vmx_engine* e, uint32_t kernel_class_mask)
+{
+    REQUIRE(e, "vmx_set_profiling_mask");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->profiling) collect_spans(e);
+    e->prof_mask = kernel_class_mask;
     return 0;
 }
 

@@ -138,6 +138,7 @@ def load_library():
     lib.vmx_matvec_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_void_p]
     lib.vmx_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    lib.vmx_set_profiling_mask.argtypes = [C.c_void_p, C.c_uint32]
     lib.vmx_get_timings.argtypes = [C.c_void_p, dptr, C.POINTER(C.c_int64), C.c_int32]
     lib.vmx_struct_size.argtypes = [C.c_int32]
     for which, struct in enumerate((Tracer, PipeDesc, MetalDesc, ItemDesc)):
@@ -154,7 +155,7 @@ EXPORTED_SYMBOLS = [
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
-    'vmx_set_profiling', 'vmx_get_timings', 'vmx_kernel_name']
+    'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
 # --------------------------------------------------------------------------------------
@@ -679,6 +680,14 @@ class Engine:
 
     def set_profiling(self, on):
         self._check(self.lib.vmx_set_profiling(self._h, int(bool(on))))
+
+    def set_profiling_classes(self, names):
+        """Time only the named kernel classes (see timings()) while profiling is on."""
+        index = {self.lib.vmx_kernel_name(i).decode(): i for i in range(VMX_N_KERNELS)}
+        mask = 0
+        for name in names:
+            mask |= 1 << index[name]
+        self._check(self.lib.vmx_set_profiling_mask(self._h, mask))
 
     def timings(self, reset=True):
         ms = np.zeros(VMX_N_KERNELS)
