@@ -152,7 +152,7 @@ struct vmx_engine {
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
     int64_t xi_total = 0, xim_total = 0;
     DevBuf<double> theta, scal, metal_bias, pl, coef, xi, xim, model, chi2;
-    DevBuf<int32_t> status, mock_index;
+    DevBuf<int32_t> status, mock_index, k_live;
     std::vector<int32_t> h_mock_index;
     int last_B = 0;
     EngineDev dev{};
@@ -281,7 +281,7 @@ static int pk_variant(const vmx_pipe_desc& d, bool paired)
 // D[n][m] = sum_k A[m][k] X[n][k]; returns the number of K slabs written (consumer sums them).
 static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64_t a_batch, int M, int K,
                           const double* X, int ldx, int64_t x_batch, int N, double* D, int ldd,
-                          int64_t d_batch, int nbatch, int slab_rows_avail)
+                          int64_t d_batch, int nbatch, int slab_rows_avail, const int32_t* k_limit = nullptr)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.a_batch = a_batch;
@@ -324,7 +324,7 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
     int klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
     while (nsplit > 1 && (int64_t)klen * (nsplit - 1) >= K) { nsplit /= 2; klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK; }
     g.nsplit = nsplit; g.klen = klen; g.d_slab = (int64_t)N * ldd;
-    g.tm = tm; g.tn = tn;
+    g.tm = tm; g.tn = tn; g.k_limit = k_limit;
     const int ngroups = 8 / nsplit;
     const int per_xcd = ((tm + ngroups - 1) / ngroups) * tn;
     dim3 grid(8 * per_xcd, nbatch), block(256);
@@ -933,7 +933,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->metal_bias.alloc((size_t)Bm * (e->metals.size() + 1)) ||
         e->pl.alloc((size_t)VMX_MAX_ELL * ncols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * ncols * e->ncp) ||
         e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
-        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm)) return -2;
+        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(1)) return -2;
     e->h_mock_index.assign(Bm, -1);
     if (e->mock_index.upload(e->h_mock_index.data(), Bm)) return -2;
 
@@ -957,7 +957,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.prior_slot = e->d_prior_slot.p; D.prior_mean = e->d_prior_mean.p; D.prior_sigma = e->d_prior_sigma.p;
     D.n_params = n_params;
     D.theta = e->theta.p; D.scal = e->scal.p; D.metal_bias = e->metal_bias.p; D.pl = e->pl.p; D.coef = e->coef.p;
-    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p; D.mock_index = e->mock_index.p;
+    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p; D.k_live = e->k_live.p; D.mock_index = e->mock_index.p;
     D.model_size = e->model_size;
     D.gcinv = e->gcinv.p; D.g_n = e->g_n; D.g_ld = e->g_ld; D.gres = e->gres.p; D.gz = e->gz.p;
 
@@ -1030,7 +1030,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode)
         const int64_t ncols = (int64_t)B * n_pipe;
         launch_product(e, KC_FFTLOG, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
                        e->pl.p, e->nkp, ncols * e->nkp, (int)ncols, e->coef.p, e->ncp, ncols * e->ncp,
-                       VMX_MAX_ELL, 0);
+                       VMX_MAX_ELL, 0, e->k_live.p);
     }
     {
         ScopedTimer t(e, KC_XI);

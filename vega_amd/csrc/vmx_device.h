@@ -132,6 +132,7 @@ struct EngineDev {
     double* model;              // [B][model_size]
     double* chi2;               // [B]
     int32_t* status;            // [B]
+    int32_t* k_live;            // [1] wavenumbers >= *k_live have P_ell = 0 for every walker and pipeline of the batch
     const int32_t* mock_index;  // [B] row of the mock pool used as data by walker b, -1: the item's data vector
     int32_t model_size;
     // global covariance mode
@@ -160,6 +161,7 @@ __global__ void k_prologue(EngineDev D, int B)
     // thread = (walker, slot): slots 0 .. n_pipe-1 fill one pipeline's scalars, slot n_pipe the walker-level values
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = gid / (D.n_pipe + 1), slot = gid % (D.n_pipe + 1);
+    if (gid == 0) *D.k_live = 0;
     if (b >= B) return;
     const double* t = D.theta + (size_t)b * D.n_params;
 
@@ -729,6 +731,8 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     double e_max = T.e0 + fmax(T.e1, 0.0) + fmax(T.e2, 0.0);
     if (T.paired) e_max += fmax(T.p0 + fmax(T.p1, 0.0), 0.0);
     const bool live_block = __syncthreads_or(!(e_max < -200.0)) != 0;     // block-uniform: the mu loops contain barriers
+    // the FFTLog product skips the wavenumbers past the last live block (their P_ell is exactly zero)
+    if (live_block && threadIdx.x == 0) atomicMax(D.k_live, min((int)(blockIdx.z + 1) * KT, D.nk));
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
     if (variant == PKV_SHARED_W) {
         // one mu loop for all member pipelines (e.g. QSO x each metal line): they share W and differ only in
@@ -839,6 +843,7 @@ __global__ __launch_bounds__(256) void k_pk_poly(EngineDev D, const int32_t* pol
     const double inv_nmu = 1.0 / (double)D.n_mu;
     const size_t ncols = (size_t)B * D.n_pipe, col = (size_t)b * D.n_pipe + p;
     const double* mg0 = D.gk_mom + (size_t)(d.gk_table >= 0 ? d.gk_table : D.n_gk) * 6 * D.nkp;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(D.k_live, D.nk);     // no damping factor: every wavenumber is live
     for (int i = threadIdx.x; i < D.nk; i += 256) {
         const double k = D.k[i];
         double c01 = sc[S_BIAS1], c02 = sc[S_BIAS2];
@@ -886,6 +891,7 @@ struct GemmArgs {
     int M, N, K;            // K already padded to a multiple of 32 (zero padded operands)
     int nsplit, klen;       // klen multiple of the K step; nsplit in {1, 2, 4, 8} for the MFMA kernel
     int tm, tn;             // block tiles along matrix rows / walkers (MFMA kernel)
+    const int32_t* k_limit; // optional device scalar: operand columns >= *k_limit are zero and skipped (MFMA kernel)
 };
 
 // Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
@@ -918,6 +924,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
     const int m0 = mt * BM, n0 = nt * BN;
     const int kbeg = split * g.klen;
     int kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
+    if (g.k_limit) { const int kl = (*g.k_limit + BK - 1) / BK * BK; if (kend > kl) kend = kl; }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 1) * (BM / 2), wn = (wave >> 1) * (BN / 2);
