@@ -91,7 +91,9 @@ def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
     algo_bytes = 8.0 * (n * n + n + n)          # 8 (N_out N_in + B N_in + B N_out)
     cold = algo_bytes / (ms / launches * 1e-3) / 1e9
     hot = algo_bytes / (ms_hot / launches_hot * 1e-3) / 1e9
-    return {'shape': [n, n], 'batch': 1, 'bound': 'hbm', 'algorithmic_bytes': algo_bytes,
+    traffic_file = REPO / 'profiles' / 'r01_distortion_gemv_traffic.json'
+    traffic = json.loads(traffic_file.read_text())['fetch_bytes_per_launch'] if traffic_file.exists() and n == 2500 else None
+    return {'shape': [n, n], 'batch': 1, 'bound': 'hbm', 'algorithmic_bytes': algo_bytes, 'traffic': traffic,
             'us_per_launch': ms / launches * 1e3, 'achieved': cold, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': cold / HBM_PEAK_GBS, 'achieved_cache_resident': hot, 'max_rel_err': err,
             'note': '8 distinct 50 MB matrices round-robin (HBM); cache_resident = one matrix reused'}
@@ -176,6 +178,8 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--workload', default='joint', choices=['joint', 'auto', 'joint_metals'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--core-only', action='store_true',
+                    help='calibration + warm-up + timed steps only (the command the rocprofv3 summaries in profiles/ use)')
     ap.add_argument('--force-dist', action='store_true', help='run the collective path even with one rank')
     args = ap.parse_args()
 
@@ -314,16 +318,25 @@ def main():
                     'frac_of_issue_ceiling': tf / reach}
 
         roofline = roofline_for(dominant, live['ms_per_launch'])
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of `bench.py --core-only` (a counter pass
+        # cannot run inside this process): the committed summary of the latest collection is attached when present
+        traffic_file = REPO / 'profiles' / 'r01_bench_core_traffic.json'
+        traffic = json.loads(traffic_file.read_text())['kernels'] if traffic_file.exists() else {}
+        if roofline is not None and dominant in traffic and args.workload == 'joint' and B == 256:
+            roofline['traffic'] = traffic[dominant]['hbm_bytes_per_launch']
+            roofline['traffic_unit'] = 'bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r01_bench_core_traffic.json)'
+            roofline['algorithmic_bytes_per_launch'] = traffic[dominant]['algorithmic_bytes_per_launch']
         if roofline is not None:
             roofline['launches_timed'] = live['launches']
             roofline['timing'] = 'HIP events on the launch streams, over the timed region'
         roofline_other = [r for r in (roofline_for(k, v['ms_per_launch']) for k, v in kernels.items() if k != dominant)
                           if r is not None]
-        distortion = distortion_microbench(eng, torch)
-        single = single_point_latency(local_rank)
-        mc_fits = monte_carlo_fits(vega) if args.workload == 'joint' else None
+        extras = not args.core_only
+        distortion = distortion_microbench(eng, torch) if extras else None
+        single = single_point_latency(local_rank) if extras else None
+        mc_fits = monte_carlo_fits(vega) if extras and args.workload == 'joint' else None
         cpu = None
-        if not args.no_cpu_baseline:
+        if extras and not args.no_cpu_baseline:
             cpu, ref_vals = cpu_baseline(prob, eng.names, host_theta)
             got = chi2_check = vega.chi2_batch(host_theta[:len(ref_vals)])
             rel = float(np.max(np.abs(got - np.array(ref_vals)) / np.abs(ref_vals)))

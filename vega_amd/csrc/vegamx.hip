@@ -328,7 +328,12 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
     const int ngroups = 8 / nsplit;
     const int per_xcd = ((tm + ngroups - 1) / ngroups) * tn;
     dim3 grid(8 * per_xcd, nbatch), block(256);
-    hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK>), grid, block, 0, e->cur, g);
+    switch (kc) {
+        case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_DISTORTION>), grid, block, 0, e->cur, g); break;
+        case KC_INVCOV: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_INVCOV>), grid, block, 0, e->cur, g); break;
+        case KC_FFTLOG: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_FFTLOG>), grid, block, 0, e->cur, g); break;
+        default: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_OTHER>), grid, block, 0, e->cur, g); break;
+    }
     return nsplit;
 }
 

@@ -897,7 +897,8 @@ struct GemmArgs {
 // Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
 // (BM/2) x (BN/2) sub-tile as (BN/32) x (BM/32) MFMA tiles.  LDS rows are padded to BK + 2 doubles, which
 // makes the 16-row x 4-k operand read pattern of v_mfma_f64_16x16x4 conflict-free for ds_read_b64.
-template <int BM, int BN, int BK>
+// TAG = kernel class of the caller: one instantiation (and one name in a profiler's kernel table) per product of the chain.
+template <int BM, int BN, int BK, int TAG>
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
 {
     constexpr int LD = BK + 2;
