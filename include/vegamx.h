@@ -187,6 +187,10 @@ int vmx_set_shotnoise_table(vmx_engine* e, const double* a, int32_t n, double ta
 /* Returns the item id (>= 0). */
 int vmx_add_item(vmx_engine* e, const vmx_item_desc* desc);
 int vmx_item_add_metal(vmx_engine* e, int32_t item, const vmx_metal_desc* desc);
+/* `fast_metals` (metals.py:144-169): a metal x metal correlation frozen at the first evaluation.  The metal is
+ * added with desc.pipeline = -1 and contributes bias_product * xi[bin] with this static vector (already
+ * multiplied by its metal matrix and multiplicity-free: desc.multiplicity still applies). */
+int vmx_item_set_metal_static(vmx_engine* e, int32_t item, int32_t index, const double* xi, int32_t n_model);
 
 /* Additive template of the non-peak component: v += amp * vec[bin] before the pre-distortion broadband
  * (DESI instrumental systematics, model.py:133-135, correlation_func.py:553-595).  amp = theta[slot], or
@@ -254,7 +258,9 @@ int vmx_set_constant_nl_hint(vmx_engine* e, int32_t enabled);
 void* vmx_stream(vmx_engine* e);
 
 /* Stage taps for parity tests: copy an internal buffer of the last evaluation to the host.
- * what: 0 = P_ell(k) [n_ell_max][B*n_pipe][nk_pad]; 1 = xi per pipeline [B][n] (index = pipeline).
+ * what: 0 = P_ell(k) [n_ell_max][B*n_pipe][nk_pad]; 1 = xi per pipeline [B][n] (index = pipeline);
+ * 2 = spline coefficients; 3 = metal correlation after its metal matrix [B][pad32(n_model)] (index = metal, in the
+ * global order of vmx_item_add_metal).
  * Returns the number of doubles written (<= capacity) or a negative error. */
 int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, int64_t capacity);
 

@@ -533,12 +533,33 @@ def correlation_function(prob, pipe, grid, pk, pk_lin, params, taps=None):
 # --------------------------------------------------------------------------------------
 # metals (reference vega/metals.py:209-367)
 # --------------------------------------------------------------------------------------
+def reset_metal_cache(prob):
+    """Forget the frozen metal x metal correlations of `fast_metals` (a fresh reference VegaInterface)."""
+    for item in prob.items.values():
+        item.__dict__.pop('_oracle_xi_metal_metal', None)
+
+
 def metals_compute(prob, item, grid, params, pk_lin, taps=None):
-    """Metals.compute, slow (exact) mode (reference metals.py:258-336)."""
+    """Metals.compute (reference metals.py:258-336): exact mode, and the `fast_metals` mode with its two caches -
+    metal x metal correlations frozen at the first evaluation (:144-169, keyed by the tracer pair), and the
+    per-call cache of the undistorted main x metal correlations (:171-207), whose key is (beta1, beta2, every
+    parameter value) WITHOUT the tracer pair: pairs with equal betas reuse the first such pair's xi, computed on that
+    first pair's coordinates."""
     opts = item.metal_opts
     local = dict(params)
     main = (item.tracer1.name, item.tracer2.name)
+    fast_metals = opts['fast_metals']
+    if fast_metals and 'growth_rate' in local and prob.growth_rate is not None:
+        local['growth_rate'] = prob.growth_rate               # reference metals.py:280-282
+    frozen = item.__dict__.setdefault('_oracle_xi_metal_metal', {}) if fast_metals else None
+    cross_cache = {}                                          # cleared at every call (reference :284)
     xi_metals = np.zeros(item.model_grid.size)
+
+    def undistorted(pair, fast):
+        pk = power_spectrum(pair.pipeline, grid, pk_lin, prob.pk_fid, local, fast_metals=fast)
+        xi = correlation_function(prob, pair.pipeline, grid, pk, pk_lin, local)
+        return xi * 2 if pair.double_count else xi            # reference metals.py:238-239
+
     for pair in item.metals:
         n1, n2 = pair.names
         if opts['single_metal_beta']:
@@ -546,7 +567,7 @@ def metals_compute(prob, item, grid, params, pk_lin, taps=None):
                 local[f'beta_{n1}'] = local['beta_metals']
             if n2 not in main:
                 local[f'beta_{n2}'] = local['beta_metals']
-        b1, _, b2, _ = bias_beta(local, n1, n2)
+        b1, beta1, b2, beta2 = bias_beta(local, n1, n2)
         bias_product = b1 * b2
         if (not pair.cross_with_main) and opts['separate_metal_auto_biases'] and n1 != n2:
             for cand in pair.auto_bias_names:
@@ -557,12 +578,22 @@ def metals_compute(prob, item, grid, params, pk_lin, taps=None):
                 raise ValueError(f'no separate auto bias for {pair.names}')
 
         fast = opts['fast_metal_bias']
-        pk = power_spectrum(pair.pipeline, grid, pk_lin, prob.pk_fid, local, fast_metals=fast)
-        xi = correlation_function(prob, pair.pipeline, grid, pk, pk_lin, local)
-        if pair.double_count:
-            xi = xi * 2                                   # reference metals.py:238-239
-        if pair.matrix is not None:
-            xi = pair.matrix.dot(xi)                      # reference metals.py:338-367
+        if fast_metals and pair.cross_with_main:
+            key = (beta1, beta2) + tuple(local[k] for k in sorted(local))
+            if key not in cross_cache:
+                cross_cache[key] = undistorted(pair, True)
+            xi = cross_cache[key]
+            if pair.matrix is not None:
+                xi = pair.matrix.dot(xi)                      # reference metals.py:338-367
+        elif fast_metals:
+            if pair.names not in frozen:
+                xi = undistorted(pair, True)
+                frozen[pair.names] = pair.matrix.dot(xi) if pair.matrix is not None else xi
+            xi = frozen[pair.names]
+        else:
+            xi = undistorted(pair, fast)
+            if pair.matrix is not None:
+                xi = pair.matrix.dot(xi)
         if taps is not None:
             taps.setdefault('xi_metal', {})[pair.names] = xi
         xi_metals = xi_metals + (bias_product * xi if fast else xi)

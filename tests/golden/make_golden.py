@@ -140,6 +140,15 @@ def derive_configs():
     text = re.sub(r'\[metals\][^\[]*', '', (cfg_out / 'full4' / 'lyalya_lyalya.ini').read_text())
     (d / 'lyalya_lyalya.ini').write_text(text.replace('[model]', '[model]\nUVB-shotnoise = True\n'
                                                       'desi-instrumental-systematics = True'))
+    # joint + metals with the reference's `fast_metals` switch (metal x metal xi frozen at the first evaluation)
+    d = cfg_out / 'joint_metals_fast'
+    d.mkdir(exist_ok=True)
+    items = ['lyalya_lyalya', 'lyalya_qso']
+    line = 'ini files = ' + ' '.join(f'configs/joint_metals_fast/{it}.ini' for it in items)
+    (d / 'main.ini').write_text(re.sub(r'ini files = .*', line, main))
+    for it in items:
+        text = (cfg_out / 'joint_metals' / f'{it}.ini').read_text()
+        (d / f'{it}.ini').write_text(text.replace('[model]', '[model]\nfast_metals = True'))
     print('wrote configs under', cfg_out)
 
 
@@ -366,6 +375,44 @@ def dump_extras(VegaInterface):
         print('extras: chi2', out['fid/chi2'], out['walker0/chi2'])
 
 
+def dump_fast_metals(VegaInterface):
+    """`fast_metals = True` (reference metals.py:53,144-169,280-282): metal x metal correlations are computed at
+    the FIRST evaluation and reused for ever after.  Sequence dumped: chi2 at the fiducial point (fills the cache),
+    then 4 walkers (chi2 and model each), all against that frozen cache."""
+    os.chdir(REF / 'tests')
+    items = ['lyalya_lyalya', 'lyalya_qso']
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, items, True)
+        for it in items:
+            p = Path(tmp) / f'{it}.ini'
+            p.write_text(p.read_text().replace('[model]', '[model]\nfast_metals = True'))
+        vega = VegaInterface(main)
+        out = {'fid/chi2': vega.chi2()}
+        model = vega.compute_model(run_init=False)
+        for name in items:
+            out[f'fid/model/{name}'] = model[name]
+        names, walkers = make_walkers(vega.params, 4, seed=WALKER_SEED + 9)
+        # the mode assumes that only the metal biases change between evaluations (metals.py:147-148): the
+        # metal betas stay at their fiducial values, everything else is perturbed
+        for w in walkers:
+            for n in names:
+                if n.startswith('beta_') and n not in ('beta_LYA', 'beta_QSO', 'beta_hcd'):
+                    w[n] = vega.params[n]
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+        chi2s = []
+        for i, w in enumerate(walkers):
+            _reset_caches(vega)
+            chi2s.append(vega.chi2(w))
+            _reset_caches(vega)
+            model = vega.compute_model(w, run_init=False)
+            for name in items:
+                out[f'walker{i}/model/{name}'] = model[name]
+        out['chi2'] = np.array(chi2s)
+        np.savez_compressed(HERE / 'expected_joint_metals_fast.npz', **out)
+        print('fast_metals: fid chi2', out['fid/chi2'], 'walkers', out['chi2'])
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -373,12 +420,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -391,3 +438,5 @@ if __name__ == '__main__':
         dump_mc(VI)
     if 'extras' in what:
         dump_extras(VI)
+    if 'fast_metals' in what:
+        dump_fast_metals(VI)

@@ -128,3 +128,41 @@ def test_table_bundle_round_trip(tmp_path):
     back = read_tables(tmp_path / 'x.npz')[0]
     assert back.header == {'RPMIN': 0.0, 'NP': 50} and back.names == ['RP', 'DM']
     np.testing.assert_array_equal(back.data['DM'], np.eye(3))
+
+
+def test_fast_metal_plan_follows_the_reference_caches():
+    """metals_plan.fast_metal_plan: metal x metal pairs become static vectors, main x metal pairs with equal betas
+    share the first such pair's pipeline (the reference's per-call cache is blind to the tracer pair), unless a
+    sampled parameter could separate their betas later."""
+    import copy
+    from vega_amd import metals_plan
+    prob = load_problem('joint_metals_fast')
+    assert metals_plan.needs_freeze(prob) and not metals_plan.needs_freeze(load_problem('joint_metals'))
+    calls = []
+
+    def metal_xi(name, mi):
+        calls.append((name, mi))
+        return np.full(prob.items[name].model_grid.size, float(mi))
+
+    plan, pinned = metals_plan.fast_metal_plan(prob, dict(prob.params), metal_xi)
+    assert set(pinned) == {f'beta_{m}' for m in ('SiII(1190)', 'SiII(1193)', 'SiIII(1207)', 'SiII(1260)')}
+    auto, cross = plan['lyalya_lyalya'], plan['lyalya_qso']
+    pairs = prob.items['lyalya_lyalya'].metals
+    kinds = [k for k, _ in auto]
+    assert kinds.count('pipeline') == 1 and kinds.count('share') == 3 and kinds.count('static') == 11
+    for (kind, arg), pair in zip(auto, pairs):
+        assert (kind == 'static') == (not pair.cross_with_main)
+        if kind == 'share':
+            assert auto[arg][0] == 'pipeline' and pairs[arg].cross_with_main
+    assert [k for k, _ in cross] == ['pipeline', 'share', 'share', 'share']
+    assert len(calls) == 11
+    # a different beta separates a pair from its leader
+    pars = dict(prob.params)
+    pars['beta_SiII(1193)'] = 0.7
+    kinds = [k for k, _ in metals_plan.fast_metal_plan(prob, pars, metal_xi)[0]['lyalya_qso']]
+    assert kinds.count('pipeline') == 2
+    # equal values but one of the betas is sampled: no sharing with that pair
+    prob2 = copy.deepcopy(prob)
+    prob2.sample_params['limits']['beta_SiII(1193)'] = (0., 5.)
+    kinds = [k for k, _ in metals_plan.fast_metal_plan(prob2, dict(prob2.params), metal_xi)[0]['lyalya_qso']]
+    assert kinds.count('pipeline') == 2 and kinds.count('share') == 2

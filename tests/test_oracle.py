@@ -239,3 +239,27 @@ def test_uv_shotnoise_and_instrumental_systematics_match_reference():
     assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-12)
     np.testing.assert_allclose(oc.compute_model(prob, pars)['lyalya_lyalya'], exp['walker0/model'],
                                rtol=1e-11, atol=1e-16)
+
+
+def test_fast_metals_caches_match_reference():
+    """`fast_metals = True` (reference metals.py:144-207): metal x metal correlations frozen at the first
+    evaluation and the pair-blind per-call cache of the main x metal correlations - the oracle reproduces the
+    reference's sequence (fiducial first, then walkers) bit for bit."""
+    prob = load_problem('joint_metals_fast')
+    exp = np.load(GOLDEN / 'expected_joint_metals_fast.npz')
+    oc.reset_metal_cache(prob)
+    assert oc.chi2(prob) == pytest.approx(float(exp['fid/chi2']), rel=1e-13)
+    names = [str(n) for n in exp['param_names']]
+    for i, row in enumerate(exp['theta']):
+        pars = dict(zip(names, row))
+        assert oc.chi2(prob, pars) == pytest.approx(float(exp['chi2'][i]), rel=1e-13)
+        model = oc.compute_model(prob, pars)
+        for name in prob.items:
+            ref = exp[f'walker{i}/model/{name}']
+            assert np.abs(model[name] - ref).max() <= 1e-13 * np.abs(ref).max()
+    # a different first evaluation freezes different metal x metal terms: the mode is history dependent
+    oc.reset_metal_cache(prob)
+    first = dict(zip(names, exp['theta'][0]))
+    oc.chi2(prob, first)
+    assert oc.chi2(prob) != pytest.approx(float(exp['fid/chi2']), rel=1e-9)
+    oc.reset_metal_cache(prob)

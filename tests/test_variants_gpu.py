@@ -192,3 +192,35 @@ def test_uv_shotnoise_and_instrumental_systematics():
     assert np.abs(got - exp['walker0/model']).max() <= XI_RTOL * np.abs(exp['walker0/model']).max()
     vega.close()
     _check(prob, n_walkers=2)
+
+
+def test_fast_metals_frozen_caches_match_reference():
+    """`fast_metals = True`: the reference's own sequence (chi2 at the fiducial point first - which freezes the
+    metal x metal terms - then walkers) through the engine, against the reference's outputs.  After the freeze the
+    engine runs 6 pipelines instead of 23: 4 core + one main x metal pipeline per item (equal betas), and the 11
+    metal x metal terms are static vectors."""
+    from vega_amd import VegaInterface
+    from conftest import load_problem
+    exp = np.load(GOLDEN / 'expected_joint_metals_fast.npz')
+    vega = VegaInterface(None, problem=load_problem('joint_metals_fast'), max_batch=4)
+    assert len(vega.engine.pipe_index) == 23
+    assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    assert len(vega.engine.pipe_index) == 6
+    model = vega.compute_model()
+    for name in vega.corr_items:
+        ref = exp[f'fid/model/{name}']
+        assert np.abs(model[name] - ref).max() <= XI_RTOL * np.abs(ref).max()
+    names = [str(n) for n in exp['param_names']]
+    theta = np.stack([vega.engine.theta_from_params(dict(zip(names, row))) for row in exp['theta']])
+    chi2, status = vega.chi2_batch(theta, return_status=True)
+    assert not status.any()
+    np.testing.assert_allclose(chi2, exp['chi2'], rtol=CHI2_RTOL)
+    models = vega.compute_model_batch(theta)
+    for i in range(theta.shape[0]):
+        for name in vega.corr_items:
+            ref = exp[f'walker{i}/model/{name}']
+            assert np.abs(models[name][i] - ref).max() <= XI_RTOL * np.abs(ref).max(), (i, name)
+    # an unsampled beta that made two pairs share a pipeline may not move afterwards
+    with pytest.raises(ValueError, match='fast_metals'):
+        vega.chi2({'beta_SiII(1193)': 0.7})
+    vega.close()

@@ -80,7 +80,7 @@ static int upload_padded(DevBuf<double>& buf, const double* host, int rows, int 
 
 struct MetalHost {
     MetalDev dev{};
-    DevBuf<double> mat;
+    DevBuf<double> mat, svec;
     int rows = 0, cols = 0;
 };
 
@@ -553,16 +553,32 @@ int vmx_item_add_metal(vmx_engine* e, int32_t item, const vmx_metal_desc* desc)
 {
     REQUIRE(e && !e->finalized && desc, "vmx_item_add_metal");
     REQUIRE(item == (int)e->items.size() - 1, "metals must be added to the most recent item");
-    REQUIRE(desc->pipeline >= 0 && desc->pipeline < (int)e->pipes.size(), "metal pipeline id");
+    REQUIRE(desc->pipeline >= -1 && desc->pipeline < (int)e->pipes.size(), "metal pipeline id");
     ItemHost* it = e->items[item];
     REQUIRE((int)it->metals.size() < VMX_MAX_METALS, "too many metals");
     auto* m = new MetalHost();
     m->dev.d = *desc;
     m->dev.mat_off = -1;
+    m->dev.svec = nullptr;
     it->metals.push_back(m);
     e->metals.push_back(m);
     it->dev.n_metals = (int)it->metals.size();
     return (int)it->metals.size() - 1;
+}
+
+int vmx_item_set_metal_static(vmx_engine* e, int32_t item, int32_t index, const double* xi, int32_t n_model)
+{
+    REQUIRE(e && !e->finalized && xi, "vmx_item_set_metal_static");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(index >= 0 && index < (int)it->metals.size(), "metal index");
+    REQUIRE(n_model == it->dev.d.n_model, "static metal correlation size");
+    MetalHost* m = it->metals[index];
+    REQUIRE(m->dev.d.pipeline == -1, "a static correlation replaces the pipeline: add the metal with pipeline = -1");
+    HIP_OK(hipSetDevice(e->device));
+    if (m->svec.upload(xi, (size_t)n_model)) return -2;
+    m->dev.svec = m->svec.p;
+    return 0;
 }
 
 int vmx_item_add_broadband(vmx_engine* e, int32_t item, int32_t position, int32_t func, int32_t n_coef,
@@ -615,6 +631,7 @@ int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index
         REQUIRE(!e->finalized, "metal matrices must be set before vmx_finalize");
         REQUIRE(index >= 0 && index < (int)it->metals.size(), "metal index");
         MetalHost* m = it->metals[index];
+        REQUIRE(m->dev.d.pipeline >= 0, "a static metal correlation takes no matrix");
         REQUIRE(rows == it->dev.d.n_model && cols == e->pipes[m->dev.d.pipeline].n, "metal matrix shape");
         if (upload_padded(m->mat, dense, rows, cols, vmx_pad(cols))) return -2;
         m->rows = rows; m->cols = cols;
@@ -888,6 +905,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     std::vector<MetalDev> metals;
     for (auto* it : e->items)
         for (auto* m : it->metals) {
+            REQUIRE(m->dev.d.pipeline >= 0 || m->dev.svec, "metal without pipeline and without static correlation");
             if (m->dev.mat_off >= 0) { m->dev.xim_off = xim_off; xim_off += (int64_t)Bm * it->dev.n_model_pad; }
             metals.push_back(m->dev);
         }
@@ -1191,6 +1209,13 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
         if (index < 0 || index >= (int)e->pipes.size()) { fail(-1, "invalid argument: pipeline index"); return -1; }
         src = e->xi.p + e->pipes[index].xi_off; count = (int64_t)B * e->pipes[index].n_pad;
     } else if (what == 2) { src = e->coef.p; count = (int64_t)VMX_MAX_ELL * B * e->pipes.size() * e->ncp; }
+    else if (what == 3) {
+        // correlation of metal `index` (global order of vmx_item_add_metal) after its metal matrix
+        if (index < 0 || index >= (int)e->metals.size() || e->metals[index]->dev.mat_off < 0) { fail(-1, "invalid argument: metal without matrix"); return -1; }
+        int n_model_pad = 0;
+        for (auto* it : e->items) for (auto* m : it->metals) if (m == e->metals[index]) n_model_pad = it->dev.n_model_pad;
+        src = e->xim.p + e->metals[index]->dev.xim_off; count = (int64_t)B * n_model_pad;
+    }
     else { fail(-1, "invalid argument: what"); return -1; }
     if (count > capacity) { fail(-1, "invalid argument: capacity too small"); return -1; }
     if (hipMemcpy(out, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }

@@ -59,6 +59,7 @@ struct MetalDev {
     int64_t mat_off;      // offset of the dense metal matrix (-1: identity)
     int32_t mat_ld;
     int64_t xim_off;      // offset into the metal-product buffer (per-walker stride n_model_pad)
+    const double* svec;   // static correlation [n_model] (fast_metals: frozen metal x metal term) instead of a pipeline
 };
 
 struct ItemDev {
@@ -1277,7 +1278,8 @@ __global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item)
         const MetalDev& md = D.metals[it.metal_begin + m];
         const double f = D.metal_bias[(size_t)b * D.n_metals_total + it.metal_begin + m];
         double x;
-        if (md.mat_off >= 0) x = D.xim[md.xim_off + (size_t)b * it.n_model_pad + bin];
+        if (md.svec) x = md.svec[bin];
+        else if (md.mat_off >= 0) x = D.xim[md.xim_off + (size_t)b * it.n_model_pad + bin];
         else { const PipeDev& Pm = D.pipes[md.d.pipeline]; x = D.xi[Pm.xi_off + (size_t)b * Pm.n_pad + bin]; }
         v = fma(f, x, v);
     }

@@ -137,6 +137,7 @@ def load_library():
     lib.vmx_debug_read.restype = C.c_int64
     lib.vmx_matvec_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_void_p]
+    lib.vmx_item_set_metal_static.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_profiling_mask.argtypes = [C.c_void_p, C.c_uint32]
     lib.vmx_get_timings.argtypes = [C.c_void_p, dptr, C.POINTER(C.c_int64), C.c_int32]
@@ -152,7 +153,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table',
     'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
-    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
+    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
@@ -385,9 +386,13 @@ class Lowering:
 class Engine:
     """One vegamx engine handle on one GPU, built from a Problem."""
 
-    def __init__(self, problem, max_batch=256, device=0, extra_names=()):
+    def __init__(self, problem, max_batch=256, device=0, extra_names=(), metal_plan=None):
         self.lib = load_library()
         self.prob = problem
+        # fast_metals (see fast_metal_plan): per item, per metal pair ('pipeline', None) | ('share', leader index)
+        # | ('static', xi vector)
+        self.metal_plan = metal_plan or {}
+        self.metal_source = {}          # (item name, pair index) -> (global metal index, pipeline id, has matrix)
         self.low = Lowering(problem, extra_names)
         self.names = self.low.names
         self.n_params = len(self.names)
@@ -487,6 +492,7 @@ class Engine:
 
         self.item_names = list(prob.items)
         self.model_slices = {}
+        n_metals_total = 0
         off = 0
         self.pipe_index = {}
         for qi, (name, item) in enumerate(prob.items.items()):
@@ -506,6 +512,8 @@ class Engine:
                 override = prob.growth_rate if (opts['fast_metals'] and 'growth_rate' in low.slot
                                                 and prob.growth_rate is not None) else None
                 beta_subst = {}
+                plan = self.metal_plan.get(name)
+                pair_pid = {}
                 for mi, pair in enumerate(item.metals):
                     n1, n2 = pair.names
                     if opts['single_metal_beta']:
@@ -516,10 +524,17 @@ class Engine:
                                 beta_subst[n] = 'beta_metals'
                     betas = (beta_subst.get(n1), beta_subst.get(n2))
                     fast = bool(opts['fast_metal_bias'])
-                    pid = self._add_pipeline(
-                        low.pipeline(self, pair.pipeline, 'full', fast_metals=fast, beta_names=betas,
-                                     growth_rate_override=override), pair.pipeline, prob.pk_full)
-                    self.pipe_index[(name, pair.names)] = pid
+                    kind, arg = plan[mi] if plan else ('pipeline', None)
+                    if kind == 'pipeline':
+                        pid = self._add_pipeline(
+                            low.pipeline(self, pair.pipeline, 'full', fast_metals=fast, beta_names=betas,
+                                         growth_rate_override=override), pair.pipeline, prob.pk_full)
+                        self.pipe_index[(name, pair.names)] = pid
+                        pair_pid[mi] = pid
+                    elif kind == 'share':
+                        pid = pair_pid[arg]     # the reference's per-call cache hands this pair the leader's xi
+                    else:
+                        pid = -1
                     md = MetalDesc()
                     md.pipeline = pid
                     md.tracer[0] = low.tracer(pair.pipeline.tracer1, beta_name=betas[0])
@@ -539,7 +554,12 @@ class Engine:
                     md.apply_bias = int(fast)
                     md.multiplicity = 2.0 if pair.double_count else 1.0
                     self._check(lib.vmx_item_add_metal(self._h, iid, C.byref(md)))
-                    if pair.matrix is not None:
+                    self.metal_source[(name, mi)] = (n_metals_total, pid, pair.matrix is not None)
+                    n_metals_total += 1
+                    if kind == 'static':
+                        vec = _f64(arg)
+                        self._check(lib.vmx_item_set_metal_static(self._h, iid, mi, _dp(vec), vec.size))
+                    elif pair.matrix is not None:
                         dense = _f64(pair.matrix.toarray() if hasattr(pair.matrix, 'toarray') else pair.matrix)
                         self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_METAL, mi, dense.shape[0],
                                                             dense.shape[1], _dp(dense)))
@@ -674,6 +694,16 @@ class Engine:
         if n < 0:
             raise EngineError(self.lib.vmx_last_error().decode())
         return out[:n]
+
+    def metal_xi(self, item_name, pair_index):
+        """Correlation of one metal pair in the last evaluation (walker 0): after its metal matrix, before the
+        bias product and the multiplicity."""
+        g, pid, has_matrix = self.metal_source[(item_name, pair_index)]
+        n = self.prob.items[item_name].model_grid.size
+        cap = self.max_batch * ((n + 31) // 32 * 32)
+        if has_matrix:
+            return self.debug_read(3, g, cap)[:n].copy()
+        return self.debug_read(1, pid, cap)[:n].copy()
 
     def matvec_device(self, d_A, rows, cols_padded, d_x, B, d_y):
         self._check(self.lib.vmx_matvec_device(self._h, d_A, rows, cols_padded, d_x, B, d_y))

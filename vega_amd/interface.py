@@ -10,6 +10,7 @@ import copy
 
 import numpy as np
 
+from . import metals_plan
 from .engine import Engine
 from .setup import build_problem
 
@@ -53,8 +54,14 @@ class VegaInterface:
         self._use_global_cov = self.problem.global_cov is not None
         self.monte_carlo = False
         self._mc_active = False
-        self.engine = Engine(self.problem, max_batch=max_batch, device=device, extra_names=extra_names)
+        self._engine_args = dict(max_batch=max_batch, device=device, extra_names=extra_names)
+        self.engine = Engine(self.problem, **self._engine_args)
         self.param_names = self.engine.names
+        # fast_metals: the reference fills its metal caches at the first evaluation (metals_plan.py)
+        self._metals_frozen = not metals_plan.needs_freeze(self.problem)
+        self._pinned_slots = np.zeros(0, dtype=np.int64)
+        self._pinned_values = np.zeros(0)
+        self._pinned_names = []
 
     # ------------------------------------------------------------------ parameter marshalling
     def _theta(self, params=None):
@@ -65,6 +72,37 @@ class VegaInterface:
         if isinstance(params_list, np.ndarray):
             return np.atleast_2d(params_list)
         return np.stack([self._theta(p) for p in params_list])
+
+    def freeze_metals(self, params=None):
+        """`fast_metals`: evaluate once with every metal pair on its own pipeline, keep the metal x metal
+        correlations of that evaluation as static vectors and rebuild the engine without their pipelines (and with
+        the main x metal pairs the reference's per-call cache merges sharing one).  Called automatically by the
+        first evaluation, with that evaluation's parameters - the moment the reference fills its caches.  The
+        engine object is replaced: re-read ``self.engine`` afterwards."""
+        if self._metals_frozen:
+            return
+        theta = np.asarray(params, dtype=np.float64) if isinstance(params, np.ndarray) else self._theta(params)
+        boot = self.engine
+        boot.eval(theta[None, :])
+        plan, pinned = metals_plan.fast_metal_plan(self.problem, dict(zip(boot.names, theta)), boot.metal_xi)
+        boot.close()
+        self.engine = Engine(self.problem, metal_plan=plan, **self._engine_args)
+        assert self.engine.names == self.param_names
+        self._pinned_slots = np.array([self.engine.low.slot[n] for n in pinned], dtype=np.int64)
+        self._pinned_values = np.array(list(pinned.values()), dtype=np.float64)
+        self._pinned_names = list(pinned)
+        self._metals_frozen = True
+        self._mc_active = False
+
+    def _check_pinned(self, theta):
+        """Main x metal pairs that shared the reference's per-call cache at the first evaluation share a pipeline
+        here; that stays equivalent only while the unsampled parameters behind their equal betas keep their
+        values."""
+        if self._pinned_slots.size and not np.array_equal(
+                np.broadcast_to(self._pinned_values, (theta.shape[0], self._pinned_values.size)),
+                theta[:, self._pinned_slots]):
+            raise ValueError('fast_metals: ' + ', '.join(self._pinned_names) + ' must keep the values of the first '
+                             'evaluation (or be listed in [sample]): main x metal pairs with equal betas were merged')
 
     def _sync_monte_carlo(self):
         """chi2 reads the current mock and the scaled inverse covariance in Monte-Carlo mode
@@ -91,6 +129,8 @@ class VegaInterface:
             raise NotImplementedError('direct_pk is not accelerated')
         if marg_coeff is not None:
             raise NotImplementedError('marginalisation templates are not accelerated')
+        self.freeze_metals(params)
+        self._check_pinned(self._theta(params)[None, :])
         _, status, model = self.engine.eval(self._theta(params)[None, :], want_model=True)
         if status[0]:
             from .errors import VegaModelError
@@ -101,6 +141,8 @@ class VegaInterface:
         """float chi2; 1e100 when the model cannot be evaluated (reference :268-279)."""
         if direct_pk is not None or return_marg_coeff:
             raise NotImplementedError('direct_pk / marginalisation coefficients are not accelerated')
+        self.freeze_metals(params)
+        self._check_pinned(self._theta(params)[None, :])
         self._sync_monte_carlo()
         chi2, _, _ = self.engine.eval(self._theta(params)[None, :])
         return float(chi2[0])
@@ -136,8 +178,10 @@ class VegaInterface:
     def chi2_batch(self, params_list, return_status=False):
         """chi2 for many parameter points: list of dicts or [B, n_params] array (column order
         ``self.param_names``).  Points are evaluated in chunks of ``max_batch``."""
-        self._sync_monte_carlo()
         theta = self.theta_matrix(params_list)
+        self.freeze_metals(theta[0])        # fast_metals: the first point of the first batch plays the first call
+        self._check_pinned(theta)
+        self._sync_monte_carlo()
         out = np.empty(theta.shape[0])
         status = np.empty(theta.shape[0], dtype=np.int32)
         mb = self.engine.max_batch
@@ -152,6 +196,8 @@ class VegaInterface:
 
     def compute_model_batch(self, params_list):
         theta = self.theta_matrix(params_list)
+        self.freeze_metals(theta[0])
+        self._check_pinned(theta)
         blocks = []
         mb = self.engine.max_batch
         for lo in range(0, theta.shape[0], mb):
@@ -165,6 +211,7 @@ class VegaInterface:
         vega/vega_interface.py:581, vega/minimizer.py:39-103).  Returns a FitResult with one fit; the best fit
         is also kept in ``self.bestfit``."""
         from .montecarlo import MonteCarlo
+        self.freeze_metals()
         self._sync_monte_carlo()
         fitter = MonteCarlo(self).minimizer(tol=tol)
         start = None
@@ -178,6 +225,7 @@ class VegaInterface:
         """Create ``num_mocks`` mocks around ``fiducial_model`` (default: the model at the current parameters)
         and fit them all in lock-step (reference Analysis.run_monte_carlo, vega/analysis.py:224-308)."""
         from .montecarlo import MonteCarlo
+        self.freeze_metals()
         if fiducial_model is None:
             fiducial_model = self.compute_model()
         self.analysis = MonteCarlo(self)
