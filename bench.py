@@ -44,7 +44,8 @@ def build_problem(workload):
     from vega_amd.setup import build_problem as bp
     from vega_amd import synthetic
     cfg = {'joint': 'configs/joint/main.ini', 'auto': 'configs/auto/main.ini',
-           'joint_metals': 'configs/joint_metals/main.ini'}[workload]
+           'joint_metals': 'configs/joint_metals/main.ini',
+           'joint_metals_fast': 'configs/joint_metals_fast/main.ini'}[workload]
     prob = bp(cfg, search_dirs=[REPO / 'tests' / 'golden'])
     for item in prob.items.values():
         item.distortion = synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt)
@@ -176,7 +177,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256)
-    ap.add_argument('--workload', default='joint', choices=['joint', 'auto', 'joint_metals'])
+    ap.add_argument('--workload', default='joint', choices=['joint', 'auto', 'joint_metals', 'joint_metals_fast'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--core-only', action='store_true',
                     help='calibration + warm-up + timed steps only (the command the rocprofv3 summaries in profiles/ use)')
@@ -208,6 +209,7 @@ def main():
     B = args.batch
     prob = build_problem(args.workload)
     vega = VegaInterface(None, problem=prob, max_batch=B, device=local_rank)
+    vega.freeze_metals()            # fast_metals workloads: the first evaluation (fiducial point) fills the metal caches
     eng = vega.engine
     dev = torch.device('cuda', local_rank)
     # the walkers of SURVEY 8d vary biases, betas, alphas, HCD and velocity-dispersion parameters; the Arinyo

@@ -166,3 +166,35 @@ def test_fast_metal_plan_follows_the_reference_caches():
     prob2.sample_params['limits']['beta_SiII(1193)'] = (0., 5.)
     kinds = [k for k, _ in metals_plan.fast_metal_plan(prob2, dict(prob2.params), metal_xi)[0]['lyalya_qso']]
     assert kinds.count('pipeline') == 2 and kinds.count('share') == 2
+
+
+def test_monte_carlo_tables_round_trip_in_the_reference_layout(tmp_path):
+    """vega_amd.output.write_monte_carlo: the HDUs / columns of reference vega/output.py:442-520, read back with
+    the FITS reader that parses the reference's own files."""
+    from types import SimpleNamespace
+    from vega_amd import fitslite, output
+    rng = np.random.default_rng(0)
+    n_mocks, names = 5, ['ap', 'at', 'bias_eta_LYA']
+    values, errors = rng.normal(size=(n_mocks, 3)), rng.uniform(0.1, 1, size=(n_mocks, 3))
+    analysis = SimpleNamespace(
+        mc_mocks={'lyalya_lyalya': rng.normal(size=(n_mocks, 40)), 'lyalya_qso': rng.normal(size=(n_mocks, 60))},
+        mc_bestfits={n: np.stack([values[:, j], errors[:, j]], axis=1) for j, n in enumerate(names)},
+        mc_covariances=[rng.normal(size=(3, 3)) for _ in range(n_mocks)],
+        mc_chisq=list(rng.uniform(90, 110, n_mocks)), mc_valid_minima=[True, True, False, True, True],
+        mc_valid_hesse=[True] * n_mocks, mc_failed_mask=[False, False, True, False, False])
+    path = output.write_monte_carlo(analysis, tmp_path / 'monte_carlo', cpu_id=3)
+    assert path.name == 'monte_carlo_3.fits' and path.stat().st_size % 2880 == 0
+    hdul = fitslite.open(path)
+    assert [h.header.get('EXTNAME') for h in hdul[1:]] == ['Bestfit', 'FitInfo', 'Mocks']
+    best = hdul[1].data
+    assert [s.strip() for s in best['names']] == names
+    np.testing.assert_array_equal(best['values'], values.T)
+    np.testing.assert_array_equal(best['errors'], errors.T)
+    cov = np.array(analysis.mc_covariances).reshape(n_mocks * 3, 3).T
+    np.testing.assert_array_equal(best['covariance'], cov)
+    info = hdul[2].data
+    np.testing.assert_array_equal(info['chisq'], analysis.mc_chisq)
+    assert bytes(info['valid_minima'].astype('u1')) == b'TTFTT' and bytes(info['failed_mask'].astype('u1')) == b'FFTFF'
+    np.testing.assert_array_equal(hdul[3].data['lyalya_qso'], analysis.mc_mocks['lyalya_qso'])
+    with pytest.raises(OSError):
+        output.write_monte_carlo(analysis, tmp_path / 'monte_carlo', cpu_id=3)

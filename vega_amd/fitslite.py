@@ -167,3 +167,76 @@ def open(path):  # noqa: A001 - mirrors astropy.io.fits.open
             hdus.append(HDU(header))
         pos += ((size + _BLOCK - 1) // _BLOCK) * _BLOCK
     return hdus
+
+
+# ------------------------------------------------------------------------------------------ writer
+def _card(key, value, comment=''):
+    if isinstance(value, bool):
+        v = f"{'T' if value else 'F':>20}"
+    elif isinstance(value, (int, np.integer)):
+        v = f'{int(value):>20}'
+    elif isinstance(value, float):
+        v = f'{value:>20.13E}'
+    else:
+        text = "'" + str(value).replace("'", "''").ljust(8) + "'"
+        v = f'{text:<20}'
+    card = f'{key:<8}= {v}'
+    if comment:
+        card += f' / {comment}'
+    return card[:_CARD].ljust(_CARD)
+
+
+def _header_bytes(cards):
+    text = ''.join(cards) + 'END'.ljust(_CARD)
+    text += ' ' * (-len(text) % _BLOCK)
+    return text.encode('ascii')
+
+
+def write_tables(path, tables, overwrite=False):
+    """Write a FITS file: empty primary HDU + one BINTABLE per entry of ``tables`` =
+    [(extname, [(column name, TFORM, array), ...]), ...].  TFORM: 'D' / 'nD' (float64), 'K' / 'nK' (int64),
+    'L' (logical), 'nA' (strings).  Vector columns take arrays of shape [rows, n].  The layout is the one
+    ``astropy.io.fits.BinTableHDU.from_columns`` produces for the same columns (reference vega/output.py)."""
+    import os
+    if os.path.exists(path) and not overwrite:
+        raise OSError(f'File {path!r} already exists.')
+    out = [_header_bytes([_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', 8),
+                          _card('NAXIS', 0), _card('EXTEND', True)])]
+    for extname, columns in tables:
+        names, formats, arrays = [], [], []
+        nrow = None
+        for name, tform, arr in columns:
+            repeat, code = _parse_tform(tform)
+            arr = np.asarray(arr)
+            if code == 'A':
+                arr = np.char.encode(np.char.ljust(arr.astype(str), repeat), 'ascii').astype(f'S{repeat}')
+                fmt = f'S{repeat}'
+            elif code == 'L':
+                arr = np.where(arr.astype(bool), ord('T'), ord('F')).astype('i1')
+                fmt = 'i1' if repeat == 1 else ('i1', (repeat,))
+            else:
+                base, _ = _TFORM_DTYPES[code]
+                arr = arr.astype(base)
+                fmt = base if repeat == 1 else (base, (repeat,))
+            if repeat > 1 and code != 'A' and (arr.ndim != 2 or arr.shape[1] != repeat):
+                raise ValueError(f'column {name!r}: array shape {arr.shape} does not match TFORM {tform}')
+            if nrow is None:
+                nrow = arr.shape[0]
+            elif arr.shape[0] != nrow:
+                raise ValueError(f'column {name!r} has {arr.shape[0]} rows, expected {nrow}')
+            names.append(name); formats.append(fmt); arrays.append(arr)
+        dt = np.dtype({'names': names, 'formats': formats})
+        rec = np.zeros(nrow or 0, dtype=dt)
+        for name, arr in zip(names, arrays):
+            rec[name] = arr
+        cards = [_card('XTENSION', 'BINTABLE', 'binary table extension'), _card('BITPIX', 8), _card('NAXIS', 2),
+                 _card('NAXIS1', dt.itemsize), _card('NAXIS2', nrow or 0), _card('PCOUNT', 0), _card('GCOUNT', 1),
+                 _card('TFIELDS', len(names))]
+        for i, (name, tform, _) in enumerate(columns, start=1):
+            cards += [_card(f'TTYPE{i}', name), _card(f'TFORM{i}', tform)]
+        cards.append(_card('EXTNAME', extname))
+        data = rec.tobytes()
+        out += [_header_bytes(cards), data + b'\x00' * (-len(data) % _BLOCK)]
+    with builtins.open(path, 'wb') as f:
+        for chunk in out:
+            f.write(chunk)

@@ -117,12 +117,21 @@ class MonteCarlo:
         self.has_monte_carlo = True
         return res
 
+    def write(self, directory, cpu_id=None, overwrite=False):
+        """`monte_carlo[_<cpu_id>].fits` in the reference's layout (reference vega/output.py:442-520)."""
+        from .output import write_monte_carlo
+        return write_monte_carlo(self, directory, cpu_id=cpu_id, overwrite=overwrite)
 
-def run_monte_carlo_sharded(vega, fiducial_model, num_mc_mocks, seed=0, rank=0, world_size=1, **kw):
+
+def run_monte_carlo_sharded(vega, fiducial_model, num_mc_mocks, seed=0, rank=0, world_size=1, output_dir=None,
+                            **kw):
     """The rank's share of ``num_mc_mocks`` with the reference's seeding: ceil(N / size) mocks per rank drawn
-    from ``seed + rank`` (reference bin/run_vega_mc_mpi.py:52-65)."""
+    from ``seed + rank``, and one result file per rank when ``output_dir`` is given (reference
+    bin/run_vega_mc_mpi.py:52-71)."""
     lo, hi = shard_bounds(num_mc_mocks, world_size, rank)
     per = -(-num_mc_mocks // world_size)
     mc = MonteCarlo(vega)
     res = mc.run_monte_carlo(fiducial_model, num_mocks=per, seed=int(seed + rank), **kw)
+    if output_dir is not None:
+        mc.write(output_dir, cpu_id=rank if world_size > 1 else None, overwrite=True)
     return mc, res, (lo, hi)
