@@ -129,9 +129,13 @@ def single_point_latency(device, reps=200):
             'us_per_eval': dt * 1e6, 'kernel_us_per_launch': kern}
 
 
-def monte_carlo_fits(vega, n_mocks=128):
-    """BASELINE configs[4] in miniature: n_mocks Monte-Carlo realisations of the bench workload, each fitted over
-    (ap, at, bias_eta_LYA, beta_LYA, beta_QSO, bias_hcd) by the batched minimiser, all in lock-step."""
+def monte_carlo_fits(prob, device, n_mocks=1024):
+    """One GPU's share of BASELINE configs[4] (8192 mocks over 8 GPUs): n_mocks Monte-Carlo realisations of the
+    bench workload, each fitted over (ap, at, bias_eta_LYA, beta_LYA, beta_QSO, bias_hcd) by the batched minimiser,
+    all in lock-step; mock generation (Cholesky factor x normal draws) included."""
+    from vega_amd import VegaInterface
+    vega = VegaInterface(None, problem=prob, max_batch=4096, device=device)
+    vega.chi2()
     names = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'bias_hcd']
     limits = {'ap': (0.5, 1.5), 'at': (0.5, 1.5), 'bias_eta_LYA': (-2., 0.), 'beta_LYA': (0., 5.),
               'beta_QSO': (0., 1.), 'bias_hcd': (-0.5, 0.)}
@@ -143,6 +147,7 @@ def monte_carlo_fits(vega, n_mocks=128):
     dt = time.perf_counter() - t0
     truth = np.array([vega.params[n] for n in names])
     pulls = (res.values - truth) / res.errors
+    vega.close()
     return {'workload': f'{n_mocks} mocks x {len(names)}-parameter fits (mock generation + minimisation + Hessian)',
             'fits_per_s': n_mocks / dt, 'seconds': dt, 'chi2_evaluations': int(res.nfcn.sum()),
             'evals_per_fit': float(res.nfcn.mean()), 'valid_fraction': float(res.is_valid.mean()),
@@ -336,7 +341,7 @@ def main():
         extras = not args.core_only
         distortion = distortion_microbench(eng, torch) if extras else None
         single = single_point_latency(local_rank) if extras else None
-        mc_fits = monte_carlo_fits(vega) if extras and args.workload == 'joint' else None
+        mc_fits = monte_carlo_fits(prob, local_rank) if extras and args.workload == 'joint' else None
         cpu = None
         if extras and not args.no_cpu_baseline:
             cpu, ref_vals = cpu_baseline(prob, eng.names, host_theta)

@@ -272,6 +272,12 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
 int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t cols,
                       const double* d_x, int32_t B, double* d_y);
 
+/* Host-pointer convenience around the same product: Y[b] = A X[b] for row-major host arrays A [rows][cols],
+ * X [B][cols], Y [B][rows] (padding, upload and download inside; synchronous).  Used once per Monte-Carlo run for
+ * mock = fiducial + cholesky(C) . randn (data.py:751-753) on all mocks at once. */
+int vmx_matmul_host(vmx_engine* e, const double* A, int32_t rows, int32_t cols, const double* X, int32_t B,
+                    double* Y);
+
 /* Restrict the event pairs of vmx_set_profiling to the kernel classes whose bit (1 << class index, the index
  * vmx_kernel_name enumerates) is set: timing one class perturbs a timed run far less than timing all of them.
  * vmx_set_profiling(e, 1) resets the mask to all classes. */

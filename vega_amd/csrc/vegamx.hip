@@ -1246,6 +1246,21 @@ int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t co
     return 0;
 }
 
+int vmx_matmul_host(vmx_engine* e, const double* A, int32_t rows, int32_t cols, const double* X, int32_t B, double* Y)
+{
+    REQUIRE(e && A && X && Y && rows > 0 && cols > 0 && B > 0, "vmx_matmul_host");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    const int ld = vmx_pad(cols), ldy = vmx_pad(rows);
+    DevBuf<double> dA, dX, dY;
+    if (upload_padded(dA, A, rows, cols, ld) || upload_padded(dX, X, B, cols, ld) || dY.alloc((size_t)B * ldy, true)) return -2;
+    if (vmx_matvec_device(e, dA.p, rows, ld, dX.p, B, dY.p)) return -2;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipMemcpy2D(Y, (size_t)rows * sizeof(double), dY.p, (size_t)ldy * sizeof(double), (size_t)rows * sizeof(double), B,
+                       hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int vmx_set_profiling(vmx_engine* e, int32_t enabled)
 {
     REQUIRE(e, "vmx_set_profiling");

@@ -138,6 +138,7 @@ def load_library():
     lib.vmx_matvec_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_void_p]
     lib.vmx_item_set_metal_static.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
+    lib.vmx_matmul_host.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_int32, dptr, C.c_int32, dptr]
     lib.vmx_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_profiling_mask.argtypes = [C.c_void_p, C.c_uint32]
     lib.vmx_get_timings.argtypes = [C.c_void_p, dptr, C.POINTER(C.c_int64), C.c_int32]
@@ -155,7 +156,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device',
+    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -707,6 +708,13 @@ class Engine:
 
     def matvec_device(self, d_A, rows, cols_padded, d_x, B, d_y):
         self._check(self.lib.vmx_matvec_device(self._h, d_A, rows, cols_padded, d_x, B, d_y))
+
+    def matmul_host(self, A, X):
+        """X @ A.T on the GPU for host arrays A [rows, cols], X [B, cols] (the product kernels of the chain)."""
+        A, X = _f64(A), _f64(X)
+        Y = np.empty((X.shape[0], A.shape[0]))
+        self._check(self.lib.vmx_matmul_host(self._h, _dp(A), A.shape[0], A.shape[1], _dp(X), X.shape[0], _dp(Y)))
+        return Y
 
     def set_profiling(self, on):
         self._check(self.lib.vmx_set_profiling(self._h, int(bool(on))))

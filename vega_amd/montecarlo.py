@@ -14,8 +14,10 @@ from .minimizer import BatchedMinimizer
 from .parallel import shard_bounds
 
 
-def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecast=False):
-    """dict name -> [num_mocks, n_masked] masked mock data vectors, in the reference's draw order."""
+def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecast=False, matmul=None):
+    """dict name -> [num_mocks, n_masked] masked mock data vectors, in the reference's draw order.
+    ``matmul(L, Z) -> Z @ L.T`` (default: NumPy) applies the Cholesky factor to all draws of an item at once -
+    the driver passes the engine's product so that the only O(n^2) step per mock runs on the GPU."""
     scale = 1. if scale is None else scale
     np.random.seed(seed)
     chol = {}
@@ -31,17 +33,23 @@ def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecas
             model = model[keep]
         fid[name] = model[item.data_mask]
         if not forecast:
-            n = item.data_size
-            cov = np.eye(n) if item.cov is None else item.cov[:, item.data_mask][item.data_mask, :]
-            chol[name] = np.linalg.cholesky(scale * cov)
-    mocks = {name: np.empty((num_mocks, item.data_size)) for name, item in problem.items.items()}
+            cache = item.__dict__.setdefault('_masked_cholesky', {})       # one factorisation per (item, scale)
+            if scale not in cache:
+                n = item.data_size
+                cov = np.eye(n) if item.cov is None else item.cov[:, item.data_mask][item.data_mask, :]
+                cache[scale] = np.linalg.cholesky(scale * cov)
+            chol[name] = cache[scale]
+    if forecast:
+        return {name: np.tile(fid[name], (num_mocks, 1)) for name in problem.items}
+    # the legacy global generator is consumed mock by mock, item by item (reference vega/data.py:751-753)
+    draws = {name: np.empty((num_mocks, item.data_size)) for name, item in problem.items.items()}
     for i in range(num_mocks):
         for name, item in problem.items.items():
-            if forecast:
-                mocks[name][i] = fid[name]
-            else:
-                mocks[name][i] = fid[name] + chol[name].dot(np.random.randn(item.data_size))
-    return mocks
+            draws[name][i] = np.random.randn(item.data_size)
+    if matmul is None:
+        def matmul(L, Z):
+            return Z @ L.T
+    return {name: fid[name][None, :] + matmul(chol[name], draws[name]) for name in problem.items}
 
 
 class MonteCarlo:
@@ -86,7 +94,8 @@ class MonteCarlo:
                         run_mc_fits=True, sample_params=None):
         vega = self.vega
         eng = vega.engine
-        mocks = create_mocks(vega.problem, fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast)
+        mocks = create_mocks(vega.problem, fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast,
+                             matmul=eng.matmul_host)
         self.mc_mocks = mocks
         if not run_mc_fits:
             self.has_monte_carlo = True
