@@ -230,17 +230,24 @@ def main():
         if i == 0:
             host_theta = th
         pools.append(torch.from_numpy(th).to(dev))
-    chi2_dev = torch.zeros(B, dtype=torch.float64, device=dev)
-    gathered = torch.zeros(world * B, dtype=torch.float64, device=dev) if use_dist else None
-
-    # the collective is ordered after the evaluation on the engine's own stream: no host synchronisation per step
+    # two output / gather buffer pairs: the collective of step i runs on its own stream while step i + 1 computes
+    chi2_bufs = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered = [torch.zeros(world * B, dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
     eng_stream = torch.cuda.ExternalStream(eng.stream_handle(), device=dev)
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    comm_done = [None, None]
 
     def step(i):
-        eng.eval_device(pools[i % n_pool].data_ptr(), B, chi2_dev.data_ptr())
+        slot = i % 2
+        if use_dist and comm_done[slot] is not None:
+            eng_stream.wait_event(comm_done[slot])      # the gather that last read this buffer pair has finished
+        eng.eval_device(pools[i % n_pool].data_ptr(), B, chi2_bufs[slot].data_ptr())
         if use_dist:
-            with torch.cuda.stream(eng_stream):
-                dist.all_gather_into_tensor(gathered, chi2_dev)
+            # one all_gather of chi2 per step, ordered after the evaluation by an event: no host synchronisation
+            comm_stream.wait_event(eng_stream.record_event())
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(gathered[slot], chi2_bufs[slot])
+                comm_done[slot] = comm_stream.record_event()
 
     # Calibration pass (untimed): HIP-event pairs around every kernel class give the per-kernel breakdown and name
     # the dominant class.  Event pairs around all ~20 launches of a step cost ~7 % of throughput, so the timed
@@ -285,8 +292,9 @@ def main():
     if use_dist:
         # the gathered vector holds every rank's chi2 of the last step, rank-major
         torch.cuda.synchronize()
-        mine = gathered[rank * B:(rank + 1) * B]
-        if not torch.equal(mine, chi2_dev) or not bool(torch.isfinite(gathered).all()):
+        last = (args.steps - 1) % 2
+        mine = gathered[last][rank * B:(rank + 1) * B]
+        if not torch.equal(mine, chi2_bufs[last]) or not bool(torch.isfinite(gathered[last]).all()):
             raise SystemExit('all_gather of chi2 returned unexpected values')
     if rank == 0:
         total_evals = B * args.steps * world
