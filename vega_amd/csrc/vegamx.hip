@@ -159,6 +159,7 @@ struct vmx_engine {
 
     // host path: pinned staging buffers and one captured graph per batch size
     double* pin_theta = nullptr; double* pin_chi2 = nullptr; int32_t* pin_status = nullptr;
+    double* dpin_theta = nullptr; double* dpin_chi2 = nullptr; int32_t* dpin_status = nullptr;   // device views
     std::map<int, hipGraphExec_t> graphs;
     bool use_graphs = true;
 
@@ -278,10 +279,14 @@ static int pk_variant(const vmx_pipe_desc& d, bool paired)
     return PKV_GENERIC;
 }
 
+// the single-walker streaming kernel keeps x in LDS
+static bool gemv1_applies(int N, int K) { return N == 1 && K <= 5120 && (size_t)K * sizeof(double) <= 48 * 1024; }
+
 // D[n][m] = sum_k A[m][k] X[n][k]; returns the number of K slabs written (consumer sums them).
 static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64_t a_batch, int M, int K,
                           const double* X, int ldx, int64_t x_batch, int N, double* D, int ldd,
-                          int64_t d_batch, int nbatch, int slab_rows_avail, const int32_t* k_limit = nullptr)
+                          int64_t d_batch, int nbatch, int slab_rows_avail, const int32_t* k_limit = nullptr,
+                          int fused_item = -1)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.a_batch = a_batch;
@@ -289,7 +294,7 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
     g.D = D; g.ldd = ldd; g.d_batch = d_batch;
     g.M = M; g.N = N; g.K = K;
     ScopedTimer timer(e, kc);
-    if (N == 1 && K <= 5120 && (size_t)K * sizeof(double) <= 48 * 1024) {
+    if (gemv1_applies(N, K)) {
         // persistent streaming kernel: 2 blocks per CU, rows strided over blocks
         g.nsplit = 1; g.klen = K; g.d_slab = 0;
         int blocks = 512;
@@ -297,8 +302,13 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
         if (blocks > M) blocks = M;
         dim3 grid(blocks, 1, nbatch), block(256);
         const size_t shmem = (size_t)K * sizeof(double);
-        if (K <= 2560) hipLaunchKernelGGL(k_gemv1<5>, grid, block, shmem, e->cur, g);
-        else hipLaunchKernelGGL(k_gemv1<10>, grid, block, shmem, e->cur, g);
+        if (fused_item >= 0) {
+            if (K <= 2560) hipLaunchKernelGGL((k_gemv1<5, true>), grid, block, shmem, e->cur, g, e->dev, fused_item);
+            else hipLaunchKernelGGL((k_gemv1<10, true>), grid, block, shmem, e->cur, g, e->dev, fused_item);
+        } else {
+            if (K <= 2560) hipLaunchKernelGGL((k_gemv1<5, false>), grid, block, shmem, e->cur, g, e->dev, 0);
+            else hipLaunchKernelGGL((k_gemv1<10, false>), grid, block, shmem, e->cur, g, e->dev, 0);
+        }
         return 1;
     }
     if (N <= 8) {
@@ -992,9 +1002,16 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     }
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
 
-    HIP_OK(hipHostMalloc((void**)&e->pin_theta, (size_t)Bm * n_params * sizeof(double), hipHostMallocDefault));
-    HIP_OK(hipHostMalloc((void**)&e->pin_chi2, (size_t)Bm * sizeof(double), hipHostMallocDefault));
-    HIP_OK(hipHostMalloc((void**)&e->pin_status, (size_t)Bm * sizeof(int32_t), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&e->pin_theta, (size_t)Bm * n_params * sizeof(double), hipHostMallocMapped));
+    HIP_OK(hipHostMalloc((void**)&e->pin_chi2, (size_t)Bm * sizeof(double), hipHostMallocMapped));
+    HIP_OK(hipHostMalloc((void**)&e->pin_status, (size_t)Bm * sizeof(int32_t), hipHostMallocMapped));
+    if (!getenv("VMX_NO_ZERO_COPY") &&
+        (hipHostGetDevicePointer((void**)&e->dpin_theta, e->pin_theta, 0) != hipSuccess ||
+         hipHostGetDevicePointer((void**)&e->dpin_chi2, e->pin_chi2, 0) != hipSuccess ||
+         hipHostGetDevicePointer((void**)&e->dpin_status, e->pin_status, 0) != hipSuccess)) {
+        (void)hipGetLastError();
+        e->dpin_theta = nullptr; e->dpin_chi2 = nullptr; e->dpin_status = nullptr;     // staging copies instead
+    }
 
     HIP_OK(hipStreamSynchronize(e->stream));
     e->finalized = true;
@@ -1004,15 +1021,22 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 int vmx_model_size(vmx_engine* e) { return e ? e->model_size : -1; }
 
 // enqueue the whole kernel chain for the B parameter points already in e->theta
-static int run_chain(vmx_engine* e, int B, bool tab_mode)
+static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false)
 {
     EngineDev D = e->dev;
     D.n_const_slots = tab_mode ? (int)e->const_slots.size() : 0;
+    if (zero_copy) {
+        D.theta_host = e->dpin_theta; D.theta_copy = e->theta.p;
+        D.chi2_host = e->dpin_chi2; D.status_host = e->dpin_status;
+    }
     const int n_pipe = D.n_pipe;
     {
         ScopedTimer t(e, KC_PROLOGUE);
         const int n_thr = B * (n_pipe + 1);
-        hipLaunchKernelGGL(k_prologue, dim3((n_thr + 63) / 64), dim3(64), 0, e->stream, D, B);
+        if (zero_copy)      // one block holds every walker of the (small) batch in LDS
+            hipLaunchKernelGGL(k_prologue, dim3(1), dim3((n_thr + 63) / 64 * 64), (size_t)B * e->n_params * sizeof(double), e->stream, D, B);
+        else
+            hipLaunchKernelGGL(k_prologue, dim3((n_thr + 63) / 64), dim3(64), 0, e->stream, D, B);
     }
     {
         ScopedTimer t(e, KC_PK);
@@ -1075,15 +1099,19 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode)
             launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
                            e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, d.n_model_pad, 0, 1, 0);
         }
-        {
+        // a single walker is latency-bound: its distortion product assembles x while staging it and finishes
+        // each row with the post step, instead of three launches
+        const bool fuse = B == 1 && it->has_dm && gemv1_applies(1, d.n_model_pad);
+        if (!fuse) {
             ScopedTimer t(e, KC_ASSEMBLE);
             hipLaunchKernelGGL(k_assemble, dim3((d.d.n_model + 255) / 256, B), dim3(256), 0, e->cur, D, (int)q);
         }
         int dist_slabs = 1;
         if (it->has_dm)
             dist_slabs = launch_product(e, KC_DISTORTION, it->dm.p, d.n_model_pad, 0, d.d.n_dist, d.n_model_pad,
-                                        it->vec.p, d.n_model_pad, 0, B, it->dist.p, d.n_dist_pad, 0, 1, e->slab_rows);
-        {
+                                        it->vec.p, d.n_model_pad, 0, B, it->dist.p, d.n_dist_pad, 0, 1, e->slab_rows,
+                                        nullptr, fuse ? (int)q : -1);
+        if (!fuse) {
             ScopedTimer t(e, KC_POST);
             hipLaunchKernelGGL(k_post, dim3((d.d.n_dist + 255) / 256, B), dim3(256), 0, e->cur, D, (int)q, B, dist_slabs);
         }
@@ -1109,17 +1137,17 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode)
 }
 
 // run the chain for B walkers: replay a captured graph when one exists (or can be captured), else launch eagerly
-static int run_chain_cached(vmx_engine* e, int B, bool tab_mode)
+static int run_chain_cached(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false)
 {
     tab_mode = tab_mode && e->n_xtab > 0;
-    if (!e->use_graphs || e->profiling) return run_chain(e, B, tab_mode);
-    const int key = B * 2 + (tab_mode ? 1 : 0);
+    if (!e->use_graphs || e->profiling) return run_chain(e, B, tab_mode, zero_copy);
+    const int key = (B * 2 + (tab_mode ? 1 : 0)) * 2 + (zero_copy ? 1 : 0);
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
-        if (e->graphs.size() >= 64) return run_chain(e, B, tab_mode);
+        if (e->graphs.size() >= 64) return run_chain(e, B, tab_mode, zero_copy);
         hipGraph_t graph = nullptr;
         HIP_OK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = run_chain(e, B, tab_mode);
+        const int rc = run_chain(e, B, tab_mode, zero_copy);
         hipError_t err = hipStreamEndCapture(e->stream, &graph);
         if (rc || err != hipSuccess || graph == nullptr) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -1127,7 +1155,7 @@ static int run_chain_cached(vmx_engine* e, int B, bool tab_mode)
                          err != hipSuccess ? hipGetErrorString(err) : "launch error");
             (void)hipGetLastError();
             e->use_graphs = false;      // capture is not available: stay on eager launches
-            return run_chain(e, B, tab_mode);
+            return run_chain(e, B, tab_mode, zero_copy);
         }
         hipGraphExec_t exec = nullptr;
         err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1135,7 +1163,7 @@ static int run_chain_cached(vmx_engine* e, int B, bool tab_mode)
         if (err != hipSuccess) {
             std::fprintf(stderr, "[vegamx] graph instantiation failed (%s): falling back to eager launches\n", hipGetErrorString(err));
             e->use_graphs = false;
-            return run_chain(e, B, tab_mode);
+            return run_chain(e, B, tab_mode, zero_copy);
         }
         it = e->graphs.emplace(key, exec).first;
     }
@@ -1181,16 +1209,21 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     REQUIRE(e && e->finalized && theta, "vmx_eval");
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
+    // small batches are latency-bound: the first kernel reads the walkers from the mapped pinned buffer and the last
+    // one stores chi2 / status there, which removes three staging copies (~25 us of a ~100 us evaluation)
+    const bool zero_copy = B <= 8 && B * ((int)e->pipes.size() + 1) <= 1024 && (size_t)B * e->n_params * sizeof(double) <= 48 * 1024 &&
+                           e->dpin_theta && e->dpin_chi2 && e->dpin_status;
     std::memcpy(e->pin_theta, theta, (size_t)B * e->n_params * sizeof(double));
-    HIP_OK(hipMemcpyAsync(e->theta.p, e->pin_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    if (!zero_copy)
+        HIP_OK(hipMemcpyAsync(e->theta.p, e->pin_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
     // the D_NL * G table pays off once a batch shares its Arinyo parameters (checked here, on the host copy)
     bool tab_mode = B >= 16 && e->n_xtab > 0;
     for (int b = 1; b < B && tab_mode; ++b)
         for (int slot : e->const_slots)
             if (theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = false; break; }
-    if (run_chain_cached(e, B, tab_mode)) return -2;
-    if (chi2) HIP_OK(hipMemcpyAsync(e->pin_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    if (status) HIP_OK(hipMemcpyAsync(e->pin_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (run_chain_cached(e, B, tab_mode, zero_copy)) return -2;
+    if (chi2 && !zero_copy) HIP_OK(hipMemcpyAsync(e->pin_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (status && !zero_copy) HIP_OK(hipMemcpyAsync(e->pin_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (model) HIP_OK(hipMemcpyAsync(model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if (vmx_sync(e)) return -2;
     if (chi2) std::memcpy(chi2, e->pin_chi2, (size_t)B * sizeof(double));

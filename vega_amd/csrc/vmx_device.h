@@ -124,6 +124,9 @@ struct EngineDev {
     // batch buffers
     int32_t n_params;
     const double* theta;        // [B][n_params]
+    // small host batches skip the staging copies: k_prologue reads the walkers from mapped pinned host memory and
+    // leaves a device copy in `theta_copy` (= theta) for the later kernels; k_chi2 stores its results to host too
+    const double* theta_host; double* theta_copy; double* chi2_host; int32_t* status_host;
     double* scal;               // [B][n_pipe][VMX_NS]
     double* metal_bias;         // [B][n_metals_total]
     double* pl;                 // [n_ell][B*n_pipe][nkp]
@@ -163,8 +166,17 @@ __global__ void k_prologue(EngineDev D, int B)
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = gid / (D.n_pipe + 1), slot = gid % (D.n_pipe + 1);
     if (gid == 0) *D.k_live = 0;
-    if (b >= B) return;
     const double* t = D.theta + (size_t)b * D.n_params;
+    if (D.theta_host) {
+        // zero-copy entry (small batches, one block): one coalesced read of the walkers from mapped host memory into
+        // LDS - a single PCIe round trip instead of one per parameter lookup - and the device copy for later kernels
+        extern __shared__ double s_theta[];
+        const int count = B * D.n_params;
+        for (int i = threadIdx.x; i < count; i += blockDim.x) { const double v = D.theta_host[i]; s_theta[i] = v; D.theta_copy[i] = v; }
+        __syncthreads();
+        t = s_theta + (size_t)b * D.n_params;
+    }
+    if (b >= B) return;
 
     if (slot < D.n_pipe) {
         const int p = slot;
@@ -873,6 +885,95 @@ __global__ __launch_bounds__(256) void k_pk_poly(EngineDev D, const int32_t* pol
 }
 
 // ------------------------------------------------------------------------------------------------
+// broadband helpers
+// ------------------------------------------------------------------------------------------------
+__device__ inline double bb_total(const EngineDev& D, const ItemDev& it, int pos, const double* t, int bin, int n)
+{
+    const bool mul = (pos == VMX_BB_PRE_MUL || pos == VMX_BB_POST_MUL);
+    double total = mul ? 1.0 : 0.0;
+    for (int q = 0; q < it.n_bb[pos]; ++q) {
+        const BBTermDev& term = it.bb[pos][q];
+        const double* basis = D.bb_basis + term.basis_off;
+        double corr = 0.0;
+        if (term.func == VMX_BB_SKY) {
+            const double scale = t[term.slot[0]], sigma = t[term.slot[1]];
+            const double rt = basis[bin], w = basis[(size_t)n + bin];
+            if (w != 0.0) {
+                const double q2 = rt / sigma;
+                corr = scale / (sigma * sqrt(2.0 * M_PI)) * exp(-0.5 * q2 * q2);
+            }
+        } else {
+            for (int cidx = 0; cidx < term.n_coef; ++cidx) corr = fma(t[term.slot[cidx]], basis[(size_t)cidx * n + bin], corr);
+        }
+        if (mul) total *= (1.0 + corr); else total += corr;
+    }
+    return total;
+}
+
+// combine components, add metals, apply pre-distortion broadband (model.py:119-140,186)
+__device__ inline double assemble_bin(const EngineDev& D, const ItemDev& it, int b, int bin)
+{
+    const double* t = D.theta + (size_t)b * D.n_params;
+    const double bao = t[it.d.bao_amp_slot];
+    const PipeDev& Pp = D.pipes[it.d.pipe_peak];
+    const PipeDev& Ps = D.pipes[it.d.pipe_smooth];
+    double v = bao * D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin] + D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
+    for (int m = 0; m < it.n_metals; ++m) {
+        const MetalDev& md = D.metals[it.metal_begin + m];
+        const double f = D.metal_bias[(size_t)b * D.n_metals_total + it.metal_begin + m];
+        double x;
+        if (md.svec) x = md.svec[bin];
+        else if (md.mat_off >= 0) x = D.xim[md.xim_off + (size_t)b * it.n_model_pad + bin];
+        else { const PipeDev& Pm = D.pipes[md.d.pipeline]; x = D.xi[Pm.xi_off + (size_t)b * Pm.n_pad + bin]; }
+        v = fma(f, x, v);
+    }
+    if (it.add_vec) v = fma(it.add_slot >= 0 ? t[it.add_slot] : it.add_default, it.add_vec[bin], v);
+    if (it.n_bb[VMX_BB_PRE_MUL]) v *= bb_total(D, it, VMX_BB_PRE_MUL, t, bin, it.d.n_model);
+    if (it.n_bb[VMX_BB_PRE_ADD]) v += (1.0 + bao) * bb_total(D, it, VMX_BB_PRE_ADD, t, bin, it.d.n_model);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item)
+{
+    const ItemDev& it = D.items[item];
+    const int b = blockIdx.y;
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= it.d.n_model) return;
+    it.vec[(size_t)b * it.n_model_pad + bin] = assemble_bin(D, it, b, bin);
+}
+
+// post-distortion broadband, model output and masked residual (model.py:147-149; vega_interface.py:310-315)
+__device__ inline void post_bin(const EngineDev& D, const ItemDev& it, int b, int bin, double v)
+{
+    const double* t = D.theta + (size_t)b * D.n_params;
+    if (it.n_bb[VMX_BB_POST_MUL]) v *= bb_total(D, it, VMX_BB_POST_MUL, t, bin, it.d.n_dist);
+    if (it.n_bb[VMX_BB_POST_ADD]) v += (1.0 + t[it.d.bao_amp_slot]) * bb_total(D, it, VMX_BB_POST_ADD, t, bin, it.d.n_dist);
+    D.model[(size_t)b * D.model_size + it.model_off + bin] = v;
+    const int mi = it.inv_mask[bin];
+    if (mi >= 0) {
+        const int mock = D.mock_index[b];
+        const double dat = (mock >= 0 && it.mock_pool) ? it.mock_pool[(size_t)mock * it.n_masked + mi] : it.data[mi];
+        const double diff = dat - v;
+        it.res[(size_t)b * it.n_masked_pad + mi] = diff;
+        if (D.gres) D.gres[(size_t)b * D.g_ld + it.masked_off + mi] = diff;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B, int dist_slabs)
+{
+    const ItemDev& it = D.items[item];
+    const int b = blockIdx.y;
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= it.d.n_dist) return;
+    double v;
+    if (it.dm) {
+        v = 0.0;
+        for (int s = 0; s < dist_slabs; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
+    } else v = it.vec[(size_t)b * it.n_model_pad + bin];
+    post_bin(D, it, b, bin, v);
+}
+
+// ------------------------------------------------------------------------------------------------
 // D^T[n][m] = sum_k A[m][k] * X[n][k]      (A static matrix, X / D one vector per walker)
 //   fp64 MFMA 16x16x4; block tile 64 x 64 x 16, 4 waves each owning a 32 x 32 quadrant.
 //   split-K partial sums go to separate slabs of D
@@ -1061,8 +1162,11 @@ __global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
 //   flight per row and the next row is requested before the current one is reduced.  Partial sums of the four
 //   waves meet in LDS once at the end (fixed order: bitwise reproducible).
 #define GEMV1_MAX_ROWS 24
-template <int CPW>
-__global__ __launch_bounds__(256) void k_gemv1(GemmArgs g)
+//   FUSED (distortion step of a single walker): x is assembled on the fly while it is staged (k_assemble's work, redone
+//   by every block - 10 bins per thread) and each finished row goes straight through k_post's epilogue, which
+//   removes two launches from a ~100 us latency-bound chain.
+template <int CPW, bool FUSED>
+__global__ __launch_bounds__(256) void k_gemv1(GemmArgs g, EngineDev D, int item)
 {
     extern __shared__ double sx[];                 // [K]
     __shared__ double part[GEMV1_MAX_ROWS][4];
@@ -1085,7 +1189,12 @@ __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g)
 #pragma unroll
         for (int c = 0; c < CPW; ++c) cur[c] = __builtin_nontemporal_load((const v2d*)(a + koff[c]));
     }
-    for (int k = tid * 2; k < g.K; k += 512) *(v2d*)&sx[k] = *(const v2d*)(X + k);
+    if constexpr (FUSED) {
+        const ItemDev& it = D.items[item];
+        for (int k = tid; k < g.K; k += 256) sx[k] = k < it.d.n_model ? assemble_bin(D, it, 0, k) : 0.0;
+    } else {
+        for (int k = tid * 2; k < g.K; k += 512) *(v2d*)&sx[k] = *(const v2d*)(X + k);
+    }
     __syncthreads();
     int t = 0;
     for (; row < g.M; row += gridDim.x, ++t) {
@@ -1110,7 +1219,9 @@ __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g)
     __syncthreads();
     if (tid < t) {
         const int r = blockIdx.x + tid * gridDim.x;
-        Dp[r] = (part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]);
+        const double v = (part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]);
+        if constexpr (FUSED) post_bin(D, D.items[item], 0, r, v);
+        else Dp[r] = v;
     }
 }
 
@@ -1236,85 +1347,6 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
     D.xi[P.xi_off + (size_t)b * P.n_pad + bin] = xi;
 }
 
-// ------------------------------------------------------------------------------------------------
-// broadband helpers
-// ------------------------------------------------------------------------------------------------
-__device__ inline double bb_total(const EngineDev& D, const ItemDev& it, int pos, const double* t, int bin, int n)
-{
-    const bool mul = (pos == VMX_BB_PRE_MUL || pos == VMX_BB_POST_MUL);
-    double total = mul ? 1.0 : 0.0;
-    for (int q = 0; q < it.n_bb[pos]; ++q) {
-        const BBTermDev& term = it.bb[pos][q];
-        const double* basis = D.bb_basis + term.basis_off;
-        double corr = 0.0;
-        if (term.func == VMX_BB_SKY) {
-            const double scale = t[term.slot[0]], sigma = t[term.slot[1]];
-            const double rt = basis[bin], w = basis[(size_t)n + bin];
-            if (w != 0.0) {
-                const double q2 = rt / sigma;
-                corr = scale / (sigma * sqrt(2.0 * M_PI)) * exp(-0.5 * q2 * q2);
-            }
-        } else {
-            for (int cidx = 0; cidx < term.n_coef; ++cidx) corr = fma(t[term.slot[cidx]], basis[(size_t)cidx * n + bin], corr);
-        }
-        if (mul) total *= (1.0 + corr); else total += corr;
-    }
-    return total;
-}
-
-// combine components, add metals, apply pre-distortion broadband (model.py:119-140,186)
-__global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item)
-{
-    const ItemDev& it = D.items[item];
-    const int b = blockIdx.y;
-    const int bin = blockIdx.x * 256 + threadIdx.x;
-    if (bin >= it.d.n_model) return;
-    const double* t = D.theta + (size_t)b * D.n_params;
-    const double bao = t[it.d.bao_amp_slot];
-    const PipeDev& Pp = D.pipes[it.d.pipe_peak];
-    const PipeDev& Ps = D.pipes[it.d.pipe_smooth];
-    double v = bao * D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin] + D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
-    for (int m = 0; m < it.n_metals; ++m) {
-        const MetalDev& md = D.metals[it.metal_begin + m];
-        const double f = D.metal_bias[(size_t)b * D.n_metals_total + it.metal_begin + m];
-        double x;
-        if (md.svec) x = md.svec[bin];
-        else if (md.mat_off >= 0) x = D.xim[md.xim_off + (size_t)b * it.n_model_pad + bin];
-        else { const PipeDev& Pm = D.pipes[md.d.pipeline]; x = D.xi[Pm.xi_off + (size_t)b * Pm.n_pad + bin]; }
-        v = fma(f, x, v);
-    }
-    if (it.add_vec) v = fma(it.add_slot >= 0 ? t[it.add_slot] : it.add_default, it.add_vec[bin], v);
-    if (it.n_bb[VMX_BB_PRE_MUL]) v *= bb_total(D, it, VMX_BB_PRE_MUL, t, bin, it.d.n_model);
-    if (it.n_bb[VMX_BB_PRE_ADD]) v += (1.0 + bao) * bb_total(D, it, VMX_BB_PRE_ADD, t, bin, it.d.n_model);
-    it.vec[(size_t)b * it.n_model_pad + bin] = v;
-}
-
-// post-distortion broadband, model output and masked residual (model.py:147-149; vega_interface.py:310-315)
-__global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B, int dist_slabs)
-{
-    const ItemDev& it = D.items[item];
-    const int b = blockIdx.y;
-    const int bin = blockIdx.x * 256 + threadIdx.x;
-    if (bin >= it.d.n_dist) return;
-    const double* t = D.theta + (size_t)b * D.n_params;
-    double v;
-    if (it.dm) {
-        v = 0.0;
-        for (int s = 0; s < dist_slabs; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
-    } else v = it.vec[(size_t)b * it.n_model_pad + bin];
-    if (it.n_bb[VMX_BB_POST_MUL]) v *= bb_total(D, it, VMX_BB_POST_MUL, t, bin, it.d.n_dist);
-    if (it.n_bb[VMX_BB_POST_ADD]) v += (1.0 + t[it.d.bao_amp_slot]) * bb_total(D, it, VMX_BB_POST_ADD, t, bin, it.d.n_dist);
-    D.model[(size_t)b * D.model_size + it.model_off + bin] = v;
-    const int mi = it.inv_mask[bin];
-    if (mi >= 0) {
-        const int mock = D.mock_index[b];
-        const double dat = (mock >= 0 && it.mock_pool) ? it.mock_pool[(size_t)mock * it.n_masked + mi] : it.data[mi];
-        const double diff = dat - v;
-        it.res[(size_t)b * it.n_masked_pad + mi] = diff;
-        if (D.gres) D.gres[(size_t)b * D.g_ld + it.masked_off + mi] = diff;
-    }
-}
-
 // chi2 = sum_items diff^T (C^-1 diff) + priors; sentinel on failure
 __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs)
 {
@@ -1357,5 +1389,6 @@ __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs
         int st = D.status[b];
         if (!(c == c) || c > 1e300 || c < -1e300) { st |= VMX_STATUS_NONFINITE; D.status[b] = st; }
         D.chi2[b] = st ? 1e100 : c;
+        if (D.chi2_host) { D.chi2_host[b] = st ? 1e100 : c; D.status_host[b] = st; }
     }
 }
