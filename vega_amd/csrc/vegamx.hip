@@ -149,6 +149,7 @@ struct vmx_engine {
 
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
     int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
+    bool pk_small_attr = false;      // the single-walker P(k) shape asked for its > 64 KB of LDS
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
     int64_t xi_total = 0, xim_total = 0;
     DevBuf<double> theta, scal, metal_bias, pl, coef, xi, xim, model, chi2;
@@ -1044,7 +1045,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         bool need_mubv = false;
         for (auto& g : e->pk_groups)
             if (e->pipes[g.pipe].d.nl_model == VMX_NL_ARINYO && !(tab_mode && g.xtab >= 0)) need_mubv = true;
-        const size_t shmem = ((need_mubv ? (size_t)e->n_mu : 0) + 2048) * sizeof(double);
+        size_t shmem = ((need_mubv ? (size_t)e->n_mu : 0) + 2048) * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
         if (tab_mode)
             for (auto& g : e->pk_groups)
@@ -1069,7 +1070,16 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
             } while (0)
             if ((int64_t)B * n_groups >= 24) VMX_LAUNCH_PK(64, 4);
             else if ((int64_t)B * n_groups >= 4) VMX_LAUNCH_PK(16, 16);
-            else VMX_LAUNCH_PK(8, 32);
+            else {
+                // + the block's slice of the G table, staged in LDS ([n_mu][8])
+                shmem = ((size_t)e->n_mu + 2048 + (size_t)8 * e->n_mu) * sizeof(double);
+                if (!e->pk_small_attr) {
+                    HIP_OK(hipFuncSetAttribute((const void*)k_pk_multipoles<8, 32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                    HIP_OK(hipFuncSetAttribute((const void*)k_pk_multipoles<8, 32, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                    e->pk_small_attr = true;
+                }
+                VMX_LAUNCH_PK(8, 32);
+            }
 #undef VMX_LAUNCH_PK
         }
     }

@@ -724,6 +724,18 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     }
     T.gk_stride = (size_t)MS * D.nkp;
     T.gk = d.gk_table >= 0 ? D.gk + (size_t)d.gk_table * n_mu * D.nkp + (size_t)ms * D.nkp + ic : nullptr;
+    if constexpr (KT == 8) {
+        // single-walker shape (one wave per SIMD, ~31 mu steps per thread): nothing hides the latency of the table
+        // reads inside the loop, so every thread requests its own entries back to back here and the loop reads LDS
+        if (T.gk != nullptr) {
+            double* s_g = smem + 2048 + D.n_mu + (size_t)ms * KT + kk;      // [n_mu][KT]
+            const double* src = T.gk;
+#pragma unroll 8
+            for (int j = ms; j < n_mu; j += MS) { s_g[(size_t)(j - ms) * KT] = *src; src += T.gk_stride; }
+            T.gk = s_g;
+            T.gk_stride = (size_t)MS * KT;
+        }
+    }
 
     // peak partner: extra factor exp(p0 + p1 mu^2) from the additional Gaussian broadening
     const double dmu = (double)MS * inv_nmu;
