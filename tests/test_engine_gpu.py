@@ -219,3 +219,52 @@ def test_constant_nl_table_mode():
     assert not status[ok].any()
     np.testing.assert_allclose(chi2[ok], tab[ok], rtol=1e-11)
     vega.close()
+
+
+def test_every_batch_size_takes_a_consistent_path():
+    """The product kernels switch with the batch size (single-walker streaming kernel fused with assemble / post,
+    small-batch streaming, MFMA tiles with ragged edges and split-K, per-batch D_NL table from 16 walkers on, zero-copy
+    staging up to 8): chi2 and models of the same walkers must not depend on how they are batched."""
+    from vega_amd import VegaInterface, synthetic
+    from vega_amd.setup import build_problem
+    prob = build_problem('configs/joint/main.ini', search_dirs=[GOLDEN])
+    for item in prob.items.values():
+        item.distortion = synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt)
+        item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt))
+    vega = VegaInterface(None, problem=prob, max_batch=128)
+    eng = vega.engine
+    varied = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO', 'drp_QSO',
+              'bias_hcd', 'beta_hcd', 'L0_hcd', 'bao_amp', 'sigmaNL_par', 'par_sigma_smooth']
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 128, varied=varied, seed=77)
+    ref_chi2, ref_status, ref_model = eng.eval(theta, want_model=True)         # one batch of 128: MFMA + table mode
+    assert not ref_status.any()
+    scale = np.abs(ref_model).max()
+    for size in (1, 2, 3, 5, 8, 9, 15, 16, 17, 33, 100):
+        lo = 0
+        while lo < 128:
+            hi = min(lo + size, 128)
+            chi2, status, model = eng.eval(theta[lo:hi], want_model=True)
+            assert not status.any()
+            np.testing.assert_allclose(chi2, ref_chi2[lo:hi], rtol=1e-10, err_msg=f'batch size {size} at {lo}')
+            assert np.abs(model - ref_model[lo:hi]).max() <= 1e-11 * scale, (size, lo)
+            lo = hi if size > 3 else lo + 41          # the smallest sizes: a few positions are enough
+    vega.close()
+
+
+def test_maximum_batch_with_metals():
+    """BASELINE configs[3] shape at its largest: 4096 walkers of the joint + metals configuration in one call
+    (23 pipelines); spot-checked against the oracle and against small batches."""
+    from oracle import vega_cpu as oc
+    from vega_amd import synthetic
+    vega = _engine('joint_metals', max_batch=4096)
+    eng = vega.engine
+    varied = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'bias_hcd', 'bias_eta_SiII(1190)',
+              'bias_eta_SiII(1193)', 'bias_eta_SiIII(1207)', 'bias_eta_SiII(1260)', 'bias_eta_CIV(eff)']
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 4096, varied=varied, seed=5)
+    chi2, status = vega.chi2_batch(theta, return_status=True)
+    assert not status.any() and np.isfinite(chi2).all()
+    for i in (0, 2047, 4095):
+        assert chi2[i] == pytest.approx(oc.chi2(vega.problem, dict(zip(eng.names, theta[i]))), rel=CHI2_RTOL)
+    small = eng.eval(theta[1000:1008])[0]
+    np.testing.assert_allclose(chi2[1000:1008], small, rtol=1e-10)
+    vega.close()
