@@ -186,6 +186,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--core-only', action='store_true',
                     help='calibration + warm-up + timed steps only (the command the rocprofv3 summaries in profiles/ use)')
+    ap.add_argument('--no-static-metals', action='store_true', help='keep every metal pair on its own pipeline')
     ap.add_argument('--force-dist', action='store_true', help='run the collective path even with one rank')
     args = ap.parse_args()
 
@@ -215,6 +216,8 @@ def main():
     prob = build_problem(args.workload)
     vega = VegaInterface(None, problem=prob, max_batch=B, device=local_rank)
     vega.freeze_metals()            # fast_metals workloads: the first evaluation (fiducial point) fills the metal caches
+    if not args.no_static_metals:
+        vega.freeze_static_metals() # polynomial metal pairs -> their exact static Kaiser basis (no-op without metals)
     eng = vega.engine
     dev = torch.device('cuda', local_rank)
     # the walkers of SURVEY 8d vary biases, betas, alphas, HCD and velocity-dispersion parameters; the Arinyo

@@ -191,6 +191,15 @@ int vmx_item_add_metal(vmx_engine* e, int32_t item, const vmx_metal_desc* desc);
  * added with desc.pipeline = -1 and contributes bias_product * xi[bin] with this static vector (already
  * multiplied by its metal matrix and multiplicity-free: desc.multiplicity still applies). */
 int vmx_item_set_metal_static(vmx_engine* e, int32_t item, int32_t index, const double* xi, int32_t n_model);
+/* Exact static form of a metal pair whose P(k,mu) is the bias-free Kaiser polynomial times static factors only
+ * (power_spectrum.py:198-222 with fast_metals; no HCD / UV / non-linear / smoothing / velocity-dispersion term, fixed
+ * coordinates): xi = Y0 + (beta1 + beta2) Y1 + beta1 beta2 Y2 with three static vectors (after the pair's metal matrix,
+ * redshift evolution and growth).  basis = [3][n_model]; the metal is added with desc.pipeline = -1, its tracers
+ * provide beta1, beta2 and the bias product per walker. */
+int vmx_item_set_metal_basis(vmx_engine* e, int32_t item, int32_t index, const double* basis, int32_t n_model);
+/* Set-up hook used to extract those vectors with the engine itself: while enabled, every tracer of a bias-free
+ * (fast_metals) pipeline takes beta = `beta` instead of its parameters. */
+int vmx_set_metal_beta_override(vmx_engine* e, int32_t enabled, double beta);
 
 /* Additive template of the non-peak component: v += amp * vec[bin] before the pre-distortion broadband
  * (DESI instrumental systematics, model.py:133-135, correlation_func.py:553-595).  amp = theta[slot], or

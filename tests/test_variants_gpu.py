@@ -221,6 +221,69 @@ def test_fast_metals_frozen_caches_match_reference():
             ref = exp[f'walker{i}/model/{name}']
             assert np.abs(models[name][i] - ref).max() <= XI_RTOL * np.abs(ref).max(), (i, name)
     # an unsampled beta that made two pairs share a pipeline may not move afterwards
-    with pytest.raises(ValueError, match='fast_metals'):
+    with pytest.raises(ValueError, match='frozen metal terms'):
         vega.chi2({'beta_SiII(1193)': 0.7})
+    vega.close()
+
+
+@pytest.mark.parametrize('tag', ['joint_metals', 'auto_metals'])
+def test_static_metal_basis_is_exact(tag):
+    """freeze_static_metals(): polynomial metal pairs become xi = Y0 + (b1 + b2) Y1 + b1 b2 Y2 with static vectors
+    (metal matrix included).  Same chi2 / models as the per-walker pipelines and as the oracle, for walkers that
+    move every sampled-type parameter including the metal biases and betas."""
+    from scipy import sparse
+    from oracle import vega_cpu as oc
+    from vega_amd import VegaInterface, synthetic
+    prob = _fresh(tag)
+    rng = np.random.default_rng(3)
+    for item in prob.items.values():          # dense-ish metal matrices: the static form must carry them
+        for pair in item.metals[::3]:
+            n_out, n_in = item.model_grid.size, pair.pipeline.r.size
+            dense = np.eye(n_out, n_in) * 0.9
+            dense[rng.integers(0, n_out, 3000), rng.integers(0, n_in, 3000)] += 0.03 * rng.standard_normal(3000)
+            pair.matrix = sparse.csr_array(dense)
+    vega = VegaInterface(None, problem=prob, max_batch=8)
+    eng = vega.engine
+    n_before = len(eng.pipe_index)
+    varied = [n for n in eng.names if n.startswith(('bias_eta_', 'beta_')) or n in ('ap', 'at', 'bao_amp', 'bias_hcd')]
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 6, varied=varied, seed=8)
+    before_chi2, _, before_model = eng.eval(theta, want_model=True)
+    vega.freeze_static_metals()
+    eng = vega.engine
+    n_metal_pipes = sum(1 for item in prob.items.values() for _ in item.metals)
+    assert len(eng.pipe_index) < n_before and len(eng.pipe_index) >= n_before - n_metal_pipes
+    chi2, status, model = eng.eval(theta, want_model=True)
+    assert not status.any()
+    np.testing.assert_allclose(chi2, before_chi2, rtol=1e-9)
+    assert np.abs(model - before_model).max() <= 1e-11 * np.abs(before_model).max()
+    for i in (0, 5):
+        pars = dict(zip(eng.names, theta[i]))
+        assert chi2[i] == pytest.approx(oc.chi2(prob, pars), rel=CHI2_RTOL)
+        ref = oc.compute_model(prob, pars)
+        for name, sl in eng.model_slices.items():
+            assert np.abs(model[i, sl] - ref[name]).max() <= XI_RTOL * np.abs(ref[name]).max()
+    with pytest.raises(ValueError, match='frozen metal terms'):
+        vega.chi2({'alpha_SiII(1190)': 1.3})
+    vega.close()
+
+
+def test_static_metal_basis_after_fast_metals():
+    """fast_metals + freeze_static_metals(): the merged main x metal pairs (leader and the pairs reading its pipeline)
+    also become static Kaiser bases; results equal those of the frozen-cache engine before the step."""
+    from vega_amd import VegaInterface, synthetic
+    from conftest import load_problem
+    vega = VegaInterface(None, problem=load_problem('joint_metals_fast'), max_batch=8)
+    vega.freeze_metals()
+    eng = vega.engine
+    assert len(eng.pipe_index) == 6
+    varied = [n for n in eng.names if n.startswith('bias_eta_') or n in ('beta_LYA', 'beta_QSO', 'ap', 'at', 'bao_amp')]
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 6, varied=varied, seed=12)
+    before_chi2, _, before_model = eng.eval(theta, want_model=True)
+    vega.freeze_static_metals()
+    eng = vega.engine
+    assert len(eng.pipe_index) == 5          # 4 core + QSO x metal (Lorentzian velocity dispersion: not polynomial)
+    chi2, status, model = eng.eval(theta, want_model=True)
+    assert not status.any()
+    np.testing.assert_allclose(chi2, before_chi2, rtol=1e-9)
+    assert np.abs(model - before_model).max() <= 1e-11 * np.abs(before_model).max()
     vega.close()

@@ -80,7 +80,7 @@ static int upload_padded(DevBuf<double>& buf, const double* host, int rows, int 
 
 struct MetalHost {
     MetalDev dev{};
-    DevBuf<double> mat, svec;
+    DevBuf<double> mat, svec, basis;
     int rows = 0, cols = 0;
 };
 
@@ -571,6 +571,7 @@ int vmx_item_add_metal(vmx_engine* e, int32_t item, const vmx_metal_desc* desc)
     m->dev.d = *desc;
     m->dev.mat_off = -1;
     m->dev.svec = nullptr;
+    m->dev.basis = nullptr;
     it->metals.push_back(m);
     e->metals.push_back(m);
     it->dev.n_metals = (int)it->metals.size();
@@ -589,6 +590,34 @@ int vmx_item_set_metal_static(vmx_engine* e, int32_t item, int32_t index, const 
     HIP_OK(hipSetDevice(e->device));
     if (m->svec.upload(xi, (size_t)n_model)) return -2;
     m->dev.svec = m->svec.p;
+    return 0;
+}
+
+int vmx_item_set_metal_basis(vmx_engine* e, int32_t item, int32_t index, const double* basis, int32_t n_model)
+{
+    REQUIRE(e && !e->finalized && basis, "vmx_item_set_metal_basis");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(index >= 0 && index < (int)it->metals.size(), "metal index");
+    REQUIRE(n_model == it->dev.d.n_model, "metal basis size");
+    MetalHost* m = it->metals[index];
+    REQUIRE(m->dev.d.pipeline == -1, "a static basis replaces the pipeline: add the metal with pipeline = -1");
+    HIP_OK(hipSetDevice(e->device));
+    if (upload_padded(m->basis, basis, 3, n_model, vmx_pad(n_model))) return -2;
+    m->dev.basis = m->basis.p;
+    return 0;
+}
+
+int vmx_set_metal_beta_override(vmx_engine* e, int32_t enabled, double beta)
+{
+    REQUIRE(e && e->finalized, "vmx_set_metal_beta_override");
+    e->dev.beta_override_on = enabled ? 1 : 0;
+    e->dev.beta_override = beta;
+    // captured graphs hold the previous value: drop them
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
+    e->graphs.clear();
     return 0;
 }
 
@@ -916,7 +945,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     std::vector<MetalDev> metals;
     for (auto* it : e->items)
         for (auto* m : it->metals) {
-            REQUIRE(m->dev.d.pipeline >= 0 || m->dev.svec, "metal without pipeline and without static correlation");
+            REQUIRE(m->dev.d.pipeline >= 0 || m->dev.svec || m->dev.basis, "metal without pipeline and without static correlation");
             if (m->dev.mat_off >= 0) { m->dev.xim_off = xim_off; xim_off += (int64_t)Bm * it->dev.n_model_pad; }
             metals.push_back(m->dev);
         }
@@ -964,7 +993,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     // workspace (pad regions are zeroed once here and never written afterwards)
     const size_t ncols = (size_t)Bm * n_pipe;
     if (e->theta.alloc((size_t)Bm * n_params) || e->scal.alloc(ncols * VMX_NS) ||
-        e->metal_bias.alloc((size_t)Bm * (e->metals.size() + 1)) ||
+        e->metal_bias.alloc((size_t)Bm * 3 * (e->metals.size() + 1)) ||
         e->pl.alloc((size_t)VMX_MAX_ELL * ncols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * ncols * e->ncp) ||
         e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
         e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(1)) return -2;

@@ -60,6 +60,7 @@ struct MetalDev {
     int32_t mat_ld;
     int64_t xim_off;      // offset into the metal-product buffer (per-walker stride n_model_pad)
     const double* svec;   // static correlation [n_model] (fast_metals: frozen metal x metal term) instead of a pipeline
+    const double* basis;  // static Kaiser basis [3][n_model]: xi = Y0 + (beta1 + beta2) Y1 + beta1 beta2 Y2
 };
 
 struct ItemDev {
@@ -128,7 +129,8 @@ struct EngineDev {
     // leaves a device copy in `theta_copy` (= theta) for the later kernels; k_chi2 stores its results to host too
     const double* theta_host; double* theta_copy; double* chi2_host; int32_t* status_host;
     double* scal;               // [B][n_pipe][VMX_NS]
-    double* metal_bias;         // [B][n_metals_total]
+    double* metal_bias;         // [B][3][n_metals_total]: bias product x multiplicity, beta1 + beta2, beta1 * beta2
+    double beta_override; int32_t beta_override_on;      // set-up hook: betas of the bias-free metal pipelines
     double* pl;                 // [n_ell][B*n_pipe][nkp]
     double* coef;               // [n_ell][B*n_pipe][ncp]
     double* xi;                 // per pipeline [B][n]
@@ -190,6 +192,7 @@ __global__ void k_prologue(EngineDev D, int B)
         if (d.same_tracer) { b2 = b1; be2 = be1; }
         else tracer_bias_beta(t, d.tracer[1], gr, b2, be2);
 
+        if (d.fast_metals && D.beta_override_on) { be1 = D.beta_override; be2 = D.beta_override; }
         const bool eff1 = d.tracer[0].is_lya && (d.uvb || d.heii || d.hcd_model != VMX_HCD_NONE);
         const bool eff2 = d.tracer[1].is_lya && (d.uvb || d.heii || d.hcd_model != VMX_HCD_NONE);
         if (d.fast_metals && !eff1) { s[S_BIAS1] = 1.0; s[S_BB1] = be1; }
@@ -256,18 +259,19 @@ __global__ void k_prologue(EngineDev D, int B)
         return;
     }
 
-    // metal bias products (reference metals.py:295-313, :331-332)
+    // metal bias products (reference metals.py:295-313, :331-332) and the Kaiser coefficients of the static-basis metals
     for (int m = 0; m < D.n_metals_total; ++m) {
         const vmx_metal_desc& d = D.metals[m].d;
         double f = d.multiplicity;
-        if (d.apply_bias) {
-            const double gr = th(t, d.growth_rate_slot, d.growth_rate_default);
-            double b1, be1, b2, be2;
-            tracer_bias_beta(t, d.tracer[0], gr, b1, be1);
-            if (d.same_tracer) { b2 = b1; } else tracer_bias_beta(t, d.tracer[1], gr, b2, be2);
-            f *= b1 * b2 * th(t, d.extra_bias_slot, 1.0);
-        }
-        D.metal_bias[(size_t)b * D.n_metals_total + m] = f;
+        const double gr = th(t, d.growth_rate_slot, d.growth_rate_default);
+        double b1, be1, b2, be2;
+        tracer_bias_beta(t, d.tracer[0], gr, b1, be1);
+        if (d.same_tracer) { b2 = b1; be2 = be1; } else tracer_bias_beta(t, d.tracer[1], gr, b2, be2);
+        if (d.apply_bias) f *= b1 * b2 * th(t, d.extra_bias_slot, 1.0);
+        double* mb = D.metal_bias + (size_t)b * 3 * D.n_metals_total;
+        mb[m] = f;
+        mb[D.n_metals_total + m] = be1 + be2;
+        mb[2 * D.n_metals_total + m] = be1 * be2;
     }
     int st = 0;
     for (int q = 0; q < D.n_const_slots; ++q)
@@ -932,9 +936,13 @@ __device__ inline double assemble_bin(const EngineDev& D, const ItemDev& it, int
     double v = bao * D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin] + D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
     for (int m = 0; m < it.n_metals; ++m) {
         const MetalDev& md = D.metals[it.metal_begin + m];
-        const double f = D.metal_bias[(size_t)b * D.n_metals_total + it.metal_begin + m];
+        const double* mb = D.metal_bias + (size_t)b * 3 * D.n_metals_total + it.metal_begin + m;
+        const double f = mb[0];
         double x;
-        if (md.svec) x = md.svec[bin];
+        if (md.basis) {
+            const double* y = md.basis + bin;
+            x = fma(mb[2 * D.n_metals_total], y[2 * (size_t)it.n_model_pad], fma(mb[D.n_metals_total], y[it.n_model_pad], y[0]));
+        } else if (md.svec) x = md.svec[bin];
         else if (md.mat_off >= 0) x = D.xim[md.xim_off + (size_t)b * it.n_model_pad + bin];
         else { const PipeDev& Pm = D.pipes[md.d.pipeline]; x = D.xi[Pm.xi_off + (size_t)b * Pm.n_pad + bin]; }
         v = fma(f, x, v);

@@ -138,6 +138,8 @@ def load_library():
     lib.vmx_matvec_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_void_p]
     lib.vmx_item_set_metal_static.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
+    lib.vmx_item_set_metal_basis.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
+    lib.vmx_set_metal_beta_override.argtypes = [C.c_void_p, C.c_int32, C.c_double]
     lib.vmx_matmul_host.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_int32, dptr, C.c_int32, dptr]
     lib.vmx_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_profiling_mask.argtypes = [C.c_void_p, C.c_uint32]
@@ -154,7 +156,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table',
     'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
-    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
+    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
@@ -391,7 +393,7 @@ class Engine:
         self.lib = load_library()
         self.prob = problem
         # fast_metals (see fast_metal_plan): per item, per metal pair ('pipeline', None) | ('share', leader index)
-        # | ('static', xi vector)
+        # | ('static', xi vector) | ('basis', [3, n_model] Kaiser basis)
         self.metal_plan = metal_plan or {}
         self.metal_source = {}          # (item name, pair index) -> (global metal index, pipeline id, has matrix)
         self.low = Lowering(problem, extra_names)
@@ -560,6 +562,10 @@ class Engine:
                     if kind == 'static':
                         vec = _f64(arg)
                         self._check(lib.vmx_item_set_metal_static(self._h, iid, mi, _dp(vec), vec.size))
+                    elif kind == 'basis':
+                        basis = _f64(arg)
+                        assert basis.shape == (3, item.model_grid.size)
+                        self._check(lib.vmx_item_set_metal_basis(self._h, iid, mi, _dp(basis), basis.shape[1]))
                     elif pair.matrix is not None:
                         dense = _f64(pair.matrix.toarray() if hasattr(pair.matrix, 'toarray') else pair.matrix)
                         self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_METAL, mi, dense.shape[0],
@@ -705,6 +711,10 @@ class Engine:
         if has_matrix:
             return self.debug_read(3, g, cap)[:n].copy()
         return self.debug_read(1, pid, cap)[:n].copy()
+
+    def set_metal_beta_override(self, beta=None):
+        """Set-up hook: every tracer of a bias-free metal pipeline takes ``beta`` (None: back to the parameters)."""
+        self._check(self.lib.vmx_set_metal_beta_override(self._h, int(beta is not None), 0.0 if beta is None else float(beta)))
 
     def matvec_device(self, d_A, rows, cols_padded, d_x, B, d_y):
         self._check(self.lib.vmx_matvec_device(self._h, d_A, rows, cols_padded, d_x, B, d_y))

@@ -94,6 +94,30 @@ class VegaInterface:
         self._metals_frozen = True
         self._mc_active = False
 
+    def freeze_static_metals(self, params=None):
+        """Opt-in set-up step for samplers and minimisers: metal pairs whose P(k,mu) is the bias-free Kaiser
+        polynomial times static factors (no HCD / UV / non-linear / smoothing / velocity-dispersion term, unscaled
+        coordinates, unsampled redshift-evolution exponents) are replaced by their exact static form
+        xi = Y0 + (beta1 + beta2) Y1 + beta1 beta2 Y2 (metals_plan.static_basis_plan) - no P(k,mu), FFTLog, bin
+        evaluation or metal-matrix product per walker for them any more.  Results are unchanged to rounding as
+        long as the pinned parameters (the pairs' `alpha_<tracer>`) keep the values they have in ``params``
+        (default: the configured ones); evaluations that move them raise.  The engine object is replaced."""
+        theta = np.asarray(params, dtype=np.float64) if isinstance(params, np.ndarray) else self._theta(params)
+        self.freeze_metals(theta)
+        old = self.engine
+        plan, pinned = metals_plan.static_basis_plan(self.problem, old, theta, base_plan=old.metal_plan)
+        if not pinned and plan == old.metal_plan:
+            return
+        old.close()
+        self.engine = Engine(self.problem, metal_plan=plan, **self._engine_args)
+        assert self.engine.names == self.param_names
+        merged = dict(zip(self._pinned_names, self._pinned_values))
+        merged.update(pinned)
+        self._pinned_names = list(merged)
+        self._pinned_slots = np.array([self.engine.low.slot[n] for n in merged], dtype=np.int64)
+        self._pinned_values = np.array(list(merged.values()), dtype=np.float64)
+        self._mc_active = False
+
     def _check_pinned(self, theta):
         """Main x metal pairs that shared the reference's per-call cache at the first evaluation share a pipeline
         here; that stays equivalent only while the unsampled parameters behind their equal betas keep their
@@ -101,8 +125,8 @@ class VegaInterface:
         if self._pinned_slots.size and not np.array_equal(
                 np.broadcast_to(self._pinned_values, (theta.shape[0], self._pinned_values.size)),
                 theta[:, self._pinned_slots]):
-            raise ValueError('fast_metals: ' + ', '.join(self._pinned_names) + ' must keep the values of the first '
-                             'evaluation (or be listed in [sample]): main x metal pairs with equal betas were merged')
+            raise ValueError('frozen metal terms: ' + ', '.join(self._pinned_names) + ' must keep the values they had '
+                             'when the terms were frozen (or be listed in [sample] beforehand)')
 
     def _sync_monte_carlo(self):
         """chi2 reads the current mock and the scaled inverse covariance in Monte-Carlo mode

@@ -12,6 +12,8 @@ With `fast_metals = True` the reference
 The plan is made once, with the parameters of the first evaluation, exactly when the reference fills its caches.
 """
 
+import numpy as np
+
 DEFAULT_GROWTH_RATE = 0.970386      # reference vega/utils.py:60
 
 
@@ -81,4 +83,78 @@ def fast_metal_plan(problem, params, metal_xi):
                 leaders[key] = (mi, sources)
             entries.append(('pipeline', None))
         plan[name] = entries
+    return plan, pinned
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# exact static form of polynomial metal pairs
+# ----------------------------------------------------------------------------------------------------------------
+def _basis_eligible(problem, item, pair, sampled):
+    """A pair can be written xi = Y0 + (beta1 + beta2) Y1 + beta1 beta2 Y2 with static Y when its P(k,mu) is the
+    bias-free Kaiser polynomial (reference power_spectrum.py:198-222) times static factors only and nothing else
+    that is sampled enters its correlation function.  Returns the names of the unsampled parameters the Y depend on
+    (to be pinned), or None."""
+    if not item.metal_opts['fast_metal_bias']:
+        return None
+    pk, xi = pair.pipeline.pk, pair.pipeline.xi
+    if pk.hcd_model is not None or pk.uvb or pk.heii or pk.small_scale_nl is not None:
+        return None
+    if pk.fullshape_smoothing is not None or pk.velocity_dispersion is not None or not pk.use_gk:
+        return None
+    if getattr(xi, 'radiation', False) or getattr(xi, 'relativistic', False) or getattr(xi, 'asymmetry', False):
+        return None
+    if getattr(xi, 'uv_shotnoise', False) or getattr(problem.scale, 'metal_scaling', False):
+        return None
+    pinned = set()
+    for tr in (pair.pipeline.tracer1, pair.pipeline.tracer2):
+        if xi.evol_model.get(tr.name, 'standard') != 'standard':
+            return None
+        pinned.add('alpha_' + tr.name)
+    if pinned & sampled:
+        return None
+    return pinned
+
+
+def static_basis_plan(problem, engine, theta, base_plan=None):
+    """({item name: plan entries}, pinned) in which every eligible metal pair that still owns a pipeline in
+    ``base_plan`` (default: every pair) becomes ('basis', [Y0, Y1, Y2]).  The vectors are extracted with ``engine``
+    (built with ``base_plan``) - three evaluations of ``theta`` with all bias-free metal betas forced to 0, +1, -1:
+        xi(beta) = Y0 + 2 beta Y1 + beta^2 Y2   =>   Y0 = xi(0), Y1 = (xi(1) - xi(-1)) / 4, Y2 = (xi(1) + xi(-1)) / 2 - xi(0)
+    - so they carry the pair's metal matrix, redshift evolution and growth factors exactly as the chain applies them.
+    ``pinned`` {name: value}: the unsampled parameters the vectors depend on."""
+    sampled = set(problem.sample_params.get('limits', {})) if problem.sample_params else set()
+    theta = np.asarray(theta, dtype=np.float64)
+    params = dict(zip(engine.names, theta))
+    plan = {name: list(entries) for name, entries in (base_plan or {}).items()}
+    targets = []
+    for name, item in problem.items.items():
+        if not item.metals or item.metal_opts['single_metal_beta']:
+            continue        # the substitution order of metals.py:289-293 is kept by the pipelines
+        entries = plan.setdefault(name, [('pipeline', None)] * len(item.metals))
+        for mi, pair in enumerate(item.metals):
+            kind, arg = entries[mi]
+            if kind not in ('pipeline', 'share'):
+                continue
+            # a pair that reads another pair's pipeline (fast_metals sharing) has that pair's P(k,mu) and tracers
+            source = item.metals[arg] if kind == 'share' else pair
+            need = _basis_eligible(problem, item, source, sampled)
+            if need is not None:
+                targets.append((name, mi, need))
+    if not targets:
+        return plan, {}
+    xi = {}
+    try:
+        for beta in (0.0, 1.0, -1.0):
+            engine.set_metal_beta_override(beta)
+            engine.eval(theta[None, :])
+            for name, mi, _ in targets:
+                xi[(name, mi, beta)] = engine.metal_xi(name, mi)
+    finally:
+        engine.set_metal_beta_override(None)
+    pinned = {}
+    for name, mi, need in targets:
+        y0, up, down = xi[(name, mi, 0.0)], xi[(name, mi, 1.0)], xi[(name, mi, -1.0)]
+        plan[name][mi] = ('basis', np.stack([y0, (up - down) / 4.0, (up + down) / 2.0 - y0]))
+        for src in need:
+            pinned[src] = params[src]
     return plan, pinned
