@@ -167,6 +167,10 @@ int vmx_set_fvoigt_table(vmx_engine* e, const double* x, const double* f, int32_
 /* G(k) binning table for one (bin_size_rp, bin_size_rt) pair (power_spectrum.py:481-502).
  * Returns the table id (>= 0). */
 int vmx_add_gk_table(vmx_engine* e, double bin_size_rp, double bin_size_rt);
+/* The same with the mock-binning factor of power_spectrum.py:143-160 folded in: G(bin sizes) * G(mock sizes);
+ * a size of 0 leaves its sinc out (`mock-los-smoothing = only-los` -> mock_size_rt = 0). */
+int vmx_add_gk_table_mock(vmx_engine* e, double bin_size_rp, double bin_size_rt, double mock_size_rp,
+                      double mock_size_rt);
 
 /* Returns the pipeline id (>= 0).  r, mu, z, rel_z_evol, xi_growth: [n] (correlation_func.py:46-80,252). */
 int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const double* r,

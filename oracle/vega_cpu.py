@@ -250,6 +250,23 @@ def power_spectrum(pipe, grid, pk_lin, pk_fid, params, fast_metals=False):
             pk = pk * _mcdonald(grid)
     if opts.use_gk:
         pk = pk * _gk(opts, grid, pipe.dataset, params)
+    if opts.mock_bin_size is not None:
+        # reference power_spectrum.py:143-160
+        par = per = opts.mock_bin_size
+        if opts.mock_los_smoothing == 'growth':
+            par = par * (1 + params['growth_rate'])
+        elif opts.mock_los_smoothing == 'amplitude':
+            par = par * (1 + params['los_smooth_amp'])
+        elif opts.mock_los_smoothing == 'only-los':
+            per = 0
+        elif opts.mock_los_smoothing is not None:
+            raise ValueError(f'Unknown mock LOS smoothing option {opts.mock_los_smoothing}.')
+        gm = 1.
+        if par != 0:
+            gm = gm * sinc(grid.k_par * par / 2)
+        if per != 0:
+            gm = gm * sinc(grid.k_trans * per / 2)
+        pk = pk * gm
     if params['peak']:
         pk = pk * _peak_nl(grid, params)
     if opts.fullshape_smoothing is not None and not skip_nl:

@@ -140,6 +140,13 @@ def derive_configs():
     text = re.sub(r'\[metals\][^\[]*', '', (cfg_out / 'full4' / 'lyalya_lyalya.ini').read_text())
     (d / 'lyalya_lyalya.ini').write_text(text.replace('[model]', '[model]\nUVB-shotnoise = True\n'
                                                       'desi-instrumental-systematics = True'))
+    # auto-correlation with the mock-binning factor (power_spectrum.py:143-160), line-of-sight size scaled by the growth rate
+    d = cfg_out / 'auto_mockbin'
+    d.mkdir(exist_ok=True)
+    (d / 'main.ini').write_text(re.sub(r'ini files = .*', 'ini files = configs/auto_mockbin/lyalya_lyalya.ini', main))
+    text = re.sub(r'\[metals\][^\[]*', '', (cfg_out / 'full4' / 'lyalya_lyalya.ini').read_text())
+    (d / 'lyalya_lyalya.ini').write_text(text.replace('[model]', '[model]\nmock-bin-size = 2.0\n'
+                                                      'mock-los-smoothing = growth'))
     # joint + metals with the reference's `fast_metals` switch (metal x metal xi frozen at the first evaluation)
     d = cfg_out / 'joint_metals_fast'
     d.mkdir(exist_ok=True)
@@ -375,6 +382,29 @@ def dump_extras(VegaInterface):
         print('extras: chi2', out['fid/chi2'], out['walker0/chi2'])
 
 
+def dump_mockbin(VegaInterface):
+    """`mock-bin-size` with `mock-los-smoothing = growth` (reference power_spectrum.py:143-160): fiducial point and
+    one walker."""
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_lyalya'], False)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(item.read_text().replace('[model]', '[model]\nmock-bin-size = 2.0\n'
+                                                 'mock-los-smoothing = growth'))
+        vega = VegaInterface(main)
+        out = {'fid/chi2': vega.chi2(), 'fid/model': vega.compute_model(run_init=False)['lyalya_lyalya']}
+        names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 6)
+        walkers[0]['growth_rate'] = vega.params['growth_rate']      # template growth rate: not a free parameter
+        _reset_caches(vega)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[walkers[0][n] for n in names]])
+        out['walker0/chi2'] = vega.chi2(walkers[0])
+        _reset_caches(vega)
+        out['walker0/model'] = vega.compute_model(walkers[0], run_init=False)['lyalya_lyalya']
+        np.savez_compressed(HERE / 'expected_mockbin.npz', **out)
+        print('mockbin: chi2', out['fid/chi2'], out['walker0/chi2'])
+
+
 def dump_fast_metals(VegaInterface):
     """`fast_metals = True` (reference metals.py:53,144-169,280-282): metal x metal correlations are computed at
     the FIRST evaluation and reused for ever after.  Sequence dumped: chi2 at the fiducial point (fills the cache),
@@ -420,12 +450,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -440,3 +470,5 @@ if __name__ == '__main__':
         dump_extras(VI)
     if 'fast_metals' in what:
         dump_fast_metals(VI)
+    if 'mockbin' in what:
+        dump_mockbin(VI)

@@ -263,3 +263,14 @@ def test_fast_metals_caches_match_reference():
     oc.chi2(prob, first)
     assert oc.chi2(prob) != pytest.approx(float(exp['fid/chi2']), rel=1e-9)
     oc.reset_metal_cache(prob)
+
+
+def test_mock_binning_matches_reference():
+    """`mock-bin-size` + `mock-los-smoothing = growth` (reference power_spectrum.py:143-160)."""
+    prob = load_problem('auto_mockbin')
+    exp = np.load(GOLDEN / 'expected_mockbin.npz')
+    assert oc.chi2(prob) == pytest.approx(float(exp['fid/chi2']), rel=1e-13)
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-13)
+    model = oc.compute_model(prob, pars)['lyalya_lyalya']
+    assert np.abs(model - exp['walker0/model']).max() <= 1e-13 * np.abs(model).max()

@@ -287,3 +287,26 @@ def test_static_metal_basis_after_fast_metals():
     np.testing.assert_allclose(chi2, before_chi2, rtol=1e-9)
     assert np.abs(model - before_model).max() <= 1e-11 * np.abs(before_model).max()
     vega.close()
+
+
+def test_mock_binning():
+    """`mock-bin-size` (reference power_spectrum.py:143-160) folded into the static G table: against the reference's
+    own output, and the other line-of-sight options against the oracle."""
+    from vega_amd import VegaInterface
+    prob = _fresh('auto_mockbin')
+    exp = np.load(GOLDEN / 'expected_mockbin.npz')
+    vega = VegaInterface(None, problem=prob, max_batch=2)
+    assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert vega.chi2(pars) == pytest.approx(float(exp['walker0/chi2']), rel=CHI2_RTOL)
+    got = vega.compute_model(pars)['lyalya_lyalya']
+    assert np.abs(got - exp['walker0/model']).max() <= XI_RTOL * np.abs(exp['walker0/model']).max()
+    vega.close()
+    for los in (None, 'only-los'):
+        prob = _fresh('auto_mockbin')
+        prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = los
+        _check(prob, n_walkers=1)
+    prob = _fresh('auto_mockbin')
+    prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = 'amplitude'
+    with pytest.raises(NotImplementedError):
+        VegaInterface(None, problem=prob, max_batch=1)

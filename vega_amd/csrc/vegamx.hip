@@ -113,7 +113,8 @@ struct vmx_engine {
     int n_xtab = 0;
     bool const_hint = false;
     int fv_n = 0;
-    std::vector<std::pair<double, double>> gk_tables;
+    struct GkSpec { double rp, rt, mock_rp, mock_rt; };   // G(rp, rt) * G(mock_rp, mock_rt); a zero size = factor 1
+    std::vector<GkSpec> gk_tables;
     std::vector<double> h_k, h_mu;
 
     int n_coef = 0, ncp = 0, n_knots = 0;
@@ -464,13 +465,20 @@ int vmx_set_fvoigt_table(vmx_engine* e, const double* x, const double* f, int32_
     return 0;
 }
 
-int vmx_add_gk_table(vmx_engine* e, double bin_size_rp, double bin_size_rt)
+int vmx_add_gk_table_mock(vmx_engine* e, double bin_size_rp, double bin_size_rt, double mock_size_rp, double mock_size_rt)
 {
     if (!e || e->finalized || e->nk == 0) return fail(-1, "invalid argument: set the template first");
-    for (size_t i = 0; i < e->gk_tables.size(); ++i)
-        if (e->gk_tables[i].first == bin_size_rp && e->gk_tables[i].second == bin_size_rt) return (int)i;
-    e->gk_tables.push_back({bin_size_rp, bin_size_rt});
+    for (size_t i = 0; i < e->gk_tables.size(); ++i) {
+        const auto& g = e->gk_tables[i];
+        if (g.rp == bin_size_rp && g.rt == bin_size_rt && g.mock_rp == mock_size_rp && g.mock_rt == mock_size_rt) return (int)i;
+    }
+    e->gk_tables.push_back({bin_size_rp, bin_size_rt, mock_size_rp, mock_size_rt});
     return (int)e->gk_tables.size() - 1;
+}
+
+int vmx_add_gk_table(vmx_engine* e, double bin_size_rp, double bin_size_rt)
+{
+    return vmx_add_gk_table_mock(e, bin_size_rp, bin_size_rt, 0.0, 0.0);
 }
 
 int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const double* r, const double* mu,
@@ -856,7 +864,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         for (size_t t = 0; t < e->gk_tables.size(); ++t) {
             dim3 grid((e->nkp + 255) / 256, e->n_mu), block(256);
             hipLaunchKernelGGL(k_gk_table, grid, block, 0, e->stream, e->gk.p + t * gk_stride, e->k.p, e->mu.p,
-                               e->nk, e->nkp, e->n_mu, e->gk_tables[t].first, e->gk_tables[t].second);
+                               e->nk, e->nkp, e->n_mu, e->gk_tables[t].rp, e->gk_tables[t].rt, e->gk_tables[t].mock_rp, e->gk_tables[t].mock_rt);
         }
         HIP_OK(hipGetLastError());
     }

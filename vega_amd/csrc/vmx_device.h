@@ -284,7 +284,7 @@ __global__ void k_prologue(EngineDev D, int B)
 // static G(k, mu) table
 // ------------------------------------------------------------------------------------------------
 __global__ void k_gk_table(double* out, const double* k, const double* mu, int nk, int nkp, int n_mu,
-                           double bs_rp, double bs_rt)
+                           double bs_rp, double bs_rt, double mock_rp, double mock_rt)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
@@ -297,6 +297,11 @@ __global__ void k_gk_table(double* out, const double* k, const double* mu, int n
         g = 1.0;
         if (bs_rp != 0.0) { const double x = kpar * bs_rp / 2.0; g = g * (sin(x) / x); }
         if (bs_rt != 0.0) { const double x = ktr * bs_rt / 2.0; g = g * (sin(x) / x); }
+        // mock binning: a second factor of the same form (power_spectrum.py:143-160)
+        double gm = 1.0;
+        if (mock_rp != 0.0) { const double x = kpar * mock_rp / 2.0; gm = gm * (sin(x) / x); }
+        if (mock_rt != 0.0) { const double x = ktr * mock_rt / 2.0; gm = gm * (sin(x) / x); }
+        g *= gm;
     }
     out[(size_t)j * nkp + i] = g;
 }

@@ -107,6 +107,7 @@ def load_library():
     lib.vmx_set_template.argtypes = [C.c_void_p, C.c_int32, dptr, dptr, dptr, dptr, dptr, C.c_int32]
     lib.vmx_set_fftlog.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_double, C.c_double, C.c_int32]
     lib.vmx_add_gk_table.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.vmx_add_gk_table_mock.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
     lib.vmx_set_spline_extrapolation.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_fvoigt_table.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_add_pipeline.argtypes = [C.c_void_p, C.POINTER(PipeDesc), C.c_int32, dptr, dptr, dptr, dptr, dptr]
@@ -154,7 +155,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table',
+    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
     'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
@@ -321,11 +322,26 @@ class Lowering:
         d.nl_model = NL[nl]
 
         d.gk_table = -1
+        bs_rp = bs_rt = mock_rp = mock_rt = 0.0
         if pk.use_gk:
             # frozen at the parameters of the first call (reference power_spectrum.py:139-141, :494-495)
             bs_rp = params.get(f'par binsize {pipe.dataset}', pk.bin_size_rp)
             bs_rt = params.get(f'per binsize {pipe.dataset}', pk.bin_size_rt)
-            d.gk_table = engine._gk_table(float(bs_rp), float(bs_rt))
+        if pk.mock_bin_size is not None:
+            # a second binning factor (reference power_spectrum.py:143-160); static unless it follows a parameter
+            mock_rp = mock_rt = pk.mock_bin_size
+            if pk.mock_los_smoothing == 'growth':
+                sampled = set((self.prob.sample_params or {}).get('limits', {}))
+                if 'growth_rate' in sampled:
+                    raise NotImplementedError('mock-los-smoothing = growth with a sampled growth_rate is not accelerated')
+                mock_rp *= 1 + params['growth_rate']
+            elif pk.mock_los_smoothing == 'amplitude':
+                raise NotImplementedError('mock-los-smoothing = amplitude (a parameter-dependent binning kernel) is '
+                                          'not accelerated')
+            elif pk.mock_los_smoothing == 'only-los':
+                mock_rt = 0.0
+        if pk.use_gk or pk.mock_bin_size is not None:
+            d.gk_table = engine._gk_table(float(bs_rp), float(bs_rt), float(mock_rp), float(mock_rt))
 
         d.peak_nl = int(is_peak)
         d.sigma_nl_par_slot, d.sigma_nl_per_slot = self.s('sigmaNL_par'), self.s('sigmaNL_per')
@@ -415,10 +431,10 @@ class Engine:
             raise EngineError(self.lib.vmx_last_error().decode())
         return rc
 
-    def _gk_table(self, bs_rp, bs_rt):
-        key = (bs_rp, bs_rt)
+    def _gk_table(self, bs_rp, bs_rt, mock_rp=0.0, mock_rt=0.0):
+        key = (bs_rp, bs_rt, mock_rp, mock_rt)
         if key not in self._gk:
-            self._gk[key] = self._check(self.lib.vmx_add_gk_table(self._h, bs_rp, bs_rt))
+            self._gk[key] = self._check(self.lib.vmx_add_gk_table_mock(self._h, bs_rp, bs_rt, mock_rp, mock_rt))
         return self._gk[key]
 
     def _set_shotnoise_table(self):

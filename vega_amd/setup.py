@@ -8,7 +8,7 @@ the constructors of ``PowerSpectrum`` / ``PktoXi`` / ``CorrelationFunction`` / `
 records; nothing here is evaluated per likelihood call.
 
 Options outside the hot-path scope (SURVEY.md section 8 "next": new_metals matrix construction,
-small-scale marginalisation, blinding offsets, mock binning, DESI instrumental systematics,
+small-scale marginalisation, blinding offsets, DESI instrumental systematics,
 UV shot noise) raise ``NotImplementedError`` instead of being silently ignored.
 """
 import configparser
@@ -127,6 +127,8 @@ class PkOptions:
     small_scale_nl: str = None   # None | 'arinyo' | 'mcdonald'
     fullshape_smoothing: str = None  # None | 'gauss' | 'exp'
     velocity_dispersion: str = None  # None | 'gauss' | 'lorentz'
+    mock_bin_size: float = None      # 'mock-bin-size' (reference power_spectrum.py:143-160)
+    mock_los_smoothing: str = None   # None | 'growth' | 'amplitude' | 'only-los'
     n_mu: int = 1000
 
 
@@ -375,7 +377,10 @@ def _pk_options(section, bin_size_rp, bin_size_rt, search_dirs):
             raise ValueError('"velocity dispersion" must be of type "gauss" or "lorentz".')
 
     if 'mock-bin-size' in section:
-        raise NotImplementedError('mock-bin-size is outside the accelerated hot path')
+        opts.mock_bin_size = section.getfloat('mock-bin-size')
+        opts.mock_los_smoothing = section.get('mock-los-smoothing', None)
+        if opts.mock_los_smoothing not in (None, 'growth', 'amplitude', 'only-los'):
+            raise ValueError(f'Unknown mock LOS smoothing option {opts.mock_los_smoothing}.')
     return opts
 
 
