@@ -10,7 +10,7 @@ class _FakeEngine:
     def __init__(self):
         self.tables = {}
 
-    def _gk_table(self, a, b):
+    def _gk_table(self, a, b, c=0.0, d=0.0):
         return self.tables.setdefault((a, b), len(self.tables))
 
 
