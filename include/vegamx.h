@@ -114,6 +114,7 @@ typedef struct {
     int32_t rad_slot[4];            /* strength, asymmetry, lifetime, decrease */
     int32_t uv_shotnoise;           /* UV-background shot noise (correlation_func.py:649-686) */
     int32_t uvsn_slot[3];           /* uv_shotnoise_amp, lambda_uv, bias_gamma (or bias_gamma_e) */
+    int32_t single_ell;             /* -1, or ell / 2: return that multipole xi_ell(r') alone (pktoxi.py:122-155) */
     double  z_eff;
 } vmx_pipe_desc;
 

@@ -51,9 +51,15 @@ def test_unsupported_options_fail_loudly():
     prob = load_problem('auto')
     low = E.Lowering(prob)
     core = prob.items['lyalya_lyalya'].core
-    core.xi.single_multipole = 2
+    core.pk.mock_bin_size, core.pk.mock_los_smoothing = 2.0, 'amplitude'     # a parameter-dependent binning kernel
     try:
         with pytest.raises(NotImplementedError):
+            low.pipeline(_FakeEngine(), core, 'smooth')
+    finally:
+        core.pk.mock_bin_size, core.pk.mock_los_smoothing = None, None
+    core.xi.single_multipole = 3
+    try:
+        with pytest.raises(ValueError):
             low.pipeline(_FakeEngine(), core, 'smooth')
     finally:
         core.xi.single_multipole = -1

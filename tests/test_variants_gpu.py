@@ -310,3 +310,11 @@ def test_mock_binning():
     prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = 'amplitude'
     with pytest.raises(NotImplementedError):
         VegaInterface(None, problem=prob, max_batch=1)
+
+
+def test_single_multipole():
+    """`single_multipole = ell`: the model is xi_ell(r') alone, without its Legendre factor (reference pktoxi.py:122-155)."""
+    for ell in (0, 2, 4):
+        prob = _fresh('auto')
+        prob.items['lyalya_lyalya'].core.xi.single_multipole = ell
+        _check(prob, n_walkers=1)

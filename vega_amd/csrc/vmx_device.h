@@ -1305,7 +1305,8 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
             const double w1 = 3.0 * t3 - 6.0 * t2 + 4.0;
             const double w2 = -3.0 * t3 + 3.0 * t2 + 3.0 * t + 1.0;
             const double s = (cf[0] * w0 + cf[1] * w1 + cf[2] * w2 + cf[3] * t3) * (1.0 / 6.0);
-            xi += s * legendre_even(e, rmu);
+            if (d.single_ell >= 0) { if (e == d.single_ell) xi = s; }      // one multipole, no Legendre factor
+            else xi += s * legendre_even(e, rmu);
         }
         if (oob) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
     }

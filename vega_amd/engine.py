@@ -61,7 +61,7 @@ class PipeDesc(C.Structure):
         ('n_ell', C.c_int32), ('scale_mode', C.c_int32), ('scale_slot', C.c_int32 * 2),
         ('drp_slot', C.c_int32), ('croom_slot', C.c_int32 * 2), ('radiation', C.c_int32),
         ('rad_slot', C.c_int32 * 4), ('uv_shotnoise', C.c_int32), ('uvsn_slot', C.c_int32 * 3),
-        ('z_eff', C.c_double)]
+        ('single_ell', C.c_int32), ('z_eff', C.c_double)]
 
 
 class MetalDesc(C.Structure):
@@ -254,8 +254,8 @@ class Lowering:
     def pipeline(self, engine, pipe, component, fast_metals=False, beta_names=(None, None),
                  growth_rate_override=None):
         pk, xi = pipe.pk, pipe.xi
-        if xi.single_multipole >= 0:
-            raise NotImplementedError('single_multipole is not accelerated')
+        if xi.single_multipole >= 0 and (xi.single_multipole % 2 or xi.single_multipole > xi.ell_max):
+            raise ValueError(f'single_multipole = {xi.single_multipole} is not one of the even multipoles <= ell_max')
         if (xi.relativistic or xi.asymmetry) and self.prob.scale.two_alpha_smooth:
             raise NotImplementedError('odd multipoles with two-alpha-smooth are not accelerated')
         if xi.ell_max not in (0, 2, 4, 6):
@@ -380,6 +380,7 @@ class Lowering:
         d.damping_power = pk.damping_power
 
         d.n_ell = xi.ell_max // 2 + 1
+        d.single_ell = xi.single_multipole // 2 if xi.single_multipole >= 0 else -1
         mode, slots = self.scale(pipe, is_peak)
         d.scale_mode = mode
         d.scale_slot[0], d.scale_slot[1] = slots
