@@ -201,6 +201,15 @@ def test_constant_nl_table_mode():
     np.testing.assert_allclose(tab, plain, rtol=1e-11)
     for i in (0, 17, 47):
         assert tab[i] == pytest.approx(oc.chi2(vega.problem, dict(zip(eng.names, theta[i]))), rel=CHI2_RTOL)
+    # the table is rebuilt only when the shared parameters change between batches
+    other = theta.copy()
+    other[:, eng.low.slot['dnl_arinyo_q1']] *= 1.05
+    tab_other = eng.eval(other)[0]
+    plain_other = np.concatenate([eng.eval(other[lo:lo + 8])[0] for lo in range(0, 48, 8)])
+    np.testing.assert_allclose(tab_other, plain_other, rtol=1e-11)
+    assert np.abs(tab_other / tab - 1).max() > 1e-6
+    np.testing.assert_array_equal(eng.eval(theta)[0], tab)              # back to the first parameters: same table again
+    np.testing.assert_array_equal(eng.eval(theta)[0], tab)              # and reused as is
     # device entry point with the hint on, one walker violating it
     bad = theta.copy()
     bad[5, eng.low.slot['dnl_arinyo_q1']] *= 1.01
