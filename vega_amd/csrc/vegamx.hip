@@ -1134,11 +1134,17 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
     }
     SlabInfo slabs{};
     if (e->items.size() > 1) HIP_OK(hipEventRecord(e->ev_fork, e->stream));
-    for (size_t q = 0; q < e->items.size(); ++q) {
+    // the item with the largest distortion product is the critical path: it is enqueued first, on the main stream
+    std::vector<size_t> order(e->items.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+        return (int64_t)e->items[a]->dev.d.n_dist * e->items[a]->dev.d.n_model > (int64_t)e->items[b]->dev.d.n_dist * e->items[b]->dev.d.n_model; });
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+        const size_t q = order[oi];
         ItemHost* it = e->items[q];
         const ItemDev& d = it->dev;
-        e->cur = q == 0 ? e->stream : e->aux[q - 1];
-        if (q > 0) HIP_OK(hipStreamWaitEvent(e->cur, e->ev_fork, 0));
+        e->cur = oi == 0 ? e->stream : e->aux[oi - 1];
+        if (oi > 0) HIP_OK(hipStreamWaitEvent(e->cur, e->ev_fork, 0));
         // metal matrix products (no split-K: the consumer reads one slab)
         for (auto* m : it->metals) {
             if (m->dev.mat_off < 0) continue;
@@ -1166,7 +1172,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         if (it->has_cinv && !e->gcinv.p)
             slabs.z[q] = launch_product(e, KC_INVCOV, it->cinv.p, d.n_masked_pad, 0, d.n_masked, d.n_masked_pad,
                                         it->res.p, d.n_masked_pad, 0, B, it->z.p, d.n_masked_pad, 0, 1, e->slab_rows);
-        if (q > 0) HIP_OK(hipEventRecord(e->ev_join[q - 1], e->cur));
+        if (oi > 0) HIP_OK(hipEventRecord(e->ev_join[oi - 1], e->cur));
     }
     e->cur = e->stream;
     for (size_t q = 1; q < e->items.size(); ++q) HIP_OK(hipStreamWaitEvent(e->stream, e->ev_join[q - 1], 0));
