@@ -129,6 +129,41 @@ def single_point_latency(device, reps=200):
             'us_per_eval': dt * 1e6, 'kernel_us_per_launch': kern}
 
 
+def metals_throughput(device, batch=512, steps=10):
+    """One GPU's share of BASELINE configs[3] (4096 walkers over 8 GPUs): joint fit + the 15 + 4 metal pairs of the
+    reference's test configuration, 512 walkers per step, walkers resident in HBM.  Polynomial metal pairs run in
+    their exact static form (VegaInterface.freeze_static_metals); `exact_pipelines` is the same with every pair on
+    its own P(k,mu) -> xi pipeline."""
+    import torch
+    from vega_amd import VegaInterface, synthetic
+    prob = build_problem('joint_metals')
+    dev = torch.device('cuda', device)
+    out = {'workload': f'configs[3] share: joint + metals (15 + 4 pairs), B={batch} walkers/step'}
+    for label, freeze in (('exact_pipelines', False), ('static_basis', True)):
+        vega = VegaInterface(None, problem=prob, max_batch=batch, device=device)
+        if freeze:
+            vega.freeze_static_metals()
+        eng = vega.engine
+        eng.set_constant_nl_hint(True)
+        pools = [torch.from_numpy(synthetic.walkers(eng.low.theta0, eng.names, batch, varied=VARIED,
+                                                    seed=synthetic.SEED + 77 + i)).to(dev) for i in range(4)]
+        chi2 = torch.zeros(batch, dtype=torch.float64, device=dev)
+        for i in range(5):
+            eng.eval_device(pools[i % 4].data_ptr(), batch, chi2.data_ptr())
+        eng.sync()
+        dt = float('inf')
+        for _ in range(2):              # best of two blocks: a one-off stall (module load, clock ramp) is not the rate
+            t0 = time.perf_counter()
+            for i in range(steps):
+                eng.eval_device(pools[i % 4].data_ptr(), batch, chi2.data_ptr())
+            eng.sync()
+            dt = min(dt, time.perf_counter() - t0)
+        out[label] = {'evals_per_s': batch * steps / dt, 'ms_per_step': dt / steps * 1e3,
+                      'pipelines_per_eval': len(eng.pipe_index)}
+        vega.close()
+    return out
+
+
 def monte_carlo_fits(prob, device, n_mocks=1024):
     """One GPU's share of BASELINE configs[4] (8192 mocks over 8 GPUs): n_mocks Monte-Carlo realisations of the
     bench workload, each fitted over (ap, at, bias_eta_LYA, beta_LYA, beta_QSO, bias_hcd) by the batched minimiser,
@@ -353,6 +388,7 @@ def main():
         distortion = distortion_microbench(eng, torch) if extras else None
         single = single_point_latency(local_rank) if extras else None
         mc_fits = monte_carlo_fits(prob, local_rank) if extras and args.workload == 'joint' else None
+        metals = metals_throughput(local_rank) if extras and args.workload == 'joint' else None
         cpu = None
         if extras and not args.no_cpu_baseline:
             cpu, ref_vals = cpu_baseline(prob, eng.names, host_theta)
@@ -372,7 +408,7 @@ def main():
                        'batch_per_gpu': B, 'pipelines_per_eval': len(eng.pipe_index),
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
-            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'single_point': single, 'monte_carlo_fits': mc_fits, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'cpu_baseline': cpu,
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
         }
         print(json.dumps(out))
