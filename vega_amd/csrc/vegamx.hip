@@ -1083,6 +1083,13 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         for (auto& g : e->pk_groups)
             if (e->pipes[g.pipe].d.nl_model == VMX_NL_ARINYO && !(tab_mode && g.xtab >= 0)) need_mubv = true;
         size_t shmem = ((need_mubv ? (size_t)e->n_mu : 0) + 2048) * sizeof(double);
+        // + the (mu^2, mu^4) table of the tabulated and shared-W mu loops (the large-batch shapes; 40 KB per block at most,
+        // four blocks per CU)
+        bool want_mu_tab = false;
+        for (auto& g : e->pk_groups)
+            if ((tab_mode && g.xtab >= 0) || g.variant == PKV_SHARED_W) want_mu_tab = true;
+        int mu_tab_off = want_mu_tab ? (int)(shmem / sizeof(double)) : -1;
+        if (want_mu_tab) shmem += (size_t)2 * e->n_mu * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
         if (tab_mode)
             for (auto& g : e->pk_groups)
@@ -1102,14 +1109,15 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
 #define VMX_LAUNCH_PK(KT, MS)                                                                                        \
             do {                                                                                                     \
                 const dim3 grid(B, n_groups, (e->nk + (KT) - 1) / (KT));                                             \
-                if (generic) hipLaunchKernelGGL((k_pk_multipoles<KT, MS, 1, true>), grid, dim3(256), shmem, e->stream, D, gp, mp, tm, B);   \
-                else hipLaunchKernelGGL((k_pk_multipoles<KT, MS, 1, false>), grid, dim3(256), shmem, e->stream, D, gp, mp, tm, B);         \
+                if (generic) hipLaunchKernelGGL((k_pk_multipoles<KT, MS, 1, true>), grid, dim3(256), shmem, e->stream, D, gp, mp, tm, B, mu_tab_off);   \
+                else hipLaunchKernelGGL((k_pk_multipoles<KT, MS, 1, false>), grid, dim3(256), shmem, e->stream, D, gp, mp, tm, B, mu_tab_off);         \
             } while (0)
             if ((int64_t)B * n_groups >= 24) VMX_LAUNCH_PK(64, 4);
             else if ((int64_t)B * n_groups >= 4) VMX_LAUNCH_PK(16, 16);
             else {
                 // + the block's slice of the G table, staged in LDS ([n_mu][8])
                 shmem = ((size_t)e->n_mu + 2048 + (size_t)8 * e->n_mu) * sizeof(double);
+                mu_tab_off = -1;
                 if (!e->pk_small_attr) {
                     HIP_OK(hipFuncSetAttribute((const void*)k_pk_multipoles<8, 32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
                     HIP_OK(hipFuncSetAttribute((const void*)k_pk_multipoles<8, 32, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

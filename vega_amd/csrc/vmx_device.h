@@ -370,6 +370,9 @@ __device__ __forceinline__ double vmx_rsqrt(double x)
     return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 #define PK_REANCHOR 64      // steps between exact re-evaluations of the exponential recurrences
 
 // One work group of the P(k,mu) stage: a pipeline and, when the item's peak component differs from its
@@ -509,26 +512,24 @@ __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mu
 //   W(k, mu) = G(k, mu) exp(e0 + e1 mu^2) / sqrt((1 + (k mu s1)^2)(1 + (k mu s2)^2)),
 // from which every member pipeline P = P_lin (c0_1 + c1_1 mu^2)(c0_2 + c1_2 mu^2) W forms its own moments.
 template <int MS, int WB>
-__device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, double inv_nmu, double* wm)
+__device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, double inv_nmu, const v2d* s_mu24, double* wm)
 {
-    const double dmu = (double)MS * inv_nmu;
     double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
     const double* gk = T.gk;
     double g_next = (gk != nullptr) ? *gk : 1.0;
-    double mu = ((double)ms + 0.5) * inv_nmu;
+    const double k2 = T.k * T.k;
+    const double k2vd1 = k2 * T.vd1, k2vd2 = k2 * T.vd2;
     for (int j = ms; j < n_mu; j += MS) {
-        const double mu2 = mu * mu;
+        // (mu^2, mu^4) from the block's LDS table when the launch provides one
+        double mu2, mu4;
+        if (s_mu24 != nullptr) { const v2d mm = s_mu24[j]; mu2 = mm.x; mu4 = mm.y; }
+        else { const double mu = ((double)j + 0.5) * inv_nmu; mu2 = mu * mu; mu4 = mu2 * mu2; }
         const double g = g_next;
         if (j + MS < n_mu && gk != nullptr) { gk += T.gk_stride; g_next = *gk; }
         double val = g;
         if (!T.noexp) val *= vmx_exp(fma(T.e1, mu2, T.e0));
-        if (T.has_vd1 || T.has_vd2) {
-            const double kpar = T.k * mu;
-            const double kp2 = kpar * kpar;
-            if (T.has_vd1) val *= vmx_rsqrt(fma(kp2, T.vd1, 1.0));
-            if (T.has_vd2) val *= vmx_rsqrt(fma(kp2, T.vd2, 1.0));
-        }
-        const double mu4 = mu2 * mu2;
+        if (T.has_vd1) val *= vmx_rsqrt(fma(k2vd1, mu2, 1.0));
+        if (T.has_vd2) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));
         m0 += val;
         m1 = fma(mu2, val, m1);
         m2 = fma(mu4, val, m2);
@@ -536,9 +537,7 @@ __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, d
         m3 += v6;
         m4 = fma(mu2, v6, m4);
         m5 = fma(mu4, v6, m5);
-        mu = ((double)(j + MS) + 0.5) * inv_nmu;
     }
-    (void)dmu;
     wm[0] = m0; wm[1] = m1; wm[2] = m2; wm[3] = m3; wm[4] = m4; wm[5] = m5;
 }
 
@@ -568,8 +567,11 @@ __global__ __launch_bounds__(256) void k_xtab(EngineDev D, int pipe, int xtab)
 // every PK_REANCHOR steps).
 template <int MS, int WB, int KM, bool PAIRED, int NVD>
 __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int ms, int n_mu, double inv_nmu,
-                                            double* s, double* q)
+                                            const v2d* s_mu24, double* s, double* q)
 {
+    // mu^2 and mu^4 of every step come from an LDS table (a wave shares its mu: one broadcast read instead of three
+    // multiplications and an addition in the VALU-bound loop)
+    const double k2vd2 = T.k * T.k * T.vd2;
     const bool same = (KM == KM_SAME_HCD);
     const double dmu = (double)MS * inv_nmu;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
@@ -596,7 +598,8 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
         int jend = j0 + MS * PK_REANCHOR;
         if (jend > n_mu) jend = n_mu;
         for (int j = j0; j < jend; j += MS) {
-            const double mu2 = mu * mu;
+            const v2d mm = s_mu24[j];
+            const double mu2 = mm.x, mu4 = mm.y;
             const double g = g_a;
             g_a = g_b; g_b = g_c;
             if (step + 3 < n_steps) { g_c = *tab; tab += T.gk_stride; }
@@ -605,8 +608,8 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
             const double A1 = fma(F, hmu, fma(T.c1_1, mu2, T.c0_1));
             const double AA = same ? A1 * A1 : A1 * fma(T.c1_2, mu2, T.c0_2);
             double val = AA * (g * gs);
-            if (NVD == 1) { const double kpar = T.k * mu; val *= vmx_rsqrt(fma(kpar * kpar, T.vd2, 1.0)); }
-            const double mu4 = mu2 * mu2, mu6 = mu4 * mu2;
+            if (NVD == 1) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));
+            const double mu6 = mu4 * mu2;
             s0 += val;
             s1 = fma(mu2, val, s1);
             s2 = fma(mu4, val, s2);
@@ -623,7 +626,6 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
             gs *= gr;
             gr *= gq;
             F *= T.Fq;
-            mu += dmu;
         }
     }
     s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3;
@@ -638,7 +640,7 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
 #endif
 template <int KT, int MS, int WB, bool GENERIC>
 __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipoles(EngineDev D, const PkGroup* groups, const int32_t* members,
-                                                       int tab_mode, int B)
+                                                       int tab_mode, int B, int mu_tab_off)
 {
     extern __shared__ double smem[];
     const int wb = (WB > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x / (KT * MS)) : 0;
@@ -648,6 +650,9 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     double* s_mubv = smem + 2048 + (size_t)wb * D.n_mu;       // [WB][n_mu]   mu^bv (Arinyo), one table per walker
     const bool use_tab = tab_mode && groups[blockIdx.y].xtab >= 0 &&
                          (groups[blockIdx.y].variant == PKV_AUTO_CORE || groups[blockIdx.y].variant == PKV_CROSS_CORE);
+    v2d* s_mu24 = (v2d*)(smem + (mu_tab_off >= 0 ? mu_tab_off : 0));        // [n_mu] (mu^2, mu^4) when the launch has room
+    if (mu_tab_off >= 0 && (use_tab || groups[blockIdx.y].variant == PKV_SHARED_W))
+        for (int j = threadIdx.x; j < D.n_mu; j += 256) { const double m = D.mu[j], m2 = m * m; s_mu24[j] = (v2d){m2, m2 * m2}; }
 
     int b = blockIdx.x * WB + wb;
     const bool walker_ok = b < B;
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
         // one mu loop for all member pipelines (e.g. QSO x each metal line): they share W and differ only in
         // the Kaiser polynomials
         double wm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (live_block) pk_w_loop<MS, WB>(T, ms, n_mu, inv_nmu, wm);
+        if (live_block) pk_w_loop<MS, WB>(T, ms, n_mu, inv_nmu, mu_tab_off >= 0 ? s_mu24 : nullptr, wm);
         for (int n = 0; n < 6; ++n) s_red[n * 256 + threadIdx.x] = wm[n];
         __syncthreads();
         if (lt < KT && valid && walker_ok) {
@@ -817,8 +822,8 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     if (use_tab) {
         if (live_block) {
             T.gk = D.xtab + ((size_t)xt * n_mu + ms) * D.nkp + ic;
-            if (variant == PKV_AUTO_CORE) pk_tab_loop<MS, WB, KM_SAME_HCD, true, 0>(T, -k2 * gb, ms, n_mu, inv_nmu, s, q);
-            else pk_tab_loop<MS, WB, KM_FIRST_HCD, true, 1>(T, -k2 * gb, ms, n_mu, inv_nmu, s, q);
+            if (variant == PKV_AUTO_CORE) pk_tab_loop<MS, WB, KM_SAME_HCD, true, 0>(T, -k2 * gb, ms, n_mu, inv_nmu, s_mu24, s, q);
+            else pk_tab_loop<MS, WB, KM_FIRST_HCD, true, 1>(T, -k2 * gb, ms, n_mu, inv_nmu, s_mu24, s, q);
         }
     } else if (live_block)
     switch (variant) {
@@ -1004,8 +1009,6 @@ __global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B, int 
 //   split-K partial sums go to separate slabs of D
 //   (summed in fixed order by the consumer: results are bitwise reproducible).
 // ------------------------------------------------------------------------------------------------
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define GEMM_BM 64
 #define GEMM_BN 64
