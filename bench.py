@@ -359,7 +359,10 @@ def main():
                     shapes = [(816, 814)] * 4
                 n_vec = B * (4 * n_items // 2 if kclass == 'fftlog_spline_product' else 1)
                 flops = sum(2.0 * m * n * n_vec for m, n in shapes)
-                if kclass != 'fftlog_spline_product':     # one launch per item (average); the FFTLog launch covers all ell
+                if kclass == 'invcov_product':
+                    flops /= 2.0            # the half (lower-triangular) form of the symmetric inverse covariance
+                # the FFTLog launch covers all ell and, for B > 8, one launch covers every item's product
+                if kclass != 'fftlog_spline_product' and kernels[kclass]['launches_per_step'] > 1:
                     flops /= len(shapes)
                 bound, peak, reach = 'mfma', FP64_MFMA_PEAK_TF, FP64_MFMA_MEASURED_TF
             else:

@@ -78,6 +78,19 @@ static int upload_padded(DevBuf<double>& buf, const double* host, int rows, int 
     return 0;
 }
 
+// Inverse covariances are stored in "half form": L[i][j] = (C[i][j] + C[j][i]) / 2 below the diagonal, C[i][i] / 2 on
+// it and 0 above, so that r^T C^-1 r = 2 r^T (L r) exactly in exact arithmetic - the product then needs the lower
+// triangle only (half the flops, and half the bytes for a single walker).
+static std::vector<double> half_form(const double* c, int n)
+{
+    std::vector<double> out((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < i; ++j) out[(size_t)i * n + j] = 0.5 * (c[(size_t)i * n + j] + c[(size_t)j * n + i]);
+        out[(size_t)i * n + i] = 0.5 * c[(size_t)i * n + i];
+    }
+    return out;
+}
+
 struct MetalHost {
     MetalDev dev{};
     DevBuf<double> mat, svec, basis;
@@ -284,11 +297,53 @@ static int pk_variant(const vmx_pipe_desc& d, bool paired)
 // the single-walker streaming kernel keeps x in LDS
 static bool gemv1_applies(int N, int K) { return N == 1 && K <= 5120 && (size_t)K * sizeof(double) <= 48 * 1024; }
 
+// Tiling of one MFMA product: fills the tile / split fields of `g`, returns the number of K slabs and, in *per_xcd,
+// the blocks each XCD runs for it.  `other_tiles`: tiles of the other problems of the same launch.
+static int plan_gemm(vmx_engine* e, GemmArgs& g, int nbatch, int slab_rows_avail, const int32_t* k_limit, bool tri,
+                     int other_tiles, int* per_xcd)
+{
+    constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    const int tm_eff = tri ? (tm + 1) / 2 : tm;       // a triangular matrix pairs its row tiles (k_gemm_nt)
+    const int tiles = tm_eff * tn * nbatch + other_tiles;
+    // split K (1, 2, 4 or 8 ways: a split belongs to whole XCDs) until the launch has at least 512 blocks (2 per CU);
+    // partial sums go to separate slabs, which the consumer kernels re-read: more splits cost there
+    int nsplit = 1;
+    while (nsplit < 8 && tiles * nsplit < 512) nsplit *= 2;
+    if (e->gemm_split_override > 0) nsplit = e->gemm_split_override;
+    while (nsplit > 1 && (int64_t)nsplit * g.N > slab_rows_avail) nsplit /= 2;
+    int klen = ((g.K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+    while (nsplit > 1 && (int64_t)klen * (nsplit - 1) >= g.K) { nsplit /= 2; klen = ((g.K + nsplit - 1) / nsplit + BK - 1) / BK * BK; }
+    g.nsplit = nsplit; g.klen = klen; g.d_slab = (int64_t)g.N * g.ldd;
+    g.tm = tm; g.tn = tn; g.k_limit = k_limit; g.tri = tri ? 1 : 0;
+    const int ngroups = 8 / nsplit;
+    *per_xcd = ((tm_eff + ngroups - 1) / ngroups) * tn;
+    return nsplit;
+}
+
+static int gemm_tiles(int M, int N, bool tri)
+{
+    const int tm = (M + GEMM_BM - 1) / GEMM_BM, tn = (N + GEMM_BN - 1) / GEMM_BN;
+    return (tri ? (tm + 1) / 2 : tm) * tn;
+}
+
+static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per_xcd_total, int nbatch)
+{
+    constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
+    dim3 grid(8 * per_xcd_total, nbatch), block(256);
+    switch (kc) {
+        case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_DISTORTION>), grid, block, 0, e->cur, G); break;
+        case KC_INVCOV: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_INVCOV>), grid, block, 0, e->cur, G); break;
+        case KC_FFTLOG: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_FFTLOG>), grid, block, 0, e->cur, G); break;
+        default: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_OTHER>), grid, block, 0, e->cur, G); break;
+    }
+}
+
 // D[n][m] = sum_k A[m][k] X[n][k]; returns the number of K slabs written (consumer sums them).
 static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64_t a_batch, int M, int K,
                           const double* X, int ldx, int64_t x_batch, int N, double* D, int ldd,
                           int64_t d_batch, int nbatch, int slab_rows_avail, const int32_t* k_limit = nullptr,
-                          int fused_item = -1)
+                          int fused_item = -1, bool tri = false)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.a_batch = a_batch;
@@ -324,28 +379,11 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
         }
         return 1;
     }
-    constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
-    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-    const int tiles = tm * tn * nbatch;
-    // split K (1, 2, 4 or 8 ways: a split belongs to whole XCDs) until at least 512 blocks exist (
-    // 2 per CU); partial sums go to separate slabs, which the consumer kernels re-read: more splits cost there
-    int nsplit = 1;
-    while (nsplit < 8 && tiles * nsplit < 512) nsplit *= 2;
-    if (e->gemm_split_override > 0) nsplit = e->gemm_split_override;
-    while (nsplit > 1 && (int64_t)nsplit * N > slab_rows_avail) nsplit /= 2;
-    int klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
-    while (nsplit > 1 && (int64_t)klen * (nsplit - 1) >= K) { nsplit /= 2; klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK; }
-    g.nsplit = nsplit; g.klen = klen; g.d_slab = (int64_t)N * ldd;
-    g.tm = tm; g.tn = tn; g.k_limit = k_limit;
-    const int ngroups = 8 / nsplit;
-    const int per_xcd = ((tm + ngroups - 1) / ngroups) * tn;
-    dim3 grid(8 * per_xcd, nbatch), block(256);
-    switch (kc) {
-        case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_DISTORTION>), grid, block, 0, e->cur, g); break;
-        case KC_INVCOV: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_INVCOV>), grid, block, 0, e->cur, g); break;
-        case KC_FFTLOG: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_FFTLOG>), grid, block, 0, e->cur, g); break;
-        default: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_OTHER>), grid, block, 0, e->cur, g); break;
-    }
+    GemmGroup G{};
+    int per_xcd = 0;
+    const int nsplit = plan_gemm(e, g, nbatch, slab_rows_avail, k_limit, tri, 0, &per_xcd);
+    G.p[0] = g; G.n = 1; G.seq_end[0] = per_xcd;
+    launch_gemm_group(e, kc, G, per_xcd, nbatch);
     return nsplit;
 }
 
@@ -665,14 +703,15 @@ int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index
     } else if (kind == VMX_MAT_INVCOV) {
         REQUIRE(it->has_mask, "set the mask before the inverse covariance");
         REQUIRE(rows == it->dev.n_masked && cols == rows, "inverse covariance shape");
+        const std::vector<double> half = half_form(dense, rows);
         if (e->finalized) {
             REQUIRE(it->has_cinv, "an identity inverse covariance cannot be replaced after vmx_finalize");
             HIP_OK(hipStreamSynchronize(e->stream));
-            HIP_OK(hipMemcpy2D(it->cinv.p, (size_t)it->dev.n_masked_pad * sizeof(double), dense,
+            HIP_OK(hipMemcpy2D(it->cinv.p, (size_t)it->dev.n_masked_pad * sizeof(double), half.data(),
                                (size_t)cols * sizeof(double), (size_t)cols * sizeof(double), rows,
                                hipMemcpyHostToDevice));
         } else {
-            if (upload_padded(it->cinv, dense, rows, cols, it->dev.n_masked_pad)) return -2;
+            if (upload_padded(it->cinv, half.data(), rows, cols, it->dev.n_masked_pad)) return -2;
             it->has_cinv = true;
         }
     } else if (kind == VMX_MAT_METAL) {
@@ -763,15 +802,16 @@ int vmx_set_global_invcov(vmx_engine* e, const double* invcov, int32_t n)
 {
     REQUIRE(e && invcov && n > 0, "vmx_set_global_invcov");
     HIP_OK(hipSetDevice(e->device));
+    const std::vector<double> half = half_form(invcov, n);
     if (e->finalized) {
         REQUIRE(e->g_n == n, "global inverse covariance size changed");
         HIP_OK(hipStreamSynchronize(e->stream));
-        HIP_OK(hipMemcpy2D(e->gcinv.p, (size_t)e->g_ld * sizeof(double), invcov, (size_t)n * sizeof(double),
+        HIP_OK(hipMemcpy2D(e->gcinv.p, (size_t)e->g_ld * sizeof(double), half.data(), (size_t)n * sizeof(double),
                            (size_t)n * sizeof(double), n, hipMemcpyHostToDevice));
         return 0;
     }
     e->g_n = n; e->g_ld = vmx_pad(n);
-    return upload_padded(e->gcinv, invcov, n, n, e->g_ld);
+    return upload_padded(e->gcinv, half.data(), n, n, e->g_ld);
 }
 
 int vmx_add_prior(vmx_engine* e, int32_t slot, double mean, double sigma)
@@ -791,9 +831,9 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     HIP_OK(hipSetDevice(e->device));
     const int Bm = max_batch;
     e->n_params = n_params; e->max_batch = Bm;
-    // split-K slabs are re-read by the consumer kernels: at most 512 walker rows of slabs per product (measured
+    // split-K slabs are re-read by the consumer kernels: at most 1024 walker rows of slabs per product (measured
     // best in the full chain, where the items overlap on separate streams and fill the chip anyway)
-    e->slab_rows = Bm > 512 ? Bm : 512;
+    e->slab_rows = Bm > 1024 ? Bm : 1024;
     if (const char* ov = getenv("VMX_GEMM_SPLIT")) e->gemm_split_override = atoi(ov);
     if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
 
@@ -1141,8 +1181,69 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         hipLaunchKernelGGL(k_xi_bins, dim3((max_n + 255) / 256, n_pipe, B), dim3(256), 0, e->stream, D);
     }
     SlabInfo slabs{};
+    for (size_t q = 0; q < e->items.size(); ++q) slabs.z[q] = 1;
+    const bool grouped = B > 8 && e->items.size() <= VMX_MAX_GROUP;
+    if (grouped) {
+        // Large batches: the items advance together on one stream and their products share launches - every tile of
+        // every item's distortion product (then of every C^-1 product) is in flight at once.
+        e->cur = e->stream;
+        int max_model = 0, max_dist = 0;
+        for (auto* it : e->items) {
+            max_model = std::max(max_model, (int)it->dev.d.n_model); max_dist = std::max(max_dist, (int)it->dev.d.n_dist);
+            for (auto* m : it->metals) {
+                if (m->dev.mat_off < 0) continue;
+                const PipeDev& P = e->pipes[m->dev.d.pipeline];
+                launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
+                               e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, it->dev.n_model_pad, 0, 1, 0);
+            }
+        }
+        {
+            ScopedTimer t(e, KC_ASSEMBLE);
+            hipLaunchKernelGGL(k_assemble_all, dim3((max_model + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->cur, D);
+        }
+        SlabInfo dslabs{};
+        for (size_t q = 0; q < e->items.size(); ++q) dslabs.z[q] = 1;
+        for (int stage = 0; stage < 2; ++stage) {       // 0: distortion products, 1: C^-1 products
+            if (stage == 1 && e->gcinv.p) break;
+            GemmGroup G{};
+            int tiles_total = 0, per_xcd_total = 0;
+            for (auto* it : e->items) {
+                const ItemDev& d = it->dev;
+                if (stage == 0 ? it->has_dm : it->has_cinv)
+                    tiles_total += stage == 0 ? gemm_tiles(d.d.n_dist, B, false) : gemm_tiles(d.n_masked, B, true);
+            }
+            for (size_t q = 0; q < e->items.size(); ++q) {
+                ItemHost* it = e->items[q];
+                const ItemDev& d = it->dev;
+                if (!(stage == 0 ? it->has_dm : it->has_cinv)) continue;
+                GemmArgs g{};
+                if (stage == 0) {
+                    g.A = it->dm.p; g.lda = d.n_model_pad; g.X = it->vec.p; g.ldx = d.n_model_pad; g.D = it->dist.p; g.ldd = d.n_dist_pad;
+                    g.M = d.d.n_dist; g.N = B; g.K = d.n_model_pad;
+                } else {
+                    g.A = it->cinv.p; g.lda = d.n_masked_pad; g.X = it->res.p; g.ldx = d.n_masked_pad; g.D = it->z.p; g.ldd = d.n_masked_pad;
+                    g.M = d.n_masked; g.N = B; g.K = d.n_masked_pad;
+                }
+                int per_xcd = 0;
+                const int own = stage == 0 ? gemm_tiles(g.M, B, false) : gemm_tiles(g.M, B, true);
+                const int ns = plan_gemm(e, g, 1, e->slab_rows, nullptr, stage == 1, tiles_total - own, &per_xcd);
+                (stage == 0 ? dslabs : slabs).z[q] = ns;
+                per_xcd_total += per_xcd;
+                G.p[G.n] = g; G.seq_end[G.n] = per_xcd_total; ++G.n;
+            }
+            if (G.n > 0) {
+                ScopedTimer t(e, stage == 0 ? KC_DISTORTION : KC_INVCOV);
+                launch_gemm_group(e, stage == 0 ? KC_DISTORTION : KC_INVCOV, G, per_xcd_total, 1);
+            }
+            if (stage == 0) {
+                ScopedTimer t(e, KC_POST);
+                hipLaunchKernelGGL(k_post_all, dim3((max_dist + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->cur, D, B, dslabs);
+            }
+        }
+    } else {
     if (e->items.size() > 1) HIP_OK(hipEventRecord(e->ev_fork, e->stream));
-    // the item with the largest distortion product is the critical path: it is enqueued first, on the main stream
+    // small batches are latency-bound: the items run on forked streams; the item with the largest distortion product is
+    // the critical path and is enqueued first, on the main stream
     std::vector<size_t> order(e->items.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
@@ -1176,18 +1277,20 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
             ScopedTimer t(e, KC_POST);
             hipLaunchKernelGGL(k_post, dim3((d.d.n_dist + 255) / 256, B), dim3(256), 0, e->cur, D, (int)q, B, dist_slabs);
         }
-        slabs.z[q] = 1;
         if (it->has_cinv && !e->gcinv.p)
             slabs.z[q] = launch_product(e, KC_INVCOV, it->cinv.p, d.n_masked_pad, 0, d.n_masked, d.n_masked_pad,
-                                        it->res.p, d.n_masked_pad, 0, B, it->z.p, d.n_masked_pad, 0, 1, e->slab_rows);
+                                        it->res.p, d.n_masked_pad, 0, B, it->z.p, d.n_masked_pad, 0, 1, e->slab_rows,
+                                        nullptr, -1, true);
         if (oi > 0) HIP_OK(hipEventRecord(e->ev_join[oi - 1], e->cur));
     }
     e->cur = e->stream;
     for (size_t q = 1; q < e->items.size(); ++q) HIP_OK(hipStreamWaitEvent(e->stream, e->ev_join[q - 1], 0));
+    }
+    e->cur = e->stream;
     slabs.g = 1;
     if (e->gcinv.p)
         slabs.g = launch_product(e, KC_INVCOV, e->gcinv.p, e->g_ld, 0, e->g_n, e->g_ld, e->gres.p, e->g_ld, 0, B,
-                                 e->gz.p, e->g_ld, 0, 1, e->slab_rows);
+                                 e->gz.p, e->g_ld, 0, 1, e->slab_rows, nullptr, -1, true);
     {
         ScopedTimer t(e, KC_CHI2);
         hipLaunchKernelGGL(k_chi2, dim3(B), dim3(256), 0, e->stream, D, B, slabs);

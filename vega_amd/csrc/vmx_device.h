@@ -85,7 +85,6 @@ struct ItemDev {
     double* z;                                // [S][B][n_masked_pad] C^-1 residual slabs
 };
 
-struct SlabInfo { int32_t z[16]; int32_t g; };   // split-K slab counts of the C^-1 products
 
 struct EngineDev {
     // template
@@ -972,6 +971,16 @@ __global__ __launch_bounds__(256) void k_assemble(EngineDev D, int item)
     it.vec[(size_t)b * it.n_model_pad + bin] = assemble_bin(D, it, b, bin);
 }
 
+// every item in one launch (blockIdx.z = item)
+__global__ __launch_bounds__(256) void k_assemble_all(EngineDev D)
+{
+    const ItemDev& it = D.items[blockIdx.z];
+    const int b = blockIdx.y;
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= it.d.n_model) return;
+    it.vec[(size_t)b * it.n_model_pad + bin] = assemble_bin(D, it, b, bin);
+}
+
 // post-distortion broadband, model output and masked residual (model.py:147-149; vega_interface.py:310-315)
 __device__ inline void post_bin(const EngineDev& D, const ItemDev& it, int b, int bin, double v)
 {
@@ -1003,6 +1012,22 @@ __global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B, int 
     post_bin(D, it, b, bin, v);
 }
 
+struct SlabInfo { int32_t z[16]; int32_t g; };   // split-K slab counts of a product per item (+ the global one)
+
+__global__ __launch_bounds__(256) void k_post_all(EngineDev D, int B, SlabInfo dist_slabs)
+{
+    const ItemDev& it = D.items[blockIdx.z];
+    const int b = blockIdx.y;
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= it.d.n_dist) return;
+    double v;
+    if (it.dm) {
+        v = 0.0;
+        for (int s = 0; s < dist_slabs.z[blockIdx.z]; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
+    } else v = it.vec[(size_t)b * it.n_model_pad + bin];
+    post_bin(D, it, b, bin, v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // D^T[n][m] = sum_k A[m][k] * X[n][k]      (A static matrix, X / D one vector per walker)
 //   fp64 MFMA 16x16x4; block tile 64 x 64 x 16, 4 waves each owning a 32 x 32 quadrant.
@@ -1022,14 +1047,20 @@ struct GemmArgs {
     int nsplit, klen;       // klen multiple of the K step; nsplit in {1, 2, 4, 8} for the MFMA kernel
     int tm, tn;             // block tiles along matrix rows / walkers (MFMA kernel)
     const int32_t* k_limit; // optional device scalar: operand columns >= *k_limit are zero and skipped (MFMA kernel)
+    int tri;                // A is lower triangular (zeros above the diagonal): row tile mt needs k < (mt + 1) BM only
 };
+
+// Several independent products in one launch (the distortion products of all correlation items, then their C^-1
+// products): every tile of every problem is in flight at once, so the small problems fill the tail of the large one.
+#define VMX_MAX_GROUP 8
+struct GemmGroup { GemmArgs p[VMX_MAX_GROUP]; int32_t n; int32_t seq_end[VMX_MAX_GROUP]; };
 
 // Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
 // (BM/2) x (BN/2) sub-tile as (BN/32) x (BM/32) MFMA tiles.  LDS rows are padded to BK + 2 doubles, which
 // makes the 16-row x 4-k operand read pattern of v_mfma_f64_16x16x4 conflict-free for ds_read_b64.
 // TAG = kernel class of the caller: one instantiation (and one name in a profiler's kernel table) per product of the chain.
 template <int BM, int BN, int BK, int TAG>
-__global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
+__global__ __launch_bounds__(256) void k_gemm_nt(GemmGroup G)
 {
     constexpr int LD = BK + 2;
     constexpr int TI = BN / 32;        // MFMA tiles per wave along walkers
@@ -1043,25 +1074,45 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
     // XCD x works on K split (x % nsplit) only, so the walker operand it touches (N x klen doubles) stays in its
     // L2, and it visits the walker tiles of one matrix-row tile back to back, so the matrix tile is fetched from
     // HBM once and found in L2 by the other walker tiles.  gridDim.x = 8 * blocks per XCD.
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    int seq = blockIdx.x >> 3;
+    int pi = 0;
+    while (pi < G.n - 1 && seq >= G.seq_end[pi]) ++pi;          // which problem this block belongs to (block-uniform)
+    if (pi > 0) seq -= G.seq_end[pi - 1];
+    const GemmArgs& g = G.p[pi];
     const int split = xcd % g.nsplit, group = xcd / g.nsplit, ngroups = 8 / g.nsplit;
-    const int mt = (seq / g.tn) * ngroups + group, nt = seq % g.tn;
-    if (mt >= g.tm) return;
+    // triangular A: a block takes row tile p and its mirror tm - 1 - p, whose K ranges add up to the same length for
+    // every p, so all blocks carry equal work
+    const int tm_eff = g.tri ? (g.tm + 1) / 2 : g.tm;
+    const int mt0 = (seq / g.tn) * ngroups + group, nt = seq % g.tn;
+    if (mt0 >= tm_eff) return;
+    const int npass = (g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
     const int batch = blockIdx.y;
     const double* A = g.A + batch * g.a_batch;
     const double* X = g.X + batch * g.x_batch;
     double* Dp = g.D + batch * g.d_batch + split * g.d_slab;
 
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int kbeg = split * g.klen;
-    int kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
-    if (g.k_limit) { const int kl = (*g.k_limit + BK - 1) / BK * BK; if (kend > kl) kend = kl; }
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 1) * (BM / 2), wn = (wave >> 1) * (BN / 2);
-
     const int lrow = tid / (BK / 2);
     const int lk = (tid % (BK / 2)) * 2;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int n0 = nt * BN;
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int mt = pass == 0 ? mt0 : g.tm - 1 - mt0;
+    const int m0 = mt * BM;
+    int kbeg, kend;
+    if (g.tri) {
+        int kmax = ((mt + 1) * BM + BK - 1) / BK * BK; if (kmax > g.K) kmax = g.K;
+        const int klen = ((kmax + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;
+        kbeg = split * klen; kend = kbeg + klen; if (kend > kmax) kend = kmax;
+    } else {
+        kbeg = split * g.klen; kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
+    }
+    if (g.k_limit) { const int kl = (*g.k_limit + BK - 1) / BK * BK; if (kend > kl) kend = kl; }
+    if (pass > 0) __syncthreads();          // the LDS buffers of the first tile are free again
+
     const double* pa[PA];
     const double* px[PX];
 #pragma unroll
@@ -1083,7 +1134,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
         for (int p = 0; p < PX; ++p) rx[p] = *(const v2d*)(px[p] + kbeg);
     }
     int buf = 0;
-    const int frow = lane & 15, fk = lane >> 4;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) *(v2d*)&sA[buf][(lrow + p * RPP) * LD + lk] = ra[p];
@@ -1128,6 +1178,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g)
                 const int m = m0 + wm + 16 * j + (lane & 15);
                 if (n < g.N && m < g.M) Dp[(size_t)n * g.ldd + m] = acc[i][j][r];
             }
+  }
 }
 
 // y[n][m] = sum over slabs (fixed order) - used by the stand-alone product entry point
@@ -1386,7 +1437,7 @@ __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs
         for (int i = threadIdx.x; i < D.g_n; i += 256) {
             double z = 0.0;
             for (int s = 0; s < slabs.g; ++s) z += D.gz[((size_t)s * B + b) * D.g_ld + i];
-            acc = fma(D.gres[(size_t)b * D.g_ld + i], z, acc);
+            acc = fma(D.gres[(size_t)b * D.g_ld + i], 2.0 * z, acc);         // gcinv holds the half form (see vegamx.hip)
         }
     } else {
         for (int q = 0; q < D.n_items; ++q) {
@@ -1397,6 +1448,7 @@ __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs
                 if (it.cinv) {
                     z = 0.0;
                     for (int s = 0; s < slabs.z[q]; ++s) z += it.z[((size_t)s * B + b) * it.n_masked_pad + i];
+                    z *= 2.0;               // cinv holds the half form: r^T C^-1 r = 2 r^T (L r)
                 } else z = rres;
                 acc = fma(rres, z, acc);
             }
