@@ -349,7 +349,7 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
     g.A = A; g.lda = lda; g.a_batch = a_batch;
     g.X = X; g.ldx = ldx; g.x_batch = x_batch;
     g.D = D; g.ldd = ldd; g.d_batch = d_batch;
-    g.M = M; g.N = N; g.K = K;
+    g.M = M; g.N = N; g.K = K; g.tri = tri ? 1 : 0;
     ScopedTimer timer(e, kc);
     if (gemv1_applies(N, K)) {
         // persistent streaming kernel: 2 blocks per CU, rows strided over blocks

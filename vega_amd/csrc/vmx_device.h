@@ -1207,8 +1207,10 @@ __global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.0;
     // K is a multiple of 16; each lane consumes double2 chunks, 128 doubles per wave step, 4 steps in flight
+    // (a lower-triangular A has nothing but zeros past its diagonal: the row ends there)
+    const int K = g.tri ? min(g.K, (row + 2) & ~1) : g.K;
     int k = lane * 2;
-    for (; k + 384 < g.K; k += 512) {
+    for (; k + 384 < K; k += 512) {
         const v2d a0 = *(const v2d*)(a + k), a1 = *(const v2d*)(a + k + 128);
         const v2d a2 = *(const v2d*)(a + k + 256), a3 = *(const v2d*)(a + k + 384);
 #pragma unroll
@@ -1219,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
                     + a2.x * x2.x + a2.y * x2.y + a3.x * x3.x + a3.y * x3.y;
         }
     }
-    for (; k < g.K; k += 128) {
+    for (; k < K; k += 128) {
         const v2d a0 = *(const v2d*)(a + k);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -1263,10 +1265,12 @@ __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g, EngineDev D, int item
     // request the first row of the matrix stream before staging x, so both latencies overlap
     v2d cur[CPW], nxt[CPW];
     int row = blockIdx.x;
+    const v2d zero2 = (v2d){0.0, 0.0};
     if (row < g.M) {
         const double* a = A + (size_t)row * g.lda;
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) cur[c] = __builtin_nontemporal_load((const v2d*)(a + koff[c]));
+        for (int c = 0; c < CPW; ++c)       // a lower-triangular A is zero past the diagonal: those bytes are not read
+            cur[c] = (!g.tri || koff[c] <= row) ? __builtin_nontemporal_load((const v2d*)(a + koff[c])) : zero2;
     }
     if constexpr (FUSED) {
         const ItemDev& it = D.items[item];
@@ -1281,7 +1285,8 @@ __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g, EngineDev D, int item
         if (next < g.M) {
             const double* a = A + (size_t)next * g.lda;
 #pragma unroll
-            for (int c = 0; c < CPW; ++c) nxt[c] = __builtin_nontemporal_load((const v2d*)(a + koff[c]));
+            for (int c = 0; c < CPW; ++c)
+                nxt[c] = (!g.tri || koff[c] <= next) ? __builtin_nontemporal_load((const v2d*)(a + koff[c])) : zero2;
         }
         double acc = 0.0;
 #pragma unroll
