@@ -44,3 +44,21 @@ def load_problem(name, **kw):
 @pytest.fixture(scope='session')
 def problem_loader():
     return load_problem
+
+
+def fits_ingest_problem(tmp_path):
+    """The auto-correlation config pointed at a FITS data file that carries the synthetic distortion matrix and
+    covariance (written with the package's own FITS writer in the reference's layout)."""
+    import re
+    from vega_amd import synthetic
+    from vega_amd.setup import build_problem
+    from vega_amd.tables import read_tables
+    source = read_tables(GOLDEN / 'inputs' / 'cf_lya-exp.npz')
+    data_path = synthetic.write_data_file(tmp_path / 'cf_lya-synth.fits', source)
+    cfg = tmp_path / 'configs' / 'ingest'
+    cfg.mkdir(parents=True)
+    main = (GOLDEN / 'configs' / 'auto' / 'main.ini').read_text()
+    (cfg / 'main.ini').write_text(re.sub(r'ini files = .*', 'ini files = configs/ingest/lyalya_lyalya.ini', main))
+    item = (GOLDEN / 'configs' / 'auto' / 'lyalya_lyalya.ini').read_text()
+    (cfg / 'lyalya_lyalya.ini').write_text(re.sub(r'filename = .*', f'filename = {data_path}', item, count=1))
+    return build_problem('configs/ingest/main.ini', search_dirs=[tmp_path, GOLDEN])

@@ -405,6 +405,34 @@ def dump_mockbin(VegaInterface):
         print('mockbin: chi2', out['fid/chi2'], out['walker0/chi2'])
 
 
+def dump_fits_ingest(VegaInterface):
+    """Static-state ingestion (reference vega/data.py:285-473, utils.py:271-298): a data FITS file that carries the
+    synthetic distortion matrix (`DM`) and covariance (`CO`) as vector columns - written by
+    vega_amd.synthetic.write_data_file from the reference's own test file - read by the unmodified reference;
+    chi2 / log-likelihood / model at the fiducial point and one walker."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        source = read_tables(REF / 'tests/data/cf_lya-exp.fits.gz')
+        data_path = synthetic.write_data_file(Path(tmp) / 'cf_lya-synth.fits', source)
+        main = _ref_main(tmp, ['lyalya_lyalya'], False)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(re.sub(r'filename = .*', f'filename = {data_path}', item.read_text(), count=1))
+        vega = VegaInterface(main)
+        data = vega.data['lyalya_lyalya']
+        assert data.has_distortion and data.cov_mat is not None
+        out = {'fid/chi2': vega.chi2(), 'fid/log_lik': vega.log_lik(),
+               'fid/model': vega.compute_model(run_init=False)['lyalya_lyalya'],
+               'log_cov_det': data.log_cov_det, 'data_size': data.data_size}
+        names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 3)
+        _reset_caches(vega)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[walkers[0][n] for n in names]])
+        out['walker0/chi2'] = vega.chi2(walkers[0])
+        np.savez_compressed(HERE / 'expected_fits_ingest.npz', **out)
+        print('fits ingest: chi2', out['fid/chi2'], 'log_lik', out['fid/log_lik'], out['walker0/chi2'])
+
+
 def dump_fast_metals(VegaInterface):
     """`fast_metals = True` (reference metals.py:53,144-169,280-282): metal x metal correlations are computed at
     the FIRST evaluation and reused for ever after.  Sequence dumped: chi2 at the fiducial point (fills the cache),
@@ -450,12 +478,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -472,3 +500,5 @@ if __name__ == '__main__':
         dump_fast_metals(VI)
     if 'mockbin' in what:
         dump_mockbin(VI)
+    if 'fits_ingest' in what:
+        dump_fits_ingest(VI)

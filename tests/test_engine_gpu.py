@@ -277,3 +277,18 @@ def test_maximum_batch_with_metals():
     small = eng.eval(theta[1000:1008])[0]
     np.testing.assert_allclose(chi2[1000:1008], small, rtol=1e-10)
     vega.close()
+
+
+def test_fits_ingestion_through_the_engine(tmp_path):
+    """Distortion matrix and covariance ingested from a FITS data file (reference vega/data.py:285-473): the engine
+    against what the unmodified reference computed from the same file."""
+    from conftest import fits_ingest_problem
+    from vega_amd import VegaInterface
+    exp = np.load(GOLDEN / 'expected_fits_ingest.npz')
+    vega = VegaInterface(None, problem=fits_ingest_problem(tmp_path), max_batch=2)
+    assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    assert vega.log_lik() == pytest.approx(float(exp['fid/log_lik']), rel=1e-9)
+    _assert_xi(vega.compute_model()['lyalya_lyalya'], exp['fid/model'], 'fits ingest')
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert vega.chi2(pars) == pytest.approx(float(exp['walker0/chi2']), rel=CHI2_RTOL)
+    vega.close()

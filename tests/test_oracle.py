@@ -274,3 +274,24 @@ def test_mock_binning_matches_reference():
     assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-13)
     model = oc.compute_model(prob, pars)['lyalya_lyalya']
     assert np.abs(model - exp['walker0/model']).max() <= 1e-13 * np.abs(model).max()
+
+
+def test_fits_ingestion_matches_reference(tmp_path):
+    """Static-state ingestion (reference vega/data.py:285-473, utils.py:271-298): distortion matrix and covariance
+    read from vector columns of a FITS data file.  The reference read the same file (same writer, same generator)
+    for tests/golden/expected_fits_ingest.npz."""
+    from conftest import fits_ingest_problem
+    from vega_amd import synthetic
+    prob = fits_ingest_problem(tmp_path)
+    exp = np.load(GOLDEN / 'expected_fits_ingest.npz')
+    item = prob.items['lyalya_lyalya']
+    assert item.data_size == int(exp['data_size'])
+    np.testing.assert_array_equal(item.distortion.toarray(),
+                                  synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt))
+    assert item.log_cov_det == pytest.approx(float(exp['log_cov_det']), rel=1e-12)
+    assert oc.chi2(prob) == pytest.approx(float(exp['fid/chi2']), rel=1e-10)
+    assert oc.log_lik(prob) == pytest.approx(float(exp['fid/log_lik']), rel=1e-10)
+    model = oc.compute_model(prob)['lyalya_lyalya']
+    assert np.abs(model - exp['fid/model']).max() <= 1e-12 * np.abs(model).max()
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-10)

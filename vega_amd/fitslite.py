@@ -194,7 +194,7 @@ def _header_bytes(cards):
 
 def write_tables(path, tables, overwrite=False):
     """Write a FITS file: empty primary HDU + one BINTABLE per entry of ``tables`` =
-    [(extname, [(column name, TFORM, array), ...]), ...].  TFORM: 'D' / 'nD' (float64), 'K' / 'nK' (int64),
+    [(extname, [(column name, TFORM, array), ...]) or (extname, columns, {header keyword: value}), ...].  TFORM: 'D' / 'nD' (float64), 'K' / 'nK' (int64),
     'L' (logical), 'nA' (strings).  Vector columns take arrays of shape [rows, n].  The layout is the one
     ``astropy.io.fits.BinTableHDU.from_columns`` produces for the same columns (reference vega/output.py)."""
     import os
@@ -202,7 +202,9 @@ def write_tables(path, tables, overwrite=False):
         raise OSError(f'File {path!r} already exists.')
     out = [_header_bytes([_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', 8),
                           _card('NAXIS', 0), _card('EXTEND', True)])]
-    for extname, columns in tables:
+    for entry in tables:
+        extname, columns = entry[0], entry[1]
+        extra = entry[2] if len(entry) > 2 else {}
         names, formats, arrays = [], [], []
         nrow = None
         for name, tform, arr in columns:
@@ -235,6 +237,8 @@ def write_tables(path, tables, overwrite=False):
         for i, (name, tform, _) in enumerate(columns, start=1):
             cards += [_card(f'TTYPE{i}', name), _card(f'TFORM{i}', tform)]
         cards.append(_card('EXTNAME', extname))
+        for key, value in extra.items():
+            cards.append(_card(key, value))
         data = rec.tobytes()
         out += [_header_bytes(cards), data + b'\x00' * (-len(data) % _BLOCK)]
     with builtins.open(path, 'wb') as f:

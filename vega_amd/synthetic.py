@@ -68,3 +68,26 @@ def walkers(theta_fid, names, n, varied=None, seed=SEED, scale=0.02, limits=None
             lo, hi = limits[name]
             theta[:, j] = np.clip(theta[:, j], lo, hi)
     return theta
+
+
+def write_data_file(path, source, with_distortion=True, with_covariance=True):
+    """A correlation data file in the layout the reference reads (vega/data.py:285-421): HDU 1 = RP, RT, Z, DA (+ the
+    synthetic distortion matrix `DM` and covariance `CO` of this module as vector columns) with the grid keywords,
+    HDU 2 = the model-grid coordinates DMRP, DMRT, DMZ.  ``source`` is a reference-format table list
+    (vega_amd.tables.read_tables) whose grids and data vector are reused."""
+    from . import fitslite
+    t1, t2 = source[0], source[1]
+    rp, rt = np.asarray(t1.data['RP'], dtype=float), np.asarray(t1.data['RT'], dtype=float)
+    cols = [('RP', 'D', rp), ('RT', 'D', rt), ('Z', 'D', t1.data['Z']), ('DA', 'D', t1.data['DA'])]
+    n = rp.size
+    if with_distortion:
+        cols.append(('DM', f'{n}D', distortion_matrix(np.asarray(t2.data['DMRP'], dtype=float),
+                                                     np.asarray(t2.data['DMRT'], dtype=float))))
+    if with_covariance:
+        cols.append(('CO', f'{n}D', covariance(rp, rt)))
+    hdr = {k: t1.header[k] for k in ('RPMIN', 'RPMAX', 'RTMAX', 'NP', 'NT')}
+    fitslite.write_tables(str(path), [
+        ('COR', cols, hdr),
+        ('DMATTRI', [('DMRP', 'D', t2.data['DMRP']), ('DMRT', 'D', t2.data['DMRT']), ('DMZ', 'D', t2.data['DMZ'])])],
+        overwrite=True)
+    return path
