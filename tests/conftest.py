@@ -62,3 +62,27 @@ def fits_ingest_problem(tmp_path):
     item = (GOLDEN / 'configs' / 'auto' / 'lyalya_lyalya.ini').read_text()
     (cfg / 'lyalya_lyalya.ini').write_text(re.sub(r'filename = .*', f'filename = {data_path}', item, count=1))
     return build_problem('configs/ingest/main.ini', search_dirs=[tmp_path, GOLDEN])
+
+
+def marginalization_problem(tmp_path, options):
+    """fits_ingest_problem with small-scale marginalisation options added to the [model] section."""
+    import re
+    from vega_amd import synthetic
+    from vega_amd.setup import build_problem
+    from vega_amd.tables import read_tables
+    source = read_tables(GOLDEN / 'inputs' / 'cf_lya-exp.npz')
+    data_path = synthetic.write_data_file(tmp_path / 'cf_lya-synth.fits', source)
+    cfg = tmp_path / 'configs' / 'marg'
+    cfg.mkdir(parents=True, exist_ok=True)
+    main = (GOLDEN / 'configs' / 'auto' / 'main.ini').read_text()
+    (cfg / 'main.ini').write_text(re.sub(r'ini files = .*', 'ini files = configs/marg/lyalya_lyalya.ini', main))
+    item = (GOLDEN / 'configs' / 'auto' / 'lyalya_lyalya.ini').read_text()
+    item = re.sub(r'filename = .*', f'filename = {data_path}', item, count=1).replace('[model]', '[model]\n' + options)
+    (cfg / 'lyalya_lyalya.ini').write_text(item)
+    return build_problem('configs/marg/main.ini', search_dirs=[tmp_path, GOLDEN])
+
+
+MARGINALIZATION_CASES = {
+    'rtmax': 'marginalize-below-rtmax = 16.0\nmarginalize-prior-sigma = 5.0',
+    'allrmin': 'marginalize-all-rmin-cuts = True\nmarginalize-match-data-bins = True',
+}

@@ -433,6 +433,32 @@ def dump_fits_ingest(VegaInterface):
         print('fits ingest: chi2', out['fid/chi2'], 'log_lik', out['fid/log_lik'], out['walker0/chi2'])
 
 
+def dump_marginalization(VegaInterface):
+    """Small-scale marginalisation (reference vega/correlation_item.py:175-268, vega/data.py:96-128, :762-828): the
+    covariance of the FITS data file of dump_fits_ingest updated with the distorted templates of the bins at
+    rt < 16 Mpc/h (and, second variant, of every bin the r-min cut removes, matched to data bins)."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    out = {}
+    for tag, opts in (('rtmax', 'marginalize-below-rtmax = 16.0\nmarginalize-prior-sigma = 5.0'),
+                      ('allrmin', 'marginalize-all-rmin-cuts = True\nmarginalize-match-data-bins = True')):
+        with tempfile.TemporaryDirectory() as tmp:
+            source = read_tables(REF / 'tests/data/cf_lya-exp.fits.gz')
+            data_path = synthetic.write_data_file(Path(tmp) / 'cf_lya-synth.fits', source)
+            main = _ref_main(tmp, ['lyalya_lyalya'], False)
+            item = Path(tmp) / 'lyalya_lyalya.ini'
+            text = re.sub(r'filename = .*', f'filename = {data_path}', item.read_text(), count=1)
+            item.write_text(text.replace('[model]', '[model]\n' + opts))
+            vega = VegaInterface(main)
+            data = vega.data['lyalya_lyalya']
+            out[f'{tag}/chi2'] = vega.chi2()
+            out[f'{tag}/log_lik'] = vega.log_lik()
+            out[f'{tag}/num_marg_modes'] = data.num_marg_modes
+            out[f'{tag}/cov_update_trace'] = np.trace(data.cov_marg_update)
+            print('marginalization', tag, out[f'{tag}/chi2'], out[f'{tag}/log_lik'], data.num_marg_modes)
+    np.savez_compressed(HERE / 'expected_marginalization.npz', **out)
+
+
 def dump_fast_metals(VegaInterface):
     """`fast_metals = True` (reference metals.py:53,144-169,280-282): metal x metal correlations are computed at
     the FIRST evaluation and reused for ever after.  Sequence dumped: chi2 at the fiducial point (fills the cache),
@@ -478,12 +504,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -502,3 +528,5 @@ if __name__ == '__main__':
         dump_mockbin(VI)
     if 'fits_ingest' in what:
         dump_fits_ingest(VI)
+    if 'marginalization' in what:
+        dump_marginalization(VI)

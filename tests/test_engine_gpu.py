@@ -292,3 +292,15 @@ def test_fits_ingestion_through_the_engine(tmp_path):
     pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
     assert vega.chi2(pars) == pytest.approx(float(exp['walker0/chi2']), rel=CHI2_RTOL)
     vega.close()
+
+
+def test_small_scale_marginalization_through_the_engine(tmp_path):
+    """The covariance updated with the small-scale marginalisation templates at set-up (reference
+    vega/data.py:96-128): chi2 and log-likelihood of the engine against the unmodified reference."""
+    from conftest import marginalization_problem, MARGINALIZATION_CASES
+    from vega_amd import VegaInterface
+    exp = np.load(GOLDEN / 'expected_marginalization.npz')
+    vega = VegaInterface(None, problem=marginalization_problem(tmp_path, MARGINALIZATION_CASES['rtmax']), max_batch=2)
+    assert vega.chi2() == pytest.approx(float(exp['rtmax/chi2']), rel=CHI2_RTOL)
+    assert vega.log_lik() == pytest.approx(float(exp['rtmax/log_lik']), rel=1e-8)
+    vega.close()

@@ -295,3 +295,16 @@ def test_fits_ingestion_matches_reference(tmp_path):
     assert np.abs(model - exp['fid/model']).max() <= 1e-12 * np.abs(model).max()
     pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
     assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-10)
+
+
+@pytest.mark.parametrize('tag', ['rtmax', 'allrmin'])
+def test_small_scale_marginalization_matches_reference(tmp_path, tag):
+    """Small-scale marginalisation (reference vega/correlation_item.py:175-268, vega/data.py:96-128, :762-828): the
+    set-up time covariance update, against chi2 / log-likelihood of the unmodified reference on the same file."""
+    from conftest import marginalization_problem, MARGINALIZATION_CASES
+    prob = marginalization_problem(tmp_path, MARGINALIZATION_CASES[tag])
+    exp = np.load(GOLDEN / 'expected_marginalization.npz')
+    item = prob.items['lyalya_lyalya']
+    assert np.trace(item.cov_marg_update) == pytest.approx(float(exp[f'{tag}/cov_update_trace']), rel=1e-10)
+    assert oc.chi2(prob) == pytest.approx(float(exp[f'{tag}/chi2']), rel=1e-8)
+    assert oc.log_lik(prob) == pytest.approx(float(exp[f'{tag}/log_lik']), rel=1e-8)

@@ -487,6 +487,64 @@ def _parse_broadband(section, item_name):
 
 
 # --------------------------------------------------------------------------------------
+# small-scale marginalisation: a set-up time covariance update
+# (reference vega/correlation_item.py:175-268, vega/data.py:96-109, :762-828)
+# --------------------------------------------------------------------------------------
+def marginalization_templates(model_grid, dist_grid, cuts, marg, match_data_bins=False):
+    """Undistorted templates [n_model, n_templates]: one indicator per marginalised model bin (or per nearest
+    distorted-grid bin with ``match_data_bins``)."""
+    if 'all-rmin' not in marg:
+        sets = []
+        if 'rtmax' in marg:
+            sets.append(np.nonzero(model_grid.rt_regular < marg['rtmax'])[0])
+        if 'rtmin' in marg:
+            sets.append(np.nonzero(model_grid.rt_regular > marg['rtmin'])[0])
+        if 'rpmax' in marg:
+            sets.append(np.nonzero(np.abs(model_grid.rp_regular) < marg['rpmax'])[0])
+        if 'rpmin' in marg:
+            sets.append(np.nonzero(np.abs(model_grid.rp_regular) > marg['rpmin'])[0])
+        common = sets[0]
+        for other in sets[1:]:
+            common = np.intersect1d(common, other)
+        if common.size == 0:
+            raise ValueError('No common indices found for small-scale marginalization templates.')
+    else:
+        # every model bin under a distorted-grid bin that the small-scale cuts remove
+        def get(key, default):
+            return float(cuts.get(key, default)) if cuts is not None else default
+        keep = (dist_grid.rp_regular > get('rp-min', 0.)) & (dist_grid.rt_regular > get('rt-min', 0.))
+        keep &= dist_grid.r_regular > get('r-min', 10.)
+        keep = keep.reshape(dist_grid.n_rp, dist_grid.n_rt)
+        cb = model_grid.n_rp // dist_grid.n_rp
+        mask_model = np.zeros((model_grid.n_rp, model_grid.n_rt))
+        for i in range(dist_grid.n_rp):
+            for j in range(dist_grid.n_rt):
+                mask_model[i * cb:i * cb + cb, j * cb:j * cb + cb] = keep[i, j]
+        common = np.nonzero(~mask_model.reshape(-1).astype(bool))[0]
+    n = model_grid.rt_regular.size
+    ones = np.ones(common.size)
+    if match_data_bins:
+        rp, rt = model_grid.rp[common], model_grid.rt[common]
+        nearest = ((dist_grid.rp[None, :] - rp[:, None])**2 + (dist_grid.rt[None, :] - rt[:, None])**2).argmin(axis=1)
+        unique = np.unique(nearest)
+        rows = np.searchsorted(unique, nearest)
+        return sparse.coo_array((ones, (rows, common)), shape=(unique.size, n)).tocsr().T
+    return sparse.coo_array((ones, (np.arange(common.size), common)), shape=(common.size, n)).tocsr().T
+
+
+def marginalization_cov_update(distortion, model_grid, dist_grid, cuts, marg, model_mask, prior_sigma=10.0,
+                               match_data_bins=False, factor=1e-8):
+    """A A^T of the distorted, masked, prior-scaled templates with degenerate modes removed by an SVD
+    (reference vega/data.py:762-828): the matrix added to the masked block of the covariance."""
+    templates = distortion.dot(marginalization_templates(model_grid, dist_grid, cuts, marg, match_data_bins))
+    t = (templates * prior_sigma)[model_mask, :].toarray()
+    u, sv, _ = np.linalg.svd(t, full_matrices=False)
+    w = sv > factor * sv[0]
+    u, sv = u[:, w], sv[w]
+    return np.dot(u * sv**2, u.T)
+
+
+# --------------------------------------------------------------------------------------
 # one correlation item
 # --------------------------------------------------------------------------------------
 def _build_item(cfg, consts, search_dirs):
@@ -496,12 +554,16 @@ def _build_item(cfg, consts, search_dirs):
     tr2 = Tracer(d.get('tracer2', tr1.name), d.get('tracer2-type', tr1.type))
     model_sec = cfg['model']
 
-    for key in ('marginalize-below-rtmax', 'marginalize-above-rtmin', 'marginalize-below-rpmax',
-                'marginalize-above-rpmin'):
+    # small-scale marginalisation (reference vega/correlation_item.py:53-72)
+    marg = {}
+    for key, short in (('marginalize-below-rtmax', 'rtmax'), ('marginalize-above-rtmin', 'rtmin'),
+                       ('marginalize-below-rpmax', 'rpmax'), ('marginalize-above-rpmin', 'rpmin')):
         if model_sec.getfloat(key, 0) > 0:
-            raise NotImplementedError('small-scale marginalisation is outside the hot path')
+            marg[short] = model_sec.getfloat(key, 0)
     if model_sec.getboolean('marginalize-all-rmin-cuts', False):
-        raise NotImplementedError('small-scale marginalisation is outside the hot path')
+        marg['all-rmin'] = True
+    if marg and model_sec.getboolean('fit-marginalized-scales', False):
+        raise NotImplementedError('fit-marginalized-scales is not supported')
     if model_sec.getboolean('new_metals', False):
         raise NotImplementedError('new_metals (metal-matrix construction) is outside the hot path')
     if 'filename' not in d or not d.getboolean('has_datafile', True):
@@ -564,6 +626,18 @@ def _build_item(cfg, consts, search_dirs):
     cuts = cfg['cuts'] if 'cuts' in cfg else None
     data_mask = data_grid.scale_cut_mask(cuts)
     model_mask = dist_grid.scale_cut_mask(cuts)
+
+    if marg:
+        if distortion is None:
+            raise ValueError('Distortion matrix required for marginalization')
+        if cov is None:
+            cov = np.eye(data_vec.size)
+        cov = np.array(cov, dtype=float)
+        update = marginalization_cov_update(
+            distortion, model_grid, dist_grid, cuts, marg, model_mask,
+            prior_sigma=model_sec.getfloat('marginalize-prior-sigma', 10.0),
+            match_data_bins=model_sec.getboolean('marginalize-match-data-bins', False))
+        cov[np.ix_(data_mask, data_mask)] += update
 
     # the reference injects the data bin sizes into the [model] / [metals] sections
     # (reference vega/model.py:38-39, vega/metals.py:119-123)
@@ -669,11 +743,13 @@ def _build_item(cfg, consts, search_dirs):
                          [*search_dirs, *[Path(d) / 'inputs' for d in search_dirs]])
         inst_sys_table = np.loadtxt(path, delimiter=',', skiprows=1)
 
-    return CorrItem(name=name, tracer1=tr1, tracer2=tr2, core=core, model_grid=model_grid,
+    item = CorrItem(name=name, tracer1=tr1, tracer2=tr2, core=core, model_grid=model_grid,
                     dist_grid=dist_grid, data_grid=data_grid, metals=metals, metal_opts=metal_opts,
                     broadband=broadband, distortion=distortion, data_vec=data_vec,
                     data_mask=data_mask, model_mask=model_mask, cov=cov,
                     rp_binsize=data_grid.rp_binsize, inst_sys_table=inst_sys_table)
+    item.cov_marg_update = update if marg else None        # also added to a global covariance (build_problem)
+    return item
 
 
 # --------------------------------------------------------------------------------------
@@ -816,6 +892,14 @@ def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
         cov_scale = control.getfloat('cov_scale', None) if 'control' in main else None
         if cov_scale is not None:
             global_cov = global_cov * cov_scale
+        # marginalisation templates update the items' diagonal blocks (reference vega_interface.py:918-938)
+        j = 0
+        for item in items.values():
+            n = item.data_vec.size
+            if getattr(item, 'cov_marg_update', None) is not None:
+                block = global_cov[j:j + n, j:j + n]
+                block[np.ix_(item.data_mask, item.data_mask)] += item.cov_marg_update
+            j += n
 
     return Problem(k=k, pk_full=pk_full, pk_smooth=pk_smooth, z_fid=z_fid, z_eff=z_eff,
                    omega_m=om, omega_de=ode, growth_rate=growth_rate, scale=scale,
