@@ -748,6 +748,13 @@ def chi2(prob, params=None, data_override=None):
         model = compute_model(prob, params)
     except OracleModelError:
         return 1e100
+    # marginalize-in-fit: best-fit template coefficients from the residual, templates added to the model
+    # (reference vega_interface.py:282-292, :546-579; the coefficients ignore a global covariance)
+    for name, item in prob.items.items():
+        if getattr(item, 'marginalize_in_fit', False) and item.marg_diff2coeff is not None:
+            data = item.masked_data_vec if (data_override is None or prob.global_cov is not None) else data_override[name]
+            coeff = item.marg_diff2coeff.dot(data - model[name][item.model_mask])
+            model[name] = model[name] + item.marg_templates.dot(coeff)
     if prob.global_cov is not None:
         g = prob.global_masks()
         data = np.concatenate([it.masked_data_vec for it in prob.items.values()]) \

@@ -64,8 +64,9 @@ def fits_ingest_problem(tmp_path):
     return build_problem('configs/ingest/main.ini', search_dirs=[tmp_path, GOLDEN])
 
 
-def marginalization_problem(tmp_path, options):
-    """fits_ingest_problem with small-scale marginalisation options added to the [model] section."""
+def marginalization_problem(tmp_path, options, in_fit=False):
+    """fits_ingest_problem with small-scale marginalisation options added to the [model] section (and the templates
+    fitted on the fly instead of folded into the covariance when ``in_fit``)."""
     import re
     from vega_amd import synthetic
     from vega_amd.setup import build_problem
@@ -75,6 +76,8 @@ def marginalization_problem(tmp_path, options):
     cfg = tmp_path / 'configs' / 'marg'
     cfg.mkdir(parents=True, exist_ok=True)
     main = (GOLDEN / 'configs' / 'auto' / 'main.ini').read_text()
+    if in_fit:
+        main = main.replace('[control]', '[control]\nmarginalize-in-fit = True')
     (cfg / 'main.ini').write_text(re.sub(r'ini files = .*', 'ini files = configs/marg/lyalya_lyalya.ini', main))
     item = (GOLDEN / 'configs' / 'auto' / 'lyalya_lyalya.ini').read_text()
     item = re.sub(r'filename = .*', f'filename = {data_path}', item, count=1).replace('[model]', '[model]\n' + options)

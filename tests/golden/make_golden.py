@@ -456,6 +456,18 @@ def dump_marginalization(VegaInterface):
             out[f'{tag}/num_marg_modes'] = data.num_marg_modes
             out[f'{tag}/cov_update_trace'] = np.trace(data.cov_marg_update)
             print('marginalization', tag, out[f'{tag}/chi2'], out[f'{tag}/log_lik'], data.num_marg_modes)
+            # the same templates fitted on the fly instead (control: marginalize-in-fit)
+            mp = Path(main)
+            mp.write_text(mp.read_text().replace('[control]', '[control]\nmarginalize-in-fit = True'))
+            vega = VegaInterface(main)
+            out[f'{tag}/infit/chi2'] = vega.chi2()
+            out[f'{tag}/infit/log_lik'] = vega.log_lik()
+            names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 4)
+            _reset_caches(vega)
+            out[f'{tag}/infit/param_names'] = np.array(names)
+            out[f'{tag}/infit/theta'] = np.array([[walkers[0][n] for n in names]])
+            out[f'{tag}/infit/walker0/chi2'] = vega.chi2(walkers[0])
+            print('  in fit:', out[f'{tag}/infit/chi2'], out[f'{tag}/infit/log_lik'], out[f'{tag}/infit/walker0/chi2'])
     np.savez_compressed(HERE / 'expected_marginalization.npz', **out)
 
 

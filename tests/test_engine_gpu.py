@@ -304,3 +304,18 @@ def test_small_scale_marginalization_through_the_engine(tmp_path):
     assert vega.chi2() == pytest.approx(float(exp['rtmax/chi2']), rel=CHI2_RTOL)
     assert vega.log_lik() == pytest.approx(float(exp['rtmax/log_lik']), rel=1e-8)
     vega.close()
+
+
+def test_marginalize_in_fit_through_the_engine(tmp_path):
+    """`marginalize-in-fit`: the engine evaluates diff^T (P^T C^-1 P) diff with the static projector of the template
+    fit; against the unmodified reference, which fits and adds the templates at every call."""
+    from conftest import marginalization_problem, MARGINALIZATION_CASES
+    from vega_amd import VegaInterface
+    exp = np.load(GOLDEN / 'expected_marginalization.npz')
+    prob = marginalization_problem(tmp_path, MARGINALIZATION_CASES['rtmax'], in_fit=True)
+    vega = VegaInterface(None, problem=prob, max_batch=2)
+    assert vega.chi2() == pytest.approx(float(exp['rtmax/infit/chi2']), rel=CHI2_RTOL)
+    assert vega.log_lik() == pytest.approx(float(exp['rtmax/infit/log_lik']), rel=1e-8)
+    pars = {str(n): float(v) for n, v in zip(exp['rtmax/infit/param_names'], exp['rtmax/infit/theta'][0])}
+    assert vega.chi2(pars) == pytest.approx(float(exp['rtmax/infit/walker0/chi2']), rel=CHI2_RTOL)
+    vega.close()

@@ -308,3 +308,21 @@ def test_small_scale_marginalization_matches_reference(tmp_path, tag):
     assert np.trace(item.cov_marg_update) == pytest.approx(float(exp[f'{tag}/cov_update_trace']), rel=1e-10)
     assert oc.chi2(prob) == pytest.approx(float(exp[f'{tag}/chi2']), rel=1e-8)
     assert oc.log_lik(prob) == pytest.approx(float(exp[f'{tag}/log_lik']), rel=1e-8)
+
+
+@pytest.mark.parametrize('tag', ['rtmax', 'allrmin'])
+def test_marginalize_in_fit_matches_reference(tmp_path, tag):
+    """`marginalize-in-fit` (reference vega_interface.py:282-292, :546-579): the oracle fits the template coefficients
+    from the residual and adds the templates to the model, as the reference does; the product path uses the
+    equivalent static matrix P^T C^-1 P (CorrItem.chi2_matrix) - both against the reference's values."""
+    from conftest import marginalization_problem, MARGINALIZATION_CASES
+    prob = marginalization_problem(tmp_path, MARGINALIZATION_CASES[tag], in_fit=True)
+    exp = np.load(GOLDEN / 'expected_marginalization.npz')
+    assert oc.chi2(prob) == pytest.approx(float(exp[f'{tag}/infit/chi2']), rel=1e-9)
+    assert oc.log_lik(prob) == pytest.approx(float(exp[f'{tag}/infit/log_lik']), rel=1e-9)
+    pars = {str(n): float(v) for n, v in zip(exp[f'{tag}/infit/param_names'], exp[f'{tag}/infit/theta'][0])}
+    assert oc.chi2(prob, pars) == pytest.approx(float(exp[f'{tag}/infit/walker0/chi2']), rel=1e-9)
+    # the static form the engine is given
+    item = prob.items['lyalya_lyalya']
+    diff = item.masked_data_vec - oc.compute_model(prob, pars)['lyalya_lyalya'][item.model_mask]
+    assert diff.dot(item.chi2_matrix.dot(diff)) == pytest.approx(float(exp[f'{tag}/infit/walker0/chi2']), rel=1e-9)

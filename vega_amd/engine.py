@@ -634,14 +634,14 @@ class Engine:
             self._check(lib.vmx_item_set_mask(self._h, iid, _ip(idx), idx.size))
             self._check(lib.vmx_item_set_data(self._h, iid, _dp(_f64(item.masked_data_vec)), idx.size))
             if item.cov is not None and prob.global_cov is None:
-                cinv = _f64(item.inv_masked_cov)
+                cinv = _f64(item.chi2_matrix)      # C^-1, or P^T C^-1 P with marginalize-in-fit (setup.py)
                 self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_INVCOV, 0, cinv.shape[0], cinv.shape[1],
                                                     _dp(cinv)))
             self.model_slices[name] = slice(off, off + item.dist_grid.size)
             off += item.dist_grid.size
 
         if prob.global_cov is not None:
-            g = _f64(prob.global_masks()['invcov'])
+            g = _f64(prob.global_masks()['chi2_matrix'])
             self._check(lib.vmx_set_global_invcov(self._h, _dp(g), g.shape[0]))
         for pname, (mean, sigma) in prob.priors.items():
             self._check(lib.vmx_add_prior(self._h, low.need(pname), float(mean), float(sigma)))

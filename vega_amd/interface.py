@@ -139,11 +139,13 @@ class VegaInterface:
                     raise ValueError(f'monte_carlo is set but data[{name!r}].masked_mc_mock is None')
                 self.engine.set_data(name, view.masked_mc_mock)
                 if view.scaled_inv_masked_cov is not None and not self._use_global_cov:
+                    if self.problem.items[name].marginalize_in_fit:
+                        raise NotImplementedError('a rescaled covariance with marginalize-in-fit is not supported')
                     self.engine.set_invcov(name, view.scaled_inv_masked_cov)
             else:
                 self.engine.set_data(name, view.masked_data_vec)
                 if self.problem.items[name].cov is not None and not self._use_global_cov:
-                    self.engine.set_invcov(name, view.inv_masked_cov)
+                    self.engine.set_invcov(name, self.problem.items[name].chi2_matrix)
         self._mc_active = self.monte_carlo
 
     # ------------------------------------------------------------------ reference surface

@@ -103,7 +103,7 @@ class MonteCarlo:
         for name, pool in mocks.items():
             eng.set_mock_pool(name, pool)
             if scale is not None and vega.problem.items[name].cov is not None and not vega._use_global_cov:
-                eng.set_invcov(name, vega.problem.items[name].inv_masked_cov / scale)
+                eng.set_invcov(name, vega.problem.items[name].chi2_matrix / scale)
         fitter = self.minimizer(sample_params)
         self._mock_rows = np.arange(num_mocks, dtype=np.int32)
         try:
@@ -114,7 +114,7 @@ class MonteCarlo:
             if scale is not None:
                 for name, item in vega.problem.items.items():
                     if item.cov is not None and not vega._use_global_cov:
-                        eng.set_invcov(name, item.inv_masked_cov)
+                        eng.set_invcov(name, item.chi2_matrix)
         self.fit_result = res
         self.mc_bestfits = {n: np.stack([res.values[:, j], res.errors[:, j]], axis=1)
                             for j, n in enumerate(res.names)}

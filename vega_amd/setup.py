@@ -232,6 +232,29 @@ class CorrItem:
                 self._inv_masked_cov = np.linalg.inv(masked)
         return self._inv_masked_cov
 
+    # marginalize-in-fit (reference vega_interface.py:282-292, :546-579): the best-fit template coefficients are a
+    # linear map of the residual, coeff = M diff, and the templates T are added to the model before chi2, so
+    # diff' = (I - T_masked M) diff =: P diff with a static projector P
+    marg_templates = None        # distorted templates [n_dist, n_templates] (sparse)
+    marg_diff2coeff = None       # M [n_templates, n_masked]
+    marginalize_in_fit = False
+
+    def marg_projector(self):
+        tm = self.marg_templates[self.model_mask, :]
+        tm = tm.toarray() if hasattr(tm, 'toarray') else np.asarray(tm)
+        return np.eye(self.data_size) - tm.dot(self.marg_diff2coeff)
+
+    @property
+    def chi2_matrix(self):
+        """The matrix Q of chi2 = diff^T Q diff: the inverse masked covariance, or P^T C^-1 P when the
+        marginalisation templates are fitted on the fly."""
+        if not (self.marginalize_in_fit and self.marg_diff2coeff is not None):
+            return self.inv_masked_cov
+        if getattr(self, '_chi2_matrix', None) is None:
+            P = self.marg_projector()
+            self._chi2_matrix = P.T.dot(self.inv_masked_cov).dot(P)
+        return self._chi2_matrix
+
     @property
     def log_cov_det(self):
         if self._log_cov_det is None:
@@ -246,6 +269,7 @@ class CorrItem:
         self.cov = None if cov is None else np.asarray(cov, dtype=float)
         self._inv_masked_cov = None
         self._log_cov_det = None
+        self._chi2_matrix = None
 
 
 @dataclass
@@ -294,8 +318,20 @@ class Problem:
             data_mask = np.concatenate([it.data_mask for it in self.items.values()])
             model_mask = np.concatenate([it.model_mask for it in self.items.values()])
             masked = self.global_cov[:, data_mask][data_mask, :]
-            self._global = dict(data_mask=data_mask, model_mask=model_mask,
-                                invcov=np.linalg.inv(masked),
+            invcov = np.linalg.inv(masked)
+            chi2_matrix = invcov
+            if any(it.marginalize_in_fit and it.marg_diff2coeff is not None for it in self.items.values()):
+                # block-diagonal projector of the items that fit their templates (reference :282-292: the
+                # coefficients ignore the global covariance)
+                P = np.eye(masked.shape[0])
+                j = 0
+                for it in self.items.values():
+                    n = it.data_size
+                    if it.marginalize_in_fit and it.marg_diff2coeff is not None:
+                        P[j:j + n, j:j + n] = it.marg_projector()
+                    j += n
+                chi2_matrix = P.T.dot(invcov).dot(P)
+            self._global = dict(data_mask=data_mask, model_mask=model_mask, invcov=invcov, chi2_matrix=chi2_matrix,
                                 log_det=float(np.linalg.slogdet(masked)[1]))
         return self._global
 
@@ -547,7 +583,7 @@ def marginalization_cov_update(distortion, model_grid, dist_grid, cuts, marg, mo
 # --------------------------------------------------------------------------------------
 # one correlation item
 # --------------------------------------------------------------------------------------
-def _build_item(cfg, consts, search_dirs):
+def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     d = cfg['data']
     name = d.get('name')
     tr1 = Tracer(d.get('tracer1'), d.get('tracer1-type'))
@@ -633,11 +669,19 @@ def _build_item(cfg, consts, search_dirs):
         if cov is None:
             cov = np.eye(data_vec.size)
         cov = np.array(cov, dtype=float)
-        update = marginalization_cov_update(
-            distortion, model_grid, dist_grid, cuts, marg, model_mask,
-            prior_sigma=model_sec.getfloat('marginalize-prior-sigma', 10.0),
-            match_data_bins=model_sec.getboolean('marginalize-match-data-bins', False))
-        cov[np.ix_(data_mask, data_mask)] += update
+        prior_sigma = model_sec.getfloat('marginalize-prior-sigma', 10.0)
+        match_bins = model_sec.getboolean('marginalize-match-data-bins', False)
+        marg_templates = distortion.dot(marginalization_templates(model_grid, dist_grid, cuts, marg, match_bins))
+        # coefficient solve of the templates against the covariance before any update (reference data.py:101-128)
+        inv = np.linalg.inv(cov[:, data_mask][data_mask, :])
+        tm = marg_templates[model_mask, :]
+        G = tm.T.dot(inv)
+        A = tm.T.dot(G.T).T + np.diag(np.full(marg_templates.shape[1], prior_sigma**-2))
+        marg_diff2coeff = np.linalg.inv(A).dot(G)
+        update = marginalization_cov_update(distortion, model_grid, dist_grid, cuts, marg, model_mask,
+                                            prior_sigma=prior_sigma, match_data_bins=match_bins)
+        if not marginalize_in_fit:
+            cov[np.ix_(data_mask, data_mask)] += update
 
     # the reference injects the data bin sizes into the [model] / [metals] sections
     # (reference vega/model.py:38-39, vega/metals.py:119-123)
@@ -748,7 +792,11 @@ def _build_item(cfg, consts, search_dirs):
                     broadband=broadband, distortion=distortion, data_vec=data_vec,
                     data_mask=data_mask, model_mask=model_mask, cov=cov,
                     rp_binsize=data_grid.rp_binsize, inst_sys_table=inst_sys_table)
-    item.cov_marg_update = update if marg else None        # also added to a global covariance (build_problem)
+    # also added to a global covariance (build_problem)
+    item.cov_marg_update = update if (marg and not marginalize_in_fit) else None
+    if marg:
+        item.marg_templates, item.marg_diff2coeff = marg_templates, marg_diff2coeff
+        item.marginalize_in_fit = bool(marginalize_in_fit)
     return item
 
 
@@ -816,11 +864,11 @@ def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
     consts = (z_fid, z_eff, om, ode)
 
     control = main['control'] if 'control' in main else {}
+    marginalize_in_fit = False
     if 'control' in main:
         if main['control'].getboolean('model_pk', False):
             raise NotImplementedError('model_pk is not supported')
-        if main['control'].getboolean('marginalize-in-fit', False):
-            raise NotImplementedError('marginalize-in-fit is not supported')
+        marginalize_in_fit = main['control'].getboolean('marginalize-in-fit', False)
 
     items = {}
     cfgs = {}
@@ -828,7 +876,7 @@ def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
         cfg = _parser(find_file(os.path.expandvars(path), dirs))
         cfgs[cfg['data'].get('name')] = cfg
     for name, cfg in cfgs.items():
-        items[name] = _build_item(cfg, consts, dirs)
+        items[name] = _build_item(cfg, consts, dirs, marginalize_in_fit)
 
     # parameters: component configs first, main config wins (reference :705-736)
     params = {}
