@@ -178,6 +178,12 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
                      const double* mu, const double* z, const double* rel_z_evol,
                      const double* xi_growth);
 
+/* `new-bias-evolution` (correlation_func.py:238-299): in a cross-correlation the two tracers evolve with their own
+ * redshifts z -/+ rp / (2 D_H(z)).  rel_z_1 / rel_z_2 [n] = (1 + z_tracer) / (1 + z_eff) per bin for the pipeline's
+ * first / second tracer as given to vmx_add_pipeline; replaces the common rel_z_evol of that call. */
+int vmx_pipeline_set_tracer_evolution(vmx_engine* e, int32_t pipeline, const double* rel_z_1,
+                                      const double* rel_z_2, int32_t n);
+
 /* Odd-multipole terms of a cross-correlation component (correlation_func.py:150-155, pktoxi.py:321-382):
  * coef [4][n_coef] = cubic B-spline coefficients (knots x0 + h i in ln r) of the Hamilton-FFTLog transforms of the
  * component's isotropic linear spectrum, in the order rel ell=1, rel ell=3, asy ell=0, asy ell=2;

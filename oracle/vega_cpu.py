@@ -437,13 +437,15 @@ def rescale_coords(r, mu, ap, at, delta_rp=0.):
     return rr, rmu
 
 
-def _tracer_evol(pipe, params, name, z_eff):
-    """reference correlation_func.py:301-370"""
+def _tracer_evol(pipe, params, name, z_eff, rel_z_evol=None):
+    """reference correlation_func.py:301-370; ``rel_z_evol``: the tracer's own redshift grid with new-bias-evolution
+    (:276-299)"""
     if pipe.xi.evol_model.get(name, 'standard') == 'croom':
         assert name == 'QSO'
         p0, p1 = params['croom_par0'], params['croom_par1']
         return (p0 + p1 * (1. + pipe.z)**2) / (p0 + p1 * (1 + z_eff)**2)
-    return pipe.rel_z_evol**params[f'alpha_{name}']
+    rel = pipe.rel_z_evol if rel_z_evol is None else rel_z_evol
+    return rel**params[f'alpha_{name}']
 
 
 def qso_radiation(pipe, params, rescaled_r, rescaled_mu):
@@ -520,8 +522,8 @@ def correlation_function(prob, pipe, grid, pk, pk_lin, params, taps=None):
     rr, rmu = rescale_coords(pipe.r, pipe.mu, ap, at, delta_rp)
     xi = pk_to_xi(pipe, grid, rr, rmu, pk, taps)
 
-    evol = _tracer_evol(pipe, params, pipe.tracer1.name, prob.z_eff)
-    evol = evol * _tracer_evol(pipe, params, pipe.tracer2.name, prob.z_eff)
+    evol = _tracer_evol(pipe, params, pipe.tracer1.name, prob.z_eff, getattr(pipe, 'rel_z_evol_1', None))
+    evol = evol * _tracer_evol(pipe, params, pipe.tracer2.name, prob.z_eff, getattr(pipe, 'rel_z_evol_2', None))
     xi = xi * evol
     xi = xi * pipe.xi_growth
 

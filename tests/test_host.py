@@ -204,3 +204,36 @@ def test_monte_carlo_tables_round_trip_in_the_reference_layout(tmp_path):
     np.testing.assert_array_equal(hdul[3].data['lyalya_qso'], analysis.mc_mocks['lyalya_qso'])
     with pytest.raises(OSError):
         output.write_monte_carlo(analysis, tmp_path / 'monte_carlo', cpu_id=3)
+
+
+def test_file_cosmology_and_new_bias_evolution(tmp_path):
+    """A data file that carries a picca cosmology (OMEGAM ... header keywords, reference vega/data.py:360-366) is
+    accepted; with `new-bias-evolution = True` the cross-correlation pipelines get one redshift grid per tracer
+    (reference correlation_func.py:238-274), the auto-correlation keeps the mean redshift."""
+    import re
+    from vega_amd import synthetic
+    from vega_amd.setup import build_problem, picca_dist_hubble
+    from vega_amd.tables import read_tables
+    cfg = tmp_path / 'configs' / 'cosmo'
+    cfg.mkdir(parents=True)
+    main = (GOLDEN / 'configs' / 'joint' / 'main.ini').read_text()
+    main = re.sub(r'ini files = .*', 'ini files = configs/cosmo/lyalya_lyalya.ini configs/cosmo/lyalya_qso.ini', main)
+    (cfg / 'main.ini').write_text(main)
+    header = {'OMEGAM': 0.3147, 'OMEGAR': 7.9e-5}
+    for name, bundle in (('lyalya_lyalya', 'cf_lya-exp.npz'), ('lyalya_qso', 'xcf_lya-exp.npz')):
+        text = (GOLDEN / 'configs' / 'joint' / f'{name}.ini').read_text()
+        path = synthetic.write_data_file(tmp_path / f'{name}.fits', read_tables(GOLDEN / 'inputs' / bundle),
+                                         with_distortion=False, with_covariance=False, extra_header=header)
+        text = re.sub(r'filename = .*', f'filename = {path}', text, count=1)
+        (cfg / f'{name}.ini').write_text(text.replace('[model]', '[model]\nnew-bias-evolution = True'))
+    prob = build_problem('configs/cosmo/main.ini', search_dirs=[tmp_path, GOLDEN])
+    auto, cross = prob.items['lyalya_lyalya'].core, prob.items['lyalya_qso'].core
+    assert auto.rel_z_evol_1 is None and cross.rel_z_evol_1 is not None
+    cosmo = {'Omega_m': 0.3147, 'Omega_k': 0., 'Omega_r': 7.9e-5, 'wl': -1.}
+    shift = cross.r * cross.mu / (2 * picca_dist_hubble(cross.z, cosmo))
+    forest = (1 + cross.z + shift) / (1 + prob.z_eff)
+    quasar = (1 + cross.z - shift) / (1 + prob.z_eff)
+    assert cross.tracer1.type == 'continuous' and cross.tracer2.type == 'discrete'
+    np.testing.assert_allclose(cross.rel_z_evol_1, forest, rtol=1e-15)
+    np.testing.assert_allclose(cross.rel_z_evol_2, quasar, rtol=1e-15)
+    assert np.abs(shift).max() > 0.05       # the split is not a rounding effect

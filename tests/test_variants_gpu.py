@@ -318,3 +318,24 @@ def test_single_multipole():
         prob = _fresh('auto')
         prob.items['lyalya_lyalya'].core.xi.single_multipole = ell
         _check(prob, n_walkers=1)
+
+
+def test_new_bias_evolution_with_a_file_cosmology():
+    """`new-bias-evolution` (reference correlation_func.py:238-299): the QSO and the forest of a cross-correlation
+    evolve with z -/+ rp / (2 D_H(z)), D_H from the picca cosmology of the data file's header (restated, picca being
+    absent: parity with the reference is unpinned for this option; engine against oracle here)."""
+    from vega_amd.setup import picca_dist_hubble
+    prob = _fresh('joint')
+    cosmo = {'Omega_m': 0.315, 'Omega_k': 0., 'Omega_r': 7.9e-5, 'wl': -1.}
+    # D_H of a flat LCDM cosmology at z = 2.3, Mpc/h
+    e_z = np.sqrt(0.315 * 3.3**3 + 7.9e-5 * 3.3**4 + (1 - 0.315 - 7.9e-5))
+    assert picca_dist_hubble(np.array([2.3]), cosmo)[0] == pytest.approx(2997.92458 / e_z, rel=1e-6)
+    cross = prob.items['lyalya_qso'].core
+    cross.xi.new_bias_evol = True
+    z, z_eff = cross.z, prob.z_eff
+    shift = cross.r * cross.mu / (2 * picca_dist_hubble(z, cosmo))
+    rel_q, rel_f = (1 + z - shift) / (1 + z_eff), (1 + z + shift) / (1 + z_eff)
+    assert cross.tracer2.type == 'discrete'
+    cross.rel_z_evol_1, cross.rel_z_evol_2 = rel_f, rel_q
+    prob.params['alpha_QSO'] = 1.44      # different exponents make the split visible
+    _check(prob, n_walkers=2)

@@ -137,8 +137,8 @@ struct vmx_engine {
     double x0[VMX_MAX_ELL] = {0}, h[VMX_MAX_ELL] = {0};
 
     std::vector<PipeDev> pipes;
-    std::vector<double> h_r, h_mu_c, h_z, h_relz, h_lnrelz, h_growth;
-    DevBuf<double> cr, cmu, cz, crelz, clnrelz, cgrowth;
+    std::vector<double> h_r, h_mu_c, h_z, h_relz, h_lnrelz, h_lnrelz2, h_growth;
+    DevBuf<double> cr, cmu, cz, crelz, clnrelz, clnrelz2, cgrowth;
     DevBuf<PipeDev> d_pipes;
     std::vector<PkGroup> pk_groups;
     DevBuf<PkGroup> d_pk_groups;
@@ -532,18 +532,38 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     // tracer last) so that the specialised mu loops see one canonical order.
     if (!p.d.same_tracer && ((!p.d.tracer[0].is_lya && p.d.tracer[1].is_lya) ||
                              (p.d.tracer[0].is_lya == p.d.tracer[1].is_lya && p.d.tracer[0].discrete &&
-                              !p.d.tracer[1].discrete)))
+                              !p.d.tracer[1].discrete))) {
         std::swap(p.d.tracer[0], p.d.tracer[1]);
+        p.tracers_swapped = 1;
+    }
     p.n = n;
     p.coord_off = (int64_t)e->h_r.size();
     e->h_r.insert(e->h_r.end(), r, r + n);
     e->h_mu_c.insert(e->h_mu_c.end(), mu, mu + n);
     e->h_z.insert(e->h_z.end(), z, z + n);
     e->h_relz.insert(e->h_relz.end(), rel_z_evol, rel_z_evol + n);
-    for (int i = 0; i < n; ++i) e->h_lnrelz.push_back(std::log(rel_z_evol[i]));
+    for (int i = 0; i < n; ++i) { e->h_lnrelz.push_back(std::log(rel_z_evol[i])); e->h_lnrelz2.push_back(std::log(rel_z_evol[i])); }
     e->h_growth.insert(e->h_growth.end(), xi_growth, xi_growth + n);
     e->pipes.push_back(p);
     return (int)e->pipes.size() - 1;
+}
+
+int vmx_pipeline_set_tracer_evolution(vmx_engine* e, int32_t pipeline, const double* rel_z_1, const double* rel_z_2, int32_t n)
+{
+    REQUIRE(e && !e->finalized && rel_z_1 && rel_z_2, "vmx_pipeline_set_tracer_evolution");
+    REQUIRE(pipeline >= 0 && pipeline < (int)e->pipes.size(), "pipeline id");
+    PipeDev& p = e->pipes[pipeline];
+    REQUIRE(n == p.n, "tracer evolution size");
+    REQUIRE(p.d.tracer[0].evol_kind == VMX_EVOL_STD && p.d.tracer[1].evol_kind == VMX_EVOL_STD,
+            "Croom model is not supported with new bias evol");
+    // vmx_add_pipeline may have swapped the tracers into its canonical order
+    const bool swapped = p.tracers_swapped != 0;
+    for (int i = 0; i < n; ++i) {
+        e->h_lnrelz[(size_t)p.coord_off + i] = std::log((swapped ? rel_z_2 : rel_z_1)[i]);
+        e->h_lnrelz2[(size_t)p.coord_off + i] = std::log((swapped ? rel_z_1 : rel_z_2)[i]);
+    }
+    p.split_evol = 1;
+    return 0;
 }
 
 int vmx_pipeline_set_odd_terms(vmx_engine* e, int32_t pipeline, const double* coef, int32_t n_coef, double x0,
@@ -921,7 +941,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     // coordinates and pipelines
     if (e->cr.upload(e->h_r.data(), e->h_r.size()) || e->cmu.upload(e->h_mu_c.data(), e->h_mu_c.size()) ||
         e->cz.upload(e->h_z.data(), e->h_z.size()) || e->crelz.upload(e->h_relz.data(), e->h_relz.size()) ||
-        e->clnrelz.upload(e->h_lnrelz.data(), e->h_lnrelz.size()) ||
+        e->clnrelz.upload(e->h_lnrelz.data(), e->h_lnrelz.size()) || e->clnrelz2.upload(e->h_lnrelz2.data(), e->h_lnrelz2.size()) ||
         e->cgrowth.upload(e->h_growth.data(), e->h_growth.size())) return -2;
     int64_t xi_off = 0;
     for (auto& p : e->pipes) { p.n_pad = vmx_pad(p.n); p.xi_off = xi_off; xi_off += (int64_t)Bm * p.n_pad; }
@@ -1058,7 +1078,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
     }
     D.n_pipe = n_pipe; D.pipes = e->d_pipes.p;
-    D.cr = e->cr.p; D.cmu = e->cmu.p; D.cz = e->cz.p; D.crelz = e->crelz.p; D.clnrelz = e->clnrelz.p; D.cgrowth = e->cgrowth.p;
+    D.cr = e->cr.p; D.cmu = e->cmu.p; D.cz = e->cz.p; D.crelz = e->crelz.p; D.clnrelz = e->clnrelz.p; D.clnrelz2 = e->clnrelz2.p; D.cgrowth = e->cgrowth.p;
     D.n_items = (int)e->items.size(); D.items = e->d_items.p;
     D.metals = e->d_metals.p; D.n_metals_total = (int)e->metals.size();
     D.bb_basis = e->bb_basis.p;

@@ -41,6 +41,8 @@ struct PipeDev {
     int32_t n_pad;        // per-walker stride of the xi buffer (zero tail)
     int64_t coord_off;    // offset into the coordinate arrays
     int64_t xi_off;       // offset into the xi buffer
+    int32_t split_evol;   // new-bias-evolution: clnrelz holds tracer 1's ln(rel z), clnrelz2 tracer 2's
+    int32_t tracers_swapped;   // vmx_add_pipeline put the caller's second tracer first (canonical order)
     // odd-multipole (relativistic / asymmetry) terms: static spline coefficients + amplitude slots
     int32_t odd_rel, odd_asy, odd_ncoef;
     int32_t odd_slot[5];
@@ -110,6 +112,7 @@ struct EngineDev {
     int32_t n_pipe;
     const PipeDev* pipes;
     const double* cr; const double* cmu; const double* cz; const double* crelz; const double* clnrelz; const double* cgrowth;
+    const double* clnrelz2;     // second tracer's ln(rel z) (same layout; equals clnrelz unless split_evol)
     // items
     int32_t n_items;
     const ItemDev* items;
@@ -1374,7 +1377,8 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
     double ev;
     if (d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD) {
         // relz^a1 * relz^a2 = exp((a1 + a2) ln relz), ln relz tabulated at upload
-        ev = vmx_exp((sc[S_EV1A] + sc[S_EV2A]) * D.clnrelz[c]);
+        ev = P.split_evol ? vmx_exp(fma(sc[S_EV1A], D.clnrelz[c], sc[S_EV2A] * D.clnrelz2[c]))
+                          : vmx_exp((sc[S_EV1A] + sc[S_EV2A]) * D.clnrelz[c]);
     } else {
         ev = 1.0;
         for (int q = 0; q < 2; ++q) {

@@ -142,6 +142,7 @@ def load_library():
     lib.vmx_item_set_metal_basis.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_metal_beta_override.argtypes = [C.c_void_p, C.c_int32, C.c_double]
     lib.vmx_matmul_host.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_int32, dptr, C.c_int32, dptr]
+    lib.vmx_pipeline_set_tracer_evolution.argtypes = [C.c_void_p, C.c_int32, dptr, dptr, C.c_int32]
     lib.vmx_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_profiling_mask.argtypes = [C.c_void_p, C.c_uint32]
     lib.vmx_get_timings.argtypes = [C.c_void_p, dptr, C.POINTER(C.c_int64), C.c_int32]
@@ -156,7 +157,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
-    'vmx_add_pipeline', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
+    'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
@@ -473,6 +474,10 @@ class Engine:
         pid = self._check(self.lib.vmx_add_pipeline(
             self._h, C.byref(desc), n, _dp(_f64(pipe.r)), _dp(_f64(pipe.mu)), _dp(_f64(pipe.z)),
             _dp(_f64(pipe.rel_z_evol)), _dp(_f64(pipe.xi_growth))))
+        if getattr(pipe, 'rel_z_evol_1', None) is not None:
+            # new-bias-evolution: each tracer of a cross-correlation evolves with its own redshift
+            self._check(self.lib.vmx_pipeline_set_tracer_evolution(
+                self._h, pid, _dp(_f64(pipe.rel_z_evol_1)), _dp(_f64(pipe.rel_z_evol_2)), n))
         if pipe.xi.relativistic or pipe.xi.asymmetry:
             # static splines of the odd-multipole terms of this component's linear spectrum
             low, k = self.low, self.prob.k

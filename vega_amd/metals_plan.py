@@ -105,6 +105,7 @@ def _basis_eligible(problem, item, pair, sampled):
         return None
     if getattr(xi, 'uv_shotnoise', False) or getattr(problem.scale, 'metal_scaling', False):
         return None
+    # (new-bias-evolution only changes the static redshift factors the basis already carries)
     pinned = set()
     for tr in (pair.pipeline.tracer1, pair.pipeline.tracer2):
         if xi.evol_model.get(tr.name, 'standard') != 'standard':

@@ -139,6 +139,7 @@ class XiOptions:
     ell_max: int = 6
     old_fftlog: bool = False
     single_multipole: int = -1
+    new_bias_evol: bool = False      # separate redshifts of the two tracers in a cross-correlation
     evol_model: dict = field(default_factory=dict)   # tracer name -> 'standard' | 'croom'
     radiation: bool = False
     relativistic: bool = False
@@ -161,6 +162,8 @@ class Pipeline:
     z: np.ndarray
     xi_growth: np.ndarray
     rel_z_evol: np.ndarray
+    rel_z_evol_1: np.ndarray = None      # per-tracer (1 + z_tracer) / (1 + z_eff) with new-bias-evolution
+    rel_z_evol_2: np.ndarray = None
     delta_rp_name: str = None
 
     @property
@@ -446,14 +449,25 @@ def _xi_options(model_section, xi_section, tracers):
     opts.uv_shotnoise = xi_section.getboolean('UVB-shotnoise', False) if 'UVB-shotnoise' in xi_section else False
     if opts.uv_shotnoise and opts.rescale_coords_systematics:
         raise NotImplementedError('UVB-shotnoise with rescale-coords-systematics is not supported')
-    if xi_section.getboolean('new-bias-evolution', False):
-        raise NotImplementedError('new-bias-evolution needs a picca cosmology (not supported)')
+    opts.new_bias_evol = xi_section.getboolean('new-bias-evolution', False)
     if xi_section.getboolean('old_growth_func', False):
         raise NotImplementedError('old_growth_func is not supported')
     return opts
 
 
-def _make_pipeline(tr1, tr2, dataset, pk_opts, xi_opts, grid, problem_consts, metal_corr):
+def picca_dist_hubble(z, cosmo):
+    """D_H(z) = c / H(z) in Mpc/h of the picca cosmology a data file carries (OMEGAM, OMEGAK, OMEGAR, WL header
+    keywords; reference vega/data.py:360-366, vega/correlation_item.py:138-151).  picca (picca.constants.Cosmo) is
+    absent from the reference tree and from this image: this restates its published construction - H on a 10000-point
+    grid up to z = 10, linearly interpolated - and is NOT pinned against picca itself."""
+    om, ok, orad, wl = cosmo['Omega_m'], cosmo['Omega_k'], cosmo['Omega_r'], cosmo['wl']
+    ol = 1. - ok - om - orad
+    zg = np.arange(10000) * (10. / 10000)
+    hubble = 100. * np.sqrt(ol * (1. + zg)**(3. * (1. + wl)) + ok * (1. + zg)**2 + om * (1. + zg)**3 + orad * (1. + zg)**4)
+    return np.interp(z, zg, 299792.458 / hubble)
+
+
+def _make_pipeline(tr1, tr2, dataset, pk_opts, xi_opts, grid, problem_consts, metal_corr, cosmo=None):
     z_fid, z_eff, om, ode = problem_consts
     if xi_opts.radiation:
         names = [tr1.name, tr2.name]
@@ -471,11 +485,21 @@ def _make_pipeline(tr1, tr2, dataset, pk_opts, xi_opts, grid, problem_consts, me
     elif tr2.type == 'discrete' and tr1.type != 'discrete':
         delta_rp_name = 'drp_' + tr2.name
     z = grid.z
-    return Pipeline(
+    pipe = Pipeline(
         tracer1=tr1, tracer2=tr2, dataset=dataset, pk=pk_opts, xi=xi_opts,
         metal_corr=metal_corr, r=grid.r, mu=grid.mu, z=z,
         xi_growth=np.asarray(growth_squared(z, z_fid, om, ode), dtype=float),
         rel_z_evol=(1. + z) / (1 + z_eff), delta_rp_name=delta_rp_name)
+    # new-bias-evolution (reference vega/correlation_func.py:238-274): in a cross-correlation the two tracers sit
+    # at z -/+ rp / (2 D_H(z)); auto-correlations and files without a cosmology keep the mean redshift
+    if xi_opts.new_bias_evol and tr1.type != tr2.type and cosmo is not None:
+        if 'croom' in xi_opts.evol_model.values():
+            raise ValueError('Croom model is not supported with new bias evol')
+        shift = (grid.r * grid.mu) / (2 * picca_dist_hubble(z, cosmo))
+        rel_q, rel_f = (1. + z - shift) / (1 + z_eff), (1. + z + shift) / (1 + z_eff)
+        pipe.rel_z_evol_1 = rel_q if tr1.type == 'discrete' else rel_f
+        pipe.rel_z_evol_2 = rel_q if tr2.type == 'discrete' else rel_f
+    return pipe
 
 
 def _use_metal_correlation(name1, name2, use_metal_autos):
@@ -649,8 +673,10 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     rescale = d.getfloat('cov_rescale', None)
     if cov is not None and rescale is not None:
         cov = cov * rescale
-    if 'OMEGAM' in hdr:
-        raise NotImplementedError('data files carrying a picca cosmology (OMEGAM) are not supported')
+    cosmo = None
+    if 'OMEGAM' in hdr:     # the picca cosmology of the file: only new-bias-evolution (and new_metals) use it
+        cosmo = {'Omega_m': float(hdr['OMEGAM']), 'Omega_k': float(hdr.get('OMEGAK', 0.)),
+                 'Omega_r': float(hdr.get('OMEGAR', 0.)), 'wl': float(hdr.get('WL', -1.))}
 
     if model_grid is None:
         model_grid = data_grid
@@ -687,7 +713,7 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     # (reference vega/model.py:38-39, vega/metals.py:119-123)
     bs_rp, bs_rt = data_grid.rp_binsize, data_grid.rt_binsize
     core = _make_pipeline(tr1, tr2, name, _pk_options(model_sec, bs_rp, bs_rt, search_dirs),
-                          _xi_options(model_sec, model_sec, (tr1, tr2)), model_grid, consts, False)
+                          _xi_options(model_sec, model_sec, (tr1, tr2)), model_grid, consts, False, cosmo=cosmo)
 
     # ---- metals (reference vega/data.py:475-687, vega/metals.py:43-142)
     metals = []
@@ -768,7 +794,7 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
             grid, mat = stored[pair] if pair in stored else stored[pair[::-1]]
             t_a, t_b = catalog[pair[0]], catalog[pair[1]]
             pipe = _make_pipeline(t_a, t_b, name, metal_pk,
-                                  _xi_options(model_sec, msec, (t_a, t_b)), grid, consts, True)
+                                  _xi_options(model_sec, msec, (t_a, t_b)), grid, consts, True, cosmo=cosmo)
             main = (tr1.name, tr2.name)
             metals.append(MetalPair(
                 names=pair, pipeline=pipe, matrix=mat,

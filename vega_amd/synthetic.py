@@ -70,7 +70,7 @@ def walkers(theta_fid, names, n, varied=None, seed=SEED, scale=0.02, limits=None
     return theta
 
 
-def write_data_file(path, source, with_distortion=True, with_covariance=True):
+def write_data_file(path, source, with_distortion=True, with_covariance=True, extra_header=None):
     """A correlation data file in the layout the reference reads (vega/data.py:285-421): HDU 1 = RP, RT, Z, DA (+ the
     synthetic distortion matrix `DM` and covariance `CO` of this module as vector columns) with the grid keywords,
     HDU 2 = the model-grid coordinates DMRP, DMRT, DMZ.  ``source`` is a reference-format table list
@@ -86,6 +86,7 @@ def write_data_file(path, source, with_distortion=True, with_covariance=True):
     if with_covariance:
         cols.append(('CO', f'{n}D', covariance(rp, rt)))
     hdr = {k: t1.header[k] for k in ('RPMIN', 'RPMAX', 'RTMAX', 'NP', 'NT')}
+    hdr.update(extra_header or {})
     fitslite.write_tables(str(path), [
         ('COR', cols, hdr),
         ('DMATTRI', [('DMRP', 'D', t2.data['DMRP']), ('DMRT', 'D', t2.data['DMRT']), ('DMZ', 'D', t2.data['DMZ'])])],
