@@ -167,7 +167,7 @@ struct vmx_engine {
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
     int64_t xi_total = 0, xim_total = 0;
     DevBuf<double> theta, scal, metal_bias, pl, coef, xi, xim, model, chi2;
-    DevBuf<int32_t> status, mock_index, k_live;
+    DevBuf<int32_t> status, mock_index, k_live, coef_win;
     std::vector<int32_t> h_mock_index;
     int last_B = 0;
     EngineDev dev{};
@@ -343,13 +343,13 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
 static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64_t a_batch, int M, int K,
                           const double* X, int ldx, int64_t x_batch, int N, double* D, int ldd,
                           int64_t d_batch, int nbatch, int slab_rows_avail, const int32_t* k_limit = nullptr,
-                          int fused_item = -1, bool tri = false)
+                          int fused_item = -1, bool tri = false, const int32_t* m_window = nullptr)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.a_batch = a_batch;
     g.X = X; g.ldx = ldx; g.x_batch = x_batch;
     g.D = D; g.ldd = ldd; g.d_batch = d_batch;
-    g.M = M; g.N = N; g.K = K; g.tri = tri ? 1 : 0;
+    g.M = M; g.N = N; g.K = K; g.tri = tri ? 1 : 0; g.m_window = m_window;
     ScopedTimer timer(e, kc);
     if (gemv1_applies(N, K)) {
         // persistent streaming kernel: 2 blocks per CU, rows strided over blocks
@@ -543,6 +543,15 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     e->h_z.insert(e->h_z.end(), z, z + n);
     e->h_relz.insert(e->h_relz.end(), rel_z_evol, rel_z_evol + n);
     for (int i = 0; i < n; ++i) { e->h_lnrelz.push_back(std::log(rel_z_evol[i])); e->h_lnrelz2.push_back(std::log(rel_z_evol[i])); }
+    // extremes of |rp| and rt over the bins with r != 0: k_prologue bounds the rescaled separations with them
+    p.rp_absmin = 1e300; p.rp_absmax = 0.0; p.rt_min = 1e300; p.rt_max = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (r[i] == 0.0) continue;
+        const double rp = std::fabs(r[i] * mu[i]), rt = r[i] * std::sqrt(std::max(0.0, 1.0 - mu[i] * mu[i]));
+        p.rp_absmin = std::min(p.rp_absmin, rp); p.rp_absmax = std::max(p.rp_absmax, rp);
+        p.rt_min = std::min(p.rt_min, rt); p.rt_max = std::max(p.rt_max, rt);
+    }
+    if (p.rp_absmin > p.rp_absmax) { p.rp_absmin = 0.0; p.rt_min = 0.0; }       // no bin with r != 0
     e->h_growth.insert(e->h_growth.end(), xi_growth, xi_growth + n);
     e->pipes.push_back(p);
     return (int)e->pipes.size() - 1;
@@ -1065,6 +1074,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->pl.alloc((size_t)VMX_MAX_ELL * ncols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * ncols * e->ncp) ||
         e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
         e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(1)) return -2;
+    {
+        const int32_t empty_window[2] = {0x7fffffff, -1};
+        if (e->coef_win.upload(empty_window, 2)) return -2;
+    }
     e->h_mock_index.assign(Bm, -1);
     if (e->mock_index.upload(e->h_mock_index.data(), Bm)) return -2;
 
@@ -1088,7 +1101,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.prior_slot = e->d_prior_slot.p; D.prior_mean = e->d_prior_mean.p; D.prior_sigma = e->d_prior_sigma.p;
     D.n_params = n_params;
     D.theta = e->theta.p; D.scal = e->scal.p; D.metal_bias = e->metal_bias.p; D.pl = e->pl.p; D.coef = e->coef.p;
-    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p; D.k_live = e->k_live.p; D.mock_index = e->mock_index.p;
+    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p; D.k_live = e->k_live.p; D.coef_win = e->coef_win.p; D.mock_index = e->mock_index.p;
     D.model_size = e->model_size;
     D.gcinv = e->gcinv.p; D.g_n = e->g_n; D.g_ld = e->g_ld; D.gres = e->gres.p; D.gz = e->gz.p;
 
@@ -1192,7 +1205,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         const int64_t ncols = (int64_t)B * n_pipe;
         launch_product(e, KC_FFTLOG, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
                        e->pl.p, e->nkp, ncols * e->nkp, (int)ncols, e->coef.p, e->ncp, ncols * e->ncp,
-                       VMX_MAX_ELL, 0, e->k_live.p);
+                       VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
     }
     {
         ScopedTimer t(e, KC_XI);

@@ -41,6 +41,7 @@ struct PipeDev {
     int32_t n_pad;        // per-walker stride of the xi buffer (zero tail)
     int64_t coord_off;    // offset into the coordinate arrays
     int64_t xi_off;       // offset into the xi buffer
+    double rp_absmin, rp_absmax, rt_min, rt_max;    // over the bins with r != 0 (bounds of the rescaled separations)
     int32_t split_evol;   // new-bias-evolution: clnrelz holds tracer 1's ln(rel z), clnrelz2 tracer 2's
     int32_t tracers_swapped;   // vmx_add_pipeline put the caller's second tracer first (canonical order)
     // odd-multipole (relativistic / asymmetry) terms: static spline coefficients + amplitude slots
@@ -141,6 +142,7 @@ struct EngineDev {
     double* chi2;               // [B]
     int32_t* status;            // [B]
     int32_t* k_live;            // [1] wavenumbers >= *k_live have P_ell = 0 for every walker and pipeline of the batch
+    int32_t* coef_win;          // [2] first / last spline coefficient any bin of the batch reads (k_prologue; reset by k_chi2)
     const int32_t* mock_index;  // [B] row of the mock pool used as data by walker b, -1: the item's data vector
     int32_t model_size;
     // global covariance mode
@@ -250,6 +252,32 @@ __global__ void k_prologue(EngineDev D, int B)
         }
         s[S_AP] = ap; s[S_AT] = at;
         s[S_DRP] = th(t, d.drp_slot, 0.0);
+        {
+            // Spline coefficients this (walker, pipeline) can read: r'^2 = ap^2 (rp + drp)^2 + at^2 rt^2 over its bins is
+            // bounded by the extremes of |rp|, rt (|rp + drp| lies in [max(0, |rp| - |drp|), |rp| + |drp|]); the FFTLog
+            // product computes the rows inside the batch's window only.  NaN / out-of-range inputs open the window fully.
+            const PipeDev& P = D.pipes[p];
+            const double adrp = fabs(s[S_DRP]);
+            const double lo_rp = fmax(P.rp_absmin - adrp, 0.0), hi_rp = P.rp_absmax + adrp;
+            const double r2lo = ap * ap * lo_rp * lo_rp + at * at * P.rt_min * P.rt_min;
+            const double r2hi = ap * ap * hi_rp * hi_rp + at * at * P.rt_max * P.rt_max;
+            int jlo = 0, jhi = D.n_coef - 1;
+            if (r2lo > 0.0 && r2hi >= r2lo && r2hi < 1e300) {
+                const double xlo = 0.5 * log(r2lo), xhi = 0.5 * log(r2hi);
+                double ulo = 1e300, uhi = -1e300;
+                for (int e = 0; e < d.n_ell; ++e) {
+                    ulo = fmin(ulo, (xlo - D.x0[e]) / D.h[e]);
+                    uhi = fmax(uhi, (xhi - D.x0[e]) / D.h[e]);
+                }
+                if (ulo > -1e9 && uhi < 1e9) {
+                    jlo = max(0, (int)floor(ulo) - 2);
+                    jhi = min(D.n_coef - 1, (int)floor(uhi) + 5);
+                }
+            }
+            if (P.odd_rel || P.odd_asy || D.extrapolate) { jlo = 0; jhi = D.n_coef - 1; }
+            atomicMin(&D.coef_win[0], jlo);
+            atomicMax(&D.coef_win[1], jhi);
+        }
         for (int q = 0; q < 2; ++q) {
             const vmx_tracer& tr = d.tracer[q];
             double a, c = 0.0;
@@ -1050,6 +1078,7 @@ struct GemmArgs {
     int nsplit, klen;       // klen multiple of the K step; nsplit in {1, 2, 4, 8} for the MFMA kernel
     int tm, tn;             // block tiles along matrix rows / walkers (MFMA kernel)
     const int32_t* k_limit; // optional device scalar: operand columns >= *k_limit are zero and skipped (MFMA kernel)
+    const int32_t* m_window; // optional device int[2]: only the rows [lo, hi] of the result are needed (MFMA and streaming kernels)
     int tri;                // A is lower triangular (zeros above the diagonal): row tile mt needs k < (mt + 1) BM only
 };
 
@@ -1114,6 +1143,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmGroup G)
         kbeg = split * g.klen; kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
     }
     if (g.k_limit) { const int kl = (*g.k_limit + BK - 1) / BK * BK; if (kend > kl) kend = kl; }
+    if (g.m_window && (m0 + BM <= g.m_window[0] || m0 > g.m_window[1])) continue;      // block-uniform: no barrier is skipped
     if (pass > 0) __syncthreads();          // the LDS buffers of the first tile are free again
 
     const double* pa[PA];
@@ -1205,6 +1235,7 @@ __global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= g.M) return;
+    if (g.m_window && (row < g.m_window[0] || row > g.m_window[1])) return;
     const double* a = A + (size_t)row * g.lda;
     double acc[NB];
 #pragma unroll
@@ -1480,5 +1511,6 @@ __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs
         if (!(c == c) || c > 1e300 || c < -1e300) { st |= VMX_STATUS_NONFINITE; D.status[b] = st; }
         D.chi2[b] = st ? 1e100 : c;
         if (D.chi2_host) { D.chi2_host[b] = st ? 1e100 : c; D.status_host[b] = st; }
+        if (b == 0) { D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1; }      // the next evaluation starts from an empty window
     }
 }
