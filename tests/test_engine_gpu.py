@@ -319,3 +319,31 @@ def test_marginalize_in_fit_through_the_engine(tmp_path):
     pars = {str(n): float(v) for n, v in zip(exp['rtmax/infit/param_names'], exp['rtmax/infit/theta'][0])}
     assert vega.chi2(pars) == pytest.approx(float(exp['rtmax/infit/walker0/chi2']), rel=CHI2_RTOL)
     vega.close()
+
+
+def test_spline_coefficient_window_follows_the_batch():
+    """The FFTLog product only computes the spline-coefficient rows the batch's bins can reach (a device window from
+    every walker's scale parameters and delta_rp).  Walkers with very different dilations in one batch - and a batch
+    evaluated after a narrower one - give the same results as one-by-one evaluations."""
+    vega = _engine('joint', max_batch=32)
+    eng = vega.engine
+    slot = eng.low.slot
+    theta = np.tile(eng.low.theta0, (32, 1))
+    rng = np.random.default_rng(17)
+    theta[:, slot['ap']] = rng.uniform(0.55, 1.45, 32)
+    theta[:, slot['at']] = rng.uniform(0.55, 1.45, 32)
+    theta[:, slot['drp_QSO']] = rng.uniform(-25., 25., 32)
+    theta[0, slot['ap']], theta[0, slot['at']] = 0.5, 0.5            # the two extremes share the batch
+    theta[1, slot['ap']], theta[1, slot['at']] = 1.5, 1.5
+    narrow = eng.eval(np.tile(eng.low.theta0, (16, 1)), want_model=True)      # a narrow window first
+    assert not narrow[1].any()
+    chi2, status, model = eng.eval(theta, want_model=True)
+    assert not status.any()
+    for i in (0, 1, 7, 31):
+        c1, s1, m1 = eng.eval(theta[i:i + 1], want_model=True)
+        assert not s1.any()
+        assert chi2[i] == pytest.approx(c1[0], rel=1e-11)
+        assert np.abs(model[i] - m1[0]).max() <= 1e-12 * np.abs(m1[0]).max()
+    again = eng.eval(np.tile(eng.low.theta0, (16, 1)), want_model=True)       # and a narrow one after the wide one
+    np.testing.assert_array_equal(again[0], narrow[0])
+    vega.close()
