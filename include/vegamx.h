@@ -267,6 +267,12 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
 int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2,
                     double* d_model, int32_t* d_status);
 int vmx_sync(vmx_engine* e);
+/* direct_pk (vega_interface.py:208-248 -> model.py:188-207): while set, every item's model is its smooth pipeline
+ * (no peak component, no metals with the default no-metal-decomp; additive broadband terms enter once) evaluated with
+ * the linear spectrum pk[b][nk] of walker b (host pointer, e.g. the output of a Boltzmann code per parameter point)
+ * instead of the fiducial template.  pk = NULL returns to the template. */
+int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk);
+
 /* Samplers usually keep the Arinyo non-linear parameters fixed.  When they are identical for every walker of a
  * batch the factor D_NL(k,mu) G(k,mu) is tabulated once per batch instead of being exponentiated per walker and
  * grid point.  vmx_eval (host theta) detects this by itself; for vmx_eval_device the caller states it here.

@@ -727,9 +727,18 @@ def local_params(prob, params=None):
     return out
 
 
-def compute_model(prob, params=None, taps=None):
+def model_compute_direct(prob, item, params, pk_full):
+    """Model.compute_direct (reference model.py:188-207): one component from the caller's full spectrum."""
+    pars = dict(params)
+    pars['peak'] = False
+    return _component(prob, item, pars, np.asarray(pk_full, dtype=float), 'full', xi_metals=None)
+
+
+def compute_model(prob, params=None, taps=None, direct_pk=None):
     """VegaInterface.compute_model (reference vega_interface.py:208-248)."""
     lp = local_params(prob, params)
+    if direct_pk is not None:
+        return {name: model_compute_direct(prob, item, lp, direct_pk) for name, item in prob.items.items()}
     return {name: model_compute(prob, item, lp, None if taps is None else taps.setdefault(name, {}))
             for name, item in prob.items.items()}
 
@@ -744,10 +753,10 @@ def prior_chi2(prob, params=None):
     return chi2
 
 
-def chi2(prob, params=None, data_override=None):
+def chi2(prob, params=None, data_override=None, direct_pk=None):
     """VegaInterface.chi2 (reference vega_interface.py:250-325); 1e100 on a model error."""
     try:
-        model = compute_model(prob, params)
+        model = compute_model(prob, params, direct_pk=direct_pk)
     except OracleModelError:
         return 1e100
     # marginalize-in-fit: best-fit template coefficients from the residual, templates added to the model

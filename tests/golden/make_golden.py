@@ -471,6 +471,36 @@ def dump_marginalization(VegaInterface):
     np.savez_compressed(HERE / 'expected_marginalization.npz', **out)
 
 
+def direct_pk_vector(k, pk_full):
+    """A stand-in for a Boltzmann-code spectrum: the fiducial one tilted and rescaled."""
+    return 1.07 * pk_full * (k / 0.1)**0.03
+
+
+def dump_direct_pk(VegaInterface):
+    """`direct_pk` (reference vega_interface.py:208-248 -> model.py:188-207): chi2 and model from a caller-supplied
+    full spectrum, joint fit with metals configured (which the direct path leaves out with the default
+    no-metal-decomp) and a post-distortion additive broadband (which enters once instead of (1 + bao_amp) times)."""
+    os.chdir(REF / 'tests')
+    items = ['lyalya_lyalya', 'lyalya_qso']
+    with tempfile.TemporaryDirectory() as tmp:
+        vega = VegaInterface(_ref_main(tmp, items, True))
+        pk = direct_pk_vector(vega.fiducial['k'], vega.fiducial['pk_full'])
+        out = {'direct_pk': pk, 'fid/chi2': vega.chi2(direct_pk=pk)}
+        model = vega.compute_model(run_init=False, direct_pk=pk)
+        for name in items:
+            out[f'fid/model/{name}'] = model[name]
+        names, walkers = make_walkers(vega.params, 2, seed=WALKER_SEED + 8)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+        chi2s = []
+        for i, w in enumerate(walkers):
+            _reset_caches(vega)
+            chi2s.append(vega.chi2(w, direct_pk=pk * (1 + 0.01 * (i + 1))))
+        out['chi2'] = np.array(chi2s)
+        np.savez_compressed(HERE / 'expected_direct_pk.npz', **out)
+        print('direct_pk: chi2', out['fid/chi2'], out['chi2'])
+
+
 def dump_fast_metals(VegaInterface):
     """`fast_metals = True` (reference metals.py:53,144-169,280-282): metal x metal correlations are computed at
     the FIRST evaluation and reused for ever after.  Sequence dumped: chi2 at the fiducial point (fills the cache),
@@ -516,12 +546,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -542,3 +572,5 @@ if __name__ == '__main__':
         dump_fits_ingest(VI)
     if 'marginalization' in what:
         dump_marginalization(VI)
+    if 'direct_pk' in what:
+        dump_direct_pk(VI)

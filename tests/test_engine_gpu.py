@@ -347,3 +347,24 @@ def test_spline_coefficient_window_follows_the_batch():
     again = eng.eval(np.tile(eng.low.theta0, (16, 1)), want_model=True)       # and a narrow one after the wide one
     np.testing.assert_array_equal(again[0], narrow[0])
     vega.close()
+
+
+def test_direct_pk():
+    """`direct_pk`: chi2 / model from caller-supplied linear spectra, against the reference's values - one at a time
+    through the reference's signature, and as a batch with one spectrum per parameter point."""
+    vega = _engine('joint_metals', max_batch=4)
+    exp = np.load(GOLDEN / 'expected_direct_pk.npz')
+    pk = exp['direct_pk']
+    base = vega.chi2()
+    assert vega.chi2(direct_pk=pk) == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    model = vega.compute_model(direct_pk=pk)
+    for name in vega.corr_items:
+        _assert_xi(model[name], exp[f'fid/model/{name}'], f'direct {name}')
+    assert vega.chi2() == pytest.approx(base, rel=1e-14)             # back on the fiducial template
+    names = [str(n) for n in exp['param_names']]
+    pars = [dict(zip(names, row)) for row in exp['theta']]
+    spectra = np.stack([pk * 1.01, pk * 1.02])
+    for i in range(2):
+        assert vega.chi2(pars[i], direct_pk=spectra[i]) == pytest.approx(float(exp['chi2'][i]), rel=CHI2_RTOL)
+    np.testing.assert_allclose(vega.chi2_batch_direct(pars, spectra), exp['chi2'], rtol=CHI2_RTOL)
+    vega.close()

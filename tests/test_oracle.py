@@ -326,3 +326,15 @@ def test_marginalize_in_fit_matches_reference(tmp_path, tag):
     item = prob.items['lyalya_lyalya']
     diff = item.masked_data_vec - oc.compute_model(prob, pars)['lyalya_lyalya'][item.model_mask]
     assert diff.dot(item.chi2_matrix.dot(diff)) == pytest.approx(float(exp[f'{tag}/infit/walker0/chi2']), rel=1e-9)
+
+
+def test_direct_pk_matches_reference():
+    """`direct_pk` (reference vega_interface.py:208-248 -> model.py:188-207): one component from the caller's spectrum,
+    no metals with the default no-metal-decomp, additive broadband entering once."""
+    prob = load_problem('joint_metals')
+    exp = np.load(GOLDEN / 'expected_direct_pk.npz')
+    assert oc.chi2(prob, direct_pk=exp['direct_pk']) == pytest.approx(float(exp['fid/chi2']), rel=1e-13)
+    names = [str(n) for n in exp['param_names']]
+    for i, row in enumerate(exp['theta']):
+        got = oc.chi2(prob, dict(zip(names, row)), direct_pk=exp['direct_pk'] * (1 + 0.01 * (i + 1)))
+        assert got == pytest.approx(float(exp['chi2'][i]), rel=1e-13)

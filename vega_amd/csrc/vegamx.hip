@@ -168,6 +168,8 @@ struct vmx_engine {
     int64_t xi_total = 0, xim_total = 0;
     DevBuf<double> theta, scal, metal_bias, pl, coef, xi, xim, model, chi2;
     DevBuf<int32_t> status, mock_index, k_live, coef_win;
+    DevBuf<double> pk_direct;        // [max_batch][nkp] per-walker linear spectra of the direct_pk mode
+    bool direct = false;
     std::vector<int32_t> h_mock_index;
     int last_B = 0;
     EngineDev dev{};
@@ -1338,7 +1340,7 @@ static int run_chain_cached(vmx_engine* e, int B, bool tab_mode, bool zero_copy 
 {
     tab_mode = tab_mode && e->n_xtab > 0;
     if (!e->use_graphs || e->profiling) return run_chain(e, B, tab_mode, zero_copy);
-    const int key = (B * 2 + (tab_mode ? 1 : 0)) * 2 + (zero_copy ? 1 : 0);
+    const int key = ((B * 2 + (tab_mode ? 1 : 0)) * 2 + (zero_copy ? 1 : 0)) * 2 + (e->direct ? 1 : 0);
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
         if (e->graphs.size() >= 64) return run_chain(e, B, tab_mode, zero_copy);
@@ -1384,6 +1386,21 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
 }
 
 void* vmx_stream(vmx_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk)
+{
+    REQUIRE(e && e->finalized, "vmx_set_direct_pk");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (!pk) { e->direct = false; e->dev.pk_direct = nullptr; return 0; }
+    REQUIRE(B > 0 && B <= e->max_batch && nk == e->nk, "direct_pk shape: [B <= max_batch][nk]");
+    if (e->pk_direct.n < (size_t)e->max_batch * e->nkp && e->pk_direct.alloc((size_t)e->max_batch * e->nkp, true)) return -2;
+    HIP_OK(hipMemcpy2D(e->pk_direct.p, (size_t)e->nkp * sizeof(double), pk, (size_t)nk * sizeof(double),
+                       (size_t)nk * sizeof(double), B, hipMemcpyHostToDevice));
+    e->direct = true;
+    e->dev.pk_direct = e->pk_direct.p;       // every kernel of the chain takes its EngineDev from e->dev
+    return 0;
+}
 
 int vmx_set_constant_nl_hint(vmx_engine* e, int32_t enabled)
 {

@@ -141,6 +141,9 @@ struct EngineDev {
     double* model;              // [B][model_size]
     double* chi2;               // [B]
     int32_t* status;            // [B]
+    // direct_pk mode (model.py:188-207): the model is the smooth pipeline of every item evaluated with a linear spectrum
+    // supplied per walker (e.g. by a Boltzmann code); no peak component, and additive terms enter once
+    const double* pk_direct;    // [B][nkp] or null
     int32_t* k_live;            // [1] wavenumbers >= *k_live have P_ell = 0 for every walker and pipeline of the batch
     int32_t* coef_win;          // [2] first / last spline coefficient any bin of the batch reads (k_prologue; reset by k_chi2)
     const int32_t* mock_index;  // [B] row of the mock pool used as data by walker b, -1: the item's data vector
@@ -890,7 +893,9 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
         const size_t ncols = (size_t)B * D.n_pipe;
         for (int half = 0; half < (T.paired ? 2 : 1); ++half) {
             const int pipe = half ? pp : p;
-            const double pk = damp * D.pklin[(size_t)D.pipes[pipe].d.pk_lin_kind * D.nkp + i];
+            const int kind = D.pipes[pipe].d.pk_lin_kind;
+            const double pk = damp * ((D.pk_direct && kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i]
+                                                                                 : D.pklin[(size_t)kind * D.nkp + i]);
             const size_t col = (size_t)b * D.n_pipe + pipe;
             for (int e = 0; e < D.n_ell; ++e) {
                 double sum = 0.0;
@@ -973,8 +978,10 @@ __device__ inline double assemble_bin(const EngineDev& D, const ItemDev& it, int
     const double bao = t[it.d.bao_amp_slot];
     const PipeDev& Pp = D.pipes[it.d.pipe_peak];
     const PipeDev& Ps = D.pipes[it.d.pipe_smooth];
-    double v = bao * D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin] + D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
-    for (int m = 0; m < it.n_metals; ++m) {
+    const bool direct = D.pk_direct != nullptr;
+    double v = D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
+    if (!direct) v = fma(bao, D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin], v);
+    for (int m = 0; m < (direct ? 0 : it.n_metals); ++m) {
         const MetalDev& md = D.metals[it.metal_begin + m];
         const double* mb = D.metal_bias + (size_t)b * 3 * D.n_metals_total + it.metal_begin + m;
         const double f = mb[0];
@@ -989,7 +996,7 @@ __device__ inline double assemble_bin(const EngineDev& D, const ItemDev& it, int
     }
     if (it.add_vec) v = fma(it.add_slot >= 0 ? t[it.add_slot] : it.add_default, it.add_vec[bin], v);
     if (it.n_bb[VMX_BB_PRE_MUL]) v *= bb_total(D, it, VMX_BB_PRE_MUL, t, bin, it.d.n_model);
-    if (it.n_bb[VMX_BB_PRE_ADD]) v += (1.0 + bao) * bb_total(D, it, VMX_BB_PRE_ADD, t, bin, it.d.n_model);
+    if (it.n_bb[VMX_BB_PRE_ADD]) v += (direct ? 1.0 : 1.0 + bao) * bb_total(D, it, VMX_BB_PRE_ADD, t, bin, it.d.n_model);
     return v;
 }
 
@@ -1017,7 +1024,8 @@ __device__ inline void post_bin(const EngineDev& D, const ItemDev& it, int b, in
 {
     const double* t = D.theta + (size_t)b * D.n_params;
     if (it.n_bb[VMX_BB_POST_MUL]) v *= bb_total(D, it, VMX_BB_POST_MUL, t, bin, it.d.n_dist);
-    if (it.n_bb[VMX_BB_POST_ADD]) v += (1.0 + t[it.d.bao_amp_slot]) * bb_total(D, it, VMX_BB_POST_ADD, t, bin, it.d.n_dist);
+    if (it.n_bb[VMX_BB_POST_ADD])
+        v += (D.pk_direct ? 1.0 : 1.0 + t[it.d.bao_amp_slot]) * bb_total(D, it, VMX_BB_POST_ADD, t, bin, it.d.n_dist);
     D.model[(size_t)b * D.model_size + it.model_off + bin] = v;
     const int mi = it.inv_mask[bin];
     if (mi >= 0) {

@@ -132,6 +132,7 @@ def load_library():
     lib.vmx_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vmx_sync.argtypes = [C.c_void_p]
     lib.vmx_set_constant_nl_hint.argtypes = [C.c_void_p, C.c_int32]
+    lib.vmx_set_direct_pk.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_int32]
     lib.vmx_stream.argtypes = [C.c_void_p]
     lib.vmx_stream.restype = C.c_void_p
     lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
@@ -160,7 +161,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -733,6 +734,14 @@ class Engine:
         if has_matrix:
             return self.debug_read(3, g, cap)[:n].copy()
         return self.debug_read(1, pid, cap)[:n].copy()
+
+    def set_direct_pk(self, pk=None):
+        """direct_pk mode: per-walker linear spectra [B, nk] (None: back to the fiducial template)."""
+        if pk is None:
+            self._check(self.lib.vmx_set_direct_pk(self._h, None, 0, 0))
+            return
+        pk = _f64(np.atleast_2d(pk))
+        self._check(self.lib.vmx_set_direct_pk(self._h, _dp(pk), pk.shape[0], pk.shape[1]))
 
     def set_metal_beta_override(self, beta=None):
         """Set-up hook: every tracer of a bias-free metal pipeline takes ``beta`` (None: back to the parameters)."""

@@ -128,6 +128,29 @@ class VegaInterface:
             raise ValueError('frozen metal terms: ' + ', '.join(self._pinned_names) + ' must keep the values they had '
                              'when the terms were frozen (or be listed in [sample] beforehand)')
 
+    def _direct(self, direct_pk):
+        """Context: evaluate with the caller's linear spectrum (one [nk] vector, or [B, nk] for a batch) in place of
+        the fiducial template - the reference's ``direct_pk`` argument (vega_interface.py:208-248)."""
+        import contextlib
+        engine = self.engine
+
+        @contextlib.contextmanager
+        def ctx():
+            if direct_pk is None:
+                yield
+                return
+            if any(item.metals and not item.metal_opts['no_metal_decomp'] for item in self.problem.items.values()):
+                raise NotImplementedError('direct_pk with no-metal-decomp = False is not accelerated')
+            if any(item.core.xi.relativistic or item.core.xi.asymmetry for item in self.problem.items.values()):
+                raise NotImplementedError('direct_pk with the odd-multipole terms (static splines of the template) '
+                                          'is not accelerated')
+            engine.set_direct_pk(direct_pk)
+            try:
+                yield
+            finally:
+                engine.set_direct_pk(None)
+        return ctx()
+
     def _sync_monte_carlo(self):
         """chi2 reads the current mock and the scaled inverse covariance in Monte-Carlo mode
         (reference vega/vega_interface.py:296-297, :311-313)."""
@@ -151,13 +174,12 @@ class VegaInterface:
     # ------------------------------------------------------------------ reference surface
     def compute_model(self, params=None, run_init=True, direct_pk=None, marg_coeff=None):
         """dict name -> model correlation function (distorted grid), as the reference returns."""
-        if direct_pk is not None:
-            raise NotImplementedError('direct_pk is not accelerated')
         if marg_coeff is not None:
             raise NotImplementedError('marginalisation templates are not accelerated')
         self.freeze_metals(params)
         self._check_pinned(self._theta(params)[None, :])
-        _, status, model = self.engine.eval(self._theta(params)[None, :], want_model=True)
+        with self._direct(direct_pk):
+            _, status, model = self.engine.eval(self._theta(params)[None, :], want_model=True)
         if status[0]:
             from .errors import VegaModelError
             raise VegaModelError(f'model evaluation failed (status {int(status[0])})')
@@ -165,12 +187,13 @@ class VegaInterface:
 
     def chi2(self, params=None, direct_pk=None, return_marg_coeff=False):
         """float chi2; 1e100 when the model cannot be evaluated (reference :268-279)."""
-        if direct_pk is not None or return_marg_coeff:
-            raise NotImplementedError('direct_pk / marginalisation coefficients are not accelerated')
+        if return_marg_coeff:
+            raise NotImplementedError('marginalisation coefficients are not returned')
         self.freeze_metals(params)
         self._check_pinned(self._theta(params)[None, :])
         self._sync_monte_carlo()
-        chi2, _, _ = self.engine.eval(self._theta(params)[None, :])
+        with self._direct(direct_pk):
+            chi2, _, _ = self.engine.eval(self._theta(params)[None, :])
         return float(chi2[0])
 
     def log_lik(self, params=None, direct_pk=None, return_marg_coeff=False):
@@ -201,6 +224,19 @@ class VegaInterface:
         return total
 
     # ------------------------------------------------------------------ batched surface
+    def chi2_batch_direct(self, params_list, direct_pk):
+        """chi2 of B parameter points, each with its own linear spectrum direct_pk[b] (e.g. one Boltzmann-code run per
+        point): the batched form of ``chi2(params, direct_pk=...)``.  B <= max_batch."""
+        theta = self.theta_matrix(params_list)
+        direct_pk = np.atleast_2d(np.asarray(direct_pk, dtype=np.float64))
+        if direct_pk.shape[0] != theta.shape[0] or theta.shape[0] > self.engine.max_batch:
+            raise ValueError('one spectrum per parameter point, at most max_batch points')
+        self.freeze_metals(theta[0])
+        self._check_pinned(theta)
+        self._sync_monte_carlo()
+        with self._direct(direct_pk):
+            return self.engine.eval(theta)[0]
+
     def chi2_batch(self, params_list, return_status=False):
         """chi2 for many parameter points: list of dicts or [B, n_params] array (column order
         ``self.param_names``).  Points are evaluated in chunks of ``max_batch``."""
