@@ -88,4 +88,5 @@ def marginalization_problem(tmp_path, options, in_fit=False):
 MARGINALIZATION_CASES = {
     'rtmax': 'marginalize-below-rtmax = 16.0\nmarginalize-prior-sigma = 5.0',
     'allrmin': 'marginalize-all-rmin-cuts = True\nmarginalize-match-data-bins = True',
+    'fitscales': 'marginalize-below-rtmax = 12.0\nfit-marginalized-scales = True\nmarginalize-match-data-bins = True',
 }

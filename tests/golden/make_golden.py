@@ -441,7 +441,9 @@ def dump_marginalization(VegaInterface):
     os.chdir(REF / 'tests')
     out = {}
     for tag, opts in (('rtmax', 'marginalize-below-rtmax = 16.0\nmarginalize-prior-sigma = 5.0'),
-                      ('allrmin', 'marginalize-all-rmin-cuts = True\nmarginalize-match-data-bins = True')):
+                      ('allrmin', 'marginalize-all-rmin-cuts = True\nmarginalize-match-data-bins = True'),
+                      ('fitscales', 'marginalize-below-rtmax = 12.0\nfit-marginalized-scales = True\n'
+                                    'marginalize-match-data-bins = True')):
         with tempfile.TemporaryDirectory() as tmp:
             source = read_tables(REF / 'tests/data/cf_lya-exp.fits.gz')
             data_path = synthetic.write_data_file(Path(tmp) / 'cf_lya-synth.fits', source)

@@ -297,7 +297,7 @@ def test_fits_ingestion_matches_reference(tmp_path):
     assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-10)
 
 
-@pytest.mark.parametrize('tag', ['rtmax', 'allrmin'])
+@pytest.mark.parametrize('tag', ['rtmax', 'allrmin', 'fitscales'])
 def test_small_scale_marginalization_matches_reference(tmp_path, tag):
     """Small-scale marginalisation (reference vega/correlation_item.py:175-268, vega/data.py:96-128, :762-828): the
     set-up time covariance update, against chi2 / log-likelihood of the unmodified reference on the same file."""
@@ -310,7 +310,7 @@ def test_small_scale_marginalization_matches_reference(tmp_path, tag):
     assert oc.log_lik(prob) == pytest.approx(float(exp[f'{tag}/log_lik']), rel=1e-8)
 
 
-@pytest.mark.parametrize('tag', ['rtmax', 'allrmin'])
+@pytest.mark.parametrize('tag', ['rtmax', 'allrmin', 'fitscales'])
 def test_marginalize_in_fit_matches_reference(tmp_path, tag):
     """`marginalize-in-fit` (reference vega_interface.py:282-292, :546-579): the oracle fits the template coefficients
     from the residual and adds the templates to the model, as the reference does; the product path uses the

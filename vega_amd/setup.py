@@ -592,6 +592,26 @@ def marginalization_templates(model_grid, dist_grid, cuts, marg, match_data_bins
     return sparse.coo_array((ones, (np.arange(common.size), common)), shape=(common.size, n)).tocsr().T
 
 
+def marginalization_scale_mask(grid, cuts, marg):
+    """Bins that are marginalised (reference vega/coordinates.py:184-217)."""
+    mask = np.ones_like(grid.rp_regular, dtype=bool)
+    if 'rtmax' in marg:
+        mask &= grid.rt_regular < marg['rtmax']
+    if 'rtmin' in marg:
+        mask &= grid.rt_regular > marg['rtmin']
+    if 'rpmax' in marg:
+        mask &= np.abs(grid.rp_regular) < marg['rpmax']
+    if 'rpmin' in marg:
+        mask &= np.abs(grid.rp_regular) > marg['rpmin']
+    if 'all-rmin' in marg:
+        def get(key, default):
+            return float(cuts.get(key, default)) if cuts is not None else default
+        keep = (grid.rp_regular > get('rp-min', 0.)) & (grid.rt_regular > get('rt-min', 0.))
+        keep &= grid.r_regular > get('r-min', 10.)
+        mask = ~keep
+    return mask
+
+
 def marginalization_cov_update(distortion, model_grid, dist_grid, cuts, marg, model_mask, prior_sigma=10.0,
                                match_data_bins=False, factor=1e-8):
     """A A^T of the distorted, masked, prior-scaled templates with degenerate modes removed by an SVD
@@ -622,8 +642,7 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
             marg[short] = model_sec.getfloat(key, 0)
     if model_sec.getboolean('marginalize-all-rmin-cuts', False):
         marg['all-rmin'] = True
-    if marg and model_sec.getboolean('fit-marginalized-scales', False):
-        raise NotImplementedError('fit-marginalized-scales is not supported')
+    fit_marg_scales = bool(marg) and model_sec.getboolean('fit-marginalized-scales', False)
     if model_sec.getboolean('new_metals', False):
         raise NotImplementedError('new_metals (metal-matrix construction) is outside the hot path')
     if 'filename' not in d or not d.getboolean('has_datafile', True):
@@ -692,6 +711,12 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     if marg:
         if distortion is None:
             raise ValueError('Distortion matrix required for marginalization')
+        if fit_marg_scales:
+            # the marginalised scales join the fitted bins (reference vega/data.py:793-812)
+            data_mask = data_mask | marginalization_scale_mask(data_grid, cuts, marg)
+            model_mask = model_mask | marginalization_scale_mask(dist_grid, cuts, marg)
+            if data_mask.sum() != model_mask.sum():
+                raise ValueError('Data and model masks should be the same after marginalization scale cuts.')
         if cov is None:
             cov = np.eye(data_vec.size)
         cov = np.array(cov, dtype=float)
@@ -702,7 +727,9 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
         inv = np.linalg.inv(cov[:, data_mask][data_mask, :])
         tm = marg_templates[model_mask, :]
         G = tm.T.dot(inv)
-        A = tm.T.dot(G.T).T + np.diag(np.full(marg_templates.shape[1], prior_sigma**-2))
+        A = tm.T.dot(G.T).T
+        if not (fit_marg_scales and match_bins):
+            A = A + np.diag(np.full(marg_templates.shape[1], prior_sigma**-2))
         marg_diff2coeff = np.linalg.inv(A).dot(G)
         update = marginalization_cov_update(distortion, model_grid, dist_grid, cuts, marg, model_mask,
                                             prior_sigma=prior_sigma, match_data_bins=match_bins)
