@@ -368,3 +368,32 @@ def test_direct_pk():
         assert vega.chi2(pars[i], direct_pk=spectra[i]) == pytest.approx(float(exp['chi2'][i]), rel=CHI2_RTOL)
     np.testing.assert_allclose(vega.chi2_batch_direct(pars, spectra), exp['chi2'], rtol=CHI2_RTOL)
     vega.close()
+
+
+def test_wide_parameter_ranges_against_the_oracle():
+    """Walkers drawn uniformly over wide ranges of the sampled-type parameters (far from the fiducial point: strong /
+    vanishing HCD and velocity-dispersion terms, large dilations, negative and small biases) against the oracle."""
+    from oracle import vega_cpu as oc
+    vega = _engine('joint', max_batch=16)
+    eng = vega.engine
+    ranges = {'ap': (0.7, 1.3), 'at': (0.7, 1.3), 'bias_eta_LYA': (-0.5, -0.01), 'beta_LYA': (0.1, 4.0),
+              'beta_QSO': (0.05, 1.0), 'bias_hcd': (-0.2, 0.0), 'beta_hcd': (0.0, 1.5), 'L0_hcd': (1.0, 40.0),
+              'sigma_velo_disp_lorentz_QSO': (0.0, 15.0), 'drp_QSO': (-10.0, 10.0), 'bao_amp': (0.0, 2.0),
+              'sigmaNL_par': (2.0, 12.0), 'sigmaNL_per': (1.0, 8.0), 'par_sigma_smooth': (0.5, 6.0),
+              'per_sigma_smooth': (0.5, 6.0), 'dnl_arinyo_q1': (0.3, 1.5), 'dnl_arinyo_kv': (0.3, 3.0),
+              'dnl_arinyo_av': (0.1, 0.9), 'dnl_arinyo_bv': (1.0, 2.0), 'dnl_arinyo_kp': (8.0, 40.0),
+              'bias_gamma': (0.0, 0.3), 'lambda_uv': (100.0, 600.0)}
+    rng = np.random.default_rng(2026)
+    theta = np.tile(eng.low.theta0, (16, 1))
+    for name, (lo, hi) in ranges.items():
+        if name in eng.low.slot:
+            theta[:, eng.low.slot[name]] = rng.uniform(lo, hi, 16)
+    chi2, status, model = eng.eval(theta, want_model=True)
+    assert not status.any()
+    for i in range(16):
+        pars = dict(zip(eng.names, theta[i]))
+        assert chi2[i] == pytest.approx(oc.chi2(vega.problem, pars), rel=CHI2_RTOL), i
+        ref = oc.compute_model(vega.problem, pars)
+        for name, sl in eng.model_slices.items():
+            _assert_xi(model[i, sl], ref[name], f'walker {i} {name}')
+    vega.close()
