@@ -91,6 +91,19 @@ def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
     engine.sync()
     ms_hot, launches_hot = engine.timings(reset=True)['matvec_api']
     engine.set_profiling(False)
+    # context: a library reduction (torch.sum) over the same matrices, same round-robin, timed with events on torch's stream
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for m in mats:
+        m.sum()
+    torch.cuda.synchronize()
+    read_ms = 0.0
+    for i in range(reps):
+        ev0.record()
+        mats[i % copies].sum()
+        ev1.record()
+        ev1.synchronize()
+        read_ms += ev0.elapsed_time(ev1)
+    plain_read = 8.0 * n * ld / (read_ms / reps * 1e-3) / 1e9
     algo_bytes = 8.0 * (n * n + n + n)          # 8 (N_out N_in + B N_in + B N_out)
     cold = algo_bytes / (ms / launches * 1e-3) / 1e9
     hot = algo_bytes / (ms_hot / launches_hot * 1e-3) / 1e9
@@ -99,6 +112,7 @@ def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
     return {'shape': [n, n], 'batch': 1, 'bound': 'hbm', 'algorithmic_bytes': algo_bytes, 'traffic': traffic,
             'us_per_launch': ms / launches * 1e3, 'achieved': cold, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': cold / HBM_PEAK_GBS, 'achieved_cache_resident': hot, 'max_rel_err': err,
+            'torch_sum_same_bytes_GBs': plain_read,   # a library reduction over the same bytes (context)
             'note': '8 distinct 50 MB matrices round-robin (HBM); cache_resident = one matrix reused'}
 
 
