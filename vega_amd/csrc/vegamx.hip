@@ -122,7 +122,8 @@ struct vmx_engine {
     int nk = 0, nkp = 0, n_mu = 0;
     DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom, fv_x, fv_f, xtab;
     std::vector<int32_t> const_slots;
-    DevBuf<int32_t> d_const_slots;
+    DevBuf<int32_t> d_const_slots, d_xtab_pipe, xtab_dirty;
+    DevBuf<double> xtab_key;
     int n_xtab = 0;
     bool const_hint = false;
     int fv_n = 0;
@@ -1008,6 +1009,13 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             }
         }
         if (e->n_xtab > 0 && e->xtab.alloc((size_t)e->n_xtab * e->n_mu * e->nkp, true)) return -2;
+        {
+            std::vector<int32_t> xp((size_t)e->n_xtab + 1, -1);
+            for (auto& g : e->pk_groups) if (g.xtab >= 0) xp[g.xtab] = g.pipe;
+            std::vector<double> key((size_t)e->n_xtab * 6 + 1, std::nan(""));
+            if (e->d_xtab_pipe.upload(xp.data(), xp.size()) || e->xtab_key.upload(key.data(), key.size()) ||
+                e->xtab_dirty.alloc((size_t)e->n_xtab + 1, true)) return -2;
+        }
         e->const_slots.push_back(-1);
         if (e->d_const_slots.upload(e->const_slots.data(), e->const_slots.size())) return -2;
         e->const_slots.pop_back();
@@ -1087,7 +1095,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
     D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p; D.lnmu = e->lnmu.p;
-    D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.xtab = e->xtab.p; D.const_slots = e->d_const_slots.p; D.n_const_slots = 0; D.n_gk = (int)e->gk_tables.size();
+    D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.xtab = e->xtab.p; D.const_slots = e->d_const_slots.p; D.n_const_slots = 0; D.xtab_pipe = e->d_xtab_pipe.p; D.n_xtab = e->n_xtab; D.xtab_key = e->xtab_key.p; D.xtab_dirty = e->xtab_dirty.p; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp; D.extrapolate = e->extrapolate ? 1 : 0;
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
@@ -1167,9 +1175,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         if (want_mu_tab) shmem += (size_t)2 * e->n_mu * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
         if (tab_mode)
-            for (auto& g : e->pk_groups)
-                if (g.xtab >= 0)
-                    hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, e->n_mu), dim3(256), 0, e->stream, D, g.pipe, g.xtab);
+            hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, e->n_mu, e->n_xtab), dim3(256), 0, e->stream, D);
         if (!e->pk_poly.empty())
             hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
         const int tm = tab_mode ? 1 : 0;

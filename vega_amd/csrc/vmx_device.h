@@ -103,6 +103,10 @@ struct EngineDev {
     const double* gk;           // [tables][n_mu][nkp]
     double* xtab;               // [arinyo groups][n_mu][nkp]  D_NL(k,mu)^power * G(k,mu) of the batch's first walker
     const int32_t* const_slots; int32_t n_const_slots;   // parameters asserted constant across the batch
+    // the table only changes with the Arinyo parameters: k_prologue compares them with the ones the table was built
+    // from (xtab_key [tables][6]); k_xtab recomputes a stale table and merely re-touches a current one (the rewrite keeps
+    // it cache-resident for k_pk_multipoles after the matrix streams of the previous evaluation)
+    const int32_t* xtab_pipe; int32_t n_xtab; double* xtab_key; int32_t* xtab_dirty;
     const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
     int32_t n_gk;
     // fftlog / spline
@@ -175,6 +179,19 @@ __global__ void k_prologue(EngineDev D, int B)
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = gid / (D.n_pipe + 1), slot = gid % (D.n_pipe + 1);
     if (gid == 0) *D.k_live = 0;
+    if (gid == 0 && D.n_const_slots > 0) {
+        // table mode: which D_NL * G tables are stale?  (walker 0 stands for the batch; the others are checked below)
+        for (int g = 0; g < D.n_xtab; ++g) {
+            const vmx_pipe_desc& dg = D.pipes[D.xtab_pipe[g]].d;
+            int dirty = 0;
+            for (int i = 0; i < 6; ++i) {
+                const double v = dg.arinyo_slot[i] >= 0 ? D.theta[dg.arinyo_slot[i]] : 0.0;
+                if (!(D.xtab_key[g * 6 + i] == v)) dirty = 1;       // keys start as NaN
+                D.xtab_key[g * 6 + i] = v;
+            }
+            D.xtab_dirty[g] = dirty;
+        }
+    }
     const double* t = D.theta + (size_t)b * D.n_params;
     if (D.theta_host) {
         // zero-copy entry (small batches, one block): one coalesced read of the walkers from mapped host memory into
@@ -575,10 +592,17 @@ __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, d
 }
 
 // D_NL(k,mu)^power * G(k,mu) from the Arinyo parameters of the batch's first walker (power_spectrum.py:435-479)
-__global__ __launch_bounds__(256) void k_xtab(EngineDev D, int pipe, int xtab)
+__global__ __launch_bounds__(256) void k_xtab(EngineDev D)
 {
+    const int xtab = blockIdx.z, pipe = D.xtab_pipe[xtab];
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
     if (i >= D.nkp) return;
+    double* cell = D.xtab + ((size_t)xtab * D.n_mu + j) * D.nkp + i;
+    if (!D.xtab_dirty[xtab]) {
+        // built from the same parameters by an earlier batch: rewrite the value it holds (no arithmetic, same cache effect)
+        *cell = *(volatile double*)cell;
+        return;
+    }
     double val = 0.0;
     if (i < D.nk) {
         const vmx_pipe_desc& d = D.pipes[pipe].d;
@@ -592,7 +616,7 @@ __global__ __launch_bounds__(256) void k_xtab(EngineDev D, int pipe, int xtab)
         val = exp(fmin(d.arinyo_power * (g * (1.0 - v * m) - kp * kp), 709.0));
         if (d.gk_table >= 0) val *= D.gk[((size_t)d.gk_table * D.n_mu + j) * D.nkp + i];
     }
-    D.xtab[((size_t)xtab * D.n_mu + j) * D.nkp + i] = val;
+    *cell = val;
 }
 
 // mu loop against the tabulated D_NL * G: no exponential is left in the loop - the HCD factor, the Gaussian
