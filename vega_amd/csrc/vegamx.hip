@@ -1334,7 +1334,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
                                  e->gz.p, e->g_ld, 0, 1, e->slab_rows, nullptr, -1, true);
     {
         ScopedTimer t(e, KC_CHI2);
-        hipLaunchKernelGGL(k_chi2, dim3(B), dim3(256), 0, e->stream, D, B, slabs);
+        hipLaunchKernelGGL(k_chi2, dim3(B), dim3(CHI2_THREADS), 0, e->stream, D, B, slabs);
     }
     HIP_OK(hipGetLastError());
     e->last_B = B;

@@ -1500,13 +1500,15 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
 }
 
 // chi2 = sum_items diff^T (C^-1 diff) + priors; sentinel on failure
-__global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs)
+// (1024 threads per walker: the kernel is a bandwidth-bound reduction with one block per walker)
+#define CHI2_THREADS 1024
+__global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabInfo slabs)
 {
-    __shared__ double red[256];
+    __shared__ double red[CHI2_THREADS];
     const int b = blockIdx.x;
     double acc = 0.0;
     if (D.gcinv) {
-        for (int i = threadIdx.x; i < D.g_n; i += 256) {
+        for (int i = threadIdx.x; i < D.g_n; i += CHI2_THREADS) {
             double z = 0.0;
             for (int s = 0; s < slabs.g; ++s) z += D.gz[((size_t)s * B + b) * D.g_ld + i];
             acc = fma(D.gres[(size_t)b * D.g_ld + i], 2.0 * z, acc);         // gcinv holds the half form (see vegamx.hip)
@@ -1514,7 +1516,7 @@ __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs
     } else {
         for (int q = 0; q < D.n_items; ++q) {
             const ItemDev& it = D.items[q];
-            for (int i = threadIdx.x; i < it.n_masked; i += 256) {
+            for (int i = threadIdx.x; i < it.n_masked; i += CHI2_THREADS) {
                 const double rres = it.res[(size_t)b * it.n_masked_pad + i];
                 double z;
                 if (it.cinv) {
@@ -1528,7 +1530,7 @@ __global__ __launch_bounds__(256) void k_chi2(EngineDev D, int B, SlabInfo slabs
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = CHI2_THREADS / 2; off > 0; off >>= 1) {
         if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
