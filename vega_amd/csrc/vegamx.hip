@@ -1142,13 +1142,19 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 int vmx_model_size(vmx_engine* e) { return e ? e->model_size : -1; }
 
 // enqueue the whole kernel chain for the B parameter points already in e->theta
-static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false)
+static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
+                     double* d_chi2 = nullptr, int32_t* d_status = nullptr)
 {
     EngineDev D = e->dev;
     D.n_const_slots = tab_mode ? (int)e->const_slots.size() : 0;
     if (zero_copy) {
-        D.theta_host = e->dpin_theta; D.theta_copy = e->theta.p;
+        D.theta_host = e->dpin_theta; D.theta_copy = e->theta.p; D.src_lds = 1;
         D.chi2_host = e->dpin_chi2; D.status_host = e->dpin_status;
+    } else if (d_theta) {
+        // device entry point, eager launches: the first kernel reads the caller's walkers in place and the last one
+        // writes the caller's outputs - no staging copies
+        D.theta_host = d_theta; D.theta_copy = e->theta.p; D.src_lds = 0;
+        D.chi2_host = d_chi2; D.status_host = d_status;
     }
     const int n_pipe = D.n_pipe;
     {
@@ -1383,10 +1389,17 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     REQUIRE(e && e->finalized && d_theta, "vmx_eval_device");
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
-    HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    if (run_chain_cached(e, B, e->const_hint && B >= 16)) return -2;
-    if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
+    if (B >= 64 || !e->use_graphs || e->profiling) {
+        // large batches: eager launches cost nothing next to the kernels, and they let the chain read / write the
+        // caller's buffers directly (a captured graph would pin their addresses)
+        const bool tab = e->const_hint && B >= 16 && e->n_xtab > 0;
+        if (run_chain(e, B, tab, false, d_theta, d_chi2, d_status)) return -2;
+    } else {
+        HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        if (run_chain_cached(e, B, e->const_hint && B >= 16)) return -2;
+        if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
+    }
     if (d_model) HIP_OK(hipMemcpyAsync(d_model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     return 0;
 }

@@ -135,6 +135,8 @@ struct EngineDev {
     // small host batches skip the staging copies: k_prologue reads the walkers from mapped pinned host memory and
     // leaves a device copy in `theta_copy` (= theta) for the later kernels; k_chi2 stores its results to host too
     const double* theta_host; double* theta_copy; double* chi2_host; int32_t* status_host;
+    int32_t src_lds;            // 1: theta_host is mapped host memory, staged through LDS by one block (tiny batches);
+                                // 0: theta_host is the caller's device buffer, read in place (large batches, eager launches)
     double* scal;               // [B][n_pipe][VMX_NS]
     double* metal_bias;         // [B][3][n_metals_total]: bias product x multiplicity, beta1 + beta2, beta1 * beta2
     double beta_override; int32_t beta_override_on;      // set-up hook: betas of the bias-free metal pipelines
@@ -185,7 +187,7 @@ __global__ void k_prologue(EngineDev D, int B)
             const vmx_pipe_desc& dg = D.pipes[D.xtab_pipe[g]].d;
             int dirty = 0;
             for (int i = 0; i < 6; ++i) {
-                const double v = dg.arinyo_slot[i] >= 0 ? D.theta[dg.arinyo_slot[i]] : 0.0;
+                const double v = dg.arinyo_slot[i] >= 0 ? (D.theta_host ? D.theta_host : D.theta)[dg.arinyo_slot[i]] : 0.0;
                 if (!(D.xtab_key[g * 6 + i] == v)) dirty = 1;       // keys start as NaN
                 D.xtab_key[g * 6 + i] = v;
             }
@@ -193,7 +195,8 @@ __global__ void k_prologue(EngineDev D, int B)
         }
     }
     const double* t = D.theta + (size_t)b * D.n_params;
-    if (D.theta_host) {
+    const double* t0 = D.theta_host ? D.theta_host : D.theta;         // walker 0, for the constant-parameter check
+    if (D.theta_host && D.src_lds) {
         // zero-copy entry (small batches, one block): one coalesced read of the walkers from mapped host memory into
         // LDS - a single PCIe round trip instead of one per parameter lookup - and the device copy for later kernels
         extern __shared__ double s_theta[];
@@ -203,6 +206,11 @@ __global__ void k_prologue(EngineDev D, int B)
         t = s_theta + (size_t)b * D.n_params;
     }
     if (b >= B) return;
+    if (D.theta_host && !D.src_lds) {
+        // the caller's device buffer is read in place; the threads of a walker leave the copy the later kernels use
+        t = D.theta_host + (size_t)b * D.n_params;
+        for (int i = slot; i < D.n_params; i += D.n_pipe + 1) D.theta_copy[(size_t)b * D.n_params + i] = t[i];
+    }
 
     if (slot < D.n_pipe) {
         const int p = slot;
@@ -325,7 +333,7 @@ __global__ void k_prologue(EngineDev D, int B)
     }
     int st = 0;
     for (int q = 0; q < D.n_const_slots; ++q)
-        if (t[D.const_slots[q]] != D.theta[D.const_slots[q]]) st = VMX_STATUS_NOT_CONSTANT;
+        if (t[D.const_slots[q]] != t0[D.const_slots[q]]) st = VMX_STATUS_NOT_CONSTANT;
     D.status[b] = st;
     D.chi2[b] = 0.0;
 }
@@ -1544,7 +1552,8 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabI
         int st = D.status[b];
         if (!(c == c) || c > 1e300 || c < -1e300) { st |= VMX_STATUS_NONFINITE; D.status[b] = st; }
         D.chi2[b] = st ? 1e100 : c;
-        if (D.chi2_host) { D.chi2_host[b] = st ? 1e100 : c; D.status_host[b] = st; }
+        if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
+        if (D.status_host) D.status_host[b] = st;
         if (b == 0) { D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1; }      // the next evaluation starts from an empty window
     }
 }
