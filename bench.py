@@ -239,6 +239,8 @@ def main():
                     help='calibration + warm-up + timed steps only (the command the rocprofv3 summaries in profiles/ use)')
     ap.add_argument('--no-static-metals', action='store_true', help='keep every metal pair on its own pipeline')
     ap.add_argument('--force-dist', action='store_true', help='run the collective path even with one rank')
+    ap.add_argument('--lanes', type=int, default=1,
+                    help='independent engines per GPU; step i runs on lane i %% lanes, so consecutive steps overlap')
     args = ap.parse_args()
 
     import torch
@@ -265,15 +267,23 @@ def main():
 
     B = args.batch
     prob = build_problem(args.workload)
-    vega = VegaInterface(None, problem=prob, max_batch=B, device=local_rank)
-    vega.freeze_metals()            # fast_metals workloads: the first evaluation (fiducial point) fills the metal caches
-    if not args.no_static_metals:
-        vega.freeze_static_metals() # polynomial metal pairs -> their exact static Kaiser basis (no-op without metals)
-    eng = vega.engine
     dev = torch.device('cuda', local_rank)
-    # the walkers of SURVEY 8d vary biases, betas, alphas, HCD and velocity-dispersion parameters; the Arinyo
-    # non-linear parameters are shared by a batch, which the device entry point is told (violations are flagged)
-    eng.set_constant_nl_hint(True)
+    vegas = []
+    # the two-lane section below (two engines, consecutive steps overlapping) needs a second engine
+    n_engines = max(args.lanes, 1) if args.core_only or world > 1 else max(args.lanes, 2)
+    for _ in range(n_engines):
+        v = VegaInterface(None, problem=prob, max_batch=B, device=local_rank)
+        v.freeze_metals()           # fast_metals workloads: the first evaluation (fiducial point) fills the metal caches
+        if not args.no_static_metals:
+            v.freeze_static_metals()    # polynomial metal pairs -> their exact static Kaiser basis (no-op without metals)
+        # the walkers of SURVEY 8d vary biases, betas, alphas, HCD and velocity-dispersion parameters; the Arinyo
+        # non-linear parameters are shared by a batch, which the device entry point is told (violations are flagged)
+        v.engine.set_constant_nl_hint(True)
+        vegas.append(v)
+    vega = vegas[0]
+    eng = vega.engine
+    engines = [v.engine for v in vegas]
+    L = max(args.lanes, 1)
 
     # distinct walker batches per step and per rank, resident in HBM before timing
     n_pool = min(args.steps, 8)
@@ -285,20 +295,26 @@ def main():
             host_theta = th
         pools.append(torch.from_numpy(th).to(dev))
     # two output / gather buffer pairs: the collective of step i runs on its own stream while step i + 1 computes
-    chi2_bufs = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(2)]
-    gathered = [torch.zeros(world * B, dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
-    eng_stream = torch.cuda.ExternalStream(eng.stream_handle(), device=dev)
+    nslot = 2 * len(engines)
+    chi2_bufs = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(nslot)]
+    gathered = [torch.zeros(world * B, dtype=torch.float64, device=dev) for _ in range(nslot)] if use_dist else None
+    eng_streams = [torch.cuda.ExternalStream(e.stream_handle(), device=dev) for e in engines]
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
-    comm_done = [None, None]
+    comm_done = [None] * nslot
 
-    def step(i):
-        slot = i % 2
+    def sync_all():
+        for e in engines:
+            e.sync()
+
+    def step(i, lanes=L):
+        slot = i % nslot
+        lane = i % lanes
         if use_dist and comm_done[slot] is not None:
-            eng_stream.wait_event(comm_done[slot])      # the gather that last read this buffer pair has finished
-        eng.eval_device(pools[i % n_pool].data_ptr(), B, chi2_bufs[slot].data_ptr())
+            eng_streams[lane].wait_event(comm_done[slot])   # the gather that last read this buffer pair has finished
+        engines[lane].eval_device(pools[i % n_pool].data_ptr(), B, chi2_bufs[slot].data_ptr())
         if use_dist:
             # one all_gather of chi2 per step, ordered after the evaluation by an event: no host synchronisation
-            comm_stream.wait_event(eng_stream.record_event())
+            comm_stream.wait_event(eng_streams[lane].record_event())
             with torch.cuda.stream(comm_stream):
                 dist.all_gather_into_tensor(gathered[slot], chi2_bufs[slot])
                 comm_done[slot] = comm_stream.record_event()
@@ -307,13 +323,16 @@ def main():
     # the dominant class.  Event pairs around all ~20 launches of a step cost ~7 % of throughput, so the timed
     # region below keeps them around the dominant class only (< 1 %): its launch durations are still measured live,
     # over the timed region, on the streams the kernels run on.
-    eng.set_profiling(True)
-    for i in range(max(args.warmup, 3)):
+    for i in range(max(args.warmup, 3) * L):
         step(i)
+    sync_all()
+    eng.set_profiling(True)
+    for i in range(3):
+        step(i * L)                 # lane 0 alone: uncontended kernel durations
     eng.sync()
     eng.timings(reset=True)
     for i in range(5):
-        step(i)
+        step(i * L)
     eng.sync()
     breakdown = eng.timings(reset=True)
     dominant = max((k for k, v in breakdown.items() if v[1]), key=lambda k: breakdown[k][0])
@@ -323,7 +342,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    eng.sync()
+    sync_all()
     torch.cuda.synchronize()
     eng.timings(reset=True)
     if use_dist:
@@ -332,13 +351,32 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    eng.sync()
+    sync_all()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timings = eng.timings(reset=True)
     eng.set_profiling(False)
+
+    two_lanes = None
+    if len(engines) > L and not use_dist:
+        # Two engines on the same GPU, consecutive steps alternating between them: one lane's launch tails and small
+        # kernels are filled by the other's work.  Reported beside `value`, not as it: co-running kernels share the
+        # chip, so per-launch durations (and with them the roofline fraction above) are only clean with one lane.
+        nl = len(engines)
+        for i in range(2 * nl):
+            step(i, nl)
+        sync_all()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, nl)
+        sync_all()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        two_lanes = {'lanes': nl, 'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
+                     'note': f'{nl} independent engines per GPU, step i on lane i % {nl}, B={B} walkers per step'}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
@@ -348,7 +386,7 @@ def main():
     if use_dist:
         # the gathered vector holds every rank's chi2 of the last step, rank-major
         torch.cuda.synchronize()
-        last = (args.steps - 1) % 2
+        last = (args.steps - 1) % nslot
         mine = gathered[last][rank * B:(rank + 1) * B]
         if not torch.equal(mine, chi2_bufs[last]) or not bool(torch.isfinite(gathered[last]).all()):
             raise SystemExit('all_gather of chi2 returned unexpected values')
@@ -406,6 +444,11 @@ def main():
         if roofline is not None:
             roofline['launches_timed'] = live[roof_class]['launches']
             roofline['timing'] = 'HIP events on the launch stream, over the timed region'
+            if L > 1:
+                # the lanes' kernels share the chip, so a launch timed live is slower than the same launch alone
+                roofline['timing'] += f' (lane 0 of {L}; the other lanes run concurrently)'
+                roofline['alone'] = {k: roofline_for(roof_class, kernels[roof_class]['ms_per_launch'])[k]
+                                     for k in ('achieved', 'frac', 'ms_per_launch', 'frac_of_issue_ceiling')}
         roofline_other = []
         for k, v in kernels.items():
             if k == roof_class:
@@ -437,17 +480,18 @@ def main():
                                    'ell=0,2,4,6, dense synthetic 2500^2 + 5000^2 distortion matrices and '
                                    '1590^2 + 3180^2 inverse covariances (BASELINE configs[2])'
                        if args.workload == 'joint' else args.workload,
-                       'batch_per_gpu': B, 'pipelines_per_eval': len(eng.pipe_index),
+                       'batch_per_gpu': B, 'lanes_per_gpu': L, 'pipelines_per_eval': len(eng.pipe_index),
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
-            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'cpu_baseline': cpu,
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
         }
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    vega.close()
+    for v in vegas:
+        v.close()
 
 
 if __name__ == '__main__':
