@@ -212,6 +212,13 @@ int vmx_item_set_metal_basis(vmx_engine* e, int32_t item, int32_t index, const d
  * (fast_metals) pipeline takes beta = `beta` instead of its parameters. */
 int vmx_set_metal_beta_override(vmx_engine* e, int32_t enabled, double beta);
 
+/* Parameter-level blinding (vega_interface.py:389-421 `_get_lcl_prms`, utils.py:375-393 `apply_blinding`): every
+ * walker is mapped theta[p] -> scale[p] * theta[p] + shift[p] before anything reads it (model and priors alike).
+ * The reference's blinding is shift = pi - exp(v^2) on the blinded names and (scale, shift) = (0, 1) on the
+ * full-shape scale parameters it pins to 1.  scale, shift: [n_params] host arrays, or NULL, NULL to switch it off.
+ * While a transform is set the device entry point stages the walkers through the engine's own buffer. */
+int vmx_set_parameter_transform(vmx_engine* e, const double* scale, const double* shift);
+
 /* Additive template of the non-peak component: v += amp * vec[bin] before the pre-distortion broadband
  * (DESI instrumental systematics, model.py:133-135, correlation_func.py:553-595).  amp = theta[slot], or
  * default_amp when slot = -1. */

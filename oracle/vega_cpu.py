@@ -719,11 +719,22 @@ def model_compute(prob, item, params, taps=None):
     return pars['bao_amp'] * xi_peak + xi_smooth
 
 
+BLIND_FIXED_PARS = ('ap_full', 'at_full', 'aiso_full', 'epsilon_full', 'phi_full')     # reference utils.py:16-18
+
+
 def local_params(prob, params=None):
-    """VegaInterface._get_lcl_prms without blinding (reference vega_interface.py:389-421)."""
+    """VegaInterface._get_lcl_prms (reference vega_interface.py:389-421) with utils.apply_blinding (utils.py:375-393):
+    ``prob.blinding_offsets`` plays the reference's ``_rnsps`` (None = no parameter-level blinding)."""
     out = dict(prob.params)
     if params is not None:
         out.update(params)
+    rnsps = getattr(prob, 'blinding_offsets', None)
+    if rnsps is not None:
+        for par, val in rnsps.items():
+            out[par] += (np.pi - np.exp(val**2))
+        for par in out:
+            if par in BLIND_FIXED_PARS:
+                out[par] = 1.
     return out
 
 

@@ -64,6 +64,28 @@ def fits_ingest_problem(tmp_path):
     return build_problem('configs/ingest/main.ini', search_dirs=[tmp_path, GOLDEN])
 
 
+def blinding_problem(tmp_path, sample_extra=''):
+    """The auto-correlation config on a `desi_dr3` data file (BLINDING header, DA_BLIND column next to DA; the file
+    tests/golden/make_golden.py::dump_blinding gave the reference) with a prior on a sampled parameter."""
+    import re
+    from vega_amd import synthetic
+    from vega_amd.setup import build_problem
+    from vega_amd.tables import read_tables
+    source = read_tables(GOLDEN / 'inputs' / 'cf_lya-exp.npz')
+    data_path = synthetic.write_data_file(tmp_path / 'cf_lya-blind.fits', source, with_distortion=False,
+                                          extra_header={'BLINDING': 'desi_dr3'},
+                                          blind_data=synthetic.blinded_data_vector(source[0].data['DA']))
+    cfg = tmp_path / 'configs' / 'blind'
+    cfg.mkdir(parents=True, exist_ok=True)
+    main = (GOLDEN / 'configs' / 'auto' / 'main.ini').read_text()
+    main = re.sub(r'ini files = .*', 'ini files = configs/blind/lyalya_lyalya.ini', main)
+    main = main.replace('[sample]', '[sample]\n' + sample_extra) + '\n[priors]\nbeta_LYA = gaussian 1.6 0.1\n'
+    (cfg / 'main.ini').write_text(main)
+    item = (GOLDEN / 'configs' / 'auto' / 'lyalya_lyalya.ini').read_text()
+    (cfg / 'lyalya_lyalya.ini').write_text(re.sub(r'filename = .*', f'filename = {data_path}', item, count=1))
+    return build_problem('configs/blind/main.ini', search_dirs=[tmp_path, GOLDEN])
+
+
 def marginalization_problem(tmp_path, options, in_fit=False):
     """fits_ingest_problem with small-scale marginalisation options added to the [model] section (and the templates
     fitted on the fly instead of folded into the covariance when ``in_fit``)."""

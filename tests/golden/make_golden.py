@@ -433,6 +433,51 @@ def dump_fits_ingest(VegaInterface):
         print('fits ingest: chi2', out['fid/chi2'], 'log_lik', out['fid/log_lik'], out['walker0/chi2'])
 
 
+def dump_blinding(VegaInterface):
+    """Blinding (reference vega/data.py:305-339, vega_interface.py:389-421, :853-886, utils.py:375-393): a `desi_dr3`
+    data file - the DA_BLIND column replaces DA - read by the unmodified reference, first without parameter
+    offsets (the reference has no offsets file for that strategy), then with `_rnsps` set by hand to pin
+    apply_blinding for model and priors alike."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        source = read_tables(REF / 'tests/data/cf_lya-exp.fits.gz')
+        data_path = synthetic.write_data_file(Path(tmp) / 'cf_lya-blind.fits', source, with_distortion=False,
+                                              extra_header={'BLINDING': 'desi_dr3'},
+                                              blind_data=synthetic.blinded_data_vector(source[0].data['DA']))
+        main = _ref_main(tmp, ['lyalya_lyalya'], False)
+        mp = Path(main)
+        mp.write_text(mp.read_text() + '\n[priors]\nbeta_LYA = gaussian 1.6 0.1\n')
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(re.sub(r'filename = .*', f'filename = {data_path}', item.read_text(), count=1))
+        vega = VegaInterface(main)
+        assert vega._blind and vega._rnsps is None and vega.data['lyalya_lyalya'].blind
+        out = {'plain/chi2': vega.chi2(), 'plain/log_lik': vega.log_lik()}
+        vega._rnsps = synthetic.blinding_offsets()
+        _reset_caches(vega)
+        out['offsets/chi2'] = vega.chi2()
+        out['offsets/log_lik'] = vega.log_lik()
+        out['offsets/prior_chi2'] = vega.compute_prior_chi2()
+        out['offsets/model'] = vega.compute_model(run_init=False)['lyalya_lyalya']
+        names, walkers = make_walkers(vega.params, 2, seed=WALKER_SEED + 6)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+        vals = []
+        for w in walkers:
+            _reset_caches(vega)
+            vals.append(vega.chi2(w))
+        out['offsets/walker_chi2'] = np.array(vals)
+        # sampling a blinded parameter on such data is an error in the reference
+        mp.write_text(mp.read_text().replace('[sample]', '[sample]\ngrowth_rate = True'))
+        try:
+            VegaInterface(main)
+            out['sampled_blinded_error'] = np.array('')
+        except ValueError as err:
+            out['sampled_blinded_error'] = np.array(str(err))
+        np.savez_compressed(HERE / 'expected_blinding.npz', **out)
+        print('blinding:', {k: v for k, v in out.items() if np.ndim(v) == 0})
+
+
 def dump_marginalization(VegaInterface):
     """Small-scale marginalisation (reference vega/correlation_item.py:175-268, vega/data.py:96-128, :762-828): the
     covariance of the FITS data file of dump_fits_ingest updated with the distorted templates of the bins at
@@ -548,12 +593,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -576,3 +621,5 @@ if __name__ == '__main__':
         dump_marginalization(VI)
     if 'direct_pk' in what:
         dump_direct_pk(VI)
+    if 'blinding' in what:
+        dump_blinding(VI)

@@ -294,6 +294,40 @@ def test_fits_ingestion_through_the_engine(tmp_path):
     vega.close()
 
 
+def test_blinding_through_the_engine(tmp_path):
+    """Blinded data and parameter-level blinding (reference vega/data.py:305-339, vega_interface.py:389-421,
+    utils.py:375-393): host entry point (zero-copy and staged batches) and device entry point against what the
+    unmodified reference computed with the same offsets."""
+    import torch
+    from conftest import blinding_problem
+    from vega_amd import VegaInterface, synthetic
+    exp = np.load(GOLDEN / 'expected_blinding.npz')
+    vega = VegaInterface(None, problem=blinding_problem(tmp_path), max_batch=96)
+    assert vega._blind and vega._rnsps is None
+    assert vega.chi2() == pytest.approx(float(exp['plain/chi2']), rel=CHI2_RTOL)
+    assert vega.log_lik() == pytest.approx(float(exp['plain/log_lik']), rel=1e-9)
+    vega.set_blinding_offsets(synthetic.blinding_offsets())
+    assert vega.chi2() == pytest.approx(float(exp['offsets/chi2']), rel=CHI2_RTOL)
+    assert vega.log_lik() == pytest.approx(float(exp['offsets/log_lik']), rel=1e-9)
+    assert vega.compute_prior_chi2() == pytest.approx(float(exp['offsets/prior_chi2']), rel=1e-12)
+    _assert_xi(vega.compute_model()['lyalya_lyalya'], exp['offsets/model'], 'blinding')
+    names = [str(n) for n in exp['param_names']]
+    theta = np.stack([vega._theta(dict(zip(names, row))) for row in exp['theta']])
+    want = exp['offsets/walker_chi2']
+    np.testing.assert_allclose(vega.chi2_batch(theta), want, rtol=CHI2_RTOL)
+    big = np.tile(theta, (48, 1))                   # 96 walkers: staged host copy; eager path on device buffers
+    np.testing.assert_allclose(vega.chi2_batch(big), np.tile(want, 48), rtol=CHI2_RTOL)
+    d_theta = torch.from_numpy(big).cuda()
+    d_chi2 = torch.zeros(96, dtype=torch.float64, device='cuda')
+    vega.engine.eval_device(d_theta.data_ptr(), 96, d_chi2.data_ptr())
+    vega.engine.sync()
+    np.testing.assert_allclose(d_chi2.cpu().numpy(), np.tile(want, 48), rtol=CHI2_RTOL)
+    assert torch.equal(d_theta.cpu(), torch.from_numpy(big))        # the caller's walkers are left as they were
+    vega.set_blinding_offsets(None)
+    assert vega.chi2() == pytest.approx(float(exp['plain/chi2']), rel=CHI2_RTOL)
+    vega.close()
+
+
 def test_small_scale_marginalization_through_the_engine(tmp_path):
     """The covariance updated with the small-scale marginalisation templates at set-up (reference
     vega/data.py:96-128): chi2 and log-likelihood of the engine against the unmodified reference."""

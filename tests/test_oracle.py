@@ -297,6 +297,50 @@ def test_fits_ingestion_matches_reference(tmp_path):
     assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-10)
 
 
+def test_blinding_matches_reference(tmp_path):
+    """Blinded data (reference vega/data.py:305-339: DA_BLIND replaces DA for `desi_dr3`) and parameter-level
+    blinding (vega_interface.py:389-421, utils.py:375-393: p += pi - exp(v^2), seen by the model and the priors),
+    against the unmodified reference on the same file with `_rnsps` set to the same offsets."""
+    from conftest import blinding_problem
+    from vega_amd import synthetic
+    from vega_amd.setup import init_blinding
+    prob = blinding_problem(tmp_path)
+    exp = np.load(GOLDEN / 'expected_blinding.npz')
+    item = prob.items['lyalya_lyalya']
+    assert item.blind and item.blinding_strat == 'desi_dr3'
+    assert init_blinding(prob.items, prob.sample_params) == (True, [])
+    assert oc.chi2(prob) == pytest.approx(float(exp['plain/chi2']), rel=1e-12)
+    assert oc.log_lik(prob) == pytest.approx(float(exp['plain/log_lik']), rel=1e-12)
+    prob.blinding_offsets = synthetic.blinding_offsets()
+    assert oc.chi2(prob) == pytest.approx(float(exp['offsets/chi2']), rel=1e-12)
+    assert oc.log_lik(prob) == pytest.approx(float(exp['offsets/log_lik']), rel=1e-12)
+    assert oc.prior_chi2(prob) == pytest.approx(float(exp['offsets/prior_chi2']), rel=1e-12)
+    model = oc.compute_model(prob)['lyalya_lyalya']
+    assert np.abs(model - exp['offsets/model']).max() <= 1e-13 * np.abs(model).max()
+    for row, want in zip(exp['theta'], exp['offsets/walker_chi2']):
+        pars = {str(n): float(v) for n, v in zip(exp['param_names'], row)}
+        assert oc.chi2(prob, pars) == pytest.approx(float(want), rel=1e-12)
+
+
+def test_blinding_checks_mirror_the_reference(tmp_path):
+    """vega_interface.py:853-886: sampling a blinded parameter on `desi_dr3` data stops with the reference's own
+    message (it has no offsets file for that strategy); the full-shape scale parameters must stay fixed."""
+    from conftest import blinding_problem
+    from vega_amd.setup import init_blinding, blinding_transform
+    exp = np.load(GOLDEN / 'expected_blinding.npz')
+    prob = blinding_problem(tmp_path, sample_extra='growth_rate = True')
+    with pytest.raises(ValueError) as err:
+        init_blinding(prob.items, prob.sample_params)
+    assert str(err.value) == str(exp['sampled_blinded_error'])
+    sampled = {'limits': {'ap_full': (0.5, 1.5)}}
+    with pytest.raises(ValueError, match='ap_full must be fixed'):
+        init_blinding(prob.items, sampled)
+    with pytest.raises(ValueError, match='bias_QSO and beta_QSO'):
+        init_blinding(prob.items, {'limits': {'bias_QSO': (0, 1), 'beta_QSO': (0, 1)}})
+    scale, shift = blinding_transform(['ap', 'ap_full', 'beta_LYA'], {'ap': 0.3})
+    assert scale.tolist() == [1.0, 0.0, 1.0] and shift.tolist() == [np.pi - np.exp(0.09), 1.0, 0.0]
+
+
 @pytest.mark.parametrize('tag', ['rtmax', 'allrmin', 'fitscales'])
 def test_small_scale_marginalization_matches_reference(tmp_path, tag):
     """Small-scale marginalisation (reference vega/correlation_item.py:175-268, vega/data.py:96-128, :762-828): the

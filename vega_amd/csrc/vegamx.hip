@@ -177,6 +177,8 @@ struct vmx_engine {
 
     // host path: pinned staging buffers and one captured graph per batch size
     double* pin_theta = nullptr; double* pin_chi2 = nullptr; int32_t* pin_status = nullptr;
+    std::vector<double> blind_scale, blind_shift;       // parameter-level blinding (empty = off); device copy [2][n_params]
+    DevBuf<double> d_blind;
     double* dpin_theta = nullptr; double* dpin_chi2 = nullptr; int32_t* dpin_status = nullptr;   // device views
     std::map<int, hipGraphExec_t> graphs;
     bool use_graphs = true;
@@ -683,6 +685,22 @@ int vmx_item_set_metal_basis(vmx_engine* e, int32_t item, int32_t index, const d
     HIP_OK(hipSetDevice(e->device));
     if (upload_padded(m->basis, basis, 3, n_model, vmx_pad(n_model))) return -2;
     m->dev.basis = m->basis.p;
+    return 0;
+}
+
+int vmx_set_parameter_transform(vmx_engine* e, const double* scale, const double* shift)
+{
+    REQUIRE(e && e->finalized, "vmx_set_parameter_transform");
+    REQUIRE((scale == nullptr) == (shift == nullptr), "scale and shift are given together");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    e->blind_scale.clear(); e->blind_shift.clear();
+    if (!scale) return 0;
+    e->blind_scale.assign(scale, scale + e->n_params);
+    e->blind_shift.assign(shift, shift + e->n_params);
+    if (e->d_blind.n < (size_t)2 * e->n_params && e->d_blind.alloc((size_t)2 * e->n_params)) return -2;
+    HIP_OK(hipMemcpy(e->d_blind.p, scale, (size_t)e->n_params * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(e->d_blind.p + e->n_params, shift, (size_t)e->n_params * sizeof(double), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1389,7 +1407,15 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     REQUIRE(e && e->finalized && d_theta, "vmx_eval_device");
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
-    if (B >= 64 || !e->use_graphs || e->profiling) {
+    if (!e->blind_scale.empty()) {
+        // parameter-level blinding: the walkers are transformed in the engine's own copy
+        HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        const int n = B * e->n_params;
+        hipLaunchKernelGGL(k_theta_affine, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->theta.p, e->d_blind.p, e->n_params, n);
+        if (run_chain_cached(e, B, e->const_hint && B >= 16)) return -2;
+        if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
+    } else if (B >= 64 || !e->use_graphs || e->profiling) {
         // large batches: eager launches cost nothing next to the kernels, and they let the chain read / write the
         // caller's buffers directly (a captured graph would pin their addresses)
         const bool tab = e->const_hint && B >= 16 && e->n_xtab > 0;
@@ -1446,7 +1472,13 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     // one stores chi2 / status there, which removes three staging copies (~25 us of a ~100 us evaluation)
     const bool zero_copy = B <= 8 && B * ((int)e->pipes.size() + 1) <= 1024 && (size_t)B * e->n_params * sizeof(double) <= 48 * 1024 &&
                            e->dpin_theta && e->dpin_chi2 && e->dpin_status;
-    std::memcpy(e->pin_theta, theta, (size_t)B * e->n_params * sizeof(double));
+    if (e->blind_scale.empty()) std::memcpy(e->pin_theta, theta, (size_t)B * e->n_params * sizeof(double));
+    else        // parameter-level blinding, applied while staging (same expression as k_theta_affine)
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < e->n_params; ++i) {
+                const size_t o = (size_t)b * e->n_params + i;
+                e->pin_theta[o] = e->blind_scale[i] == 1.0 ? theta[o] + e->blind_shift[i] : e->blind_scale[i] * theta[o] + e->blind_shift[i];
+            }
     if (!zero_copy)
         HIP_OK(hipMemcpyAsync(e->theta.p, e->pin_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
     // the D_NL * G table pays off once a batch shares its Arinyo parameters (checked here, on the host copy)

@@ -1,6 +1,7 @@
 // Device-side data layout and kernels of the vegamx engine (gfx950 / CDNA4 only).
 //
 // Stage map (reference file:line each kernel replaces):
+//   k_theta_affine    parameter-level blinding of the walkers               vega_interface.py:389-421, utils.py:375-393
 //   k_prologue        parameters -> per-(walker, pipeline) scalars        utils.py:45-108, scale_parameters.py:38-230
 //   k_gk_table        G(k,mu) binning table (static)                       power_spectrum.py:481-502
 //   k_pk_multipoles   P(k,mu) and its Legendre projection, fused           power_spectrum.py:87-196 + pktoxi.py:138
@@ -173,6 +174,17 @@ __device__ inline void tracer_bias_beta(const double* t, const vmx_tracer& tr, d
     const double eta = has_eta ? t[tr.bias_eta_slot] : 0.0;
     if (!has_bias) bias = eta * gr / beta;
     if (!has_beta) beta = eta * gr / bias;
+}
+
+// parameter-level blinding (vega_interface.py:389-421, utils.py:375-393): theta -> scale * theta + shift, in place;
+// tr = [scale[n_params], shift[n_params]].  A unit scale is a plain addition, as the reference's `+=`.
+__global__ void k_theta_affine(double* theta, const double* tr, int n_params, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = i % n_params;
+    const double s = tr[p], sh = tr[n_params + p], t = theta[i];
+    theta[i] = s == 1.0 ? t + sh : s * t + sh;
 }
 
 __global__ void k_prologue(EngineDev D, int B)

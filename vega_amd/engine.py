@@ -142,6 +142,7 @@ def load_library():
     lib.vmx_item_set_metal_static.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
     lib.vmx_item_set_metal_basis.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_metal_beta_override.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+    lib.vmx_set_parameter_transform.argtypes = [C.c_void_p, dptr, dptr]
     lib.vmx_matmul_host.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_int32, dptr, C.c_int32, dptr]
     lib.vmx_pipeline_set_tracer_evolution.argtypes = [C.c_void_p, C.c_int32, dptr, dptr, C.c_int32]
     lib.vmx_set_profiling.argtypes = [C.c_void_p, C.c_int32]
@@ -161,7 +162,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -742,6 +743,17 @@ class Engine:
             return
         pk = _f64(np.atleast_2d(pk))
         self._check(self.lib.vmx_set_direct_pk(self._h, _dp(pk), pk.shape[0], pk.shape[1]))
+
+    def set_parameter_transform(self, scale=None, shift=None):
+        """Parameter-level blinding: every walker becomes scale * theta + shift (per column) before the model and the
+        priors read it; None switches it off."""
+        if scale is None:
+            self._check(self.lib.vmx_set_parameter_transform(self._h, None, None))
+            return
+        scale, shift = _f64(scale), _f64(shift)
+        if scale.shape != (self.n_params,) or shift.shape != (self.n_params,):
+            raise ValueError('scale and shift hold one value per parameter column')
+        self._check(self.lib.vmx_set_parameter_transform(self._h, _dp(scale), _dp(shift)))
 
     def set_metal_beta_override(self, beta=None):
         """Set-up hook: every tracer of a bias-free metal pipeline takes ``beta`` (None: back to the parameters)."""

@@ -55,6 +55,10 @@ class VegaInterface:
         self.monte_carlo = False
         self._mc_active = False
         self._engine_args = dict(max_batch=max_batch, device=device, extra_names=extra_names)
+        # parameter-level blinding (reference vega_interface.py:123-127, :853-886): checked before anything is computed
+        from .setup import init_blinding
+        self._blind, _ = init_blinding(self.problem.items, self.sample_params)
+        self._rnsps = None
         self.engine = Engine(self.problem, **self._engine_args)
         self.param_names = self.engine.names
         # fast_metals: the reference fills its metal caches at the first evaluation (metals_plan.py)
@@ -62,6 +66,32 @@ class VegaInterface:
         self._pinned_slots = np.zeros(0, dtype=np.int64)
         self._pinned_values = np.zeros(0)
         self._pinned_names = []
+
+    # ------------------------------------------------------------------ blinding
+    def set_blinding_offsets(self, offsets):
+        """Install the parameter offsets ``{name: v}`` of a blinding file (the reference's ``_rnsps``, read by
+        utils.get_blinding:320-372 from collaboration files it only names for some strategies): from then on every
+        evaluation - scalar, batched or on device buffers - sees p + pi - exp(v^2) for those parameters and 1 for
+        the full-shape scale parameters, model and priors alike (vega_interface.py:389-421).  None removes them."""
+        if offsets is not None and not self._blind:
+            # the reference asserts the same inconsistency (vega_interface.py:409-413)
+            raise AssertionError('Blinding offsets (_rnsps) are set but blinding flag is False.')
+        self._rnsps = dict(offsets) if offsets is not None else None
+        self._push_blinding()
+
+    def _push_blinding(self):
+        if self._rnsps is None:
+            self.engine.set_parameter_transform(None, None)
+            return
+        from .setup import blinding_transform
+        self.engine.set_parameter_transform(*blinding_transform(self.param_names, self._rnsps))
+
+    def _blinded(self, theta):
+        if self._rnsps is None:
+            return theta
+        from .setup import blinding_transform
+        scale, shift = blinding_transform(self.param_names, self._rnsps)
+        return np.where(scale == 1.0, theta + shift, scale * theta + shift)
 
     # ------------------------------------------------------------------ parameter marshalling
     def _theta(self, params=None):
@@ -88,6 +118,7 @@ class VegaInterface:
         boot.close()
         self.engine = Engine(self.problem, metal_plan=plan, **self._engine_args)
         assert self.engine.names == self.param_names
+        self._push_blinding()
         self._pinned_slots = np.array([self.engine.low.slot[n] for n in pinned], dtype=np.int64)
         self._pinned_values = np.array(list(pinned.values()), dtype=np.float64)
         self._pinned_names = list(pinned)
@@ -111,6 +142,7 @@ class VegaInterface:
         old.close()
         self.engine = Engine(self.problem, metal_plan=plan, **self._engine_args)
         assert self.engine.names == self.param_names
+        self._push_blinding()
         merged = dict(zip(self._pinned_names, self._pinned_values))
         merged.update(pinned)
         self._pinned_names = list(merged)
@@ -217,7 +249,7 @@ class VegaInterface:
         return log_norm
 
     def compute_prior_chi2(self, params=None):
-        theta = self._theta(params)
+        theta = self._blinded(self._theta(params))
         total = 0.
         for name, (mean, sigma) in self.priors.items():
             total += (theta[self.engine.low.slot[name]] - mean)**2 / sigma**2

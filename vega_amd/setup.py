@@ -7,9 +7,8 @@ the constructors of ``PowerSpectrum`` / ``PktoXi`` / ``CorrelationFunction`` / `
 ``BroadbandPolynomials``.  It reads the same ``.ini`` keys and produces plain arrays and option
 records; nothing here is evaluated per likelihood call.
 
-Options outside the hot-path scope (SURVEY.md section 8 "next": new_metals matrix construction,
-small-scale marginalisation, blinding offsets, DESI instrumental systematics,
-UV shot noise) raise ``NotImplementedError`` instead of being silently ignored.
+Options outside the hot-path scope (new_metals matrix construction, a parameter-dependent mock binning
+kernel, ...) raise ``NotImplementedError`` instead of being silently ignored.
 """
 import configparser
 import os
@@ -25,6 +24,64 @@ from scipy.interpolate import interp1d
 from .tables import find_file, read_tables
 
 TRUE_WORDS = ('True', 'true', 't', 'y', 'yes')
+
+# blinding (reference vega/data.py:9, vega/utils.py:16-25)
+BLINDING_STRATEGIES = ('desi_dr3',)
+BLIND_FIXED_PARS = ('ap_full', 'at_full', 'aiso_full', 'epsilon_full', 'phi_full')
+VEGA_BLINDED_PARS = {'phi_smooth': ('all',), 'growth_rate': ('all',)}
+
+
+def init_blinding(items, sample_params):
+    """Parameter-level blinding checks of the reference (vega/vega_interface.py:853-886): returns (blind, names of the
+    sampled parameters that must carry an offset).  The offsets themselves live in collaboration files the
+    reference names per strategy (vega/utils.py:320-372); it has none for `desi_dr3`, so sampling a blinded parameter
+    on such data is the reference's ValueError."""
+    strat = None
+    blind = False
+    for item in items.values():
+        if getattr(item, 'blind', False):
+            blind = True
+            if strat is None:
+                strat = item.blinding_strat
+            elif strat != item.blinding_strat:
+                raise ValueError('Different blinding strategies found in the data sets.')
+    if not blind:
+        return False, []
+    sampled = sample_params.get('limits', {})
+    blind_pars = []
+    for par in sampled:
+        if par in BLIND_FIXED_PARS:
+            raise ValueError(f'Running on blind data, parameter {par} must be fixed.')
+        if par not in VEGA_BLINDED_PARS:
+            continue
+        tracers = VEGA_BLINDED_PARS[par]
+        # reference correlation_item.py:153-173
+        if any('all' in tracers or any(t in item.tracer1.name or t in item.tracer2.name for t in tracers)
+               for item in items.values()):
+            blind_pars.append(par)
+    if blind_pars:
+        # reference utils.get_blinding: only desi_y1 / desi_y3 are known there, both without an offsets file
+        if strat not in ('desi_y1', 'desi_y3'):
+            raise ValueError(f'Unknown blinding version: {strat}.')
+        blind_pars = []
+    if 'bias_QSO' in sampled and 'beta_QSO' in sampled:
+        raise ValueError('Running on blind data and sampling bias_QSO and beta_QSO.')
+    return True, blind_pars
+
+
+def blinding_transform(names, offsets):
+    """(scale, shift) per parameter column for blinding offsets {name: v}: p += pi - exp(v^2) on the blinded names
+    and the full-shape scale parameters pinned to 1 (reference vega/utils.py:375-393, vega_interface.py:413-419)."""
+    scale, shift = np.ones(len(names)), np.zeros(len(names))
+    for i, name in enumerate(names):
+        if name in offsets:
+            shift[i] = np.pi - np.exp(offsets[name]**2)
+        if name in BLIND_FIXED_PARS:
+            scale[i], shift[i] = 0.0, 1.0
+    unknown = set(offsets) - set(names)
+    if unknown:
+        raise KeyError(f'blinding offsets for parameters the model does not have: {sorted(unknown)}')
+    return scale, shift
 
 
 # --------------------------------------------------------------------------------------
@@ -652,10 +709,26 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     tabs = read_tables(find_file(d.get('filename'), search_dirs))
     t1 = tabs[0]
     hdr = t1.header
+    # blinding strategy of the file (reference vega/data.py:305-339): `desi_dr3` data are blinded (DA_BLIND must be
+    # there), the earlier DESI tags and none / None are not, anything else is an error
     blinding = hdr.get('BLINDING', None)
-    if blinding not in (None, 'none', 'None', 'desi_m2', 'desi_y1', 'desi_y3'):
-        raise NotImplementedError(f'blinded data ({blinding}) is not supported')
-    data_vec = np.asarray(t1.data['DA'], dtype=float)
+    if blinding in ('none', 'None'):
+        blinding = None
+    blind = False
+    if blinding in BLINDING_STRATEGIES:
+        blind = True
+        if blinding == 'desi_dr3' and 'DA_BLIND' not in t1.data:
+            raise AssertionError('Blinding failed, do not run!!!')
+        if 'DA_BLIND' in t1.data:
+            data_vec = np.asarray(t1.data['DA_BLIND'], dtype=float)
+        elif 'DA' in t1.data:
+            data_vec = np.asarray(t1.data['DA'], dtype=float)
+        else:
+            raise ValueError('No DA or DA_BLIND column found in data file.')
+    elif blinding is None or blinding in ('desi_m2', 'desi_y1', 'desi_y3'):
+        data_vec = np.asarray(t1.data['DA'], dtype=float)
+    else:
+        raise ValueError(f'Unknown blinding strategy {blinding}.')
     data_grid = Grid(hdr['RPMIN'], hdr['RPMAX'], hdr['RTMAX'], hdr['NP'], hdr['NT'],
                      rp=t1.data['RP'], rt=t1.data['RT'], z=t1.data['Z'])
 
@@ -850,6 +923,7 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     if marg:
         item.marg_templates, item.marg_diff2coeff = marg_templates, marg_diff2coeff
         item.marginalize_in_fit = bool(marginalize_in_fit)
+    item.blind, item.blinding_strat = blind, (blinding if blind else None)
     return item
 
 

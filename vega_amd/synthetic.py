@@ -70,7 +70,23 @@ def walkers(theta_fid, names, n, varied=None, seed=SEED, scale=0.02, limits=None
     return theta
 
 
-def write_data_file(path, source, with_distortion=True, with_covariance=True, extra_header=None):
+def blinded_data_vector(data_vec):
+    """Deterministic stand-in for a blinded data vector (the `DA_BLIND` column of a `desi_dr3` file)."""
+    data_vec = np.asarray(data_vec, dtype=float)
+    return 1.02 * data_vec + 1e-6 * np.sin(0.37 * np.arange(data_vec.size))
+
+
+BLINDING_SHIFTS = {'growth_rate': 0.03, 'ap': -0.01, 'bias_hcd': 0.004, 'beta_LYA': 0.02}
+
+
+def blinding_offsets(shifts=None):
+    """Offsets v whose blinding p += pi - exp(v^2) (reference vega/utils.py:375-393) moves each parameter by the
+    wanted amount."""
+    shifts = BLINDING_SHIFTS if shifts is None else shifts
+    return {name: float(np.sqrt(np.log(np.pi - d))) for name, d in shifts.items()}
+
+
+def write_data_file(path, source, with_distortion=True, with_covariance=True, extra_header=None, blind_data=None):
     """A correlation data file in the layout the reference reads (vega/data.py:285-421): HDU 1 = RP, RT, Z, DA (+ the
     synthetic distortion matrix `DM` and covariance `CO` of this module as vector columns) with the grid keywords,
     HDU 2 = the model-grid coordinates DMRP, DMRT, DMZ.  ``source`` is a reference-format table list
@@ -80,6 +96,8 @@ def write_data_file(path, source, with_distortion=True, with_covariance=True, ex
     rp, rt = np.asarray(t1.data['RP'], dtype=float), np.asarray(t1.data['RT'], dtype=float)
     cols = [('RP', 'D', rp), ('RT', 'D', rt), ('Z', 'D', t1.data['Z']), ('DA', 'D', t1.data['DA'])]
     n = rp.size
+    if blind_data is not None:      # a blinded data vector next to DA (reference vega/data.py:313-327)
+        cols.append(('DA_BLIND', 'D', np.asarray(blind_data, dtype=float)))
     if with_distortion:
         cols.append(('DM', f'{n}D', distortion_matrix(np.asarray(t2.data['DMRP'], dtype=float),
                                                      np.asarray(t2.data['DMRT'], dtype=float))))
