@@ -128,6 +128,10 @@ typedef struct {
     int32_t extra_bias_slot;        /* bias_<m1>_<m2> (separate-metal-auto-biases), -1 none */
     int32_t apply_bias;             /* fast_metal_bias: multiply by the bias product afterwards */
     double  multiplicity;           /* 2 for distinct metals in an auto-correlation (:238-239) */
+    int32_t amplitude_slot;         /* -1, or a parameter multiplying the contribution: with `no-metal-decomp = False`
+                                     * (model.py:120-123, :186) a pair enters twice, its smooth-spectrum pipeline as is
+                                     * and its peak-spectrum pipeline times bao_amp */
+    int32_t reserved;
 } vmx_metal_desc;
 
 typedef struct {

@@ -478,6 +478,32 @@ def dump_blinding(VegaInterface):
         print('blinding:', {k: v for k, v in out.items() if np.ndim(v) == 0})
 
 
+def dump_metal_decomp(VegaInterface):
+    """`no-metal-decomp = False` (reference model.py:120-123, :181-186): the 15 metal pairs of the auto-correlation
+    computed per component (smooth spectrum; peak spectrum with its broadening, times bao_amp) instead of once on
+    the full spectrum.  Fiducial point and two walkers."""
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_lyalya'], True)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(item.read_text().replace('[model]', '[model]\nno-metal-decomp = False'))
+        vega = VegaInterface(main)
+        assert not vega.models['lyalya_lyalya'].no_metal_decomp
+        out = {'fid/chi2': vega.chi2(), 'fid/model': vega.compute_model(run_init=False)['lyalya_lyalya']}
+        names, walkers = make_walkers(vega.params, 2, seed=WALKER_SEED + 7)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+        vals = []
+        for w in walkers:
+            _reset_caches(vega)
+            vals.append(vega.chi2(w))
+        out['chi2'] = np.array(vals)
+        _reset_caches(vega)
+        out['walker0/model'] = vega.compute_model(walkers[0], run_init=False)['lyalya_lyalya']
+        np.savez_compressed(HERE / 'expected_metal_decomp.npz', **out)
+        print('metal decomp: chi2', out['fid/chi2'], out['chi2'])
+
+
 def dump_marginalization(VegaInterface):
     """Small-scale marginalisation (reference vega/correlation_item.py:175-268, vega/data.py:96-128, :762-828): the
     covariance of the FITS data file of dump_fits_ingest updated with the distorted templates of the bins at
@@ -593,12 +619,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -623,3 +649,5 @@ if __name__ == '__main__':
         dump_direct_pk(VI)
     if 'blinding' in what:
         dump_blinding(VI)
+    if 'metal_decomp' in what:
+        dump_metal_decomp(VI)

@@ -52,11 +52,14 @@ def test_unsupported_options_fail_loudly():
     low = E.Lowering(prob)
     core = prob.items['lyalya_lyalya'].core
     core.pk.mock_bin_size, core.pk.mock_los_smoothing = 2.0, 'amplitude'     # a parameter-dependent binning kernel
+    prob.params['los_smooth_amp'] = 0.3
+    prob.sample_params['limits']['los_smooth_amp'] = (0., 1.)
     try:
         with pytest.raises(NotImplementedError):
             low.pipeline(_FakeEngine(), core, 'smooth')
     finally:
         core.pk.mock_bin_size, core.pk.mock_los_smoothing = None, None
+        del prob.params['los_smooth_amp'], prob.sample_params['limits']['los_smooth_amp']
     core.xi.single_multipole = 3
     try:
         with pytest.raises(ValueError):

@@ -297,6 +297,19 @@ def test_fits_ingestion_matches_reference(tmp_path):
     assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-10)
 
 
+def test_metal_decomposition_matches_reference():
+    """`no-metal-decomp = False` (reference model.py:120-123, :181-186): metals per component."""
+    prob = load_problem('auto_metals')
+    prob.items['lyalya_lyalya'].metal_opts['no_metal_decomp'] = False
+    exp = np.load(GOLDEN / 'expected_metal_decomp.npz')
+    assert oc.chi2(prob) == pytest.approx(float(exp['fid/chi2']), rel=1e-12)
+    model = oc.compute_model(prob)['lyalya_lyalya']
+    assert np.abs(model - exp['fid/model']).max() <= 1e-13 * np.abs(model).max()
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert oc.chi2(prob, pars) == pytest.approx(float(exp['chi2'][0]), rel=1e-12)
+    prob.items['lyalya_lyalya'].metal_opts['no_metal_decomp'] = True
+
+
 def test_blinding_matches_reference(tmp_path):
     """Blinded data (reference vega/data.py:305-339: DA_BLIND replaces DA for `desi_dr3`) and parameter-level
     blinding (vega_interface.py:389-421, utils.py:375-393: p += pi - exp(v^2), seen by the model and the priors),

@@ -306,10 +306,40 @@ def test_mock_binning():
         prob = _fresh('auto_mockbin')
         prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = los
         _check(prob, n_walkers=1)
+    # `amplitude`: the line-of-sight bin follows `los_smooth_amp` - static while that parameter is not sampled
     prob = _fresh('auto_mockbin')
     prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = 'amplitude'
+    prob.params['los_smooth_amp'] = 0.4
+    _check(prob, n_walkers=1, vary=['bias_eta_LYA', 'beta_LYA', 'ap', 'at', 'bias_hcd'])
+    prob = _fresh('auto_mockbin')
+    prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = 'amplitude'
+    prob.params['los_smooth_amp'] = 0.4
+    prob.sample_params['limits']['los_smooth_amp'] = (0., 1.)
     with pytest.raises(NotImplementedError):
         VegaInterface(None, problem=prob, max_batch=1)
+
+
+def test_metal_decomposition():
+    """`no-metal-decomp = False` (reference model.py:120-123, :181-186): every metal pair enters twice - its
+    smooth-spectrum pipeline, and its peak-spectrum pipeline (with the peak's broadening) times bao_amp.  Against
+    the unmodified reference."""
+    from vega_amd import VegaInterface
+    prob = _fresh('auto_metals')
+    prob.items['lyalya_lyalya'].metal_opts['no_metal_decomp'] = False
+    exp = np.load(GOLDEN / 'expected_metal_decomp.npz')
+    vega = VegaInterface(None, problem=prob, max_batch=2)
+    assert len(vega.engine.pipe_index) == 2 + 15        # (+ 15 peak pipelines that are not indexed)
+    assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    got = vega.compute_model()['lyalya_lyalya']
+    assert np.abs(got - exp['fid/model']).max() <= XI_RTOL * np.abs(exp['fid/model']).max()
+    names = [str(n) for n in exp['param_names']]
+    theta = np.stack([vega._theta(dict(zip(names, row))) for row in exp['theta']])
+    np.testing.assert_allclose(vega.chi2_batch(theta), exp['chi2'], rtol=CHI2_RTOL)
+    got = vega.compute_model(dict(zip(names, exp['theta'][0])))['lyalya_lyalya']
+    assert np.abs(got - exp['walker0/model']).max() <= XI_RTOL * np.abs(exp['walker0/model']).max()
+    vega.freeze_static_metals()                         # nothing is eligible: the engine stays as it is
+    assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    vega.close()
 
 
 def test_single_multipole():

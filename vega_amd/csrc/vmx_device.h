@@ -338,6 +338,7 @@ __global__ void k_prologue(EngineDev D, int B)
         tracer_bias_beta(t, d.tracer[0], gr, b1, be1);
         if (d.same_tracer) { b2 = b1; be2 = be1; } else tracer_bias_beta(t, d.tracer[1], gr, b2, be2);
         if (d.apply_bias) f *= b1 * b2 * th(t, d.extra_bias_slot, 1.0);
+        if (d.amplitude_slot >= 0) f *= t[d.amplitude_slot];
         double* mb = D.metal_bias + (size_t)b * 3 * D.n_metals_total;
         mb[m] = f;
         mb[D.n_metals_total + m] = be1 + be2;

@@ -67,7 +67,8 @@ class PipeDesc(C.Structure):
 class MetalDesc(C.Structure):
     _fields_ = [('pipeline', C.c_int32), ('tracer', Tracer * 2), ('same_tracer', C.c_int32),
                 ('growth_rate_slot', C.c_int32), ('growth_rate_default', C.c_double),
-                ('extra_bias_slot', C.c_int32), ('apply_bias', C.c_int32), ('multiplicity', C.c_double)]
+                ('extra_bias_slot', C.c_int32), ('apply_bias', C.c_int32), ('multiplicity', C.c_double),
+                ('amplitude_slot', C.c_int32), ('reserved', C.c_int32)]
 
 
 class ItemDesc(C.Structure):
@@ -333,14 +334,14 @@ class Lowering:
         if pk.mock_bin_size is not None:
             # a second binning factor (reference power_spectrum.py:143-160); static unless it follows a parameter
             mock_rp = mock_rt = pk.mock_bin_size
-            if pk.mock_los_smoothing == 'growth':
+            if pk.mock_los_smoothing in ('growth', 'amplitude'):
+                # the binning kernel follows a parameter: static as long as that parameter is not sampled
+                name = 'growth_rate' if pk.mock_los_smoothing == 'growth' else 'los_smooth_amp'
                 sampled = set((self.prob.sample_params or {}).get('limits', {}))
-                if 'growth_rate' in sampled:
-                    raise NotImplementedError('mock-los-smoothing = growth with a sampled growth_rate is not accelerated')
-                mock_rp *= 1 + params['growth_rate']
-            elif pk.mock_los_smoothing == 'amplitude':
-                raise NotImplementedError('mock-los-smoothing = amplitude (a parameter-dependent binning kernel) is '
-                                          'not accelerated')
+                if name in sampled:
+                    raise NotImplementedError(f'mock-los-smoothing = {pk.mock_los_smoothing} with a sampled {name} '
+                                              '(a parameter-dependent binning kernel) is not accelerated')
+                mock_rp *= 1 + params[name]
             elif pk.mock_los_smoothing == 'only-los':
                 mock_rt = 0.0
         if pk.use_gk or pk.mock_bin_size is not None:
@@ -533,14 +534,23 @@ class Engine:
 
             if item.metals:
                 opts = item.metal_opts
-                if not opts['no_metal_decomp']:
-                    raise NotImplementedError('no-metal-decomp = False is not accelerated')
                 main = (item.tracer1.name, item.tracer2.name)
                 override = prob.growth_rate if (opts['fast_metals'] and 'growth_rate' in low.slot
                                                 and prob.growth_rate is not None) else None
                 beta_subst = {}
                 plan = self.metal_plan.get(name)
+                # `no-metal-decomp = False` (reference model.py:120-123, :181-186): the metal terms are computed per
+                # component - on the smooth spectrum, and on the peak spectrum (with the peak's non-linear broadening)
+                # times bao_amp - instead of once on the full spectrum: every pair enters twice
+                if opts['no_metal_decomp']:
+                    components = [('full', prob.pk_full, -1)]
+                else:
+                    if opts['fast_metals'] or any(kind != 'pipeline' for kind, _ in plan or ()):
+                        raise NotImplementedError('no-metal-decomp = False with fast_metals is not accelerated (the '
+                                                  "reference's metal caches then ignore the component)")
+                    components = [('smooth', prob.pk_smooth, -1), ('peak', pk_peak, low.need('bao_amp'))]
                 pair_pid = {}
+                entry = 0
                 for mi, pair in enumerate(item.metals):
                     n1, n2 = pair.names
                     if opts['single_metal_beta']:
@@ -552,48 +562,53 @@ class Engine:
                     betas = (beta_subst.get(n1), beta_subst.get(n2))
                     fast = bool(opts['fast_metal_bias'])
                     kind, arg = plan[mi] if plan else ('pipeline', None)
-                    if kind == 'pipeline':
-                        pid = self._add_pipeline(
-                            low.pipeline(self, pair.pipeline, 'full', fast_metals=fast, beta_names=betas,
-                                         growth_rate_override=override), pair.pipeline, prob.pk_full)
-                        self.pipe_index[(name, pair.names)] = pid
-                        pair_pid[mi] = pid
-                    elif kind == 'share':
-                        pid = pair_pid[arg]     # the reference's per-call cache hands this pair the leader's xi
-                    else:
-                        pid = -1
-                    md = MetalDesc()
-                    md.pipeline = pid
-                    md.tracer[0] = low.tracer(pair.pipeline.tracer1, beta_name=betas[0])
-                    md.tracer[1] = low.tracer(pair.pipeline.tracer2, beta_name=betas[1])
-                    md.same_tracer = int(n1 == n2)
-                    if override is not None:
-                        md.growth_rate_slot, md.growth_rate_default = -1, override
-                    else:
-                        md.growth_rate_slot, md.growth_rate_default = low.s('growth_rate'), DEFAULT_GROWTH_RATE
-                    md.extra_bias_slot = -1
-                    if (not pair.cross_with_main) and opts['separate_metal_auto_biases'] and n1 != n2:
-                        found = [c for c in pair.auto_bias_names if c in low.slot]
-                        if not found:
-                            raise ValueError(f'Separate metal auto biases is on, but no {pair.auto_bias_names[0]} '
-                                             f'or {pair.auto_bias_names[1]} parameter found for {pair.names}.')
-                        md.extra_bias_slot = low.slot[found[0]]
-                    md.apply_bias = int(fast)
-                    md.multiplicity = 2.0 if pair.double_count else 1.0
-                    self._check(lib.vmx_item_add_metal(self._h, iid, C.byref(md)))
-                    self.metal_source[(name, mi)] = (n_metals_total, pid, pair.matrix is not None)
-                    n_metals_total += 1
-                    if kind == 'static':
-                        vec = _f64(arg)
-                        self._check(lib.vmx_item_set_metal_static(self._h, iid, mi, _dp(vec), vec.size))
-                    elif kind == 'basis':
-                        basis = _f64(arg)
-                        assert basis.shape == (3, item.model_grid.size)
-                        self._check(lib.vmx_item_set_metal_basis(self._h, iid, mi, _dp(basis), basis.shape[1]))
-                    elif pair.matrix is not None:
-                        dense = _f64(pair.matrix.toarray() if hasattr(pair.matrix, 'toarray') else pair.matrix)
-                        self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_METAL, mi, dense.shape[0],
-                                                            dense.shape[1], _dp(dense)))
+                    for component, pk_lin, amplitude_slot in components:
+                        if kind == 'pipeline':
+                            pid = self._add_pipeline(
+                                low.pipeline(self, pair.pipeline, component, fast_metals=fast, beta_names=betas,
+                                             growth_rate_override=override), pair.pipeline, pk_lin)
+                            if component != 'peak':
+                                self.pipe_index[(name, pair.names)] = pid
+                                pair_pid[mi] = pid
+                        elif kind == 'share':
+                            pid = pair_pid[arg]     # the reference's per-call cache hands this pair the leader's xi
+                        else:
+                            pid = -1
+                        md = MetalDesc()
+                        md.pipeline = pid
+                        md.amplitude_slot = amplitude_slot
+                        md.tracer[0] = low.tracer(pair.pipeline.tracer1, beta_name=betas[0])
+                        md.tracer[1] = low.tracer(pair.pipeline.tracer2, beta_name=betas[1])
+                        md.same_tracer = int(n1 == n2)
+                        if override is not None:
+                            md.growth_rate_slot, md.growth_rate_default = -1, override
+                        else:
+                            md.growth_rate_slot, md.growth_rate_default = low.s('growth_rate'), DEFAULT_GROWTH_RATE
+                        md.extra_bias_slot = -1
+                        if (not pair.cross_with_main) and opts['separate_metal_auto_biases'] and n1 != n2:
+                            found = [c for c in pair.auto_bias_names if c in low.slot]
+                            if not found:
+                                raise ValueError(f'Separate metal auto biases is on, but no {pair.auto_bias_names[0]} '
+                                                 f'or {pair.auto_bias_names[1]} parameter found for {pair.names}.')
+                            md.extra_bias_slot = low.slot[found[0]]
+                        md.apply_bias = int(fast)
+                        md.multiplicity = 2.0 if pair.double_count else 1.0
+                        self._check(lib.vmx_item_add_metal(self._h, iid, C.byref(md)))
+                        if component != 'peak':
+                            self.metal_source[(name, mi)] = (n_metals_total, pid, pair.matrix is not None)
+                        n_metals_total += 1
+                        if kind == 'static':
+                            vec = _f64(arg)
+                            self._check(lib.vmx_item_set_metal_static(self._h, iid, entry, _dp(vec), vec.size))
+                        elif kind == 'basis':
+                            basis = _f64(arg)
+                            assert basis.shape == (3, item.model_grid.size)
+                            self._check(lib.vmx_item_set_metal_basis(self._h, iid, entry, _dp(basis), basis.shape[1]))
+                        elif pair.matrix is not None:
+                            dense = _f64(pair.matrix.toarray() if hasattr(pair.matrix, 'toarray') else pair.matrix)
+                            self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_METAL, entry, dense.shape[0],
+                                                                dense.shape[1], _dp(dense)))
+                        entry += 1
 
             if item.inst_sys_table is not None:
                 vec = _f64(static_terms.instrumental_systematics_template(item))

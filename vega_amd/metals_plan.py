@@ -94,7 +94,7 @@ def _basis_eligible(problem, item, pair, sampled):
     bias-free Kaiser polynomial (reference power_spectrum.py:198-222) times static factors only and nothing else
     that is sampled enters its correlation function.  Returns the names of the unsampled parameters the Y depend on
     (to be pinned), or None."""
-    if not item.metal_opts['fast_metal_bias']:
+    if not item.metal_opts['fast_metal_bias'] or not item.metal_opts['no_metal_decomp']:
         return None
     pk, xi = pair.pipeline.pk, pair.pipeline.xi
     if pk.hcd_model is not None or pk.uvb or pk.heii or pk.small_scale_nl is not None:
