@@ -459,7 +459,7 @@ def main():
                 r['timing'] = 'HIP events over the timed region' if timed else 'calibration pass'
                 r['largest_total_time'] = k == dominant
                 roofline_other.append(r)
-        extras = not args.core_only
+        extras = not args.core_only and world == 1        # the side sections and the CPU baseline belong to the N = 1 run
         distortion = distortion_microbench(eng, torch) if extras else None
         single = single_point_latency(local_rank) if extras else None
         mc_fits = monte_carlo_fits(prob, local_rank) if extras and args.workload == 'joint' else None

@@ -86,6 +86,56 @@ def blinding_problem(tmp_path, sample_extra=''):
     return build_problem('configs/blind/main.ini', search_dirs=[tmp_path, GOLDEN])
 
 
+def new_bias_evol_problem(tmp_path):
+    """The cross-correlation with `new-bias-evolution = True` on a data file that carries a picca cosmology in its
+    header (the file tests/golden/make_golden.py::dump_new_bias_evol gave the reference)."""
+    import re
+    from vega_amd import synthetic
+    from vega_amd.setup import build_problem
+    from vega_amd.tables import read_tables
+    source = read_tables(GOLDEN / 'inputs' / 'xcf_lya-exp.npz')
+    data_path = synthetic.write_data_file(tmp_path / 'xdata.fits', source, with_distortion=False,
+                                          with_covariance=False, extra_header=synthetic.PICCA_COSMOLOGY_HEADER)
+    cfg = tmp_path / 'configs' / 'biasevol'
+    cfg.mkdir(parents=True, exist_ok=True)
+    main = (GOLDEN / 'configs' / 'joint' / 'main.ini').read_text()
+    (cfg / 'main.ini').write_text(re.sub(r'ini files = .*', 'ini files = configs/biasevol/lyalya_qso.ini', main))
+    text = (GOLDEN / 'configs' / 'joint' / 'lyalya_qso.ini').read_text()
+    text = re.sub(r'filename = .*', f'filename = {data_path}', text, count=1)
+    (cfg / 'lyalya_qso.ini').write_text(text.replace('[model]', '[model]\nnew-bias-evolution = True'))
+    return build_problem('configs/biasevol/main.ini', search_dirs=[tmp_path, GOLDEN])
+
+
+NEW_METALS_CASES = {'auto': ('auto_metals', 'lyalya_lyalya', 'cf_lya-exp.npz', False),
+                    'cross': ('joint_metals', 'lyalya_qso', 'xcf_lya-exp.npz', False),
+                    'auto_rp': ('auto_metals', 'lyalya_lyalya', 'cf_lya-exp.npz', True)}
+
+
+def new_metals_problem(tmp_path, tag):
+    """One correlation with `new_metals = True`: metal matrices built at set-up from the synthetic stacked-delta file
+    and object catalogue (the inputs tests/golden/make_golden.py::dump_new_metals gave the reference)."""
+    import re
+    from vega_amd import synthetic
+    from vega_amd.setup import build_problem
+    from vega_amd.tables import read_tables
+    config, item_name, data_file, rp_only = NEW_METALS_CASES[tag]
+    source = read_tables(GOLDEN / 'inputs' / data_file)
+    data_path = synthetic.write_data_file(tmp_path / 'data.fits', source, with_distortion=False,
+                                          with_covariance=False, extra_header=synthetic.PICCA_COSMOLOGY_HEADER)
+    stack = synthetic.write_stacked_deltas(tmp_path / 'stack.fits')
+    cat = synthetic.write_object_catalog(tmp_path / 'cat.fits')
+    cfg = tmp_path / 'configs' / 'newmetals'
+    cfg.mkdir(parents=True, exist_ok=True)
+    main = (GOLDEN / 'configs' / config / 'main.ini').read_text()
+    (cfg / 'main.ini').write_text(re.sub(r'ini files = .*', f'ini files = configs/newmetals/{item_name}.ini', main))
+    text = (GOLDEN / 'configs' / config / f'{item_name}.ini').read_text()
+    text = re.sub(r'filename = .*', f'filename = {data_path}\nweights-tracer1 = {stack}\n'
+                  f'weights-tracer2 = {cat if "qso" in item_name else stack}', text, count=1)
+    text = text.replace('[model]', '[model]\nnew_metals = True' + ('\nrp_only_metal_mats = True' if rp_only else ''))
+    (cfg / f'{item_name}.ini').write_text(text + '\n' + synthetic.METAL_MATRIX_SECTION)
+    return build_problem('configs/newmetals/main.ini', search_dirs=[tmp_path, GOLDEN]), item_name
+
+
 def marginalization_problem(tmp_path, options, in_fit=False):
     """fits_ingest_problem with small-scale marginalisation options added to the [model] section (and the templates
     fitted on the fly instead of folded into the covariance when ``in_fit``)."""

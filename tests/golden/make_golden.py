@@ -504,6 +504,80 @@ def dump_metal_decomp(VegaInterface):
         print('metal decomp: chi2', out['fid/chi2'], out['chi2'])
 
 
+NEW_METALS_CASES = {'auto': ('lyalya_lyalya', 'cf_lya-exp.fits.gz', False), 'cross': ('lyalya_qso', 'xcf_lya-exp.fits.gz', False),
+                    'auto_rp': ('lyalya_lyalya', 'cf_lya-exp.fits.gz', True)}
+
+
+def dump_new_metals(VegaInterface):
+    """`new_metals = True` (reference vega/metals.py:83-112, :389-752): metal matrices built at set-up from a stacked-
+    delta file / an object catalogue (synthetic, vega_amd.synthetic) instead of read from a picca file - full
+    (rp, rt) matrices for an auto- and a cross-correlation, the rp-only form for the auto-correlation.  picca being
+    absent, the reference runs on the restated wavelengths / comoving distance of tools/refshim/picca.  Dumps chi2 at
+    the fiducial point and one walker, and per pair the effective coordinates and the matrix applied to a probe."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    out = {}
+    for tag, (item_name, data_file, rp_only) in NEW_METALS_CASES.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            source = read_tables(REF / 'tests/data' / data_file)
+            data_path = synthetic.write_data_file(Path(tmp) / 'data.fits', source, with_distortion=False,
+                                                  with_covariance=False, extra_header=synthetic.PICCA_COSMOLOGY_HEADER)
+            stack = synthetic.write_stacked_deltas(Path(tmp) / 'stack.fits')
+            cat = synthetic.write_object_catalog(Path(tmp) / 'cat.fits')
+            main = _ref_main(tmp, [item_name], True)
+            item = Path(tmp) / f'{item_name}.ini'
+            text = re.sub(r'filename = .*', f'filename = {data_path}\nweights-tracer1 = {stack}\n'
+                          f'weights-tracer2 = {cat if "qso" in item_name else stack}', item.read_text(), count=1)
+            text = text.replace('[model]', '[model]\nnew_metals = True' + ('\nrp_only_metal_mats = True' if rp_only else ''))
+            item.write_text(text + '\n' + synthetic.METAL_MATRIX_SECTION)
+            vega = VegaInterface(main)
+            metals = vega.models[item_name].metals
+            assert metals.new_metals and metals.rp_only_metal_mats == rp_only
+            out[f'{tag}/chi2'] = vega.chi2()
+            out[f'{tag}/model'] = vega.compute_model(run_init=False)[item_name]
+            names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 8)
+            _reset_caches(vega)
+            out[f'{tag}/param_names'] = np.array(names)
+            out[f'{tag}/theta'] = np.array([[walkers[0][n] for n in names]])
+            out[f'{tag}/walker0/chi2'] = vega.chi2(walkers[0])
+            pairs = list(metals.rp_metal_dmats)
+            out[f'{tag}/pairs'] = np.array(['|'.join(p_) for p_ in pairs])
+            probe = np.cos(0.013 * np.arange(metals.size))
+            for i, pair in enumerate(pairs):
+                xi_obj = metals.Xi_metal[pair]
+                out[f'{tag}/pair{i}/r'] = xi_obj._r
+                out[f'{tag}/pair{i}/mu'] = xi_obj._mu
+                out[f'{tag}/pair{i}/z'] = xi_obj._z
+                out[f'{tag}/pair{i}/applied'] = metals.apply_metal_matrix(probe, pair)
+            print('new_metals', tag, out[f'{tag}/chi2'], out[f'{tag}/walker0/chi2'], len(pairs), 'pairs')
+    np.savez_compressed(HERE / 'expected_new_metals.npz', **out)
+
+
+def dump_new_bias_evol(VegaInterface):
+    """`new-bias-evolution = True` (reference correlation_func.py:238-299) on the cross-correlation, the cosmology
+    taken from the data file's header (picca's D_H restated in tools/refshim/picca): fiducial point, one walker."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        source = read_tables(REF / 'tests/data/xcf_lya-exp.fits.gz')
+        data_path = synthetic.write_data_file(Path(tmp) / 'xdata.fits', source, with_distortion=False,
+                                              with_covariance=False, extra_header=synthetic.PICCA_COSMOLOGY_HEADER)
+        main = _ref_main(tmp, ['lyalya_qso'], False)
+        item = Path(tmp) / 'lyalya_qso.ini'
+        text = re.sub(r'filename = .*', f'filename = {data_path}', item.read_text(), count=1)
+        item.write_text(text.replace('[model]', '[model]\nnew-bias-evolution = True'))
+        vega = VegaInterface(main)
+        assert vega.models['lyalya_qso'].Xi_core._use_new_bias_evol
+        out = {'fid/chi2': vega.chi2(), 'fid/model': vega.compute_model(run_init=False)['lyalya_qso']}
+        names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 9)
+        _reset_caches(vega)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[walkers[0][n] for n in names]])
+        out['walker0/chi2'] = vega.chi2(walkers[0])
+        np.savez_compressed(HERE / 'expected_new_bias_evol.npz', **out)
+        print('new bias evol: chi2', out['fid/chi2'], out['walker0/chi2'])
+
+
 def dump_marginalization(VegaInterface):
     """Small-scale marginalisation (reference vega/correlation_item.py:175-268, vega/data.py:96-128, :762-828): the
     covariance of the FITS data file of dump_fits_ingest updated with the distorted templates of the bins at
@@ -619,12 +693,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -651,3 +725,7 @@ if __name__ == '__main__':
         dump_blinding(VI)
     if 'metal_decomp' in what:
         dump_metal_decomp(VI)
+    if 'new_metals' in what:
+        dump_new_metals(VI)
+    if 'new_bias_evol' in what:
+        dump_new_bias_evol(VI)

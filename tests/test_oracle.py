@@ -310,6 +310,45 @@ def test_metal_decomposition_matches_reference():
     prob.items['lyalya_lyalya'].metal_opts['no_metal_decomp'] = True
 
 
+@pytest.mark.parametrize('tag', ['auto', 'cross', 'auto_rp'])
+def test_new_metals_matches_reference(tmp_path, tag):
+    """`new_metals = True` (reference vega/metals.py:83-112, :389-752): the matrices and effective coordinates built by
+    vega_amd/metal_matrices.py from a stacked-delta file / object catalogue against the ones the unmodified reference
+    built from the same files (both on the restated picca wavelengths and comoving distance), then chi2."""
+    from conftest import new_metals_problem
+    prob, name = new_metals_problem(tmp_path, tag)
+    exp = np.load(GOLDEN / 'expected_new_metals.npz')
+    item = prob.items[name]
+    pairs = [tuple(str(p).split('|')) for p in exp[f'{tag}/pairs']]
+    assert [m.names for m in item.metals] == pairs
+    probe = np.cos(0.013 * np.arange(item.model_grid.size))
+    for i, metal in enumerate(item.metals):
+        np.testing.assert_allclose(metal.pipeline.r, exp[f'{tag}/pair{i}/r'], rtol=1e-13)
+        np.testing.assert_allclose(metal.pipeline.mu, exp[f'{tag}/pair{i}/mu'], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(metal.pipeline.z, exp[f'{tag}/pair{i}/z'], rtol=1e-13)
+        want = exp[f'{tag}/pair{i}/applied']
+        assert np.abs(metal.matrix.dot(probe) - want).max() <= 1e-13 * np.abs(want).max()
+    assert oc.chi2(prob) == pytest.approx(float(exp[f'{tag}/chi2']), rel=1e-11)
+    model = oc.compute_model(prob)[name]
+    assert np.abs(model - exp[f'{tag}/model']).max() <= 1e-12 * np.abs(model).max()
+    pars = {str(n): float(v) for n, v in zip(exp[f'{tag}/param_names'], exp[f'{tag}/theta'][0])}
+    assert oc.chi2(prob, pars) == pytest.approx(float(exp[f'{tag}/walker0/chi2']), rel=1e-11)
+
+
+def test_new_bias_evolution_matches_reference(tmp_path):
+    """`new-bias-evolution` (reference correlation_func.py:238-299) with the cosmology of the data file's header:
+    against the unmodified reference on the same file (picca's D_H restated on both sides)."""
+    from conftest import new_bias_evol_problem
+    prob = new_bias_evol_problem(tmp_path)
+    exp = np.load(GOLDEN / 'expected_new_bias_evol.npz')
+    assert prob.items['lyalya_qso'].core.rel_z_evol_1 is not None
+    assert oc.chi2(prob) == pytest.approx(float(exp['fid/chi2']), rel=1e-11)
+    model = oc.compute_model(prob)['lyalya_qso']
+    assert np.abs(model - exp['fid/model']).max() <= 1e-13 * np.abs(model).max()
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-11)
+
+
 def test_blinding_matches_reference(tmp_path):
     """Blinded data (reference vega/data.py:305-339: DA_BLIND replaces DA for `desi_dr3`) and parameter-level
     blinding (vega_interface.py:389-421, utils.py:375-393: p += pi - exp(v^2), seen by the model and the priors),

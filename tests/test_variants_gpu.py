@@ -342,6 +342,24 @@ def test_metal_decomposition():
     vega.close()
 
 
+@pytest.mark.parametrize('tag', ['cross', 'auto_rp'])
+def test_new_metals_through_the_engine(tmp_path, tag):
+    """`new_metals = True`: metal matrices built at set-up (vega_amd/metal_matrices.py; reference
+    vega/metals.py:389-752) and applied by the engine like matrices read from a file - chi2 and model against the
+    unmodified reference on the same stacked-delta file / catalogue."""
+    from conftest import new_metals_problem
+    from vega_amd import VegaInterface
+    prob, name = new_metals_problem(tmp_path, tag)
+    exp = np.load(GOLDEN / 'expected_new_metals.npz')
+    vega = VegaInterface(None, problem=prob, max_batch=2)
+    assert vega.chi2() == pytest.approx(float(exp[f'{tag}/chi2']), rel=CHI2_RTOL)
+    got = vega.compute_model()[name]
+    assert np.abs(got - exp[f'{tag}/model']).max() <= XI_RTOL * np.abs(exp[f'{tag}/model']).max()
+    pars = {str(n): float(v) for n, v in zip(exp[f'{tag}/param_names'], exp[f'{tag}/theta'][0])}
+    assert vega.chi2(pars) == pytest.approx(float(exp[f'{tag}/walker0/chi2']), rel=CHI2_RTOL)
+    vega.close()
+
+
 def test_single_multipole():
     """`single_multipole = ell`: the model is xi_ell(r') alone, without its Legendre factor (reference pktoxi.py:122-155)."""
     for ell in (0, 2, 4):
@@ -350,10 +368,24 @@ def test_single_multipole():
         _check(prob, n_walkers=1)
 
 
+def test_new_bias_evolution_against_the_reference(tmp_path):
+    """`new-bias-evolution` with the cosmology of the data file: engine against the unmodified reference."""
+    from conftest import new_bias_evol_problem
+    from vega_amd import VegaInterface
+    exp = np.load(GOLDEN / 'expected_new_bias_evol.npz')
+    vega = VegaInterface(None, problem=new_bias_evol_problem(tmp_path), max_batch=2)
+    assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    got = vega.compute_model()['lyalya_qso']
+    assert np.abs(got - exp['fid/model']).max() <= XI_RTOL * np.abs(exp['fid/model']).max()
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert vega.chi2(pars) == pytest.approx(float(exp['walker0/chi2']), rel=CHI2_RTOL)
+    vega.close()
+
+
 def test_new_bias_evolution_with_a_file_cosmology():
     """`new-bias-evolution` (reference correlation_func.py:238-299): the QSO and the forest of a cross-correlation
     evolve with z -/+ rp / (2 D_H(z)), D_H from the picca cosmology of the data file's header (restated, picca being
-    absent: parity with the reference is unpinned for this option; engine against oracle here)."""
+    absent); engine against oracle here, the reference itself in the test above)."""
     from vega_amd.setup import picca_dist_hubble
     prob = _fresh('joint')
     cosmo = {'Omega_m': 0.315, 'Omega_k': 0., 'Omega_r': 7.9e-5, 'wl': -1.}

@@ -700,8 +700,7 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     if model_sec.getboolean('marginalize-all-rmin-cuts', False):
         marg['all-rmin'] = True
     fit_marg_scales = bool(marg) and model_sec.getboolean('fit-marginalized-scales', False)
-    if model_sec.getboolean('new_metals', False):
-        raise NotImplementedError('new_metals (metal-matrix construction) is outside the hot path')
+    new_metals = model_sec.getboolean('new_metals', False)
     if 'filename' not in d or not d.getboolean('has_datafile', True):
         raise NotImplementedError('correlation items without a data file are not supported')
 
@@ -830,12 +829,16 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
         for m in (in1 or []) + (in2 or []):
             catalog[m] = Tracer(m, 'continuous')
 
-        mtabs = read_tables(find_file(msec.get('filename'), search_dirs))
-        mh = mtabs[0].header
-        prefix = 'DM_BLIND_' if mh.get('BLINDING', 'none') != 'none' else 'DM_'
+        mtabs = mh = prefix = None
+        if not new_metals:
+            mtabs = read_tables(find_file(msec.get('filename'), search_dirs))
+            mh = mtabs[0].header
+            prefix = 'DM_BLIND_' if mh.get('BLINDING', 'none') != 'none' else 'DM_'
         pairs = []          # (tracers tuple as listed, column-name stem)
 
         def _stem(a, b):
+            if new_metals:
+                return None
             stem = f'{a}_{b}'
             return stem if mtabs[1].has('RP_' + stem) else f'{b}_{a}'
 
@@ -863,11 +866,31 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
         )
         if metal_opts['fast_metals'] or metal_opts['separate_metal_auto_biases']:
             metal_opts['fast_metal_bias'] = True
-        if model_sec.getboolean('rp_only_metal_mats', False):
-            raise NotImplementedError('rp_only_metal_mats belongs to new_metals')
+        rp_only = model_sec.getboolean('rp_only_metal_mats', False)
+        if rp_only and not new_metals:
+            raise ValueError('rp_only_metal_mats needs new_metals = True (matrices read from a file are full ones)')
 
         stored = {}
+        builder = None
+        if new_metals:
+            # matrices built here from the stacked-delta weights (reference vega/metals.py:83-112, :389-752)
+            from .metal_matrices import MetalMatrixBuilder, PiccaCosmo
+            if cosmo is None:
+                raise ValueError('new_metals needs the cosmology keywords (OMEGAM, ...) in the data file header')
+            if 'metal-matrix' not in cfg:
+                raise ValueError('new_metals needs a [metal-matrix] section')
+            w1 = d.get('weights-tracer1', None)
+            if w1 is None:
+                raise ValueError('new_metals needs [data] weights-tracer1')
+            w2 = d.get('weights-tracer2', None) or w1
+            builder = MetalMatrixBuilder(
+                ((tr1.name, tr1.type), (tr2.name, tr2.type)),
+                (find_file(w1, search_dirs), find_file(w2, search_dirs)), model_grid, dict(cfg['metal-matrix']),
+                PiccaCosmo(Om=cosmo['Omega_m'], Ok=cosmo['Omega_k'], Or=cosmo['Omega_r'], wl=cosmo['wl']),
+                zmin=d.getfloat('zmin', 0.0), zmax=d.getfloat('zmax', 10.0))
         for tracers, stem in pairs:
+            if new_metals:
+                continue
             grid = Grid(mh['RPMIN'], mh['RPMAX'], mh['RTMAX'], mh['NP'], mh['NT'],
                         rp=mtabs[1].data['RP_' + stem], rt=mtabs[1].data['RT_' + stem],
                         z=mtabs[1].data['Z_' + stem])
@@ -891,7 +914,18 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
             if pair in seen:
                 continue
             seen.append(pair)
-            grid, mat = stored[pair] if pair in stored else stored[pair[::-1]]
+            if builder is not None:
+                # the canonical order puts each absorber on the side of the tracer whose forest holds it
+                if rp_only:
+                    m_rp, rp_eff, rt_eff, z_eff = builder.rp_matrix(*pair)
+                    mat = sparse.csr_array(builder.expand_rp_matrix(m_rp))
+                else:
+                    mat, rp_eff, rt_eff, z_eff = builder.rp_rt_matrix(*pair)
+                    mat = sparse.csr_array(mat)
+                grid = Grid(model_grid.rp_min, model_grid.rp_max, model_grid.rt_max, model_grid.n_rp, model_grid.n_rt,
+                            rp=rp_eff, rt=rt_eff, z=z_eff)
+            else:
+                grid, mat = stored[pair] if pair in stored else stored[pair[::-1]]
             t_a, t_b = catalog[pair[0]], catalog[pair[1]]
             pipe = _make_pipeline(t_a, t_b, name, metal_pk,
                                   _xi_options(model_sec, msec, (t_a, t_b)), grid, consts, True, cosmo=cosmo)

@@ -110,3 +110,38 @@ def write_data_file(path, source, with_distortion=True, with_covariance=True, ex
         ('DMATTRI', [('DMRP', 'D', t2.data['DMRP']), ('DMRT', 'D', t2.data['DMRT']), ('DMZ', 'D', t2.data['DMZ'])])],
         overwrite=True)
     return path
+
+
+PICCA_COSMOLOGY_HEADER = {'OMEGAM': 0.315, 'OMEGAK': 0., 'OMEGAR': 7.9e-5, 'WL': -1.}
+
+METAL_MATRIX_SECTION = """[metal-matrix]
+rebin_factor = 2
+alpha_LYA = 2.9
+alpha_SiII(1260) = 1.
+alpha_SiIII(1207) = 1.
+alpha_SiII(1193) = 1.
+alpha_SiII(1190) = 1.
+alpha_CIV(eff) = 1.
+z_ref_objects = 2.25
+z_evol_objects = 1.44
+z_bins_objects = 200
+"""
+
+
+def write_stacked_deltas(path, n_pix=1200):
+    """A stacked-delta file in the layout `new_metals` reads (reference vega/metals.py:405-409): LOGLAM, WEIGHT of
+    the forest pixels between 3600 and 5500 Angstrom, weights peaking mid-forest."""
+    from . import fitslite
+    loglam = np.linspace(np.log10(3600.), np.log10(5500.), n_pix)
+    lam = 10**loglam
+    weight = 0.1 + np.exp(-((lam - 4300.) / 600.)**2) * (1 + 0.2 * np.sin(lam / 37.))
+    fitslite.write_tables(str(path), [('STACK', [('LOGLAM', 'D', loglam), ('WEIGHT', 'D', weight)])], overwrite=True)
+    return path
+
+
+def write_object_catalog(path, n_obj=4000, seed=SEED):
+    """A quasar catalogue with a Z column (reference vega/metals.py:434-435)."""
+    from . import fitslite
+    z = np.clip(np.random.default_rng(seed + 17).normal(2.4, 0.3, n_obj), 1.8, 3.6)
+    fitslite.write_tables(str(path), [('CAT', [('Z', 'D', z)])], overwrite=True)
+    return path
