@@ -34,7 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 FP64_VALU_PEAK_TF = 78.6       # MI355X FP64 vector peak (spec; 256 CU x 128 flop/clk x 2.4 GHz)
 FP64_MFMA_PEAK_TF = 78.6       # MI355X FP64 matrix peak (spec)
 # what the instructions sustain on this part (scripts/micro/fp64_peaks.hip, profiles/r01_fp64_peaks.txt):
-FP64_MFMA_MEASURED_TF = 49.3   # v_mfma_f64_16x16x4_f64, 8 waves / SIMD
+FP64_MFMA_MEASURED_TF = 49.3   # v_mfma_f64_16x16x4_f64, 8 waves / SIMD (the C^-1 and FFTLog products)
+FP64_MFMA_4X4X4_MEASURED_TF = 73.4   # v_mfma_f64_4x4x4_4b_f64 (the distortion products; profiles/r01_fp64_mfma_4x4x4.txt)
 FP64_VALU_MEASURED_TF = 61.6   # v_fma_f64 at 4 waves / SIMD, the occupancy of k_pk_multipoles (66.5 at 8)
 
 # Algorithmic flops per (k, mu) grid point of a paired peak+smooth group:
@@ -423,7 +424,8 @@ def main():
                 # the FFTLog launch covers all ell and, for B > 8, one launch covers every item's product
                 if kclass != 'fftlog_spline_product' and kernels[kclass]['launches_per_step'] > 1:
                     flops /= len(shapes)
-                bound, peak, reach = 'mfma', FP64_MFMA_PEAK_TF, FP64_MFMA_MEASURED_TF
+                bound, peak = 'mfma', FP64_MFMA_PEAK_TF
+                reach = FP64_MFMA_4X4X4_MEASURED_TF if kclass == 'distortion_product' else FP64_MFMA_MEASURED_TF
             else:
                 return None
             tf = flops / (ms_per_launch * 1e-3) / 1e12

@@ -164,6 +164,7 @@ struct vmx_engine {
 
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
     int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
+    bool gemm_44 = true;             // products on the four-block 4x4x4 fp64 MFMA (VMX_GEMM_16: the 16x16x4 kernel everywhere)
     bool pk_small_attr = false;      // the single-walker P(k) shape asked for its > 64 KB of LDS
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
     int64_t xi_total = 0, xim_total = 0;
@@ -336,6 +337,17 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
 {
     constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
     dim3 grid(8 * per_xcd_total, nbatch), block(256);
+    // the four-block 4x4x4 MFMA kernel pays off on the long-K full products (distortion and metal matrices, stand-alone
+    // products); the short triangular C^-1 products and the windowed FFTLog product stay on the 16x16x4 kernel
+    if (e->gemm_44 && kc != KC_INVCOV && kc != KC_FFTLOG) {
+        block = dim3(GEMM44_THREADS);
+        switch (kc) {
+            case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt44<KC_DISTORTION>), grid, block, 0, e->cur, G); break;
+            case KC_METAL: hipLaunchKernelGGL((k_gemm_nt44<KC_METAL>), grid, block, 0, e->cur, G); break;
+            default: hipLaunchKernelGGL((k_gemm_nt44<KC_OTHER>), grid, block, 0, e->cur, G); break;
+        }
+        return;
+    }
     switch (kc) {
         case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_DISTORTION>), grid, block, 0, e->cur, G); break;
         case KC_INVCOV: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_INVCOV>), grid, block, 0, e->cur, G); break;
@@ -885,6 +897,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     // best in the full chain, where the items overlap on separate streams and fill the chip anyway)
     e->slab_rows = Bm > 1024 ? Bm : 1024;
     if (const char* ov = getenv("VMX_GEMM_SPLIT")) e->gemm_split_override = atoi(ov);
+    if (getenv("VMX_GEMM_16")) e->gemm_44 = false;
     if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
 
     // every slot must index a theta column and the combinations the kernels rely on must be present
@@ -1277,7 +1290,13 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
                 if (stage == 0 ? it->has_dm : it->has_cinv)
                     tiles_total += stage == 0 ? gemm_tiles(d.d.n_dist, B, false) : gemm_tiles(d.n_masked, B, true);
             }
-            for (size_t q = 0; q < e->items.size(); ++q) {
+            // largest problem first: its blocks are the long ones, and the short blocks of the others then fill the tail
+            std::vector<size_t> by_size(e->items.size());
+            for (size_t q = 0; q < by_size.size(); ++q) by_size[q] = q;
+            std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) {
+                const ItemDev& da = e->items[a]->dev; const ItemDev& db = e->items[b]->dev;
+                return stage == 0 ? (int64_t)da.d.n_dist * da.d.n_model > (int64_t)db.d.n_dist * db.d.n_model : da.n_masked > db.n_masked; });
+            for (size_t q : by_size) {
                 ItemHost* it = e->items[q];
                 const ItemDev& d = it->dev;
                 if (!(stage == 0 ? it->has_dm : it->has_cinv)) continue;

@@ -1138,7 +1138,9 @@ struct GemmArgs {
 // Several independent products in one launch (the distortion products of all correlation items, then their C^-1
 // products): every tile of every problem is in flight at once, so the small problems fill the tail of the large one.
 #define VMX_MAX_GROUP 8
-struct GemmGroup { GemmArgs p[VMX_MAX_GROUP]; int32_t n; int32_t seq_end[VMX_MAX_GROUP]; };
+struct GemmGroup {
+    GemmArgs p[VMX_MAX_GROUP]; int32_t n; int32_t seq_end[VMX_MAX_GROUP];
+};
 
 // Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
 // (BM/2) x (BN/2) sub-tile as (BN/32) x (BM/32) MFMA tiles.  LDS rows are padded to BK + 2 doubles, which
@@ -1264,6 +1266,221 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmGroup G)
                 const int m = m0 + wm + 16 * j + (lane & 15);
                 if (n < g.N && m < g.M) Dp[(size_t)n * g.ldd + m] = acc[i][j][r];
             }
+  }
+}
+
+// DPP row rotation of a double (two dword moves); CTRL = 0x120 + r is row_ror:r within each 16-lane row
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_rotate(double v)
+{
+    const long long bits = __builtin_bit_cast(long long, v);
+    int lo = (int)bits, hi = (int)(bits >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// LDS reads as explicit ds_read_b64 (2 LDS cycles per wave, banks (a/4) mod 64): left to the compiler, pairs of them
+// are merged into ds_read2_b64, which costs twice the cycles and banks modulo 32.  The compiler does not count these
+// reads in its own s_waitcnt bookkeeping, so lds_wait() drains the counter before the values are used (its waits for its
+// own LDS operations stay correct: extra operations in flight only make them conservative).
+__device__ __forceinline__ unsigned lds_offset(const double* p)
+{
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) double*)p;
+}
+template <int OFFSET>
+__device__ __forceinline__ double lds_read_b64(unsigned addr)
+{
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET));
+    return v;
+}
+template <int STRIDE>
+__device__ __forceinline__ void lds_read_fragments(double (&v)[4], unsigned addr)
+{
+    v[0] = lds_read_b64<0>(addr); v[1] = lds_read_b64<STRIDE>(addr); v[2] = lds_read_b64<2 * STRIDE>(addr);
+    v[3] = lds_read_b64<3 * STRIDE>(addr);
+}
+template <int STRIDE>
+__device__ __forceinline__ void lds_read_fragments(double (&v)[8], unsigned addr)
+{
+    v[0] = lds_read_b64<0>(addr); v[1] = lds_read_b64<STRIDE>(addr); v[2] = lds_read_b64<2 * STRIDE>(addr);
+    v[3] = lds_read_b64<3 * STRIDE>(addr); v[4] = lds_read_b64<4 * STRIDE>(addr); v[5] = lds_read_b64<5 * STRIDE>(addr);
+    v[6] = lds_read_b64<6 * STRIDE>(addr); v[7] = lds_read_b64<7 * STRIDE>(addr);
+}
+__device__ __forceinline__ void lds_wait(double (&a)[4], double (&b)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+}
+__device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+}
+
+#ifndef GEMM44_THREADS
+#define GEMM44_THREADS 256
+#endif
+// The same product on the four-block fp64 MFMA (v_mfma_f64_4x4x4_4b_f64: 73-77 TFLOP/s issue rate against the 46-49 of
+// the 16x16x4 form).  The instruction multiplies four independent 4 x 4 x 4 blocks; here the four blocks are four
+// interleaved quarters of a 16-deep K step of ONE 4 x 4 output tile (operand lane 16 kk + 4 b + row holds k = 4 kk + b
+// of block b), so a fragment is 4 rows x 16 k for both operands - one ds_read_b64 each, no rotated copies.  Each
+// accumulator keeps the four partial sums of its tile in the four lane groups of a row; they are added once, after the K
+// loop (three DPP row rotations).
+//
+// Staging is direct global -> LDS (global_load_lds_dwordx4: no staging registers, no ds_write): one wave instruction
+// fills 4 rows x 32 doubles of a tile, lane-linear.  The 16-byte chunks of a row are stored XOR-swizzled with
+// 4 (row & 3) - applied to the SOURCE address here and to the fragment read address there - so the four rows of a
+// fragment read fall on disjoint quarters of the 64 banks without padding.
+//
+// Pipeline: one barrier per 32-deep K stage, placed in the MIDDLE of the stage's MFMA work.  The SIMD issues from its
+// oldest wave first, so the second resident block does not fill this block's bubbles: every latency has to be covered
+// by the wave's own MFMAs.  Stage s (LDS buffer s & 1; fragments f0 / f1 = first / second 16-deep K step):
+//     read f1(s)                                   | MFMAs on f0(s)
+//     drain LDS reads and the DMA of stage s + 1, barrier      (stage s + 1 visible, buffer s & 1 free)
+//     DMA stage s + 2 -> buffer s & 1, read f0(s + 1)          | MFMAs on f1(s)
+template <int TAG>
+__global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_nt44(GemmGroup G)
+{
+    constexpr int BM = 64, BN = 64, BK = 32;
+    constexpr int NT = GEMM44_THREADS, NW = NT / 64;
+    constexpr int FJ = 4 * 256 / NT * 2;    // A fragments per wave: 8 (4 waves, 32 x 32 wave tiles) or 4 (8 waves, 32 x 16)
+    constexpr int NP = 16 / NW;             // DMA instructions per wave, operand and stage (each fills 4 rows)
+    __shared__ double sA[2][BM * BK];
+    __shared__ double sX[2][BN * BK];
+
+    const int xcd = blockIdx.x & 7;
+    int seq = blockIdx.x >> 3;
+    int pi = 0;
+    while (pi < G.n - 1 && seq >= G.seq_end[pi]) ++pi;
+    if (pi > 0) seq -= G.seq_end[pi - 1];
+    const GemmArgs& g = G.p[pi];
+    const int split = xcd % g.nsplit, group = xcd / g.nsplit, ngroups = 8 / g.nsplit;
+    const int tm_eff = g.tri ? (g.tm + 1) / 2 : g.tm;
+    const int mt0 = (seq / g.tn) * ngroups + group, nt = seq % g.tn;
+    if (mt0 >= tm_eff) return;
+    const int npass = (g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
+    const int batch = blockIdx.y;
+    const char* A = (const char*)(g.A + batch * g.a_batch);
+    const char* X = (const char*)(g.X + batch * g.x_batch);
+    double* Dp = g.D + batch * g.d_batch + split * g.d_slab;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = NT == 256 ? (wave & 1) * 32 : (wave & 3) * 16, wn = NT == 256 ? (wave >> 1) * 32 : (wave >> 2) * 32;
+    const int fq = lane & 3, fb = (lane >> 2) & 3, fkk = lane >> 4;
+    // fragment read: row (4 f + fq), k = ks + 4 fkk + fb -> chunk (k / 2) ^ (4 fq), half k & 1
+    const unsigned frag0 = (unsigned)(((2 * fkk + (fb >> 1)) ^ (4 * fq)) * 16 + (fb & 1) * 8);      // ks = 0; ks = 16 is ^ 128
+    const unsigned fa = lds_offset(&sA[0][(wm + fq) * BK]), fx = lds_offset(&sX[0][(wn + fq) * BK]);
+    // DMA: lane l of a wave instruction brings row (l >> 4) of its 4-row group, LDS chunk l & 15 <- source chunk (l & 15) ^ (4 (l >> 4))
+    const int drow = lane >> 4;
+    const unsigned dchunk = (unsigned)(((lane & 15) ^ (4 * drow)) * 16);
+    const int n0 = nt * BN;
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int mt = pass == 0 ? mt0 : g.tm - 1 - mt0;
+    const int m0 = mt * BM;
+    int kbeg, kend;
+    if (g.tri) {
+        int kmax = ((mt + 1) * BM + BK - 1) / BK * BK; if (kmax > g.K) kmax = g.K;
+        const int klen = ((kmax + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;
+        kbeg = split * klen; kend = kbeg + klen; if (kend > kmax) kend = kmax;
+    } else {
+        kbeg = split * g.klen; kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
+    }
+    if (g.k_limit) { const int kl = (*g.k_limit + BK - 1) / BK * BK; if (kend > kl) kend = kl; }
+    if (g.m_window && (m0 + BM <= g.m_window[0] || m0 > g.m_window[1])) continue;
+    if (pass > 0) __syncthreads();
+
+    // 32-bit byte offsets of this lane's DMA sources from the (scalar) operand bases
+    unsigned oa[NP], ox[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int r = m0 + (p * NW + wave) * 4 + drow; if (r >= g.M) r = g.M - 1;
+        oa[p] = (unsigned)(r * g.lda) * 8u + dchunk;
+        r = n0 + (p * NW + wave) * 4 + drow; if (r >= g.N) r = g.N - 1;
+        ox[p] = (unsigned)(r * g.ldx) * 8u + dchunk;
+    }
+    auto dma_stage = [&](int k, int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (oa[p] + (unsigned)k * 8u)),
+                                             (__attribute__((address_space(3))) void*)&sA[buf][(p * NW + wave) * 4 * BK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (ox[p] + (unsigned)k * 8u)),
+                                             (__attribute__((address_space(3))) void*)&sX[buf][(p * NW + wave) * 4 * BK], 16, 0, 0);
+        }
+    };
+
+    double acc[8][FJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = 0.0;
+
+    double a0[FJ], x0[8], a1[FJ], x1[8];
+    if (kbeg < kend) {
+        dma_stage(kbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kbeg + BK < kend) dma_stage(kbeg + BK, 1);
+        lds_read_fragments<4 * BK * 8>(a0, fa + frag0);
+        lds_read_fragments<4 * BK * 8>(x0, fx + frag0);
+        lds_wait(a0, x0);
+    }
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const unsigned boff = (unsigned)buf * (BM * BK * 8);
+        lds_read_fragments<4 * BK * 8>(a1, fa + boff + (frag0 ^ 128u));
+        lds_read_fragments<4 * BK * 8>(x1, fx + boff + (frag0 ^ 128u));
+        __builtin_amdgcn_sched_barrier(0);          // (the phases below stay in this order: the waits are placed by hand)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0[i], a0[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait(a1, x1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA of stage s + 1 has landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 2 * BK < kend) dma_stage(k0 + 2 * BK, buf);
+        if (k0 + BK < kend) {
+            const unsigned noff = (unsigned)(buf ^ 1) * (BM * BK * 8);
+            lds_read_fragments<4 * BK * 8>(a0, fa + noff + frag0);
+            lds_read_fragments<4 * BK * 8>(x0, fx + noff + frag0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1[i], a1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait(a0, x0);
+        buf ^= 1;
+    }
+
+    // result lane 16 r + 4 b + c of acc[i][j]: partial sum b of D^T[n0 + wn + 4 i + r][m0 + wm + 4 j + c].  After the
+    // rotations every lane group b holds the total; group b then stores column block j = 4 jg + b, so that a row of 16
+    // lanes writes 16 consecutive m.
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jg = 0; jg < FJ / 4; ++jg) {
+            double tot[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double v = acc[i][4 * jg + u];
+                tot[u] = (v + dpp_row_rotate<0x120 + 4>(v)) + (dpp_row_rotate<0x120 + 8>(v) + dpp_row_rotate<0x120 + 12>(v));
+            }
+            const double out = fb == 0 ? tot[0] : fb == 1 ? tot[1] : fb == 2 ? tot[2] : tot[3];
+            const int n = n0 + wn + 4 * i + (lane >> 4);
+            const int m = m0 + wm + 16 * jg + (lane & 15);
+            if (n < g.N && m < g.M) Dp[(size_t)n * g.ldd + m] = out;
+        }
   }
 }
 
