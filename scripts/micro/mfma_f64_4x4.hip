@@ -37,7 +37,7 @@ int main()
     double* out; CK(hipMalloc(&out, 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int which = 0; which < 2; ++which)
-        for (int blocks : {512, 1024, 2048}) {
+        for (int blocks : {256, 512, 1024, 2048}) {
             const int iters = 20000;
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipEventRecord(e0));

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <queue>
 #include <utility>
 #include <string>
 #include <vector>
@@ -164,6 +165,7 @@ struct vmx_engine {
 
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
     int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
+    std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
     bool gemm_44 = true;             // products on the four-block 4x4x4 fp64 MFMA (VMX_GEMM_16: the 16x16x4 kernel everywhere)
     bool pk_small_attr = false;      // the single-walker P(k) shape asked for its > 64 KB of LDS
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
@@ -306,7 +308,7 @@ static bool gemv1_applies(int N, int K) { return N == 1 && K <= 5120 && (size_t)
 // Tiling of one MFMA product: fills the tile / split fields of `g`, returns the number of K slabs and, in *per_xcd,
 // the blocks each XCD runs for it.  `other_tiles`: tiles of the other problems of the same launch.
 static int plan_gemm(vmx_engine* e, GemmArgs& g, int nbatch, int slab_rows_avail, const int32_t* k_limit, bool tri,
-                     int other_tiles, int* per_xcd)
+                     int other_tiles, int* per_xcd, int forced_split = 0)
 {
     constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
@@ -316,6 +318,7 @@ static int plan_gemm(vmx_engine* e, GemmArgs& g, int nbatch, int slab_rows_avail
     // partial sums go to separate slabs, which the consumer kernels re-read: more splits cost there
     int nsplit = 1;
     while (nsplit < 8 && tiles * nsplit < 512) nsplit *= 2;
+    if (forced_split > 0) nsplit = forced_split;
     if (e->gemm_split_override > 0) nsplit = e->gemm_split_override;
     while (nsplit > 1 && (int64_t)nsplit * g.N > slab_rows_avail) nsplit /= 2;
     int klen = ((g.K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
@@ -325,6 +328,52 @@ static int plan_gemm(vmx_engine* e, GemmArgs& g, int nbatch, int slab_rows_avail
     const int ngroups = 8 / nsplit;
     *per_xcd = ((tm_eff + ngroups - 1) / ngroups) * tn;
     return nsplit;
+}
+
+// K splits of the problems of one grouped launch.  A CU works through its blocks one after the other (the SIMDs issue
+// from the oldest wave first, so the second resident block only fills gaps), which makes a launch a list-scheduling
+// problem: blocks of `stages / split` K stages (+ a fixed start / end cost), handed in launch order to the first free of
+// the 256 CUs.  Every combination of 1 / 2 / 4 / 8-way splits is simulated (up to three problems; beyond that the
+// block-count rule of plan_gemm applies) and the shortest makespan wins, extra slabs charged with their write + re-read
+// at ~3 TB/s.
+struct SplitProblem { int tiles; int stages; int64_t slab_bytes; int max_split; };
+static std::vector<int> choose_group_splits(const std::vector<SplitProblem>& probs)
+{
+    const int n = (int)probs.size();
+    std::vector<int> best(n, 0);
+    if (n == 0 || n > 3) return best;
+    constexpr int CUS = 256;
+    constexpr double BLOCK_OVERHEAD = 4.0;                  // pipeline fill + epilogue of a block, in K stages
+    constexpr double STAGE_US = 0.85, SLAB_BYTES_PER_US = 3.0e6;
+    double best_cost = 1e300;
+    std::vector<int> cur(n, 1);
+    std::vector<double> load(CUS);
+    const int combos = 1 << (2 * n);
+    for (int c = 0; c < combos; ++c) {
+        bool ok = true;
+        double penalty = 0.0;
+        for (int i = 0; i < n; ++i) {
+            cur[i] = 1 << ((c >> (2 * i)) & 3);
+            if (cur[i] > probs[i].max_split || probs[i].stages / cur[i] < 4) ok = false;
+            penalty += (cur[i] - 1) * 2.0 * (double)probs[i].slab_bytes / SLAB_BYTES_PER_US / STAGE_US;
+        }
+        if (!ok) continue;
+        std::fill(load.begin(), load.end(), 0.0);
+        std::priority_queue<double, std::vector<double>, std::greater<double>> free_at(load.begin(), load.end());
+        double makespan = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double cost = (double)((probs[i].stages + cur[i] - 1) / cur[i]) + BLOCK_OVERHEAD;
+            const int blocks = probs[i].tiles * cur[i];
+            for (int b = 0; b < blocks; ++b) {
+                const double t = free_at.top() + cost;
+                free_at.pop(); free_at.push(t);
+                if (t > makespan) makespan = t;
+            }
+        }
+        const double total = makespan + penalty;
+        if (total < best_cost) { best_cost = total; best = cur; }
+    }
+    return best;
 }
 
 static int gemm_tiles(int M, int N, bool tri)
@@ -1296,10 +1345,31 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
             std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) {
                 const ItemDev& da = e->items[a]->dev; const ItemDev& db = e->items[b]->dev;
                 return stage == 0 ? (int64_t)da.d.n_dist * da.d.n_model > (int64_t)db.d.n_dist * db.d.n_model : da.n_masked > db.n_masked; });
+            // K splits of the group: simulated once per (stage, batch size)
+            std::vector<int>& splits = e->group_splits[stage * 100000 + B];
+            if (splits.empty() && stage == 0 && e->gemm_44) {        // (the model describes the self-pipelined 4x4x4 kernel)
+                std::vector<SplitProblem> sp;
+                for (size_t q : by_size) {
+                    ItemHost* it = e->items[q];
+                    const ItemDev& d = it->dev;
+                    if (!(stage == 0 ? it->has_dm : it->has_cinv)) continue;
+                    const int M = stage == 0 ? d.d.n_dist : d.n_masked, K = stage == 0 ? d.n_model_pad : d.n_masked_pad;
+                    const int ldd = stage == 0 ? d.n_dist_pad : d.n_masked_pad;
+                    int max_split = 1;
+                    while (max_split < 8 && (int64_t)max_split * 2 * B <= e->slab_rows) max_split *= 2;
+                    // (a triangular problem pairs its row tiles: every block covers about one full K range)
+                    sp.push_back({gemm_tiles(M, B, stage == 1), (K + GEMM_BK - 1) / GEMM_BK, (int64_t)B * ldd * 8, max_split});
+                }
+                splits = choose_group_splits(sp);
+            }
+            if (splits.empty()) splits.push_back(0);
+            size_t gi = 0;
             for (size_t q : by_size) {
                 ItemHost* it = e->items[q];
                 const ItemDev& d = it->dev;
                 if (!(stage == 0 ? it->has_dm : it->has_cinv)) continue;
+                const int forced = gi < splits.size() ? splits[gi] : 0;
+                ++gi;
                 GemmArgs g{};
                 if (stage == 0) {
                     g.A = it->dm.p; g.lda = d.n_model_pad; g.X = it->vec.p; g.ldx = d.n_model_pad; g.D = it->dist.p; g.ldd = d.n_dist_pad;
@@ -1310,7 +1380,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
                 }
                 int per_xcd = 0;
                 const int own = stage == 0 ? gemm_tiles(g.M, B, false) : gemm_tiles(g.M, B, true);
-                const int ns = plan_gemm(e, g, 1, e->slab_rows, nullptr, stage == 1, tiles_total - own, &per_xcd);
+                const int ns = plan_gemm(e, g, 1, e->slab_rows, nullptr, stage == 1, tiles_total - own, &per_xcd, forced);
                 (stage == 0 ? dslabs : slabs).z[q] = ns;
                 per_xcd_total += per_xcd;
                 G.p[G.n] = g; G.seq_end[G.n] = per_xcd_total; ++G.n;

@@ -1432,33 +1432,37 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     }
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const unsigned boff = (unsigned)buf * (BM * BK * 8);
-        lds_read_fragments<4 * BK * 8>(a1, fa + boff + (frag0 ^ 128u));
-        lds_read_fragments<4 * BK * 8>(x1, fx + boff + (frag0 ^ 128u));
-        __builtin_amdgcn_sched_barrier(0);          // (the phases below stay in this order: the waits are placed by hand)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < FJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0[i], a0[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        // first half: MFMAs on f0(s), the reads of f1(s) spread between them (one read ahead of every group of MFMAs, so
+        // the wave's MFMA stream is never held up by a burst of LDS instructions)
+        const unsigned a1p = fa + (unsigned)buf * (BM * BK * 8) + (frag0 ^ 128u);
+        const unsigned x1p = fx + (unsigned)buf * (BM * BK * 8) + (frag0 ^ 128u);
+#define VMX_G44_FIRST(i)                                                                                              \
+        if constexpr (i < FJ) a1[i] = lds_read_b64<i * 4 * BK * 8>(a1p);                                                 \
+        x1[i] = lds_read_b64<i * 4 * BK * 8>(x1p);                                                                       \
+        _Pragma("unroll") for (int j = 0; j < FJ; ++j)                                                                   \
+            acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0[i], a0[j], acc[i][j], 0, 0, 0);                            \
+        __builtin_amdgcn_sched_barrier(0);      /* keeps this order: the waits are placed by hand */
+        VMX_G44_FIRST(0) VMX_G44_FIRST(1) VMX_G44_FIRST(2) VMX_G44_FIRST(3)
+        VMX_G44_FIRST(4) VMX_G44_FIRST(5) VMX_G44_FIRST(6) VMX_G44_FIRST(7)
+#undef VMX_G44_FIRST
         lds_wait(a1, x1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA of stage s + 1 has landed
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        // second half: DMA of stage s + 2 into the buffer just released, MFMAs on f1(s) with the reads of f0(s + 1) between them
         if (k0 + 2 * BK < kend) dma_stage(k0 + 2 * BK, buf);
-        if (k0 + BK < kend) {
-            const unsigned noff = (unsigned)(buf ^ 1) * (BM * BK * 8);
-            lds_read_fragments<4 * BK * 8>(a0, fa + noff + frag0);
-            lds_read_fragments<4 * BK * 8>(x0, fx + noff + frag0);
-        }
+        // (after the last stage these reads fetch stale data that nothing uses: one code path, no branch)
+        const unsigned a0p = fa + (unsigned)(buf ^ 1) * (BM * BK * 8) + frag0;
+        const unsigned x0p = fx + (unsigned)(buf ^ 1) * (BM * BK * 8) + frag0;
+#define VMX_G44_SECOND(i)                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < FJ; ++j)                                                                   \
+            acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1[i], a1[j], acc[i][j], 0, 0, 0);                            \
+        if constexpr (i < FJ) a0[i] = lds_read_b64<i * 4 * BK * 8>(a0p);                                                 \
+        x0[i] = lds_read_b64<i * 4 * BK * 8>(x0p);                                                                       \
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < FJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1[i], a1[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        VMX_G44_SECOND(0) VMX_G44_SECOND(1) VMX_G44_SECOND(2) VMX_G44_SECOND(3)
+        VMX_G44_SECOND(4) VMX_G44_SECOND(5) VMX_G44_SECOND(6) VMX_G44_SECOND(7)
+#undef VMX_G44_SECOND
         lds_wait(a0, x0);
         buf ^= 1;
     }
