@@ -1380,30 +1380,30 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     const unsigned dchunk = (unsigned)(((lane & 15) ^ (4 * drow)) * 16);
     const int n0 = nt * BN;
 
-  for (int pass = 0; pass < npass; ++pass) {
-    const int mt = pass == 0 ? mt0 : g.tm - 1 - mt0;
-    const int m0 = mt * BM;
-    int kbeg, kend;
-    if (g.tri) {
-        int kmax = ((mt + 1) * BM + BK - 1) / BK * BK; if (kmax > g.K) kmax = g.K;
-        const int klen = ((kmax + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;
-        kbeg = split * klen; kend = kbeg + klen; if (kend > kmax) kend = kmax;
-    } else {
-        kbeg = split * g.klen; kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
-    }
-    if (g.k_limit) { const int kl = (*g.k_limit + BK - 1) / BK * BK; if (kend > kl) kend = kl; }
-    if (g.m_window && (m0 + BM <= g.m_window[0] || m0 > g.m_window[1])) continue;
-    if (pass > 0) __syncthreads();
-
-    // 32-bit byte offsets of this lane's DMA sources from the (scalar) operand bases
+    // per-pass state: tile origin, K range, DMA source offsets (32-bit byte offsets from the scalar operand bases)
+    int m0 = 0, kbeg = 0, kend = 0;
+    bool skip = false;
     unsigned oa[NP], ox[NP];
+    auto setup = [&](int pass) {
+        const int mt = pass == 0 ? mt0 : g.tm - 1 - mt0;
+        m0 = mt * BM;
+        if (g.tri) {
+            int kmax = ((mt + 1) * BM + BK - 1) / BK * BK; if (kmax > g.K) kmax = g.K;
+            const int klen = ((kmax + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;
+            kbeg = split * klen; kend = kbeg + klen; if (kend > kmax) kend = kmax;
+        } else {
+            kbeg = split * g.klen; kend = kbeg + g.klen; if (kend > g.K) kend = g.K;
+        }
+        if (g.k_limit) { const int kl = (*g.k_limit + BK - 1) / BK * BK; if (kend > kl) kend = kl; }
+        skip = g.m_window && (m0 + BM <= g.m_window[0] || m0 > g.m_window[1]);      // block-uniform
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        int r = m0 + (p * NW + wave) * 4 + drow; if (r >= g.M) r = g.M - 1;
-        oa[p] = (unsigned)(r * g.lda) * 8u + dchunk;
-        r = n0 + (p * NW + wave) * 4 + drow; if (r >= g.N) r = g.N - 1;
-        ox[p] = (unsigned)(r * g.ldx) * 8u + dchunk;
-    }
+        for (int p = 0; p < NP; ++p) {
+            int r = m0 + (p * NW + wave) * 4 + drow; if (r >= g.M) r = g.M - 1;
+            oa[p] = (unsigned)(r * g.lda) * 8u + dchunk;
+            r = n0 + (p * NW + wave) * 4 + drow; if (r >= g.N) r = g.N - 1;
+            ox[p] = (unsigned)(r * g.ldx) * 8u + dchunk;
+        }
+    };
     auto dma_stage = [&](int k, int buf) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -1413,6 +1413,14 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
                                              (__attribute__((address_space(3))) void*)&sX[buf][(p * NW + wave) * 4 * BK], 16, 0, 0);
         }
     };
+    // the first stage of a pass is requested before the previous pass stores its results (a triangular problem has two
+    // passes per block: the second one's pipeline fills behind the first one's epilogue)
+    setup(0);
+    if (!skip && kbeg < kend) dma_stage(kbeg, 0);
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int c_m0 = m0, kbeg_c = kbeg, kend_c = kend;
+    const bool c_skip = skip;
 
     double acc[8][FJ];
 #pragma unroll
@@ -1421,17 +1429,16 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
         for (int j = 0; j < FJ; ++j) acc[i][j] = 0.0;
 
     double a0[FJ], x0[8], a1[FJ], x1[8];
-    if (kbeg < kend) {
-        dma_stage(kbeg, 0);
+    if (!c_skip && kbeg_c < kend_c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kbeg + BK < kend) dma_stage(kbeg + BK, 1);
+        if (kbeg_c + BK < kend_c) dma_stage(kbeg_c + BK, 1);
         lds_read_fragments<4 * BK * 8>(a0, fa + frag0);
         lds_read_fragments<4 * BK * 8>(x0, fx + frag0);
         lds_wait(a0, x0);
     }
     int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    for (int k0 = kbeg_c; k0 < (c_skip ? kbeg_c : kend_c); k0 += BK) {
         // first half: MFMAs on f0(s), the reads of f1(s) spread between them (one read ahead of every group of MFMAs, so
         // the wave's MFMA stream is never held up by a burst of LDS instructions)
         const unsigned a1p = fa + (unsigned)buf * (BM * BK * 8) + (frag0 ^ 128u);
@@ -1450,7 +1457,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // second half: DMA of stage s + 2 into the buffer just released, MFMAs on f1(s) with the reads of f0(s + 1) between them
-        if (k0 + 2 * BK < kend) dma_stage(k0 + 2 * BK, buf);
+        if (k0 + 2 * BK < kend_c) dma_stage(k0 + 2 * BK, buf);
         // (after the last stage these reads fetch stale data that nothing uses: one code path, no branch)
         const unsigned a0p = fa + (unsigned)(buf ^ 1) * (BM * BK * 8) + frag0;
         const unsigned x0p = fx + (unsigned)(buf ^ 1) * (BM * BK * 8) + frag0;
@@ -1467,6 +1474,11 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
         buf ^= 1;
     }
 
+    if (pass + 1 < npass) {             // every wave is past the last barrier of the K loop: both buffers are free
+        setup(pass + 1);
+        if (!skip && kbeg < kend) dma_stage(kbeg, 0);
+    }
+    if (c_skip) continue;
     // result lane 16 r + 4 b + c of acc[i][j]: partial sum b of D^T[n0 + wn + 4 i + r][m0 + wm + 4 j + c].  After the
     // rotations every lane group b holds the total; group b then stores column block j = 4 jg + b, so that a row of 16
     // lanes writes 16 consecutive m.
@@ -1482,7 +1494,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
             }
             const double out = fb == 0 ? tot[0] : fb == 1 ? tot[1] : fb == 2 ? tot[2] : tot[3];
             const int n = n0 + wn + 4 * i + (lane >> 4);
-            const int m = m0 + wm + 16 * jg + (lane & 15);
+            const int m = c_m0 + wm + 16 * jg + (lane & 15);
             if (n < g.N && m < g.M) Dp[(size_t)n * g.ldd + m] = out;
         }
   }
