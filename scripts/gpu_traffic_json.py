@@ -11,9 +11,9 @@ B = 256
 SHAPES_DIST = [(2500, 2500), (5000, 5000)]
 SHAPES_COV = [(1590, 1590), (3180, 3180)]
 CLASSES = {
-    'distortion_product': ('k_gemm_nt<64, 64, 32, 6>', sum(8 * m * n + 8 * B * (m + n) for m, n in SHAPES_DIST)),
+    'distortion_product': ('k_gemm_nt44<6>', sum(8 * m * n + 8 * B * (m + n) for m, n in SHAPES_DIST)),
     'invcov_product': ('k_gemm_nt<64, 64, 32, 8>', sum(8 * m * n / 2 + 8 * B * (m + n) for m, n in SHAPES_COV)),
-    'fftlog_spline_product': ('k_gemm_nt<64, 64, 32, 2>', None),
+    'fftlog_spline_product': ('k_gemm_nt44<2>', None),
     'pk_multipoles': ('k_pk_multipoles', None),
     'xi_bins': ('k_xi_bins', None),
     'chi2': ('k_chi2', None),
