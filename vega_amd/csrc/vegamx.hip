@@ -388,14 +388,12 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
     dim3 grid(8 * per_xcd_total, nbatch), block(256);
     // the four-block 4x4x4 MFMA kernel runs every full product (distortion and metal matrices, FFTLog o spline,
     // stand-alone products); the short triangular C^-1 products are faster on the 16x16x4 kernel, whose two resident
-    // blocks hide each other's start and end (0.093 against 0.103 ms)
-    static const bool all44 = getenv("VMX_GEMM_44_ALL") != nullptr;
-    if (e->gemm_44 && (all44 || kc != KC_INVCOV)) {
+    // blocks hide each other's start and end (0.093 against 0.103 - 0.126 ms: two short passes per block)
+    if (e->gemm_44 && kc != KC_INVCOV) {
         block = dim3(GEMM44_THREADS);
         switch (kc) {
             case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt44<KC_DISTORTION>), grid, block, 0, e->cur, G); break;
             case KC_METAL: hipLaunchKernelGGL((k_gemm_nt44<KC_METAL>), grid, block, 0, e->cur, G); break;
-            case KC_INVCOV: hipLaunchKernelGGL((k_gemm_nt44<KC_INVCOV>), grid, block, 0, e->cur, G); break;
             case KC_FFTLOG: hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G); break;
             default: hipLaunchKernelGGL((k_gemm_nt44<KC_OTHER>), grid, block, 0, e->cur, G); break;
         }
