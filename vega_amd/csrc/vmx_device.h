@@ -192,19 +192,17 @@ __global__ void k_prologue(EngineDev D, int B)
     // thread = (walker, slot): slots 0 .. n_pipe-1 fill one pipeline's scalars, slot n_pipe the walker-level values
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = gid / (D.n_pipe + 1), slot = gid % (D.n_pipe + 1);
+    __shared__ int s_win[2 * 16];               // per wave: spline-coefficient window of its (walker, pipeline) threads
+    if ((threadIdx.x & 63) == 0) { s_win[2 * (threadIdx.x >> 6)] = 0x7fffffff; s_win[2 * (threadIdx.x >> 6) + 1] = -1; }
     if (gid == 0) *D.k_live = 0;
-    if (gid == 0 && D.n_const_slots > 0) {
-        // table mode: which D_NL * G tables are stale?  (walker 0 stands for the batch; the others are checked below)
-        for (int g = 0; g < D.n_xtab; ++g) {
-            const vmx_pipe_desc& dg = D.pipes[D.xtab_pipe[g]].d;
-            int dirty = 0;
-            for (int i = 0; i < 6; ++i) {
-                const double v = dg.arinyo_slot[i] >= 0 ? (D.theta_host ? D.theta_host : D.theta)[dg.arinyo_slot[i]] : 0.0;
-                if (!(D.xtab_key[g * 6 + i] == v)) dirty = 1;       // keys start as NaN
-                D.xtab_key[g * 6 + i] = v;
-            }
-            D.xtab_dirty[g] = dirty;
-        }
+    for (int key = gid; D.n_const_slots > 0 && key < 6 * D.n_xtab; key += gridDim.x * blockDim.x) {
+        // table mode: which D_NL * G tables are stale?  (walker 0 stands for the batch; the others are checked below.)  One
+        // thread per key; k_chi2 clears the flags for the next evaluation.
+        const int g = key / 6, i = key % 6;
+        const vmx_pipe_desc& dg = D.pipes[D.xtab_pipe[g]].d;
+        const double v = dg.arinyo_slot[i] >= 0 ? (D.theta_host ? D.theta_host : D.theta)[dg.arinyo_slot[i]] : 0.0;
+        if (!(D.xtab_key[g * 6 + i] == v)) atomicOr(&D.xtab_dirty[g], 1);       // keys start as NaN
+        D.xtab_key[g * 6 + i] = v;
     }
     const double* t = D.theta + (size_t)b * D.n_params;
     const double* t0 = D.theta_host ? D.theta_host : D.theta;         // walker 0, for the constant-parameter check
@@ -227,7 +225,10 @@ __global__ void k_prologue(EngineDev D, int B)
     if (slot < D.n_pipe) {
         const int p = slot;
         const vmx_pipe_desc& d = D.pipes[p].d;
-        double* s = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+        // the scalars are collected in registers and stored at the end: with stores in between, the compiler has to keep
+        // every parameter load behind the previous store (the pointers may alias) - ~30 dependent L2 round trips
+        double s[VMX_NS];
+#pragma unroll
         for (int i = 0; i < VMX_NS; ++i) s[i] = 0.0;
 
         const double gr = th(t, d.growth_rate_slot, d.growth_rate_default);
@@ -265,6 +266,7 @@ __global__ void k_prologue(EngineDev D, int B)
             ga += d.smooth_weight[i] * sp * sp; gb += d.smooth_weight[i] * st * st;
         }
         if (d.exp_par_slot >= 0) { const double a = t[d.exp_par_slot], c = t[d.exp_per_slot]; s[S_EA] = a * a; s[S_EB] = c * c; }
+#pragma unroll
         for (int q = 0; q < 2; ++q) {
             const vmx_tracer& tr = d.tracer[q];
             if (d.vd_kind == VMX_VD_NONE || !tr.discrete) continue;
@@ -315,9 +317,18 @@ __global__ void k_prologue(EngineDev D, int B)
                 }
             }
             if (P.odd_rel || P.odd_asy || D.extrapolate) { jlo = 0; jhi = D.n_coef - 1; }
-            atomicMin(&D.coef_win[0], jlo);
-            atomicMax(&D.coef_win[1], jhi);
+            // one pair of global atomics per wave, not per thread (2 x 1280 atomics on two addresses took ~20 us): the
+            // wave's lanes meet in its own LDS slot first; LDS operations of a wave complete in order
+            int* w_win = s_win + 2 * (threadIdx.x >> 6);
+            atomicMin(&w_win[0], jlo);
+            atomicMax(&w_win[1], jhi);
+            const unsigned long long here = __ballot(1);
+            if ((threadIdx.x & 63) == __ffsll((long long)here) - 1) {
+                atomicMin(&D.coef_win[0], w_win[0]);
+                atomicMax(&D.coef_win[1], w_win[1]);
+            }
         }
+#pragma unroll
         for (int q = 0; q < 2; ++q) {
             const vmx_tracer& tr = d.tracer[q];
             double a, c = 0.0;
@@ -325,7 +336,13 @@ __global__ void k_prologue(EngineDev D, int B)
             else a = t[tr.alpha_slot];
             s[q == 0 ? S_EV1A : S_EV2A] = a; s[q == 0 ? S_EV1B : S_EV2B] = c;
         }
-        if (d.radiation) { for (int i = 0; i < 4; ++i) s[S_RAD_S + i] = t[d.rad_slot[i]]; }
+        if (d.radiation) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[S_RAD_S + i] = t[d.rad_slot[i]];
+        }
+        double* out = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+#pragma unroll
+        for (int i = 0; i < VMX_NS; ++i) out[i] = s[i];
         return;
     }
 
@@ -1800,6 +1817,9 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabI
         D.chi2[b] = st ? 1e100 : c;
         if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
         if (D.status_host) D.status_host[b] = st;
-        if (b == 0) { D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1; }      // the next evaluation starts from an empty window
+        if (b == 0) {       // the next evaluation starts from an empty window and clean table flags
+            D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
+            for (int g = 0; g < D.n_xtab; ++g) D.xtab_dirty[g] = 0;
+        }
     }
 }
