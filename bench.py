@@ -244,6 +244,12 @@ def main():
                     help='independent engines per GPU; step i runs on lane i %% lanes, so consecutive steps overlap')
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: whatever libraries print there (RCCL's version banner when a
+    # communicator is first used, for one) goes to stderr until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -488,7 +494,8 @@ def main():
             'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'cpu_baseline': cpu,
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
