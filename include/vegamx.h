@@ -240,6 +240,13 @@ int vmx_item_add_broadband(vmx_engine* e, int32_t item, int32_t position, int32_
  * VMX_MAT_INVCOV [n_masked][n_masked] (vega_interface.py:316); VMX_MAT_METAL [n_model][n_pair]
  * with `index` = position of the metal in the order of vmx_item_add_metal (metals.py:338-367).
  * A matrix that is never set is the identity (data.py:77-78, :683-684). */
+/* A metal matrix in Kronecker form, M = A (x) B on the bin order rt-fastest (index = rt + n_rt * rp): what
+ * `new_metals` builds (metals.py:501-655: np.einsum('ij,kl->ikjl', rp_1d_dmat, rt_1d_dmat)), and with b_rt = NULL
+ * (B = identity) the rp-only form (metals.py:354-358, :657-752).  The product M xi = A Xi B^T is applied as two small
+ * products per walker instead of one [n_model]^2 product.  a_rp [n_rp][n_rp], b_rt [n_rt][n_rt], row-major;
+ * n_rp * n_rt = n_model of the item = bins of the pair's pipeline. */
+int vmx_item_set_metal_kron(vmx_engine* e, int32_t item, int32_t index, const double* a_rp, int32_t n_rp,
+                            const double* b_rt, int32_t n_rt);
 int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index, int32_t rows,
                         int32_t cols, const double* dense);
 /* Indices (into the n_dist model bins) kept by the model mask (data.py:410). */

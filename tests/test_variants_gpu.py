@@ -351,13 +351,19 @@ def test_new_metals_through_the_engine(tmp_path, tag):
     from vega_amd import VegaInterface
     prob, name = new_metals_problem(tmp_path, tag)
     exp = np.load(GOLDEN / 'expected_new_metals.npz')
-    vega = VegaInterface(None, problem=prob, max_batch=2)
-    assert vega.chi2() == pytest.approx(float(exp[f'{tag}/chi2']), rel=CHI2_RTOL)
-    got = vega.compute_model()[name]
-    assert np.abs(got - exp[f'{tag}/model']).max() <= XI_RTOL * np.abs(exp[f'{tag}/model']).max()
     pars = {str(n): float(v) for n, v in zip(exp[f'{tag}/param_names'], exp[f'{tag}/theta'][0])}
-    assert vega.chi2(pars) == pytest.approx(float(exp[f'{tag}/walker0/chi2']), rel=CHI2_RTOL)
-    vega.close()
+    # the matrices are Kronecker products: applied as two small products per walker (default) or uploaded dense
+    for kron in (True, False):
+        vega = VegaInterface(None, problem=prob, max_batch=12, kron_metals=kron)
+        assert vega.chi2() == pytest.approx(float(exp[f'{tag}/chi2']), rel=CHI2_RTOL)
+        got = vega.compute_model()[name]
+        assert np.abs(got - exp[f'{tag}/model']).max() <= XI_RTOL * np.abs(exp[f'{tag}/model']).max()
+        assert vega.chi2(pars) == pytest.approx(float(exp[f'{tag}/walker0/chi2']), rel=CHI2_RTOL)
+        # a batch large enough for the grouped (MFMA) path
+        batch = vega.chi2_batch([pars] * 11 + [None])
+        np.testing.assert_allclose(batch[:11], float(exp[f'{tag}/walker0/chi2']), rtol=CHI2_RTOL)
+        assert batch[11] == pytest.approx(float(exp[f'{tag}/chi2']), rel=CHI2_RTOL)
+        vega.close()
 
 
 def test_single_multipole():

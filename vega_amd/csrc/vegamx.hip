@@ -94,7 +94,7 @@ static std::vector<double> half_form(const double* c, int n)
 
 struct MetalHost {
     MetalDev dev{};
-    DevBuf<double> mat, svec, basis;
+    DevBuf<double> mat, svec, basis, kron_a, kron_b;
     int rows = 0, cols = 0;
 };
 
@@ -841,6 +841,28 @@ int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index
     return 0;
 }
 
+int vmx_item_set_metal_kron(vmx_engine* e, int32_t item, int32_t index, const double* a_rp, int32_t n_rp,
+                            const double* b_rt, int32_t n_rt)
+{
+    REQUIRE(e && !e->finalized && a_rp, "vmx_item_set_metal_kron (before vmx_finalize)");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(index >= 0 && index < (int)it->metals.size(), "metal index");
+    MetalHost* m = it->metals[index];
+    REQUIRE(m->dev.d.pipeline >= 0, "a static metal correlation takes no matrix");
+    REQUIRE(n_rp > 0 && n_rt > 0 && n_rp * n_rt == it->dev.d.n_model && n_rp * n_rt == e->pipes[m->dev.d.pipeline].n,
+            "Kronecker factors: n_rp * n_rt must be the item's (and the pair's) bin count");
+    REQUIRE((size_t)(2 * n_rp * n_rt + std::max(n_rp * n_rp, n_rt * n_rt)) * sizeof(double) <= 160 * 1024,
+            "Kronecker factors too large for the LDS kernel: pass the dense matrix instead");
+    HIP_OK(hipSetDevice(e->device));
+    if (m->kron_a.upload(a_rp, (size_t)n_rp * n_rp)) return -2;
+    if (b_rt && m->kron_b.upload(b_rt, (size_t)n_rt * n_rt)) return -2;
+    m->dev.kron_a = m->kron_a.p; m->dev.kron_b = b_rt ? m->kron_b.p : nullptr;
+    m->dev.kron_nrp = n_rp; m->dev.kron_nrt = n_rt;
+    m->dev.mat_off = 0;                 // "has a matrix": its product lives in the metal-product buffer
+    return 0;
+}
+
 int vmx_item_set_mask(vmx_engine* e, int32_t item, const int32_t* idx, int32_t n_masked)
 {
     REQUIRE(e && !e->finalized && idx, "vmx_item_set_mask");
@@ -1224,6 +1246,20 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 int vmx_model_size(vmx_engine* e) { return e ? e->model_size : -1; }
 
 // enqueue the whole kernel chain for the B parameter points already in e->theta
+// Kronecker-form metal matrix: one block per walker (k_metal_kron)
+static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, MetalHost* m, int B)
+{
+    ScopedTimer t(e, KC_METAL);
+    int item = 0, metal = 0;
+    for (size_t q = 0; q < e->items.size(); ++q) if (e->items[q] == it) item = (int)q;
+    for (size_t i = 0; i < it->metals.size(); ++i) if (it->metals[i] == m) metal = (int)i;
+    const int n = m->dev.kron_nrp * m->dev.kron_nrt;
+    const size_t shmem = (size_t)(2 * n + std::max(m->dev.kron_nrp * m->dev.kron_nrp, m->dev.kron_nrt * m->dev.kron_nrt)) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_metal_kron, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_metal_kron, dim3(B), dim3(256), shmem, e->cur, D, item, metal, B);
+}
+
 static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
                      double* d_chi2 = nullptr, int32_t* d_status = nullptr)
 {
@@ -1321,6 +1357,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
             max_model = std::max(max_model, (int)it->dev.d.n_model); max_dist = std::max(max_dist, (int)it->dev.d.n_dist);
             for (auto* m : it->metals) {
                 if (m->dev.mat_off < 0) continue;
+                if (m->dev.kron_a) { launch_metal_kron(e, D, it, m, B); continue; }
                 const PipeDev& P = e->pipes[m->dev.d.pipeline];
                 launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
                                e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, it->dev.n_model_pad, 0, 1, 0);
@@ -1413,6 +1450,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         // metal matrix products (no split-K: the consumer reads one slab)
         for (auto* m : it->metals) {
             if (m->dev.mat_off < 0) continue;
+            if (m->dev.kron_a) { launch_metal_kron(e, D, it, m, B); continue; }
             const PipeDev& P = e->pipes[m->dev.d.pipeline];
             launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
                            e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, d.n_model_pad, 0, 1, 0);

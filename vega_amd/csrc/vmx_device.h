@@ -65,6 +65,9 @@ struct MetalDev {
     int64_t xim_off;      // offset into the metal-product buffer (per-walker stride n_model_pad)
     const double* svec;   // static correlation [n_model] (fast_metals: frozen metal x metal term) instead of a pipeline
     const double* basis;  // static Kaiser basis [3][n_model]: xi = Y0 + (beta1 + beta2) Y1 + beta1 beta2 Y2
+    const double* kron_a; // Kronecker-form metal matrix A (x) B (mat_off = 0 then marks "has a matrix"): A [n_rp][n_rp],
+    const double* kron_b; //   B [n_rt][n_rt] or nullptr (identity)
+    int32_t kron_nrp, kron_nrt;
 };
 
 struct ItemDev {
@@ -1034,6 +1037,64 @@ __device__ inline double bb_total(const EngineDev& D, const ItemDev& it, int pos
 }
 
 // combine components, add metals, apply pre-distortion broadband (model.py:119-140,186)
+// Metal matrix in Kronecker form (new_metals; metals.py:338-367, :501-655): out = A Xi B^T for one (walker, metal pair),
+// Xi = the pair's correlation as [n_rp][n_rt].  One block per (walker, pair): Xi and the factors sit in LDS, the first
+// product T = Xi B^T is written back to LDS, the second one out = A T goes to the metal-product buffer.
+__global__ __launch_bounds__(256) void k_metal_kron(EngineDev D, int item, int metal, int B)
+{
+    extern __shared__ double sk[];
+    const ItemDev& it = D.items[item];
+    const MetalDev& md = D.metals[it.metal_begin + metal];
+    const PipeDev& P = D.pipes[md.d.pipeline];
+    const int b = blockIdx.x;
+    const int nrp = md.kron_nrp, nrt = md.kron_nrt, n = nrp * nrt;
+    double* sx = sk;                    // Xi, then reused for nothing else
+    double* st = sk + n;                // T = Xi B^T
+    double* sm = sk + 2 * n;            // B, then A
+    const double* x = D.xi + P.xi_off + (size_t)b * P.n_pad;
+    for (int i = threadIdx.x; i < n; i += 256) sx[i] = x[i];
+    if (md.kron_b) {
+        for (int i = threadIdx.x; i < nrt * nrt; i += 256) sm[i] = md.kron_b[i];
+        __syncthreads();
+        // T[p][t] = sum_u Xi[p][u] B[t][u]; a thread owns 5 consecutive t of one p (one Xi read per 5 FMAs)
+        const int nt5 = (nrt + 4) / 5;
+        for (int w = threadIdx.x; w < nrp * nt5; w += 256) {
+            const int p = w / nt5, tb = (w % nt5) * 5;
+            const double* xr = sx + p * nrt;
+            double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int u = 0; u < nrt; ++u) {
+                const double xv = xr[u];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[i] = fma(xv, sm[min(tb + i, nrt - 1) * nrt + u], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) if (tb + i < nrt) st[p * nrt + tb + i] = acc[i];
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        for (int o = threadIdx.x; o < n; o += 256) st[o] = sx[o];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < nrp * nrp; i += 256) sm[i] = md.kron_a[i];
+    __syncthreads();
+    // out[p][t] = sum_q A[p][q] T[q][t]; a thread owns 5 consecutive p of one t (one T read per 5 FMAs, t fastest over the
+    // lanes: coalesced stores)
+    double* out = D.xim + md.xim_off + (size_t)b * it.n_model_pad;
+    const int np5 = (nrp + 4) / 5;
+    for (int w = threadIdx.x; w < np5 * nrt; w += 256) {
+        const int t = w % nrt, pb = (w / nrt) * 5;
+        double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < nrp; ++q) {
+            const double tv = st[q * nrt + t];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc[i] = fma(sm[min(pb + i, nrp - 1) * nrp + q], tv, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (pb + i < nrp) out[(pb + i) * nrt + t] = acc[i];
+    }
+}
+
 __device__ inline double assemble_bin(const EngineDev& D, const ItemDev& it, int b, int bin)
 {
     const double* t = D.theta + (size_t)b * D.n_params;

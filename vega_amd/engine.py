@@ -142,6 +142,7 @@ def load_library():
                                       C.c_void_p]
     lib.vmx_item_set_metal_static.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
     lib.vmx_item_set_metal_basis.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32]
+    lib.vmx_item_set_metal_kron.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_metal_beta_override.argtypes = [C.c_void_p, C.c_int32, C.c_double]
     lib.vmx_set_parameter_transform.argtypes = [C.c_void_p, dptr, dptr]
     lib.vmx_matmul_host.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_int32, dptr, C.c_int32, dptr]
@@ -161,7 +162,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
-    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
+    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
@@ -410,12 +411,13 @@ class Lowering:
 class Engine:
     """One vegamx engine handle on one GPU, built from a Problem."""
 
-    def __init__(self, problem, max_batch=256, device=0, extra_names=(), metal_plan=None):
+    def __init__(self, problem, max_batch=256, device=0, extra_names=(), metal_plan=None, kron_metals=True):
         self.lib = load_library()
         self.prob = problem
         # fast_metals (see fast_metal_plan): per item, per metal pair ('pipeline', None) | ('share', leader index)
         # | ('static', xi vector) | ('basis', [3, n_model] Kaiser basis)
         self.metal_plan = metal_plan or {}
+        self.kron_metals = bool(kron_metals)   # False: Kronecker-form metal matrices are uploaded dense (diagnosis)
         self.metal_source = {}          # (item name, pair index) -> (global metal index, pipeline id, has matrix)
         self.low = Lowering(problem, extra_names)
         self.names = self.low.names
@@ -604,6 +606,14 @@ class Engine:
                             basis = _f64(arg)
                             assert basis.shape == (3, item.model_grid.size)
                             self._check(lib.vmx_item_set_metal_basis(self._h, iid, entry, _dp(basis), basis.shape[1]))
+                        elif getattr(pair, 'kron', None) is not None and self.kron_metals:
+                            # new_metals matrices are Kronecker products: two small products per walker instead of one
+                            # [n_model]^2 product
+                            a_rp = _f64(pair.kron[0])
+                            b_rt = None if pair.kron[1] is None else _f64(pair.kron[1])
+                            n_rt = item.model_grid.size // a_rp.shape[0]
+                            self._check(lib.vmx_item_set_metal_kron(self._h, iid, entry, _dp(a_rp), a_rp.shape[0],
+                                                                    None if b_rt is None else _dp(b_rt), n_rt))
                         elif pair.matrix is not None:
                             dense = _f64(pair.matrix.toarray() if hasattr(pair.matrix, 'toarray') else pair.matrix)
                             self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_METAL, entry, dense.shape[0],

@@ -92,6 +92,7 @@ class MetalMatrixBuilder:
         self.n_rp, self.n_rt = grid.n_rp, grid.n_rt
         self.any_discrete = 'discrete' in (tracers[0][1], tracers[1][1])
         self._raw = {}
+        self.last_factors = None
 
     # ---- inputs -----------------------------------------------------------------------------------------------
     def _getfloat(self, key, default=None):
@@ -215,6 +216,7 @@ class MetalMatrixBuilder:
         n = self.n_rp * self.n_rt
         # bin index = rt index + n_rt * rp index on both sides
         full = sparse.csr_matrix(np.einsum('ij,kl->ikjl', m_rp, m_rt).reshape(n, n))
+        self.last_factors = (m_rp, m_rt)        # the engine applies the two factors instead of their Kronecker product
 
         rp_eff, z_eff = self._effective_rp_z(assumed_rp, weights, z_true, rp_edges)
         lo = np.arange(self.n_rt) * self.grid.rt_max / self.n_rt

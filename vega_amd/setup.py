@@ -236,6 +236,7 @@ class MetalPair:
     double_count: bool           # xi *= 2 (reference vega/metals.py:238-239)
     cross_with_main: bool
     auto_bias_names: tuple = None  # candidate 'bias_<m1>_<m2>' names (separate-metal-auto-biases)
+    kron: tuple = None           # (A [n_rp, n_rp], B [n_rt, n_rt] or None): matrix = kron(A, B), as new_metals builds it
 
 
 @dataclass
@@ -914,14 +915,17 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
             if pair in seen:
                 continue
             seen.append(pair)
+            kron = None
             if builder is not None:
                 # the canonical order puts each absorber on the side of the tracer whose forest holds it
                 if rp_only:
                     m_rp, rp_eff, rt_eff, z_eff = builder.rp_matrix(*pair)
                     mat = sparse.csr_array(builder.expand_rp_matrix(m_rp))
+                    kron = (m_rp, None)
                 else:
                     mat, rp_eff, rt_eff, z_eff = builder.rp_rt_matrix(*pair)
                     mat = sparse.csr_array(mat)
+                    kron = builder.last_factors
                 grid = Grid(model_grid.rp_min, model_grid.rp_max, model_grid.rt_max, model_grid.n_rp, model_grid.n_rt,
                             rp=rp_eff, rt=rt_eff, z=z_eff)
             else:
@@ -931,7 +935,7 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
                                   _xi_options(model_sec, msec, (t_a, t_b)), grid, consts, True, cosmo=cosmo)
             main = (tr1.name, tr2.name)
             metals.append(MetalPair(
-                names=pair, pipeline=pipe, matrix=mat,
+                names=pair, pipeline=pipe, matrix=mat, kron=kron,
                 double_count=is_auto and pair[0] != pair[1],
                 cross_with_main=(pair[0] in main or pair[1] in main),
                 auto_bias_names=(f'bias_{pair[0]}_{pair[1]}', f'bias_{pair[1]}_{pair[0]}')))
