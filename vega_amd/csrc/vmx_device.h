@@ -198,17 +198,8 @@ __global__ void k_prologue(EngineDev D, int B)
     __shared__ int s_win[2 * 16];               // per wave: spline-coefficient window of its (walker, pipeline) threads
     if ((threadIdx.x & 63) == 0) { s_win[2 * (threadIdx.x >> 6)] = 0x7fffffff; s_win[2 * (threadIdx.x >> 6) + 1] = -1; }
     if (gid == 0) *D.k_live = 0;
-    for (int key = gid; D.n_const_slots > 0 && key < 6 * D.n_xtab; key += gridDim.x * blockDim.x) {
-        // table mode: which D_NL * G tables are stale?  (walker 0 stands for the batch; the others are checked below.)  One
-        // thread per key; k_chi2 clears the flags for the next evaluation.
-        const int g = key / 6, i = key % 6;
-        const vmx_pipe_desc& dg = D.pipes[D.xtab_pipe[g]].d;
-        const double v = dg.arinyo_slot[i] >= 0 ? (D.theta_host ? D.theta_host : D.theta)[dg.arinyo_slot[i]] : 0.0;
-        if (!(D.xtab_key[g * 6 + i] == v)) atomicOr(&D.xtab_dirty[g], 1);       // keys start as NaN
-        D.xtab_key[g * 6 + i] = v;
-    }
     const double* t = D.theta + (size_t)b * D.n_params;
-    const double* t0 = D.theta_host ? D.theta_host : D.theta;         // walker 0, for the constant-parameter check
+    const double* t0 = D.theta_host ? D.theta_host : D.theta;         // walker 0: table keys and the constant-parameter check
     if (D.theta_host && D.src_lds) {
         // zero-copy entry (small batches, one block): one coalesced read of the walkers from mapped host memory into
         // LDS - a single PCIe round trip instead of one per parameter lookup - and the device copy for later kernels
@@ -217,6 +208,16 @@ __global__ void k_prologue(EngineDev D, int B)
         for (int i = threadIdx.x; i < count; i += blockDim.x) { const double v = D.theta_host[i]; s_theta[i] = v; D.theta_copy[i] = v; }
         __syncthreads();
         t = s_theta + (size_t)b * D.n_params;
+        t0 = s_theta;           // (no second trip over PCIe for walker 0)
+    }
+    for (int key = gid; D.n_const_slots > 0 && key < 6 * D.n_xtab; key += gridDim.x * blockDim.x) {
+        // table mode: which D_NL * G tables are stale?  (walker 0 stands for the batch; the others are checked below.)  One
+        // thread per key; k_chi2 clears the flags for the next evaluation.
+        const int g = key / 6, i = key % 6;
+        const vmx_pipe_desc& dg = D.pipes[D.xtab_pipe[g]].d;
+        const double v = dg.arinyo_slot[i] >= 0 ? t0[dg.arinyo_slot[i]] : 0.0;
+        if (!(D.xtab_key[g * 6 + i] == v)) atomicOr(&D.xtab_dirty[g], 1);       // keys start as NaN
+        D.xtab_key[g * 6 + i] = v;
     }
     if (b >= B) return;
     if (D.theta_host && !D.src_lds) {
