@@ -1112,7 +1112,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
                 }
             }
         }
-        if (e->n_xtab > 0 && e->xtab.alloc((size_t)e->n_xtab * e->n_mu * e->nkp, true)) return -2;
+        // (+ 4 x 32 rows: the mu loop requests its table rows four steps ahead without checking for the end)
+        if (e->n_xtab > 0 && e->xtab.alloc(((size_t)e->n_xtab * e->n_mu + 128) * e->nkp, true)) return -2;
         {
             std::vector<int32_t> xp((size_t)e->n_xtab + 1, -1);
             for (auto& g : e->pk_groups) if (g.xtab >= 0) xp[g.xtab] = g.pipe;

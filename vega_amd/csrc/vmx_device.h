@@ -674,15 +674,14 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
     const bool same = (KM == KM_SAME_HCD);
     const double dmu = (double)MS * inv_nmu;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-    // the table stream runs three steps ahead of its use (one outstanding load per step covers the L2 latency)
+    // The table stream runs four steps ahead of its use, in four registers used in turn (the loop is unrolled by four: a
+    // rotating register window costs five moves per step and makes the compiler wait for ALL outstanding loads at every
+    // use - vmcnt(0) - which serialises each step behind an L2 round trip; with fixed registers it waits vmcnt(3)).
     const double* tab = T.gk;
-    const int n_steps = (n_mu - ms + MS - 1) / MS;
-    double g_a = *tab;
-    double g_b = (n_steps > 1) ? tab[T.gk_stride] : 0.0;
-    double g_c = (n_steps > 2) ? tab[2 * T.gk_stride] : 0.0;
-    tab += 3 * T.gk_stride;
-    int step = 0;
+    double g0 = *tab, g1 = tab[T.gk_stride], g2 = tab[2 * T.gk_stride], g3 = tab[3 * T.gk_stride];
+    tab += 4 * T.gk_stride;
     const double gq = vmx_exp(2.0 * T.e1 * dmu * dmu);
+    static_assert(PK_REANCHOR % 4 == 0, "the four-register window restarts with every re-anchoring chunk");
     for (int j0 = ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
         if (WB > 1) __syncthreads();       // keep the walkers of a block on the same table rows (L1 reuse)
         double mu = ((double)j0 + 0.5) * inv_nmu;
@@ -696,36 +695,45 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
         }
         int jend = j0 + MS * PK_REANCHOR;
         if (jend > n_mu) jend = n_mu;
-        for (int j = j0; j < jend; j += MS) {
-            const v2d mm = s_mu24[j];
-            const double mu2 = mm.x, mu4 = mm.y;
-            const double g = g_a;
-            g_a = g_b; g_b = g_c;
-            if (step + 3 < n_steps) { g_c = *tab; tab += T.gk_stride; }
-            ++step;
-            const double hmu = fma(T.hbb, mu2, T.hb);
-            const double A1 = fma(F, hmu, fma(T.c1_1, mu2, T.c0_1));
-            const double AA = same ? A1 * A1 : A1 * fma(T.c1_2, mu2, T.c0_2);
-            double val = AA * (g * gs);
-            if (NVD == 1) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));
-            const double mu6 = mu4 * mu2;
-            s0 += val;
-            s1 = fma(mu2, val, s1);
-            s2 = fma(mu4, val, s2);
-            s3 = fma(mu6, val, s3);
-            if (PAIRED) {
-                const double vp = val * pg;
-                q0 += vp;
-                q1 = fma(mu2, vp, q1);
-                q2 = fma(mu4, vp, q2);
-                q3 = fma(mu6, vp, q3);
-                pg *= pr;
-                pr *= T.pq;
-            }
-            gs *= gr;
-            gr *= gq;
-            F *= T.Fq;
+#define VMX_PK_TAB_STEP(GREG, J)                                                                                      \
+        {                                                                                                             \
+            const v2d mm = s_mu24[J];                                                                                 \
+            const double mu2 = mm.x, mu4 = mm.y;                                                                      \
+            const double g = GREG;                                                                                    \
+            GREG = *tab; tab += T.gk_stride;    /* (rows past the end are padding of the table buffer) */              \
+            const double hmu = fma(T.hbb, mu2, T.hb);                                                                 \
+            const double A1 = fma(F, hmu, fma(T.c1_1, mu2, T.c0_1));                                                  \
+            const double AA = same ? A1 * A1 : A1 * fma(T.c1_2, mu2, T.c0_2);                                         \
+            double val = AA * (g * gs);                                                                               \
+            if (NVD == 1) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));                                                     \
+            const double mu6 = mu4 * mu2;                                                                             \
+            s0 += val;                                                                                                \
+            s1 = fma(mu2, val, s1);                                                                                   \
+            s2 = fma(mu4, val, s2);                                                                                   \
+            s3 = fma(mu6, val, s3);                                                                                   \
+            if (PAIRED) {                                                                                             \
+                const double vp = val * pg;                                                                           \
+                q0 += vp;                                                                                             \
+                q1 = fma(mu2, vp, q1);                                                                                \
+                q2 = fma(mu4, vp, q2);                                                                                \
+                q3 = fma(mu6, vp, q3);                                                                                \
+                pg *= pr;                                                                                             \
+                pr *= T.pq;                                                                                           \
+            }                                                                                                         \
+            gs *= gr;                                                                                                 \
+            gr *= gq;                                                                                                 \
+            F *= T.Fq;                                                                                                \
         }
+        for (int j = j0; j < jend; j += 4 * MS) {
+            VMX_PK_TAB_STEP(g0, j)
+            if (j + MS >= jend) break;
+            VMX_PK_TAB_STEP(g1, j + MS)
+            if (j + 2 * MS >= jend) break;
+            VMX_PK_TAB_STEP(g2, j + 2 * MS)
+            if (j + 3 * MS >= jend) break;
+            VMX_PK_TAB_STEP(g3, j + 3 * MS)
+        }
+#undef VMX_PK_TAB_STEP
     }
     s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3;
     q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
