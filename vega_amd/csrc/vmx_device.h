@@ -724,15 +724,19 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
             gr *= gq;                                                                                                 \
             F *= T.Fq;                                                                                                \
         }
-        for (int j = j0; j < jend; j += 4 * MS) {
+        // whole groups of four steps in a loop without exits (the compiler then counts the outstanding loads exactly),
+        // the remainder - last chunk only - after it
+        const int chunk_steps = (jend - j0 + MS - 1) / MS;
+        int j = j0;
+        for (int it = 0; it < chunk_steps / 4; ++it, j += 4 * MS) {
             VMX_PK_TAB_STEP(g0, j)
-            if (j + MS >= jend) break;
             VMX_PK_TAB_STEP(g1, j + MS)
-            if (j + 2 * MS >= jend) break;
             VMX_PK_TAB_STEP(g2, j + 2 * MS)
-            if (j + 3 * MS >= jend) break;
             VMX_PK_TAB_STEP(g3, j + 3 * MS)
         }
+        if (chunk_steps % 4 > 0) VMX_PK_TAB_STEP(g0, j)
+        if (chunk_steps % 4 > 1) VMX_PK_TAB_STEP(g1, j + MS)
+        if (chunk_steps % 4 > 2) VMX_PK_TAB_STEP(g2, j + 2 * MS)
 #undef VMX_PK_TAB_STEP
     }
     s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3;
