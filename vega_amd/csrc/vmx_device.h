@@ -1673,16 +1673,34 @@ __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g, EngineDev D, int item
 #pragma unroll
     for (int c = 0; c < CPW; ++c) { koff[c] = (w + 4 * c) * 128 + lane * 2; kval[c] = koff[c] < g.K; if (!kval[c]) koff[c] = 0; }
 
-    // request the first row of the matrix stream before staging x, so both latencies overlap
-    v2d cur[CPW], nxt[CPW];
-    int row = blockIdx.x;
-    const v2d zero2 = (v2d){0.0, 0.0};
-    if (row < g.M) {
-        const double* a = A + (size_t)row * g.lda;
+    // Two row buffers used in turn (the row loop is unrolled by two): with fixed registers the compiler waits for the
+    // buffer it is about to reduce only - vmcnt(CPW) - while the other row's loads stay in flight; a rotating
+    // "current / next" pair made it wait for every outstanding load (vmcnt(0)), one row in flight per wave.
+    // Loads are unconditional: a lane past the end of the row (or, for a lower-triangular A, past the diagonal, whose
+    // bytes need not be read) re-reads the row's first 16 bytes and its product is masked when the row is reduced.
+    v2d bufa[CPW], bufb[CPW];
+    const int row0 = blockIdx.x, G = gridDim.x;
+    const int n_rows = row0 < g.M ? (g.M - row0 + G - 1) / G : 0;        // rows of this block
+    auto load_row = [&](v2d (&dst)[CPW], int r) {
+        if (r > g.M - 1) r = g.M - 1;               // (a request past the last row repeats it; it is never reduced)
+        const double* a = A + (size_t)r * g.lda;
 #pragma unroll
-        for (int c = 0; c < CPW; ++c)       // a lower-triangular A is zero past the diagonal: those bytes are not read
-            cur[c] = (!g.tri || koff[c] <= row) ? __builtin_nontemporal_load((const v2d*)(a + koff[c])) : zero2;
-    }
+        for (int c = 0; c < CPW; ++c)
+            dst[c] = __builtin_nontemporal_load((const v2d*)(a + ((!g.tri || koff[c] <= r) ? koff[c] : 0)));
+    };
+    auto reduce_row = [&](const v2d (&src)[CPW], int r, int t) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const v2d x = *(const v2d*)&sx[koff[c]];
+            const double term = src[c].x * x.x + src[c].y * x.y;
+            acc += (kval[c] && (!g.tri || koff[c] <= r)) ? term : 0.0;
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) part[t][w] = acc;
+    };
+    // request the first row of the matrix stream before staging x, so both latencies overlap
+    if (n_rows > 0) load_row(bufa, row0);
     if constexpr (FUSED) {
         const ItemDev& it = D.items[item];
         for (int k = tid; k < g.K; k += 256) sx[k] = k < it.d.n_model ? assemble_bin(D, it, 0, k) : 0.0;
@@ -1690,27 +1708,15 @@ __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g, EngineDev D, int item
         for (int k = tid * 2; k < g.K; k += 512) *(v2d*)&sx[k] = *(const v2d*)(X + k);
     }
     __syncthreads();
-    int t = 0;
-    for (; row < g.M; row += gridDim.x, ++t) {
-        const int next = row + gridDim.x;
-        if (next < g.M) {
-            const double* a = A + (size_t)next * g.lda;
-#pragma unroll
-            for (int c = 0; c < CPW; ++c)
-                nxt[c] = (!g.tri || koff[c] <= next) ? __builtin_nontemporal_load((const v2d*)(a + koff[c])) : zero2;
-        }
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-            const v2d x = *(const v2d*)&sx[koff[c]];
-            const double term = cur[c].x * x.x + cur[c].y * x.y;
-            acc += kval[c] ? term : 0.0;
-        }
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) part[t][w] = acc;
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) cur[c] = nxt[c];
+    const int t = n_rows;
+    for (int it = 0; it < n_rows / 2; ++it) {
+        const int ra = row0 + 2 * it * G;
+        load_row(bufb, ra + G);
+        reduce_row(bufa, ra, 2 * it);
+        load_row(bufa, ra + 2 * G);
+        reduce_row(bufb, ra + G, 2 * it + 1);
     }
+    if (n_rows & 1) reduce_row(bufa, row0 + (n_rows - 1) * G, n_rows - 1);
     __syncthreads();
     if (tid < t) {
         const int r = blockIdx.x + tid * gridDim.x;
