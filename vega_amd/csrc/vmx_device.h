@@ -608,28 +608,49 @@ __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, d
 {
     double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
     const double* gk = T.gk;
-    double g_next = (gk != nullptr) ? *gk : 1.0;
     const double k2 = T.k * T.k;
     const double k2vd1 = k2 * T.vd1, k2vd2 = k2 * T.vd2;
-    for (int j = ms; j < n_mu; j += MS) {
-        // (mu^2, mu^4) from the block's LDS table when the launch provides one
-        double mu2, mu4;
-        if (s_mu24 != nullptr) { const v2d mm = s_mu24[j]; mu2 = mm.x; mu4 = mm.y; }
-        else { const double mu = ((double)j + 0.5) * inv_nmu; mu2 = mu * mu; mu4 = mu2 * mu2; }
-        const double g = g_next;
-        if (j + MS < n_mu && gk != nullptr) { gk += T.gk_stride; g_next = *gk; }
-        double val = g;
-        if (!T.noexp) val *= vmx_exp(fma(T.e1, mu2, T.e0));
-        if (T.has_vd1) val *= vmx_rsqrt(fma(k2vd1, mu2, 1.0));
-        if (T.has_vd2) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));
-        m0 += val;
-        m1 = fma(mu2, val, m1);
-        m2 = fma(mu4, val, m2);
-        const double v6 = val * (mu4 * mu2);
-        m3 += v6;
-        m4 = fma(mu2, v6, m4);
-        m5 = fma(mu4, v6, m5);
+#define VMX_PK_W_STEP(G, J)                                                                                           \
+    {                                                                                                                 \
+        /* (mu^2, mu^4) from the block's LDS table when the launch provides one */                                    \
+        double mu2, mu4;                                                                                              \
+        if (s_mu24 != nullptr) { const v2d mm = s_mu24[J]; mu2 = mm.x; mu4 = mm.y; }                                  \
+        else { const double mu = ((double)(J) + 0.5) * inv_nmu; mu2 = mu * mu; mu4 = mu2 * mu2; }                     \
+        double val = G;                                                                                               \
+        if (!T.noexp) val *= vmx_exp(fma(T.e1, mu2, T.e0));                                                           \
+        if (T.has_vd1) val *= vmx_rsqrt(fma(k2vd1, mu2, 1.0));                                                        \
+        if (T.has_vd2) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));                                                        \
+        m0 += val;                                                                                                    \
+        m1 = fma(mu2, val, m1);                                                                                       \
+        m2 = fma(mu4, val, m2);                                                                                       \
+        const double v6 = val * (mu4 * mu2);                                                                          \
+        m3 += v6;                                                                                                     \
+        m4 = fma(mu2, v6, m4);                                                                                        \
+        m5 = fma(mu4, v6, m5);                                                                                        \
     }
+    const int n_steps = (n_mu - ms + MS - 1) / MS;
+    int j = ms, done = 0;
+    if (gk != nullptr && n_steps >= 8) {
+        // the table runs four steps ahead in four registers used in turn (see pk_tab_loop); the groups of this loop
+        // request rows that exist, the last four requested rows are consumed after it
+        double g0 = gk[0], g1 = gk[T.gk_stride], g2 = gk[2 * T.gk_stride], g3 = gk[3 * T.gk_stride];
+        gk += 4 * T.gk_stride;
+        const int groups = (n_steps - 4) / 4;
+        for (int it = 0; it < groups; ++it, j += 4 * MS) {
+            { const double g = g0; g0 = *gk; gk += T.gk_stride; VMX_PK_W_STEP(g, j) }
+            { const double g = g1; g1 = *gk; gk += T.gk_stride; VMX_PK_W_STEP(g, j + MS) }
+            { const double g = g2; g2 = *gk; gk += T.gk_stride; VMX_PK_W_STEP(g, j + 2 * MS) }
+            { const double g = g3; g3 = *gk; gk += T.gk_stride; VMX_PK_W_STEP(g, j + 3 * MS) }
+        }
+        VMX_PK_W_STEP(g0, j) VMX_PK_W_STEP(g1, j + MS) VMX_PK_W_STEP(g2, j + 2 * MS) VMX_PK_W_STEP(g3, j + 3 * MS)
+        j += 4 * MS;
+        done = 4 * groups + 4;
+    }
+    for (int st = done; st < n_steps; ++st, j += MS) {
+        const double g = (T.gk != nullptr) ? T.gk[(size_t)st * T.gk_stride] : 1.0;
+        VMX_PK_W_STEP(g, j)
+    }
+#undef VMX_PK_W_STEP
     wm[0] = m0; wm[1] = m1; wm[2] = m2; wm[3] = m3; wm[4] = m4; wm[5] = m5;
 }
 
