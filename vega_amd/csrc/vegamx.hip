@@ -140,7 +140,7 @@ struct vmx_engine {
 
     std::vector<PipeDev> pipes;
     std::vector<double> h_r, h_mu_c, h_z, h_relz, h_lnrelz, h_lnrelz2, h_growth;
-    DevBuf<double> cr, cmu, cz, crelz, clnrelz, clnrelz2, cgrowth;
+    DevBuf<double> cr, cmu, crp, crt, cz, crelz, clnrelz, clnrelz2, cgrowth;
     DevBuf<PipeDev> d_pipes;
     std::vector<PkGroup> pk_groups;
     DevBuf<PkGroup> d_pk_groups;
@@ -1055,6 +1055,14 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     }
 
     // coordinates and pipelines
+    {
+        std::vector<double> rp(e->h_r.size()), rt(e->h_r.size());
+        for (size_t i = 0; i < rp.size(); ++i) {
+            const double r = e->h_r[i], m = e->h_mu_c[i];
+            rp[i] = r * m; rt[i] = r * std::sqrt(1.0 - m * m);        // correlation_func.py:216-217
+        }
+        if (e->crp.upload(rp.data(), rp.size()) || e->crt.upload(rt.data(), rt.size())) return -2;
+    }
     if (e->cr.upload(e->h_r.data(), e->h_r.size()) || e->cmu.upload(e->h_mu_c.data(), e->h_mu_c.size()) ||
         e->cz.upload(e->h_z.data(), e->h_z.size()) || e->crelz.upload(e->h_relz.data(), e->h_relz.size()) ||
         e->clnrelz.upload(e->h_lnrelz.data(), e->h_lnrelz.size()) || e->clnrelz2.upload(e->h_lnrelz2.data(), e->h_lnrelz2.size()) ||
@@ -1203,10 +1211,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.xtab = e->xtab.p; D.const_slots = e->d_const_slots.p; D.n_const_slots = 0; D.xtab_pipe = e->d_xtab_pipe.p; D.n_xtab = e->n_xtab; D.xtab_key = e->xtab_key.p; D.xtab_dirty = e->xtab_dirty.p; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp; D.extrapolate = e->extrapolate ? 1 : 0;
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
-        D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
+        D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.inv_h[i] = 1.0 / e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
     }
     D.n_pipe = n_pipe; D.pipes = e->d_pipes.p;
-    D.cr = e->cr.p; D.cmu = e->cmu.p; D.cz = e->cz.p; D.crelz = e->crelz.p; D.clnrelz = e->clnrelz.p; D.clnrelz2 = e->clnrelz2.p; D.cgrowth = e->cgrowth.p;
+    D.cr = e->cr.p; D.cmu = e->cmu.p; D.crp = e->crp.p; D.crt = e->crt.p; D.cz = e->cz.p; D.crelz = e->crelz.p; D.clnrelz = e->clnrelz.p; D.clnrelz2 = e->clnrelz2.p; D.cgrowth = e->cgrowth.p;
     D.n_items = (int)e->items.size(); D.items = e->d_items.p;
     D.metals = e->d_metals.p; D.n_metals_total = (int)e->metals.size();
     D.bb_basis = e->bb_basis.p;

@@ -31,7 +31,7 @@ enum {
     S_AQ1, S_AQ2, S_AKV, S_AAV, S_ABV, S_AKP,
     S_VD1, S_VD2,
     S_AP, S_AT, S_DRP, S_EV1A, S_EV1B, S_EV2A, S_EV2B,
-    S_RAD_S, S_RAD_A, S_RAD_L, S_RAD_D
+    S_RAD_S, S_RAD_A, S_RAD_L, S_RAD_D, S_RAD_IL, S_RAD_ID        // (IL, ID: reciprocals of the lifetime and decrease lengths)
 };
 
 static inline int vmx_pad(int n) { return (n + VMX_PAD - 1) / VMX_PAD * VMX_PAD; }
@@ -116,10 +116,11 @@ struct EngineDev {
     // fftlog / spline
     int32_t n_coef, ncp;        // coefficients per ell, padded
     int32_t extrapolate;        // splines extend beyond their knots (legacy transform) instead of flagging
-    double x0[VMX_MAX_ELL], h[VMX_MAX_ELL], xlast[VMX_MAX_ELL];
+    double x0[VMX_MAX_ELL], h[VMX_MAX_ELL], xlast[VMX_MAX_ELL], inv_h[VMX_MAX_ELL];
     // pipelines
     int32_t n_pipe;
     const PipeDev* pipes;
+    const double* crp; const double* crt;       // r mu and r sqrt(1 - mu^2) of every bin (static)
     const double* cr; const double* cmu; const double* cz; const double* crelz; const double* clnrelz; const double* cgrowth;
     const double* clnrelz2;     // second tracer's ln(rel z) (same layout; equals clnrelz unless split_evol)
     // items
@@ -343,6 +344,7 @@ __global__ void k_prologue(EngineDev D, int B)
         if (d.radiation) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[S_RAD_S + i] = t[d.rad_slot[i]];
+            s[S_RAD_IL] = 1.0 / s[S_RAD_L]; s[S_RAD_ID] = 1.0 / s[S_RAD_D];
         }
         double* out = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
 #pragma unroll
@@ -1770,50 +1772,80 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
     const vmx_pipe_desc& d = P.d;
     const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
     const size_t c = P.coord_off + bin;
-    const double r = D.cr[c], mu = D.cmu[c];
-    const double drp = sc[S_DRP];
+    // The kernel is a chain of dependent lookups (coordinates -> r' -> knot index -> coefficients -> evolution ...); left
+    // in program order every one of them is a separate round trip to L2 and a wave spends its life waiting (~12 trips,
+    // 0.079 ms per step).  Everything that does not depend on a computed address is therefore requested up front -
+    // coordinates, per-bin factors, the walker's scalars, the descriptor fields - and the coefficient taps of all
+    // multipoles are requested together (below): three trips instead.
+    const double r = D.cr[c], rp0 = D.crp[c], rt0 = D.crt[c];
+    const double lnrelz = D.clnrelz[c], growth = D.cgrowth[c];
+    const double drp = sc[S_DRP], s_ap = sc[S_AP], s_at = sc[S_AT];
+    const double ev1a = sc[S_EV1A], ev2a = sc[S_EV2A];
+    const int n_ell = d.n_ell, single_ell = d.single_ell;
+    const bool std_evol = d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD;
+    const bool radiation = d.radiation && !d.is_peak, uv_shotnoise = d.uv_shotnoise != 0;
+    const bool split_evol = P.split_evol, odd_terms = P.odd_rel || P.odd_asy;
 
-    // reference correlation_func.py:200-236
-    double rr = 0.0, rmu = 0.0;
+    // reference correlation_func.py:200-236: r' = sqrt(r_par'^2 + r_perp'^2), mu' = r_par' / r'.  The kernel is VALU-bound
+    // (~600 instructions per bin, most of them in fp64 division, square root and logarithm sequences): mu' comes from one
+    // reciprocal square root, ln r' = ln(r'^2) / 2, the knot coordinate from a multiplication by 1 / h.
+    double rr2 = 0.0, rmu = 0.0;
     if (r != 0.0) {
-        const double rp = r * mu + drp;
-        const double rt = r * sqrt(1.0 - mu * mu);
-        const double rrp = sc[S_AP] * rp, rrt = sc[S_AT] * rt;
-        rr = sqrt(rrp * rrp + rrt * rrt);
-        rmu = rrp / rr;
+        const double rrp = s_ap * (rp0 + drp), rrt = s_at * rt0;
+        rr2 = fma(rrp, rrp, rrt * rrt);
+        if (rr2 != 0.0) rmu = rrp * vmx_rsqrt(rr2);
     }
 
     double xi = 0.0;
-    if (rr != 0.0) {
-        const double x = log(rr);
+    bool oob = false;
+    if (rr2 != 0.0) {
+        const double x = 0.5 * log(rr2);
         const size_t ncols = (size_t)gridDim.z * D.n_pipe;
         const size_t col = (size_t)b * D.n_pipe + p;
-        bool oob = false;
-        for (int e = 0; e < d.n_ell; ++e) {
-            if (!D.extrapolate && (x < D.x0[e] || x > D.xlast[e])) { oob = true; continue; }   // VegaBoundsError (pktoxi.py:149-152)
-            const double u = (x - D.x0[e]) / D.h[e];
+        // knot index and taps of every multipole first (a multipole the pipeline does not have reads the taps of ell = 0
+        // and is dropped), then the 16 coefficient loads in one go, then the arithmetic
+        const double* cf[4];
+        double tt[4];
+        bool on[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ee = e < n_ell ? e : 0;
+            const bool inside = D.extrapolate || !(x < D.x0[ee] || x > D.xlast[ee]);     // VegaBoundsError (pktoxi.py:149-152)
+            on[e] = e < n_ell && inside;
+            if (e < n_ell && !inside) oob = true;
+            const double u = (x - D.x0[ee]) * D.inv_h[ee];
             int j = (int)floor(u);
             if (j < 0) j = 0;
             if (j > D.n_coef - 4) j = D.n_coef - 4;
-            const double t = u - (double)j, t2 = t * t, t3 = t2 * t;
+            if (!(u == u)) j = 0;                   // (a NaN separation must not become an address)
+            tt[e] = u - (double)j;
+            cf[e] = D.coef + ((size_t)ee * ncols + col) * D.ncp + j;
+        }
+        double tap[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tap[e][q] = cf[e][q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double t = tt[e], t2 = t * t, t3 = t2 * t;
             const double omt = 1.0 - t;
-            const double* cf = D.coef + ((size_t)e * ncols + col) * D.ncp + j;
             const double w0 = omt * omt * omt;
             const double w1 = 3.0 * t3 - 6.0 * t2 + 4.0;
             const double w2 = -3.0 * t3 + 3.0 * t2 + 3.0 * t + 1.0;
-            const double s = (cf[0] * w0 + cf[1] * w1 + cf[2] * w2 + cf[3] * t3) * (1.0 / 6.0);
-            if (d.single_ell >= 0) { if (e == d.single_ell) xi = s; }      // one multipole, no Legendre factor
-            else xi += s * legendre_even(e, rmu);
+            const double s = (tap[e][0] * w0 + tap[e][1] * w1 + tap[e][2] * w2 + tap[e][3] * t3) * (1.0 / 6.0);
+            if (on[e]) {
+                if (single_ell >= 0) { if (e == single_ell) xi = s; }      // one multipole, no Legendre factor
+                else xi += s * legendre_even(e, rmu);
+            }
         }
-        if (oob) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
     }
 
     // bias evolution (correlation_func.py:276-370) and growth (:143)
     double ev;
-    if (d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD) {
+    if (std_evol) {
         // relz^a1 * relz^a2 = exp((a1 + a2) ln relz), ln relz tabulated at upload
-        ev = P.split_evol ? vmx_exp(fma(sc[S_EV1A], D.clnrelz[c], sc[S_EV2A] * D.clnrelz2[c]))
-                          : vmx_exp((sc[S_EV1A] + sc[S_EV2A]) * D.clnrelz[c]);
+        ev = split_evol ? vmx_exp(fma(ev1a, lnrelz, ev2a * D.clnrelz2[c])) : vmx_exp((ev1a + ev2a) * lnrelz);
     } else {
         ev = 1.0;
         for (int q = 0; q < 2; ++q) {
@@ -1825,19 +1857,19 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
         }
     }
     xi *= ev;
-    xi *= D.cgrowth[c];
+    xi *= growth;
 
-    if (d.radiation && !d.is_peak) {
+    if (radiation) {
         // reference correlation_func.py:446-489 (unrescaled coordinates, shifted by delta_rp)
-        const double rp = r * mu + drp;
-        const double rt = r * sqrt(1.0 - mu * mu);
-        const double rs = sqrt(rp * rp + rt * rt);
-        const double ms = rp / rs;
-        double xr = sc[S_RAD_S] / (rs * rs) * (1.0 - sc[S_RAD_A] * (1.0 - ms * ms));
-        xr *= exp(-rs * ((1.0 + ms) / sc[S_RAD_L] + 1.0 / sc[S_RAD_D]));
+        const double rp = rp0 + drp;
+        const double rs2 = fma(rp, rp, rt0 * rt0);
+        const double irs = vmx_rsqrt(rs2);              // (r = 0 bins carry rs2 = drp^2 > 0 or are masked downstream)
+        const double rs = rs2 * irs, ms = rp * irs;
+        double xr = sc[S_RAD_S] * (irs * irs) * (1.0 - sc[S_RAD_A] * (1.0 - ms * ms));
+        xr *= vmx_exp(-rs * fma(1.0 + ms, sc[S_RAD_IL], sc[S_RAD_ID]));
         xi += xr;
     }
-    if (d.uv_shotnoise) {
+    if (uv_shotnoise) {
         // reference correlation_func.py:649-686 on the unrescaled separation
         const double* t = D.theta + (size_t)b * D.n_params;
         const double amp = t[d.uvsn_slot[0]], lam = t[d.uvsn_slot[1]], bg = t[d.uvsn_slot[2]];
@@ -1849,9 +1881,10 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
         else { const int j = (int)pos; const double f = pos - (double)j; a = D.sn_a[j] + f * (D.sn_a[j + 1] - D.sn_a[j]); }
         xi += bg * bg * amp * lam / r * a;
     }
-    if (P.odd_rel || P.odd_asy) {
+    if (odd_terms) {
         // reference pktoxi.py:321-382 on the rescaled coordinates (correlation_func.py:491-551)
         const double* t = D.theta + (size_t)b * D.n_params;
+        const double rr = sqrt(rr2);
         const double x = log(rr);
         const double u = (x - P.odd_x0) / P.odd_h;
         int j = (int)floor(u);
@@ -1868,6 +1901,7 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
         if (P.odd_rel) xi += t[P.odd_slot[0]] * sp[0] * l1 + t[P.odd_slot[1]] * sp[1] * l3;
         if (P.odd_asy) xi += (t[P.odd_slot[2]] * sp[2] - t[P.odd_slot[3]] * sp[3]) * rr * l1 + t[P.odd_slot[4]] * sp[3] * rr * l3;
     }
+    if (oob) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
     D.xi[P.xi_off + (size_t)b * P.n_pad + bin] = xi;
 }
 
