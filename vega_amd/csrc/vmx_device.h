@@ -1910,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
 #define CHI2_THREADS 1024
 __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabInfo slabs)
 {
-    __shared__ double red[CHI2_THREADS];
+    __shared__ double red[CHI2_THREADS / 64];
     const int b = blockIdx.x;
     double acc = 0.0;
     if (D.gcinv) {
@@ -1926,22 +1926,28 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabI
                 const double rres = it.res[(size_t)b * it.n_masked_pad + i];
                 double z;
                 if (it.cinv) {
-                    z = 0.0;
-                    for (int s = 0; s < slabs.z[q]; ++s) z += it.z[((size_t)s * B + b) * it.n_masked_pad + i];
+                    // up to 8 split-K slabs, requested together (a run-time trip count makes every load wait for the
+                    // previous one) and added in slab order
+                    const int ns = slabs.z[q];
+                    double zs[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) zs[s] = it.z[((size_t)(s < ns ? s : 0) * B + b) * it.n_masked_pad + i];
+                    z = zs[0];
+#pragma unroll
+                    for (int s = 1; s < 8; ++s) z += s < ns ? zs[s] : 0.0;
                     z *= 2.0;               // cinv holds the half form: r^T C^-1 r = 2 r^T (L r)
                 } else z = rres;
                 acc = fma(rres, z, acc);
             }
         }
     }
-    red[threadIdx.x] = acc;
+    // fixed-order reduction: within each wave by shuffles, then the 16 wave sums by one thread
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    for (int off = CHI2_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        double c = red[0];
+        double c = 0.0;
+        for (int w = 0; w < CHI2_THREADS / 64; ++w) c += red[w];
         const double* t = D.theta + (size_t)b * D.n_params;
         for (int q = 0; q < D.n_priors; ++q) {
             const double dlt = t[D.prior_slot[q]] - D.prior_mean[q];
