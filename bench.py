@@ -231,8 +231,8 @@ def cpu_baseline(prob, names, theta, seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--workload', default='joint', choices=['joint', 'auto', 'joint_metals', 'joint_metals_fast'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
