@@ -1255,18 +1255,22 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 int vmx_model_size(vmx_engine* e) { return e ? e->model_size : -1; }
 
 // enqueue the whole kernel chain for the B parameter points already in e->theta
-// Kronecker-form metal matrix: one block per walker (k_metal_kron)
-static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, MetalHost* m, int B)
+// Kronecker-form metal matrices of an item: one launch, one block per (walker, metal) (k_metal_kron)
+static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, int B)
 {
-    ScopedTimer t(e, KC_METAL);
-    int item = 0, metal = 0;
+    int item = 0;
     for (size_t q = 0; q < e->items.size(); ++q) if (e->items[q] == it) item = (int)q;
-    for (size_t i = 0; i < it->metals.size(); ++i) if (it->metals[i] == m) metal = (int)i;
-    const int n = m->dev.kron_nrp * m->dev.kron_nrt;
-    const size_t shmem = (size_t)(2 * n + std::max(m->dev.kron_nrp * m->dev.kron_nrp, m->dev.kron_nrt * m->dev.kron_nrt)) * sizeof(double);
+    size_t shmem = 0;
+    for (auto* m : it->metals) {
+        if (!m->dev.kron_a) continue;
+        const int n = m->dev.kron_nrp * m->dev.kron_nrt;
+        shmem = std::max(shmem, (size_t)(2 * n + std::max(m->dev.kron_nrp * m->dev.kron_nrp, m->dev.kron_nrt * m->dev.kron_nrt)) * sizeof(double));
+    }
+    if (shmem == 0) return;
+    ScopedTimer t(e, KC_METAL);
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_metal_kron, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k_metal_kron, dim3(B), dim3(256), shmem, e->cur, D, item, metal, B);
+    hipLaunchKernelGGL(k_metal_kron, dim3(B, (unsigned)it->metals.size()), dim3(256), shmem, e->cur, D, item, B);
 }
 
 static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
@@ -1364,9 +1368,9 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         int max_model = 0, max_dist = 0;
         for (auto* it : e->items) {
             max_model = std::max(max_model, (int)it->dev.d.n_model); max_dist = std::max(max_dist, (int)it->dev.d.n_dist);
+            launch_metal_kron(e, D, it, B);
             for (auto* m : it->metals) {
-                if (m->dev.mat_off < 0) continue;
-                if (m->dev.kron_a) { launch_metal_kron(e, D, it, m, B); continue; }
+                if (m->dev.mat_off < 0 || m->dev.kron_a) continue;
                 const PipeDev& P = e->pipes[m->dev.d.pipeline];
                 launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
                                e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, it->dev.n_model_pad, 0, 1, 0);
@@ -1457,9 +1461,9 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         e->cur = oi == 0 ? e->stream : e->aux[oi - 1];
         if (oi > 0) HIP_OK(hipStreamWaitEvent(e->cur, e->ev_fork, 0));
         // metal matrix products (no split-K: the consumer reads one slab)
+        launch_metal_kron(e, D, it, B);
         for (auto* m : it->metals) {
-            if (m->dev.mat_off < 0) continue;
-            if (m->dev.kron_a) { launch_metal_kron(e, D, it, m, B); continue; }
+            if (m->dev.mat_off < 0 || m->dev.kron_a) continue;
             const PipeDev& P = e->pipes[m->dev.d.pipeline];
             launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
                            e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, d.n_model_pad, 0, 1, 0);

@@ -1075,12 +1075,14 @@ __device__ inline double bb_total(const EngineDev& D, const ItemDev& it, int pos
 // combine components, add metals, apply pre-distortion broadband (model.py:119-140,186)
 // Metal matrix in Kronecker form (new_metals; metals.py:338-367, :501-655): out = A Xi B^T for one (walker, metal pair),
 // Xi = the pair's correlation as [n_rp][n_rt].  One block per (walker, pair): Xi and the factors sit in LDS, the first
-// product T = Xi B^T is written back to LDS, the second one out = A T goes to the metal-product buffer.
-__global__ __launch_bounds__(256) void k_metal_kron(EngineDev D, int item, int metal, int B)
+// product T = Xi B^T is written back to LDS, the second one out = A T goes to the metal-product buffer.  One launch
+// covers every Kronecker-form metal of an item.
+__global__ __launch_bounds__(256) void k_metal_kron(EngineDev D, int item, int B)
 {
     extern __shared__ double sk[];
     const ItemDev& it = D.items[item];
-    const MetalDev& md = D.metals[it.metal_begin + metal];
+    const MetalDev& md = D.metals[it.metal_begin + blockIdx.y];     // grid.y = every metal of the item
+    if (!md.kron_a) return;                                         // (block-uniform)
     const PipeDev& P = D.pipes[md.d.pipeline];
     const int b = blockIdx.x;
     const int nrp = md.kron_nrp, nrt = md.kron_nrt, n = nrp * nrt;
