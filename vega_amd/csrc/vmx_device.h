@@ -5,9 +5,13 @@
 //   k_prologue        parameters -> per-(walker, pipeline) scalars        utils.py:45-108, scale_parameters.py:38-230
 //   k_gk_table        G(k,mu) binning table (static)                       power_spectrum.py:481-502
 //   k_pk_multipoles   P(k,mu) and its Legendre projection, fused           power_spectrum.py:87-196 + pktoxi.py:138
-//   k_gemm_nt / k_gemv  D = A . X for a static matrix and a batch of walker vectors:
+//   k_xtab            D_NL(k,mu)^p G(k,mu) of a batch that shares its non-linear parameters   power_spectrum.py:435-502
+//   k_pk_poly         pipelines whose mu dependence is the Kaiser polynomial x static G: closed form
+//   k_gemm_nt44 / k_gemm_nt / k_gemv / k_gemv1   D = A . X for a static matrix and a batch of walker vectors
+//                     (4x4x4 four-block MFMA / 16x16x4 MFMA / streaming for <= 8 walkers / one walker):
 //                     FFTLog+spline operator (pktoxi.py:141-144), metal matrices (metals.py:338-367),
 //                     distortion matrix (model.py:143-144), inverse covariance (vega_interface.py:316)
+//   k_metal_kron      metal matrix in Kronecker form A (x) B (new_metals)  metals.py:338-367, :501-655
 //   k_xi_bins         spline evaluation on rescaled bins, Legendre sum, bias evolution, growth,
 //                     QSO radiation                                         pktoxi.py:144-162, correlation_func.py:117-236,276-349,446-489
 //   k_assemble        peak/smooth/metals combination + pre-distortion broadband   model.py:119-140,186, metals.py:331-334
