@@ -1255,6 +1255,47 @@ struct GemmArgs {
     int tri;                // A is lower triangular (zeros above the diagonal): row tile mt needs k < (mt + 1) BM only
 };
 
+// LDS reads as explicit ds_read_b64 (2 LDS cycles per wave, banks (a/4) mod 64): left to the compiler, pairs of them
+// are merged into ds_read2_b64, which costs twice the cycles and banks modulo 32.  The compiler does not count these
+// reads in its own s_waitcnt bookkeeping, so lds_wait() drains the counter before the values are used (its waits for its
+// own LDS operations stay correct: extra operations in flight only make them conservative).
+__device__ __forceinline__ unsigned lds_offset(const double* p)
+{
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) double*)p;
+}
+template <int OFFSET>
+__device__ __forceinline__ double lds_read_b64(unsigned addr)
+{
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET));
+    return v;
+}
+template <int STRIDE>
+__device__ __forceinline__ void lds_read_fragments(double (&v)[4], unsigned addr)
+{
+    v[0] = lds_read_b64<0>(addr); v[1] = lds_read_b64<STRIDE>(addr); v[2] = lds_read_b64<2 * STRIDE>(addr);
+    v[3] = lds_read_b64<3 * STRIDE>(addr);
+}
+template <int STRIDE>
+__device__ __forceinline__ void lds_read_fragments(double (&v)[8], unsigned addr)
+{
+    v[0] = lds_read_b64<0>(addr); v[1] = lds_read_b64<STRIDE>(addr); v[2] = lds_read_b64<2 * STRIDE>(addr);
+    v[3] = lds_read_b64<3 * STRIDE>(addr); v[4] = lds_read_b64<4 * STRIDE>(addr); v[5] = lds_read_b64<5 * STRIDE>(addr);
+    v[6] = lds_read_b64<6 * STRIDE>(addr); v[7] = lds_read_b64<7 * STRIDE>(addr);
+}
+__device__ __forceinline__ void lds_wait(double (&a)[4], double (&b)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+}
+__device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+}
+
 // Several independent products in one launch (the distortion products of all correlation items, then their C^-1
 // products): every tile of every problem is in flight at once, so the small problems fill the tail of the large one.
 #define VMX_MAX_GROUP 8
@@ -1355,15 +1396,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmGroup G)
 #pragma unroll
             for (int p = 0; p < PX; ++p) rx[p] = *(const v2d*)(px[p] + kn);
         }
-        const double* a = &sA[buf][0];
-        const double* x = &sX[buf][0];
+        // explicit ds_read_b64 (see lds_read_b64): compiler-merged ds_read2_b64 pairs bank modulo 32 and conflict on this
+        // layout (40 % of the LDS cycles); the fragments of the next K step are requested before this step's MFMAs
+        const unsigned a = lds_offset(&sA[buf][(wm + frow) * LD + fk]);
+        const unsigned x = lds_offset(&sX[buf][(wn + frow) * LD + fk]);
+        static_assert(TI == 2 && TJ == 2, "fragment registers below are written for 2 x 2 MFMA tiles per wave");
+        double av[2][TJ], xv[2][TI];
+        av[0][0] = lds_read_b64<0>(a); av[0][1] = lds_read_b64<16 * LD * 8>(a);
+        xv[0][0] = lds_read_b64<0>(x); xv[0][1] = lds_read_b64<16 * LD * 8>(x);
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 4) {
-            double av[TJ], xv[TI];
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) av[j] = a[(wm + 16 * j + frow) * LD + ks + fk];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) xv[i] = x[(wn + 16 * i + frow) * LD + ks + fk];
+            const int cur = (ks / 4) & 1, nxt = cur ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[cur][0]), "+v"(av[cur][1]), "+v"(xv[cur][0]), "+v"(xv[cur][1]));
+            if (ks + 4 < BK) {
+                av[nxt][0] = lds_read_b64<0>(a + (ks + 4) * 8); av[nxt][1] = lds_read_b64<16 * LD * 8>(a + (ks + 4) * 8);
+                xv[nxt][0] = lds_read_b64<0>(x + (ks + 4) * 8); xv[nxt][1] = lds_read_b64<16 * LD * 8>(x + (ks + 4) * 8);
+            }
             // MFMA computes C[i][j] += sum_k Aop[i][k] Bop[k][j]; rows <- walkers (X), cols <- matrix rows (A):
             // the result tile is D^T[n][m], whose register layout (row = (lane>>4) + 4 r, col = lane & 15)
             // stores 16 consecutive m per 16 lanes -> coalesced along m.
@@ -1371,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmGroup G)
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[i], av[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[cur][i], av[cur][j], acc[i][j], 0, 0, 0);
         }
         buf ^= 1;
     }
@@ -1398,47 +1446,6 @@ __device__ __forceinline__ double dpp_row_rotate(double v)
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-
-// LDS reads as explicit ds_read_b64 (2 LDS cycles per wave, banks (a/4) mod 64): left to the compiler, pairs of them
-// are merged into ds_read2_b64, which costs twice the cycles and banks modulo 32.  The compiler does not count these
-// reads in its own s_waitcnt bookkeeping, so lds_wait() drains the counter before the values are used (its waits for its
-// own LDS operations stay correct: extra operations in flight only make them conservative).
-__device__ __forceinline__ unsigned lds_offset(const double* p)
-{
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) double*)p;
-}
-template <int OFFSET>
-__device__ __forceinline__ double lds_read_b64(unsigned addr)
-{
-    double v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET));
-    return v;
-}
-template <int STRIDE>
-__device__ __forceinline__ void lds_read_fragments(double (&v)[4], unsigned addr)
-{
-    v[0] = lds_read_b64<0>(addr); v[1] = lds_read_b64<STRIDE>(addr); v[2] = lds_read_b64<2 * STRIDE>(addr);
-    v[3] = lds_read_b64<3 * STRIDE>(addr);
-}
-template <int STRIDE>
-__device__ __forceinline__ void lds_read_fragments(double (&v)[8], unsigned addr)
-{
-    v[0] = lds_read_b64<0>(addr); v[1] = lds_read_b64<STRIDE>(addr); v[2] = lds_read_b64<2 * STRIDE>(addr);
-    v[3] = lds_read_b64<3 * STRIDE>(addr); v[4] = lds_read_b64<4 * STRIDE>(addr); v[5] = lds_read_b64<5 * STRIDE>(addr);
-    v[6] = lds_read_b64<6 * STRIDE>(addr); v[7] = lds_read_b64<7 * STRIDE>(addr);
-}
-__device__ __forceinline__ void lds_wait(double (&a)[4], double (&b)[8])
-{
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
-                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
-}
-__device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
-{
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
 }
 
 #ifndef GEMM44_THREADS
