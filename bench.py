@@ -56,6 +56,16 @@ def build_problem(workload):
     return prob
 
 
+WORKLOAD_TEXT = {
+    'joint': 'joint: Lya x Lya + QSO x Lya joint fit, B={B} walkers/GPU/step, ell=0,2,4,6, dense synthetic 2500^2 + '
+             '5000^2 distortion matrices and 1590^2 + 3180^2 inverse covariances (BASELINE configs[2])',
+    'joint_metals': 'joint_metals: joint fit + full metals (SiII/SiIII/CIV: 15 + 4 metal pairs with their metal '
+                    'matrices), B={B} walkers/GPU/step = {total} walkers/step over the node, same dense synthetic '
+                    'distortion matrices and covariances (BASELINE configs[3]: 4096 walkers over 8 GPUs = --batch 512)',
+    'joint_metals_fast': 'joint_metals_fast: configs[3] with the reference\'s fast_metals switch, B={B} walkers/GPU/step',
+    'auto': 'auto: Lya x Lya auto-correlation only, B={B} walkers/GPU/step, dense synthetic 2500^2 distortion matrix',
+}
+
 VARIED = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO', 'drp_QSO',
           'bias_hcd', 'beta_hcd', 'L0_hcd', 'bias_eta_SiII(1190)', 'bias_eta_SiII(1193)',
           'bias_eta_SiIII(1207)', 'bias_eta_SiII(1260)', 'bias_eta_CIV(eff)']
@@ -206,26 +216,74 @@ def monte_carlo_fits(prob, device, n_mocks=1024):
             'pull_rms': [float(v) for v in pulls.std(axis=0)]}
 
 
-def cpu_baseline(prob, names, theta, seconds=15.0):
-    """The oracle (CPU restatement of the reference) on a bounded sample of the same walkers."""
-    from contextlib import nullcontext
+_CPU = {}
+
+
+def _cpu_worker_init(workload):
+    """Worker of the CPU baseline: its own copy of the problem, one BLAS thread."""
     from oracle import vega_cpu as oracle
     try:
         from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
+        _CPU['limit'] = threadpool_limits(limits=1)
     except Exception:       # pragma: no cover
-        ctx = nullcontext()
-    with ctx:
-        oracle.chi2(prob)       # warm caches (grids, FFTLog objects)
-        t0 = time.perf_counter()
-        done = 0
-        vals = []
-        while done < theta.shape[0] and (time.perf_counter() - t0) < seconds:
-            vals.append(oracle.chi2(prob, dict(zip(names, theta[done]))))
-            done += 1
-        dt = time.perf_counter() - t0
-    return {'value': done / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{done} walkers of the same workload, oracle/vega_cpu.py chi2, 1 thread, {dt:.1f} s'}, vals
+        pass
+    _CPU['prob'] = build_problem(workload)
+    _CPU['oracle'] = oracle
+    oracle.chi2(_CPU['prob'])       # warm caches (grids, FFTLog objects)
+
+
+def _cpu_worker_eval(pars):
+    return _CPU['oracle'].chi2(_CPU['prob'], pars)
+
+
+def cpu_baseline(workload, names, theta, repeats=7, warmups=2):
+    """The oracle (CPU restatement of the reference) on the host cores, SURVEY 8d: a pool of one worker per core
+    (one BLAS thread each), every repeat evaluates one walker per worker; median of `repeats` after `warmups`; plus
+    the single-core figure from one worker alone.  Runs BEFORE the GPU is initialised (worker processes are started
+    from a process that has not touched the device)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, 16, theta.shape[0]))        # the GPU box's share for one GPU is 16 processes
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+    for k in saved:
+        os.environ[k] = '1'
+    try:
+        # ProcessPoolExecutor, not multiprocessing.Pool: a worker that dies (or whose initializer raises) breaks the pool
+        # with an exception instead of being respawned for ever
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(workers, mp_context=mp.get_context('spawn'), initializer=_cpu_worker_init,
+                                 initargs=(workload,)) as pool:
+            walkers = [dict(zip(names, row)) for row in theta]
+            times, vals = [], {}
+            t_start = time.perf_counter()
+            for r in range(warmups + repeats):
+                block = [(r * workers + i) % len(walkers) for i in range(workers)]
+                t0 = time.perf_counter()
+                out = list(pool.map(_cpu_worker_eval, [walkers[i] for i in block], chunksize=1))
+                dt = time.perf_counter() - t0
+                if r >= warmups:
+                    times.append(dt)
+                vals.update(zip(block, out))
+            # one core: one walker at a time (the other workers idle)
+            n_single = 5
+            t0 = time.perf_counter()
+            for i in range(n_single):
+                pool.submit(_cpu_worker_eval, walkers[i % len(walkers)]).result()
+            single = n_single / (time.perf_counter() - t0)
+            total = time.perf_counter() - t_start
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    med = float(np.median(times))
+    done = sorted(vals)
+    return {'value': workers / med, 'unit': 'evals/s', 'cores': workers, 'host_cpu_count': cores, 'kind': 'port',
+            'one_core_value': single,
+            'sample': f'{workers} worker processes (1 BLAS thread each) x 1 walker per repeat, median of {repeats} repeats '
+                      f'after {warmups} warm-ups ({med * 1e3:.0f} ms per repeat), {len(done)} distinct walkers of the same '
+                      f'workload, oracle/vega_cpu.py chi2; {total:.1f} s in all'}, done, [vals[i] for i in done]
 
 
 def main():
@@ -250,12 +308,36 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    # every rank makes sure the library exists before any collective is entered: one compiles (file lock), the
+    # others wait on the lock - not in a barrier
+    import fcntl
+    import __graft_entry__ as entry
+    with open(REPO / 'vega_amd' / '.build.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            entry.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+    B = args.batch
+    prob = build_problem(args.workload)
+    from vega_amd import synthetic
+    from vega_amd.engine import Lowering
+    low = Lowering(prob)
+    host_theta = synthetic.walkers(low.theta0, low.names, B, varied=VARIED, seed=synthetic.SEED + 1000 * rank)
+
+    # the CPU baseline runs first, on rank 0 of the N = 1 run, before this process touches the GPU
+    cpu = cpu_idx = cpu_vals = None
+    if rank == 0 and world == 1 and not args.core_only and not args.no_cpu_baseline:
+        cpu, cpu_idx, cpu_vals = cpu_baseline(args.workload, low.names, host_theta)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the vegamx engine has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -265,15 +347,8 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    import __graft_entry__ as entry
-    if rank == 0:
-        entry.build()
-    if use_dist:
-        dist.barrier()
-    from vega_amd import VegaInterface, synthetic
+    from vega_amd import VegaInterface
 
-    B = args.batch
-    prob = build_problem(args.workload)
     dev = torch.device('cuda', local_rank)
     vegas = []
     # the two-lane section below (two engines, consecutive steps overlapping) needs a second engine
@@ -293,13 +368,12 @@ def main():
     L = max(args.lanes, 1)
 
     # distinct walker batches per step and per rank, resident in HBM before timing
+    assert eng.names == low.names
     n_pool = min(args.steps, 8)
     pools = []
-    host_theta = None
     for i in range(n_pool):
-        th = synthetic.walkers(eng.low.theta0, eng.names, B, varied=VARIED, seed=synthetic.SEED + 1000 * rank + i)
-        if i == 0:
-            host_theta = th
+        th = host_theta if i == 0 else synthetic.walkers(eng.low.theta0, eng.names, B, varied=VARIED,
+                                                         seed=synthetic.SEED + 1000 * rank + i)
         pools.append(torch.from_numpy(th).to(dev))
     # two output / gather buffer pairs: the collective of step i runs on its own stream while step i + 1 computes
     nslot = 2 * len(engines)
@@ -472,22 +546,15 @@ def main():
         single = single_point_latency(local_rank) if extras else None
         mc_fits = monte_carlo_fits(prob, local_rank) if extras and args.workload == 'joint' else None
         metals = metals_throughput(local_rank) if extras and args.workload == 'joint' else None
-        cpu = None
-        if extras and not args.no_cpu_baseline:
-            cpu, ref_vals = cpu_baseline(prob, eng.names, host_theta)
-            got = chi2_check = vega.chi2_batch(host_theta[:len(ref_vals)])
-            rel = float(np.max(np.abs(got - np.array(ref_vals)) / np.abs(ref_vals)))
-            cpu['max_rel_chi2_diff_vs_gpu'] = rel
-            del chi2_check
+        if cpu is not None:
+            got = vega.chi2_batch(host_theta[cpu_idx])
+            cpu['max_rel_chi2_diff_vs_gpu'] = float(np.max(np.abs(got - np.array(cpu_vals)) / np.abs(cpu_vals)))
         out = {
             'metric': 'model+chi2 evals/sec (Lya auto+cross)', 'value': value, 'unit': 'evals/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'{args.workload}: Lya x Lya + QSO x Lya joint fit, B={B} walkers/GPU/step, '
-                                   'ell=0,2,4,6, dense synthetic 2500^2 + 5000^2 distortion matrices and '
-                                   '1590^2 + 3180^2 inverse covariances (BASELINE configs[2])'
-                       if args.workload == 'joint' else args.workload,
+            'config': {'workload': WORKLOAD_TEXT[args.workload].format(B=B, total=B * world),
                        'batch_per_gpu': B, 'lanes_per_gpu': L, 'pipelines_per_eval': len(eng.pipe_index),
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},

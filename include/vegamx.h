@@ -291,6 +291,22 @@ int vmx_sync(vmx_engine* e);
  * instead of the fiducial template.  pk = NULL returns to the template. */
 int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk);
 
+/* `Model.compute(pars, pk_full, pk_smooth)` (model.py:157-187) takes the linear spectra per call: replace the
+ * template's spectra (pk_peak = pk_full - pk_smooth as formed by the caller, model.py:177) after vmx_finalize.  The
+ * Arinyo term keeps the fiducial Delta^2(k) of vmx_set_template (power_spectrum.py:72-73, :462).  nk must equal the
+ * template's. */
+int vmx_set_linear_spectra(vmx_engine* e, const double* pk_peak, const double* pk_smooth, const double* pk_full,
+                           int32_t nk);
+
+/* Small-scale marginalisation coefficients (vega_interface.py:546-579 `compute_marg_coeff`; returned by
+ * chi2 / log_lik(..., return_marg_coeff=True), :282-325, which is what the PolyChord adapter calls,
+ * samplers/polychord.py:106-113): coeff = M . (data - model[mask]) with the static matrix
+ * M = `marg_diff2coeff_matrix` [n_templates][n_masked] (data.py:762-828).  Set before vmx_finalize;
+ * vmx_marg_coeff applies it to the residuals of the LAST evaluation (B = its batch size) with the engine's product
+ * kernels and copies out [B][n_templates] (host pointer; synchronous). */
+int vmx_item_set_marg_matrix(vmx_engine* e, int32_t item, const double* m, int32_t n_templates, int32_t n_masked);
+int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B);
+
 /* Samplers usually keep the Arinyo non-linear parameters fixed.  When they are identical for every walker of a
  * batch the factor D_NL(k,mu) G(k,mu) is tabulated once per batch instead of being exponentiated per walker and
  * grid point.  vmx_eval (host theta) detects this by itself; for vmx_eval_device the caller states it here.

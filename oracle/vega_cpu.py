@@ -702,19 +702,22 @@ def _component(prob, item, params, pk_lin, component, xi_metals=None, taps=None)
     return xi
 
 
-def model_compute(prob, item, params, taps=None):
-    """Model.compute (reference model.py:157-187)."""
+def model_compute(prob, item, params, taps=None, pk_full=None, pk_smooth=None):
+    """Model.compute(pars, pk_full, pk_smooth) (reference model.py:157-187); the spectra default to the fiducial
+    ones, as VegaInterface.compute_model passes them (vega_interface.py:239-240)."""
+    pk_full = prob.pk_full if pk_full is None else np.asarray(pk_full, dtype=float)
+    pk_smooth = prob.pk_smooth if pk_smooth is None else np.asarray(pk_smooth, dtype=float)
     pars = dict(params)
     pars['peak'] = True
-    xi_peak = _component(prob, item, pars, prob.pk_full - prob.pk_smooth, 'peak', taps=taps)
+    xi_peak = _component(prob, item, pars, pk_full - pk_smooth, 'peak', taps=taps)
     pars['peak'] = False
     xi_metals = None
     if item.metals and item.metal_opts['no_metal_decomp']:
         grid = _grid(prob, item.core.pk.n_mu)
-        xi_metals = metals_compute(prob, item, grid, pars, prob.pk_full, taps)
+        xi_metals = metals_compute(prob, item, grid, pars, pk_full, taps)
         if taps is not None:
             taps['xi_metals'] = xi_metals.copy()
-    xi_smooth = _component(prob, item, pars, prob.pk_smooth, 'smooth', xi_metals=xi_metals,
+    xi_smooth = _component(prob, item, pars, pk_smooth, 'smooth', xi_metals=xi_metals,
                            taps=taps)
     return pars['bao_amp'] * xi_peak + xi_smooth
 
@@ -764,19 +767,32 @@ def prior_chi2(prob, params=None):
     return chi2
 
 
-def chi2(prob, params=None, data_override=None, direct_pk=None):
-    """VegaInterface.chi2 (reference vega_interface.py:250-325); 1e100 on a model error."""
+def compute_marg_coeff(prob, model, data_override=None):
+    """VegaInterface.compute_marg_coeff (reference vega_interface.py:546-579): per item with marginalisation
+    templates, the best-fit coefficients M . (data - model[mask]); a global covariance is ignored."""
+    out = {}
+    for name, item in prob.items.items():
+        if getattr(item, 'marg_diff2coeff', None) is None:
+            continue
+        data = item.masked_data_vec if (data_override is None or prob.global_cov is not None) else data_override[name]
+        out[name] = item.marg_diff2coeff.dot(data - model[name][item.model_mask])
+    return out
+
+
+def chi2(prob, params=None, data_override=None, direct_pk=None, return_marg_coeff=False):
+    """VegaInterface.chi2 (reference vega_interface.py:250-325); 1e100 on a model error.  ``return_marg_coeff``:
+    the tuple (chi2, coefficients) of :281-286, :321-322 ((1e100, None) on a model error: the oracle keeps no
+    ``_random_marg_coeff`` history)."""
     try:
         model = compute_model(prob, params, direct_pk=direct_pk)
     except OracleModelError:
-        return 1e100
+        return (1e100, None) if return_marg_coeff else 1e100
     # marginalize-in-fit: best-fit template coefficients from the residual, templates added to the model
     # (reference vega_interface.py:282-292, :546-579; the coefficients ignore a global covariance)
+    coeffs = compute_marg_coeff(prob, model, data_override)
     for name, item in prob.items.items():
         if getattr(item, 'marginalize_in_fit', False) and item.marg_diff2coeff is not None:
-            data = item.masked_data_vec if (data_override is None or prob.global_cov is not None) else data_override[name]
-            coeff = item.marg_diff2coeff.dot(data - model[name][item.model_mask])
-            model[name] = model[name] + item.marg_templates.dot(coeff)
+            model[name] = model[name] + item.marg_templates.dot(coeffs[name])
     if prob.global_cov is not None:
         g = prob.global_masks()
         data = np.concatenate([it.masked_data_vec for it in prob.items.values()]) \
@@ -791,6 +807,8 @@ def chi2(prob, params=None, data_override=None, direct_pk=None):
             diff = data - model[name][item.model_mask]
             total += diff.T.dot(item.inv_masked_cov.dot(diff))
     total += prior_chi2(prob, params)
+    if return_marg_coeff:
+        return float(total), coeffs
     return float(total)
 
 

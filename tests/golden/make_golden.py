@@ -132,6 +132,12 @@ def derive_configs():
                 if not metals:
                     text = re.sub(r'\[metals\][^\[]*', '', text)
                 (d / f'{it}.ini').write_text(text)
+    # BASELINE configs[1]: the auto-correlation alone with ell = 0, 2, 4
+    d = cfg_out / 'auto_ell4'
+    d.mkdir(exist_ok=True)
+    (d / 'main.ini').write_text(re.sub(r'ini files = .*', 'ini files = configs/auto_ell4/lyalya_lyalya.ini', main))
+    text = re.sub(r'\[metals\][^\[]*', '', (cfg_out / 'full4' / 'lyalya_lyalya.ini').read_text())
+    (d / 'lyalya_lyalya.ini').write_text(text.replace('[model]', '[model]\nell_max = 4'))
     # auto-correlation with the UV shot-noise and DESI instrumental-systematics terms switched on
     d = cfg_out / 'auto_extras'
     d.mkdir(exist_ok=True)
@@ -686,6 +692,163 @@ def dump_fast_metals(VegaInterface):
         print('fast_metals: fid chi2', out['fid/chi2'], 'walkers', out['chi2'])
 
 
+def _inject_synthetic(vega, items):
+    """The seeded distortion matrices and covariances of vega_amd.synthetic in place of the identity stand-ins the
+    reference uses for its test files (vega/data.py:77-80)."""
+    from scipy.sparse import csr_array
+    for name in items:
+        data = vega.data[name]
+        data._distortion_mat = csr_array(synthetic.distortion_matrix(data.model_coordinates.rp_grid,
+                                                                      data.model_coordinates.rt_grid))
+        data._cov_mat = synthetic.covariance(data.data_coordinates.rp_grid, data.data_coordinates.rt_grid)
+        data._inv_masked_cov = None
+        data._log_cov_det = None
+
+
+def dump_config1(VegaInterface):
+    """BASELINE configs[1] as stated: Lya x Lya auto-correlation only, ell = 0, 2, 4 (`ell_max = 4`), dense synthetic
+    2500^2 distortion matrix and covariance; chi2 / log-likelihood / model at the fiducial point and for 4 walkers,
+    one evaluation at a time."""
+    os.chdir(REF / 'tests')
+    items = ['lyalya_lyalya']
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, items, False)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(item.read_text().replace('[model]', '[model]\nell_max = 4'))
+        vega = VegaInterface(main)
+        _inject_synthetic(vega, items)
+        assert vega.models['lyalya_lyalya'].PktoXi.ell_vals == (0, 2, 4)
+        names, walkers = make_walkers(vega.params, 4, seed=WALKER_SEED + 21)
+        out = {'param_names': np.array(names), 'theta': np.array([[w[n] for n in names] for w in walkers])}
+        _reset_caches(vega)
+        out['fid/chi2'] = vega.chi2()
+        out['fid/log_lik'] = vega.log_lik()
+        out['fid/model/lyalya_lyalya'] = vega.compute_model(run_init=False)['lyalya_lyalya']
+        chi2s = []
+        for i, w in enumerate(walkers):
+            _reset_caches(vega)
+            chi2s.append(vega.chi2(w))
+            _reset_caches(vega)
+            out[f'walker{i}/model/lyalya_lyalya'] = vega.compute_model(w, run_init=False)['lyalya_lyalya']
+        out['chi2'] = np.array(chi2s)
+        np.savez_compressed(HERE / 'expected_config1.npz', **out)
+        print('config1: fid chi2', out['fid/chi2'], 'walkers', out['chi2'])
+
+
+def dump_marg_coeff(VegaInterface):
+    """The marginalisation coefficients through the public surface (reference vega/vega_interface.py:208-325,
+    :546-579; the PolyChord adapter calls log_lik(..., return_marg_coeff=True), vega/samplers/polychord.py:106-113):
+    `chi2 / log_lik(return_marg_coeff=True)` and `compute_model(marg_coeff=...)` on the data file of
+    dump_marginalization, templates folded into the covariance and fitted on the fly, at the fiducial point, for one
+    walker, and for a walker whose model cannot be evaluated (the first coefficients ever computed come back)."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    out = {}
+    opts = 'marginalize-below-rtmax = 16.0\nmarginalize-prior-sigma = 5.0'
+    for mode in ('cov', 'infit'):
+        with tempfile.TemporaryDirectory() as tmp:
+            source = read_tables(REF / 'tests/data/cf_lya-exp.fits.gz')
+            data_path = synthetic.write_data_file(Path(tmp) / 'cf_lya-synth.fits', source)
+            main = _ref_main(tmp, ['lyalya_lyalya'], False)
+            item = Path(tmp) / 'lyalya_lyalya.ini'
+            text = re.sub(r'filename = .*', f'filename = {data_path}', item.read_text(), count=1)
+            item.write_text(text.replace('[model]', '[model]\n' + opts))
+            if mode == 'infit':
+                mp = Path(main)
+                mp.write_text(mp.read_text().replace('[control]', '[control]\nmarginalize-in-fit = True'))
+            vega = VegaInterface(main)
+            chi2, coeff = vega.chi2(return_marg_coeff=True)
+            out[f'{mode}/fid/chi2'] = chi2
+            out[f'{mode}/fid/coeff'] = coeff['lyalya_lyalya']
+            ll, flat = vega.log_lik(return_marg_coeff=True)
+            out[f'{mode}/fid/log_lik'] = ll
+            out[f'{mode}/fid/coeff_flat'] = flat
+            out[f'{mode}/fid/model_plain'] = vega.compute_model(run_init=False)['lyalya_lyalya']
+            out[f'{mode}/fid/model_with_templates'] = vega.compute_model(run_init=False, marg_coeff=coeff)['lyalya_lyalya']
+            names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 4)
+            _reset_caches(vega)
+            out[f'{mode}/param_names'] = np.array(names)
+            out[f'{mode}/theta'] = np.array([[walkers[0][n] for n in names]])
+            chi2, coeff = vega.chi2(walkers[0], return_marg_coeff=True)
+            out[f'{mode}/walker0/chi2'] = chi2
+            out[f'{mode}/walker0/coeff'] = coeff['lyalya_lyalya']
+            # a model error (rescaled separations beyond the FFTLog range): chi2 = 1e100 and the first coefficients
+            _reset_caches(vega)
+            bad_chi2, bad_coeff = vega.chi2({'ap': 1e3}, return_marg_coeff=True)
+            out[f'{mode}/bad/chi2'] = bad_chi2
+            out[f'{mode}/bad/coeff'] = bad_coeff['lyalya_lyalya']
+            print('marg coeff', mode, out[f'{mode}/fid/chi2'], out[f'{mode}/fid/coeff'][:3], bad_chi2)
+    np.savez_compressed(HERE / 'expected_marg_coeff.npz', **out)
+
+
+def dump_global_mc(VegaInterface):
+    """Monte-Carlo mocks from a global covariance (reference vega/analysis.py:164-222, used at :270-276; chi2 reads
+    analysis.current_mc_mock, vega/vega_interface.py:294-304): the joint config with the synthetic distortion matrices
+    and a `global-cov-file` written by vega_amd.synthetic; two mocks drawn as Analysis.run_monte_carlo draws them
+    (np.random.seed once, then create_global_monte_carlo per mock) and the chi2 of the fiducial parameters against
+    each; plus chi2 / log-likelihood against the data with that covariance."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    items = ['lyalya_lyalya', 'lyalya_qso']
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, items, False)
+        grids = []
+        for it, f in zip(items, ('cf_lya-exp', 'xcf_lya-exp')):
+            t = read_tables(REF / f'tests/data/{f}.fits.gz')[0].data
+            grids.append((np.asarray(t['RP'], dtype=float), np.asarray(t['RT'], dtype=float)))
+        gc_path = synthetic.write_global_covariance(Path(tmp) / 'global_cov.fits', synthetic.global_covariance(grids))
+        mp = Path(main)
+        mp.write_text(mp.read_text().replace('[data sets]', f'[data sets]\nglobal-cov-file = {gc_path}'))
+        vega = VegaInterface(main)
+        assert vega._use_global_cov
+        _inject_synthetic(vega, items)
+        out = {'data/chi2': vega.chi2(), 'data/log_lik': vega.log_lik()}
+        fid = vega.compute_model(run_init=False)
+        np.random.seed(7)
+        vega.monte_carlo = True
+        for i in range(2):
+            mock = vega.analysis.create_global_monte_carlo(fid, seed=None, scale=None)
+            out[f'mock{i}/global'] = mock.copy()
+            _reset_caches(vega)
+            out[f'mock{i}/chi2_fid'] = vega.chi2()
+            out[f'mock{i}/log_lik_fid'] = vega.log_lik()
+        # a rescaled covariance: a fresh interface (the Cholesky factor is cached with its first scale)
+        vega = VegaInterface(main)
+        _inject_synthetic(vega, items)
+        fid = vega.compute_model(run_init=False)
+        np.random.seed(7)
+        out['scaled/mock0/global'] = vega.analysis.create_global_monte_carlo(fid, seed=None, scale=0.25).copy()
+        np.savez_compressed(HERE / 'expected_global_mc.npz', **out)
+        print('global mc: data chi2', out['data/chi2'], 'mocks', out['mock0/chi2_fid'], out['mock1/chi2_fid'])
+
+
+def dump_model_compute(VegaInterface):
+    """`vega.models[name].compute(pars, pk_full, pk_smooth)` (reference vega/model.py:157-187) - the per-correlation
+    entry point below compute_model - with the fiducial spectra and with caller-supplied ones (the stand-in of
+    direct_pk_vector applied to both), joint config with metals."""
+    import copy
+    os.chdir(REF / 'tests')
+    items = ['lyalya_lyalya', 'lyalya_qso']
+    with tempfile.TemporaryDirectory() as tmp:
+        vega = VegaInterface(_ref_main(tmp, items, True))
+        k = vega.fiducial['k']
+        pk_full = direct_pk_vector(k, vega.fiducial['pk_full'])
+        pk_smooth = direct_pk_vector(k, vega.fiducial['pk_smooth'])
+        names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 31)
+        out = {'pk_full': pk_full, 'pk_smooth': pk_smooth, 'param_names': np.array(names),
+               'theta': np.array([[walkers[0][n] for n in names]])}
+        for name in items:
+            _reset_caches(vega)
+            pars = copy.deepcopy(vega.params)
+            out[f'fiducial_spectra/{name}'] = vega.models[name].compute(pars, vega.fiducial['pk_full'],
+                                                                        vega.fiducial['pk_smooth'])
+            _reset_caches(vega)
+            pars = copy.deepcopy(walkers[0])
+            out[f'own_spectra/{name}'] = vega.models[name].compute(pars, pk_full, pk_smooth)
+        np.savez_compressed(HERE / 'expected_model_compute.npz', **out)
+        print('model compute: dumped', [k for k in out if '/' in k])
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -693,12 +856,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -729,3 +892,11 @@ if __name__ == '__main__':
         dump_new_metals(VI)
     if 'new_bias_evol' in what:
         dump_new_bias_evol(VI)
+    if 'config1' in what:
+        dump_config1(VI)
+    if 'marg_coeff' in what:
+        dump_marg_coeff(VI)
+    if 'global_mc' in what:
+        dump_global_mc(VI)
+    if 'model_compute' in what:
+        dump_model_compute(VI)

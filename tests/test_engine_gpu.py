@@ -96,7 +96,9 @@ def test_synthetic_distortion_and_covariance():
         item.distortion = synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt)
         item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt))
     exp = np.load(GOLDEN / 'expected_joint_synth.npz')
-    for max_batch in (1, 8):      # streaming (GEMV) and MFMA (GEMM, split-K) paths
+    # B <= 8 takes the HBM-streaming kernels (k_gemv1 fused for one walker, k_gemv<8> for the batch of 8); the MFMA
+    # kernels (B > 8) are compared with the same fixture in tests/test_round2_gpu.py
+    for max_batch in (1, 8):
         vega = VegaInterface(None, problem=prob, max_batch=max_batch)
         assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
         theta = _theta(vega, exp)

@@ -12,7 +12,7 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(70, 96), (257, 300), (1000, 1000), (2500, 2500)]
+SHAPES = [(70, 96), (257, 300), (1000, 1000), (2500, 2500), (5000, 5000)]
 BATCHES = [1, 3, 8, 9, 37, 64, 130, 256]
 
 

@@ -102,6 +102,8 @@ struct ItemHost {
     ItemDev dev{};
     std::vector<MetalHost*> metals;
     DevBuf<double> dm, cinv, data, vec, dist, res, z, mock_pool, add_vec;
+    DevBuf<double> marg, marg_out;      // marg_diff2coeff matrix [n_templates][n_masked_pad], coefficients [max_batch][pad]
+    int n_templates = 0;
     int n_mocks = 0;
     DevBuf<int32_t> inv_mask;
     std::vector<int32_t> mask_idx;
@@ -1586,6 +1588,48 @@ int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk)
                        (size_t)nk * sizeof(double), B, hipMemcpyHostToDevice));
     e->direct = true;
     e->dev.pk_direct = e->pk_direct.p;       // every kernel of the chain takes its EngineDev from e->dev
+    return 0;
+}
+
+int vmx_set_linear_spectra(vmx_engine* e, const double* pk_peak, const double* pk_smooth, const double* pk_full, int32_t nk)
+{
+    REQUIRE(e && e->finalized && pk_peak && pk_smooth && pk_full, "vmx_set_linear_spectra (after vmx_finalize)");
+    REQUIRE(nk == e->nk, "linear spectra must live on the template's k grid");
+    for (auto& p : e->pipes) REQUIRE(!p.odd_rel && !p.odd_asy, "the odd-multipole terms hold static splines of the template's spectra");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    const double* src[3] = {pk_peak, pk_smooth, pk_full};
+    for (int i = 0; i < 3; ++i)
+        HIP_OK(hipMemcpy(e->pklin.p + (size_t)i * e->nkp, src[i], (size_t)nk * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int vmx_item_set_marg_matrix(vmx_engine* e, int32_t item, const double* m, int32_t n_templates, int32_t n_masked)
+{
+    REQUIRE(e && !e->finalized && m, "vmx_item_set_marg_matrix (before vmx_finalize)");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(it->has_mask && n_masked == it->dev.n_masked && n_templates > 0, "marginalisation matrix shape: [n_templates][n_masked]");
+    HIP_OK(hipSetDevice(e->device));
+    if (upload_padded(it->marg, m, n_templates, n_masked, it->dev.n_masked_pad)) return -2;
+    it->n_templates = n_templates;
+    return 0;
+}
+
+int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B)
+{
+    REQUIRE(e && e->finalized && out, "vmx_marg_coeff");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(it->n_templates > 0, "no marginalisation matrix was set for this item");
+    REQUIRE(B > 0 && B == e->last_B, "vmx_marg_coeff reads the residuals of the last evaluation: B must be its batch size");
+    HIP_OK(hipSetDevice(e->device));
+    const int ldo = vmx_pad(it->n_templates);
+    if (it->marg_out.n < (size_t)e->max_batch * ldo && it->marg_out.alloc((size_t)e->max_batch * ldo, true)) return -2;
+    if (vmx_matvec_device(e, it->marg.p, it->n_templates, it->dev.n_masked_pad, it->res.p, B, it->marg_out.p)) return -2;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipMemcpy2D(out, (size_t)it->n_templates * sizeof(double), it->marg_out.p, (size_t)ldo * sizeof(double),
+                       (size_t)it->n_templates * sizeof(double), B, hipMemcpyDeviceToHost));
     return 0;
 }
 

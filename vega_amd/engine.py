@@ -134,6 +134,9 @@ def load_library():
     lib.vmx_sync.argtypes = [C.c_void_p]
     lib.vmx_set_constant_nl_hint.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_direct_pk.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_int32]
+    lib.vmx_set_linear_spectra.argtypes = [C.c_void_p, dptr, dptr, dptr, C.c_int32]
+    lib.vmx_item_set_marg_matrix.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32]
+    lib.vmx_marg_coeff.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32]
     lib.vmx_stream.argtypes = [C.c_void_p]
     lib.vmx_stream.restype = C.c_void_p
     lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
@@ -164,7 +167,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -665,6 +668,10 @@ class Engine:
                 raise ValueError(f'{name}: model mask keeps {idx.size} bins but the data mask {item.data_size}')
             self._check(lib.vmx_item_set_mask(self._h, iid, _ip(idx), idx.size))
             self._check(lib.vmx_item_set_data(self._h, iid, _dp(_f64(item.masked_data_vec)), idx.size))
+            if getattr(item, 'marg_diff2coeff', None) is not None:
+                # best-fit template coefficients = M . residual (reference vega_interface.py:546-579)
+                m = _f64(item.marg_diff2coeff)
+                self._check(lib.vmx_item_set_marg_matrix(self._h, iid, _dp(m), m.shape[0], m.shape[1]))
             if item.cov is not None and prob.global_cov is None:
                 cinv = _f64(item.chi2_matrix)      # C^-1, or P^T C^-1 P with marginalize-in-fit (setup.py)
                 self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_INVCOV, 0, cinv.shape[0], cinv.shape[1],
@@ -768,6 +775,24 @@ class Engine:
             return
         pk = _f64(np.atleast_2d(pk))
         self._check(self.lib.vmx_set_direct_pk(self._h, _dp(pk), pk.shape[0], pk.shape[1]))
+
+    def set_linear_spectra(self, pk_full, pk_smooth):
+        """Replace the template's linear spectra (``Model.compute(pars, pk_full, pk_smooth)``, reference
+        model.py:157-187); the peak spectrum is their difference (model.py:177)."""
+        pk_full, pk_smooth = _f64(pk_full), _f64(pk_smooth)
+        if pk_full.shape != (self.prob.k.size,) or pk_smooth.shape != pk_full.shape:
+            raise ValueError('pk_full and pk_smooth live on the template k grid')
+        peak = _f64(pk_full - pk_smooth)
+        self._check(self.lib.vmx_set_linear_spectra(self._h, _dp(peak), _dp(pk_smooth), _dp(pk_full), pk_full.size))
+
+    def marg_coeff(self, name, B):
+        """Marginalisation-template coefficients [B, n_templates] of item ``name`` for the last evaluation (its batch
+        size B): the static map of the residual, applied by the engine's product kernels."""
+        qi = self.item_names.index(name)
+        nt = self.prob.items[name].marg_diff2coeff.shape[0]
+        out = np.empty((B, nt))
+        self._check(self.lib.vmx_marg_coeff(self._h, qi, _dp(out), B))
+        return out
 
     def set_parameter_transform(self, scale=None, shift=None):
         """Parameter-level blinding: every walker becomes scale * theta + shift (per column) before the model and the

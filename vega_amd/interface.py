@@ -35,6 +35,29 @@ class _DataView:
     full_data_size = property(lambda self: self._item.data_vec.size)
 
 
+class _ModelView:
+    """``vega.models[name]``: the per-correlation entry points of the reference's ``Model`` that sit below
+    ``compute_model`` (reference vega/model.py:157-207), over the same engine.  ``pars`` is a complete local parameter
+    dictionary as ``_get_lcl_prms`` hands it to the reference's models - blinding offsets already applied - so no
+    transform is applied here."""
+
+    def __init__(self, vega, name):
+        self._vega, self._name = vega, name
+
+    def compute(self, pars, pk_full, pk_smooth):
+        """Full correlation function of this item from the peak / smooth decomposition of the given linear spectra
+        (reference vega/model.py:157-187).  Like the reference it leaves ``pars['peak'] = False`` behind."""
+        xi = self._vega._item_model(self._name, pars, pk_full, pk_smooth)
+        pars['peak'] = False
+        return xi
+
+    def compute_direct(self, pars, pk_full):
+        """Model straight from a full linear spectrum, no decomposition (reference vega/model.py:188-207)."""
+        xi = self._vega._item_model(self._name, pars, pk_full, None)
+        pars['peak'] = False
+        return xi
+
+
 class VegaInterface:
     """GPU-backed stand-in for ``vega.VegaInterface`` restricted to the model + chi2 hot path."""
 
@@ -66,6 +89,11 @@ class VegaInterface:
         self._pinned_slots = np.zeros(0, dtype=np.int64)
         self._pinned_values = np.zeros(0)
         self._pinned_names = []
+        # marginalisation templates fitted on the fly / reported (reference vega_interface.py:281-292, :546-579)
+        self.marginalize_in_fit = any(it.marginalize_in_fit for it in self.problem.items.values())
+        self._marg_names = [n for n, it in self.problem.items.items() if it.marg_diff2coeff is not None]
+        self._random_marg_coeff = None
+        self.models = {name: _ModelView(self, name) for name in self.problem.items}
 
     # ------------------------------------------------------------------ blinding
     def set_blinding_offsets(self, offsets):
@@ -188,6 +216,16 @@ class VegaInterface:
         (reference vega/vega_interface.py:296-297, :311-313)."""
         if self.monte_carlo == self._mc_active and not self.monte_carlo:
             return
+        if self.monte_carlo and self._use_global_cov:
+            # reference vega_interface.py:296-297: the global mock of the analysis object, in item order
+            mock = getattr(getattr(self, 'analysis', None), 'current_mc_mock', None)
+            if mock is None:
+                raise ValueError('monte_carlo is set but analysis.current_mc_mock is None')
+            from .montecarlo import split_global
+            for name, part in split_global(self.problem, np.asarray(mock, dtype=np.float64)[None, :]).items():
+                self.engine.set_data(name, part[0])
+            self._mc_active = True
+            return
         for name, view in self.data.items():
             if self.monte_carlo:
                 if view.masked_mc_mock is None:
@@ -205,9 +243,9 @@ class VegaInterface:
 
     # ------------------------------------------------------------------ reference surface
     def compute_model(self, params=None, run_init=True, direct_pk=None, marg_coeff=None):
-        """dict name -> model correlation function (distorted grid), as the reference returns."""
-        if marg_coeff is not None:
-            raise NotImplementedError('marginalisation templates are not accelerated')
+        """dict name -> model correlation function (distorted grid), as the reference returns.  ``marg_coeff``
+        (dict name -> template coefficients, as ``chi2(..., return_marg_coeff=True)`` returns them) adds the
+        marginalisation templates to the items that have them (reference vega_interface.py:208-248)."""
         self.freeze_metals(params)
         self._check_pinned(self._theta(params)[None, :])
         with self._direct(direct_pk):
@@ -215,23 +253,88 @@ class VegaInterface:
         if status[0]:
             from .errors import VegaModelError
             raise VegaModelError(f'model evaluation failed (status {int(status[0])})')
-        return {name: model[0, sl].copy() for name, sl in self.engine.model_slices.items()}
+        out = {name: model[0, sl].copy() for name, sl in self.engine.model_slices.items()}
+        if marg_coeff is not None:
+            for name, item in self.problem.items.items():
+                if item.marg_templates is not None:
+                    out[name] += self._templates_times(name, np.asarray(marg_coeff[name], dtype=np.float64)[None, :])[0]
+        return out
+
+    def _templates_times(self, name, coeff):
+        """coeff [B, n_templates] -> distorted templates . coeff [B, n_dist], on the engine's product kernels."""
+        dense = self._template_cache.get(name) if hasattr(self, '_template_cache') else None
+        if dense is None:
+            tm = self.problem.items[name].marg_templates
+            dense = np.ascontiguousarray(tm.toarray() if hasattr(tm, 'toarray') else tm, dtype=np.float64)
+            self.__dict__.setdefault('_template_cache', {})[name] = dense
+        return self.engine.matmul_host(dense, coeff)
+
+    def _marg_coeff(self, B):
+        """dict name -> [B, n_templates] for the items with marginalisation templates, from the residuals of the
+        evaluation that has just run (reference vega_interface.py:546-579: per item, ignoring a global covariance)."""
+        return {name: self.engine.marg_coeff(name, B) for name in self._marg_names}
 
     def chi2(self, params=None, direct_pk=None, return_marg_coeff=False):
-        """float chi2; 1e100 when the model cannot be evaluated (reference :268-279)."""
-        if return_marg_coeff:
-            raise NotImplementedError('marginalisation coefficients are not returned')
+        """float chi2; 1e100 when the model cannot be evaluated (reference :268-279).  With ``return_marg_coeff`` the
+        reference's tuple ``(chi2, {name: coefficients})``; after a model error ``(1e100, first coefficients ever
+        computed, or None)`` (reference :273-279, :285-286)."""
         self.freeze_metals(params)
         self._check_pinned(self._theta(params)[None, :])
         self._sync_monte_carlo()
         with self._direct(direct_pk):
-            chi2, _, _ = self.engine.eval(self._theta(params)[None, :])
+            chi2, status, _ = self.engine.eval(self._theta(params)[None, :])
+        if status[0]:               # the engine's chi2 is the 1e100 sentinel
+            return (float(chi2[0]), self._random_marg_coeff) if return_marg_coeff else float(chi2[0])
+        if return_marg_coeff or (self.marginalize_in_fit and self._random_marg_coeff is None):
+            coeff = {name: c[0] for name, c in self._marg_coeff(1).items()}
+            if self._random_marg_coeff is None:
+                self._random_marg_coeff = coeff
+            if return_marg_coeff:
+                return float(chi2[0]), coeff
         return float(chi2[0])
 
     def log_lik(self, params=None, direct_pk=None, return_marg_coeff=False):
-        """Gaussian log-likelihood with its normalisation (reference :327-387)."""
-        chi2 = self.chi2(params, direct_pk, return_marg_coeff)
-        return float(self._log_norm() - 0.5 * chi2)
+        """Gaussian log-likelihood with its normalisation (reference :327-387).  With ``return_marg_coeff`` the
+        reference's ``(log_lik, coefficients of all items stacked in sorted name order)`` - the closure the PolyChord
+        adapter builds (reference vega/samplers/polychord.py:106-113) - or ``(log_lik, None)``."""
+        if not return_marg_coeff:
+            return float(self._log_norm() - 0.5 * self.chi2(params, direct_pk))
+        chi2, coeff = self.chi2(params, direct_pk, True)
+        log_lik = float(self._log_norm() - 0.5 * chi2)
+        if coeff is None:
+            return log_lik, None
+        names = sorted(coeff)
+        if len(names) > 1:
+            return log_lik, np.hstack([coeff[n] for n in names])
+        return log_lik, (coeff[names[0]] if names else np.array([]))
+
+    def _item_model(self, name, pars, pk_full, pk_smooth):
+        """One item's model for a complete local parameter dictionary and caller-supplied spectra
+        (``pk_smooth = None``: the direct form).  The whole engine evaluates; the item's slice is returned."""
+        from .errors import VegaModelError
+        theta = self.engine.theta_from_params({k: v for k, v in pars.items() if k != 'peak'})
+        self.freeze_metals(theta)
+        self._check_pinned(theta[None, :])
+        eng = self.engine
+        own = pk_smooth is not None and not (np.array_equal(pk_full, self.problem.pk_full)
+                                             and np.array_equal(pk_smooth, self.problem.pk_smooth))
+        if own and eng.metal_plan:
+            raise NotImplementedError('frozen metal terms were extracted with the fiducial spectra')
+        if self._rnsps is not None:
+            eng.set_parameter_transform(None, None)     # `pars` already carries the offsets
+        try:
+            if own:
+                eng.set_linear_spectra(pk_full, pk_smooth)
+            with self._direct(pk_full if pk_smooth is None else None):
+                _, status, model = eng.eval(theta[None, :], want_model=True)
+        finally:
+            if own:
+                eng.set_linear_spectra(self.problem.pk_full, self.problem.pk_smooth)
+            if self._rnsps is not None:
+                self._push_blinding()
+        if status[0]:
+            raise VegaModelError(f'model evaluation failed (status {int(status[0])})')
+        return model[0, eng.model_slices[name]].copy()
 
     def _log_norm(self):
         log_norm = 0.
@@ -269,21 +372,31 @@ class VegaInterface:
         with self._direct(direct_pk):
             return self.engine.eval(theta)[0]
 
-    def chi2_batch(self, params_list, return_status=False):
+    def chi2_batch(self, params_list, return_status=False, return_marg_coeff=False):
         """chi2 for many parameter points: list of dicts or [B, n_params] array (column order
-        ``self.param_names``).  Points are evaluated in chunks of ``max_batch``."""
+        ``self.param_names``).  Points are evaluated in chunks of ``max_batch``.  ``return_marg_coeff`` appends
+        ``{name: [B, n_templates]}`` (rows of walkers whose model failed are NaN)."""
         theta = self.theta_matrix(params_list)
         self.freeze_metals(theta[0])        # fast_metals: the first point of the first batch plays the first call
         self._check_pinned(theta)
         self._sync_monte_carlo()
         out = np.empty(theta.shape[0])
         status = np.empty(theta.shape[0], dtype=np.int32)
+        coeff = {name: np.empty((theta.shape[0], self.problem.items[name].marg_diff2coeff.shape[0]))
+                 for name in self._marg_names} if return_marg_coeff else None
         mb = self.engine.max_batch
         for lo in range(0, theta.shape[0], mb):
             c, s, _ = self.engine.eval(theta[lo:lo + mb])
             out[lo:lo + mb] = c
             status[lo:lo + mb] = s
-        return (out, status) if return_status else out
+            if return_marg_coeff:
+                for name, block in self._marg_coeff(c.size).items():
+                    block[s != 0] = np.nan
+                    coeff[name][lo:lo + mb] = block
+        res = (out, status) if return_status else (out,)
+        if return_marg_coeff:
+            res = res + (coeff,)
+        return res if len(res) > 1 else res[0]
 
     def log_lik_batch(self, params_list):
         return self._log_norm() - 0.5 * self.chi2_batch(params_list)
@@ -307,11 +420,15 @@ class VegaInterface:
         from .montecarlo import MonteCarlo
         self.freeze_metals()
         self._sync_monte_carlo()
-        fitter = MonteCarlo(self).minimizer(tol=tol)
-        start = None
-        if params is not None and 'values' in params:
-            start = [[params['values'].get(n, v) for n, v in zip(fitter.names, fitter.start)]]
-        self.bestfit = fitter.minimize(n_fits=1, start=start)
+        # `params` overrides entries of the sampling table, as Minimizer.minimize(params) does for chi2 scans
+        # (reference vega/minimizer.py:39-64: values / errors / limits / fix)
+        sample = {key: dict(self.sample_params.get(key, {})) for key in ('limits', 'values', 'errors', 'fix')}
+        for key in sample:
+            if params is not None and key in params:
+                sample[key].update({n: v for n, v in params[key].items() if n in sample['limits']})
+        driver = MonteCarlo(self)
+        fitter = driver.minimizer(sample, tol=tol)
+        self.bestfit = fitter.minimize(n_fits=1, fixed=driver._fixed)
         return self.bestfit
 
     def run_monte_carlo(self, fiducial_model=None, num_mocks=1, seed=0, scale=None, forecast=False,
@@ -326,6 +443,30 @@ class VegaInterface:
         return self.analysis.run_monte_carlo(fiducial_model, num_mocks=num_mocks, seed=seed, scale=scale,
                                              forecast=forecast, run_mc_fits=run_mc_fits,
                                              sample_params=sample_params)
+
+    def get_fiducial_for_monte_carlo(self, print_func=print):
+        """The fiducial model the mocks are drawn around (reference vega_interface.py:448-503): the [mc parameters]
+        on top of a fit to the data when parameters are sampled; `use_measured_fiducial` reads it from files,
+        `use_full_pk_for_mc` computes it from the full spectrum directly."""
+        if self.problem.mc_config is None:
+            raise ValueError('No Monte Carlo config provided: add a [monte carlo] section')
+        control = self.main_config['control'] if 'control' in self.main_config else {}
+        mc_params = dict(self.problem.mc_config['params'])
+        if control.get('mc_start_from_fit', None) is not None:
+            raise NotImplementedError('mc_start_from_fit (reading a previous fit file) is not supported')
+        if self.sample_params['limits']:
+            print_func('Running initial fit')
+            res = self.minimize()
+            mc_params = {**res.as_dict(), **mc_params}
+            print_func(f'Set template parameters to {mc_params}.')
+        if getattr(control, 'getboolean', None) and control.getboolean('use_measured_fiducial', False):
+            from .tables import find_file, read_tables
+            return {name: np.asarray(read_tables(find_file(control.get(f'mc_fiducial_{name}'),
+                                                           self.problem.search_dirs))[0].data['DA'], dtype=float)
+                    for name in self.corr_items}
+        if getattr(control, 'getboolean', None) and control.getboolean('use_full_pk_for_mc', False):
+            return self.compute_model(mc_params, direct_pk=self.fiducial['pk_full'])
+        return self.compute_model(mc_params)
 
     def close(self):
         self.engine.close()

@@ -185,7 +185,10 @@ class BatchedMinimizer:
                 V[i][free, free] = 0.5 * sigma[i, free]**2 / self.errordef
                 d[a] = -V[i] @ ga[a]
                 slope[a] = ga[a] @ d[a]
-            edm[act] = -0.5 * slope
+            edm[act] = np.where(bad, np.inf, -0.5 * slope)
+            # a gradient stencil that hit a point the model cannot evaluate ends the fit as a FAILED one (infinite EDM,
+            # never reported as a valid minimum), not as a converged one
+            self._bad[act[bad]] = True
             conv = (edm[act] < self.edm_goal) | bad
             done[act[conv]] = True
             n_iter[act] += 1
@@ -271,6 +274,7 @@ class BatchedMinimizer:
         self._nfcn = np.zeros(F, dtype=np.int64)
         self._x_prev = x.copy()
         self._stalled = np.zeros(F, dtype=bool)
+        self._bad = np.zeros(F, dtype=bool)
         free_all = np.array([j for j, n in enumerate(self.names) if n not in fixed], dtype=int)
         n_iter = np.zeros(F, dtype=int)
 
@@ -280,6 +284,7 @@ class BatchedMinimizer:
             x, f, edm, it0 = self._stage(x, bias, fits_all)
             n_iter += it0
             self._stalled[:] = False
+            self._bad[:] = False        # the full stage decides
         x, f, edm, it1 = self._stage(x, free_all, fits_all)
         n_iter += it1
 
@@ -292,7 +297,7 @@ class BatchedMinimizer:
         cov_int, failed = self._hesse(x, f, sigma_int, free_all, fits_all)
         cov = cov_int * jac[:, :, None] * jac[:, None, :]
         errors = np.sqrt(np.clip(np.einsum('fii->fi', cov), 0., None))
-        valid = (edm < self.edm_goal * 10) & ~failed & np.isfinite(f)
+        valid = (edm < self.edm_goal * 10) & ~failed & np.isfinite(f) & ~self._bad
         return FitResult(names=self.names, values=self.transform.to_external(x), errors=errors, covariance=cov,
                          fval=f, edm=edm, is_valid=valid, hesse_failed=failed, nfcn=self._nfcn.copy(),
                          n_iter=n_iter)

@@ -1,12 +1,18 @@
 """Monte-Carlo mocks and their batched fits (BASELINE configs[4]).
 
-Mirrors ``Data.create_monte_carlo`` (reference vega/data.py:689-760) and ``Analysis.run_monte_carlo``
-(reference vega/analysis.py:224-308, driven by bin/run_vega_mc_mpi.py:52-71): a mock is the fiducial model
-plus ``cholesky(scale * C_masked) . randn(n_masked)`` drawn from NumPy's legacy global generator after
-``np.random.seed(seed)`` - per mock, item by item - so the same seed gives the reference's mocks bit for bit.
-The fits are where the GPU changes the algorithm: instead of one MIGRAD after another, all mocks of a rank are
-minimised in lock-step by :class:`vega_amd.minimizer.BatchedMinimizer`, each batch of trial points being one
-engine call with a per-walker mock index (``vmx_set_mock_index``).
+Mirrors ``Data.create_monte_carlo`` (reference vega/data.py:689-760), ``Analysis.create_monte_carlo_sim`` /
+``create_global_monte_carlo`` (reference vega/analysis.py:124-222) and ``Analysis.run_monte_carlo``
+(reference vega/analysis.py:224-308, driven by bin/run_vega_mc_mpi.py:52-71).
+
+* independent correlations: a mock is the fiducial model plus ``cholesky(scale * C_masked) . randn(n_masked)`` drawn
+  from NumPy's legacy global generator after ``np.random.seed(seed)`` - per mock, item by item;
+* global covariance (``global-cov-file``): ONE ``randn(sum n_masked)`` per mock through the Cholesky factor of the
+  masked global covariance, so the mocks carry the cross-covariance between the correlations;
+
+either way the same seed gives the reference's mocks to rounding.  The fits are where the GPU changes the algorithm:
+instead of one MIGRAD after another, all mocks of a rank are minimised in lock-step by
+:class:`vega_amd.minimizer.BatchedMinimizer`, each batch of trial points being one engine call with a per-walker mock
+index (``vmx_set_mock_index``).
 """
 import numpy as np
 
@@ -14,42 +20,112 @@ from .minimizer import BatchedMinimizer
 from .parallel import shard_bounds
 
 
-def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecast=False, matmul=None):
-    """dict name -> [num_mocks, n_masked] masked mock data vectors, in the reference's draw order.
-    ``matmul(L, Z) -> Z @ L.T`` (default: NumPy) applies the Cholesky factor to all draws of an item at once -
-    the driver passes the engine's product so that the only O(n^2) step per mock runs on the GPU."""
-    scale = 1. if scale is None else scale
-    np.random.seed(seed)
-    chol = {}
-    fid = {}
+def _fiducial_on_data_grid(item, model):
+    """The fiducial model on the item's data grid (reference vega/data.py:737-742, analysis.py:197-206)."""
+    model = np.asarray(model, dtype=float)
+    if model.size == item.data_vec.size:
+        return model
+    if model.size != item.dist_grid.size:
+        raise ValueError('Could not match fiducial model to data or model size.')
+    # distorted-model grid -> data grid (reference vega/coordinates.py:127-144)
+    keep = (item.dist_grid.rp >= item.data_grid.rp_min) & (item.dist_grid.rp <= item.data_grid.rp_max)
+    keep &= item.dist_grid.rt <= item.data_grid.rt_max
+    return model[keep]
+
+
+def item_scales(problem, scale):
+    """Covariance scale of every item as ``create_monte_carlo_sim`` resolves it (reference analysis.py:147-156):
+    None -> the item's ``cov_rescale`` (and Data.create_monte_carlo turns a None into 1), a number -> that number,
+    a dict -> its entry, 1 for items it does not name."""
+    out = {}
     for name, item in problem.items.items():
-        model = np.asarray(fiducial_model[name], dtype=float)
-        if model.size != item.data_vec.size:
-            if model.size != item.dist_grid.size:
-                raise ValueError('Could not match fiducial model to data or model size.')
-            # distorted-model grid -> data grid (reference vega/coordinates.py:127-144)
-            keep = (item.dist_grid.rp >= item.data_grid.rp_min) & (item.dist_grid.rp <= item.data_grid.rp_max)
-            keep &= item.dist_grid.rt <= item.data_grid.rt_max
-            model = model[keep]
-        fid[name] = model[item.data_mask]
-        if not forecast:
-            cache = item.__dict__.setdefault('_masked_cholesky', {})       # one factorisation per (item, scale)
-            if scale not in cache:
-                n = item.data_size
-                cov = np.eye(n) if item.cov is None else item.cov[:, item.data_mask][item.data_mask, :]
-                cache[scale] = np.linalg.cholesky(scale * cov)
-            chol[name] = cache[scale]
+        if scale is None:
+            s = item.cov_rescale
+        elif isinstance(scale, (int, float)) and not isinstance(scale, bool):
+            s = scale
+        elif isinstance(scale, dict) and name in scale:
+            s = scale[name]
+        else:
+            s = 1.
+        out[name] = 1. if s is None else float(s)
+    return out
+
+
+def _default_matmul(L, Z):
+    return Z @ L.T
+
+
+def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecast=False, matmul=None):
+    """dict name -> [num_mocks, n_masked] masked mock data vectors of independent correlations, in the reference's
+    draw order.  ``matmul(L, Z) -> Z @ L.T`` (default: NumPy) applies the Cholesky factor to all draws of an item at
+    once - the driver passes the engine's product so that the only O(n^2) step per mock runs on the GPU."""
+    if problem.global_cov is not None:
+        raise ValueError('this problem has a global covariance: its mocks come from create_global_mocks')
+    scales = item_scales(problem, scale)
+    matmul = matmul or _default_matmul
+    np.random.seed(seed)
+    chol, fid = {}, {}
+    for name, item in problem.items.items():
+        fid[name] = _fiducial_on_data_grid(item, fiducial_model[name])
+        if forecast:
+            continue
+        if item.cov is None:
+            raise ValueError(f'{name}: Monte-Carlo mocks need a covariance matrix')
+        cache = item.__dict__.setdefault('_cholesky', {})       # one factorisation per (item, scale, masked or full)
+        key = (scales[name], bool(item.cholesky_masked_cov))
+        if key not in cache:
+            cov = item.cov[:, item.data_mask][item.data_mask, :] if item.cholesky_masked_cov else item.cov
+            cache[key] = np.linalg.cholesky(scales[name] * cov)
+        chol[name] = cache[key]
     if forecast:
-        return {name: np.tile(fid[name], (num_mocks, 1)) for name in problem.items}
-    # the legacy global generator is consumed mock by mock, item by item (reference vega/data.py:751-753)
-    draws = {name: np.empty((num_mocks, item.data_size)) for name, item in problem.items.items()}
+        return {name: np.tile(fid[name][item.data_mask], (num_mocks, 1)) for name, item in problem.items.items()}
+    # the legacy global generator is consumed mock by mock, item by item (reference vega/data.py:748-757): n_masked
+    # numbers per item, or the full data size with `cholesky-masked-cov = False`
+    draws = {name: np.empty((num_mocks, chol[name].shape[0])) for name in problem.items}
     for i in range(num_mocks):
-        for name, item in problem.items.items():
-            draws[name][i] = np.random.randn(item.data_size)
-    if matmul is None:
-        def matmul(L, Z):
-            return Z @ L.T
-    return {name: fid[name][None, :] + matmul(chol[name], draws[name]) for name in problem.items}
+        for name in problem.items:
+            draws[name][i] = np.random.randn(chol[name].shape[0])
+    out = {}
+    for name, item in problem.items.items():
+        noise = matmul(chol[name], draws[name])
+        if item.cholesky_masked_cov:
+            out[name] = fid[name][item.data_mask][None, :] + noise
+        else:
+            out[name] = (fid[name][None, :] + noise)[:, item.data_mask]
+    return out
+
+
+def create_global_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecast=False, matmul=None):
+    """[num_mocks, sum n_masked] mocks of the concatenated masked data vector from the global covariance (reference
+    vega/analysis.py:164-222): one Cholesky factor of ``scale *`` the masked global covariance - cached with the FIRST
+    scale it is built with, as the reference caches it - and one ``randn`` per mock over all correlations."""
+    gm = problem.global_masks()
+    if gm is None:
+        raise ValueError('create_global_mocks requires a global covariance matrix')
+    matmul = matmul or _default_matmul
+    np.random.seed(seed)
+    mask = gm['data_mask']
+    fid = np.concatenate([_fiducial_on_data_grid(item, fiducial_model[name])
+                          for name, item in problem.items.items()])[mask]
+    if forecast:
+        return np.tile(fid, (num_mocks, 1))
+    if gm.get('cholesky') is None:
+        masked = problem.global_cov[:, mask][mask, :]
+        gm['cholesky'] = np.linalg.cholesky((1 if scale is None else scale) * masked)
+    n = int(mask.sum())
+    draws = np.empty((num_mocks, n))
+    for i in range(num_mocks):
+        draws[i] = np.random.randn(n)
+    return fid[None, :] + matmul(gm['cholesky'], draws)
+
+
+def split_global(problem, vectors):
+    """[num_mocks, sum n_masked] -> dict name -> [num_mocks, n_masked] in item order."""
+    out, lo = {}, 0
+    for name, item in problem.items.items():
+        out[name] = np.ascontiguousarray(vectors[:, lo:lo + item.data_size])
+        lo += item.data_size
+    return out
 
 
 class MonteCarlo:
@@ -58,6 +134,7 @@ class MonteCarlo:
     def __init__(self, vega):
         self.vega = vega
         self.has_monte_carlo = False
+        self.current_mc_mock = None
 
     def minimizer(self, sample_params=None, tol=0.1):
         """BatchedMinimizer over ``sample_params`` (default: the interface's [sample] section) whose objective
@@ -88,41 +165,67 @@ class MonteCarlo:
         start = [sp['values'][n] for n in names]
         errors = [sp['errors'][n] for n in names]
         limits = [sp['limits'][n] for n in names]
+        self._fixed = tuple(n for n in names if sp.get('fix', {}).get(n, False))
         return BatchedMinimizer(evaluate, names, start, errors, limits, tol=tol)
+
+    def create_mocks(self, fiducial_model, num_mocks=1, seed=0, scale=None, forecast=False):
+        """dict name -> [num_mocks, n_masked]: the reference's mocks for ``seed``, per item or - when the problem has a
+        global covariance - split from the global draw (kept whole in ``mc_mocks['global']``)."""
+        vega = self.vega
+        prob = vega.problem
+        if prob.global_cov is not None:
+            if scale is None and prob.main_config is not None and 'control' in prob.main_config:
+                # reference vega_interface.py:531-533
+                scale = prob.main_config['control'].getfloat('global_cov_rescale', None)
+            whole = create_global_mocks(prob, fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast,
+                                        matmul=vega.engine.matmul_host)
+            self.mc_mocks = {'global': whole}
+            self.current_mc_mock = whole[-1]
+            return split_global(prob, whole)
+        mocks = create_mocks(prob, fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast,
+                             matmul=vega.engine.matmul_host)
+        self.mc_mocks = mocks
+        return mocks
 
     def run_monte_carlo(self, fiducial_model, num_mocks=1, seed=0, scale=None, forecast=False,
                         run_mc_fits=True, sample_params=None):
         vega = self.vega
         eng = vega.engine
-        mocks = create_mocks(vega.problem, fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast,
-                             matmul=eng.matmul_host)
-        self.mc_mocks = mocks
+        prob = vega.problem
+        mocks = self.create_mocks(fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast)
         if not run_mc_fits:
             self.has_monte_carlo = True
             return None
+        if sample_params is None and prob.mc_config is not None:
+            sample_params = prob.mc_config['sample']       # the [monte carlo] section (reference analysis.py:249)
+        scales = item_scales(prob, scale)
         for name, pool in mocks.items():
             eng.set_mock_pool(name, pool)
-            if scale is not None and vega.problem.items[name].cov is not None and not vega._use_global_cov:
-                eng.set_invcov(name, vega.problem.items[name].chi2_matrix / scale)
+            if scales[name] != 1. and prob.items[name].cov is not None and not vega._use_global_cov:
+                if prob.items[name].marginalize_in_fit:
+                    raise NotImplementedError('a rescaled covariance with marginalize-in-fit is not supported')
+                eng.set_invcov(name, prob.items[name].chi2_matrix / scales[name])
         fitter = self.minimizer(sample_params)
         self._mock_rows = np.arange(num_mocks, dtype=np.int32)
         try:
-            res = fitter.minimize(n_fits=num_mocks)
+            res = fitter.minimize(n_fits=num_mocks, fixed=self._fixed)
         finally:
             eng.set_mock_index(None)
             self._mock_rows = None
-            if scale is not None:
-                for name, item in vega.problem.items.items():
-                    if item.cov is not None and not vega._use_global_cov:
-                        eng.set_invcov(name, item.chi2_matrix)
+            for name, item in prob.items.items():
+                if scales[name] != 1. and item.cov is not None and not vega._use_global_cov:
+                    eng.set_invcov(name, item.chi2_matrix)
         self.fit_result = res
-        self.mc_bestfits = {n: np.stack([res.values[:, j], res.errors[:, j]], axis=1)
+        # a fit that could not run has no Bestfit / covariance row and chisq = NaN (reference analysis.py:279-297)
+        failed = ~np.isfinite(res.fval)
+        ok = ~failed
+        self.mc_bestfits = {n: np.stack([res.values[ok, j], res.errors[ok, j]], axis=1)
                             for j, n in enumerate(res.names)}
-        self.mc_covariances = list(res.covariance)
-        self.mc_chisq = list(res.fval)
+        self.mc_covariances = list(res.covariance[ok])
+        self.mc_chisq = list(np.where(failed, np.nan, res.fval))
         self.mc_valid_minima = list(res.is_valid)
         self.mc_valid_hesse = list(~res.hesse_failed)
-        self.mc_failed_mask = list(~np.isfinite(res.fval))
+        self.mc_failed_mask = list(failed)
         self.has_monte_carlo = True
         return res
 
@@ -136,10 +239,11 @@ def run_monte_carlo_sharded(vega, fiducial_model, num_mc_mocks, seed=0, rank=0, 
                             **kw):
     """The rank's share of ``num_mc_mocks`` with the reference's seeding: ceil(N / size) mocks per rank drawn
     from ``seed + rank``, and one result file per rank when ``output_dir`` is given (reference
-    bin/run_vega_mc_mpi.py:52-71)."""
+    bin/run_vega_mc_mpi.py:52-71; scripts/run_mc_sharded.py is the launcher)."""
     lo, hi = shard_bounds(num_mc_mocks, world_size, rank)
     per = -(-num_mc_mocks // world_size)
     mc = MonteCarlo(vega)
+    vega.analysis = mc
     res = mc.run_monte_carlo(fiducial_model, num_mocks=per, seed=int(seed + rank), **kw)
     if output_dir is not None:
         mc.write(output_dir, cpu_id=rank if world_size > 1 else None, overwrite=True)

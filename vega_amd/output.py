@@ -17,8 +17,9 @@ def monte_carlo_tables(analysis):
     tables = []
     bestfits = getattr(analysis, 'mc_bestfits', None)
     if bestfits:
+        # (rows of mc_bestfits / mc_covariances are the successful fits only, as in the reference: analysis.py:279-297)
         names = np.array(list(bestfits.keys()))
-        values = np.array([bestfits[n][:, 0] for n in names])          # [parameters][mocks]
+        values = np.array([bestfits[n][:, 0] for n in names])          # [parameters][successful mocks]
         errors = np.array([bestfits[n][:, 1] for n in names])
         cov = np.array(analysis.mc_covariances)                         # [mocks][parameters][parameters]
         cov = cov.reshape(values.shape[1] * len(names), len(names)).T   # reference :468
@@ -32,8 +33,15 @@ def monte_carlo_tables(analysis):
                                    ('valid_hesse', 'L', np.asarray(analysis.mc_valid_hesse)),
                                    ('failed_mask', 'L', np.asarray(analysis.mc_failed_mask))]))
     mock_cols = []
+    vega = getattr(analysis, 'vega', None)
+    items = vega.problem.items if vega is not None else {}
     for name, mocks in analysis.mc_mocks.items():
         table = np.asarray(mocks, dtype=float)
+        if name in items and table.shape[1] != items[name].data_vec.size:
+            # the reference keeps each mock on the full data grid, NaN outside the mask (data.py:749-753)
+            full = np.full((table.shape[0], items[name].data_vec.size), np.nan)
+            full[:, items[name].data_mask] = table
+            table = full
         mock_cols.append((name, f'{table.shape[1]}D', table))
     tables.append(('Mocks', mock_cols))
     return tables

@@ -269,6 +269,8 @@ class CorrItem:
     cov: np.ndarray              # full covariance or None (identity)
     rp_binsize: float = 4.0
     inst_sys_table: np.ndarray = None   # (rt, xi) table of the DESI instrumental-systematics model, or None
+    cov_rescale: float = None           # [data] cov_rescale: also the default mock scale (reference analysis.py:147-150)
+    cholesky_masked_cov: bool = True    # [data] cholesky-masked-cov (reference data.py:46, :727-757)
 
     _inv_masked_cov: np.ndarray = None
     _log_cov_det: float = None
@@ -364,6 +366,7 @@ class Problem:
     mc_config: dict = None
 
     _global = None
+    search_dirs = ()
 
     @property
     def pk_fid(self):
@@ -962,6 +965,8 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
         item.marg_templates, item.marg_diff2coeff = marg_templates, marg_diff2coeff
         item.marginalize_in_fit = bool(marginalize_in_fit)
     item.blind, item.blinding_strat = blind, (blinding if blind else None)
+    item.cov_rescale = rescale
+    item.cholesky_masked_cov = d.getboolean('cholesky-masked-cov', True)
     return item
 
 
@@ -1114,7 +1119,9 @@ def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
                 block[np.ix_(item.data_mask, item.data_mask)] += item.cov_marg_update
             j += n
 
-    return Problem(k=k, pk_full=pk_full, pk_smooth=pk_smooth, z_fid=z_fid, z_eff=z_eff,
+    prob = Problem(k=k, pk_full=pk_full, pk_smooth=pk_smooth, z_fid=z_fid, z_eff=z_eff,
                    omega_m=om, omega_de=ode, growth_rate=growth_rate, scale=scale,
                    params=params, sample_params=sample, priors=priors, items=items,
                    global_cov=global_cov, main_config=main, mc_config=mc_config)
+    prob.search_dirs = dirs
+    return prob

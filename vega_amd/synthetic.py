@@ -48,6 +48,38 @@ def covariance(rp, rt):
     return corr
 
 
+def global_covariance(grids, coupling=0.08):
+    """SPD covariance of the concatenated data vectors of several correlations (the `global-cov-file` case,
+    reference vega/vega_interface.py:888-954): the items' own :func:`covariance` blocks on the diagonal and, between
+    two items, ``coupling`` times the geometric mean of the variances with the same exponential fall-off in the
+    separation of the bin centres - a cross-covariance a joint analysis really has.  ``grids``: [(rp, rt), ...] in
+    item order.  Diagonally dominant enough to stay positive definite (checked by the Cholesky factor at use)."""
+    blocks = [covariance(rp, rt) for rp, rt in grids]
+    sizes = [b.shape[0] for b in blocks]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    cov = np.zeros((off[-1], off[-1]))
+    for i, b in enumerate(blocks):
+        cov[off[i]:off[i + 1], off[i]:off[i + 1]] = b
+    for i in range(len(blocks)):
+        for j in range(i + 1, len(blocks)):
+            rp_i, rt_i = (np.asarray(a, dtype=float) for a in grids[i])
+            rp_j, rt_j = (np.asarray(a, dtype=float) for a in grids[j])
+            sig = np.sqrt(np.outer(np.diag(blocks[i]), np.diag(blocks[j])))
+            cross = coupling * sig * 0.25**(np.abs(np.abs(rp_i[:, None]) - np.abs(rp_j[None, :])) / 4.)
+            cross *= 0.15**(np.abs(rt_i[:, None] - rt_j[None, :]) / 4.)
+            cov[off[i]:off[i + 1], off[j]:off[j + 1]] = cross
+            cov[off[j]:off[j + 1], off[i]:off[i + 1]] = cross.T
+    return cov
+
+
+def write_global_covariance(path, cov):
+    """A `global-cov-file`: HDU 1 with the vector column COV (reference vega/vega_interface.py:899-900)."""
+    from . import fitslite
+    cov = np.asarray(cov, dtype=float)
+    fitslite.write_tables(str(path), [('GLOBALCOV', [('COV', f'{cov.shape[1]}D', cov)])], overwrite=True)
+    return path
+
+
 def walkers(theta_fid, names, n, varied=None, seed=SEED, scale=0.02, limits=None):
     """``theta_b = theta_fid + scale * |theta_fid| * N(0, 1)`` on the ``varied`` names
     (all non-sentinel parameters when None), clipped to ``limits`` = {name: (lo, hi)}."""
