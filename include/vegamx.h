@@ -307,6 +307,20 @@ int vmx_set_linear_spectra(vmx_engine* e, const double* pk_peak, const double* p
 int vmx_item_set_marg_matrix(vmx_engine* e, int32_t item, const double* m, int32_t n_templates, int32_t n_masked);
 int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B);
 
+/* chi2-only evaluations (model == NULL) as a static quadratic form.  Without a multiplicative post-distortion
+ * broadband the model on the fitted bins is linear in x' = [pre-distortion vector ; additive post-distortion broadband
+ * coefficients], model = S DM' x' (model.py:143-149), so
+ *     chi2 = r0^T C^-1 r0 - 2 dx^T (DM'^T S^T C^-1 r0) + dx^T (DM'^T S^T C^-1 S DM') dx,   dx = x' - x0',  r0 = data - S DM' x0'
+ * with ONE static symmetric matrix per item in place of the distortion product (model.py:143-144) and the C^-1 product
+ * (vega_interface.py:316): about half the matrix work of an evaluation, identical results to rounding.  theta_ref
+ * [n_params] is the expansion point (x0' = its vector; any point the model can be evaluated at - the configured
+ * parameter values - keeps the three terms small next to the signal); NULL switches the form off.  The tensors are
+ * built with the engine's own kernels at the next chi2-only evaluation and refreshed when data, mocks or inverse
+ * covariances change.  Not used with a global covariance, a multiplicative or non-polynomial post-distortion
+ * broadband, direct_pk, or when a model output is requested (those run the full chain).  Returns 1 when the
+ * configuration is eligible, 0 when it is not (the call is then a no-op). */
+int vmx_set_quadratic_form(vmx_engine* e, const double* theta_ref);
+
 /* Samplers usually keep the Arinyo non-linear parameters fixed.  When they are identical for every walker of a
  * batch the factor D_NL(k,mu) G(k,mu) is tabulated once per batch instead of being exponentiated per walker and
  * grid point.  vmx_eval (host theta) detects this by itself; for vmx_eval_device the caller states it here.
@@ -346,7 +360,7 @@ int vmx_set_profiling_mask(vmx_engine* e, uint32_t kernel_class_mask);
 /* Per-kernel timing with HIP events on the engine stream.  When enabled every kernel launch of
  * vmx_eval* is bracketed by events; vmx_get_timings returns the accumulated milliseconds and
  * launch counts per kernel class since the last reset. */
-#define VMX_N_KERNELS 12
+#define VMX_N_KERNELS 13
 int vmx_set_profiling(vmx_engine* e, int32_t enabled);
 int vmx_get_timings(vmx_engine* e, double* ms, int64_t* launches, int32_t reset);
 const char* vmx_kernel_name(int32_t kernel_class);

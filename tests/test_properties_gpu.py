@@ -59,12 +59,15 @@ def test_model_as_data_round_trip(vega):
         sl = eng.model_slices[name]
         eng.set_mock_pool(name, np.ascontiguousarray(model[:, sl][:, item.model_mask]))
     eng.set_mock_index(np.arange(256))
-    own = eng.eval(theta)[0]
+    own = eng.eval(theta, want_model=True)[0]               # the full chain: residuals that vanish identically
+    own_quad = eng.eval(theta)[0]                           # chi2 only: the static quadratic form around the reference point
     eng.set_mock_index(np.roll(np.arange(256), 1))
     other = eng.eval(theta)[0]
     eng.set_mock_index(None)
     typical = np.median(other)
     assert np.all(np.abs(own) <= 1e-20 * typical + 1e-18)
+    # three terms of the size of chi2(walker's model against the reference point's model) cancel: rounding of that size
+    assert np.all(np.abs(own_quad) <= 1e-12 * typical + 1e-9)
     assert np.all(other > 0) and typical > 1.0
 
 

@@ -37,11 +37,12 @@ namespace {
 
 enum KernelClass {
     KC_PROLOGUE = 0, KC_PK, KC_FFTLOG, KC_XI, KC_METAL, KC_ASSEMBLE, KC_DISTORTION, KC_POST,
-    KC_INVCOV, KC_CHI2, KC_MATVEC, KC_OTHER
+    KC_INVCOV, KC_CHI2, KC_MATVEC, KC_OTHER, KC_QUAD
 };
 const char* kKernelNames[VMX_N_KERNELS] = {
     "prologue", "pk_multipoles", "fftlog_spline_product", "xi_bins", "metal_matrix_product",
-    "assemble", "distortion_product", "post", "invcov_product", "chi2", "matvec_api", "other"};
+    "assemble", "distortion_product", "post", "invcov_product", "chi2", "matvec_api", "other",
+    "quadratic_form_product"};
 
 template <typename T>
 struct DevBuf {
@@ -103,6 +104,11 @@ struct ItemHost {
     std::vector<MetalHost*> metals;
     DevBuf<double> dm, cinv, data, vec, dist, res, z, mock_pool, add_vec;
     DevBuf<double> marg, marg_out;      // marg_diff2coeff matrix [n_templates][n_masked_pad], coefficients [max_batch][pad]
+    // quadratic form of chi2 (vmx_device.h): W = DM'^T S^T C^-1 [nq][n_masked_pad] is kept so that new data / mocks only
+    // redo the linear terms
+    DevBuf<double> q_mat, q_w, q_lin, q_c0, q_x0, q_x, q_z;
+    DevBuf<int64_t> q_basis_off;
+    int q_rows = 0;                     // rows of q_lin / q_c0 (1 + mocks)
     int n_templates = 0;
     int n_mocks = 0;
     DevBuf<int32_t> inv_mask;
@@ -178,6 +184,11 @@ struct vmx_engine {
     bool direct = false;
     std::vector<int32_t> h_mock_index;
     int last_B = 0;
+    bool last_full = false;          // the last evaluation ran the full chain (model and residuals are valid)
+    // quadratic form of chi2: used when only chi2 is asked for (see vmx_set_quadratic_form)
+    std::vector<double> theta_ref;
+    bool quad_eligible = false, quad_mat_dirty = true, quad_lin_dirty = true, no_fuse = false;
+    int quad_use_44 = 0;             // VMX_QUAD_44: the Q' products on the four-block MFMA kernel
     EngineDev dev{};
 
     // host path: pinned staging buffers and one captured graph per batch size
@@ -391,9 +402,10 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
     // the four-block 4x4x4 MFMA kernel runs every full product (distortion and metal matrices, FFTLog o spline,
     // stand-alone products); the short triangular C^-1 products are faster on the 16x16x4 kernel, whose two resident
     // blocks hide each other's start and end (0.093 against 0.103 - 0.126 ms: two short passes per block)
-    if (e->gemm_44 && kc != KC_INVCOV) {
+    if (e->gemm_44 && kc != KC_INVCOV && !(kc == KC_QUAD && !e->quad_use_44)) {
         block = dim3(GEMM44_THREADS);
         switch (kc) {
+            case KC_QUAD: hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), grid, block, 0, e->cur, G); break;
             case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt44<KC_DISTORTION>), grid, block, 0, e->cur, G); break;
             case KC_METAL: hipLaunchKernelGGL((k_gemm_nt44<KC_METAL>), grid, block, 0, e->cur, G); break;
             case KC_FFTLOG: hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G); break;
@@ -404,6 +416,7 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
     switch (kc) {
         case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_DISTORTION>), grid, block, 0, e->cur, G); break;
         case KC_INVCOV: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_INVCOV>), grid, block, 0, e->cur, G); break;
+        case KC_QUAD: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_QUAD>), grid, block, 0, e->cur, G); break;
         case KC_FFTLOG: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_FFTLOG>), grid, block, 0, e->cur, G); break;
         default: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_OTHER>), grid, block, 0, e->cur, G); break;
     }
@@ -819,6 +832,7 @@ int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index
         REQUIRE(it->has_mask, "set the mask before the inverse covariance");
         REQUIRE(rows == it->dev.n_masked && cols == rows, "inverse covariance shape");
         const std::vector<double> half = half_form(dense, rows);
+        e->quad_mat_dirty = true;
         if (e->finalized) {
             REQUIRE(it->has_cinv, "an identity inverse covariance cannot be replaced after vmx_finalize");
             HIP_OK(hipStreamSynchronize(e->stream));
@@ -892,6 +906,7 @@ int vmx_item_set_data(vmx_engine* e, int32_t item, const double* masked_data, in
     ItemHost* it = e->items[item];
     REQUIRE(it->has_mask && n_masked == it->dev.n_masked, "data size must match the mask");
     HIP_OK(hipSetDevice(e->device));
+    e->quad_lin_dirty = true;
     if (it->has_data) {
         HIP_OK(hipStreamSynchronize(e->stream));
         HIP_OK(hipMemcpy(it->data.p, masked_data, (size_t)n_masked * sizeof(double), hipMemcpyHostToDevice));
@@ -912,6 +927,7 @@ int vmx_item_set_mock_pool(vmx_engine* e, int32_t item, const double* pool, int3
     HIP_OK(hipStreamSynchronize(e->stream));
     if (it->mock_pool.upload(pool, (size_t)n_mocks * n_masked)) return -2;
     it->n_mocks = n_mocks;
+    e->quad_lin_dirty = true;
     it->dev.mock_pool = it->mock_pool.p;
     // the item table lives in device memory: patch this item's entry
     HIP_OK(hipMemcpy(e->d_items.p + item, &it->dev, sizeof(ItemDev), hipMemcpyHostToDevice));
@@ -1249,6 +1265,20 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->dpin_theta = nullptr; e->dpin_chi2 = nullptr; e->dpin_status = nullptr;     // staging copies instead
     }
 
+    // the quadratic form of chi2 needs a model that is linear in [x ; additive post-distortion coefficients]
+    e->quad_eligible = e->gcinv.p == nullptr && e->items.size() <= 16;
+    for (auto* it : e->items) {
+        int na = 0;
+        if (it->dev.n_bb[VMX_BB_POST_MUL]) e->quad_eligible = false;
+        for (int q = 0; q < it->dev.n_bb[VMX_BB_POST_ADD]; ++q) {
+            if (it->dev.bb[VMX_BB_POST_ADD][q].func != VMX_BB_POLY) e->quad_eligible = false;
+            na += it->dev.bb[VMX_BB_POST_ADD][q].n_coef;
+        }
+        if (na > VMX_MAX_QUAD_COEF) e->quad_eligible = false;
+    }
+    if (getenv("VMX_NO_QUAD")) e->quad_eligible = false;
+    if (const char* q44 = getenv("VMX_QUAD_44")) e->quad_use_44 = atoi(q44);
+
     HIP_OK(hipStreamSynchronize(e->stream));
     e->finalized = true;
     return 0;
@@ -1276,7 +1306,7 @@ static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, i
 }
 
 static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
-                     double* d_chi2 = nullptr, int32_t* d_status = nullptr)
+                     double* d_chi2 = nullptr, int32_t* d_status = nullptr, bool quad = false)
 {
     EngineDev D = e->dev;
     D.n_const_slots = tab_mode ? (int)e->const_slots.size() : 0;
@@ -1360,6 +1390,79 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         for (auto& p : e->pipes) max_n = p.n > max_n ? p.n : max_n;
         hipLaunchKernelGGL(k_xi_bins, dim3((max_n + 255) / 256, n_pipe, B), dim3(256), 0, e->stream, D);
     }
+    // dense metal-matrix products of an item (no split-K: the consumer reads one slab)
+    auto metal_products = [&](ItemHost* it) {
+        launch_metal_kron(e, D, it, B);
+        for (auto* m : it->metals) {
+            if (m->dev.mat_off < 0 || m->dev.kron_a) continue;
+            const PipeDev& P = e->pipes[m->dev.d.pipeline];
+            launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
+                           e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, it->dev.n_model_pad, 0, 1, 0);
+        }
+    };
+    if (quad) {
+        // chi2 only: x' - x0' per item, ONE half-triangle product with the static Q' per item, reduction (vmx_device.h)
+        e->cur = e->stream;
+        int max_nq = 0;
+        for (auto* it : e->items) { max_nq = std::max(max_nq, (int)it->dev.nq_pad); metal_products(it); }
+        {
+            ScopedTimer t(e, KC_ASSEMBLE);
+            hipLaunchKernelGGL(k_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->cur, D);
+        }
+        SlabInfo qs{};
+        for (size_t q = 0; q < e->items.size(); ++q) qs.z[q] = 1;
+        if (B > 8 && e->items.size() <= VMX_MAX_GROUP) {
+            GemmGroup G{};
+            int tiles_total = 0, per_xcd_total = 0;
+            for (auto* it : e->items) tiles_total += gemm_tiles(it->dev.nq, B, true);
+            std::vector<size_t> by_size(e->items.size());
+            for (size_t q = 0; q < by_size.size(); ++q) by_size[q] = q;
+            std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return e->items[a]->dev.nq > e->items[b]->dev.nq; });
+            std::vector<int>& splits = e->group_splits[2 * 100000 + B];
+            if (splits.empty()) {
+                std::vector<SplitProblem> sp;
+                for (size_t q : by_size) {
+                    const ItemDev& d = e->items[q]->dev;
+                    int max_split = 1;
+                    while (max_split < 8 && (int64_t)max_split * 2 * B <= e->slab_rows) max_split *= 2;
+                    sp.push_back({gemm_tiles(d.nq, B, true), (d.nq_pad + GEMM_BK - 1) / GEMM_BK, (int64_t)B * d.nq_pad * 8, max_split});
+                }
+                splits = choose_group_splits(sp);
+                if (splits.empty()) splits.push_back(0);
+            }
+            size_t gi = 0;
+            for (size_t q : by_size) {
+                ItemHost* it = e->items[q];
+                const ItemDev& d = it->dev;
+                GemmArgs g{};
+                g.A = it->q_mat.p; g.lda = d.nq_pad; g.X = it->q_x.p; g.ldx = d.nq_pad; g.D = it->q_z.p; g.ldd = d.nq_pad;
+                g.M = d.nq; g.N = B; g.K = d.nq_pad;
+                int per_xcd = 0;
+                const int forced = gi < splits.size() ? splits[gi] : 0;
+                ++gi;
+                qs.z[q] = plan_gemm(e, g, 1, e->slab_rows, nullptr, true, tiles_total - gemm_tiles(d.nq, B, true), &per_xcd, forced);
+                per_xcd_total += per_xcd;
+                G.p[G.n] = g; G.seq_end[G.n] = per_xcd_total; ++G.n;
+            }
+            ScopedTimer t(e, KC_QUAD);
+            launch_gemm_group(e, KC_QUAD, G, per_xcd_total, 1);
+        } else {
+            for (size_t q = 0; q < e->items.size(); ++q) {
+                ItemHost* it = e->items[q];
+                const ItemDev& d = it->dev;
+                qs.z[q] = launch_product(e, KC_QUAD, it->q_mat.p, d.nq_pad, 0, d.nq, d.nq_pad, it->q_x.p, d.nq_pad, 0, B,
+                                         it->q_z.p, d.nq_pad, 0, 1, e->slab_rows, nullptr, -1, true);
+            }
+        }
+        {
+            ScopedTimer t(e, KC_CHI2);
+            hipLaunchKernelGGL(k_chi2_quad, dim3(B), dim3(CHI2_THREADS), 0, e->stream, D, B, qs);
+        }
+        HIP_OK(hipGetLastError());
+        e->last_B = B;
+        e->last_full = false;
+        return 0;
+    }
     SlabInfo slabs{};
     for (size_t q = 0; q < e->items.size(); ++q) slabs.z[q] = 1;
     const bool grouped = B > 8 && e->items.size() <= VMX_MAX_GROUP;
@@ -1370,13 +1473,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         int max_model = 0, max_dist = 0;
         for (auto* it : e->items) {
             max_model = std::max(max_model, (int)it->dev.d.n_model); max_dist = std::max(max_dist, (int)it->dev.d.n_dist);
-            launch_metal_kron(e, D, it, B);
-            for (auto* m : it->metals) {
-                if (m->dev.mat_off < 0 || m->dev.kron_a) continue;
-                const PipeDev& P = e->pipes[m->dev.d.pipeline];
-                launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
-                               e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, it->dev.n_model_pad, 0, 1, 0);
-            }
+            metal_products(it);
         }
         {
             ScopedTimer t(e, KC_ASSEMBLE);
@@ -1462,17 +1559,10 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         const ItemDev& d = it->dev;
         e->cur = oi == 0 ? e->stream : e->aux[oi - 1];
         if (oi > 0) HIP_OK(hipStreamWaitEvent(e->cur, e->ev_fork, 0));
-        // metal matrix products (no split-K: the consumer reads one slab)
-        launch_metal_kron(e, D, it, B);
-        for (auto* m : it->metals) {
-            if (m->dev.mat_off < 0 || m->dev.kron_a) continue;
-            const PipeDev& P = e->pipes[m->dev.d.pipeline];
-            launch_product(e, KC_METAL, m->mat.p, m->dev.mat_ld, 0, m->rows, m->dev.mat_ld,
-                           e->xi.p + P.xi_off, P.n_pad, 0, B, e->xim.p + m->dev.xim_off, d.n_model_pad, 0, 1, 0);
-        }
+        metal_products(it);
         // a single walker is latency-bound: its distortion product assembles x while staging it and finishes
         // each row with the post step, instead of three launches
-        const bool fuse = B == 1 && it->has_dm && gemv1_applies(1, d.n_model_pad);
+        const bool fuse = B == 1 && it->has_dm && gemv1_applies(1, d.n_model_pad) && !e->no_fuse;
         if (!fuse) {
             ScopedTimer t(e, KC_ASSEMBLE);
             hipLaunchKernelGGL(k_assemble, dim3((d.d.n_model + 255) / 256, B), dim3(256), 0, e->cur, D, (int)q);
@@ -1506,21 +1596,22 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
     }
     HIP_OK(hipGetLastError());
     e->last_B = B;
+    e->last_full = true;
     return 0;
 }
 
 // run the chain for B walkers: replay a captured graph when one exists (or can be captured), else launch eagerly
-static int run_chain_cached(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false)
+static int run_chain_cached(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false, bool quad = false)
 {
     tab_mode = tab_mode && e->n_xtab > 0;
-    if (!e->use_graphs || e->profiling) return run_chain(e, B, tab_mode, zero_copy);
-    const int key = ((B * 2 + (tab_mode ? 1 : 0)) * 2 + (zero_copy ? 1 : 0)) * 2 + (e->direct ? 1 : 0);
+    if (!e->use_graphs || e->profiling) return run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad);
+    const int key = (((B * 2 + (tab_mode ? 1 : 0)) * 2 + (zero_copy ? 1 : 0)) * 2 + (e->direct ? 1 : 0)) * 2 + (quad ? 1 : 0);
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
-        if (e->graphs.size() >= 64) return run_chain(e, B, tab_mode, zero_copy);
+        if (e->graphs.size() >= 64) return run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad);
         hipGraph_t graph = nullptr;
         HIP_OK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = run_chain(e, B, tab_mode, zero_copy);
+        const int rc = run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad);
         hipError_t err = hipStreamEndCapture(e->stream, &graph);
         if (rc || err != hipSuccess || graph == nullptr) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -1528,7 +1619,7 @@ static int run_chain_cached(vmx_engine* e, int B, bool tab_mode, bool zero_copy 
                          err != hipSuccess ? hipGetErrorString(err) : "launch error");
             (void)hipGetLastError();
             e->use_graphs = false;      // capture is not available: stay on eager launches
-            return run_chain(e, B, tab_mode, zero_copy);
+            return run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad);
         }
         hipGraphExec_t exec = nullptr;
         err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1536,12 +1627,132 @@ static int run_chain_cached(vmx_engine* e, int B, bool tab_mode, bool zero_copy 
         if (err != hipSuccess) {
             std::fprintf(stderr, "[vegamx] graph instantiation failed (%s): falling back to eager launches\n", hipGetErrorString(err));
             e->use_graphs = false;
-            return run_chain(e, B, tab_mode, zero_copy);
+            return run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad);
         }
         it = e->graphs.emplace(key, exec).first;
     }
     HIP_OK(hipGraphLaunch(it->second, e->stream));
     e->last_B = B;
+    e->last_full = !quad;
+    return 0;
+}
+
+// Build (or refresh) the static tensors of the quadratic form of chi2: the reference point is evaluated with the full
+// chain (its pre-distortion vectors x0 and its model m0 come from the engine's own kernels), then per item
+//   X = (S DM')^T,  W = X C^-1,  Q' = W X^T (stored in half form),  g_k = W (d_k - S m0),  c0_k = (d_k - S m0)^T C^-1 (d_k - S m0)
+// for the data vector (k = 0) and every mock of the pool, all with the engine's product kernels.  Returns 0, or a
+// negative code; a reference point the model cannot be evaluated at switches the form off (the full chain then runs).
+static int quad_build(vmx_engine* e)
+{
+    HIP_OK(hipStreamSynchronize(e->stream));
+    const int P = e->n_params;
+    std::vector<double> tref(e->theta_ref);
+    if (!e->blind_scale.empty())
+        for (int i = 0; i < P; ++i) tref[i] = e->blind_scale[i] == 1.0 ? tref[i] + e->blind_shift[i] : e->blind_scale[i] * tref[i] + e->blind_shift[i];
+    HIP_OK(hipMemcpy(e->theta.p, tref.data(), (size_t)P * sizeof(double), hipMemcpyHostToDevice));
+    e->no_fuse = true;
+    const int rc = run_chain(e, 1, false);
+    e->no_fuse = false;
+    if (rc) return rc;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    int32_t st = 0;
+    HIP_OK(hipMemcpy(&st, e->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (st) {
+        std::fprintf(stderr, "[vegamx] the reference point of the quadratic chi2 form cannot be evaluated (status %d): full chain only\n", st);
+        e->quad_eligible = false;
+        return 0;
+    }
+    e->cur = e->stream;
+    for (auto* it : e->items) {
+        ItemDev& d = it->dev;
+        const int nm = d.n_masked, nmp = d.n_masked_pad;
+        int na = 0;
+        std::vector<int64_t> boff;
+        for (int q = 0; q < d.n_bb[VMX_BB_POST_ADD]; ++q) {
+            const BBTermDev& term = d.bb[VMX_BB_POST_ADD][q];
+            for (int c = 0; c < term.n_coef; ++c) { d.q_slot[na++] = term.slot[c]; boff.push_back(term.basis_off + (int64_t)c * d.d.n_dist); }
+        }
+        d.q_na = na; d.nq = d.d.n_model + na; d.nq_pad = vmx_pad(d.nq);
+        const int nq = d.nq, nqp = d.nq_pad;
+        // reference vector x0' = [vec(theta_ref) ; (1 + bao) c_j(theta_ref)]
+        std::vector<double> x0((size_t)nqp, 0.0);
+        HIP_OK(hipMemcpy(x0.data(), it->vec.p, (size_t)d.d.n_model * sizeof(double), hipMemcpyDeviceToHost));
+        for (int j = 0; j < na; ++j) x0[d.d.n_model + j] = (e->direct ? 1.0 : 1.0 + tref[d.d.bao_amp_slot]) * tref[d.q_slot[j]];
+        if (it->q_x0.upload(x0.data(), x0.size())) return -2;
+
+        DevBuf<int32_t> midx;
+        if (midx.upload(it->mask_idx.data(), it->mask_idx.size())) return -2;
+        DevBuf<double> cfull;
+        if (it->has_cinv) {
+            if (cfull.alloc((size_t)nm * nmp, true)) return -2;
+            hipLaunchKernelGGL(k_sym_from_half, dim3((nm + 255) / 256, nm), dim3(256), 0, e->stream, cfull.p, it->cinv.p, nm, nmp);
+        }
+        if (e->quad_mat_dirty || it->q_mat.p == nullptr) {
+            DevBuf<double> X, qfull;
+            DevBuf<int64_t>& bo = it->q_basis_off;
+            boff.push_back(0);
+            if (bo.upload(boff.data(), boff.size())) return -2;
+            if (X.alloc((size_t)nq * nmp, true)) return -2;
+            hipLaunchKernelGGL(k_quad_gather, dim3((nm + 255) / 256, nq), dim3(256), 0, e->stream, X.p, nmp,
+                               it->has_dm ? it->dm.p : (const double*)nullptr, d.n_model_pad, midx.p, nm, (int)d.d.n_model, nq,
+                               e->bb_basis.p, bo.p, (int)d.d.n_dist);
+            // (allocated once: captured graphs hold these pointers, and the sizes never change)
+            if (it->q_w.p == nullptr && it->q_w.alloc((size_t)nq * nmp, true)) return -2;
+            if (it->has_cinv)
+                launch_product(e, KC_OTHER, cfull.p, nmp, 0, nm, nmp, X.p, nmp, 0, nq, it->q_w.p, nmp, 0, 1, nq);
+            else
+                HIP_OK(hipMemcpyAsync(it->q_w.p, X.p, (size_t)nq * nmp * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            if (qfull.alloc((size_t)nq * nqp, true)) return -2;
+            launch_product(e, KC_OTHER, X.p, nmp, 0, nq, nmp, it->q_w.p, nmp, 0, nq, qfull.p, nqp, 0, 1, nq);
+            if (it->q_mat.p == nullptr && it->q_mat.alloc((size_t)nq * nqp, true)) return -2;
+            hipLaunchKernelGGL(k_half_from_full, dim3((nqp + 255) / 256, nq), dim3(256), 0, e->stream, it->q_mat.p, qfull.p, nq, nqp);
+            HIP_OK(hipStreamSynchronize(e->stream));        // X / qfull are released here
+        }
+        // linear terms for the data vector and every mock of the pool
+        const int rows = 1 + it->n_mocks;
+        DevBuf<double> R0, T;
+        if (R0.alloc((size_t)rows * nmp, true)) return -2;
+        hipLaunchKernelGGL(k_quad_rows, dim3((nm + 255) / 256, rows), dim3(256), 0, e->stream, R0.p, nmp,
+                           (const double*)(e->model.p + d.model_off), midx.p, it->data.p,
+                           it->n_mocks ? it->mock_pool.p : (const double*)nullptr, nm, rows);
+        if (it->q_lin.alloc((size_t)rows * nqp, true) || it->q_c0.alloc(rows, true)) return -2;
+        launch_product(e, KC_OTHER, it->q_w.p, nmp, 0, nq, nmp, R0.p, nmp, 0, rows, it->q_lin.p, nqp, 0, 1, rows);
+        if (it->has_cinv) {
+            if (T.alloc((size_t)rows * nmp, true)) return -2;
+            launch_product(e, KC_OTHER, cfull.p, nmp, 0, nm, nmp, R0.p, nmp, 0, rows, T.p, nmp, 0, 1, rows);
+            hipLaunchKernelGGL(k_rowdot, dim3(rows), dim3(256), 0, e->stream, it->q_c0.p, R0.p, T.p, nmp, nm);
+        } else {
+            hipLaunchKernelGGL(k_rowdot, dim3(rows), dim3(256), 0, e->stream, it->q_c0.p, R0.p, R0.p, nmp, nm);
+        }
+        it->q_rows = rows;
+        if (it->q_x.n < (size_t)e->max_batch * nqp && it->q_x.alloc((size_t)e->max_batch * nqp, true)) return -2;
+        if (it->q_z.n < (size_t)e->slab_rows * nqp && it->q_z.alloc((size_t)e->slab_rows * nqp, true)) return -2;
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(e->stream));
+        d.q_x0 = it->q_x0.p; d.q_lin = it->q_lin.p; d.q_c0 = it->q_c0.p; d.q_x = it->q_x.p; d.q_z = it->q_z.p;
+    }
+    std::vector<ItemDev> items;
+    for (auto* it : e->items) items.push_back(it->dev);
+    HIP_OK(hipMemcpy(e->d_items.p, items.data(), items.size() * sizeof(ItemDev), hipMemcpyHostToDevice));
+    e->quad_mat_dirty = false;
+    e->quad_lin_dirty = false;
+    e->last_B = 0;                  // the reference evaluation is not a caller's evaluation
+    // graphs captured before hold the previous per-mock buffers (q_lin / q_c0 grow with the pool): capture again
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
+    e->graphs.clear();
+    return 0;
+}
+
+// chi2-only evaluations take the quadratic form when it applies; refreshes its tensors when data or covariances changed
+static int quad_ready(vmx_engine* e, bool* use)
+{
+    *use = false;
+    if (!e->quad_eligible || e->theta_ref.empty() || e->direct) return 0;
+    if (e->quad_mat_dirty || e->quad_lin_dirty) {
+        if (quad_build(e)) return -2;
+        if (!e->quad_eligible) return 0;
+    }
+    *use = true;
     return 0;
 }
 
@@ -1551,22 +1762,24 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     REQUIRE(e && e->finalized && d_theta, "vmx_eval_device");
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
+    bool quad = false;
+    if (!d_model && quad_ready(e, &quad)) return -2;
     if (!e->blind_scale.empty()) {
         // parameter-level blinding: the walkers are transformed in the engine's own copy
         HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         const int n = B * e->n_params;
         hipLaunchKernelGGL(k_theta_affine, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->theta.p, e->d_blind.p, e->n_params, n);
-        if (run_chain_cached(e, B, e->const_hint && B >= 16)) return -2;
+        if (run_chain_cached(e, B, e->const_hint && B >= 16, false, quad)) return -2;
         if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
     } else if (B >= 64 || !e->use_graphs || e->profiling) {
         // large batches: eager launches cost nothing next to the kernels, and they let the chain read / write the
         // caller's buffers directly (a captured graph would pin their addresses)
         const bool tab = e->const_hint && B >= 16 && e->n_xtab > 0;
-        if (run_chain(e, B, tab, false, d_theta, d_chi2, d_status)) return -2;
+        if (run_chain(e, B, tab, false, d_theta, d_chi2, d_status, quad)) return -2;
     } else {
         HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-        if (run_chain_cached(e, B, e->const_hint && B >= 16)) return -2;
+        if (run_chain_cached(e, B, e->const_hint && B >= 16, false, quad)) return -2;
         if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
     }
@@ -1623,6 +1836,8 @@ int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B)
     ItemHost* it = e->items[item];
     REQUIRE(it->n_templates > 0, "no marginalisation matrix was set for this item");
     REQUIRE(B > 0 && B == e->last_B, "vmx_marg_coeff reads the residuals of the last evaluation: B must be its batch size");
+    REQUIRE(e->last_full, "the last evaluation took the quadratic chi2 form, which forms no residuals: evaluate with a model "
+                          "output (or switch the form off with vmx_set_quadratic_form(e, NULL))");
     HIP_OK(hipSetDevice(e->device));
     const int ldo = vmx_pad(it->n_templates);
     if (it->marg_out.n < (size_t)e->max_batch * ldo && it->marg_out.alloc((size_t)e->max_batch * ldo, true)) return -2;
@@ -1631,6 +1846,15 @@ int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B)
     HIP_OK(hipMemcpy2D(out, (size_t)it->n_templates * sizeof(double), it->marg_out.p, (size_t)ldo * sizeof(double),
                        (size_t)it->n_templates * sizeof(double), B, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int vmx_set_quadratic_form(vmx_engine* e, const double* theta_ref)
+{
+    REQUIRE(e && e->finalized, "vmx_set_quadratic_form (after vmx_finalize)");
+    e->theta_ref.clear();
+    if (theta_ref) e->theta_ref.assign(theta_ref, theta_ref + e->n_params);
+    e->quad_mat_dirty = true;       // (a new reference point: everything is rebuilt at the next chi2-only evaluation)
+    return e->quad_eligible ? 1 : 0;
 }
 
 int vmx_set_constant_nl_hint(vmx_engine* e, int32_t enabled)
@@ -1658,6 +1882,8 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     // one stores chi2 / status there, which removes three staging copies (~25 us of a ~100 us evaluation)
     const bool zero_copy = B <= 8 && B * ((int)e->pipes.size() + 1) <= 1024 && (size_t)B * e->n_params * sizeof(double) <= 48 * 1024 &&
                            e->dpin_theta && e->dpin_chi2 && e->dpin_status;
+    bool quad = false;
+    if (!model && quad_ready(e, &quad)) return -2;
     if (e->blind_scale.empty()) std::memcpy(e->pin_theta, theta, (size_t)B * e->n_params * sizeof(double));
     else        // parameter-level blinding, applied while staging (same expression as k_theta_affine)
         for (int b = 0; b < B; ++b)
@@ -1672,7 +1898,7 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     for (int b = 1; b < B && tab_mode; ++b)
         for (int slot : e->const_slots)
             if (theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = false; break; }
-    if (run_chain_cached(e, B, tab_mode, zero_copy)) return -2;
+    if (run_chain_cached(e, B, tab_mode, zero_copy, quad)) return -2;
     if (chi2 && !zero_copy) HIP_OK(hipMemcpyAsync(e->pin_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if (status && !zero_copy) HIP_OK(hipMemcpyAsync(e->pin_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (model) HIP_OK(hipMemcpyAsync(model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToHost, e->stream));

@@ -26,6 +26,7 @@
 #define VMX_PAD 32           // leading dimensions are multiples of 32 doubles
 #define VMX_MAX_BB 32        // broadband terms per item and position
 #define VMX_MAX_METALS 64
+#define VMX_MAX_QUAD_COEF 64 // additive post-distortion broadband coefficients the quadratic form of chi2 can carry
 
 enum {
     S_BIAS1 = 0, S_BB1, S_BIAS2, S_BB2,
@@ -94,6 +95,15 @@ struct ItemDev {
     double* dist;                             // [S][B][n_dist_pad] distortion product slabs
     double* res;                              // [B][n_masked_pad]  residual
     double* z;                                // [S][B][n_masked_pad] C^-1 residual slabs
+    // static quadratic form of chi2 (k_assemble_quad / k_chi2_quad): x' = [pre-distortion vector ; additive
+    // post-distortion broadband coefficients (1 + bao) c_j], expanded around the reference point x0'
+    int32_t nq, nq_pad, q_na;                 // n_model + q_na entries, padded stride
+    int32_t q_slot[VMX_MAX_QUAD_COEF];        // theta column of coefficient j
+    const double* q_x0;                       // [nq_pad]  reference vector
+    const double* q_lin;                      // [1 + n_mocks][nq_pad]  DM'^T S^T C^-1 r0 (row 0: data, row 1 + k: mock k)
+    const double* q_c0;                       // [1 + n_mocks]  r0^T C^-1 r0
+    double* q_x;                              // [B][nq_pad]  x' - x0'
+    double* q_z;                              // [S][B][nq_pad]  slabs of L' (x' - x0')
 };
 
 
@@ -166,6 +176,9 @@ struct EngineDev {
     // global covariance mode
     const double* gcinv; int32_t g_n, g_ld; double* gres; double* gz;
 };
+
+struct SlabInfo { int32_t z[16]; int32_t g; };   // split-K slab counts of a product per item (+ the global one)
+#define CHI2_THREADS 1024                        // k_chi2 / k_chi2_quad: one block per walker
 
 // ------------------------------------------------------------------------------------------------
 // prologue: parameters -> scalars
@@ -1216,8 +1229,6 @@ __global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B, int 
     post_bin(D, it, b, bin, v);
 }
 
-struct SlabInfo { int32_t z[16]; int32_t g; };   // split-K slab counts of a product per item (+ the global one)
-
 __global__ __launch_bounds__(256) void k_post_all(EngineDev D, int B, SlabInfo dist_slabs)
 {
     const ItemDev& it = D.items[blockIdx.z];
@@ -1230,6 +1241,136 @@ __global__ __launch_bounds__(256) void k_post_all(EngineDev D, int B, SlabInfo d
         for (int s = 0; s < dist_slabs.z[blockIdx.z]; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
     } else v = it.vec[(size_t)b * it.n_model_pad + bin];
     post_bin(D, it, b, bin, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Static quadratic form of chi2 (chi2-only evaluations without a multiplicative post-distortion broadband).
+//
+// With x' = [x ; a] (x the pre-distortion vector of k_assemble, a_j = (1 + bao) c_j the coefficients of the additive
+// polynomial post-distortion broadband) the model on the masked bins is S DM' x', DM' = [DM | B] with the broadband
+// basis B as extra columns, so the residual r = d - S DM' x' and
+//     chi2 = r0^T C^-1 r0 - 2 dx^T (DM'^T S^T C^-1 r0) + dx^T (DM'^T S^T C^-1 S DM') dx,     dx = x' - x0',
+// expanded around a reference point x0' (r0 = d - S DM' x0': its residual), which keeps the three terms of the
+// size of the walkers' spread instead of the size of the signal (no cancellation of large numbers: finite-difference
+// gradients of a minimiser stay clean).  The matrix Q' = DM'^T S^T C^-1 S DM' is static and symmetric: ONE half-triangle
+// product per item replaces the distortion product (model.py:143-144) and the C^-1 product (vega_interface.py:316).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble_quad(EngineDev D)
+{
+    const ItemDev& it = D.items[blockIdx.z];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= it.nq_pad) return;
+    double v = 0.0;
+    if (i < it.d.n_model) v = assemble_bin(D, it, b, i) - it.q_x0[i];
+    else if (i < it.nq) {
+        const double* t = D.theta + (size_t)b * D.n_params;
+        const double f = D.pk_direct ? 1.0 : 1.0 + t[it.d.bao_amp_slot];
+        v = f * t[it.q_slot[i - it.d.n_model]] - it.q_x0[i];
+    }
+    it.q_x[(size_t)b * it.nq_pad + i] = v;
+}
+
+__global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, SlabInfo slabs)
+{
+    __shared__ double red[CHI2_THREADS / 64];
+    const int b = blockIdx.x;
+    const int mock = D.mock_index[b];
+    double acc = 0.0;
+    for (int q = 0; q < D.n_items; ++q) {
+        const ItemDev& it = D.items[q];
+        const int row = (mock >= 0 && it.mock_pool) ? 1 + mock : 0;
+        const double* g = it.q_lin + (size_t)row * it.nq_pad;
+        const int ns = slabs.z[q];
+        for (int i = threadIdx.x; i < it.nq; i += CHI2_THREADS) {
+            const double x = it.q_x[(size_t)b * it.nq_pad + i];
+            double zs[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) zs[s] = it.q_z[((size_t)(s < ns ? s : 0) * B + b) * it.nq_pad + i];
+            double z = zs[0];
+#pragma unroll
+            for (int s = 1; s < 8; ++s) z += s < ns ? zs[s] : 0.0;
+            acc = fma(x, 2.0 * (z - g[i]), acc);        // q_z holds L' dx of the half form: dx^T Q' dx = 2 dx^T (L' dx)
+        }
+        if (threadIdx.x == 0) acc += it.q_c0[row];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0.0;
+        for (int w = 0; w < CHI2_THREADS / 64; ++w) c += red[w];
+        const double* t = D.theta + (size_t)b * D.n_params;
+        for (int q = 0; q < D.n_priors; ++q) {
+            const double dlt = t[D.prior_slot[q]] - D.prior_mean[q];
+            c += dlt * dlt / (D.prior_sigma[q] * D.prior_sigma[q]);
+        }
+        int st = D.status[b];
+        if (!(c == c) || c > 1e300 || c < -1e300) { st |= VMX_STATUS_NONFINITE; D.status[b] = st; }
+        D.chi2[b] = st ? 1e100 : c;
+        if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
+        if (D.status_host) D.status_host[b] = st;
+        if (b == 0) {
+            D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
+            for (int g2 = 0; g2 < D.n_xtab; ++g2) D.xtab_dirty[g2] = 0;
+        }
+    }
+}
+
+// set-up kernels of the quadratic form ----------------------------------------------------------
+// X[j][i] = DM'[mask_idx[i]][j]: the masked rows of [DM | post-add broadband basis], transposed (row j = column j of DM')
+__global__ void k_quad_gather(double* X, int ldx, const double* dm, int dm_ld, const int32_t* mask_idx, int n_masked,
+                              int n_model, int nq, const double* bb_basis, const int64_t* basis_off, int n_dist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= n_masked || j >= nq) return;
+    const int r = mask_idx[i];
+    double v;
+    if (j < n_model) v = dm ? dm[(size_t)r * dm_ld + j] : (r == j ? 1.0 : 0.0);
+    else v = bb_basis[basis_off[j - n_model] + r];
+    X[(size_t)j * ldx + i] = v;
+}
+
+// full symmetric matrix from the half form (L below the diagonal, half the diagonal on it)
+__global__ void k_sym_from_half(double* full, const double* half, int n, int ld)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (i >= n || j >= n) return;
+    full[(size_t)i * ld + j] = i > j ? half[(size_t)i * ld + j] : i < j ? half[(size_t)j * ld + i] : 2.0 * half[(size_t)i * ld + i];
+}
+
+__global__ void k_half_from_full(double* half, const double* full, int n, int ld)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (i >= n || j >= ld) return;
+    double v = 0.0;
+    if (j < i) v = 0.5 * (full[(size_t)i * ld + j] + full[(size_t)j * ld + i]);
+    else if (j == i) v = 0.5 * full[(size_t)i * ld + i];
+    half[(size_t)i * ld + j] = v;
+}
+
+// residuals of the reference point: R0[0] = data - S m0, R0[1 + k] = mock k - S m0   (m0: its model on the distorted grid)
+__global__ void k_quad_rows(double* R0, int ld, const double* model0, const int32_t* mask_idx, const double* data,
+                            const double* pool, int n_masked, int n_rows)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (i >= n_masked || k >= n_rows) return;
+    const double d = k == 0 ? data[i] : pool[(size_t)(k - 1) * n_masked + i];
+    R0[(size_t)k * ld + i] = d - model0[mask_idx[i]];
+}
+
+// out[k] = sum_i a[k][i] b[k][i]   (one block per row, fixed-order reduction)
+__global__ __launch_bounds__(256) void k_rowdot(double* out, const double* a, const double* b, int ld, int n)
+{
+    __shared__ double red[4];
+    const int k = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc = fma(a[(size_t)k * ld + i], b[(size_t)k * ld + i], acc);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[k] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1920,7 +2061,6 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
 
 // chi2 = sum_items diff^T (C^-1 diff) + priors; sentinel on failure
 // (1024 threads per walker: the kernel is a bandwidth-bound reduction with one block per walker)
-#define CHI2_THREADS 1024
 __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabInfo slabs)
 {
     __shared__ double red[CHI2_THREADS / 64];

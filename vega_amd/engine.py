@@ -17,7 +17,7 @@ _lib = None
 
 VMX_MAX_ELL = 4
 VMX_MAX_SMOOTH = 3
-VMX_N_KERNELS = 12
+VMX_N_KERNELS = 13
 HCD = {'none': 0, 'Rogers': 1, 'sinc': 2, 'fvoigt': 3}
 NL = {'none': 0, 'arinyo': 1, 'mcdonald': 2}
 VD = {None: 0, 'gauss': 1, 'lorentz': 2}
@@ -137,6 +137,7 @@ def load_library():
     lib.vmx_set_linear_spectra.argtypes = [C.c_void_p, dptr, dptr, dptr, C.c_int32]
     lib.vmx_item_set_marg_matrix.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32]
     lib.vmx_marg_coeff.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32]
+    lib.vmx_set_quadratic_form.argtypes = [C.c_void_p, dptr]
     lib.vmx_stream.argtypes = [C.c_void_p]
     lib.vmx_stream.restype = C.c_void_p
     lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
@@ -167,7 +168,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -686,6 +687,9 @@ class Engine:
             self._check(lib.vmx_add_prior(self._h, low.need(pname), float(mean), float(sigma)))
         self._check(lib.vmx_finalize(self._h, self.n_params, self.max_batch))
         self.model_size = self._check(lib.vmx_model_size(self._h))
+        # chi2-only evaluations run as a static quadratic form around the configured parameter values when the
+        # configuration allows it (include/vegamx.h: vmx_set_quadratic_form)
+        self.quadratic_form = bool(self._check(lib.vmx_set_quadratic_form(self._h, _dp(_f64(low.theta0)))))
 
     # ---- evaluation
     def theta_from_params(self, params=None):
@@ -775,6 +779,13 @@ class Engine:
             return
         pk = _f64(np.atleast_2d(pk))
         self._check(self.lib.vmx_set_direct_pk(self._h, _dp(pk), pk.shape[0], pk.shape[1]))
+
+    def set_quadratic_form(self, on=True):
+        """Switch the quadratic form of chi2-only evaluations on (expansion point: the configured parameter values) or
+        off (every evaluation runs the full chain).  Returns whether the form is in use."""
+        ref = _f64(self.low.theta0)
+        self.quadratic_form = bool(self._check(self.lib.vmx_set_quadratic_form(self._h, _dp(ref) if on else None))) and on
+        return self.quadratic_form
 
     def set_linear_spectra(self, pk_full, pk_smooth):
         """Replace the template's linear spectra (``Model.compute(pars, pk_full, pk_smooth)``, reference

@@ -281,11 +281,14 @@ class VegaInterface:
         self.freeze_metals(params)
         self._check_pinned(self._theta(params)[None, :])
         self._sync_monte_carlo()
+        # the coefficients are a map of the residuals, which only the full chain forms (a chi2-only evaluation may take
+        # the static quadratic form, include/vegamx.h): ask for the model then
+        need_coeff = return_marg_coeff or (self.marginalize_in_fit and self._random_marg_coeff is None)
         with self._direct(direct_pk):
-            chi2, status, _ = self.engine.eval(self._theta(params)[None, :])
+            chi2, status, _ = self.engine.eval(self._theta(params)[None, :], want_model=bool(need_coeff and self._marg_names))
         if status[0]:               # the engine's chi2 is the 1e100 sentinel
             return (float(chi2[0]), self._random_marg_coeff) if return_marg_coeff else float(chi2[0])
-        if return_marg_coeff or (self.marginalize_in_fit and self._random_marg_coeff is None):
+        if need_coeff:
             coeff = {name: c[0] for name, c in self._marg_coeff(1).items()}
             if self._random_marg_coeff is None:
                 self._random_marg_coeff = coeff
@@ -386,7 +389,7 @@ class VegaInterface:
                  for name in self._marg_names} if return_marg_coeff else None
         mb = self.engine.max_batch
         for lo in range(0, theta.shape[0], mb):
-            c, s, _ = self.engine.eval(theta[lo:lo + mb])
+            c, s, _ = self.engine.eval(theta[lo:lo + mb], want_model=bool(return_marg_coeff and self._marg_names))
             out[lo:lo + mb] = c
             status[lo:lo + mb] = s
             if return_marg_coeff:
