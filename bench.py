@@ -312,6 +312,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 
+    # torch bundles its own HIP runtime: it has to be loaded before libvegamx.so brings in the system one (importing it
+    # does not touch the GPU; the first CUDA call below does, after the CPU baseline has finished)
+    import torch
+    import torch.distributed as dist
+
     # every rank makes sure the library exists before any collective is entered: one compiles (file lock), the
     # others wait on the lock - not in a barrier
     import fcntl
@@ -334,9 +339,6 @@ def main():
     cpu = cpu_idx = cpu_vals = None
     if rank == 0 and world == 1 and not args.core_only and not args.no_cpu_baseline:
         cpu, cpu_idx, cpu_vals = cpu_baseline(args.workload, low.names, host_theta)
-
-    import torch
-    import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the vegamx engine has no CPU fallback')
@@ -418,7 +420,9 @@ def main():
     breakdown = eng.timings(reset=True)
     dominant = max((k for k, v in breakdown.items() if v[1]), key=lambda k: breakdown[k][0])
     # SURVEY.md section 8d prices the roofline on the distortion-matrix step; the class with the largest total is timed too
-    roof_class = 'distortion_product' if breakdown.get('distortion_product', (0, 0))[1] else dominant
+    # ... which chi2-only steps run as the quadratic-form product (one half-triangle MFMA product per item in place
+    # of the distortion and C^-1 products, include/vegamx.h: vmx_set_quadratic_form)
+    roof_class = next((k for k in ('quadratic_form_product', 'distortion_product') if breakdown.get(k, (0, 0))[1]), dominant)
     eng.set_profiling_classes(sorted({roof_class, dominant}))
 
     for i in range(args.warmup):
@@ -488,6 +492,17 @@ def main():
                     kind = 'auto' if item.tracer1.name == item.tracer2.name else 'cross'
                     flops += B * nk * n_mu * FLOPS_PER_POINT[kind]          # one paired pass per item
                 bound, peak, reach = 'valu-fp64', FP64_VALU_PEAK_TF, FP64_VALU_MEASURED_TF
+            elif kclass == 'quadratic_form_product':
+                # x'^T Q' x' in half form: nq^2 flops per walker and item, nq = n_model + additive post-distortion coefficients
+                nqs = []
+                for it in prob.items.values():
+                    na = sum(len(range(t.r1[0], t.r1[1] + 1, t.r1[2])) * len(range(t.r2[0], t.r2[1] + 1, t.r2[2]))
+                             for t in it.broadband if t.pos == 'post' and t.kind == 'add')
+                    nqs.append(it.model_grid.size + na)
+                flops = float(sum(n * n for n in nqs)) * B
+                if kernels[kclass]['launches_per_step'] > 1:
+                    flops /= len(nqs)
+                bound, peak, reach = 'mfma', FP64_MFMA_PEAK_TF, FP64_MFMA_4X4X4_MEASURED_TF
             elif kclass in ('distortion_product', 'invcov_product'):
                 # (the FFTLog product is left out: its launch skips the operator rows and columns outside the batch's live
                 # ranges, so a flop count of the full operator would overstate it)

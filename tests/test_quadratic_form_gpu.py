@@ -137,10 +137,10 @@ def test_quadratic_form_eligibility_and_golden_configs():
     vega.close()
 
 
-def test_quadratic_form_on_the_four_block_kernel():
-    """`VMX_QUAD_44`: the half-triangle products on the four-block fp64 MFMA kernel instead of the 16x16x4 one."""
+def test_quadratic_form_on_the_sixteen_by_sixteen_kernel():
+    """`VMX_QUAD_44=0`: the half-triangle products on the 16x16x4 fp64 MFMA kernel instead of the four-block one."""
     from vega_amd import VegaInterface
-    os.environ['VMX_QUAD_44'] = '1'
+    os.environ['VMX_QUAD_44'] = '0'
     try:
         prob = synth_joint_problem()
         vega = VegaInterface(None, problem=prob, max_batch=64)

@@ -7,6 +7,7 @@
 #include "vmx_device.h"
 
 #include <cmath>
+#include <chrono>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -152,8 +153,12 @@ struct vmx_engine {
     DevBuf<PipeDev> d_pipes;
     std::vector<PkGroup> pk_groups;
     DevBuf<PkGroup> d_pk_groups;
-    std::vector<int32_t> pk_members, pk_poly;
-    DevBuf<int32_t> d_pk_members, d_pk_poly;
+    std::vector<int32_t> pk_members, pk_poly, pk_static;     // pk_static: polynomial pipelines with a static coefficient basis
+    DevBuf<int32_t> d_pk_members, d_pk_poly, d_pk_static, d_pipe_active;
+    DevBuf<double> poly_coef, poly_bins;
+    int64_t poly_bins_total = 0;
+    int n_active = 0;
+    bool poly_dirty = true;
 
     std::vector<ItemHost*> items;
     std::vector<MetalHost*> metals;
@@ -188,7 +193,9 @@ struct vmx_engine {
     // quadratic form of chi2: used when only chi2 is asked for (see vmx_set_quadratic_form)
     std::vector<double> theta_ref;
     bool quad_eligible = false, quad_mat_dirty = true, quad_lin_dirty = true, no_fuse = false;
-    int quad_use_44 = 0;             // VMX_QUAD_44: the Q' products on the four-block MFMA kernel
+    // VMX_TRACE_HOST: host-side phases of vmx_eval accumulated in nanoseconds (staging, enqueue, wait), printed at destroy
+    bool trace_host = false; double host_ns[3] = {0, 0, 0}; int64_t host_calls = 0;
+    int quad_use_44 = 1;             // the Q' products run on the four-block MFMA kernel (VMX_QUAD_44=0: the 16x16x4 kernel)
     EngineDev dev{};
 
     // host path: pinned staging buffers and one captured graph per batch size
@@ -196,8 +203,10 @@ struct vmx_engine {
     std::vector<double> blind_scale, blind_shift;       // parameter-level blinding (empty = off); device copy [2][n_params]
     DevBuf<double> d_blind;
     double* dpin_theta = nullptr; double* dpin_chi2 = nullptr; int32_t* dpin_status = nullptr;   // device views
+    int64_t* pin_done = nullptr; int64_t* dpin_done = nullptr; int64_t done_seq = 0;          // completion word of single-walker calls
     std::map<int, hipGraphExec_t> graphs;
     bool use_graphs = true;
+    bool graph_b1 = false;           // VMX_GRAPH_B1: replay a captured graph for single-walker host evaluations too
 
     // profiling
     bool profiling = false;
@@ -216,6 +225,7 @@ struct vmx_engine {
         if (pin_theta) (void)hipHostFree(pin_theta);
         if (pin_chi2) (void)hipHostFree(pin_chi2);
         if (pin_status) (void)hipHostFree(pin_status);
+        if (pin_done) (void)hipHostFree(pin_done);
         for (auto& a : aux) (void)hipStreamDestroy(a);
         for (auto& ev : ev_join) (void)hipEventDestroy(ev);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -317,6 +327,14 @@ static int pk_variant(const vmx_pipe_desc& d, bool paired)
 
 // the single-walker streaming kernel keeps x in LDS
 static bool gemv1_applies(int N, int K) { return N == 1 && K <= 5120 && (size_t)K * sizeof(double) <= 48 * 1024; }
+
+// persistent blocks of the single-walker streaming kernel (2 per CU), rows strided over them
+static int gemv1_blocks(int M)
+{
+    int blocks = 512;
+    while ((M + blocks - 1) / blocks > GEMV1_MAX_ROWS) blocks *= 2;
+    return blocks > M ? M : blocks;
+}
 
 // Tiling of one MFMA product: fills the tile / split fields of `g`, returns the number of K slabs and, in *per_xcd,
 // the blocks each XCD runs for it.  `other_tiles`: tiles of the other problems of the same launch.
@@ -437,9 +455,7 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
     if (gemv1_applies(N, K)) {
         // persistent streaming kernel: 2 blocks per CU, rows strided over blocks
         g.nsplit = 1; g.klen = K; g.d_slab = 0;
-        int blocks = 512;
-        while ((M + blocks - 1) / blocks > GEMV1_MAX_ROWS) blocks *= 2;
-        if (blocks > M) blocks = M;
+        const int blocks = gemv1_blocks(M);
         dim3 grid(blocks, 1, nbatch), block(256);
         const size_t shmem = (size_t)K * sizeof(double);
         if (fused_item >= 0) {
@@ -505,6 +521,10 @@ int vmx_create(vmx_engine** out, int device)
 void vmx_destroy(vmx_engine* e)
 {
     if (!e) return;
+    if (e->trace_host && e->host_calls)
+        std::fprintf(stderr, "[vegamx] host phases of vmx_eval over %lld calls: staging %.2f us, enqueue %.2f us, wait %.2f us\n",
+                     (long long)e->host_calls, e->host_ns[0] / e->host_calls * 1e-3, e->host_ns[1] / e->host_calls * 1e-3,
+                     e->host_ns[2] / e->host_calls * 1e-3);
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     delete e;
@@ -611,6 +631,7 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     if (desc->n_smooth < 0 || desc->n_smooth > VMX_MAX_SMOOTH) return fail(-1, "invalid argument: n_smooth");
     PipeDev p{};
     p.d = *desc;
+    p.poly_basis = -1; p.col = -1; p.poly_bins_off = -1;
     // The P(k) stage is symmetric in the two tracers: keep the Lya-like tracer first (and a discrete
     // tracer last) so that the specialised mu loops see one canonical order.
     if (!p.d.same_tracer && ((!p.d.tracer[0].is_lya && p.d.tracer[1].is_lya) ||
@@ -974,12 +995,15 @@ int vmx_add_prior(vmx_engine* e, int32_t slot, double mean, double sigma)
     return 0;
 }
 
+static int poly_basis_build(vmx_engine* e);
+
 int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 {
     REQUIRE(e && !e->finalized, "vmx_finalize");
     REQUIRE(n_params > 0 && max_batch > 0, "n_params / max_batch");
     REQUIRE(e->nk > 0 && !e->pipes.empty() && !e->items.empty(), "template, pipelines and items are required");
     REQUIRE(e->items.size() <= 16, "at most 16 correlation items");
+    REQUIRE(e->pipes.size() * sizeof(PipeDev) <= 48 * 1024, "too many pipelines for the prologue's descriptor stage");
     for (int i = 0; i < VMX_MAX_ELL; ++i) REQUIRE(e->op_set[i], "all four FFTLog operators are required");
     HIP_OK(hipSetDevice(e->device));
     const int Bm = max_batch;
@@ -990,6 +1014,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (const char* ov = getenv("VMX_GEMM_SPLIT")) e->gemm_split_override = atoi(ov);
     if (getenv("VMX_GEMM_16")) e->gemm_44 = false;
     if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
+    if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
+    if (getenv("VMX_GRAPH_B1")) e->graph_b1 = true;
 
     // every slot must index a theta column and the combinations the kernels rely on must be present
     auto slot_ok = [&](int s) { return s < n_params; };
@@ -1152,6 +1178,41 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->const_slots.pop_back();
         e->pk_members.push_back(-1);
         if (e->d_pk_members.upload(e->pk_members.data(), e->pk_members.size())) return -2;
+        // polynomial pipelines without any k-dependent walker term: their spline coefficients are linear in the Kaiser
+        // coefficients with static vectors (k_poly_basis + the FFTLog operator, once) - no P(k,mu), no FFTLog column per
+        // walker.  Every other pipeline gets a column of the P_ell / coefficient buffers.
+        {
+            std::vector<int32_t> keep;
+            e->pk_static.clear();
+            for (int p : e->pk_poly) {
+                const vmx_pipe_desc& d = e->pipes[p].d;
+                if (!d.uvb && !d.heii && !(d.damping_scale > 0.0) && !getenv("VMX_NO_STATIC_POLY")) {
+                    PipeDev& pd = e->pipes[p];
+                    pd.poly_basis = (int32_t)e->pk_static.size();
+                    e->pk_static.push_back(p);
+                    // static coordinates as well (no rescaling, no delta_rp, no odd-multipole terms): the basis is
+                    // evaluated on the bins once (k_poly_bins)
+                    if (d.scale_mode == VMX_SCALE_UNIT && d.drp_slot < 0 && !pd.odd_rel && !pd.odd_asy && !getenv("VMX_NO_STATIC_BINS")) {
+                        pd.poly_bins_off = e->poly_bins_total;
+                        e->poly_bins_total += (int64_t)3 * vmx_pad(pd.n);
+                    }
+                } else keep.push_back(p);
+            }
+            e->pk_poly.swap(keep);
+            e->n_active = 0;
+            for (auto& pd : e->pipes) {
+                if (pd.poly_basis >= 0) pd.col = -1;
+                else pd.col = e->n_active++;
+            }
+            if (e->d_pipes.upload(e->pipes.data(), e->pipes.size())) return -2;
+            e->pk_static.push_back(-1);
+            if (e->d_pk_static.upload(e->pk_static.data(), e->pk_static.size())) return -2;
+            e->pk_static.pop_back();
+            std::vector<int32_t> active;
+            for (int p = 0; p < (int)e->pipes.size(); ++p) if (e->pipes[p].col >= 0) active.push_back(p);
+            active.push_back(-1);
+            if (e->d_pipe_active.upload(active.data(), active.size())) return -2;
+        }
         e->pk_poly.push_back(-1);
         if (e->d_pk_poly.upload(e->pk_poly.data(), e->pk_poly.size())) return -2;
         e->pk_poly.pop_back();
@@ -1209,10 +1270,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     }
 
     // workspace (pad regions are zeroed once here and never written afterwards)
-    const size_t ncols = (size_t)Bm * n_pipe;
+    const size_t ncols = (size_t)Bm * n_pipe, acols = (size_t)Bm * std::max(e->n_active, 1);
     if (e->theta.alloc((size_t)Bm * n_params) || e->scal.alloc(ncols * VMX_NS) ||
         e->metal_bias.alloc((size_t)Bm * 3 * (e->metals.size() + 1)) ||
-        e->pl.alloc((size_t)VMX_MAX_ELL * ncols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * ncols * e->ncp) ||
+        e->pl.alloc((size_t)VMX_MAX_ELL * acols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * acols * e->ncp) ||
         e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
         e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(1)) return -2;
     {
@@ -1232,6 +1293,11 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.inv_h[i] = 1.0 / e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
     }
     D.n_pipe = n_pipe; D.pipes = e->d_pipes.p;
+    D.n_active = e->n_active; D.n_static = (int)e->pk_static.size();
+    if (!e->pk_static.empty() && e->poly_coef.alloc((size_t)VMX_MAX_ELL * e->pk_static.size() * 3 * e->ncp, true)) return -2;
+    D.poly_coef = e->poly_coef.p;
+    if (e->poly_bins_total > 0 && e->poly_bins.alloc((size_t)e->poly_bins_total, true)) return -2;
+    D.poly_bins = e->poly_bins.p;
     D.cr = e->cr.p; D.cmu = e->cmu.p; D.crp = e->crp.p; D.crt = e->crt.p; D.cz = e->cz.p; D.crelz = e->crelz.p; D.clnrelz = e->clnrelz.p; D.clnrelz2 = e->clnrelz2.p; D.cgrowth = e->cgrowth.p;
     D.n_items = (int)e->items.size(); D.items = e->d_items.p;
     D.metals = e->d_metals.p; D.n_metals_total = (int)e->metals.size();
@@ -1257,6 +1323,9 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     HIP_OK(hipHostMalloc((void**)&e->pin_theta, (size_t)Bm * n_params * sizeof(double), hipHostMallocMapped));
     HIP_OK(hipHostMalloc((void**)&e->pin_chi2, (size_t)Bm * sizeof(double), hipHostMallocMapped));
     HIP_OK(hipHostMalloc((void**)&e->pin_status, (size_t)Bm * sizeof(int32_t), hipHostMallocMapped));
+    HIP_OK(hipHostMalloc((void**)&e->pin_done, sizeof(int64_t), hipHostMallocMapped));
+    *e->pin_done = 0;
+    if (getenv("VMX_NO_DONE_WORD") || hipHostGetDevicePointer((void**)&e->dpin_done, e->pin_done, 0) != hipSuccess) { (void)hipGetLastError(); e->dpin_done = nullptr; }
     if (!getenv("VMX_NO_ZERO_COPY") &&
         (hipHostGetDevicePointer((void**)&e->dpin_theta, e->pin_theta, 0) != hipSuccess ||
          hipHostGetDevicePointer((void**)&e->dpin_chi2, e->pin_chi2, 0) != hipSuccess ||
@@ -1281,10 +1350,46 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 
     HIP_OK(hipStreamSynchronize(e->stream));
     e->finalized = true;
+    if (poly_basis_build(e)) { e->finalized = false; return -2; }
     return 0;
 }
 
 int vmx_model_size(vmx_engine* e) { return e ? e->model_size : -1; }
+
+// static spline-coefficient basis of the polynomial pipelines: C[ell][basis][i] = OP_ell . V_i[ell] (k_poly_basis), with the
+// product kernels of the chain; redone when the linear spectra change (vmx_set_linear_spectra)
+static int poly_basis_build(vmx_engine* e)
+{
+    e->poly_dirty = false;
+    const int ns = (int)e->pk_static.size();
+    if (ns == 0) return 0;
+    DevBuf<double> V;
+    const int64_t rows = (int64_t)ns * 3;
+    if (V.alloc((size_t)VMX_MAX_ELL * rows * e->nkp, true)) return -2;
+    e->cur = e->stream;
+    hipLaunchKernelGGL(k_poly_basis, dim3((e->nkp + 255) / 256, ns), dim3(256), 0, e->stream, e->dev, e->d_pk_static.p, V.p);
+    launch_product(e, KC_OTHER, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
+                   V.p, e->nkp, rows * e->nkp, (int)rows, e->poly_coef.p, e->ncp, rows * e->ncp, VMX_MAX_ELL, (int)rows);
+    HIP_OK(hipGetLastError());
+    if (e->poly_bins_total > 0) {
+        std::vector<int32_t> ok(ns, 1);
+        DevBuf<int32_t> d_ok;
+        if (d_ok.upload(ok.data(), ok.size())) return -2;
+        int max_n = 0;
+        for (int p : e->pk_static) max_n = std::max(max_n, (int)e->pipes[p].n);
+        hipLaunchKernelGGL(k_poly_bins, dim3((max_n + 255) / 256, ns, 3), dim3(256), 0, e->stream, e->dev, e->d_pk_static.p,
+                           e->poly_bins.p, d_ok.p);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(e->stream));
+        HIP_OK(hipMemcpy(ok.data(), d_ok.p, ok.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        bool changed = false;
+        for (int sb = 0; sb < ns; ++sb)
+            if (!ok[sb] && e->pipes[e->pk_static[sb]].poly_bins_off >= 0) { e->pipes[e->pk_static[sb]].poly_bins_off = -1; changed = true; }
+        if (changed) HIP_OK(hipMemcpy(e->d_pipes.p, e->pipes.data(), e->pipes.size() * sizeof(PipeDev), hipMemcpyHostToDevice));
+    }
+    HIP_OK(hipStreamSynchronize(e->stream));
+    return 0;
+}
 
 // enqueue the whole kernel chain for the B parameter points already in e->theta
 // Kronecker-form metal matrices of an item: one launch, one block per (walker, metal) (k_metal_kron)
@@ -1306,7 +1411,8 @@ static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, i
 }
 
 static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
-                     double* d_chi2 = nullptr, int32_t* d_status = nullptr, bool quad = false)
+                     double* d_chi2 = nullptr, int32_t* d_status = nullptr, bool quad = false,
+                     const double* theta_by_value = nullptr)
 {
     EngineDev D = e->dev;
     D.n_const_slots = tab_mode ? (int)e->const_slots.size() : 0;
@@ -1319,14 +1425,21 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         D.theta_host = d_theta; D.theta_copy = e->theta.p; D.src_lds = 0;
         D.chi2_host = d_chi2; D.status_host = d_status;
     }
+    if (theta_by_value && zero_copy && B == 1 && e->dpin_done && !e->profiling) { D.done_host = e->dpin_done; D.done_seq = ++e->done_seq; }
     const int n_pipe = D.n_pipe;
     {
         ScopedTimer t(e, KC_PROLOGUE);
         const int n_thr = B * (n_pipe + 1);
-        if (zero_copy)      // one block holds every walker of the (small) batch in LDS
-            hipLaunchKernelGGL(k_prologue, dim3(1), dim3((n_thr + 63) / 64 * 64), (size_t)B * e->n_params * sizeof(double), e->stream, D, B);
+        const size_t desc_bytes = (size_t)n_pipe * sizeof(PipeDev);      // the pipeline descriptors, staged in LDS by every block
+        if (zero_copy && theta_by_value) {
+            // (eager launches only: a captured graph would replay the walker it was captured with)
+            ThetaArg ta;
+            std::memcpy(ta.v, theta_by_value, (size_t)B * e->n_params * sizeof(double));
+            hipLaunchKernelGGL(k_prologue_byval, dim3(1), dim3((n_thr + 63) / 64 * 64), desc_bytes + (size_t)B * e->n_params * sizeof(double), e->stream, D, B, ta);
+        } else if (zero_copy)      // one block holds every walker of the (small) batch in LDS
+            hipLaunchKernelGGL(k_prologue, dim3(1), dim3((n_thr + 63) / 64 * 64), desc_bytes + (size_t)B * e->n_params * sizeof(double), e->stream, D, B);
         else
-            hipLaunchKernelGGL(k_prologue, dim3((n_thr + 63) / 64), dim3(64), 0, e->stream, D, B);
+            hipLaunchKernelGGL(k_prologue, dim3((n_thr + 63) / 64), dim3(64), desc_bytes, e->stream, D, B);
     }
     {
         ScopedTimer t(e, KC_PK);
@@ -1379,16 +1492,28 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         }
     }
     {
-        const int64_t ncols = (int64_t)B * n_pipe;
-        launch_product(e, KC_FFTLOG, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
-                       e->pl.p, e->nkp, ncols * e->nkp, (int)ncols, e->coef.p, e->ncp, ncols * e->ncp,
-                       VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
+        const int64_t ncols = (int64_t)B * e->n_active;
+        if (ncols > 0)
+            launch_product(e, KC_FFTLOG, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
+                           e->pl.p, e->nkp, ncols * e->nkp, (int)ncols, e->coef.p, e->ncp, ncols * e->ncp,
+                           VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
     }
-    {
+    // chi2-only small batches of items without metal terms: bins + quadratic-form entries in one kernel
+    bool xi_fused = quad && B <= 8 && (size_t)n_pipe == 2 * e->items.size();
+    for (auto* it : e->items) if (!it->metals.empty() || it->dev.d.pipe_peak == it->dev.d.pipe_smooth) xi_fused = false;
+    if (xi_fused) {
+        ScopedTimer t(e, KC_XI);
+        int max_nq = 0;
+        for (auto* it : e->items) max_nq = std::max(max_nq, (int)it->dev.nq_pad);
+        hipLaunchKernelGGL(k_xi_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->stream, D);
+    } else {
         ScopedTimer t(e, KC_XI);
         int max_n = 0;
         for (auto& p : e->pipes) max_n = p.n > max_n ? p.n : max_n;
-        hipLaunchKernelGGL(k_xi_bins, dim3((max_n + 255) / 256, n_pipe, B), dim3(256), 0, e->stream, D);
+        if (e->n_active > 0)
+            hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, e->n_active, B), dim3(256), 0, e->stream, D, e->d_pipe_active.p);
+        if (!e->pk_static.empty())
+            hipLaunchKernelGGL(k_xi_bins<true>, dim3((max_n + 255) / 256, (unsigned)e->pk_static.size(), B), dim3(256), 0, e->stream, D, e->d_pk_static.p);
     }
     // dense metal-matrix products of an item (no split-K: the consumer reads one slab)
     auto metal_products = [&](ItemHost* it) {
@@ -1405,7 +1530,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         e->cur = e->stream;
         int max_nq = 0;
         for (auto* it : e->items) { max_nq = std::max(max_nq, (int)it->dev.nq_pad); metal_products(it); }
-        {
+        if (!xi_fused) {
             ScopedTimer t(e, KC_ASSEMBLE);
             hipLaunchKernelGGL(k_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->cur, D);
         }
@@ -1814,7 +1939,7 @@ int vmx_set_linear_spectra(vmx_engine* e, const double* pk_peak, const double* p
     const double* src[3] = {pk_peak, pk_smooth, pk_full};
     for (int i = 0; i < 3; ++i)
         HIP_OK(hipMemcpy(e->pklin.p + (size_t)i * e->nkp, src[i], (size_t)nk * sizeof(double), hipMemcpyHostToDevice));
-    return 0;
+    return poly_basis_build(e);
 }
 
 int vmx_item_set_marg_matrix(vmx_engine* e, int32_t item, const double* m, int32_t n_templates, int32_t n_masked)
@@ -1877,6 +2002,7 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
 {
     REQUIRE(e && e->finalized && theta, "vmx_eval");
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
+    const auto t_begin = std::chrono::steady_clock::now();
     HIP_OK(hipSetDevice(e->device));
     // small batches are latency-bound: the first kernel reads the walkers from the mapped pinned buffer and the last
     // one stores chi2 / status there, which removes three staging copies (~25 us of a ~100 us evaluation)
@@ -1898,13 +2024,36 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     for (int b = 1; b < B && tab_mode; ++b)
         for (int slot : e->const_slots)
             if (theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = false; break; }
-    if (run_chain_cached(e, B, tab_mode, zero_copy, quad)) return -2;
+    const auto t_staged = std::chrono::steady_clock::now();
+    // a single walker is latency-bound end to end: eager launches start the first kernel while the later ones are
+    // still being enqueued, which a graph launch cannot (measured: 70 against 75 us per evaluation)
+    if (B == 1 && !e->graph_b1) {
+        const bool by_value = zero_copy && e->n_params <= VMX_THETA_ARG_MAX;
+        if (run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad, by_value ? e->pin_theta : nullptr)) return -2;
+    }
+    else if (run_chain_cached(e, B, tab_mode, zero_copy, quad)) return -2;
     if (chi2 && !zero_copy) HIP_OK(hipMemcpyAsync(e->pin_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if (status && !zero_copy) HIP_OK(hipMemcpyAsync(e->pin_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (model) HIP_OK(hipMemcpyAsync(model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    if (vmx_sync(e)) return -2;
+    const auto t_enqueued = std::chrono::steady_clock::now();
+    bool waited = false;
+    if (B == 1 && zero_copy && !model && !e->graph_b1 && e->dpin_done && !e->profiling && e->n_params <= VMX_THETA_ARG_MAX) {
+        // the last kernel of a single-walker chain publishes a sequence number after chi2 / status (system-scope fence):
+        // the host waits on that word in mapped memory - a few microseconds sooner than the stream's completion signal
+        const int64_t want = e->done_seq;
+        volatile int64_t* word = e->pin_done;
+        for (int64_t spin = 0; spin < (int64_t)1 << 26 && !waited; ++spin) waited = *word == want;
+    }
+    if (!waited && vmx_sync(e)) return -2;
     if (chi2) std::memcpy(chi2, e->pin_chi2, (size_t)B * sizeof(double));
     if (status) std::memcpy(status, e->pin_status, (size_t)B * sizeof(int32_t));
+    if (e->trace_host) {
+        const auto t_end = std::chrono::steady_clock::now();
+        e->host_ns[0] += std::chrono::duration<double, std::nano>(t_staged - t_begin).count();
+        e->host_ns[1] += std::chrono::duration<double, std::nano>(t_enqueued - t_staged).count();
+        e->host_ns[2] += std::chrono::duration<double, std::nano>(t_end - t_enqueued).count();
+        ++e->host_calls;
+    }
     return 0;
 }
 
@@ -1914,11 +2063,11 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
     if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) { fail(-2, "hip sync"); return -2; }
     const int B = e->last_B;
     const double* src = nullptr; int64_t count = 0;
-    if (what == 0) { src = e->pl.p; count = (int64_t)VMX_MAX_ELL * B * e->pipes.size() * e->nkp; }
+    if (what == 0) { src = e->pl.p; count = (int64_t)VMX_MAX_ELL * B * e->n_active * e->nkp; }
     else if (what == 1) {
         if (index < 0 || index >= (int)e->pipes.size()) { fail(-1, "invalid argument: pipeline index"); return -1; }
         src = e->xi.p + e->pipes[index].xi_off; count = (int64_t)B * e->pipes[index].n_pad;
-    } else if (what == 2) { src = e->coef.p; count = (int64_t)VMX_MAX_ELL * B * e->pipes.size() * e->ncp; }
+    } else if (what == 2) { src = e->coef.p; count = (int64_t)VMX_MAX_ELL * B * e->n_active * e->ncp; }
     else if (what == 3) {
         // correlation of metal `index` (global order of vmx_item_add_metal) after its metal matrix
         if (index < 0 || index >= (int)e->metals.size() || e->metals[index]->dev.mat_off < 0) { fail(-1, "invalid argument: metal without matrix"); return -1; }

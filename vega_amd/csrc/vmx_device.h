@@ -48,6 +48,11 @@ struct PipeDev {
     int64_t coord_off;    // offset into the coordinate arrays
     int64_t xi_off;       // offset into the xi buffer
     double rp_absmin, rp_absmax, rt_min, rt_max;    // over the bins with r != 0 (bounds of the rescaled separations)
+    int32_t col;          // column of this pipeline in the P_ell / spline-coefficient buffers (-1: it has none, see poly_basis)
+    int32_t poly_basis;   // >= 0: its P(k,mu) is the Kaiser polynomial times static factors only, so its spline
+                          // coefficients are a0 C0 + a1 C1 + a2 C2 with the static vectors C (EngineDev::poly_coef): no
+                          // P(k,mu), no FFTLog column per walker
+    int64_t poly_bins_off; // >= 0: ... and its coordinates are static too: offset of Y[3][n_pad] in EngineDev::poly_bins
     int32_t split_evol;   // new-bias-evolution: clnrelz holds tracer 1's ln(rel z), clnrelz2 tracer 2's
     int32_t tracers_swapped;   // vmx_add_pipeline put the caller's second tracer first (canonical order)
     // odd-multipole (relativistic / asymmetry) terms: static spline coefficients + amplitude slots
@@ -133,6 +138,10 @@ struct EngineDev {
     double x0[VMX_MAX_ELL], h[VMX_MAX_ELL], xlast[VMX_MAX_ELL], inv_h[VMX_MAX_ELL];
     // pipelines
     int32_t n_pipe;
+    int32_t n_active;           // pipelines with a column in pl / coef (the others carry a static coefficient basis)
+    const double* poly_coef;    // [n_ell][n_static][3][ncp]  FFTLog o spline of the Kaiser-basis spectra of those
+    const double* poly_bins;    // per static-coordinate pipeline [3][n_pad]: the basis evaluated on its bins
+    int32_t n_static;
     const PipeDev* pipes;
     const double* crp; const double* crt;       // r mu and r sqrt(1 - mu^2) of every bin (static)
     const double* cr; const double* cmu; const double* cz; const double* crelz; const double* clnrelz; const double* cgrowth;
@@ -175,6 +184,9 @@ struct EngineDev {
     int32_t model_size;
     // global covariance mode
     const double* gcinv; int32_t g_n, g_ld; double* gres; double* gz;
+    // zero-copy host evaluations: the last kernel publishes done_seq in mapped host memory after its results, so the
+    // host can wait on that word instead of on the stream (null: no such wait)
+    volatile int64_t* done_host; int64_t done_seq;
 };
 
 struct SlabInfo { int32_t z[16]; int32_t g; };   // split-K slab counts of a product per item (+ the global one)
@@ -208,7 +220,13 @@ __global__ void k_theta_affine(double* theta, const double* tr, int n_params, in
     theta[i] = s == 1.0 ? t + sh : s * t + sh;
 }
 
-__global__ void k_prologue(EngineDev D, int B)
+// A single walker through the host entry point travels in the kernel arguments (no read of mapped host memory over
+// PCIe at the head of a latency-bound chain); up to this many parameters.
+#define VMX_THETA_ARG_MAX 160
+struct ThetaArg { double v[VMX_THETA_ARG_MAX]; };
+
+template <bool BYVAL>
+__device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const ThetaArg* ta)
 {
     // thread = (walker, slot): slots 0 .. n_pipe-1 fill one pipeline's scalars, slot n_pipe the walker-level values
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,29 +234,42 @@ __global__ void k_prologue(EngineDev D, int B)
     __shared__ int s_win[2 * 16];               // per wave: spline-coefficient window of its (walker, pipeline) threads
     if ((threadIdx.x & 63) == 0) { s_win[2 * (threadIdx.x >> 6)] = 0x7fffffff; s_win[2 * (threadIdx.x >> 6) + 1] = -1; }
     if (gid == 0) *D.k_live = 0;
+    // LDS: [pipeline descriptors][walkers of a zero-copy batch].  The descriptors are read dozens of times behind
+    // data-dependent branches; from global memory every such read is its own round trip (~10 us of a single-walker
+    // chain), so the block stages them once.
+    extern __shared__ double s_dyn[];
+    const int n_desc = D.n_pipe * (int)(sizeof(PipeDev) / sizeof(double));
+    {
+        const double* src = (const double*)D.pipes;
+        for (int i = threadIdx.x; i < n_desc; i += blockDim.x) s_dyn[i] = src[i];
+    }
+    const PipeDev* s_pipes = (const PipeDev*)s_dyn;
+    double* s_theta = s_dyn + n_desc;
     const double* t = D.theta + (size_t)b * D.n_params;
     const double* t0 = D.theta_host ? D.theta_host : D.theta;         // walker 0: table keys and the constant-parameter check
-    if (D.theta_host && D.src_lds) {
-        // zero-copy entry (small batches, one block): one coalesced read of the walkers from mapped host memory into
-        // LDS - a single PCIe round trip instead of one per parameter lookup - and the device copy for later kernels
-        extern __shared__ double s_theta[];
+    if (BYVAL || (D.theta_host && D.src_lds)) {
+        // zero-copy entry (small batches, one block): one coalesced read of the walkers - from the kernel arguments, or
+        // from mapped host memory in a single PCIe round trip - into LDS, and the device copy for later kernels
         const int count = B * D.n_params;
-        for (int i = threadIdx.x; i < count; i += blockDim.x) { const double v = D.theta_host[i]; s_theta[i] = v; D.theta_copy[i] = v; }
-        __syncthreads();
+        for (int i = threadIdx.x; i < count; i += blockDim.x) {
+            const double v = BYVAL ? ta->v[i] : D.theta_host[i];
+            s_theta[i] = v; D.theta_copy[i] = v;
+        }
         t = s_theta + (size_t)b * D.n_params;
         t0 = s_theta;           // (no second trip over PCIe for walker 0)
     }
+    __syncthreads();
     for (int key = gid; D.n_const_slots > 0 && key < 6 * D.n_xtab; key += gridDim.x * blockDim.x) {
         // table mode: which D_NL * G tables are stale?  (walker 0 stands for the batch; the others are checked below.)  One
         // thread per key; k_chi2 clears the flags for the next evaluation.
         const int g = key / 6, i = key % 6;
-        const vmx_pipe_desc& dg = D.pipes[D.xtab_pipe[g]].d;
+        const vmx_pipe_desc& dg = s_pipes[D.xtab_pipe[g]].d;
         const double v = dg.arinyo_slot[i] >= 0 ? t0[dg.arinyo_slot[i]] : 0.0;
         if (!(D.xtab_key[g * 6 + i] == v)) atomicOr(&D.xtab_dirty[g], 1);       // keys start as NaN
         D.xtab_key[g * 6 + i] = v;
     }
     if (b >= B) return;
-    if (D.theta_host && !D.src_lds) {
+    if (!BYVAL && D.theta_host && !D.src_lds) {
         // the caller's device buffer is read in place; the threads of a walker leave the copy the later kernels use
         t = D.theta_host + (size_t)b * D.n_params;
         for (int i = slot; i < D.n_params; i += D.n_pipe + 1) D.theta_copy[(size_t)b * D.n_params + i] = t[i];
@@ -246,7 +277,7 @@ __global__ void k_prologue(EngineDev D, int B)
 
     if (slot < D.n_pipe) {
         const int p = slot;
-        const vmx_pipe_desc& d = D.pipes[p].d;
+        const vmx_pipe_desc& d = s_pipes[p].d;
         // the scalars are collected in registers and stored at the end: with stores in between, the compiler has to keep
         // every parameter load behind the previous store (the pointers may alias) - ~30 dependent L2 round trips
         double s[VMX_NS];
@@ -320,7 +351,7 @@ __global__ void k_prologue(EngineDev D, int B)
             // Spline coefficients this (walker, pipeline) can read: r'^2 = ap^2 (rp + drp)^2 + at^2 rt^2 over its bins is
             // bounded by the extremes of |rp|, rt (|rp + drp| lies in [max(0, |rp| - |drp|), |rp| + |drp|]); the FFTLog
             // product computes the rows inside the batch's window only.  NaN / out-of-range inputs open the window fully.
-            const PipeDev& P = D.pipes[p];
+            const PipeDev& P = s_pipes[p];
             const double adrp = fabs(s[S_DRP]);
             const double lo_rp = fmax(P.rp_absmin - adrp, 0.0), hi_rp = P.rp_absmax + adrp;
             const double r2lo = ap * ap * lo_rp * lo_rp + at * at * P.rt_min * P.rt_min;
@@ -390,6 +421,9 @@ __global__ void k_prologue(EngineDev D, int B)
     D.status[b] = st;
     D.chi2[b] = 0.0;
 }
+
+__global__ void k_prologue(EngineDev D, int B) { prologue_body<false>(D, B, nullptr); }
+__global__ void k_prologue_byval(EngineDev D, int B, ThetaArg ta) { prologue_body<true>(D, B, &ta); }
 
 // ------------------------------------------------------------------------------------------------
 // static G(k, mu) table
@@ -938,7 +972,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
                 wm[n] = sum;
             }
             const PkGroup& G = groups[blockIdx.y];
-            const size_t ncols = (size_t)B * D.n_pipe;
+            const size_t ncols = (size_t)B * D.n_active;
             for (int mi = 0; mi < G.n_members; ++mi) {
                 const int pm = members[G.member_off + mi];
                 const vmx_pipe_desc& dm = D.pipes[pm].d;
@@ -960,7 +994,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
                 double damp = 1.0;
                 if (dm.damping_scale > 0.0) damp = exp(-dm.damping_scale * dm.damping_scale * pow(k, (double)dm.damping_power) / 2.0);
                 const double pk = damp * D.pklin[(size_t)dm.pk_lin_kind * D.nkp + i] * inv_nmu;
-                const size_t col = (size_t)b * D.n_pipe + pm;
+                const size_t col = (size_t)b * D.n_active + D.pipes[pm].col;
                 D.pl[((size_t)0 * ncols + col) * D.nkp + i] = pk * mm[0];
                 D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
                 D.pl[((size_t)2 * ncols + col) * D.nkp + i] = pk * (39.375 * mm[2] - 33.75 * mm[1] + 3.375 * mm[0]);
@@ -1008,13 +1042,13 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     if (lt < KT && valid && walker_ok) {
         double damp = 1.0;
         if (d.damping_scale > 0.0) damp = exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
-        const size_t ncols = (size_t)B * D.n_pipe;
+        const size_t ncols = (size_t)B * D.n_active;
         for (int half = 0; half < (T.paired ? 2 : 1); ++half) {
             const int pipe = half ? pp : p;
             const int kind = D.pipes[pipe].d.pk_lin_kind;
             const double pk = damp * ((D.pk_direct && kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i]
                                                                                  : D.pklin[(size_t)kind * D.nkp + i]);
-            const size_t col = (size_t)b * D.n_pipe + pipe;
+            const size_t col = (size_t)b * D.n_active + D.pipes[pipe].col;
             for (int e = 0; e < D.n_ell; ++e) {
                 double sum = 0.0;
                 for (int qq = 0; qq < MS; ++qq) sum += s_red[(half * 4 + e) * 256 + (wb * MS + qq) * KT + kk];
@@ -1033,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_pk_poly(EngineDev D, const int32_t* pol
     const vmx_pipe_desc& d = D.pipes[p].d;
     const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
     const double inv_nmu = 1.0 / (double)D.n_mu;
-    const size_t ncols = (size_t)B * D.n_pipe, col = (size_t)b * D.n_pipe + p;
+    const size_t ncols = (size_t)B * D.n_active, col = (size_t)b * D.n_active + D.pipes[p].col;
     const double* mg0 = D.gk_mom + (size_t)(d.gk_table >= 0 ? d.gk_table : D.n_gk) * 6 * D.nkp;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(D.k_live, D.nk);     // no damping factor: every wavenumber is live
     for (int i = threadIdx.x; i < D.nk; i += 256) {
@@ -1060,6 +1094,29 @@ __global__ __launch_bounds__(256) void k_pk_poly(EngineDev D, const int32_t* pol
         D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
         D.pl[((size_t)2 * ncols + col) * D.nkp + i] = pk * (39.375 * mm[2] - 33.75 * mm[1] + 3.375 * mm[0]);
         D.pl[((size_t)3 * ncols + col) * D.nkp + i] = pk * (187.6875 * mm[3] - 255.9375 * mm[2] + 85.3125 * mm[1] - 4.0625 * mm[0]);
+    }
+}
+
+// Kaiser-basis spectra of a pipeline with a static coefficient basis: with P(k,mu) = P_lin (a0 + a1 mu^2 + a2 mu^4) G(k,mu)
+// the multipoles are a0 V0 + a1 V1 + a2 V2, V_i[ell](k) = P_lin(k) / n_mu * sum_n c_{ell n} M_{n+i}(k), M = moments of G.
+// out: [n_ell][n_static][3][nkp] (the FFTLog o spline operator then turns every row into a coefficient vector).
+__global__ __launch_bounds__(256) void k_poly_basis(EngineDev D, const int32_t* static_pipes, double* out)
+{
+    const int sb = blockIdx.y, p = static_pipes[sb];
+    const vmx_pipe_desc& d = D.pipes[p].d;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D.nkp) return;
+    const double inv_nmu = 1.0 / (double)D.n_mu;
+    const double* mg = D.gk_mom + (size_t)(d.gk_table >= 0 ? d.gk_table : D.n_gk) * 6 * D.nkp + i;
+    const double pk = i < D.nk ? D.pklin[(size_t)d.pk_lin_kind * D.nkp + i] * inv_nmu : 0.0;
+    for (int q = 0; q < 3; ++q) {
+        const double m0 = mg[(size_t)q * D.nkp], m1 = mg[(size_t)(q + 1) * D.nkp], m2 = mg[(size_t)(q + 2) * D.nkp],
+                     m3 = mg[(size_t)(q + 3) * D.nkp];
+        const size_t row = (size_t)sb * 3 + q, rows = (size_t)D.n_static * 3;
+        out[((size_t)0 * rows + row) * D.nkp + i] = pk * m0;
+        out[((size_t)1 * rows + row) * D.nkp + i] = pk * (7.5 * m1 - 2.5 * m0);
+        out[((size_t)2 * rows + row) * D.nkp + i] = pk * (39.375 * m2 - 33.75 * m1 + 3.375 * m0);
+        out[((size_t)3 * rows + row) * D.nkp + i] = pk * (187.6875 * m3 - 255.9375 * m2 + 85.3125 * m1 - 4.0625 * m0);
     }
 }
 
@@ -1310,6 +1367,7 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
         D.chi2[b] = st ? 1e100 : c;
         if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
         if (D.status_host) D.status_host[b] = st;
+        if (D.done_host) { __threadfence_system(); *D.done_host = D.done_seq; }      // (set for single-walker calls only)
         if (b == 0) {
             D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
             for (int g2 = 0; g2 < D.n_xtab; ++g2) D.xtab_dirty[g2] = 0;
@@ -1917,12 +1975,87 @@ __device__ inline double legendre_even(int e, double x)
     }
 }
 
-__global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
+// xi of bin `bin` of pipeline p for walker b of a batch of nB (everything k_xi_bins computes); oob: the rescaled
+// separation left the spline's range
+// Legendre sum of the cubic-spline multipoles at ln r' = x, mu' = rmu for pipeline P (pktoxi.py:144-162).
+//   STATIC_BASIS = false: the walker's spline coefficients (column P.col of D.coef);
+//   STATIC_BASIS = true : a0 C0 + a1 C1 + a2 C2 of the pipeline's static coefficient basis (D.poly_coef).
+template <bool STATIC_BASIS>
+__device__ __forceinline__ double spline_legendre(const EngineDev& D, const PipeDev& P, int b, int nB, double x, double rmu,
+                                                  double a0, double a1, double a2, bool& oob)
 {
-    const int p = blockIdx.y, b = blockIdx.z;
+    const vmx_pipe_desc& d = P.d;
+    const int n_ell = d.n_ell, single_ell = d.single_ell;
+    const size_t ncols = (size_t)nB * D.n_active;
+    const size_t col = (size_t)b * D.n_active + (P.col >= 0 ? P.col : 0);
+    // knot index and taps of every multipole first (a multipole the pipeline does not have reads the taps of ell = 0
+    // and is dropped), then the 16 coefficient loads in one go, then the arithmetic
+    const double* cf[4];
+    double tt[4];
+    bool on[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ee = e < n_ell ? e : 0;
+        const bool inside = D.extrapolate || !(x < D.x0[ee] || x > D.xlast[ee]);     // VegaBoundsError (pktoxi.py:149-152)
+        on[e] = e < n_ell && inside;
+        if (e < n_ell && !inside) oob = true;
+        const double u = (x - D.x0[ee]) * D.inv_h[ee];
+        int j = (int)floor(u);
+        if (j < 0) j = 0;
+        if (j > D.n_coef - 4) j = D.n_coef - 4;
+        if (!(u == u)) j = 0;                   // (a NaN separation must not become an address)
+        tt[e] = u - (double)j;
+        cf[e] = STATIC_BASIS ? D.poly_coef + ((size_t)ee * D.n_static + P.poly_basis) * 3 * D.ncp + j
+                             : D.coef + ((size_t)ee * ncols + col) * D.ncp + j;
+    }
+    double tap[4][4];
+    if (STATIC_BASIS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                tap[e][q] = fma(a2, cf[e][2 * D.ncp + q], fma(a1, cf[e][D.ncp + q], a0 * cf[e][q]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tap[e][q] = cf[e][q];
+    }
+    double xi = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double t = tt[e], t2 = t * t, t3 = t2 * t;
+        const double omt = 1.0 - t;
+        const double w0 = omt * omt * omt;
+        const double w1 = 3.0 * t3 - 6.0 * t2 + 4.0;
+        const double w2 = -3.0 * t3 + 3.0 * t2 + 3.0 * t + 1.0;
+        const double s = (tap[e][0] * w0 + tap[e][1] * w1 + tap[e][2] * w2 + tap[e][3] * t3) * (1.0 / 6.0);
+        if (on[e]) {
+            if (single_ell >= 0) { if (e == single_ell) xi = s; }      // one multipole, no Legendre factor
+            else xi += s * legendre_even(e, rmu);
+        }
+    }
+    return xi;
+}
+
+// Kaiser coefficients a0 + a1 mu^2 + a2 mu^4 = (c0_1 + c1_1 mu^2)(c0_2 + c1_2 mu^2) of a static-basis pipeline, as
+// k_pk_poly forms them from the walker's scalars
+__device__ __forceinline__ void kaiser_coefficients(const vmx_pipe_desc& d, const double* sc, double& a0, double& a1, double& a2)
+{
+    double c01 = sc[S_BIAS1], c02 = sc[S_BIAS2];
+    const double c11 = sc[S_BB1], c12 = d.same_tracer ? sc[S_BB1] : sc[S_BB2];
+    if (d.same_tracer) c02 = c01;
+    a0 = c01 * c02; a1 = fma(c01, c12, c11 * c02); a2 = c11 * c12;
+}
+
+// xi of bin `bin` of pipeline p for walker b of a batch of nB (everything k_xi_bins computes); oob: the rescaled
+// separation left the spline's range.  MODE 0: per-walker spline coefficients; 1: static coefficient basis; 2: static
+// coefficient basis on static coordinates - the spline and Legendre sums of the three basis vectors were evaluated per
+// bin at set-up (k_poly_bins), three loads and three FMAs are left.
+template <int MODE>
+__device__ __forceinline__ double xi_bin_value(const EngineDev& D, int p, int b, int bin, int nB, bool& oob_out)
+{
     const PipeDev& P = D.pipes[p];
-    const int bin = blockIdx.x * 256 + threadIdx.x;
-    if (bin >= P.n) return;
     const vmx_pipe_desc& d = P.d;
     const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
     const size_t c = P.coord_off + bin;
@@ -1930,69 +2063,33 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
     // in program order every one of them is a separate round trip to L2 and a wave spends its life waiting (~12 trips,
     // 0.079 ms per step).  Everything that does not depend on a computed address is therefore requested up front -
     // coordinates, per-bin factors, the walker's scalars, the descriptor fields - and the coefficient taps of all
-    // multipoles are requested together (below): three trips instead.
+    // multipoles are requested together (spline_legendre): three trips instead.
     const double r = D.cr[c], rp0 = D.crp[c], rt0 = D.crt[c];
     const double lnrelz = D.clnrelz[c], growth = D.cgrowth[c];
     const double drp = sc[S_DRP], s_ap = sc[S_AP], s_at = sc[S_AT];
     const double ev1a = sc[S_EV1A], ev2a = sc[S_EV2A];
-    const int n_ell = d.n_ell, single_ell = d.single_ell;
     const bool std_evol = d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD;
     const bool radiation = d.radiation && !d.is_peak, uv_shotnoise = d.uv_shotnoise != 0;
     const bool split_evol = P.split_evol, odd_terms = P.odd_rel || P.odd_asy;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (MODE != 0) kaiser_coefficients(d, sc, a0, a1, a2);
 
     // reference correlation_func.py:200-236: r' = sqrt(r_par'^2 + r_perp'^2), mu' = r_par' / r'.  The kernel is VALU-bound
     // (~600 instructions per bin, most of them in fp64 division, square root and logarithm sequences): mu' comes from one
     // reciprocal square root, ln r' = ln(r'^2) / 2, the knot coordinate from a multiplication by 1 / h.
     double rr2 = 0.0, rmu = 0.0;
-    if (r != 0.0) {
-        const double rrp = s_ap * (rp0 + drp), rrt = s_at * rt0;
-        rr2 = fma(rrp, rrp, rrt * rrt);
-        if (rr2 != 0.0) rmu = rrp * vmx_rsqrt(rr2);
-    }
-
     double xi = 0.0;
     bool oob = false;
-    if (rr2 != 0.0) {
-        const double x = 0.5 * log(rr2);
-        const size_t ncols = (size_t)gridDim.z * D.n_pipe;
-        const size_t col = (size_t)b * D.n_pipe + p;
-        // knot index and taps of every multipole first (a multipole the pipeline does not have reads the taps of ell = 0
-        // and is dropped), then the 16 coefficient loads in one go, then the arithmetic
-        const double* cf[4];
-        double tt[4];
-        bool on[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ee = e < n_ell ? e : 0;
-            const bool inside = D.extrapolate || !(x < D.x0[ee] || x > D.xlast[ee]);     // VegaBoundsError (pktoxi.py:149-152)
-            on[e] = e < n_ell && inside;
-            if (e < n_ell && !inside) oob = true;
-            const double u = (x - D.x0[ee]) * D.inv_h[ee];
-            int j = (int)floor(u);
-            if (j < 0) j = 0;
-            if (j > D.n_coef - 4) j = D.n_coef - 4;
-            if (!(u == u)) j = 0;                   // (a NaN separation must not become an address)
-            tt[e] = u - (double)j;
-            cf[e] = D.coef + ((size_t)ee * ncols + col) * D.ncp + j;
+    if (MODE == 2) {
+        const double* y = D.poly_bins + P.poly_bins_off + bin;
+        xi = fma(a2, y[2 * (size_t)P.n_pad], fma(a1, y[P.n_pad], a0 * y[0]));
+    } else {
+        if (r != 0.0) {
+            const double rrp = s_ap * (rp0 + drp), rrt = s_at * rt0;
+            rr2 = fma(rrp, rrp, rrt * rrt);
+            if (rr2 != 0.0) rmu = rrp * vmx_rsqrt(rr2);
         }
-        double tap[4][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tap[e][q] = cf[e][q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double t = tt[e], t2 = t * t, t3 = t2 * t;
-            const double omt = 1.0 - t;
-            const double w0 = omt * omt * omt;
-            const double w1 = 3.0 * t3 - 6.0 * t2 + 4.0;
-            const double w2 = -3.0 * t3 + 3.0 * t2 + 3.0 * t + 1.0;
-            const double s = (tap[e][0] * w0 + tap[e][1] * w1 + tap[e][2] * w2 + tap[e][3] * t3) * (1.0 / 6.0);
-            if (on[e]) {
-                if (single_ell >= 0) { if (e == single_ell) xi = s; }      // one multipole, no Legendre factor
-                else xi += s * legendre_even(e, rmu);
-            }
-        }
+        if (rr2 != 0.0) xi = spline_legendre<MODE == 1>(D, P, b, nB, 0.5 * log(rr2), rmu, a0, a1, a2, oob);
     }
 
     // bias evolution (correlation_func.py:276-370) and growth (:143)
@@ -2055,8 +2152,81 @@ __global__ __launch_bounds__(256) void k_xi_bins(EngineDev D)
         if (P.odd_rel) xi += t[P.odd_slot[0]] * sp[0] * l1 + t[P.odd_slot[1]] * sp[1] * l3;
         if (P.odd_asy) xi += (t[P.odd_slot[2]] * sp[2] - t[P.odd_slot[3]] * sp[3]) * rr * l1 + t[P.odd_slot[4]] * sp[3] * rr * l3;
     }
+    oob_out = oob;
+    return xi;
+}
+
+// pipes: the pipelines of this launch (STATIC_BASIS = true: those with a static coefficient basis, PipeDev::poly_basis;
+// false: those with a column of per-walker spline coefficients) - two instantiations, because the 48 tap loads of the
+// static form would otherwise cost every pipeline its occupancy
+template <bool STATIC_BASIS>
+__global__ __launch_bounds__(256) void k_xi_bins(EngineDev D, const int32_t* pipes)
+{
+    const int p = pipes[blockIdx.y], b = blockIdx.z;
+    const PipeDev& P = D.pipes[p];
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= P.n) return;
+    bool oob;
+    double xi;
+    if (STATIC_BASIS && P.poly_bins_off >= 0) xi = xi_bin_value<2>(D, p, b, bin, (int)gridDim.z, oob);      // (block-uniform)
+    else xi = xi_bin_value<STATIC_BASIS ? 1 : 0>(D, p, b, bin, (int)gridDim.z, oob);
     if (oob) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
     D.xi[P.xi_off + (size_t)b * P.n_pad + bin] = xi;
+}
+
+// Set-up: static-basis pipelines on static coordinates (no rescaling, no delta_rp): Y_i[bin] = Legendre sum of the splines of
+// basis vector i at the bin's own (r, mu).  grid = (bins, static pipelines, 3); `ok` is cleared for a pipeline with a bin
+// outside the spline range (it then stays on the tap form, which flags walkers as the reference raises).
+__global__ __launch_bounds__(256) void k_poly_bins(EngineDev D, const int32_t* pipes, double* out, int32_t* ok)
+{
+    const int sb = blockIdx.y, p = pipes[sb], i = blockIdx.z;
+    const PipeDev& P = D.pipes[p];
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= P.n || P.poly_bins_off < 0) return;
+    const size_t c = P.coord_off + bin;
+    const double r = D.cr[c], rp0 = D.crp[c], rt0 = D.crt[c];
+    double xi = 0.0;
+    bool oob = false;
+    if (r != 0.0) {
+        const double rr2 = fma(rp0, rp0, rt0 * rt0);
+        if (rr2 != 0.0)
+            xi = spline_legendre<true>(D, P, 0, 1, 0.5 * log(rr2), rp0 * vmx_rsqrt(rr2), i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0,
+                                       i == 2 ? 1.0 : 0.0, oob);
+    }
+    if (oob) ok[sb] = 0;
+    out[P.poly_bins_off + (size_t)i * P.n_pad + bin] = xi;
+}
+
+// Items without metal terms, chi2-only small batches: the bins of the peak and the smooth component and the entry
+// x' - x0' of the quadratic form in one kernel (one launch less in a latency-bound chain).  grid = (bins, walkers, items).
+__global__ __launch_bounds__(256) void k_xi_assemble_quad(EngineDev D)
+{
+    const ItemDev& it = D.items[blockIdx.z];
+    const int b = blockIdx.y, nB = gridDim.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= it.nq_pad) return;
+    const double* t = D.theta + (size_t)b * D.n_params;
+    double v = 0.0;
+    if (i < it.d.n_model) {
+        const PipeDev& Pp = D.pipes[it.d.pipe_peak];
+        const PipeDev& Ps = D.pipes[it.d.pipe_smooth];
+        bool oob_p, oob_s;
+        const double xs = xi_bin_value<0>(D, it.d.pipe_smooth, b, i, nB, oob_s);
+        const double xp = xi_bin_value<0>(D, it.d.pipe_peak, b, i, nB, oob_p);
+        if (oob_p || oob_s) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
+        D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + i] = xs;        // (the stage taps stay valid)
+        D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + i] = xp;
+        // assemble_bin without metals (model.py:119-140,186)
+        const double bao = t[it.d.bao_amp_slot];
+        v = fma(bao, xp, xs);
+        if (it.add_vec) v = fma(it.add_slot >= 0 ? t[it.add_slot] : it.add_default, it.add_vec[i], v);
+        if (it.n_bb[VMX_BB_PRE_MUL]) v *= bb_total(D, it, VMX_BB_PRE_MUL, t, i, it.d.n_model);
+        if (it.n_bb[VMX_BB_PRE_ADD]) v += (1.0 + bao) * bb_total(D, it, VMX_BB_PRE_ADD, t, i, it.d.n_model);
+        v -= it.q_x0[i];
+    } else if (i < it.nq) {
+        v = (1.0 + t[it.d.bao_amp_slot]) * t[it.q_slot[i - it.d.n_model]] - it.q_x0[i];
+    }
+    it.q_x[(size_t)b * it.nq_pad + i] = v;
 }
 
 // chi2 = sum_items diff^T (C^-1 diff) + priors; sentinel on failure
@@ -2111,6 +2281,7 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabI
         D.chi2[b] = st ? 1e100 : c;
         if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
         if (D.status_host) D.status_host[b] = st;
+        if (D.done_host) { __threadfence_system(); *D.done_host = D.done_seq; }      // (set for single-walker calls only)
         if (b == 0) {       // the next evaluation starts from an empty window and clean table flags
             D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
             for (int g = 0; g < D.n_xtab; ++g) D.xtab_dirty[g] = 0;
