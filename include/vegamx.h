@@ -249,6 +249,13 @@ int vmx_item_set_metal_kron(vmx_engine* e, int32_t item, int32_t index, const do
                             const double* b_rt, int32_t n_rt);
 int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index, int32_t rows,
                         int32_t cols, const double* dense);
+/* The distortion matrix in CSR form, as the reference holds it (scipy.sparse.csr_array: data.py:342-346, :456-459; the
+ * product of model.py:143-144): indptr [rows + 1] (int64), indices [nnz] (int32, ascending within a row), values [nnz].
+ * Replaces vmx_item_set_matrix(VMX_MAT_DISTORTION) for matrices sparse enough that streaming 12 bytes per non-zero beats
+ * 8 bytes per entry; every batch size takes the CSR kernel then (8 walkers per pass over the matrix).  Before
+ * vmx_finalize. */
+int vmx_item_set_matrix_csr(vmx_engine* e, int32_t item, int32_t rows, int32_t cols, const int64_t* indptr,
+                            const int32_t* indices, const double* values);
 /* Indices (into the n_dist model bins) kept by the model mask (data.py:410). */
 int vmx_item_set_mask(vmx_engine* e, int32_t item, const int32_t* idx, int32_t n_masked);
 /* Masked data vector, or the current Monte-Carlo mock (vega_interface.py:311-315). */

@@ -113,6 +113,8 @@ struct ItemHost {
     int n_templates = 0;
     int n_mocks = 0;
     DevBuf<int32_t> inv_mask;
+    DevBuf<int64_t> csr_ptr; DevBuf<int32_t> csr_idx; DevBuf<double> csr_val;      // CSR distortion matrix
+    int64_t csr_nnz = 0; bool has_csr = false;
     std::vector<int32_t> mask_idx;
     bool has_dm = false, has_cinv = false, has_mask = false, has_data = false;
 };
@@ -327,6 +329,21 @@ static int pk_variant(const vmx_pipe_desc& d, bool paired)
 
 // the single-walker streaming kernel keeps x in LDS
 static bool gemv1_applies(int N, int K) { return N == 1 && K <= 5120 && (size_t)K * sizeof(double) <= 48 * 1024; }
+
+// CSR distortion product of one item for B walkers -> it->dist (one slab)
+static void launch_csr(vmx_engine* e, ItemHost* it, int B)
+{
+    const ItemDev& d = it->dev;
+    ScopedTimer timer(e, KC_DISTORTION);
+    const int rows = d.d.n_dist;
+#define VMX_CSR(NB) hipLaunchKernelGGL(k_csr_spmm<NB>, dim3((rows + 3) / 4, (B + NB - 1) / NB), dim3(256), 0, e->cur, it->csr_ptr.p, \
+                                       it->csr_idx.p, it->csr_val.p, rows, it->vec.p, d.n_model_pad, B, it->dist.p, d.n_dist_pad)
+    if (B == 1) VMX_CSR(1);
+    else if (B == 2) VMX_CSR(2);
+    else if (B <= 4) VMX_CSR(4);
+    else VMX_CSR(8);
+#undef VMX_CSR
+}
 
 // persistent blocks of the single-walker streaming kernel (2 per CU), rows strided over them
 static int gemv1_blocks(int M)
@@ -847,6 +864,7 @@ int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index
     if (kind == VMX_MAT_DISTORTION) {
         REQUIRE(!e->finalized, "distortion matrix must be set before vmx_finalize");
         REQUIRE(rows == it->dev.d.n_dist && cols == it->dev.d.n_model, "distortion matrix shape");
+        REQUIRE(!it->has_csr, "the item already has a CSR distortion matrix");
         if (upload_padded(it->dm, dense, rows, cols, it->dev.n_model_pad)) return -2;
         it->has_dm = true;
     } else if (kind == VMX_MAT_INVCOV) {
@@ -875,6 +893,25 @@ int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index
         m->dev.mat_off = 0;
         m->dev.mat_ld = vmx_pad(cols);
     } else return fail(-1, "invalid argument: matrix kind");
+    return 0;
+}
+
+int vmx_item_set_matrix_csr(vmx_engine* e, int32_t item, int32_t rows, int32_t cols, const int64_t* indptr,
+                            const int32_t* indices, const double* values)
+{
+    REQUIRE(e && !e->finalized && indptr && indices && values, "vmx_item_set_matrix_csr (before vmx_finalize)");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(rows == it->dev.d.n_dist && cols == it->dev.d.n_model, "distortion matrix shape");
+    REQUIRE(!it->has_dm, "the item already has a dense distortion matrix");
+    REQUIRE(indptr[0] == 0, "indptr[0] must be 0");
+    const int64_t nnz = indptr[rows];
+    for (int r = 0; r < rows; ++r) REQUIRE(indptr[r + 1] >= indptr[r], "indptr must be non-decreasing");
+    for (int64_t k = 0; k < nnz; ++k) REQUIRE(indices[k] >= 0 && indices[k] < cols, "column index out of range");
+    HIP_OK(hipSetDevice(e->device));
+    if (it->csr_ptr.upload(indptr, (size_t)rows + 1) || it->csr_idx.upload(indices, (size_t)std::max<int64_t>(nnz, 1)) ||
+        it->csr_val.upload(values, (size_t)std::max<int64_t>(nnz, 1))) return -2;
+    it->csr_nnz = nnz; it->has_csr = true;
     return 0;
 }
 
@@ -1240,12 +1277,13 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         ItemDev& d = it->dev;
         d.model_off = model_off; model_off += d.d.n_dist;
         d.masked_off = masked_off; masked_off += d.n_masked;
-        REQUIRE(it->has_dm || d.d.n_dist == d.d.n_model, "identity distortion needs n_dist == n_model");
+        REQUIRE(it->has_dm || it->has_csr || d.d.n_dist == d.d.n_model, "identity distortion needs n_dist == n_model");
         if (it->vec.alloc((size_t)Bm * d.n_model_pad, true)) return -2;
         if (it->res.alloc((size_t)Bm * d.n_masked_pad, true)) return -2;
-        if (it->has_dm && it->dist.alloc((size_t)e->slab_rows * d.n_dist_pad, true)) return -2;
+        if ((it->has_dm || it->has_csr) && it->dist.alloc((size_t)e->slab_rows * d.n_dist_pad, true)) return -2;
         if (it->has_cinv && it->z.alloc((size_t)e->slab_rows * d.n_masked_pad, true)) return -2;
         d.dm = it->has_dm ? it->dm.p : nullptr; d.dm_ld = d.n_model_pad;
+        d.dm_ptr = it->has_csr ? it->csr_ptr.p : nullptr; d.dm_idx = it->csr_idx.p; d.dm_val = it->csr_val.p;
         d.cinv = it->has_cinv ? it->cinv.p : nullptr; d.cinv_ld = d.n_masked_pad;
         d.inv_mask = it->inv_mask.p; d.data = it->data.p;
         d.vec = it->vec.p; d.dist = it->dist.p; d.res = it->res.p; d.z = it->z.p;
@@ -1665,6 +1703,8 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
                 ScopedTimer t(e, stage == 0 ? KC_DISTORTION : KC_INVCOV);
                 launch_gemm_group(e, stage == 0 ? KC_DISTORTION : KC_INVCOV, G, per_xcd_total, 1);
             }
+            if (stage == 0)
+                for (auto* it : e->items) if (it->has_csr) launch_csr(e, it, B);       // CSR matrices: 8 walkers per pass
             if (stage == 0) {
                 ScopedTimer t(e, KC_POST);
                 hipLaunchKernelGGL(k_post_all, dim3((max_dist + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->cur, D, B, dslabs);
@@ -1697,6 +1737,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
             dist_slabs = launch_product(e, KC_DISTORTION, it->dm.p, d.n_model_pad, 0, d.d.n_dist, d.n_model_pad,
                                         it->vec.p, d.n_model_pad, 0, B, it->dist.p, d.n_dist_pad, 0, 1, e->slab_rows,
                                         nullptr, fuse ? (int)q : -1);
+        else if (it->has_csr) launch_csr(e, it, B);
         if (!fuse) {
             ScopedTimer t(e, KC_POST);
             hipLaunchKernelGGL(k_post, dim3((d.d.n_dist + 255) / 256, B), dim3(256), 0, e->cur, D, (int)q, B, dist_slabs);
@@ -1820,7 +1861,10 @@ static int quad_build(vmx_engine* e)
             if (X.alloc((size_t)nq * nmp, true)) return -2;
             hipLaunchKernelGGL(k_quad_gather, dim3((nm + 255) / 256, nq), dim3(256), 0, e->stream, X.p, nmp,
                                it->has_dm ? it->dm.p : (const double*)nullptr, d.n_model_pad, midx.p, nm, (int)d.d.n_model, nq,
-                               e->bb_basis.p, bo.p, (int)d.d.n_dist);
+                               e->bb_basis.p, bo.p, (int)d.d.n_dist, it->has_csr ? 1 : 0);
+            if (it->has_csr)
+                hipLaunchKernelGGL(k_quad_gather_csr, dim3(nm), dim3(256), 0, e->stream, X.p, nmp, it->csr_ptr.p, it->csr_idx.p,
+                                   it->csr_val.p, midx.p, nm);
             // (allocated once: captured graphs hold these pointers, and the sizes never change)
             if (it->q_w.p == nullptr && it->q_w.alloc((size_t)nq * nmp, true)) return -2;
             if (it->has_cinv)

@@ -92,6 +92,8 @@ struct ItemDev {
     int64_t masked_off;               // offset in the concatenated masked vector (global-cov mode)
     // device arrays
     const double* dm;  int32_t dm_ld;         // distortion matrix or null
+    // ... or in CSR form (scipy.sparse.csr_array of the reference, data.py:342-346): row pointers, column indices, values
+    const int64_t* dm_ptr; const int32_t* dm_idx; const double* dm_val;
     const double* cinv; int32_t cinv_ld;      // inverse covariance or null (identity)
     const int32_t* inv_mask;                  // [n_dist] -> masked index or -1
     const double* data;                       // [n_masked]
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_post(EngineDev D, int item, int B, int 
     const int bin = blockIdx.x * 256 + threadIdx.x;
     if (bin >= it.d.n_dist) return;
     double v;
-    if (it.dm) {
+    if (it.dm || it.dm_ptr) {
         v = 0.0;
         for (int s = 0; s < dist_slabs; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
     } else v = it.vec[(size_t)b * it.n_model_pad + bin];
@@ -1293,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_post_all(EngineDev D, int B, SlabInfo d
     const int bin = blockIdx.x * 256 + threadIdx.x;
     if (bin >= it.d.n_dist) return;
     double v;
-    if (it.dm) {
+    if (it.dm || it.dm_ptr) {
         v = 0.0;
         for (int s = 0; s < dist_slabs.z[blockIdx.z]; ++s) v += it.dist[((size_t)s * B + b) * it.n_dist_pad + bin];
     } else v = it.vec[(size_t)b * it.n_model_pad + bin];
@@ -1378,15 +1380,17 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
 // set-up kernels of the quadratic form ----------------------------------------------------------
 // X[j][i] = DM'[mask_idx[i]][j]: the masked rows of [DM | post-add broadband basis], transposed (row j = column j of DM')
 __global__ void k_quad_gather(double* X, int ldx, const double* dm, int dm_ld, const int32_t* mask_idx, int n_masked,
-                              int n_model, int nq, const double* bb_basis, const int64_t* basis_off, int n_dist)
+                              int n_model, int nq, const double* bb_basis, const int64_t* basis_off, int n_dist, int csr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (i >= n_masked || j >= nq) return;
     const int r = mask_idx[i];
     double v;
-    if (j < n_model) v = dm ? dm[(size_t)r * dm_ld + j] : (r == j ? 1.0 : 0.0);
-    else v = bb_basis[basis_off[j - n_model] + r];
+    if (j < n_model) {
+        if (csr) return;            // (k_quad_gather_csr scatters the non-zeros of a CSR matrix into the zeroed X)
+        v = dm ? dm[(size_t)r * dm_ld + j] : (r == j ? 1.0 : 0.0);
+    } else v = bb_basis[basis_off[j - n_model] + r];
     X[(size_t)j * ldx + i] = v;
 }
 
@@ -1824,6 +1828,59 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
             if (n < g.N && m < g.M) Dp[(size_t)n * g.ldd + m] = out;
         }
   }
+}
+
+// Distortion product with a CSR matrix (the reference keeps it as scipy csr_array: data.py:342-346, model.py:143-144):
+//   D[b][row] = sum_k val[k] X[b][idx[k]],  k in [ptr[row], ptr[row + 1])
+// one wave per matrix row, NB walkers per pass (blockIdx.y = walker tile): the row's (index, value) pairs are read once
+// per tile - 12 bytes per non-zero - and the gathers of X hit L2 (a walker's vector is ~20-40 KB).  HBM-bound for
+// B <= 8: 12 nnz + 8 (rows + 1) + 8 B (n_in + n_out) bytes.
+template <int NB>
+__global__ __launch_bounds__(256) void k_csr_spmm(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                  const double* __restrict__ val, int rows, const double* __restrict__ X,
+                                                  int ldx, int N, double* __restrict__ Dp, int ldd)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int n0 = blockIdx.y * NB;
+    const int64_t k0 = ptr[row], k1 = ptr[row + 1];
+    double acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.0;
+    // two (index, value) pairs in flight per lane
+    int64_t k = k0 + lane;
+    for (; k + 64 < k1; k += 128) {
+        const int c0 = idx[k], c1 = idx[k + 64];
+        const double v0 = val[k], v1 = val[k + 64];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double* x = X + (size_t)(n0 + b < N ? n0 + b : N - 1) * ldx;
+            acc[b] = fma(v1, x[c1], fma(v0, x[c0], acc[b]));
+        }
+    }
+    if (k < k1) {
+        const int c0 = idx[k];
+        const double v0 = val[k];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = fma(v0, X[(size_t)(n0 + b < N ? n0 + b : N - 1) * ldx + c0], acc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double v = acc[b];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && n0 + b < N) Dp[(size_t)(n0 + b) * ldd + row] = v;
+    }
+}
+
+// X[j][i] += DM[mask_idx[i]][j] for a CSR distortion matrix (the columns j < n_model of k_quad_gather's X; X starts zeroed)
+__global__ void k_quad_gather_csr(double* X, int ldx, const int64_t* ptr, const int32_t* idx, const double* val,
+                                  const int32_t* mask_idx, int n_masked)
+{
+    const int i = blockIdx.x;
+    if (i >= n_masked) return;
+    const int r = mask_idx[i];
+    for (int64_t k = ptr[r] + threadIdx.x; k < ptr[r + 1]; k += blockDim.x) X[(size_t)idx[k] * ldx + i] = val[k];
 }
 
 // y[n][m] = sum over slabs (fixed order) - used by the stand-alone product entry point

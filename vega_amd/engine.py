@@ -121,6 +121,7 @@ def load_library():
     lib.vmx_item_add_broadband.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, iptr, dptr,
                                            C.c_int32]
     lib.vmx_item_set_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dptr]
+    lib.vmx_item_set_matrix_csr.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), iptr, dptr]
     lib.vmx_item_set_mask.argtypes = [C.c_void_p, C.c_int32, iptr, C.c_int32]
     lib.vmx_item_set_data.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_global_invcov.argtypes = [C.c_void_p, dptr, C.c_int32]
@@ -166,7 +167,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
-    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix',
+    'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
@@ -415,13 +416,18 @@ class Lowering:
 class Engine:
     """One vegamx engine handle on one GPU, built from a Problem."""
 
-    def __init__(self, problem, max_batch=256, device=0, extra_names=(), metal_plan=None, kron_metals=True):
+    def __init__(self, problem, max_batch=256, device=0, extra_names=(), metal_plan=None, kron_metals=True,
+                 csr_threshold=None):
         self.lib = load_library()
         self.prob = problem
         # fast_metals (see fast_metal_plan): per item, per metal pair ('pipeline', None) | ('share', leader index)
         # | ('static', xi vector) | ('basis', [3, n_model] Kaiser basis)
         self.metal_plan = metal_plan or {}
         self.kron_metals = bool(kron_metals)   # False: Kronecker-form metal matrices are uploaded dense (diagnosis)
+        # a scipy.sparse distortion matrix stays in CSR form on the device when its density is below this fraction
+        # (12 bytes per non-zero against 8 per entry, and the dense MFMA product wins for large batches well before that)
+        self.csr_threshold = float(os.environ.get('VEGAMX_CSR_THRESHOLD', 0.3)) if csr_threshold is None else float(csr_threshold)
+        self.csr_items = []
         self.metal_source = {}          # (item name, pair index) -> (global metal index, pipeline id, has matrix)
         self.low = Lowering(problem, extra_names)
         self.names = self.low.names
@@ -661,9 +667,20 @@ class Engine:
 
             if item.distortion is not None:
                 dm = item.distortion
-                dense = _f64(dm.toarray() if hasattr(dm, 'toarray') else dm)
-                self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_DISTORTION, 0, dense.shape[0],
-                                                    dense.shape[1], _dp(dense)))
+                if hasattr(dm, 'tocsr') and dm.nnz < self.csr_threshold * dm.shape[0] * dm.shape[1]:
+                    # the reference's own representation (scipy csr_array, vega/data.py:342-346), kept as is
+                    csr = dm.tocsr()
+                    csr.sort_indices()
+                    ptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)
+                    idx = np.ascontiguousarray(csr.indices, dtype=np.int32)
+                    val = _f64(csr.data)
+                    self._check(lib.vmx_item_set_matrix_csr(self._h, iid, csr.shape[0], csr.shape[1],
+                                                            ptr.ctypes.data_as(C.POINTER(C.c_int64)), _ip(idx), _dp(val)))
+                    self.csr_items.append(name)
+                else:
+                    dense = _f64(dm.toarray() if hasattr(dm, 'toarray') else dm)
+                    self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_DISTORTION, 0, dense.shape[0],
+                                                        dense.shape[1], _dp(dense)))
             idx = np.flatnonzero(item.model_mask).astype(np.int32)
             if idx.size != item.data_size:
                 raise ValueError(f'{name}: model mask keeps {idx.size} bins but the data mask {item.data_size}')

@@ -62,7 +62,7 @@ class VegaInterface:
     """GPU-backed stand-in for ``vega.VegaInterface`` restricted to the model + chi2 hot path."""
 
     def __init__(self, main_path, search_dirs=(), max_batch=256, device=0, problem=None,
-                 extra_names=(), kron_metals=True):
+                 extra_names=(), kron_metals=True, csr_threshold=None):
         self.problem = problem if problem is not None else build_problem(main_path, search_dirs)
         self.main_config = self.problem.main_config
         self.params = self.problem.params
@@ -77,7 +77,8 @@ class VegaInterface:
         self._use_global_cov = self.problem.global_cov is not None
         self.monte_carlo = False
         self._mc_active = False
-        self._engine_args = dict(max_batch=max_batch, device=device, extra_names=extra_names, kron_metals=kron_metals)
+        self._engine_args = dict(max_batch=max_batch, device=device, extra_names=extra_names, kron_metals=kron_metals,
+                                 csr_threshold=csr_threshold)
         # parameter-level blinding (reference vega_interface.py:123-127, :853-886): checked before anything is computed
         from .setup import init_blinding
         self._blind, _ = init_blinding(self.problem.items, self.sample_params)
