@@ -110,9 +110,11 @@ typedef struct {
     int32_t scale_slot[2];
     int32_t drp_slot;               /* drp_<discrete tracer>, -1 none (correlation_func.py:65-69) */
     int32_t croom_slot[2];          /* croom_par0, croom_par1 */
-    int32_t radiation;              /* QSO radiation term (correlation_func.py:446-489) */
+    int32_t radiation;              /* QSO radiation term (correlation_func.py:446-489); 2: on the rescaled coordinates
+                                     * (`rescale-coords-systematics`, :470-472) */
     int32_t rad_slot[4];            /* strength, asymmetry, lifetime, decrease */
-    int32_t uv_shotnoise;           /* UV-background shot noise (correlation_func.py:649-686) */
+    int32_t uv_shotnoise;           /* UV-background shot noise (correlation_func.py:649-686); 2: with the reference's
+                                     * `rescale-coords-systematics` separation (:681-682) */
     int32_t uvsn_slot[3];           /* uv_shotnoise_amp, lambda_uv, bias_gamma (or bias_gamma_e) */
     int32_t single_ell;             /* -1, or ell / 2: return that multipole xi_ell(r') alone (pktoxi.py:122-155) */
     double  z_eff;
@@ -280,6 +282,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch);
 
 /* Total output size per walker: sum of n_dist over items, in item order. */
 int vmx_model_size(vmx_engine* e);
+/* Column of a pipeline in the P_ell(k) / spline-coefficient stage buffers (vmx_debug_read 0 and 2, laid out
+ * [ell][walker * n_columns + column][k]); pipelines whose multipoles are never formed per walker (Kaiser polynomial
+ * times static factors: they carry a static coefficient basis) have none: the value is then -3 - n_columns. */
+int vmx_pipeline_column(vmx_engine* e, int32_t pipeline);
 
 /* Evaluate B parameter points.  theta [B][n_params] host memory.
  * chi2 [B] (may be NULL), model [B][vmx_model_size] (may be NULL), status [B] (may be NULL).
@@ -339,7 +345,7 @@ int vmx_set_constant_nl_hint(vmx_engine* e, int32_t enabled);
 void* vmx_stream(vmx_engine* e);
 
 /* Stage taps for parity tests: copy an internal buffer of the last evaluation to the host.
- * what: 0 = P_ell(k) [n_ell_max][B*n_pipe][nk_pad]; 1 = xi per pipeline [B][n] (index = pipeline);
+ * what: 0 = P_ell(k) [n_ell_max][B*n_columns][nk_pad] (vmx_pipeline_column); 1 = xi per pipeline [B][n] (index = pipeline);
  * 2 = spline coefficients; 3 = metal correlation after its metal matrix [B][pad32(n_model)] (index = metal, in the
  * global order of vmx_item_add_metal).
  * Returns the number of doubles written (<= capacity) or a negative error. */

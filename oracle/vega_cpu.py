@@ -289,10 +289,10 @@ _LEGENDRE = {ell: special.legendre(ell) for ell in range(0, 9)}
 _P2XI_CACHE = {}
 
 
-def _p2xi(k, ell):
-    key = (k.tobytes(), ell)
+def _p2xi(k, ell, lowring=True):
+    key = (k.tobytes(), ell, bool(lowring))
     if key not in _P2XI_CACHE:
-        _P2XI_CACHE[key] = P2xi(k, l=ell, lowring=True)
+        _P2XI_CACHE[key] = P2xi(k, l=ell, lowring=lowring)        # fht_lowring (reference pktoxi.py:42,53)
     return _P2XI_CACHE[key]
 
 
@@ -360,7 +360,7 @@ def pk_to_xi(pipe, grid, r_grid, mu_grid, pk, taps=None):
     xi_ell_arr = np.zeros([len(ell_vals), len(r_grid)])
     pk_ells = pk_multipoles(grid, pk, ell_vals)
     for i, ell in enumerate(ell_vals):
-        r_fft, xi_fft = _p2xi(grid.k, ell)(pk_ells[i], extrap=False)
+        r_fft, xi_fft = _p2xi(grid.k, ell, getattr(pipe.xi, 'fht_lowring', True))(pk_ells[i], extrap=False)
         if taps is not None:
             taps.setdefault('pk_ell', {})[ell] = pk_ells[i]
             taps.setdefault('xi_fft', {})[ell] = (r_fft, xi_fft)
@@ -485,8 +485,9 @@ def shotnoise_A(ntau=100, nrho=10000):
     return _SHOTNOISE_A[key]
 
 
-def uv_shotnoise(pipe, params):
-    """reference correlation_func.py:649-686 (unrescaled coordinates)"""
+def uv_shotnoise(pipe, params, rescaled_r=None, rescaled_mu=None):
+    """reference correlation_func.py:649-686 (unrescaled coordinates; with `rescale-coords-systematics` the reference
+    forms r = sqrt(rescaled_r^2 + rescaled_mu^2), :681-682, restated as written)"""
     amp = params['uv_shotnoise_amp']
     lam = params['lambda_uv']
     if 'bias_gamma' in params:
@@ -497,6 +498,8 @@ def uv_shotnoise(pipe, params):
         raise ValueError('UV shotnoise needs bias_gamma or bias_gamma_e')
     tau, a = shotnoise_A()
     r = pipe.r
+    if pipe.xi.rescale_coords_systematics:
+        r = np.sqrt(rescaled_r**2 + rescaled_mu**2)
     return bg**2 * amp * lam / r * np.interp(r / lam, tau, a, left=a[0], right=0)
 
 
@@ -545,7 +548,7 @@ def correlation_function(prob, pipe, grid, pk, pk_lin, params, taps=None):
             xa = xa + params['Aasy3'] * x[1, :] * rr2 * _LEGENDRE[3](rmu2)
             xi = xi + xa
     if pipe.xi.uv_shotnoise:
-        xi = xi + uv_shotnoise(pipe, params)
+        xi = xi + uv_shotnoise(pipe, params, rr, rmu)
     return xi
 
 

@@ -202,3 +202,32 @@ def config1_problem():
         item.distortion = synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt)
         item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt))
     return prob
+
+
+def options2_problem(tmp_path, which):
+    """Configs of tests/golden/make_golden.py::dump_options2: 'cross' (rescale-coords-systematics + old_growth_func +
+    fht_lowring = False on the QSO x Lya item), 'auto' (UV shot noise with rescale-coords-systematics), 'model_pk'."""
+    import re
+    from vega_amd.setup import build_problem
+    cfg = tmp_path / 'configs' / f'opt2_{which}'
+    cfg.mkdir(parents=True, exist_ok=True)
+    if which == 'model_pk':
+        main = (GOLDEN / 'configs' / 'joint' / 'main.ini').read_text().replace('[control]', '[control]\nmodel_pk = True')
+        if '[control]' not in main:
+            main += '\n[control]\nmodel_pk = True\n'
+        for it in ('lyalya_lyalya', 'lyalya_qso'):
+            (cfg / f'{it}.ini').write_text((GOLDEN / 'configs' / 'joint' / f'{it}.ini').read_text())
+        main = re.sub(r'ini files = .*', f'ini files = configs/opt2_{which}/lyalya_lyalya.ini configs/opt2_{which}/lyalya_qso.ini', main)
+    else:
+        item_name = 'lyalya_qso' if which == 'cross' else 'lyalya_lyalya'
+        main = (GOLDEN / 'configs' / 'joint' / 'main.ini').read_text()
+        main = re.sub(r'ini files = .*', f'ini files = configs/opt2_{which}/{item_name}.ini', main)
+        text = (GOLDEN / 'configs' / 'joint' / f'{item_name}.ini').read_text()
+        if which == 'cross':
+            text = text.replace('[model]', '[model]\nrescale-coords-systematics = True\nold_growth_func = True\nfht_lowring = False')
+        else:
+            text = text.replace('[model]', '[model]\nUVB-shotnoise = True\nrescale-coords-systematics = True')
+            main = main.replace('[parameters]', '[parameters]\nuv_shotnoise_amp = 0.02')
+        (cfg / f'{item_name}.ini').write_text(text)
+    (cfg / 'main.ini').write_text(main)
+    return build_problem(f'configs/opt2_{which}/main.ini', search_dirs=[tmp_path, GOLDEN])

@@ -849,6 +849,62 @@ def dump_model_compute(VegaInterface):
         print('model compute: dumped', [k for k in out if '/' in k])
 
 
+def dump_options2(VegaInterface):
+    """Model options of the xi stage that round 1 rejected: `rescale-coords-systematics` (QSO radiation and UV shot
+    noise evaluated on the rescaled coordinates, reference vega/correlation_func.py:470-475, :681-684),
+    `old_growth_func` (:75-80, :405-444), `fht_lowring = False` (vega/pktoxi.py:42,53), and `model_pk` (the models are
+    the multipoles of the core power spectrum: vega/vega_interface.py:66, vega/model.py:106-107)."""
+    os.chdir(REF / 'tests')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_qso'], False)
+        item = Path(tmp) / 'lyalya_qso.ini'
+        item.write_text(item.read_text().replace('[model]', '[model]\nrescale-coords-systematics = True\n'
+                                                 'old_growth_func = True\nfht_lowring = False'))
+        vega = VegaInterface(main)
+        out['cross/fid/chi2'] = vega.chi2()
+        out['cross/fid/model'] = vega.compute_model(run_init=False)['lyalya_qso']
+        names, walkers = make_walkers(vega.params, 2, seed=WALKER_SEED + 41)
+        out['cross/param_names'] = np.array(names)
+        out['cross/theta'] = np.array([[w[n] for n in names] for w in walkers])
+        chi2s = []
+        for i, w in enumerate(walkers):
+            _reset_caches(vega)
+            chi2s.append(vega.chi2(w))
+            _reset_caches(vega)
+            out[f'cross/walker{i}/model'] = vega.compute_model(w, run_init=False)['lyalya_qso']
+        out['cross/chi2'] = np.array(chi2s)
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_lyalya'], False)
+        mp = Path(main)
+        mp.write_text(mp.read_text().replace('[parameters]', '[parameters]\nuv_shotnoise_amp = 0.02'))
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(item.read_text().replace('[model]', '[model]\nUVB-shotnoise = True\n'
+                                                 'rescale-coords-systematics = True'))
+        vega = VegaInterface(main)
+        out['auto/fid/chi2'] = vega.chi2()
+        out['auto/fid/model'] = vega.compute_model(run_init=False)['lyalya_lyalya']
+        w = {'ap': 1.03, 'at': 0.96, 'uv_shotnoise_amp': 0.03}
+        _reset_caches(vega)
+        out['auto/walker/chi2'] = vega.chi2(w)
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_lyalya', 'lyalya_qso'], False)
+        mp = Path(main)
+        mp.write_text(mp.read_text().replace('[control]', '[control]\nmodel_pk = True'))
+        vega = VegaInterface(main)
+        model = vega.compute_model(run_init=False)
+        for name in model:
+            out[f'model_pk/fid/{name}'] = np.asarray(model[name])
+        w = {'ap': 1.03, 'bias_eta_LYA': -0.21, 'beta_LYA': 1.5, 'bao_amp': 0.8, 'sigmaNL_par': 7.0}
+        _reset_caches(vega)
+        model = vega.compute_model(w, run_init=False)
+        for name in model:
+            out[f'model_pk/walker/{name}'] = np.asarray(model[name])
+    np.savez_compressed(HERE / 'expected_options2.npz', **out)
+    print('options2: cross chi2', out['cross/fid/chi2'], out['cross/chi2'], 'auto', out['auto/fid/chi2'],
+          'model_pk shape', out['model_pk/fid/lyalya_lyalya'].shape)
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -856,12 +912,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -900,3 +956,5 @@ if __name__ == '__main__':
         dump_global_mc(VI)
     if 'model_compute' in what:
         dump_model_compute(VI)
+    if 'options2' in what:
+        dump_options2(VI)

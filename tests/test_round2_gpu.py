@@ -227,3 +227,41 @@ def test_walker_sharding_on_a_real_engine_with_an_rccl_group_of_one():
         if created:
             dist.destroy_process_group()
     vega.close()
+
+
+def test_xi_stage_options_and_model_pk(tmp_path):
+    """`rescale-coords-systematics` (radiation term and UV shot noise on the rescaled coordinates), `old_growth_func`,
+    `fht_lowring = False` and `model_pk` (the models are the multipoles of the core power spectrum) against the
+    unmodified reference."""
+    from conftest import options2_problem
+    from vega_amd import VegaInterface
+    exp = np.load(GOLDEN / 'expected_options2.npz')
+    prob = options2_problem(tmp_path, 'cross')
+    vega = VegaInterface(None, problem=prob, max_batch=4)
+    mask = prob.items['lyalya_qso'].model_mask
+    assert vega.chi2() == pytest.approx(float(exp['cross/fid/chi2']), rel=CHI2_RTOL)
+    _assert_xi(vega.compute_model()['lyalya_qso'], exp['cross/fid/model'], mask, 'cross fid')
+    pars = _pars(exp, 'cross/')
+    np.testing.assert_allclose(vega.chi2_batch(pars), exp['cross/chi2'], rtol=CHI2_RTOL)
+    for i, w in enumerate(pars):
+        _assert_xi(vega.compute_model(w)['lyalya_qso'], exp[f'cross/walker{i}/model'], mask, f'cross walker {i}')
+    vega.close()
+    prob = options2_problem(tmp_path, 'auto')
+    vega = VegaInterface(None, problem=prob, max_batch=2)
+    assert vega.chi2() == pytest.approx(float(exp['auto/fid/chi2']), rel=CHI2_RTOL)
+    _assert_xi(vega.compute_model()['lyalya_lyalya'], exp['auto/fid/model'], prob.items['lyalya_lyalya'].model_mask, 'auto')
+    assert vega.chi2({'ap': 1.03, 'at': 0.96, 'uv_shotnoise_amp': 0.03}) == pytest.approx(float(exp['auto/walker/chi2']), rel=CHI2_RTOL)
+    vega.close()
+    prob = options2_problem(tmp_path, 'model_pk')
+    vega = VegaInterface(None, problem=prob, max_batch=2)
+    assert vega.model_pk
+    w = {'ap': 1.03, 'bias_eta_LYA': -0.21, 'beta_LYA': 1.5, 'bao_amp': 0.8, 'sigmaNL_par': 7.0}
+    for tag, pars in (('fid', None), ('walker', w)):
+        model = vega.compute_model(pars)
+        for name in prob.items:
+            ref = exp[f'model_pk/{tag}/{name}']
+            assert model[name].shape == ref.shape == (4, prob.k.size)
+            for ell in range(4):
+                scale = np.abs(ref[ell]).max()
+                assert np.abs(model[name][ell] - ref[ell]).max() <= 1e-10 * scale, (tag, name, ell)
+    vega.close()

@@ -194,3 +194,24 @@ def test_minimizer_reports_a_sentinel_gradient_as_a_failed_fit():
     res = m.minimize(n_fits=2, start=[[0.0, 0.0], [0.49999, 0.0]], prefit_bias=False)
     assert res.is_valid[0] and abs(res.values[0] - 0.3).max() < 1e-3
     assert not res.is_valid[1] and not np.isfinite(res.edm[1])
+
+
+def test_oracle_on_the_xi_stage_options_of_round_2(tmp_path):
+    """`rescale-coords-systematics`, `old_growth_func`, `fht_lowring = False` (reference correlation_func.py:470-475,
+    :681-684, :75-80, :405-444; pktoxi.py:42,53) against the unmodified reference."""
+    from conftest import options2_problem
+    from oracle import vega_cpu as oc
+    exp = np.load(GOLDEN / 'expected_options2.npz')
+    prob = options2_problem(tmp_path, 'cross')
+    pipe = prob.items['lyalya_qso'].core
+    assert pipe.xi.rescale_coords_systematics and pipe.xi.old_growth and not pipe.xi.fht_lowring
+    assert oc.chi2(prob) == pytest.approx(float(exp['cross/fid/chi2']), rel=1e-9)
+    mask = prob.items['lyalya_qso'].model_mask
+    _assert_xi_elementwise(oc.compute_model(prob)['lyalya_qso'], exp['cross/fid/model'], mask, 'cross fid')
+    pars = _pars(exp, 'cross/')
+    assert oc.chi2(prob, pars[0]) == pytest.approx(float(exp['cross/chi2'][0]), rel=1e-9)
+    prob = options2_problem(tmp_path, 'auto')
+    assert oc.chi2(prob) == pytest.approx(float(exp['auto/fid/chi2']), rel=1e-9)
+    _assert_xi_elementwise(oc.compute_model(prob)['lyalya_lyalya'], exp['auto/fid/model'],
+                           prob.items['lyalya_lyalya'].model_mask, 'auto fid')
+    assert oc.chi2(prob, {'ap': 1.03, 'at': 0.96, 'uv_shotnoise_amp': 0.03}) == pytest.approx(float(exp['auto/walker/chi2']), rel=1e-9)

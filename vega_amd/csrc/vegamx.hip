@@ -1229,7 +1229,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
                     e->pk_static.push_back(p);
                     // static coordinates as well (no rescaling, no delta_rp, no odd-multipole terms): the basis is
                     // evaluated on the bins once (k_poly_bins)
-                    if (d.scale_mode == VMX_SCALE_UNIT && d.drp_slot < 0 && !pd.odd_rel && !pd.odd_asy && !getenv("VMX_NO_STATIC_BINS")) {
+                    if (d.scale_mode == VMX_SCALE_UNIT && d.drp_slot < 0 && !pd.odd_rel && !pd.odd_asy && d.radiation != 2 &&
+                        d.uv_shotnoise != 2 && !getenv("VMX_NO_STATIC_BINS")) {
                         pd.poly_bins_off = e->poly_bins_total;
                         e->poly_bins_total += (int64_t)3 * vmx_pad(pd.n);
                     }
@@ -1393,6 +1394,12 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 }
 
 int vmx_model_size(vmx_engine* e) { return e ? e->model_size : -1; }
+
+int vmx_pipeline_column(vmx_engine* e, int32_t pipeline)
+{
+    REQUIRE(e && e->finalized && pipeline >= 0 && pipeline < (int)e->pipes.size(), "vmx_pipeline_column");
+    return e->pipes[pipeline].col >= 0 ? e->pipes[pipeline].col : -3 - e->n_active;     // (< -2: no column; the count is -3 - value)
+}
 
 // static spline-coefficient basis of the polynomial pipelines: C[ell][basis][i] = OP_ell . V_i[ell] (k_poly_basis), with the
 // product kernels of the chain; redone when the linear spectra change (vmx_set_linear_spectra)

@@ -2168,9 +2168,12 @@ __device__ __forceinline__ double xi_bin_value(const EngineDev& D, int p, int b,
     xi *= growth;
 
     if (radiation) {
-        // reference correlation_func.py:446-489 (unrescaled coordinates, shifted by delta_rp)
-        const double rp = rp0 + drp;
-        const double rs2 = fma(rp, rp, rt0 * rt0);
+        // reference correlation_func.py:446-489: unrescaled coordinates shifted by delta_rp, or - radiation == 2,
+        // `rescale-coords-systematics` - the rescaled ones, shifted by delta_rp once more (:470-472 as written)
+        const bool resc = d.radiation == 2;
+        const double rp = resc ? fma(s_ap, rp0 + drp, drp) : rp0 + drp;
+        const double rtr = resc ? s_at * rt0 : rt0;
+        const double rs2 = fma(rp, rp, rtr * rtr);
         const double irs = vmx_rsqrt(rs2);              // (r = 0 bins carry rs2 = drp^2 > 0 or are masked downstream)
         const double rs = rs2 * irs, ms = rp * irs;
         double xr = sc[S_RAD_S] * (irs * irs) * (1.0 - sc[S_RAD_A] * (1.0 - ms * ms));
@@ -2181,13 +2184,15 @@ __device__ __forceinline__ double xi_bin_value(const EngineDev& D, int p, int b,
         // reference correlation_func.py:649-686 on the unrescaled separation
         const double* t = D.theta + (size_t)b * D.n_params;
         const double amp = t[d.uvsn_slot[0]], lam = t[d.uvsn_slot[1]], bg = t[d.uvsn_slot[2]];
-        const double tau = r / lam;
+        // (uv_shotnoise == 2, `rescale-coords-systematics`: r = sqrt(r'^2 + mu'^2) as the reference writes it, :681-682)
+        const double rsn = d.uv_shotnoise == 2 ? sqrt(rr2 + rmu * rmu) : r;
+        const double tau = rsn / lam;
         double a;
         const double pos = (tau - D.sn_tau0) / D.sn_dtau;
         if (pos <= 0.0) a = D.sn_a[0];
         else if (pos >= (double)(D.sn_n - 1)) a = (pos == (double)(D.sn_n - 1)) ? D.sn_a[D.sn_n - 1] : 0.0;
         else { const int j = (int)pos; const double f = pos - (double)j; a = D.sn_a[j] + f * (D.sn_a[j + 1] - D.sn_a[j]); }
-        xi += bg * bg * amp * lam / r * a;
+        xi += bg * bg * amp * lam / rsn * a;
     }
     if (odd_terms) {
         // reference pktoxi.py:321-382 on the rescaled coordinates (correlation_func.py:491-551)

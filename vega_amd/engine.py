@@ -130,6 +130,7 @@ def load_library():
     lib.vmx_add_prior.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double]
     lib.vmx_finalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.vmx_model_size.argtypes = [C.c_void_p]
+    lib.vmx_pipeline_column.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_eval.argtypes = [C.c_void_p, dptr, C.c_int32, dptr, dptr, iptr]
     lib.vmx_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vmx_sync.argtypes = [C.c_void_p]
@@ -169,7 +170,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -396,12 +397,12 @@ class Lowering:
         d.scale_slot[0], d.scale_slot[1] = slots
         d.drp_slot = self.s(pipe.delta_rp_name)
         d.croom_slot[0], d.croom_slot[1] = self.s('croom_par0'), self.s('croom_par1')
-        d.radiation = int(xi.radiation)
+        # (2: `rescale-coords-systematics` - the term is evaluated on the rescaled coordinates, reference
+        # correlation_func.py:470-475, :681-684)
+        d.radiation = int(xi.radiation) * (2 if xi.rescale_coords_systematics else 1)
         for i, key in enumerate(('strength', 'asymmetry', 'lifetime', 'decrease')):
             d.rad_slot[i] = self.need('qso_rad_' + key) if xi.radiation else -1
-        if xi.radiation and xi.rescale_coords_systematics:
-            raise NotImplementedError('rescale-coords-systematics is not accelerated')
-        d.uv_shotnoise = int(xi.uv_shotnoise)
+        d.uv_shotnoise = int(xi.uv_shotnoise) * (2 if xi.rescale_coords_systematics else 1)
         for i in range(3):
             d.uvsn_slot[i] = -1
         if xi.uv_shotnoise:
@@ -489,6 +490,7 @@ class Engine:
         pid = self._check(self.lib.vmx_add_pipeline(
             self._h, C.byref(desc), n, _dp(_f64(pipe.r)), _dp(_f64(pipe.mu)), _dp(_f64(pipe.z)),
             _dp(_f64(pipe.rel_z_evol)), _dp(_f64(pipe.xi_growth))))
+        self.n_pipelines = pid + 1
         if getattr(pipe, 'rel_z_evol_1', None) is not None:
             # new-bias-evolution: each tracer of a cross-correlation evolves with its own redshift
             self._check(self.lib.vmx_pipeline_set_tracer_evolution(
@@ -525,8 +527,13 @@ class Engine:
         self.old_fftlog = old.pop()
         if self.old_fftlog:
             self._check(lib.vmx_set_spline_extrapolation(self._h, 1))
+        lowring = {p.xi.fht_lowring for it in prob.items.values() for p in [it.core] + [m.pipeline for m in it.metals]}
+        if len(lowring) != 1:
+            raise NotImplementedError('fht_lowring must be the same for every correlation')
+        lowring = lowring.pop()
         for i, ell in enumerate((0, 2, 4, 6)):
-            op, x0, h, n_knots = (fftlog_op.hamilton_xi_operator if self.old_fftlog else fftlog_op.xi_operator)(k, ell)
+            op, x0, h, n_knots = fftlog_op.hamilton_xi_operator(k, ell) if self.old_fftlog else \
+                fftlog_op.xi_operator(k, ell, lowring=lowring)
             op = _f64(op)
             self._check(lib.vmx_set_fftlog(self._h, i, _dp(op), op.shape[0], x0, h, n_knots))
 
@@ -778,6 +785,24 @@ class Engine:
         if n < 0:
             raise EngineError(self.lib.vmx_last_error().decode())
         return out[:n]
+
+    def pk_multipoles(self, B=1):
+        """P_ell(k) of the last evaluation (batch size B): dict pipeline id -> [B, 4, nk] for the pipelines that form
+        their multipoles per walker (the stage tap behind `model_pk`, reference model.py:106-107)."""
+        nk = self.prob.k.size
+        nkp = (nk + 31) // 32 * 32
+        out = {}
+        n_cols = None
+        for pid in range(self.n_pipelines):
+            col = self.lib.vmx_pipeline_column(self._h, pid)
+            if col < -2:
+                n_cols = -3 - col
+                continue
+            out[pid] = col
+        if n_cols is None:
+            n_cols = len(out)
+        pl = self.debug_read(0, 0, 4 * B * n_cols * nkp).reshape(4, B, n_cols, nkp)
+        return {pid: np.ascontiguousarray(pl[:, :, col, :nk].transpose(1, 0, 2)) for pid, col in out.items()}
 
     def metal_xi(self, item_name, pair_index):
         """Correlation of one metal pair in the last evaluation (walker 0): after its metal matrix, before the

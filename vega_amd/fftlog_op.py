@@ -25,16 +25,19 @@ def _mellin_u(ell, z):
     return np.exp(np.log(2.0) * (z - 1.5) + loggamma(0.5 * (ell + z)) - loggamma(0.5 * (3 + ell - z)))
 
 
-def fftlog_matrix(k, ell, q=1.5):
-    """(H, ln r): xi_ell(r_n) = sum_j H[n, j] P_ell(k_j) for mcfit.P2xi(k, l=ell, lowring=True)
-    called with extrap=False (zero padding)."""
+def fftlog_matrix(k, ell, q=1.5, lowring=True):
+    """(H, ln r): xi_ell(r_n) = sum_j H[n, j] P_ell(k_j) for mcfit.P2xi(k, l=ell, lowring=lowring)
+    called with extrap=False (zero padding).  ``lowring=False`` (`fht_lowring = False`, reference pktoxi.py:42,53):
+    x y = 1 and a real Nyquist term."""
     k = np.asarray(k, dtype=float)
     n = k.size
     delta = np.log(k[-1] / k[0]) / (n - 1)
     N = 2 ** int(np.ceil(np.log2(2 * n)))
-    lnxy = delta / np.pi * np.angle(_mellin_u(ell, q + 1j * np.pi / delta))
+    lnxy = delta / np.pi * np.angle(_mellin_u(ell, q + 1j * np.pi / delta)) if lowring else 0.0
     m = np.arange(N // 2 + 1)
     u = _mellin_u(ell, q + 2j * np.pi * m / (N * delta)) * np.exp(-2j * np.pi * lnxy * m / (N * delta))
+    if not lowring:
+        u[N // 2] = u[N // 2].real
 
     # g = hfft(rfft(f) u)/N uses the forward sign twice, so it is a circular CORRELATION of the padded
     # input with c = hfft(u)/N: g[i] = sum_t f[t] c[(i + t) mod N]  (hence the reversed output grid)
@@ -67,9 +70,9 @@ def notaknot_bspline_matrix(n):
     return np.linalg.solve(M, rhs)
 
 
-def xi_operator(k, ell):
+def xi_operator(k, ell, lowring=True):
     """(OP, x0, h, n_knots): B-spline coefficients of xi_ell(ln r) from P_ell(k)."""
-    H, ln_r = fftlog_matrix(k, ell)
+    H, ln_r = fftlog_matrix(k, ell, lowring=lowring)
     n = ln_r.size
     h = (ln_r[-1] - ln_r[0]) / (n - 1)
     if np.max(np.abs(np.diff(ln_r) - h)) > 1e-10 * h:

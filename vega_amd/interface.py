@@ -75,6 +75,8 @@ class VegaInterface:
                          'z_fiducial': self.problem.z_fid, 'Omega_m': self.problem.omega_m,
                          'Omega_de': self.problem.omega_de, 'growth_rate': self.problem.growth_rate}
         self._use_global_cov = self.problem.global_cov is not None
+        self.model_pk = bool(self.main_config is not None and 'control' in self.main_config
+                             and self.main_config['control'].getboolean('model_pk', False))
         self.monte_carlo = False
         self._mc_active = False
         self._engine_args = dict(max_batch=max_batch, device=device, extra_names=extra_names, kron_metals=kron_metals,
@@ -254,6 +256,17 @@ class VegaInterface:
         if status[0]:
             from .errors import VegaModelError
             raise VegaModelError(f'model evaluation failed (status {int(status[0])})')
+        if self.model_pk:
+            # `model_pk = True` ([control]; reference vega_interface.py:66, model.py:106-107, :186): the models are the
+            # multipoles P_ell(k) of the core power spectrum, bao_amp * peak + smooth, [n_ell, nk] per correlation
+            pl = self.engine.pk_multipoles(1)
+            bao = self._blinded(self._theta(params))[self.engine.low.slot['bao_amp']]
+            out = {}
+            for name, item in self.problem.items.items():
+                n_ell = item.core.xi.ell_max // 2 + 1
+                peak, smooth = pl[self.engine.pipe_index[(name, 'peak')]][0], pl[self.engine.pipe_index[(name, 'smooth')]][0]
+                out[name] = (smooth if direct_pk is not None else bao * peak + smooth)[:n_ell].copy()
+            return out
         out = {name: model[0, sl].copy() for name, sl in self.engine.model_slices.items()}
         if marg_coeff is not None:
             for name, item in self.problem.items.items():

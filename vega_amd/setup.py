@@ -158,6 +158,23 @@ def growth_squared(z, z_fid, om, ode):
     return (g(z) / g(z_fid))**2
 
 
+@lru_cache(maxsize=32)
+def _growth_interp_old(om, ode):
+    z_grid = 5. * np.arange(100, dtype=float) / 99
+    growth = np.zeros(z_grid.size)
+    for i, z in enumerate(z_grid):
+        integral = quad(lambda a: 1. / (a * _hubble(1 / a - 1, om, ode))**3, 0, 1 / (1 + z))[0]
+        growth[i] = 2.5 * om * _hubble(z, om, ode) * integral
+    return interp1d(z_grid, growth)
+
+
+def growth_squared_old(z, z_fid, om, ode):
+    """`old_growth_func = True` (reference vega/correlation_func.py:405-444, deprecated there): the growth factor
+    tabulated at 100 redshifts up to 5 and interpolated linearly."""
+    g = _growth_interp_old(om, ode)
+    return (g(z) / g(z_fid))**2
+
+
 # --------------------------------------------------------------------------------------
 # option records
 # --------------------------------------------------------------------------------------
@@ -203,6 +220,8 @@ class XiOptions:
     asymmetry: bool = False
     uv_shotnoise: bool = False
     rescale_coords_systematics: bool = False
+    fht_lowring: bool = True         # [model] fht_lowring (reference pktoxi.py:42,53)
+    old_growth: bool = False         # [model] old_growth_func (reference correlation_func.py:75-80)
 
 
 @dataclass
@@ -492,8 +511,7 @@ def _xi_options(model_section, xi_section, tracers):
     opts.old_fftlog = model_section.getboolean('old_fftlog', False)
     if model_section.getboolean('fht_extrap', False):
         raise NotImplementedError('fht_extrap is not supported')
-    if not model_section.getboolean('fht_lowring', True):
-        raise NotImplementedError('fht_lowring = False is not supported')
+    opts.fht_lowring = model_section.getboolean('fht_lowring', True)
     opts.single_multipole = xi_section.getint('single_multipole', -1)
     opts.rescale_coords_systematics = xi_section.getboolean('rescale-coords-systematics', False)
     for tr in tracers:
@@ -508,11 +526,8 @@ def _xi_options(model_section, xi_section, tracers):
     opts.asymmetry = xi_section.getboolean('standard asymmetry', False) \
         if 'standard asymmetry' in xi_section else False
     opts.uv_shotnoise = xi_section.getboolean('UVB-shotnoise', False) if 'UVB-shotnoise' in xi_section else False
-    if opts.uv_shotnoise and opts.rescale_coords_systematics:
-        raise NotImplementedError('UVB-shotnoise with rescale-coords-systematics is not supported')
     opts.new_bias_evol = xi_section.getboolean('new-bias-evolution', False)
-    if xi_section.getboolean('old_growth_func', False):
-        raise NotImplementedError('old_growth_func is not supported')
+    opts.old_growth = xi_section.getboolean('old_growth_func', False)
     return opts
 
 
@@ -549,7 +564,7 @@ def _make_pipeline(tr1, tr2, dataset, pk_opts, xi_opts, grid, problem_consts, me
     pipe = Pipeline(
         tracer1=tr1, tracer2=tr2, dataset=dataset, pk=pk_opts, xi=xi_opts,
         metal_corr=metal_corr, r=grid.r, mu=grid.mu, z=z,
-        xi_growth=np.asarray(growth_squared(z, z_fid, om, ode), dtype=float),
+        xi_growth=np.asarray((growth_squared_old if xi_opts.old_growth else growth_squared)(z, z_fid, om, ode), dtype=float),
         rel_z_evol=(1. + z) / (1 + z_eff), delta_rp_name=delta_rp_name)
     # new-bias-evolution (reference vega/correlation_func.py:238-274): in a cross-correlation the two tracers sit
     # at z -/+ rp / (2 D_H(z)); auto-correlations and files without a cosmology keep the mean redshift
@@ -1036,8 +1051,6 @@ def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
     control = main['control'] if 'control' in main else {}
     marginalize_in_fit = False
     if 'control' in main:
-        if main['control'].getboolean('model_pk', False):
-            raise NotImplementedError('model_pk is not supported')
         marginalize_in_fit = main['control'].getboolean('marginalize-in-fit', False)
 
     items = {}
