@@ -181,6 +181,10 @@ struct vmx_engine {
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
     int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
+    // work lists of the quadratic-form launches per batch size: entries, their count, per-row-tile slab counts
+    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg; int n_blocks = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; };
+    std::map<int, QuadList*> quad_lists;
+    bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
     bool gemm_44 = true;             // products on the four-block 4x4x4 fp64 MFMA (VMX_GEMM_16: the 16x16x4 kernel everywhere)
     bool pk_small_attr = false;      // the single-walker P(k) shape asked for its > 64 KB of LDS
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
@@ -224,6 +228,7 @@ struct vmx_engine {
         for (auto* m : metals) delete m;
         for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+        for (auto& q : quad_lists) delete q.second;
         if (pin_theta) (void)hipHostFree(pin_theta);
         if (pin_chi2) (void)hipHostFree(pin_chi2);
         if (pin_status) (void)hipHostFree(pin_status);
@@ -1052,6 +1057,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_GEMM_16")) e->gemm_44 = false;
     if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
     if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
+    if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
     if (getenv("VMX_GRAPH_B1")) e->graph_b1 = true;
 
     // every slot must index a theta column and the combinations the kernels rely on must be present
@@ -1401,6 +1407,75 @@ int vmx_pipeline_column(vmx_engine* e, int32_t pipeline)
     return e->pipes[pipeline].col >= 0 ? e->pipes[pipeline].col : -3 - e->n_active;     // (< -2: no column; the count is -3 - value)
 }
 
+// Work list of the quadratic-form launch for B walkers: every 64 x 64 tile of every item's half-triangle product is cut
+// into K segments of about L stages (a stage = 32 columns); L is chosen by simulating the launch as list scheduling on the
+// 256 CUs (a block costs its stages + a fixed start / end), longest blocks first.  The walker tiles of one (row tile,
+// segment) share their matrix tile: they get block indices 8 apart - the same XCD, back to back.
+static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
+{
+    auto found = e->quad_lists.find(B);
+    if (found != e->quad_lists.end()) return found->second;
+    constexpr int BM = GEMM_BM, BK = GEMM_BK, CUS = 256;
+    constexpr double OVERHEAD = 4.0;
+    const int tn = (B + GEMM_BN - 1) / GEMM_BN;
+    struct Tile { int prob, mt, stages; };
+    std::vector<Tile> tiles;
+    for (size_t q = 0; q < e->items.size(); ++q) {
+        const ItemDev& d = e->items[q]->dev;
+        const int tm = (d.nq + BM - 1) / BM, kmax_all = d.nq_pad / BK;
+        for (int mt = 0; mt < tm; ++mt) tiles.push_back({(int)q, mt, std::min(((mt + 1) * BM + BK - 1) / BK, kmax_all)});
+    }
+    const int max_slabs = std::max(1, std::min(8, e->slab_rows / std::max(B, 1)));
+    int best_L = 1 << 20;
+    double best_cost = 1e300;
+    for (int L = 16; L <= 192; L += 4) {
+        std::vector<double> costs;
+        for (auto& t : tiles) {
+            const int nseg = std::min(max_slabs, (t.stages + L - 1) / L);
+            const int len = (t.stages + nseg - 1) / nseg;
+            for (int s = 0; s < nseg * tn; ++s) costs.push_back(len + OVERHEAD);
+        }
+        std::sort(costs.begin(), costs.end(), std::greater<double>());
+        std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+        for (int c = 0; c < CUS; ++c) free_at.push(0.0);
+        double makespan = 0.0;
+        for (double c : costs) { const double t = free_at.top() + c; free_at.pop(); free_at.push(t); makespan = std::max(makespan, t); }
+        if (makespan < best_cost) { best_cost = makespan; best_L = L; }
+    }
+    auto* ql = new vmx_engine::QuadList();
+    struct Group { int prob, mt, seg, kbeg, kend; };
+    std::vector<Group> groups;
+    std::vector<int32_t> nseg_all;
+    for (size_t q = 0, ti = 0; q < e->items.size(); ++q) {
+        const ItemDev& d = e->items[q]->dev;
+        const int tm = (d.nq + BM - 1) / BM;
+        ql->nseg_off[q] = (int32_t)nseg_all.size();
+        for (int mt = 0; mt < tm; ++mt, ++ti) {
+            const int stages = tiles[ti].stages;
+            const int nseg = std::min(max_slabs, (stages + best_L - 1) / best_L);
+            const int len = (stages + nseg - 1) / nseg;
+            nseg_all.push_back(nseg);
+            ql->max_seg = std::max(ql->max_seg, nseg);
+            for (int s = 0; s < nseg; ++s) {
+                const int kb = s * len * BK, ke = std::min((s + 1) * len, stages) * BK;
+                groups.push_back({(int)q, mt, s, kb, std::max(kb, ke)});
+            }
+        }
+    }
+    std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.kend - a.kbeg > b.kend - b.kbeg; });
+    const int rows = ((int)groups.size() + 7) / 8;
+    std::vector<GemmWork> work((size_t)rows * tn * 8, GemmWork{-1, 0, 0, 0, 0, 0});
+    for (size_t j = 0; j < groups.size(); ++j) {
+        const int xcd = (int)(j % 8), r = (int)(j / 8);
+        for (int nt = 0; nt < tn; ++nt)
+            work[((size_t)r * tn + nt) * 8 + xcd] = GemmWork{groups[j].prob, groups[j].mt, nt, groups[j].kbeg, groups[j].kend, groups[j].seg};
+    }
+    ql->n_blocks = (int)work.size();
+    if (ql->work.upload(work.data(), work.size()) || ql->nseg.upload(nseg_all.data(), nseg_all.size())) { delete ql; return nullptr; }
+    e->quad_lists[B] = ql;
+    return ql;
+}
+
 // static spline-coefficient basis of the polynomial pipelines: C[ell][basis][i] = OP_ell . V_i[ell] (k_poly_basis), with the
 // product kernels of the chain; redone when the linear spectra change (vmx_set_linear_spectra)
 static int poly_basis_build(vmx_engine* e)
@@ -1581,7 +1656,28 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         }
         SlabInfo qs{};
         for (size_t q = 0; q < e->items.size(); ++q) qs.z[q] = 1;
-        if (B > 8 && e->items.size() <= VMX_MAX_GROUP) {
+        if (B > 8 && e->items.size() <= VMX_MAX_GROUP && e->quad_list_mode && e->quad_use_44 && e->gemm_44) {
+            // balanced work list: every tile cut into K segments of about equal length
+            vmx_engine::QuadList* ql = quad_work_list(e, B);
+            if (!ql) return -2;
+            GemmGroup G{};
+            for (size_t q = 0; q < e->items.size(); ++q) {
+                ItemHost* it = e->items[q];
+                const ItemDev& d = it->dev;
+                GemmArgs g{};
+                g.A = it->q_mat.p; g.lda = d.nq_pad; g.X = it->q_x.p; g.ldx = d.nq_pad; g.D = it->q_z.p; g.ldd = d.nq_pad;
+                g.M = d.nq; g.N = B; g.K = d.nq_pad; g.tri = 1; g.nsplit = 1; g.klen = d.nq_pad;
+                g.d_slab = (int64_t)B * d.nq_pad;
+                g.tm = (d.nq + GEMM_BM - 1) / GEMM_BM; g.tn = (B + GEMM_BN - 1) / GEMM_BN;
+                G.p[G.n++] = g;
+                qs.z[q] = 0;
+                qs.qseg_off[q] = ql->nseg_off[q];
+            }
+            G.work = ql->work.p;
+            qs.qseg = ql->nseg.p;
+            ScopedTimer t(e, KC_QUAD);
+            hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), dim3(ql->n_blocks, 1), dim3(GEMM44_THREADS), 0, e->cur, G);
+        } else if (B > 8 && e->items.size() <= VMX_MAX_GROUP) {
             GemmGroup G{};
             int tiles_total = 0, per_xcd_total = 0;
             for (auto* it : e->items) tiles_total += gemm_tiles(it->dev.nq, B, true);
@@ -1920,7 +2016,7 @@ static int quad_build(vmx_engine* e)
 }
 
 // chi2-only evaluations take the quadratic form when it applies; refreshes its tensors when data or covariances changed
-static int quad_ready(vmx_engine* e, bool* use)
+static int quad_ready(vmx_engine* e, bool* use, int B)
 {
     *use = false;
     if (!e->quad_eligible || e->theta_ref.empty() || e->direct) return 0;
@@ -1928,6 +2024,8 @@ static int quad_ready(vmx_engine* e, bool* use)
         if (quad_build(e)) return -2;
         if (!e->quad_eligible) return 0;
     }
+    // (device allocations must not happen inside a stream capture: the work list of this batch size is built here)
+    if (B > 8 && e->items.size() <= VMX_MAX_GROUP && e->quad_list_mode && e->quad_use_44 && e->gemm_44 && !quad_work_list(e, B)) return -2;
     *use = true;
     return 0;
 }
@@ -1939,7 +2037,7 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
     bool quad = false;
-    if (!d_model && quad_ready(e, &quad)) return -2;
+    if (!d_model && quad_ready(e, &quad, B)) return -2;
     if (!e->blind_scale.empty()) {
         // parameter-level blinding: the walkers are transformed in the engine's own copy
         HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
@@ -2060,7 +2158,7 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     const bool zero_copy = B <= 8 && B * ((int)e->pipes.size() + 1) <= 1024 && (size_t)B * e->n_params * sizeof(double) <= 48 * 1024 &&
                            e->dpin_theta && e->dpin_chi2 && e->dpin_status;
     bool quad = false;
-    if (!model && quad_ready(e, &quad)) return -2;
+    if (!model && quad_ready(e, &quad, B)) return -2;
     if (e->blind_scale.empty()) std::memcpy(e->pin_theta, theta, (size_t)B * e->n_params * sizeof(double));
     else        // parameter-level blinding, applied while staging (same expression as k_theta_affine)
         for (int b = 0; b < B; ++b)

@@ -191,7 +191,9 @@ struct EngineDev {
     volatile int64_t* done_host; int64_t done_seq;
 };
 
-struct SlabInfo { int32_t z[16]; int32_t g; };   // split-K slab counts of a product per item (+ the global one)
+// split-K slab counts of a product per item (+ the global one); z[q] = 0: a work-list launch, whose row tile t of item q
+// has qseg[qseg_off[q] + t] slabs
+struct SlabInfo { int32_t z[16]; int32_t g; const int32_t* qseg; int32_t qseg_off[16]; };
 #define CHI2_THREADS 1024                        // k_chi2 / k_chi2_quad: one block per walker
 
 // ------------------------------------------------------------------------------------------------
@@ -1340,9 +1342,10 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
         const ItemDev& it = D.items[q];
         const int row = (mock >= 0 && it.mock_pool) ? 1 + mock : 0;
         const double* g = it.q_lin + (size_t)row * it.nq_pad;
-        const int ns = slabs.z[q];
+        const int ns_all = slabs.z[q];
         for (int i = threadIdx.x; i < it.nq; i += CHI2_THREADS) {
             const double x = it.q_x[(size_t)b * it.nq_pad + i];
+            const int ns = ns_all > 0 ? ns_all : slabs.qseg[slabs.qseg_off[q] + (i >> 6)];     // (0: work-list launch)
             double zs[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) zs[s] = it.q_z[((size_t)(s < ns ? s : 0) * B + b) * it.nq_pad + i];
@@ -1458,6 +1461,13 @@ struct GemmArgs {
     int tri;                // A is lower triangular (zeros above the diagonal): row tile mt needs k < (mt + 1) BM only
 };
 
+// Work list of a grouped launch (k_gemm_nt44): one entry per block - a K segment of one 64 x 64 tile of one problem,
+// written to slab `slab` of that problem's output.  A triangular product has row tiles of very different K lengths;
+// cutting every tile into segments of about equal length (host: quad_work_list) balances the launch where whole-problem
+// K splits cannot.  Blocks take entry blockIdx.x; the host orders the entries so that the segments of a row tile meet on
+// one XCD (block -> XCD is round-robin on the index).
+struct GemmWork { int32_t prob, mt, nt, kbeg, kend, slab; };
+
 // LDS reads as explicit ds_read_b64 (2 LDS cycles per wave, banks (a/4) mod 64): left to the compiler, pairs of them
 // are merged into ds_read2_b64, which costs twice the cycles and banks modulo 32.  The compiler does not count these
 // reads in its own s_waitcnt bookkeeping, so lds_wait() drains the counter before the values are used (its waits for its
@@ -1504,6 +1514,7 @@ __device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
 #define VMX_MAX_GROUP 8
 struct GemmGroup {
     GemmArgs p[VMX_MAX_GROUP]; int32_t n; int32_t seq_end[VMX_MAX_GROUP];
+    const GemmWork* work;       // non-null: list mode (gridDim.x entries)
 };
 
 // Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
@@ -1682,17 +1693,23 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     __shared__ double sA[2][BM * BK];
     __shared__ double sX[2][BN * BK];
 
+    const bool list = G.work != nullptr;
+    GemmWork wk{};
+    if (list) { wk = G.work[blockIdx.x]; if (wk.prob < 0) return; }        // (padding entries of the list)
     const int xcd = blockIdx.x & 7;
     int seq = blockIdx.x >> 3;
     int pi = 0;
-    while (pi < G.n - 1 && seq >= G.seq_end[pi]) ++pi;
-    if (pi > 0) seq -= G.seq_end[pi - 1];
+    if (list) pi = wk.prob;
+    else {
+        while (pi < G.n - 1 && seq >= G.seq_end[pi]) ++pi;
+        if (pi > 0) seq -= G.seq_end[pi - 1];
+    }
     const GemmArgs& g = G.p[pi];
-    const int split = xcd % g.nsplit, group = xcd / g.nsplit, ngroups = 8 / g.nsplit;
+    const int split = list ? wk.slab : xcd % g.nsplit, group = xcd / g.nsplit, ngroups = 8 / g.nsplit;
     const int tm_eff = g.tri ? (g.tm + 1) / 2 : g.tm;
-    const int mt0 = (seq / g.tn) * ngroups + group, nt = seq % g.tn;
-    if (mt0 >= tm_eff) return;
-    const int npass = (g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
+    const int mt0 = list ? wk.mt : (seq / g.tn) * ngroups + group, nt = list ? wk.nt : seq % g.tn;
+    if (!list && mt0 >= tm_eff) return;
+    const int npass = (!list && g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
     const int batch = blockIdx.y;
     const char* A = (const char*)(g.A + batch * g.a_batch);
     const char* X = (const char*)(g.X + batch * g.x_batch);
@@ -1717,7 +1734,8 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     auto setup = [&](int pass) {
         const int mt = pass == 0 ? mt0 : g.tm - 1 - mt0;
         m0 = mt * BM;
-        if (g.tri) {
+        if (list) { kbeg = wk.kbeg; kend = wk.kend; }
+        else if (g.tri) {
             int kmax = ((mt + 1) * BM + BK - 1) / BK * BK; if (kmax > g.K) kmax = g.K;
             const int klen = ((kmax + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;
             kbeg = split * klen; kend = kbeg + klen; if (kend > kmax) kend = kmax;
