@@ -132,6 +132,9 @@ struct vmx_engine {
     bool finalized = false;
 
     int nk = 0, nkp = 0, n_mu = 0;
+    int n_rows = 0, n_extra = 0, mu_lo = 0, mu_hi = 0;     // node rule of the mu sums (vmx_set_mu_quadrature)
+    DevBuf<double> node_w;
+    double k_node_max = 0.0; bool mu_nodes_on = true;
     DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom, fv_x, fv_f, xtab;
     std::vector<int32_t> const_slots;
     DevBuf<int32_t> d_const_slots, d_xtab_pipe, xtab_dirty;
@@ -576,7 +579,59 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
 
     // mu grid: midpoint rule on [0, 1] (power_spectrum.py:76-77); Legendre weights
     // L_ell(mu) (2 ell + 1) / n_mu (pktoxi.py:37,55,138)
-    std::vector<double> mu(n_mu), sq(n_mu), lnm(n_mu), wl(4 * (size_t)n_mu);
+    // Node rule of the mu sums.  The reference sums P(k,mu) L_ell(mu) over n_mu midpoints (power_spectrum.py:76-77,
+    // pktoxi.py:138).  For an integrand f that is smooth on [a, b] = [mu_lo, n_mu - mu_hi] / n_mu the midpoint sum over
+    // that range is, by the Euler-Maclaurin formula (D = d/dmu, h = 1 / n_mu),
+    //     sum_j f(mu_j) = (1/h) int_a^b f - (h/24) [Df(b) - Df(a)] + (7 h^3 / 5760) [D^3 f(b) - D^3 f(a)] - O(h^5 D^5 f),
+    // so the engine keeps the first mu_lo and the last mu_hi midpoints (where sharp features of the model sit: the
+    // Gaussian smoothing / non-linear broadening, the HCD exponential and mu^bv of the Arinyo term at 0; a smoothing that
+    // is stronger across than along the line of sight at 1) and replaces the middle by two 32-point Gauss-Legendre
+    // panels plus one-sided finite-difference stencils for the two derivative terms: 84 extra nodes with fixed weights.
+    // Checked against the reference's own sums over the parameter ranges of the tests: <= 1.2e-13 of the largest
+    // k^3 P_ell (tests/test_mu_quadrature.py); used for wavenumbers up to k_node_max (smooth enough for the bin size),
+    // the plain midpoint loop above it and for the rarely used model options that are not smooth in mu.
+    std::vector<double> node_mu, node_w;
+    if (n_mu == 1000) {
+        const int lo = 96, hi = 96, panels = 2, ngl = 32;
+        const double h = 1.0 / n_mu, a = lo * h, b = (n_mu - hi) * h, eps1 = 1e-3, eps3 = 2e-3;
+        std::vector<double> gx(ngl), gw(ngl);
+        for (int i = 0; i < ngl; ++i) {            // Gauss-Legendre nodes by Newton's iteration on P_ngl
+            double x = std::cos(M_PI * (i + 0.75) / (ngl + 0.5)), dp = 1.0;
+            for (int it = 0; it < 100; ++it) {
+                double p0 = 1.0, p1 = x;
+                for (int n = 2; n <= ngl; ++n) { const double p2 = ((2 * n - 1) * x * p1 - (n - 1) * p0) / n; p0 = p1; p1 = p2; }
+                dp = ngl * (x * p1 - p0) / (x * x - 1.0);
+                const double dx = p1 / dp;
+                x -= dx;
+                if (std::fabs(dx) < 1e-16) break;
+            }
+            gx[i] = x; gw[i] = 2.0 / ((1.0 - x * x) * dp * dp);
+        }
+        for (int pnl = 0; pnl < panels; ++pnl) {
+            const double pa = a + (b - a) * pnl / panels, pb = a + (b - a) * (pnl + 1) / panels;
+            for (int i = 0; i < ngl; ++i) { node_mu.push_back(0.5 * (pb - pa) * gx[i] + 0.5 * (pa + pb)); node_w.push_back(0.5 * (pb - pa) * gw[i] / h); }
+        }
+        const double c1[5] = {-25.0 / 12, 48.0 / 12, -36.0 / 12, 16.0 / 12, -3.0 / 12};       // Df(x)    ~ sum c1_i f(x + i e) / e
+        const double c3[5] = {-5.0 / 2, 18.0 / 2, -24.0 / 2, 14.0 / 2, -3.0 / 2};              // D^3 f(x) ~ sum c3_i f(x + i e) / e^3
+        const double t1 = h / 24.0, t3 = 7.0 * h * h * h / 5760.0;
+        for (int i = 0; i < 5; ++i) {
+            // backward stencils at b (odd derivatives: - sum c_i f(b - i e) / e^n), forward ones at a
+            node_mu.push_back(b - i * eps1); node_w.push_back(-t1 * (-c1[i] / eps1));
+            node_mu.push_back(a + i * eps1); node_w.push_back(+t1 * (c1[i] / eps1));
+            node_mu.push_back(b - i * eps3); node_w.push_back(+t3 * (-c3[i] / (eps3 * eps3 * eps3)));
+            node_mu.push_back(a + i * eps3); node_w.push_back(-t3 * (c3[i] / (eps3 * eps3 * eps3)));
+        }
+        e->mu_lo = lo; e->mu_hi = hi;
+    }
+    e->n_extra = (int)node_mu.size();
+    e->n_rows = n_mu + e->n_extra;
+    if (e->node_w.upload(node_w.data(), node_w.size())) return -2;
+    const int n_rows = e->n_rows;
+    std::vector<double> mu(n_rows), sq(n_rows), lnm(n_rows), wl(4 * (size_t)n_mu);
+    for (int j = n_mu; j < n_rows; ++j) {
+        const double m = node_mu[j - n_mu];
+        mu[j] = m; sq[j] = std::sqrt(std::max(1.0 - m * m, 0.0)); lnm[j] = std::log(m);
+    }
     for (int j = 0; j < n_mu; ++j) {
         const double m = (j + 0.5) / n_mu, m2 = m * m;
         mu[j] = m; sq[j] = std::sqrt(1.0 - m2); lnm[j] = std::log(m);
@@ -587,7 +642,7 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
         wl[3 * (size_t)n_mu + j] = dmu * (0.0625 * (((231.0 * m2 - 315.0) * m2 + 105.0) * m2 - 5.0)) * 13.0;
     }
     e->h_mu = mu;
-    if (e->mu.upload(mu.data(), n_mu) || e->sq1mmu2.upload(sq.data(), n_mu) || e->lnmu.upload(lnm.data(), n_mu) || e->wl.upload(wl.data(), wl.size())) return -2;
+    if (e->mu.upload(mu.data(), n_rows) || e->sq1mmu2.upload(sq.data(), n_rows) || e->lnmu.upload(lnm.data(), n_rows) || e->wl.upload(wl.data(), wl.size())) return -2;
     return 0;
 }
 
@@ -1121,13 +1176,13 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     }
 
     // G(k) tables
-    const size_t gk_stride = (size_t)e->n_mu * e->nkp;
+    const size_t gk_stride = (size_t)e->n_rows * e->nkp;
     if (!e->gk_tables.empty()) {
         if (e->gk.alloc(gk_stride * e->gk_tables.size(), true)) return -2;
         for (size_t t = 0; t < e->gk_tables.size(); ++t) {
-            dim3 grid((e->nkp + 255) / 256, e->n_mu), block(256);
+            dim3 grid((e->nkp + 255) / 256, e->n_rows), block(256);
             hipLaunchKernelGGL(k_gk_table, grid, block, 0, e->stream, e->gk.p + t * gk_stride, e->k.p, e->mu.p,
-                               e->nk, e->nkp, e->n_mu, e->gk_tables[t].rp, e->gk_tables[t].rt, e->gk_tables[t].mock_rp, e->gk_tables[t].mock_rt);
+                               e->nk, e->nkp, e->n_rows, e->gk_tables[t].rp, e->gk_tables[t].rt, e->gk_tables[t].mock_rp, e->gk_tables[t].mock_rt);
         }
         HIP_OK(hipGetLastError());
     }
@@ -1208,7 +1263,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             }
         }
         // (+ 4 x 32 rows: the mu loop requests its table rows four steps ahead without checking for the end)
-        if (e->n_xtab > 0 && e->xtab.alloc(((size_t)e->n_xtab * e->n_mu + 128) * e->nkp, true)) return -2;
+        if (e->n_xtab > 0 && e->xtab.alloc(((size_t)e->n_xtab * e->n_rows + 128) * e->nkp, true)) return -2;
         {
             std::vector<int32_t> xp((size_t)e->n_xtab + 1, -1);
             for (auto& g : e->pk_groups) if (g.xtab >= 0) xp[g.xtab] = g.pipe;
@@ -1331,6 +1386,16 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     EngineDev& D = e->dev;
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
+    D.n_rows = e->n_rows; D.n_extra = e->n_extra; D.mu_lo = e->mu_lo; D.mu_hi = e->mu_hi; D.node_w = e->node_w.p;
+    {
+        // the node rule needs the integrand smooth on the scale of its panels: the binning sincs oscillate with k x bin
+        // size, so wavenumbers beyond 24 / (largest bin size) [6 h/Mpc for 4 Mpc/h bins] keep the midpoint loop
+        double size = 4.0;
+        for (auto& g : e->gk_tables) size = std::max(std::max(size, g.rp), std::max(g.rt, std::max(g.mock_rp, g.mock_rt)));
+        e->k_node_max = 24.0 / size;
+        if (getenv("VMX_EXACT_MU") || e->n_extra == 0) e->mu_nodes_on = false;
+        D.k_node_max = e->mu_nodes_on ? e->k_node_max : 0.0;
+    }
     D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p; D.lnmu = e->lnmu.p;
     D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.xtab = e->xtab.p; D.const_slots = e->d_const_slots.p; D.n_const_slots = 0; D.xtab_pipe = e->d_xtab_pipe.p; D.n_xtab = e->n_xtab; D.xtab_key = e->xtab_key.p; D.xtab_dirty = e->xtab_dirty.p; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp; D.extrapolate = e->extrapolate ? 1 : 0;
@@ -1567,7 +1632,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         bool need_mubv = false;
         for (auto& g : e->pk_groups)
             if (e->pipes[g.pipe].d.nl_model == VMX_NL_ARINYO && !(tab_mode && g.xtab >= 0)) need_mubv = true;
-        size_t shmem = ((need_mubv ? (size_t)e->n_mu : 0) + 2048) * sizeof(double);
+        size_t shmem = ((need_mubv ? (size_t)e->n_rows : 0) + 2048) * sizeof(double);
         // + the (mu^2, mu^4) table of the tabulated and shared-W mu loops (the large-batch shapes; 40 KB per block at most,
         // four blocks per CU)
         bool want_mu_tab = false;
@@ -1577,7 +1642,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
         if (want_mu_tab) shmem += (size_t)2 * e->n_mu * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
         if (tab_mode)
-            hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, e->n_mu, e->n_xtab), dim3(256), 0, e->stream, D);
+            hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, e->n_rows, e->n_xtab), dim3(256), 0, e->stream, D);
         if (!e->pk_poly.empty())
             hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
         const int tm = tab_mode ? 1 : 0;
@@ -1599,7 +1664,7 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
             else if ((int64_t)B * n_groups >= 4) VMX_LAUNCH_PK(16, 16);
             else {
                 // + the block's slice of the G table, staged in LDS ([n_mu][8])
-                shmem = ((size_t)e->n_mu + 2048 + (size_t)8 * e->n_mu) * sizeof(double);
+                shmem = ((size_t)e->n_rows + 2048 + (size_t)8 * e->n_rows) * sizeof(double);
                 mu_tab_off = -1;
                 if (!e->pk_small_attr) {
                     HIP_OK(hipFuncSetAttribute((const void*)k_pk_multipoles<8, 32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -2120,6 +2185,19 @@ int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B)
     HIP_OK(hipMemcpy2D(out, (size_t)it->n_templates * sizeof(double), it->marg_out.p, (size_t)ldo * sizeof(double),
                        (size_t)it->n_templates * sizeof(double), B, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule)
+{
+    REQUIRE(e && e->finalized, "vmx_set_mu_quadrature (after vmx_finalize)");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    e->mu_nodes_on = node_rule != 0 && e->n_extra > 0;
+    e->dev.k_node_max = e->mu_nodes_on ? e->k_node_max : 0.0;
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);      // (captured graphs hold the previous setting)
+    e->graphs.clear();
+    e->quad_mat_dirty = true;       // the quadratic form's reference point is re-evaluated with the new rule
+    return e->mu_nodes_on ? 1 : 0;
 }
 
 int vmx_set_quadratic_form(vmx_engine* e, const double* theta_ref)

@@ -117,6 +117,12 @@ struct ItemDev {
 struct EngineDev {
     // template
     int32_t nk, nkp, n_mu, n_ell;
+    // mu-quadrature nodes appended to every mu-indexed table (mu, lnmu, sq1mmu2, gk, xtab): rows [n_mu, n_rows).  With
+    // weights node_w they reproduce the n_mu-point midpoint sums of the reference (power_spectrum.py:76-77, pktoxi.py:138)
+    // from the first mu_lo and the last mu_hi midpoints plus n_extra nodes - see vmx_set_mu_quadrature in vegamx.h
+    int32_t n_rows, n_extra, mu_lo, mu_hi;
+    const double* node_w;       // [n_extra]
+    double k_node_max;          // k tiles up to this wavenumber use the node rule (0: the midpoint sums everywhere)
     const double* k;            // [nkp]
     const double* pklin;        // [3][nkp]
     const double* delta2;       // [nkp]
@@ -442,14 +448,15 @@ __global__ void k_gk_table(double* out, const double* k, const double* mu, int n
     if (i < nk) {
         const double kk = k[i], m = mu[j];
         const double kpar = kk * m;
-        const double ktr = kk * sqrt(1.0 - m * m);
+        const double ktr = kk * sqrt(fmax(1.0 - m * m, 0.0));
         g = 1.0;
-        if (bs_rp != 0.0) { const double x = kpar * bs_rp / 2.0; g = g * (sin(x) / x); }
-        if (bs_rt != 0.0) { const double x = ktr * bs_rt / 2.0; g = g * (sin(x) / x); }
+        // (a quadrature node sits at mu = 1, where k_trans = 0: sinc(0) = 1; the midpoint grid never gets there)
+        if (bs_rp != 0.0) { const double x = kpar * bs_rp / 2.0; g = g * (x != 0.0 ? sin(x) / x : 1.0); }
+        if (bs_rt != 0.0) { const double x = ktr * bs_rt / 2.0; g = g * (x != 0.0 ? sin(x) / x : 1.0); }
         // mock binning: a second factor of the same form (power_spectrum.py:143-160)
         double gm = 1.0;
-        if (mock_rp != 0.0) { const double x = kpar * mock_rp / 2.0; gm = gm * (sin(x) / x); }
-        if (mock_rt != 0.0) { const double x = ktr * mock_rt / 2.0; gm = gm * (sin(x) / x); }
+        if (mock_rp != 0.0) { const double x = kpar * mock_rp / 2.0; gm = gm * (x != 0.0 ? sin(x) / x : 1.0); }
+        if (mock_rt != 0.0) { const double x = ktr * mock_rt / 2.0; gm = gm * (x != 0.0 ? sin(x) / x : 1.0); }
         g *= gm;
     }
     out[(size_t)j * nkp + i] = g;
@@ -540,8 +547,9 @@ struct PkThread {
     // per-thread (one wavenumber) constants of the mu loop
     double k, c0_1, c1_1, c0_2, c1_2, hb, hbb, L0, e0, e1, e2, vd1, vd2, ea, eb, mc_kvel;
     double p0, p1, pq, Fq;
-    const double* gk;
-    size_t gk_stride;
+    const double* gk;           // this thread's first table entry (row ms of its column)
+    size_t gk_stride;           // MS rows
+    size_t gk_row;              // one row
     bool hcd1, hcd2, div1, div2, same, arinyo, rogers, sinc, fvoigt, has_exp, mcdonald, paired, has_vd1, has_vd2, noexp;
     const double* fv_x; const double* fv_f; int fv_n;
 };
@@ -564,9 +572,10 @@ __device__ inline double fvoigt_interp(double x, const double* xp, const double*
 //   SPEC = false: every switch is read from T at run time; RARE adds sinc HCD, McDonald NL, exponential
 //                 smoothing and the fast-metals division.
 template <int MS, int WB, bool SPEC, int KM, bool ARINYO, bool PAIRED, int NVD, bool RARE>
-__device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mubv, int ms, int n_mu,
+__device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mubv, int ms, int j_lo, int n_mu,
                                            double inv_nmu, double* s, double* q)
 {
+    // midpoints j_lo + ms, j_lo + ms + MS, ... < n_mu; the sums are ADDED to s / q
     const bool same = SPEC ? (KM == KM_SAME_HCD || KM == KM_SAME_PLAIN) : T.same;
     const bool hcd1 = SPEC ? (KM == KM_SAME_HCD || KM == KM_FIRST_HCD) : T.hcd1;
     const bool hcd2 = SPEC ? false : T.hcd2;
@@ -578,11 +587,11 @@ __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mu
 
     const double dmu = (double)MS * inv_nmu;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-    const double* gk = T.gk;
-    double g_next = (gk != nullptr) ? *gk : 1.0;
-    double m_next = arinyo ? s_mubv[ms] : 0.0;
+    const double* gk = T.gk != nullptr ? T.gk + (size_t)j_lo * T.gk_row : nullptr;
+    double g_next = (gk != nullptr && j_lo + ms < n_mu) ? *gk : 1.0;
+    double m_next = (arinyo && j_lo + ms < n_mu) ? s_mubv[j_lo + ms] : 0.0;
 
-    for (int j0 = ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
+    for (int j0 = j_lo + ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
         if (WB > 1) __syncthreads();       // keep the walkers of a block on the same table rows (L1 reuse)
         // exact anchors of the progressions along this thread's mu sequence
         double mu = ((double)j0 + 0.5) * inv_nmu;
@@ -653,18 +662,19 @@ __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mu
             mu += dmu;
         }
     }
-    s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3;
-    q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
+    s[0] += s0; s[1] += s1; s[2] += s2; s[3] += s3;
+    q[0] += q0; q[1] += q1; q[2] += q2; q[3] += q3;
 }
 
 // mu loop of a shared-W group: six even moments of the amplitude-free factor
 //   W(k, mu) = G(k, mu) exp(e0 + e1 mu^2) / sqrt((1 + (k mu s1)^2)(1 + (k mu s2)^2)),
 // from which every member pipeline P = P_lin (c0_1 + c1_1 mu^2)(c0_2 + c1_2 mu^2) W forms its own moments.
 template <int MS, int WB>
-__device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, double inv_nmu, const v2d* s_mu24, double* wm)
+__device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int j_lo, int n_mu, double inv_nmu, const v2d* s_mu24, double* wm)
 {
     double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
-    const double* gk = T.gk;
+    const double* gk = T.gk != nullptr ? T.gk + (size_t)j_lo * T.gk_row : nullptr;
+    const double* gk_first = gk;
     const double k2 = T.k * T.k;
     const double k2vd1 = k2 * T.vd1, k2vd2 = k2 * T.vd2;
 #define VMX_PK_W_STEP(G, J)                                                                                           \
@@ -685,8 +695,8 @@ __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, d
         m4 = fma(mu2, v6, m4);                                                                                        \
         m5 = fma(mu4, v6, m5);                                                                                        \
     }
-    const int n_steps = (n_mu - ms + MS - 1) / MS;
-    int j = ms, done = 0;
+    const int n_steps = n_mu > j_lo + ms ? (n_mu - j_lo - ms + MS - 1) / MS : 0;
+    int j = j_lo + ms, done = 0;
     if (gk != nullptr && n_steps >= 8) {
         // the table runs four steps ahead in four registers used in turn (see pk_tab_loop); the groups of this loop
         // request rows that exist, the last four requested rows are consumed after it
@@ -704,11 +714,11 @@ __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int n_mu, d
         done = 4 * groups + 4;
     }
     for (int st = done; st < n_steps; ++st, j += MS) {
-        const double g = (T.gk != nullptr) ? T.gk[(size_t)st * T.gk_stride] : 1.0;
+        const double g = (gk_first != nullptr) ? gk_first[(size_t)st * T.gk_stride] : 1.0;
         VMX_PK_W_STEP(g, j)
     }
 #undef VMX_PK_W_STEP
-    wm[0] = m0; wm[1] = m1; wm[2] = m2; wm[3] = m3; wm[4] = m4; wm[5] = m5;
+    wm[0] += m0; wm[1] += m1; wm[2] += m2; wm[3] += m3; wm[4] += m4; wm[5] += m5;
 }
 
 // D_NL(k,mu)^power * G(k,mu) from the Arinyo parameters of the batch's first walker (power_spectrum.py:435-479)
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(256) void k_xtab(EngineDev D)
     const int xtab = blockIdx.z, pipe = D.xtab_pipe[xtab];
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
     if (i >= D.nkp) return;
-    double* cell = D.xtab + ((size_t)xtab * D.n_mu + j) * D.nkp + i;
+    double* cell = D.xtab + ((size_t)xtab * D.n_rows + j) * D.nkp + i;
     if (!D.xtab_dirty[xtab]) {
         // built from the same parameters by an earlier batch: rewrite the value it holds (no arithmetic, same cache effect)
         *cell = *(volatile double*)cell;
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(256) void k_xtab(EngineDev D)
         const double kp = k / t[d.arinyo_slot[5]];
         const double m = vmx_exp(t[d.arinyo_slot[4]] * D.lnmu[j]);
         val = exp(fmin(d.arinyo_power * (g * (1.0 - v * m) - kp * kp), 709.0));
-        if (d.gk_table >= 0) val *= D.gk[((size_t)d.gk_table * D.n_mu + j) * D.nkp + i];
+        if (d.gk_table >= 0) val *= D.gk[((size_t)d.gk_table * D.n_rows + j) * D.nkp + i];
     }
     *cell = val;
 }
@@ -743,7 +753,7 @@ __global__ __launch_bounds__(256) void k_xtab(EngineDev D)
 // smoothing exp(e0 + e1 mu^2) and the peak broadening all advance as geometric progressions (re-anchored exactly
 // every PK_REANCHOR steps).
 template <int MS, int WB, int KM, bool PAIRED, int NVD>
-__device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int ms, int n_mu, double inv_nmu,
+__device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int ms, int j_lo, int n_mu, double inv_nmu,
                                             const v2d* s_mu24, double* s, double* q)
 {
     // mu^2 and mu^4 of every step come from an LDS table (a wave shares its mu: one broadcast read instead of three
@@ -755,12 +765,12 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
     // The table stream runs four steps ahead of its use, in four registers used in turn (the loop is unrolled by four: a
     // rotating register window costs five moves per step and makes the compiler wait for ALL outstanding loads at every
     // use - vmcnt(0) - which serialises each step behind an L2 round trip; with fixed registers it waits vmcnt(3)).
-    const double* tab = T.gk;
+    const double* tab = T.gk + (size_t)j_lo * T.gk_row;
     double g0 = *tab, g1 = tab[T.gk_stride], g2 = tab[2 * T.gk_stride], g3 = tab[3 * T.gk_stride];
     tab += 4 * T.gk_stride;
     const double gq = vmx_exp(2.0 * T.e1 * dmu * dmu);
     static_assert(PK_REANCHOR % 4 == 0, "the four-register window restarts with every re-anchoring chunk");
-    for (int j0 = ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
+    for (int j0 = j_lo + ms; j0 < n_mu; j0 += MS * PK_REANCHOR) {
         if (WB > 1) __syncthreads();       // keep the walkers of a block on the same table rows (L1 reuse)
         double mu = ((double)j0 + 0.5) * inv_nmu;
         double F = vmx_exp(-T.L0 * T.k * mu);
@@ -817,8 +827,69 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
         if (chunk_steps % 4 > 2) VMX_PK_TAB_STEP(g2, j + 2 * MS)
 #undef VMX_PK_TAB_STEP
     }
-    s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3;
-    q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
+    s[0] += s0; s[1] += s1; s[2] += s2; s[3] += s3;
+    q[0] += q0; q[1] += q1; q[2] += q2; q[3] += q3;
+}
+
+// The extra quadrature nodes (rows n_mu .. n_rows of the tables, weights D.node_w) of a core / plain pipeline: direct
+// evaluation - the nodes are not equally spaced, so nothing advances as a progression here.  tab: the D_NL * G table
+// replaces exp(Arinyo) * G.  Adds W_j mu_j^(2n) P(k, mu_j) to s (and the peak partner's to q).
+template <int MS, int KM, bool ARINYO, bool PAIRED, int NVD, bool TAB>
+__device__ __forceinline__ void pk_extra_nodes(const EngineDev& D, const PkThread& T, double e0g, const double* s_mubv,
+                                               int ms, double* s, double* q)
+{
+    constexpr bool same = KM == KM_SAME_HCD || KM == KM_SAME_PLAIN;
+    constexpr bool hcd1 = KM == KM_SAME_HCD || KM == KM_FIRST_HCD;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    const double k2vd2 = T.k * T.k * T.vd2;
+    const double fk = -T.L0 * T.k;
+    for (int jj = ms; jj < D.n_extra; jj += MS) {
+        const int row = D.n_mu + jj;
+        const double mu = D.mu[row], w = D.node_w[jj];
+        const double mu2 = mu * mu;
+        const double g = T.gk != nullptr ? T.gk[((size_t)row - ms) * T.gk_row] : 1.0;
+        double A1 = fma(T.c1_1, mu2, T.c0_1);
+        if (hcd1) A1 = fma(vmx_exp(fk * mu), fma(T.hbb, mu2, T.hb), A1);
+        const double AA = same ? A1 * A1 : A1 * fma(T.c1_2, mu2, T.c0_2);
+        double val;
+        if (TAB) val = AA * (g * vmx_exp(fma(T.e1, mu2, e0g)));
+        else {
+            double E = fma(T.e1, mu2, T.e0);
+            if (ARINYO) E = fma(T.e2, s_mubv[row], E);
+            val = AA * vmx_exp(E) * g;
+        }
+        if (NVD == 1) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));
+        val *= w;
+        const double mu4 = mu2 * mu2, mu6 = mu4 * mu2;
+        s0 += val; s1 = fma(mu2, val, s1); s2 = fma(mu4, val, s2); s3 = fma(mu6, val, s3);
+        if (PAIRED) {
+            const double vp = val * vmx_exp(fma(T.p1, mu2, T.p0));
+            q0 += vp; q1 = fma(mu2, vp, q1); q2 = fma(mu4, vp, q2); q3 = fma(mu6, vp, q3);
+        }
+    }
+    s[0] += s0; s[1] += s1; s[2] += s2; s[3] += s3;
+    if (PAIRED) { q[0] += q0; q[1] += q1; q[2] += q2; q[3] += q3; }
+}
+
+// ... and of a shared-W group: six moments of W at the extra nodes
+template <int MS>
+__device__ __forceinline__ void pk_w_extra_nodes(const EngineDev& D, const PkThread& T, int ms, double* wm)
+{
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
+    const double k2vd1 = T.k * T.k * T.vd1, k2vd2 = T.k * T.k * T.vd2;
+    for (int jj = ms; jj < D.n_extra; jj += MS) {
+        const int row = D.n_mu + jj;
+        const double mu = D.mu[row];
+        const double mu2 = mu * mu, mu4 = mu2 * mu2;
+        double val = D.node_w[jj] * (T.gk != nullptr ? T.gk[((size_t)row - ms) * T.gk_row] : 1.0);
+        if (!T.noexp) val *= vmx_exp(fma(T.e1, mu2, T.e0));
+        if (T.has_vd1) val *= vmx_rsqrt(fma(k2vd1, mu2, 1.0));
+        if (T.has_vd2) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));
+        m0 += val; m1 = fma(mu2, val, m1); m2 = fma(mu4, val, m2);
+        const double v6 = val * (mu4 * mu2);
+        m3 += v6; m4 = fma(mu2, v6, m4); m5 = fma(mu4, v6, m5);
+    }
+    wm[0] += m0; wm[1] += m1; wm[2] += m2; wm[3] += m3; wm[4] += m4; wm[5] += m5;
 }
 
 // Block = KT wavenumbers x MS mu-slices x WB walkers (KT * MS * WB = 256).  WB > 1 lets the waves of a block share the
@@ -836,7 +907,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     // LDS: [8][256] reduction scratch first; the per-walker mu^bv tables follow only when the launch needs them
     // (the tabulated-D_NL mode does not: a smaller footprint lets more blocks share a CU)
     double* s_red = smem;
-    double* s_mubv = smem + 2048 + (size_t)wb * D.n_mu;       // [WB][n_mu]   mu^bv (Arinyo), one table per walker
+    double* s_mubv = smem + 2048 + (size_t)wb * D.n_rows;      // [WB][n_rows]  mu^bv (Arinyo), one table per walker
     const bool use_tab = tab_mode && groups[blockIdx.y].xtab >= 0 &&
                          (groups[blockIdx.y].variant == PKV_AUTO_CORE || groups[blockIdx.y].variant == PKV_CROSS_CORE);
     v2d* s_mu24 = (v2d*)(smem + (mu_tab_off >= 0 ? mu_tab_off : 0));        // [n_mu] (mu^2, mu^4) when the launch has room
@@ -863,9 +934,13 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     PkThread T;
     T.paired = pp >= 0;
     T.arinyo = d.nl_model == VMX_NL_ARINYO;
+    // k tiles up to k_node_max take the node rule: the first mu_lo and the last mu_hi midpoints plus the extra nodes
+    // (block-uniform: every thread of a block shares the tile)
+    const bool node_mode = GENERIC ? false : (D.n_extra > 0 && variant != PKV_GENERIC &&
+                                              D.k[min((int)(blockIdx.z + 1) * KT, D.nk) - 1] <= D.k_node_max);
     if (T.arinyo && !use_tab) {
         const double bv = sc[S_ABV];
-        for (int j = lt; j < n_mu; j += KT * MS) s_mubv[j] = vmx_exp(bv * D.lnmu[j]);     // mu^bv
+        for (int j = lt; j < D.n_rows; j += KT * MS) s_mubv[j] = vmx_exp(bv * D.lnmu[j]);     // mu^bv (midpoints, then nodes)
     }
 
     __syncthreads();
@@ -926,17 +1001,19 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
         T.e0 += pow(k / 6.4, 0.569) - pow(k / 15.3, 2.01);
     }
     T.gk_stride = (size_t)MS * D.nkp;
-    T.gk = d.gk_table >= 0 ? D.gk + (size_t)d.gk_table * n_mu * D.nkp + (size_t)ms * D.nkp + ic : nullptr;
+    T.gk_row = (size_t)D.nkp;
+    T.gk = d.gk_table >= 0 ? D.gk + (size_t)d.gk_table * D.n_rows * D.nkp + (size_t)ms * D.nkp + ic : nullptr;
     if constexpr (KT == 8) {
         // single-walker shape (one wave per SIMD, ~31 mu steps per thread): nothing hides the latency of the table
         // reads inside the loop, so every thread requests its own entries back to back here and the loop reads LDS
         if (T.gk != nullptr) {
-            double* s_g = smem + 2048 + D.n_mu + (size_t)ms * KT + kk;      // [n_mu][KT]
+            double* s_g = smem + 2048 + D.n_rows + (size_t)ms * KT + kk;      // [n_rows][KT]
             const double* src = T.gk;
 #pragma unroll 8
-            for (int j = ms; j < n_mu; j += MS) { s_g[(size_t)(j - ms) * KT] = *src; src += T.gk_stride; }
+            for (int j = ms; j < D.n_rows; j += MS) { s_g[(size_t)(j - ms) * KT] = *src; src += T.gk_stride; }
             T.gk = s_g;
             T.gk_stride = (size_t)MS * KT;
+            T.gk_row = (size_t)KT;
         }
     }
 
@@ -966,7 +1043,14 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
         // one mu loop for all member pipelines (e.g. QSO x each metal line): they share W and differ only in
         // the Kaiser polynomials
         double wm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (live_block) pk_w_loop<MS, WB>(T, ms, n_mu, inv_nmu, mu_tab_off >= 0 ? s_mu24 : nullptr, wm);
+        if (live_block) {
+            const v2d* mt = mu_tab_off >= 0 ? s_mu24 : nullptr;
+            if (node_mode) {
+                pk_w_loop<MS, WB>(T, ms, 0, D.mu_lo, inv_nmu, mt, wm);
+                pk_w_loop<MS, WB>(T, ms, n_mu - D.mu_hi, n_mu, inv_nmu, mt, wm);
+                pk_w_extra_nodes<MS>(D, T, ms, wm);
+            } else pk_w_loop<MS, WB>(T, ms, 0, n_mu, inv_nmu, mt, wm);
+        }
         for (int n = 0; n < 6; ++n) s_red[n * 256 + threadIdx.x] = wm[n];
         __syncthreads();
         if (lt < KT && valid && walker_ok) {
@@ -1008,28 +1092,51 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
         return;
     }
     const int xt = groups[blockIdx.y].xtab;
+    // uniform midpoint ranges of this block: everything, or the two ends of the node rule
+    const int n_ranges = node_mode ? 2 : 1;
     if (use_tab) {
         if (live_block) {
-            T.gk = D.xtab + ((size_t)xt * n_mu + ms) * D.nkp + ic;
-            if (variant == PKV_AUTO_CORE) pk_tab_loop<MS, WB, KM_SAME_HCD, true, 0>(T, -k2 * gb, ms, n_mu, inv_nmu, s_mu24, s, q);
-            else pk_tab_loop<MS, WB, KM_FIRST_HCD, true, 1>(T, -k2 * gb, ms, n_mu, inv_nmu, s_mu24, s, q);
+            T.gk = D.xtab + ((size_t)xt * D.n_rows + ms) * D.nkp + ic;
+            T.gk_row = (size_t)D.nkp; T.gk_stride = (size_t)MS * D.nkp;
+            for (int rg = 0; rg < n_ranges; ++rg) {
+                const int j_lo = rg == 0 ? 0 : n_mu - D.mu_hi, j_hi = (node_mode && rg == 0) ? D.mu_lo : n_mu;
+                if (variant == PKV_AUTO_CORE) pk_tab_loop<MS, WB, KM_SAME_HCD, true, 0>(T, -k2 * gb, ms, j_lo, j_hi, inv_nmu, s_mu24, s, q);
+                else pk_tab_loop<MS, WB, KM_FIRST_HCD, true, 1>(T, -k2 * gb, ms, j_lo, j_hi, inv_nmu, s_mu24, s, q);
+            }
+            if (node_mode) {
+                if (variant == PKV_AUTO_CORE) pk_extra_nodes<MS, KM_SAME_HCD, true, true, 0, true>(D, T, -k2 * gb, s_mubv, ms, s, q);
+                else pk_extra_nodes<MS, KM_FIRST_HCD, true, true, 1, true>(D, T, -k2 * gb, s_mubv, ms, s, q);
+            }
         }
-    } else if (live_block)
+    } else if (live_block) {
+    for (int rg = 0; rg < n_ranges; ++rg) {
+    const int j_lo = rg == 0 ? 0 : n_mu - D.mu_hi, j_hi = (node_mode && rg == 0) ? D.mu_lo : n_mu;
     switch (variant) {
-        case PKV_AUTO_CORE: pk_mu_loop<MS, WB, true, KM_SAME_HCD, true, true, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
-        case PKV_CROSS_CORE: pk_mu_loop<MS, WB, true, KM_FIRST_HCD, true, true, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
-        case PKV_PLAIN_SAME: pk_mu_loop<MS, WB, true, KM_SAME_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
-        case PKV_PLAIN_PAIR: pk_mu_loop<MS, WB, true, KM_BOTH_PLAIN, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
-        case PKV_PLAIN_PAIR_VD: pk_mu_loop<MS, WB, true, KM_BOTH_PLAIN, false, false, 1, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q); break;
+        case PKV_AUTO_CORE: pk_mu_loop<MS, WB, true, KM_SAME_HCD, true, true, 0, false>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q); break;
+        case PKV_CROSS_CORE: pk_mu_loop<MS, WB, true, KM_FIRST_HCD, true, true, 1, false>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q); break;
+        case PKV_PLAIN_SAME: pk_mu_loop<MS, WB, true, KM_SAME_PLAIN, false, false, 0, false>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q); break;
+        case PKV_PLAIN_PAIR: pk_mu_loop<MS, WB, true, KM_BOTH_PLAIN, false, false, 0, false>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q); break;
+        case PKV_PLAIN_PAIR_VD: pk_mu_loop<MS, WB, true, KM_BOTH_PLAIN, false, false, 1, false>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q); break;
         default:
             // the run-time-switched loops (rare model options) live in the GENERIC instantiation only: their register
             // footprint would otherwise cap the occupancy of the production loops
             if constexpr (GENERIC) {
                 if (T.sinc || T.fvoigt || T.has_exp || T.mcdonald || T.div1 || T.div2)
-                    pk_mu_loop<MS, WB, false, 0, false, false, 0, true>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
+                    pk_mu_loop<MS, WB, false, 0, false, false, 0, true>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q);
                 else
-                    pk_mu_loop<MS, WB, false, 0, false, false, 0, false>(T, s_mubv, ms, n_mu, inv_nmu, s, q);
+                    pk_mu_loop<MS, WB, false, 0, false, false, 0, false>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q);
             }
+    }
+    }
+    if (node_mode)
+        switch (variant) {
+            case PKV_AUTO_CORE: pk_extra_nodes<MS, KM_SAME_HCD, true, true, 0, false>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_CROSS_CORE: pk_extra_nodes<MS, KM_FIRST_HCD, true, true, 1, false>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_PLAIN_SAME: pk_extra_nodes<MS, KM_SAME_PLAIN, false, false, 0, false>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_PLAIN_PAIR: pk_extra_nodes<MS, KM_BOTH_PLAIN, false, false, 0, false>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_PLAIN_PAIR_VD: pk_extra_nodes<MS, KM_BOTH_PLAIN, false, false, 1, false>(D, T, 0.0, s_mubv, ms, s, q); break;
+            default: break;
+        }
     }
 
     // moments -> Legendre multipoles  P_ell = (2 ell + 1) / n_mu * sum_n c_{ell n} M_n  (pktoxi.py:37,55,138)
