@@ -329,6 +329,9 @@ int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B);
  * that are not smooth in mu (exponential smoothing, Voigt / sinc HCD, McDonald), keep the plain loop.  node_rule = 0:
  * the 1000-point loop everywhere (VMX_EXACT_MU in the environment does the same).  Returns the setting in effect. */
 int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule);
+/* The extra nodes of that rule as the engine built them: mu[n], w[n] (weights in units of one midpoint); returns n
+ * (also when the buffers are NULL or too small, without writing). */
+int vmx_get_mu_nodes(vmx_engine* e, double* mu, double* w, int32_t capacity);
 
 /* chi2-only evaluations (model == NULL) as a static quadratic form.  Without a multiplicative post-distortion
  * broadband the model on the fitted bins is linear in x' = [pre-distortion vector ; additive post-distortion broadband

@@ -2187,6 +2187,18 @@ int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B)
     return 0;
 }
 
+int vmx_get_mu_nodes(vmx_engine* e, double* mu, double* w, int32_t capacity)
+{
+    REQUIRE(e && e->nk > 0, "vmx_get_mu_nodes (after vmx_set_template)");
+    if (!mu || !w || capacity < e->n_extra) return e->n_extra;
+    HIP_OK(hipSetDevice(e->device));
+    if (e->n_extra > 0) {
+        HIP_OK(hipMemcpy(mu, e->mu.p + e->n_mu, (size_t)e->n_extra * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(w, e->node_w.p, (size_t)e->n_extra * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return e->n_extra;
+}
+
 int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule)
 {
     REQUIRE(e && e->finalized, "vmx_set_mu_quadrature (after vmx_finalize)");

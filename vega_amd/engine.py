@@ -141,6 +141,7 @@ def load_library():
     lib.vmx_marg_coeff.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_quadratic_form.argtypes = [C.c_void_p, dptr]
     lib.vmx_set_mu_quadrature.argtypes = [C.c_void_p, C.c_int32]
+    lib.vmx_get_mu_nodes.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_stream.argtypes = [C.c_void_p]
     lib.vmx_stream.restype = C.c_void_p
     lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
@@ -171,7 +172,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_mu_quadrature', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_mu_quadrature', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -829,6 +830,13 @@ class Engine:
         ref = _f64(self.low.theta0)
         self.quadratic_form = bool(self._check(self.lib.vmx_set_quadratic_form(self._h, _dp(ref) if on else None))) and on
         return self.quadratic_form
+
+    def mu_nodes(self):
+        """(mu, w) of the extra nodes of the mu rule as the engine holds them."""
+        n = self._check(self.lib.vmx_get_mu_nodes(self._h, None, None, 0))
+        mu, w = np.empty(n), np.empty(n)
+        self._check(self.lib.vmx_get_mu_nodes(self._h, _dp(mu), _dp(w), n))
+        return mu, w
 
     def set_mu_quadrature(self, node_rule=True):
         """True: the node rule that reproduces the reference's 1000-point mu sums from 276 evaluations (default);
