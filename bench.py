@@ -463,6 +463,28 @@ def main():
         two_lanes = {'lanes': nl, 'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
                      'note': f'{nl} independent engines per GPU, step i on lane i % {nl}, B={B} walkers per step'}
 
+    exact_mu = None
+    if not use_dist and not args.core_only:
+        # the same steps with the reference's 1000-point mu loop itself instead of the node rule that reproduces its sums
+        # (include/vegamx.h: vmx_set_mu_quadrature) - reported beside `value`, and the two must agree
+        ref_chi2 = chi2_bufs[(args.steps - 1) % nslot].clone()
+        if eng.set_mu_quadrature(False) is False:
+            for i in range(3):
+                step(i, 1)
+            sync_all()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(i, 1)
+            sync_all()
+            dt = time.perf_counter() - t0
+            loop_chi2 = chi2_bufs[(args.steps - 1) % nslot]
+            rel = float(((loop_chi2 - ref_chi2).abs() / ref_chi2.abs()).max()) if L == 1 else None
+            exact_mu = {'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
+                        'max_rel_chi2_diff_vs_node_rule': rel,
+                        'note': 'mu sums as the plain 1000-point loop (vmx_set_mu_quadrature(0)); `value` uses the '
+                                '276-node rule that reproduces those sums to ~1e-13'}
+        eng.set_mu_quadrature(True)
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -486,11 +508,15 @@ def main():
 
         def roofline_for(kclass, ms_per_launch):
             if kclass == 'pk_multipoles':
-                nk, n_mu = prob.k.size, 1000
+                # (k, mu) points the stage evaluates per walker and item: the live wavenumbers of the step (blocks whose
+                # every value underflows are skipped) x the mu nodes of each - 276 where the node rule applies, 1000 above
+                k_live, k_node_max, n_nodes = eng.debug_read(4, 0, 3)
+                kk = prob.k[:int(k_live)]
+                points = float(np.where(kk <= k_node_max, n_nodes, 1000).sum())
                 flops = 0.0
                 for item in prob.items.values():
                     kind = 'auto' if item.tracer1.name == item.tracer2.name else 'cross'
-                    flops += B * nk * n_mu * FLOPS_PER_POINT[kind]          # one paired pass per item
+                    flops += B * points * FLOPS_PER_POINT[kind]          # one paired pass per item
                 bound, peak, reach = 'valu-fp64', FP64_VALU_PEAK_TF, FP64_VALU_MEASURED_TF
             elif kclass == 'quadratic_form_product':
                 # x'^T Q' x' in half form: nq^2 flops per walker and item, nq = n_model + additive post-distortion coefficients
@@ -573,7 +599,7 @@ def main():
                        'batch_per_gpu': B, 'lanes_per_gpu': L, 'pipelines_per_eval': len(eng.pipe_index),
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
-            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'exact_mu_loop': exact_mu, 'cpu_baseline': cpu,
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
         }
         sys.stdout.flush()
