@@ -185,7 +185,7 @@ struct vmx_engine {
     int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
     // work lists of the quadratic-form launches per batch size: entries, their count, per-row-tile slab counts
-    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg; int n_blocks = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; };
+    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg; int n_blocks = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; int seg_len = 0; };
     std::map<int, QuadList*> quad_lists;
     bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
     bool quad_band_xcd = false;      // VMX_XCD_BANDS: a K band per XCD (HBM traffic 1.96x -> 1.43x the algorithmic bytes, launch 6 % longer)
@@ -1474,76 +1474,48 @@ int vmx_pipeline_column(vmx_engine* e, int32_t pipeline)
     return e->pipes[pipeline].col >= 0 ? e->pipes[pipeline].col : -3 - e->n_active;     // (< -2: no column; the count is -3 - value)
 }
 
-// Work list of the quadratic-form launch for B walkers: every 64 x 64 tile of every item's half-triangle product is cut
-// into K segments of about L stages (a stage = 32 columns); L is chosen by simulating the launch as list scheduling on the
-// 256 CUs (a block costs its stages + a fixed start / end), longest blocks first.  The walker tiles of one (row tile,
-// segment) share their matrix tile: they get block indices 8 apart - the same XCD, back to back.
-static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
+// Work list of the quadratic-form launch for B walkers with segments of about L stages (a stage = 32 columns): every
+// 64 x 64 tile of every item's half-triangle product is cut into ceil(stages / L) K segments of equal length.  The walker
+// tiles of one (row tile, segment) share their matrix tile: they get block indices 8 apart - the same XCD, back to back.
+static vmx_engine::QuadList* quad_build_list(vmx_engine* e, int B, int L)
 {
-    auto found = e->quad_lists.find(B);
-    if (found != e->quad_lists.end()) return found->second;
-    constexpr int BM = GEMM_BM, BK = GEMM_BK, CUS = 256;
-    constexpr double OVERHEAD = 4.0;
+    constexpr int BM = GEMM_BM, BK = GEMM_BK;
     const int tn = (B + GEMM_BN - 1) / GEMM_BN;
-    struct Tile { int prob, mt, stages; };
-    std::vector<Tile> tiles;
-    for (size_t q = 0; q < e->items.size(); ++q) {
-        const ItemDev& d = e->items[q]->dev;
-        const int tm = (d.nq + BM - 1) / BM, kmax_all = d.nq_pad / BK;
-        for (int mt = 0; mt < tm; ++mt) tiles.push_back({(int)q, mt, std::min(((mt + 1) * BM + BK - 1) / BK, kmax_all)});
-    }
     const int max_slabs = std::max(1, std::min(8, e->slab_rows / std::max(B, 1)));
-    int best_L = 1 << 20;
-    double best_cost = 1e300;
-    for (int L = 16; L <= 192; L += 4) {
-        std::vector<double> costs;
-        for (auto& t : tiles) {
-            const int nseg = std::min(max_slabs, (t.stages + L - 1) / L);
-            const int len = (t.stages + nseg - 1) / nseg;
-            for (int s = 0; s < nseg * tn; ++s) costs.push_back(len + OVERHEAD);
-        }
-        std::sort(costs.begin(), costs.end(), std::greater<double>());
-        std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
-        for (int c = 0; c < CUS; ++c) free_at.push(0.0);
-        double makespan = 0.0;
-        for (double c : costs) { const double t = free_at.top() + c; free_at.pop(); free_at.push(t); makespan = std::max(makespan, t); }
-        if (makespan < best_cost) { best_cost = makespan; best_L = L; }
-    }
     auto* ql = new vmx_engine::QuadList();
     struct Group { int prob, mt, seg, kbeg, kend; };
     std::vector<Group> groups;
     std::vector<int32_t> nseg_all;
-    for (size_t q = 0, ti = 0; q < e->items.size(); ++q) {
+    for (size_t q = 0; q < e->items.size(); ++q) {
         const ItemDev& d = e->items[q]->dev;
-        const int tm = (d.nq + BM - 1) / BM;
+        const int tm = (d.nq + BM - 1) / BM, kmax_all = d.nq_pad / BK;
         ql->nseg_off[q] = (int32_t)nseg_all.size();
-        for (int mt = 0; mt < tm; ++mt, ++ti) {
-            const int stages = tiles[ti].stages;
-            const int nseg = std::min(max_slabs, (stages + best_L - 1) / best_L);
+        for (int mt = 0; mt < tm; ++mt) {
+            const int stages = std::min(((mt + 1) * BM + BK - 1) / BK, kmax_all);
+            const int nseg = std::min(max_slabs, (stages + L - 1) / L);
             const int len = (stages + nseg - 1) / nseg;
             nseg_all.push_back(nseg);
             ql->max_seg = std::max(ql->max_seg, nseg);
-            for (int s = 0; s < nseg; ++s) {
-                const int kb = s * len * BK, ke = std::min((s + 1) * len, stages) * BK;
-                groups.push_back({(int)q, mt, s, kb, std::max(kb, ke)});
+            for (int sg = 0; sg < nseg; ++sg) {
+                const int kb = sg * len * BK, ke = std::min((sg + 1) * len, stages) * BK;
+                groups.push_back({(int)q, mt, sg, kb, std::max(kb, ke)});
             }
         }
     }
     // Default: longest segments first, dealt round-robin to the XCDs.  Option (VMX_XCD_BANDS): XCD x takes a band of K - every
     // XCD has its own L2, and the slice of the walker operand a band touches (all walkers x the band's columns) then stays
     // resident there instead of being fetched by all eight; band edges cut the triangle into eight pieces of equal work.
-    // Measured: HBM traffic 306 -> 223 MB per launch (1.96x -> 1.43x the algorithmic bytes), but the launch takes 0.199
-    // instead of 0.188 ms (the kernel is MFMA-issue bound at 1.6 TB/s; the bands cost balance) - so not the default.
+    // Measured: HBM traffic 306 -> 223 MB per launch (1.96x -> 1.43x the algorithmic bytes), but the launch takes 6 % longer
+    // (the kernel is MFMA-issue bound at 1.6 TB/s; the bands cost balance) - so not the default.
     std::vector<std::vector<Group>> per_xcd(8);
     if (e->quad_band_xcd) {
         std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) {
             return a.prob != b.prob ? a.prob < b.prob : (a.kbeg != b.kbeg ? a.kbeg < b.kbeg : a.mt < b.mt); });
-        const double fixed = 0.0;
         double total = 0.0, cum = 0.0;
-        for (auto& g : groups) total += (g.kend - g.kbeg) / BK + fixed;
+        for (auto& g : groups) total += (g.kend - g.kbeg) / BK;
         for (auto& g : groups) {
             per_xcd[std::min(7, (int)(cum / total * 8.0))].push_back(g);
-            cum += (g.kend - g.kbeg) / BK + fixed;
+            cum += (g.kend - g.kbeg) / BK;
         }
     } else {
         std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.kend - a.kbeg > b.kend - b.kbeg; });
@@ -1562,9 +1534,67 @@ static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
                 work[(r * tn + nt) * 8 + xcd] = GemmWork{g.prob, g.mt, nt, g.kbeg, g.kend, g.seg};
         }
     ql->n_blocks = (int)work.size();
+    ql->seg_len = L;
     if (ql->work.upload(work.data(), work.size()) || ql->nseg.upload(nseg_all.data(), nseg_all.size())) { delete ql; return nullptr; }
-    e->quad_lists[B] = ql;
     return ql;
+}
+
+// the launch itself; fills the slab description of the consumer (k_chi2_quad)
+static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, SlabInfo& qs)
+{
+    GemmGroup G{};
+    for (size_t q = 0; q < e->items.size(); ++q) {
+        ItemHost* it = e->items[q];
+        const ItemDev& d = it->dev;
+        GemmArgs g{};
+        g.A = it->q_mat.p; g.lda = d.nq_pad; g.X = it->q_x.p; g.ldx = d.nq_pad; g.D = it->q_z.p; g.ldd = d.nq_pad;
+        g.M = d.nq; g.N = B; g.K = d.nq_pad; g.tri = 1; g.nsplit = 1; g.klen = d.nq_pad;
+        g.d_slab = (int64_t)B * d.nq_pad;
+        g.tm = (d.nq + GEMM_BM - 1) / GEMM_BM; g.tn = (B + GEMM_BN - 1) / GEMM_BN;
+        G.p[G.n++] = g;
+        qs.z[q] = 0;
+        qs.qseg_off[q] = ql->nseg_off[q];
+    }
+    G.work = ql->work.p;
+    qs.qseg = ql->nseg.p;
+    hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), dim3(ql->n_blocks, 1), dim3(GEMM44_THREADS), 0, e->cur, G);
+}
+
+// The segment length is MEASURED once per batch size: a CU keeps two blocks resident and issues from the older one first,
+// so a launch of ~1000 blocks of unequal length is neither list scheduling on 256 machines nor on 512 half-speed ones -
+// simulated choices were up to 20 % off (B = 256: 0.154 ms with 40-stage segments, 0.181 with 64, 0.157 with 80).  A fixed
+// candidate set is timed with HIP events on the engine's stream (three launches each, the minimum counts); the choice
+// only changes how the partial sums are grouped, never what is summed.  VMX_QUAD_L pins it.
+static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
+{
+    auto found = e->quad_lists.find(B);
+    if (found != e->quad_lists.end()) return found->second;
+    vmx_engine::QuadList* best = nullptr;
+    if (const char* force = getenv("VMX_QUAD_L")) best = quad_build_list(e, B, std::max(1, atoi(force)));
+    else {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { fail(-2, "hipEventCreate"); return nullptr; }
+        float best_ms = 1e30f;
+        e->cur = e->stream;
+        for (int L : {24, 32, 40, 48, 56, 64, 80, 96}) {
+            vmx_engine::QuadList* ql = quad_build_list(e, B, L);
+            if (!ql) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); delete best; return nullptr; }
+            float ms = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                SlabInfo qs{};
+                (void)hipEventRecord(ev0, e->stream);
+                quad_launch_list(e, ql, B, qs);
+                (void)hipEventRecord(ev1, e->stream);
+                (void)hipEventSynchronize(ev1);
+                float t = 0.f;
+                if (rep > 0 && hipEventElapsedTime(&t, ev0, ev1) == hipSuccess) ms = std::min(ms, t);
+            }
+            if (ms < best_ms) { best_ms = ms; delete best; best = ql; } else delete ql;
+        }
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    }
+    if (best) e->quad_lists[B] = best;
+    return best;
 }
 
 // static spline-coefficient basis of the polynomial pipelines: C[ell][basis][i] = OP_ell . V_i[ell] (k_poly_basis), with the
@@ -1751,23 +1781,8 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
             // balanced work list: every tile cut into K segments of about equal length
             vmx_engine::QuadList* ql = quad_work_list(e, B);
             if (!ql) return -2;
-            GemmGroup G{};
-            for (size_t q = 0; q < e->items.size(); ++q) {
-                ItemHost* it = e->items[q];
-                const ItemDev& d = it->dev;
-                GemmArgs g{};
-                g.A = it->q_mat.p; g.lda = d.nq_pad; g.X = it->q_x.p; g.ldx = d.nq_pad; g.D = it->q_z.p; g.ldd = d.nq_pad;
-                g.M = d.nq; g.N = B; g.K = d.nq_pad; g.tri = 1; g.nsplit = 1; g.klen = d.nq_pad;
-                g.d_slab = (int64_t)B * d.nq_pad;
-                g.tm = (d.nq + GEMM_BM - 1) / GEMM_BM; g.tn = (B + GEMM_BN - 1) / GEMM_BN;
-                G.p[G.n++] = g;
-                qs.z[q] = 0;
-                qs.qseg_off[q] = ql->nseg_off[q];
-            }
-            G.work = ql->work.p;
-            qs.qseg = ql->nseg.p;
             ScopedTimer t(e, KC_QUAD);
-            hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), dim3(ql->n_blocks, 1), dim3(GEMM44_THREADS), 0, e->cur, G);
+            quad_launch_list(e, ql, B, qs);
         } else if (B > 8 && e->items.size() <= VMX_MAX_GROUP) {
             GemmGroup G{};
             int tiles_total = 0, per_xcd_total = 0;
