@@ -186,7 +186,8 @@ struct vmx_engine {
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
     // work lists of the quadratic-form launches per batch size: entries, their count, per-row-tile slab counts
     struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg; int n_blocks = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; int seg_len = 0; };
-    std::map<int, QuadList*> quad_lists;
+    std::map<int, QuadList*> quad_lists;     // by number of walker tiles
+    std::map<int, int> quad_seg_len;         // measured segment length by power-of-two class of that number
     bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
     bool quad_band_xcd = false;      // VMX_XCD_BANDS: a K band per XCD (HBM traffic 1.96x -> 1.43x the algorithmic bytes, launch 6 % longer)
     bool gemm_44 = true;             // products on the four-block 4x4x4 fp64 MFMA (VMX_GEMM_16: the 16x16x4 kernel everywhere)
@@ -1481,7 +1482,8 @@ static vmx_engine::QuadList* quad_build_list(vmx_engine* e, int B, int L)
 {
     constexpr int BM = GEMM_BM, BK = GEMM_BK;
     const int tn = (B + GEMM_BN - 1) / GEMM_BN;
-    const int max_slabs = std::max(1, std::min(8, e->slab_rows / std::max(B, 1)));
+    // (the list serves every batch size with this many walker tiles: slabs sized for the largest of them)
+    const int max_slabs = std::max(1, std::min(8, e->slab_rows / (tn * GEMM_BN)));
     auto* ql = new vmx_engine::QuadList();
     struct Group { int prob, mt, seg, kbeg, kend; };
     std::vector<Group> groups;
@@ -1567,10 +1569,16 @@ static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, Sla
 // only changes how the partial sums are grouped, never what is summed.  VMX_QUAD_L pins it.
 static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
 {
-    auto found = e->quad_lists.find(B);
+    // a list depends on the batch size through its number of walker tiles only; the segment length is measured once per
+    // power-of-two class of that number (a fit driver calls with dozens of different batch sizes)
+    const int tn = (B + GEMM_BN - 1) / GEMM_BN;
+    auto found = e->quad_lists.find(tn);
     if (found != e->quad_lists.end()) return found->second;
+    int cls = 1;
+    while (cls < tn) cls *= 2;
     vmx_engine::QuadList* best = nullptr;
     if (const char* force = getenv("VMX_QUAD_L")) best = quad_build_list(e, B, std::max(1, atoi(force)));
+    else if (e->quad_seg_len.count(cls)) best = quad_build_list(e, B, e->quad_seg_len[cls]);
     else {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { fail(-2, "hipEventCreate"); return nullptr; }
@@ -1593,7 +1601,7 @@ static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
         }
         (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     }
-    if (best) e->quad_lists[B] = best;
+    if (best) { e->quad_lists[tn] = best; e->quad_seg_len[cls] = best->seg_len; }
     return best;
 }
 
