@@ -127,6 +127,36 @@ def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
             'note': '8 distinct 50 MB matrices round-robin (HBM); cache_resident = one matrix reused'}
 
 
+def distortion_csr(device, reps=60):
+    """The same synthetic 2500^2 distortion matrix in CSR form (73 % non-zeros, the reference's `csr_array`), B = 1: the
+    full chain of one model evaluation with the CSR product (`k_csr_spmm<1>`) timed by HIP events."""
+    from scipy import sparse
+    from vega_amd import VegaInterface
+    prob = build_problem('auto')
+    for item in prob.items.values():
+        item.distortion = sparse.csr_array(item.distortion)
+    item = next(iter(prob.items.values()))
+    vega = VegaInterface(None, problem=prob, max_batch=1, device=device, csr_threshold=1.1)
+    eng = vega.engine
+    theta = eng.theta_from_params()[None, :]
+    for _ in range(5):
+        eng.eval(theta, want_model=True)
+    eng.set_profiling(True)
+    eng.timings(reset=True)
+    for _ in range(reps):
+        eng.eval(theta, want_model=True)
+    ms, launches = eng.timings(reset=True)['distortion_product']
+    eng.set_profiling(False)
+    vega.close()
+    nnz, (rows, cols) = item.distortion.nnz, item.distortion.shape
+    algo = 12.0 * nnz + 8.0 * (rows + 1) + 8.0 * (rows + cols)          # SURVEY 8d (int64 row pointers here)
+    gbs = algo / (ms / launches * 1e-3) / 1e9
+    return {'shape': [rows, cols], 'nnz': int(nnz), 'density': nnz / (rows * cols), 'batch': 1, 'bound': 'hbm',
+            'algorithmic_bytes': algo, 'us_per_launch': ms / launches * 1e3, 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+            'note': 'one matrix reused (42 MB of CSR arrays: Infinity-Cache resident after the first evaluation)'}
+
+
 def single_point_latency(device, reps=200):
     """BASELINE configs[1]: Lya x Lya auto only, ell = 0,2,4, dense 2500^2 distortion matrix, B = 1:
     wall-clock chi2 evaluations per second through the host interface (host theta in, host chi2 out)."""
@@ -585,6 +615,7 @@ def main():
         extras = not args.core_only and world == 1        # the side sections and the CPU baseline belong to the N = 1 run
         distortion = distortion_microbench(eng, torch) if extras else None
         single = single_point_latency(local_rank) if extras else None
+        dist_csr = distortion_csr(local_rank) if extras else None
         mc_fits = monte_carlo_fits(prob, local_rank) if extras and args.workload == 'joint' else None
         metals = metals_throughput(local_rank) if extras and args.workload == 'joint' else None
         if cpu is not None:
@@ -599,7 +630,7 @@ def main():
                        'batch_per_gpu': B, 'lanes_per_gpu': L, 'pipelines_per_eval': len(eng.pipe_index),
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
-            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'exact_mu_loop': exact_mu, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'distortion_csr': dist_csr, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'exact_mu_loop': exact_mu, 'cpu_baseline': cpu,
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
         }
         sys.stdout.flush()
