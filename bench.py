@@ -201,7 +201,7 @@ def metals_throughput(device, batch=512, steps=10):
         if freeze:
             vega.freeze_static_metals()
         eng = vega.engine
-        eng.set_constant_nl_hint(True)
+        eng.set_constant_nl_hint(True, gaussian=True)
         pools = [torch.from_numpy(synthetic.walkers(eng.low.theta0, eng.names, batch, varied=VARIED,
                                                     seed=synthetic.SEED + 77 + i)).to(dev) for i in range(4)]
         chi2 = torch.zeros(batch, dtype=torch.float64, device=dev)
@@ -392,7 +392,7 @@ def main():
             v.freeze_static_metals()    # polynomial metal pairs -> their exact static Kaiser basis (no-op without metals)
         # the walkers of SURVEY 8d vary biases, betas, alphas, HCD and velocity-dispersion parameters; the Arinyo
         # non-linear parameters are shared by a batch, which the device entry point is told (violations are flagged)
-        v.engine.set_constant_nl_hint(True)
+        v.engine.set_constant_nl_hint(True, gaussian=True)
         vegas.append(v)
     vega = vegas[0]
     eng = vega.engine

@@ -349,8 +349,12 @@ int vmx_set_quadratic_form(vmx_engine* e, const double* theta_ref);
 
 /* Samplers usually keep the Arinyo non-linear parameters fixed.  When they are identical for every walker of a
  * batch the factor D_NL(k,mu) G(k,mu) is tabulated once per batch instead of being exponentiated per walker and
- * grid point.  vmx_eval (host theta) detects this by itself; for vmx_eval_device the caller states it here.
- * A walker whose Arinyo parameters differ from the first walker's while the hint is on gets
+ * grid point (level 1).  When the parameters of every Gaussian factor - smoothing (power_spectrum.py:526-556), peak
+ * broadening (:382-417), Gaussian velocity dispersion (:504-524) - are shared as well, those factors join the table and a
+ * second table serves the peak component (level 2): the HCD term is then the only exponential left per walker and
+ * (k, mu).  A table is kept across evaluations while its parameters do not change.  vmx_eval (host theta) detects the
+ * level by itself; for vmx_eval_device the caller states it here: enabled = 0 none, 1 level 1, 2 level 2.
+ * A walker whose table parameters differ from the first walker's while the hint is on gets
  * status VMX_STATUS_NOT_CONSTANT and chi2 = 1e100 - never a silently wrong value. */
 int vmx_set_constant_nl_hint(vmx_engine* e, int32_t enabled);
 /* The engine's HIP stream (hipStream_t as an opaque pointer), so that a caller can order its own work - e.g. an

@@ -136,11 +136,15 @@ struct vmx_engine {
     DevBuf<double> node_w;
     double k_node_max = 0.0; bool mu_nodes_on = true;
     DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom, fv_x, fv_f, xtab;
-    std::vector<int32_t> const_slots;
-    DevBuf<int32_t> d_const_slots, d_xtab_pipe, xtab_dirty;
+    std::vector<int32_t> const_slots;        // parameters a level-1 table depends on (the Arinyo set)
+    std::vector<int32_t> const_slots2;       // ... a level-2 table: + everything that enters a Gaussian factor
+    DevBuf<int32_t> d_const_slots, d_const_slots2, d_xtab_pipe, d_xtab_partner;
+    DevBuf<double> xtab_k;
+    DevBuf<int32_t> d_tab_groups;            // indices (into pk_groups) of the groups with tables
+    int pk_walkers_per_thread = 1;           // VMX_PK_NW
     DevBuf<double> xtab_key;
     int n_xtab = 0;
-    bool const_hint = false;
+    int const_hint = 0;              // vmx_set_constant_nl_hint: table level the caller vouches for (device-resident theta)
     int fv_n = 0;
     struct GkSpec { double rp, rt, mock_rp, mock_rt; };   // G(rp, rt) * G(mock_rp, mock_rt); a zero size = factor 1
     std::vector<GkSpec> gk_tables;
@@ -189,6 +193,7 @@ struct vmx_engine {
     std::map<int, QuadList*> quad_lists;     // by number of walker tiles
     std::map<int, int> quad_seg_len;         // measured segment length by power-of-two class of that number
     bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
+    bool no_tab2 = false;            // VMX_NO_TAB2: level-1 tables only (the Gaussian factors stay in the mu loop)
     bool quad_band_xcd = false;      // VMX_XCD_BANDS: a K band per XCD (HBM traffic 1.96x -> 1.43x the algorithmic bytes, launch 6 % longer)
     bool gemm_44 = true;             // products on the four-block 4x4x4 fp64 MFMA (VMX_GEMM_16: the 16x16x4 kernel everywhere)
     bool pk_small_attr = false;      // the single-walker P(k) shape asked for its > 64 KB of LDS
@@ -1115,6 +1120,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
     if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
     if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
+    if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
+    if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 2 ? 2 : 1;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
     if (getenv("VMX_GRAPH_B1")) e->graph_b1 = true;
 
@@ -1253,30 +1260,52 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         }
         e->n_xtab = 0;
         e->const_slots.clear();
+        e->const_slots2.clear();
+        auto add_slot = [](std::vector<int32_t>& v, int slot) {
+            if (slot >= 0 && std::find(v.begin(), v.end(), slot) == v.end()) v.push_back(slot);
+        };
         for (auto& g : e->pk_groups) {
             if (g.peak_partner >= 0) g.variant = pk_variant(e->pipes[g.pipe].d, true);
-            // core groups with the Arinyo term can run against a per-batch D_NL * G table
+            // core groups with the Arinyo term can run against per-batch tables (EngineDev::xtab_level)
             if (g.variant == PKV_AUTO_CORE || g.variant == PKV_CROSS_CORE) {
                 g.xtab = e->n_xtab++;
-                for (int i = 0; i < 6; ++i) {
-                    const int slot = e->pipes[g.pipe].d.arinyo_slot[i];
-                    if (slot >= 0 && std::find(e->const_slots.begin(), e->const_slots.end(), slot) == e->const_slots.end())
-                        e->const_slots.push_back(slot);
+                for (int i = 0; i < 6; ++i) add_slot(e->const_slots, e->pipes[g.pipe].d.arinyo_slot[i]);
+                // level 2: whatever k_prologue forms ga / gb from, for the pipeline and its peak partner
+                for (int pq : {g.pipe, g.peak_partner}) {
+                    if (pq < 0) continue;
+                    const vmx_pipe_desc& d = e->pipes[pq].d;
+                    if (d.peak_nl) {
+                        add_slot(e->const_slots2, d.sigma_nl_par_slot); add_slot(e->const_slots2, d.sigma_nl_per_slot);
+                        if (d.sigma_nl_par_slot < 0 || d.sigma_nl_per_slot < 0) add_slot(e->const_slots2, d.growth_rate_slot);
+                    }
+                    for (int i = 0; i < d.n_smooth; ++i) { add_slot(e->const_slots2, d.smooth_par_slot[i]); add_slot(e->const_slots2, d.smooth_per_slot[i]); }
+                    for (int q = 0; q < 2; ++q)
+                        if (d.vd_kind == VMX_VD_GAUSS && d.tracer[q].discrete) add_slot(e->const_slots2, d.tracer[q].vd_sigma_slot);
                 }
             }
         }
-        // (+ 4 x 32 rows: the mu loop requests its table rows four steps ahead without checking for the end)
-        if (e->n_xtab > 0 && e->xtab.alloc(((size_t)e->n_xtab * e->n_rows + 128) * e->nkp, true)) return -2;
+        for (int slot : e->const_slots) add_slot(e->const_slots2, slot);
+        // two tables per group (level 2: the pipeline's and its peak partner's); + 4 x 32 rows: the mu loop requests its table
+        // rows four steps ahead without checking for the end
+        if (e->n_xtab > 0 && (e->xtab.alloc(((size_t)e->n_xtab * 2 * e->n_rows + 128) * e->nkp, true) ||
+                              e->xtab_k.alloc((size_t)e->n_xtab * 3 * e->nkp, true))) return -2;
         {
-            std::vector<int32_t> xp((size_t)e->n_xtab + 1, -1);
-            for (auto& g : e->pk_groups) if (g.xtab >= 0) xp[g.xtab] = g.pipe;
-            std::vector<double> key((size_t)e->n_xtab * 6 + 1, std::nan(""));
-            if (e->d_xtab_pipe.upload(xp.data(), xp.size()) || e->xtab_key.upload(key.data(), key.size()) ||
-                e->xtab_dirty.alloc((size_t)e->n_xtab + 1, true)) return -2;
+            std::vector<int32_t> xp((size_t)e->n_xtab + 1, -1), xq((size_t)e->n_xtab + 1, -1);
+            for (auto& g : e->pk_groups) if (g.xtab >= 0) { xp[g.xtab] = g.pipe; xq[g.xtab] = g.peak_partner; }
+            std::vector<int32_t> tg;
+            for (size_t gi = 0; gi < e->pk_groups.size(); ++gi) if (e->pk_groups[gi].xtab >= 0) tg.push_back((int32_t)gi);
+            tg.push_back(-1);
+            if (e->d_tab_groups.upload(tg.data(), tg.size())) return -2;
+            std::vector<double> key((size_t)e->n_xtab * VMX_XTAB_KEY + 1, std::nan(""));
+            if (e->d_xtab_pipe.upload(xp.data(), xp.size()) || e->d_xtab_partner.upload(xq.data(), xq.size()) ||
+                e->xtab_key.upload(key.data(), key.size())) return -2;
         }
         e->const_slots.push_back(-1);
-        if (e->d_const_slots.upload(e->const_slots.data(), e->const_slots.size())) return -2;
+        e->const_slots2.push_back(-1);
+        if (e->d_const_slots.upload(e->const_slots.data(), e->const_slots.size()) ||
+            e->d_const_slots2.upload(e->const_slots2.data(), e->const_slots2.size())) return -2;
         e->const_slots.pop_back();
+        e->const_slots2.pop_back();
         e->pk_members.push_back(-1);
         if (e->d_pk_members.upload(e->pk_members.data(), e->pk_members.size())) return -2;
         // polynomial pipelines without any k-dependent walker term: their spline coefficients are linear in the Kaiser
@@ -1400,7 +1429,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         D.k_node_max = e->mu_nodes_on ? e->k_node_max : 0.0;
     }
     D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p; D.lnmu = e->lnmu.p;
-    D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.xtab = e->xtab.p; D.const_slots = e->d_const_slots.p; D.n_const_slots = 0; D.xtab_pipe = e->d_xtab_pipe.p; D.n_xtab = e->n_xtab; D.xtab_key = e->xtab_key.p; D.xtab_dirty = e->xtab_dirty.p; D.n_gk = (int)e->gk_tables.size();
+    D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.xtab = e->xtab.p; D.const_slots = e->d_const_slots.p; D.n_const_slots = 0; D.xtab_pipe = e->d_xtab_pipe.p; D.n_xtab = e->n_xtab; D.xtab_key = e->xtab_key.p; D.xtab_partner = e->d_xtab_partner.p; D.xtab_k = e->xtab_k.p; D.xtab_level = 0; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp; D.extrapolate = e->extrapolate ? 1 : 0;
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.inv_h[i] = 1.0 / e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
@@ -1659,12 +1688,15 @@ static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, i
     hipLaunchKernelGGL(k_metal_kron, dim3(B, (unsigned)it->metals.size()), dim3(256), shmem, e->cur, D, item, B);
 }
 
-static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
+static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
                      double* d_chi2 = nullptr, int32_t* d_status = nullptr, bool quad = false,
                      const double* theta_by_value = nullptr)
 {
     EngineDev D = e->dev;
-    D.n_const_slots = tab_mode ? (int)e->const_slots.size() : 0;
+    // tab_mode: table level of the P(k,mu) stage (EngineDev::xtab_level)
+    D.xtab_level = tab_mode;
+    D.n_const_slots = tab_mode >= 2 ? (int)e->const_slots2.size() : tab_mode ? (int)e->const_slots.size() : 0;
+    if (tab_mode >= 2) D.const_slots = e->d_const_slots2.p;
     if (zero_copy) {
         D.theta_host = e->dpin_theta; D.theta_copy = e->theta.p; D.src_lds = 1;
         D.chi2_host = e->dpin_chi2; D.status_host = e->dpin_status;
@@ -1709,8 +1741,21 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
             hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, e->n_rows, e->n_xtab), dim3(256), 0, e->stream, D);
         if (!e->pk_poly.empty())
             hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
-        const int tm = tab_mode ? 1 : 0;
-        if (n_groups == 0) {}
+        const int tm = tab_mode;
+        // level-2 groups run in their own kernel; the general one follows for whatever else the configuration has
+        int n_other = n_groups;
+        if (tab_mode >= 2 && e->n_xtab > 0) {
+            n_other = n_groups - e->n_xtab;
+            const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
+            if ((int64_t)B * e->n_xtab >= 24) {
+                if (e->pk_walkers_per_thread == 2 && B >= 64)
+                    hipLaunchKernelGGL((k_pk_tab2<64, 4, 2>), dim3((B + 1) / 2, e->n_xtab, (e->nk + 63) / 64), dim3(256), std::max(sh1, (size_t)4096 * sizeof(double)), e->stream, D, e->d_pk_groups.p, e->d_tab_groups.p, B);
+                else
+                    hipLaunchKernelGGL((k_pk_tab2<64, 4, 1>), dim3(B, e->n_xtab, (e->nk + 63) / 64), dim3(256), sh1, e->stream, D, e->d_pk_groups.p, e->d_tab_groups.p, B);
+            } else
+                hipLaunchKernelGGL((k_pk_tab2<16, 16, 1>), dim3(B, e->n_xtab, (e->nk + 15) / 16), dim3(256), sh1, e->stream, D, e->d_pk_groups.p, e->d_tab_groups.p, B);
+        }
+        if (n_other == 0) {}
         else {
             // the instantiation without the run-time-switched loops needs fewer registers (4 instead of 3 waves per
             // SIMD): use it whenever every group has a specialised loop
@@ -1984,11 +2029,11 @@ static int run_chain(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false
 }
 
 // run the chain for B walkers: replay a captured graph when one exists (or can be captured), else launch eagerly
-static int run_chain_cached(vmx_engine* e, int B, bool tab_mode, bool zero_copy = false, bool quad = false)
+static int run_chain_cached(vmx_engine* e, int B, int tab_mode, bool zero_copy = false, bool quad = false)
 {
-    tab_mode = tab_mode && e->n_xtab > 0;
+    if (e->n_xtab == 0) tab_mode = 0;
     if (!e->use_graphs || e->profiling) return run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad);
-    const int key = (((B * 2 + (tab_mode ? 1 : 0)) * 2 + (zero_copy ? 1 : 0)) * 2 + (e->direct ? 1 : 0)) * 2 + (quad ? 1 : 0);
+    const int key = (((B * 4 + tab_mode) * 2 + (zero_copy ? 1 : 0)) * 2 + (e->direct ? 1 : 0)) * 2 + (quad ? 1 : 0);
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
         if (e->graphs.size() >= 64) return run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad);
@@ -2157,17 +2202,17 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
         HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         const int n = B * e->n_params;
         hipLaunchKernelGGL(k_theta_affine, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->theta.p, e->d_blind.p, e->n_params, n);
-        if (run_chain_cached(e, B, e->const_hint && B >= 16, false, quad)) return -2;
+        if (run_chain_cached(e, B, B >= 16 ? e->const_hint : 0, false, quad)) return -2;
         if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
     } else if (B >= 64 || !e->use_graphs || e->profiling) {
         // large batches: eager launches cost nothing next to the kernels, and they let the chain read / write the
         // caller's buffers directly (a captured graph would pin their addresses)
-        const bool tab = e->const_hint && B >= 16 && e->n_xtab > 0;
+        const int tab = (B >= 16 && e->n_xtab > 0) ? e->const_hint : 0;
         if (run_chain(e, B, tab, false, d_theta, d_chi2, d_status, quad)) return -2;
     } else {
         HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-        if (run_chain_cached(e, B, e->const_hint && B >= 16, false, quad)) return -2;
+        if (run_chain_cached(e, B, B >= 16 ? e->const_hint : 0, false, quad)) return -2;
         if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
     }
@@ -2273,7 +2318,8 @@ int vmx_set_quadratic_form(vmx_engine* e, const double* theta_ref)
 int vmx_set_constant_nl_hint(vmx_engine* e, int32_t enabled)
 {
     REQUIRE(e, "vmx_set_constant_nl_hint");
-    e->const_hint = enabled != 0;
+    e->const_hint = enabled <= 0 ? 0 : enabled >= 2 ? 2 : 1;
+    if (e->no_tab2 && e->const_hint > 1) e->const_hint = 1;
     return 0;
 }
 
@@ -2308,10 +2354,13 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     if (!zero_copy)
         HIP_OK(hipMemcpyAsync(e->theta.p, e->pin_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
     // the D_NL * G table pays off once a batch shares its Arinyo parameters (checked here, on the host copy)
-    bool tab_mode = B >= 16 && e->n_xtab > 0;
-    for (int b = 1; b < B && tab_mode; ++b)
+    int tab_mode = (B >= 16 && e->n_xtab > 0) ? (e->no_tab2 ? 1 : 2) : 0;
+    for (int b = 1; b < B && tab_mode; ++b) {
         for (int slot : e->const_slots)
-            if (theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = false; break; }
+            if (theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = 0; break; }
+        for (int slot : e->const_slots2)
+            if (tab_mode == 2 && theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = 1; break; }
+    }
     const auto t_staged = std::chrono::steady_clock::now();
     // a single walker is latency-bound end to end: eager launches start the first kernel while the later ones are
     // still being enqueued, which a graph launch cannot (measured: 70 against 75 us per evaluation)

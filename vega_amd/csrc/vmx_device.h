@@ -132,12 +132,16 @@ struct EngineDev {
     const double* wl;           // [4][n_mu] L_ell(mu) (2 ell + 1) / n_mu
     const double* fv_x; const double* fv_f; int32_t fv_n;   // Voigt-profile HCD table
     const double* gk;           // [tables][n_mu][nkp]
-    double* xtab;               // [arinyo groups][n_mu][nkp]  D_NL(k,mu)^power * G(k,mu) of the batch's first walker
+    double* xtab;               // [arinyo groups][2][n_rows][nkp]  tables of the batch's first walker (see xtab_level)
     const int32_t* const_slots; int32_t n_const_slots;   // parameters asserted constant across the batch
-    // the table only changes with the Arinyo parameters: k_prologue compares them with the ones the table was built
-    // from (xtab_key [tables][6]); k_xtab recomputes a stale table and merely re-touches a current one (the rewrite keeps
-    // it cache-resident for k_pk_multipoles after the matrix streams of the previous evaluation)
-    const int32_t* xtab_pipe; int32_t n_xtab; double* xtab_key; int32_t* xtab_dirty;
+    // Table level of this evaluation (0: none).  1: D_NL^power * G - the batch shares its Arinyo parameters.  2: the batch
+    // also shares every Gaussian factor (smoothing, Gaussian velocity dispersion, peak broadening), so the table holds
+    // D_NL^power * G * exp(-k^2 (gb + (ga - gb) mu^2)) and a second one the same for the peak partner: the HCD factor is
+    // then the only exponential left per walker and (k, mu).
+    // A table only changes with those parameters: k_xtab compares them with the ones the table was built from (xtab_key
+    // [tables][VMX_XTAB_KEY], written by the chi2 kernel of the evaluation that built it), recomputes a stale table and
+    // leaves a current one alone.  xtab_k [tables][3][nkp]: per wavenumber the Arinyo part of e0, e2 and the error flag.
+    const int32_t* xtab_pipe; const int32_t* xtab_partner; int32_t n_xtab; int32_t xtab_level; double* xtab_key; double* xtab_k;
     const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
     int32_t n_gk;
     // fftlog / spline
@@ -269,15 +273,6 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
         t0 = s_theta;           // (no second trip over PCIe for walker 0)
     }
     __syncthreads();
-    for (int key = gid; D.n_const_slots > 0 && key < 6 * D.n_xtab; key += gridDim.x * blockDim.x) {
-        // table mode: which D_NL * G tables are stale?  (walker 0 stands for the batch; the others are checked below.)  One
-        // thread per key; k_chi2 clears the flags for the next evaluation.
-        const int g = key / 6, i = key % 6;
-        const vmx_pipe_desc& dg = s_pipes[D.xtab_pipe[g]].d;
-        const double v = dg.arinyo_slot[i] >= 0 ? t0[dg.arinyo_slot[i]] : 0.0;
-        if (!(D.xtab_key[g * 6 + i] == v)) atomicOr(&D.xtab_dirty[g], 1);       // keys start as NaN
-        D.xtab_key[g * 6 + i] = v;
-    }
     if (b >= B) return;
     if (!BYVAL && D.theta_host && !D.src_lds) {
         // the caller's device buffer is read in place; the threads of a walker leave the copy the later kernels use
@@ -489,8 +484,9 @@ __global__ void k_gk_moments(double* out, const double* table, const double* mu,
 // statement needs no wait states of its own.
 __device__ __forceinline__ double vmx_fma(double a, double b, double c)
 {
+    // (the constant addend in a scalar register pair: the exponential's coefficients then cost no vector registers)
     double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
 }
 
@@ -721,32 +717,77 @@ __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int j_lo, i
     wm[0] += m0; wm[1] += m1; wm[2] += m2; wm[3] += m3; wm[4] += m4; wm[5] += m5;
 }
 
-// D_NL(k,mu)^power * G(k,mu) from the Arinyo parameters of the batch's first walker (power_spectrum.py:435-479)
+#define VMX_XTAB_KEY 12
+// what the tables of group g depend on: {level, six Arinyo parameters, ga, gb of the pipeline, ga, gb of its peak partner}
+// of the batch's first walker (the scalars of k_prologue)
+__device__ inline void xtab_key_now(const EngineDev& D, int g, double* key)
+{
+    const int pipe = D.xtab_pipe[g], partner = D.xtab_partner[g];
+    const vmx_pipe_desc& d = D.pipes[pipe].d;
+    key[0] = (double)D.xtab_level;
+    for (int i = 0; i < 6; ++i) key[1 + i] = d.arinyo_slot[i] >= 0 ? D.theta[d.arinyo_slot[i]] : 0.0;
+    for (int i = 7; i < VMX_XTAB_KEY; ++i) key[i] = 0.0;
+    if (D.xtab_level >= 2) {
+        const double* sc = D.scal + (size_t)pipe * VMX_NS;
+        key[7] = sc[S_GA]; key[8] = sc[S_GB];
+        if (partner >= 0) { const double* scp = D.scal + (size_t)partner * VMX_NS; key[9] = scp[S_GA]; key[10] = scp[S_GB]; }
+    }
+}
+
+// the chi2 kernels record what the tables now hold (one thread, after every reader of the old key has finished)
+__device__ inline void xtab_key_store(const EngineDev& D)
+{
+    if (D.xtab_level <= 0) return;
+    for (int g = 0; g < D.n_xtab; ++g) {
+        double key[VMX_XTAB_KEY];
+        xtab_key_now(D, g, key);
+        for (int i = 0; i < VMX_XTAB_KEY; ++i) D.xtab_key[g * VMX_XTAB_KEY + i] = key[i];
+    }
+}
+
+// The tables of a batch that shares its non-linear (level 1) and Gaussian (level 2) parameters, from the first walker
+// (power_spectrum.py:435-479 D_NL, :526-556 smoothing, :382-417 peak broadening).  grid = (k blocks, table rows, groups).
 __global__ __launch_bounds__(256) void k_xtab(EngineDev D)
 {
     const int xtab = blockIdx.z, pipe = D.xtab_pipe[xtab];
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
     if (i >= D.nkp) return;
-    double* cell = D.xtab + ((size_t)xtab * D.n_rows + j) * D.nkp + i;
-    if (!D.xtab_dirty[xtab]) {
-        // built from the same parameters by an earlier batch: rewrite the value it holds (no arithmetic, same cache effect)
-        *cell = *(volatile double*)cell;
-        return;
-    }
-    double val = 0.0;
+    const size_t plane = (size_t)D.n_rows * D.nkp;
+    double* cell = D.xtab + (size_t)xtab * 2 * plane + (size_t)j * D.nkp + i;
+    double key[VMX_XTAB_KEY];
+    xtab_key_now(D, xtab, key);
+    bool stale = false;
+    for (int q = 0; q < VMX_XTAB_KEY; ++q) stale |= !(D.xtab_key[xtab * VMX_XTAB_KEY + q] == key[q]);      // keys start as NaN
+    if (!stale) return;      // built from the same parameters by an earlier batch
+    double val = 0.0, val_q = 0.0;
     if (i < D.nk) {
         const vmx_pipe_desc& d = D.pipes[pipe].d;
-        const double* t = D.theta;
         const double k = D.k[i], d2 = D.delta2[i];
-        const double q1 = t[d.arinyo_slot[0]], q2 = d.arinyo_slot[1] >= 0 ? t[d.arinyo_slot[1]] : 0.0;
-        const double g = q1 * d2 + q2 * d2 * d2;
-        const double v = pow(k / t[d.arinyo_slot[2]], t[d.arinyo_slot[3]]);
-        const double kp = k / t[d.arinyo_slot[5]];
-        const double m = vmx_exp(t[d.arinyo_slot[4]] * D.lnmu[j]);
-        val = exp(fmin(d.arinyo_power * (g * (1.0 - v * m) - kp * kp), 709.0));
+        const double g = key[1] * d2 + key[2] * d2 * d2;
+        const double gv = g * pow(k / key[3], key[4]);
+        const double kp = k / key[6];
+        const double gp = g - kp * kp;
+        const double m = vmx_exp(key[5] * D.lnmu[j]);
+        val = exp(fmin(d.arinyo_power * fma(-gv, m, gp), 709.0));
         if (d.gk_table >= 0) val *= D.gk[((size_t)d.gk_table * D.n_rows + j) * D.nkp + i];
+        if (D.xtab_level >= 2) {
+            const double mu = D.mu[j], mu2 = mu * mu, k2 = k * k;
+            val *= vmx_exp(-k2 * fma(key[7] - key[8], mu2, key[8]));
+            val_q = val * vmx_exp(-k2 * fma((key[9] - key[7]) - (key[10] - key[8]), mu2, key[10] - key[8]));
+        }
+        if (j == 0) {
+            // per wavenumber: the Arinyo part of e0, e2 (the underflow bound of k_pk_multipoles) and VegaArinyoError - NaN or
+            // Inf in exp(growth (1 - pec) - pressure) anywhere on the grid (power_spectrum.py:466-469); the exponent is
+            // monotonic in mu^bv, so its extremes sit at the two ends of the mu grid
+            double* kk = D.xtab_k + (size_t)xtab * 3 * D.nkp + i;
+            kk[0] = d.arinyo_power * gp;
+            kk[D.nkp] = -d.arinyo_power * gv;
+            const double lo = fma(-gv, vmx_exp(key[5] * D.lnmu[0]), gp), hi = fma(-gv, vmx_exp(key[5] * D.lnmu[D.n_mu - 1]), gp);
+            kk[2 * D.nkp] = (!(lo < 709.0) || !(hi < 709.0)) ? 1.0 : 0.0;
+        }
     }
     *cell = val;
+    if (D.xtab_level >= 2) cell[plane] = val_q;
 }
 
 // mu loop against the tabulated D_NL * G: no exponential is left in the loop - the HCD factor, the Gaussian
@@ -834,7 +875,7 @@ __device__ __forceinline__ void pk_tab_loop(const PkThread& T, double e0g, int m
 // The extra quadrature nodes (rows n_mu .. n_rows of the tables, weights D.node_w) of a core / plain pipeline: direct
 // evaluation - the nodes are not equally spaced, so nothing advances as a progression here.  tab: the D_NL * G table
 // replaces exp(Arinyo) * G.  Adds W_j mu_j^(2n) P(k, mu_j) to s (and the peak partner's to q).
-template <int MS, int KM, bool ARINYO, bool PAIRED, int NVD, bool TAB>
+template <int MS, int KM, bool ARINYO, bool PAIRED, int NVD, int TAB>
 __device__ __forceinline__ void pk_extra_nodes(const EngineDev& D, const PkThread& T, double e0g, const double* s_mubv,
                                                int ms, double* s, double* q)
 {
@@ -850,16 +891,16 @@ __device__ __forceinline__ void pk_extra_nodes(const EngineDev& D, const PkThrea
         const double g = T.gk != nullptr ? T.gk[((size_t)row - ms) * T.gk_row] : 1.0;
         double A1 = fma(T.c1_1, mu2, T.c0_1);
         if (hcd1) A1 = fma(vmx_exp(fk * mu), fma(T.hbb, mu2, T.hb), A1);
-        const double AA = same ? A1 * A1 : A1 * fma(T.c1_2, mu2, T.c0_2);
+        double AA = same ? A1 * A1 : A1 * fma(T.c1_2, mu2, T.c0_2);
+        if (NVD == 1) AA *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));
+        AA *= w;
         double val;
-        if (TAB) val = AA * (g * vmx_exp(fma(T.e1, mu2, e0g)));
+        if (TAB == 1) val = AA * (g * vmx_exp(fma(T.e1, mu2, e0g)));
         else {
             double E = fma(T.e1, mu2, T.e0);
             if (ARINYO) E = fma(T.e2, s_mubv[row], E);
             val = AA * vmx_exp(E) * g;
         }
-        if (NVD == 1) val *= vmx_rsqrt(fma(k2vd2, mu2, 1.0));
-        val *= w;
         const double mu4 = mu2 * mu2, mu6 = mu4 * mu2;
         s0 += val; s1 = fma(mu2, val, s1); s2 = fma(mu4, val, s2); s3 = fma(mu6, val, s3);
         if (PAIRED) {
@@ -910,6 +951,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     double* s_mubv = smem + 2048 + (size_t)wb * D.n_rows;      // [WB][n_rows]  mu^bv (Arinyo), one table per walker
     const bool use_tab = tab_mode && groups[blockIdx.y].xtab >= 0 &&
                          (groups[blockIdx.y].variant == PKV_AUTO_CORE || groups[blockIdx.y].variant == PKV_CROSS_CORE);
+    if (tab_mode >= 2 && use_tab) return;             // (k_pk_tab2 serves this group; block-uniform)
     v2d* s_mu24 = (v2d*)(smem + (mu_tab_off >= 0 ? mu_tab_off : 0));        // [n_mu] (mu^2, mu^4) when the launch has room
     if (mu_tab_off >= 0 && (use_tab || groups[blockIdx.y].variant == PKV_SHARED_W))
         for (int j = threadIdx.x; j < D.n_mu; j += 256) { const double m = D.mu[j], m2 = m * m; s_mu24[j] = (v2d){m2, m2 * m2}; }
@@ -978,7 +1020,13 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     T.e0 = -k2 * gb; T.e1 = -k2 * (ga - gb); T.e2 = 0.0;
     T.noexp = (ga == 0.0) && (gb == 0.0);
     bool bad = false;
-    if (T.arinyo) {
+    if (T.arinyo && use_tab) {
+        // the Arinyo terms of this wavenumber were formed with the table (k_xtab): the batch shares them
+        const double* kk = D.xtab_k + (size_t)groups[blockIdx.y].xtab * 3 * D.nkp + ic;
+        T.e0 += kk[0];
+        T.e2 = kk[D.nkp];
+        bad = kk[2 * D.nkp] != 0.0;
+    } else if (T.arinyo) {
         const double apow = d.arinyo_power;
         const double d2 = D.delta2[ic];
         const double ar_g = sc[S_AQ1] * d2 + sc[S_AQ2] * d2 * d2;
@@ -1096,7 +1144,8 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     const int n_ranges = node_mode ? 2 : 1;
     if (use_tab) {
         if (live_block) {
-            T.gk = D.xtab + ((size_t)xt * D.n_rows + ms) * D.nkp + ic;
+            const size_t plane = (size_t)D.n_rows * D.nkp;
+            T.gk = D.xtab + (size_t)xt * 2 * plane + (size_t)ms * D.nkp + ic;
             T.gk_row = (size_t)D.nkp; T.gk_stride = (size_t)MS * D.nkp;
             for (int rg = 0; rg < n_ranges; ++rg) {
                 const int j_lo = rg == 0 ? 0 : n_mu - D.mu_hi, j_hi = (node_mode && rg == 0) ? D.mu_lo : n_mu;
@@ -1104,8 +1153,8 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
                 else pk_tab_loop<MS, WB, KM_FIRST_HCD, true, 1>(T, -k2 * gb, ms, j_lo, j_hi, inv_nmu, s_mu24, s, q);
             }
             if (node_mode) {
-                if (variant == PKV_AUTO_CORE) pk_extra_nodes<MS, KM_SAME_HCD, true, true, 0, true>(D, T, -k2 * gb, s_mubv, ms, s, q);
-                else pk_extra_nodes<MS, KM_FIRST_HCD, true, true, 1, true>(D, T, -k2 * gb, s_mubv, ms, s, q);
+                if (variant == PKV_AUTO_CORE) pk_extra_nodes<MS, KM_SAME_HCD, true, true, 0, 1>(D, T, -k2 * gb, s_mubv, ms, s, q);
+                else pk_extra_nodes<MS, KM_FIRST_HCD, true, true, 1, 1>(D, T, -k2 * gb, s_mubv, ms, s, q);
             }
         }
     } else if (live_block) {
@@ -1130,11 +1179,11 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     }
     if (node_mode)
         switch (variant) {
-            case PKV_AUTO_CORE: pk_extra_nodes<MS, KM_SAME_HCD, true, true, 0, false>(D, T, 0.0, s_mubv, ms, s, q); break;
-            case PKV_CROSS_CORE: pk_extra_nodes<MS, KM_FIRST_HCD, true, true, 1, false>(D, T, 0.0, s_mubv, ms, s, q); break;
-            case PKV_PLAIN_SAME: pk_extra_nodes<MS, KM_SAME_PLAIN, false, false, 0, false>(D, T, 0.0, s_mubv, ms, s, q); break;
-            case PKV_PLAIN_PAIR: pk_extra_nodes<MS, KM_BOTH_PLAIN, false, false, 0, false>(D, T, 0.0, s_mubv, ms, s, q); break;
-            case PKV_PLAIN_PAIR_VD: pk_extra_nodes<MS, KM_BOTH_PLAIN, false, false, 1, false>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_AUTO_CORE: pk_extra_nodes<MS, KM_SAME_HCD, true, true, 0, 0>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_CROSS_CORE: pk_extra_nodes<MS, KM_FIRST_HCD, true, true, 1, 0>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_PLAIN_SAME: pk_extra_nodes<MS, KM_SAME_PLAIN, false, false, 0, 0>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_PLAIN_PAIR: pk_extra_nodes<MS, KM_BOTH_PLAIN, false, false, 0, 0>(D, T, 0.0, s_mubv, ms, s, q); break;
+            case PKV_PLAIN_PAIR_VD: pk_extra_nodes<MS, KM_BOTH_PLAIN, false, false, 1, 0>(D, T, 0.0, s_mubv, ms, s, q); break;
             default: break;
         }
     }
@@ -1167,6 +1216,224 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
             }
         }
     }
+}
+
+// The P(k,mu) stage of the core groups at table level 2 (EngineDev::xtab_level), as its own lean kernel: per walker and
+// (k, mu) node only the tracer amplitudes are left -
+//   P_s = P_lin A1 A2 T_s(k,mu) [/ sqrt(1 + (k mu sigma_v)^2)],  P_q = the same with the peak partner's table T_q,
+//   A1 = b1 (1 + beta1 mu^2) + F_hcd(k mu) b_hcd (1 + beta_hcd mu^2)              (power_spectrum.py:163-222, :263-380)
+// - so the kernel needs half the registers of k_pk_multipoles (its other loops carry the exponentials' constants) and
+// twice the waves hide the latency of the two table streams.  Block = KT wavenumbers x MS mu-slices of NW walkers (each
+// thread evaluates its nodes for NW walkers: one pair of table entries serves all of them).
+// grid = (ceil(B / NW), level-2 groups, k tiles); LDS: (mu^2, mu^4) of the midpoints and {mu, mu^2, mu^4, w} of the extra
+// nodes, reused as the [NW][8][256] reduction scratch.
+template <int KT, int MS, int NW, bool CROSS>
+__device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const PkGroup& G, int B)
+{
+    extern __shared__ double smem[];
+    // (the reduction scratch takes the place of the node tables once the loops are done: five or six blocks share a CU)
+    double* s_red = smem;
+    v2d* s_mu24 = (v2d*)smem;
+    v4d* s_node = (v4d*)(smem + 2 * D.n_mu);
+    const int p = G.pipe, pp = G.peak_partner, xt = G.xtab;
+    constexpr bool cross = CROSS;
+    const vmx_pipe_desc& d = D.pipes[p].d;
+    const int kk = threadIdx.x % KT;
+    const int ms = (KT == 64) ? __builtin_amdgcn_readfirstlane(threadIdx.x / KT) : (int)(threadIdx.x / KT);
+    const int i = blockIdx.z * KT + kk;
+    const bool valid = i < D.nk;
+    const int ic = valid ? i : D.nk - 1;
+    const int n_mu = D.n_mu;
+    const double inv_nmu = 1.0 / (double)n_mu;
+    // k tiles up to k_node_max take the node rule: the first mu_lo and the last mu_hi midpoints plus the extra nodes
+    const bool node_mode = D.n_extra > 0 && D.k[min((int)(blockIdx.z + 1) * KT, D.nk) - 1] <= D.k_node_max;
+    const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
+    for (int j = threadIdx.x; j < n_mu; j += 256)
+        if (j < lo_end || j >= hi_beg) { const double m = D.mu[j], m2 = m * m; s_mu24[j] = (v2d){m2, m2 * m2}; }
+    if (node_mode)
+        for (int j = threadIdx.x; j < D.n_extra; j += 256) {
+            const double m = D.mu[n_mu + j], m2 = m * m;
+            s_node[j] = (v4d){m, m2, m2 * m2, D.node_w[j]};
+        }
+
+    const double k = D.k[ic], k2 = k * k;
+    const double dmu = (double)MS * inv_nmu;
+    const double* kx = D.xtab_k + (size_t)xt * 3 * D.nkp + ic;
+    const bool bad = kx[2 * D.nkp] != 0.0;
+    double c01[NW], c11[NW], c02[NW], c12[NW], hb[NW], hbb[NW], fk[NW], Fq[NW], k2vd2[NW];
+    bool ok[NW];
+    double e_max = -1e300;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        int b = blockIdx.x * NW + w;
+        ok[w] = b < B;
+        if (!ok[w]) b = B - 1;                        // a surplus walker slot shadows the last walker and stores nothing
+        const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+        const double* scp = D.scal + ((size_t)b * D.n_pipe + pp) * VMX_NS;
+        c01[w] = sc[S_BIAS1]; c02[w] = sc[S_BIAS2]; c11[w] = sc[S_BB1]; c12[w] = sc[S_BB2];
+        if (d.uvb || d.heii) {
+            // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261)
+            double add = 0.0;
+            if (d.uvb) { const double x = k * sc[S_UV_LAM]; const double W = atan(x) / x; add += sc[S_UV_BG] * W / (1.0 + sc[S_UV_BP] * W); }
+            if (d.heii) { const double x = k * sc[S_HE_LAM]; const double W = atan(x) / x; add += sc[S_HE_BG] * W / (1.0 + sc[S_UV_BP] * W); }
+            if (d.tracer[0].is_lya) c01[w] += add;
+            if (d.tracer[1].is_lya) c02[w] += add;
+        }
+        hb[w] = sc[S_HCD_B]; hbb[w] = sc[S_HCD_BB];
+        fk[w] = -sc[S_HCD_L0] * k;
+        Fq[w] = vmx_exp(fk[w] * dmu);
+        k2vd2[w] = k2 * sc[S_VD2];
+        // underflow bound of the exponents over mu in (0, 1] (as in k_pk_multipoles)
+        const double ga = sc[S_GA], gb = sc[S_GB], dga = scp[S_GA] - ga, dgb = scp[S_GB] - gb;
+        const double e0 = fma(-k2, gb, kx[0]), e1 = -k2 * (ga - gb), e2 = kx[D.nkp];
+        const double p0 = -k2 * dgb, p1 = -k2 * (dga - dgb);
+        e_max = fmax(e_max, e0 + fmax(e1, 0.0) + fmax(e2, 0.0) + fmax(p0 + fmax(p1, 0.0), 0.0));
+    }
+    const bool live_block = __syncthreads_or(!(e_max < -200.0)) != 0;      // (also orders the LDS tables before the loops)
+    if (live_block && threadIdx.x == 0) atomicMax(D.k_live, min((int)(blockIdx.z + 1) * KT, D.nk));
+
+    double s[NW][4], q[NW][4];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { s[w][n] = 0.0; q[w][n] = 0.0; }
+
+    if (live_block) {
+        const size_t plane = (size_t)D.n_rows * D.nkp, row = (size_t)D.nkp, stride = (size_t)MS * D.nkp;
+        const double* base = D.xtab + (size_t)xt * 2 * plane + (size_t)ms * row + ic;
+        // one node for all NW walkers: AA = A1 A2 [/ sqrt(..)] [x weight]; the pipeline's table entry g, its partner's h
+#define VMX_TAB2_NODE(MU2, MU4, WGT, G_, H_)                                                                          \
+        {                                                                                                             \
+            const double mu6 = (MU4) * (MU2);                                                                         \
+            _Pragma("unroll")                                                                                         \
+            for (int w = 0; w < NW; ++w) {                                                                            \
+                const double A1 = fma(F[w], fma(hbb[w], (MU2), hb[w]), fma(c11[w], (MU2), c01[w]));                   \
+                double AA = cross ? A1 * fma(c12[w], (MU2), c02[w]) : A1 * A1;                                        \
+                if (cross) AA *= vmx_rsqrt(fma(k2vd2[w], (MU2), 1.0));                                                \
+                if (WGT) AA *= wgt;                                                                                   \
+                const double val = AA * (G_), vp = AA * (H_);                                                         \
+                s[w][0] += val; s[w][1] = fma((MU2), val, s[w][1]); s[w][2] = fma((MU4), val, s[w][2]); s[w][3] = fma(mu6, val, s[w][3]); \
+                q[w][0] += vp; q[w][1] = fma((MU2), vp, q[w][1]); q[w][2] = fma((MU4), vp, q[w][2]); q[w][3] = fma(mu6, vp, q[w][3]);     \
+            }                                                                                                         \
+        }
+        double F[NW];
+        const double wgt = 1.0;
+        // midpoint ranges: both table streams run four steps ahead of their use, in fixed registers used in turn (a rotating
+        // window would make every use wait for ALL outstanding loads); rows past a range's end exist (other rows / padding)
+        for (int rg = 0; rg < (node_mode ? 2 : 1); ++rg) {
+            const int j_lo = rg == 0 ? 0 : hi_beg, j_hi = rg == 0 ? lo_end : n_mu;
+            const double* tab = base + (size_t)j_lo * row;
+            double g0 = *tab, g1 = tab[stride], g2 = tab[2 * stride], g3 = tab[3 * stride];
+            double h0 = tab[plane], h1 = tab[plane + stride], h2 = tab[plane + 2 * stride], h3 = tab[plane + 3 * stride];
+            tab += 4 * stride;
+            for (int j0 = j_lo + ms; j0 < j_hi; j0 += MS * PK_REANCHOR) {
+                // exact anchor of the HCD progression F = exp(-L0 k mu) along this thread's mu sequence
+#pragma unroll
+                for (int w = 0; w < NW; ++w) F[w] = vmx_exp(fk[w] * (((double)j0 + 0.5) * inv_nmu));
+                const int jend = min(j0 + MS * PK_REANCHOR, j_hi);
+                const int steps = (jend - j0 + MS - 1) / MS;
+#define VMX_TAB2_STEP(GREG, HREG, J)                                                                                  \
+                {                                                                                                     \
+                    const v2d mm = s_mu24[J];                                                                         \
+                    const double g = GREG, h = HREG;                                                                  \
+                    GREG = *tab; HREG = tab[plane]; tab += stride;                                                    \
+                    VMX_TAB2_NODE(mm.x, mm.y, false, g, h)                                                            \
+                    _Pragma("unroll")                                                                                 \
+                    for (int w = 0; w < NW; ++w) F[w] *= Fq[w];                                                       \
+                }
+                int j = j0;
+                for (int it = 0; it < steps / 4; ++it, j += 4 * MS) {
+                    VMX_TAB2_STEP(g0, h0, j)
+                    VMX_TAB2_STEP(g1, h1, j + MS)
+                    VMX_TAB2_STEP(g2, h2, j + 2 * MS)
+                    VMX_TAB2_STEP(g3, h3, j + 3 * MS)
+                }
+                if (steps % 4 > 0) VMX_TAB2_STEP(g0, h0, j)
+                if (steps % 4 > 1) VMX_TAB2_STEP(g1, h1, j + MS)
+                if (steps % 4 > 2) VMX_TAB2_STEP(g2, h2, j + 2 * MS)
+#undef VMX_TAB2_STEP
+            }
+        }
+        if (node_mode) {
+            // the extra nodes (rows n_mu + jj): not equally spaced, so the HCD factor is exponentiated directly; the table
+            // entries run four nodes ahead as above
+            const double* tab = base + (size_t)n_mu * row;
+            double g0 = *tab, g1 = tab[stride], g2 = tab[2 * stride], g3 = tab[3 * stride];
+            double h0 = tab[plane], h1 = tab[plane + stride], h2 = tab[plane + 2 * stride], h3 = tab[plane + 3 * stride];
+            tab += 4 * stride;
+            const int steps = D.n_extra > ms ? (D.n_extra - ms + MS - 1) / MS : 0;
+#define VMX_TAB2_XSTEP(GREG, HREG, JJ)                                                                                \
+            {                                                                                                         \
+                const v4d nd = s_node[JJ];                                                                            \
+                const double wgt = nd.w;                                                                              \
+                const double g = GREG, h = HREG;                                                                      \
+                GREG = *tab; HREG = tab[plane]; tab += stride;                                                        \
+                _Pragma("unroll")                                                                                     \
+                for (int w = 0; w < NW; ++w) F[w] = vmx_exp(fk[w] * nd.x);                                            \
+                VMX_TAB2_NODE(nd.y, nd.z, true, g, h)                                                                 \
+            }
+            int jj = ms;
+            for (int it = 0; it < steps / 4; ++it, jj += 4 * MS) {
+                VMX_TAB2_XSTEP(g0, h0, jj)
+                VMX_TAB2_XSTEP(g1, h1, jj + MS)
+                VMX_TAB2_XSTEP(g2, h2, jj + 2 * MS)
+                VMX_TAB2_XSTEP(g3, h3, jj + 3 * MS)
+            }
+            if (steps % 4 > 0) VMX_TAB2_XSTEP(g0, h0, jj)
+            if (steps % 4 > 1) VMX_TAB2_XSTEP(g1, h1, jj + MS)
+            if (steps % 4 > 2) VMX_TAB2_XSTEP(g2, h2, jj + 2 * MS)
+#undef VMX_TAB2_XSTEP
+        }
+#undef VMX_TAB2_NODE
+    }
+
+    // moments -> Legendre multipoles  P_ell = (2 ell + 1) / n_mu * sum_n c_{ell n} M_n  (pktoxi.py:37,55,138)
+    __syncthreads();            // every wave is done with the node tables
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const double* m = half ? q[w] : s[w];
+            double* r = s_red + (size_t)w * 2048 + (half * 4) * 256 + threadIdx.x;
+            r[0] = m[0] * inv_nmu;
+            r[256] = (7.5 * m[1] - 2.5 * m[0]) * inv_nmu;
+            r[512] = (39.375 * m[2] - 33.75 * m[1] + 3.375 * m[0]) * inv_nmu;
+            r[768] = (187.6875 * m[3] - 255.9375 * m[2] + 85.3125 * m[1] - 4.0625 * m[0]) * inv_nmu;
+        }
+    __syncthreads();
+    if (threadIdx.x >= KT || !valid) return;
+    double damp = 1.0;
+    if (d.damping_scale > 0.0) damp = exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
+    const size_t ncols = (size_t)B * D.n_active;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (!ok[w]) continue;
+        const int b = blockIdx.x * NW + w;
+        if (bad) atomicOr(&D.status[b], VMX_STATUS_ARINYO);
+        for (int half = 0; half < 2; ++half) {
+            const int pipe = half ? pp : p;
+            const int kind = D.pipes[pipe].d.pk_lin_kind;
+            const double pk = damp * ((D.pk_direct && kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i]
+                                                                                 : D.pklin[(size_t)kind * D.nkp + i]);
+            const size_t col = (size_t)b * D.n_active + D.pipes[pipe].col;
+            for (int e = 0; e < D.n_ell; ++e) {
+                double sum = 0.0;
+                for (int qq = 0; qq < MS; ++qq) sum += s_red[(size_t)w * 2048 + (half * 4 + e) * 256 + qq * KT + kk];
+                D.pl[((size_t)e * ncols + col) * D.nkp + i] = pk * sum;
+            }
+        }
+    }
+}
+
+#ifndef VMX_TAB2_BLOCKS
+#define VMX_TAB2_BLOCKS 5
+#endif
+template <int KT, int MS, int NW>
+__global__ __launch_bounds__(256, NW == 1 ? VMX_TAB2_BLOCKS : 2) void k_pk_tab2(EngineDev D, const PkGroup* groups, const int32_t* tab_groups, int B)
+{
+    const PkGroup& G = groups[tab_groups[blockIdx.y]];
+    if (G.variant == PKV_CROSS_CORE) pk_tab2_body<KT, MS, NW, true>(D, G, B);
+    else pk_tab2_body<KT, MS, NW, false>(D, G, B);
 }
 
 // Pipelines whose only mu dependence is the Kaiser polynomial times the static G table (metal pairs without
@@ -1482,7 +1749,7 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
         if (D.done_host) { __threadfence_system(); *D.done_host = D.done_seq; }      // (set for single-walker calls only)
         if (b == 0) {
             D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
-            for (int g2 = 0; g2 < D.n_xtab; ++g2) D.xtab_dirty[g2] = 0;
+            xtab_key_store(D);
         }
     }
 }
@@ -2471,7 +2738,7 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabI
         if (D.done_host) { __threadfence_system(); *D.done_host = D.done_seq; }      // (set for single-walker calls only)
         if (b == 0) {       // the next evaluation starts from an empty window and clean table flags
             D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
-            for (int g = 0; g < D.n_xtab; ++g) D.xtab_dirty[g] = 0;
+            xtab_key_store(D);
         }
     }
 }

@@ -748,10 +748,11 @@ class Engine:
     def sync(self):
         self._check(self.lib.vmx_sync(self._h))
 
-    def set_constant_nl_hint(self, on=True):
-        """For ``eval_device``: the caller asserts that the Arinyo parameters are identical for all walkers of a
-        batch (violations are flagged per walker, never silently wrong)."""
-        self._check(self.lib.vmx_set_constant_nl_hint(self._h, int(bool(on))))
+    def set_constant_nl_hint(self, on=True, gaussian=False):
+        """For ``eval_device``: the caller asserts that the Arinyo parameters - with ``gaussian`` also the smoothing,
+        peak-broadening and Gaussian velocity-dispersion parameters - are identical for all walkers of a batch
+        (violations are flagged per walker, never silently wrong)."""
+        self._check(self.lib.vmx_set_constant_nl_hint(self._h, 0 if not on else 2 if gaussian else 1))
 
     def stream_handle(self):
         """hipStream_t of the engine as an integer (for ``torch.cuda.ExternalStream``)."""
