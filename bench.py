@@ -540,9 +540,8 @@ def main():
             if kclass == 'pk_multipoles':
                 # (k, mu) points the stage evaluates per walker and item: the live wavenumbers of the step (blocks whose
                 # every value underflows are skipped) x the mu nodes of each - 276 where the node rule applies, 1000 above
-                k_live, k_node_max, n_nodes = eng.debug_read(4, 0, 3)
-                kk = prob.k[:int(k_live)]
-                points = float(np.where(kk <= k_node_max, n_nodes, 1000).sum())
+                k_live, k_node_max, n_nodes, k_rule = eng.debug_read(4, 0, 4)
+                points = float(np.where(np.arange(int(k_live)) < k_rule, n_nodes, 1000).sum())
                 flops = 0.0
                 for item in prob.items.values():
                     kind = 'auto' if item.tracer1.name == item.tracer2.name else 'cross'

@@ -6,9 +6,9 @@ if len(sys.argv) > 1:
     sys.path.insert(0, str(REPO))
     import numpy as np
     from vega_amd import VegaInterface, synthetic
-    vega = VegaInterface('configs/joint/main.ini', search_dirs=[REPO / 'tests' / 'golden'], max_batch=256)
+    vega = VegaInterface('configs/joint/main.ini', search_dirs=[REPO / 'tests' / 'golden'], max_batch=int(os.environ.get('PKB', '256')))
     eng = vega.engine
-    theta = synthetic.walkers(eng.low.theta0, eng.names, 256, seed=3,
+    theta = synthetic.walkers(eng.low.theta0, eng.names, int(os.environ.get('PKB', '256')), seed=3,
                               varied=['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO',
                                       'drp_QSO', 'bias_hcd', 'beta_hcd', 'L0_hcd'])
     for _ in range(3):
@@ -19,16 +19,18 @@ if len(sys.argv) > 1:
         eng.eval(theta)
     t = eng.timings(reset=True)
     np.save(sys.argv[1], chi2)
-    print(json.dumps({k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in t.items() if v[1]}))
+    print(json.dumps({k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in t.items() if v[1]}), list(eng.debug_read(4, 0, 4)))
     sys.exit(0)
 out = REPO / 'gpurun_out'
 ref = None
 import numpy as np
-for label, env in (('level1', {'VMX_NO_TAB2': '1'}), ('level2_nw1', {}), ('level2_nw2', {'VMX_PK_NW': '2'}), ('notab_exact', {'VMX_NO_TAB2': '1', 'VMX_EXACT_MU': '1'})):
+for label, env in (('level1', {'VMX_NO_TAB2': '1'}), ('level2_nw1', {'VMX_PK_NW': '1'}), ('level2_nw2', {}), ('occ3', {'VMX_TAB2_LDS': '45000'}), ('occ2', {'VMX_TAB2_LDS': '60000'}), ('occ1', {'VMX_TAB2_LDS': '64000'}),
+                   ('B1024', {'PKB': '1024'}), ('B384', {'PKB': '384'})):
     f = out / f'pkmode_{label}.npy'
     r = subprocess.run([sys.executable, __file__, str(f)], env={**os.environ, **env}, capture_output=True, text=True)
     print(label, r.stdout.strip().split('\n')[-1] if r.stdout else r.stderr[-2000:])
     c = np.load(f)
     if ref is None:
         ref = c
-    print('   max rel chi2 diff vs level1:', float(np.abs(c / ref - 1).max()))
+    if c.size == ref.size:
+        print('   max rel chi2 diff vs level1:', float(np.abs(c / ref - 1).max()))

@@ -232,6 +232,70 @@ def test_constant_nl_table_mode():
     vega.close()
 
 
+def test_level2_table_mode():
+    """Batches that also share every Gaussian factor (smoothing, peak broadening) run against level-2 tables in the
+    dedicated kernel (k_pk_tab2, one or two walkers per thread): same chi2 as the per-walker path and the level-1 table
+    to rounding, equal to the oracle; the tables follow the shared parameters between batches; a walker that breaks the
+    device-side promise is flagged."""
+    import torch
+    from oracle import vega_cpu as oc
+    from vega_amd import synthetic
+    from vega_amd.engine import STATUS_NOT_CONSTANT
+    vega = _engine('joint', max_batch=96)
+    eng = vega.engine
+    varied = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO', 'drp_QSO',
+              'bias_hcd', 'beta_hcd', 'L0_hcd', 'bao_amp']
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 75, varied=varied, seed=33)       # odd: a half-filled pair
+    plain = np.concatenate([eng.eval(theta[lo:lo + 8])[0] for lo in range(0, 75, 8)])      # < 16: per-walker path
+    lvl2 = eng.eval(theta)[0]                          # 75 >= 64: two walkers per thread
+    np.testing.assert_allclose(lvl2, plain, rtol=1e-11)
+    np.testing.assert_allclose(eng.eval(theta[:40])[0], plain[:40], rtol=1e-11)            # one walker per thread
+    np.testing.assert_allclose(eng.eval(theta[:17])[0], plain[:17], rtol=1e-11)            # 16 x 16 shape
+    for i in (0, 41, 74):
+        assert lvl2[i] == pytest.approx(oc.chi2(vega.problem, dict(zip(eng.names, theta[i]))), rel=CHI2_RTOL)
+    # one walker with its own smoothing: the batch falls back to level 1 by itself
+    mixed = theta.copy()
+    mixed[9, eng.low.slot['par_sigma_smooth']] *= 1.1
+    got = eng.eval(mixed)[0]
+    ref = np.concatenate([eng.eval(mixed[lo:lo + 8])[0] for lo in range(0, 75, 8)])
+    np.testing.assert_allclose(got, ref, rtol=1e-11)
+    assert abs(got[9] / lvl2[9] - 1) > 1e-7
+    np.testing.assert_allclose(np.delete(got, 9), np.delete(lvl2, 9), rtol=1e-11)
+    # new shared smoothing / peak broadening between batches: the tables are rebuilt, and found again afterwards
+    other = theta.copy()
+    other[:, eng.low.slot['per_sigma_smooth']] *= 1.07
+    other[:, eng.low.slot['sigmaNL_par']] *= 0.93
+    got = eng.eval(other)[0]
+    ref = np.concatenate([eng.eval(other[lo:lo + 8])[0] for lo in range(0, 75, 8)])
+    np.testing.assert_allclose(got, ref, rtol=1e-11)
+    assert np.abs(got / lvl2 - 1).max() > 1e-7
+    np.testing.assert_array_equal(eng.eval(theta)[0], lvl2)
+    np.testing.assert_array_equal(eng.eval(theta)[0], lvl2)
+    # device entry point, level-2 promise, one walker breaking it through a Gaussian parameter
+    bad = theta.copy()
+    bad[5, eng.low.slot['per_sigma_smooth']] *= 1.01
+    dev = torch.device('cuda', 0)
+    d_theta = torch.from_numpy(bad).to(dev)
+    d_chi2 = torch.zeros(75, dtype=torch.float64, device=dev)
+    d_status = torch.zeros(75, dtype=torch.int32, device=dev)
+    eng.set_constant_nl_hint(True, gaussian=True)
+    eng.eval_device(d_theta.data_ptr(), 75, d_chi2.data_ptr(), None, d_status.data_ptr())
+    eng.sync()
+    status, chi2 = d_status.cpu().numpy(), d_chi2.cpu().numpy()
+    assert status[5] & STATUS_NOT_CONSTANT and chi2[5] == 1e100
+    ok = np.arange(75) != 5
+    assert not status[ok].any()
+    np.testing.assert_allclose(chi2[ok], lvl2[ok], rtol=1e-11)
+    # the level-1 promise holds for the same batch
+    eng.set_constant_nl_hint(True)
+    eng.eval_device(d_theta.data_ptr(), 75, d_chi2.data_ptr(), None, d_status.data_ptr())
+    eng.sync()
+    eng.set_constant_nl_hint(False)
+    assert not d_status.cpu().numpy().any()
+    assert d_chi2.cpu().numpy()[5] == pytest.approx(oc.chi2(vega.problem, dict(zip(eng.names, bad[5]))), rel=CHI2_RTOL)
+    vega.close()
+
+
 def test_every_batch_size_takes_a_consistent_path():
     """The product kernels switch with the batch size (single-walker streaming kernel fused with assemble / post,
     small-batch streaming, MFMA tiles with ragged edges and split-K, per-batch D_NL table from 16 walkers on, zero-copy

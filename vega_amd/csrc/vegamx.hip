@@ -140,8 +140,10 @@ struct vmx_engine {
     std::vector<int32_t> const_slots2;       // ... a level-2 table: + everything that enters a Gaussian factor
     DevBuf<int32_t> d_const_slots, d_const_slots2, d_xtab_pipe, d_xtab_partner;
     DevBuf<double> xtab_k;
-    DevBuf<int32_t> d_tab_groups;            // indices (into pk_groups) of the groups with tables
-    int pk_walkers_per_thread = 1;           // VMX_PK_NW
+    DevBuf<unsigned long long> pk_trace;     // VMX_PK_TRACE=<file>: block timeline of the last k_pk_tab2 launch, written by vmx_sync
+    size_t pk_trace_blocks = 0;
+    std::vector<Tab2Group> tab2_groups;      // the groups with tables, as k_pk_tab2 takes them (cross groups first)
+    int pk_walkers_per_thread = 2;           // VMX_PK_NW (batches of 64 walkers or more)
     DevBuf<double> xtab_key;
     int n_xtab = 0;
     int const_hint = 0;              // vmx_set_constant_nl_hint: table level the caller vouches for (device-resident theta)
@@ -193,6 +195,7 @@ struct vmx_engine {
     std::map<int, QuadList*> quad_lists;     // by number of walker tiles
     std::map<int, int> quad_seg_len;         // measured segment length by power-of-two class of that number
     bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
+    int xi_fused_max_b = 1 << 30;    // VMX_XI_FUSED_MAXB (an experiment knob: the fused kernel wins at every batch size)
     bool no_tab2 = false;            // VMX_NO_TAB2: level-1 tables only (the Gaussian factors stay in the mu loop)
     bool quad_band_xcd = false;      // VMX_XCD_BANDS: a K band per XCD (HBM traffic 1.96x -> 1.43x the algorithmic bytes, launch 6 % longer)
     bool gemm_44 = true;             // products on the four-block 4x4x4 fp64 MFMA (VMX_GEMM_16: the 16x16x4 kernel everywhere)
@@ -1121,7 +1124,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
     if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
-    if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 2 ? 2 : 1;
+    if (const char* v = getenv("VMX_XI_FUSED_MAXB")) e->xi_fused_max_b = atoi(v);
+    if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
     if (getenv("VMX_GRAPH_B1")) e->graph_b1 = true;
 
@@ -1288,14 +1292,22 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         // two tables per group (level 2: the pipeline's and its peak partner's); + 4 x 32 rows: the mu loop requests its table
         // rows four steps ahead without checking for the end
         if (e->n_xtab > 0 && (e->xtab.alloc(((size_t)e->n_xtab * 2 * e->n_rows + 128) * e->nkp, true) ||
-                              e->xtab_k.alloc((size_t)e->n_xtab * 3 * e->nkp, true))) return -2;
+                              e->xtab_k.alloc((size_t)e->n_xtab * 4 * e->nkp, true))) return -2;
         {
             std::vector<int32_t> xp((size_t)e->n_xtab + 1, -1), xq((size_t)e->n_xtab + 1, -1);
             for (auto& g : e->pk_groups) if (g.xtab >= 0) { xp[g.xtab] = g.pipe; xq[g.xtab] = g.peak_partner; }
-            std::vector<int32_t> tg;
-            for (size_t gi = 0; gi < e->pk_groups.size(); ++gi) if (e->pk_groups[gi].xtab >= 0) tg.push_back((int32_t)gi);
-            tg.push_back(-1);
-            if (e->d_tab_groups.upload(tg.data(), tg.size())) return -2;
+            e->tab2_groups.clear();
+            for (int cross = 1; cross >= 0; --cross)
+                for (auto& g : e->pk_groups) {
+                    if (g.xtab < 0 || (g.variant == PKV_CROSS_CORE) != (cross == 1)) continue;
+                    const vmx_pipe_desc& d = e->pipes[g.pipe].d;
+                    Tab2Group t{};
+                    t.pipe = g.pipe; t.partner = g.peak_partner; t.xtab = g.xtab; t.cross = cross;
+                    t.kind_s = d.pk_lin_kind; t.kind_q = e->pipes[g.peak_partner].d.pk_lin_kind;
+                    t.uvb = d.uvb; t.heii = d.heii; t.lya1 = d.tracer[0].is_lya; t.lya2 = d.tracer[1].is_lya;
+                    t.damping_power = d.damping_power; t.damping_scale = d.damping_scale;
+                    e->tab2_groups.push_back(t);          // (col_s / col_q: once the active columns are numbered)
+                }
             std::vector<double> key((size_t)e->n_xtab * VMX_XTAB_KEY + 1, std::nan(""));
             if (e->d_xtab_pipe.upload(xp.data(), xp.size()) || e->d_xtab_partner.upload(xq.data(), xq.size()) ||
                 e->xtab_key.upload(key.data(), key.size())) return -2;
@@ -1335,6 +1347,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
                 if (pd.poly_basis >= 0) pd.col = -1;
                 else pd.col = e->n_active++;
             }
+            for (auto& t : e->tab2_groups) { t.col_s = e->pipes[t.pipe].col; t.col_q = e->pipes[t.partner].col; }
             if (e->d_pipes.upload(e->pipes.data(), e->pipes.size())) return -2;
             e->pk_static.push_back(-1);
             if (e->d_pk_static.upload(e->pk_static.data(), e->pk_static.size())) return -2;
@@ -1407,7 +1420,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->metal_bias.alloc((size_t)Bm * 3 * (e->metals.size() + 1)) ||
         e->pl.alloc((size_t)VMX_MAX_ELL * acols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * acols * e->ncp) ||
         e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
-        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(1)) return -2;
+        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(2)) return -2;
     {
         const int32_t empty_window[2] = {0x7fffffff, -1};
         if (e->coef_win.upload(empty_window, 2)) return -2;
@@ -1450,7 +1463,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.prior_slot = e->d_prior_slot.p; D.prior_mean = e->d_prior_mean.p; D.prior_sigma = e->d_prior_sigma.p;
     D.n_params = n_params;
     D.theta = e->theta.p; D.scal = e->scal.p; D.metal_bias = e->metal_bias.p; D.pl = e->pl.p; D.coef = e->coef.p;
-    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p; D.k_live = e->k_live.p; D.coef_win = e->coef_win.p; D.mock_index = e->mock_index.p;
+    D.xi = e->xi.p; D.xim = e->xim.p; D.model = e->model.p; D.chi2 = e->chi2.p; D.status = e->status.p; D.k_live = e->k_live.p; D.coef_win = e->coef_win.p; D.pk_trace = nullptr; D.mock_index = e->mock_index.p;
     D.model_size = e->model_size;
     D.gcinv = e->gcinv.p; D.g_n = e->g_n; D.g_ld = e->g_ld; D.gres = e->gres.p; D.gz = e->gz.p;
 
@@ -1738,7 +1751,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         if (want_mu_tab) shmem += (size_t)2 * e->n_mu * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
         if (tab_mode)
-            hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, e->n_rows, e->n_xtab), dim3(256), 0, e->stream, D);
+            hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, (e->n_rows + XTAB_ROWS - 1) / XTAB_ROWS, e->n_xtab), dim3(256), 0, e->stream, D);
         if (!e->pk_poly.empty())
             hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
         const int tm = tab_mode;
@@ -1747,13 +1760,23 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         if (tab_mode >= 2 && e->n_xtab > 0) {
             n_other = n_groups - e->n_xtab;
             const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
-            if ((int64_t)B * e->n_xtab >= 24) {
-                if (e->pk_walkers_per_thread == 2 && B >= 64)
-                    hipLaunchKernelGGL((k_pk_tab2<64, 4, 2>), dim3((B + 1) / 2, e->n_xtab, (e->nk + 63) / 64), dim3(256), std::max(sh1, (size_t)4096 * sizeof(double)), e->stream, D, e->d_pk_groups.p, e->d_tab_groups.p, B);
-                else
-                    hipLaunchKernelGGL((k_pk_tab2<64, 4, 1>), dim3(B, e->n_xtab, (e->nk + 63) / 64), dim3(256), sh1, e->stream, D, e->d_pk_groups.p, e->d_tab_groups.p, B);
-            } else
-                hipLaunchKernelGGL((k_pk_tab2<16, 16, 1>), dim3(B, e->n_xtab, (e->nk + 15) / 16), dim3(256), sh1, e->stream, D, e->d_pk_groups.p, e->d_tab_groups.p, B);
+            if (getenv("VMX_PK_TRACE")) {
+                e->pk_trace_blocks = (size_t)B * ((e->nk + 15) / 16) * e->tab2_groups.size();     // (an upper bound: unused entries stay zero)
+                if (!e->pk_trace.p && e->pk_trace.alloc(4 * (size_t)e->max_batch * ((e->nk + 15) / 16) * e->tab2_groups.size(), true)) return -2;
+                D.pk_trace = e->pk_trace.p;
+            }
+            for (size_t first = 0; first < e->tab2_groups.size(); first += VMX_TAB2_GROUPS) {
+                Tab2Args A{};
+                const int n = (int)std::min<size_t>(VMX_TAB2_GROUPS, e->tab2_groups.size() - first);
+                for (int q = 0; q < n; ++q) A.g[q] = e->tab2_groups[first + q];
+                if ((int64_t)B * e->n_xtab >= 24) {
+                    if (e->pk_walkers_per_thread == 2 && B >= 64)
+                        hipLaunchKernelGGL((k_pk_tab2<64, 4, 2>), dim3((B + 1) / 2, n, (e->nk + 63) / 64), dim3(256), std::max(sh1, (size_t)4096 * sizeof(double)), e->stream, D, A, B);
+                    else
+                        hipLaunchKernelGGL((k_pk_tab2<64, 4, 1>), dim3(B, n, (e->nk + 63) / 64), dim3(256), sh1, e->stream, D, A, B);
+                } else
+                    hipLaunchKernelGGL((k_pk_tab2<16, 16, 1>), dim3(B, n, (e->nk + 15) / 16), dim3(256), sh1, e->stream, D, A, B);
+            }
         }
         if (n_other == 0) {}
         else {
@@ -1793,7 +1816,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                            VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
     }
     // chi2-only small batches of items without metal terms: bins + quadratic-form entries in one kernel
-    bool xi_fused = quad && B <= 8 && (size_t)n_pipe == 2 * e->items.size();
+    bool xi_fused = quad && B <= e->xi_fused_max_b && (size_t)n_pipe == 2 * e->items.size();
     for (auto* it : e->items) if (!it->metals.empty() || it->dev.d.pipe_peak == it->dev.d.pipe_smooth) xi_fused = false;
     if (xi_fused) {
         ScopedTimer t(e, KC_XI);
@@ -2329,6 +2352,11 @@ int vmx_sync(vmx_engine* e)
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     if (e->profiling) collect_spans(e);
+    if (e->pk_trace.p && e->pk_trace_blocks) {
+        std::vector<unsigned long long> h(4 * e->pk_trace_blocks);
+        HIP_OK(hipMemcpy(h.data(), e->pk_trace.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("VMX_PK_TRACE"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
     return 0;
 }
 
@@ -2416,10 +2444,11 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
         // [0] the number of leading wavenumbers with a live P(k,mu) block in the last evaluation (the rest are exact zeros),
         // [1] the wavenumber up to which the mu sums take the node rule (0: plain loop), [2] nodes per wavenumber of that rule
         if (capacity < 3) { fail(-1, "invalid argument: capacity too small"); return -1; }
-        int32_t live = 0;
-        if (hipMemcpy(&live, e->k_live.p, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }
-        out[0] = live; out[1] = e->dev.k_node_max; out[2] = e->mu_lo + e->mu_hi + e->n_extra;
-        return 3;
+        int32_t live[2] = {0, 0};
+        if (hipMemcpy(live, e->k_live.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }
+        out[0] = live[0]; out[1] = e->dev.k_node_max; out[2] = e->mu_lo + e->mu_hi + e->n_extra;
+        if (capacity >= 4) out[3] = live[1];
+        return capacity >= 4 ? 4 : 3;
     }
     else { fail(-1, "invalid argument: what"); return -1; }
     if (count > capacity) { fail(-1, "invalid argument: capacity too small"); return -1; }

@@ -140,7 +140,7 @@ struct EngineDev {
     // then the only exponential left per walker and (k, mu).
     // A table only changes with those parameters: k_xtab compares them with the ones the table was built from (xtab_key
     // [tables][VMX_XTAB_KEY], written by the chi2 kernel of the evaluation that built it), recomputes a stale table and
-    // leaves a current one alone.  xtab_k [tables][3][nkp]: per wavenumber the Arinyo part of e0, e2 and the error flag.
+    // leaves a current one alone.  xtab_k [tables][4][nkp]: per wavenumber the Arinyo part of e0, e2, the error flag, the (level-2) bound of the exponents.
     const int32_t* xtab_pipe; const int32_t* xtab_partner; int32_t n_xtab; int32_t xtab_level; double* xtab_key; double* xtab_k;
     const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
     int32_t n_gk;
@@ -190,7 +190,9 @@ struct EngineDev {
     // direct_pk mode (model.py:188-207): the model is the smooth pipeline of every item evaluated with a linear spectrum
     // supplied per walker (e.g. by a Boltzmann code); no peak component, and additive terms enter once
     const double* pk_direct;    // [B][nkp] or null
-    int32_t* k_live;            // [1] wavenumbers >= *k_live have P_ell = 0 for every walker and pipeline of the batch
+    int32_t* k_live;            // [0] wavenumbers >= *k_live have P_ell = 0 for every walker and pipeline of the batch;
+                                // [1] wavenumbers < k_live[1] sat in tiles that took the mu node rule (a statistic)
+    unsigned long long* pk_trace;   // debugging aid (VMX_PK_TRACE): per block of k_pk_tab2 {start, end (100 MHz ticks), hw id, xcc id}
     int32_t* coef_win;          // [2] first / last spline coefficient any bin of the batch reads (k_prologue; reset by k_chi2)
     const int32_t* mock_index;  // [B] row of the mock pool used as data by walker b, -1: the item's data vector
     int32_t model_size;
@@ -247,7 +249,7 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
     const int b = gid / (D.n_pipe + 1), slot = gid % (D.n_pipe + 1);
     __shared__ int s_win[2 * 16];               // per wave: spline-coefficient window of its (walker, pipeline) threads
     if ((threadIdx.x & 63) == 0) { s_win[2 * (threadIdx.x >> 6)] = 0x7fffffff; s_win[2 * (threadIdx.x >> 6) + 1] = -1; }
-    if (gid == 0) *D.k_live = 0;
+    if (gid == 0) { D.k_live[0] = 0; D.k_live[1] = 0; }
     // LDS: [pipeline descriptors][walkers of a zero-copy batch].  The descriptors are read dozens of times behind
     // data-dependent branches; from global memory every such read is its own round trip (~10 us of a single-walker
     // chain), so the block stages them once.
@@ -526,6 +528,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define PK_REANCHOR 64      // steps between exact re-evaluations of the exponential recurrences
+// Bounds on the exponent of a wavenumber's largest (k, mu) value: below VMX_PK_DEAD a whole tile is skipped (its multipoles
+// are exact zeros; exp(-200) ~ 1e-87 leaves > 60 decades of margin for the amplitudes); below VMX_PK_NEGLIGIBLE
+// (exp(-100) ~ 4e-44 of the unsuppressed spectrum - beyond the last bit of any xi) a wavenumber no longer decides
+// whether its tile may take the mu node rule.
+#define VMX_PK_DEAD (-200.0)
+#define VMX_PK_NEGLIGIBLE (-100.0)
 
 // One work group of the P(k,mu) stage: a pipeline and, when the item's peak component differs from its
 // smooth component only by the peak non-linear broadening (power_spectrum.py:163-164), that peak
@@ -746,19 +754,22 @@ __device__ inline void xtab_key_store(const EngineDev& D)
 }
 
 // The tables of a batch that shares its non-linear (level 1) and Gaussian (level 2) parameters, from the first walker
-// (power_spectrum.py:435-479 D_NL, :526-556 smoothing, :382-417 peak broadening).  grid = (k blocks, table rows, groups).
+// (power_spectrum.py:435-479 D_NL, :526-556 smoothing, :382-417 peak broadening).  grid = (k blocks, row blocks, groups);
+// a launch that finds its tables current costs a few microseconds (~1000 blocks that read the key and leave).
+#define XTAB_ROWS 8
 __global__ __launch_bounds__(256) void k_xtab(EngineDev D)
 {
     const int xtab = blockIdx.z, pipe = D.xtab_pipe[xtab];
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= D.nkp) return;
     const size_t plane = (size_t)D.n_rows * D.nkp;
-    double* cell = D.xtab + (size_t)xtab * 2 * plane + (size_t)j * D.nkp + i;
     double key[VMX_XTAB_KEY];
     xtab_key_now(D, xtab, key);
     bool stale = false;
     for (int q = 0; q < VMX_XTAB_KEY; ++q) stale |= !(D.xtab_key[xtab * VMX_XTAB_KEY + q] == key[q]);      // keys start as NaN
     if (!stale) return;      // built from the same parameters by an earlier batch
+    for (int j = blockIdx.y * XTAB_ROWS; j < min((int)(blockIdx.y + 1) * XTAB_ROWS, D.n_rows); ++j) {
+    double* cell = D.xtab + (size_t)xtab * 2 * plane + (size_t)j * D.nkp + i;
     double val = 0.0, val_q = 0.0;
     if (i < D.nk) {
         const vmx_pipe_desc& d = D.pipes[pipe].d;
@@ -779,15 +790,20 @@ __global__ __launch_bounds__(256) void k_xtab(EngineDev D)
             // per wavenumber: the Arinyo part of e0, e2 (the underflow bound of k_pk_multipoles) and VegaArinyoError - NaN or
             // Inf in exp(growth (1 - pec) - pressure) anywhere on the grid (power_spectrum.py:466-469); the exponent is
             // monotonic in mu^bv, so its extremes sit at the two ends of the mu grid
-            double* kk = D.xtab_k + (size_t)xtab * 3 * D.nkp + i;
+            double* kk = D.xtab_k + (size_t)xtab * 4 * D.nkp + i;
             kk[0] = d.arinyo_power * gp;
             kk[D.nkp] = -d.arinyo_power * gv;
             const double lo = fma(-gv, vmx_exp(key[5] * D.lnmu[0]), gp), hi = fma(-gv, vmx_exp(key[5] * D.lnmu[D.n_mu - 1]), gp);
             kk[2 * D.nkp] = (!(lo < 709.0) || !(hi < 709.0)) ? 1.0 : 0.0;
+            // level 2: every exponent is shared by the batch - the underflow bound of k_pk_multipoles, per wavenumber
+            const double k2 = k * k, ga = key[7], gb = key[8], dga = key[9] - key[7], dgb = key[10] - key[8];
+            kk[3 * D.nkp] = fma(-k2, gb, kk[0]) + fmax(-k2 * (ga - gb), 0.0) + fmax(kk[D.nkp], 0.0) +
+                            fmax(-k2 * dgb + fmax(-k2 * (dga - dgb), 0.0), 0.0);
         }
     }
     *cell = val;
     if (D.xtab_level >= 2) cell[plane] = val_q;
+    }
 }
 
 // mu loop against the tabulated D_NL * G: no exponential is left in the loop - the HCD factor, the Gaussian
@@ -976,10 +992,6 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     PkThread T;
     T.paired = pp >= 0;
     T.arinyo = d.nl_model == VMX_NL_ARINYO;
-    // k tiles up to k_node_max take the node rule: the first mu_lo and the last mu_hi midpoints plus the extra nodes
-    // (block-uniform: every thread of a block shares the tile)
-    const bool node_mode = GENERIC ? false : (D.n_extra > 0 && variant != PKV_GENERIC &&
-                                              D.k[min((int)(blockIdx.z + 1) * KT, D.nk) - 1] <= D.k_node_max);
     if (T.arinyo && !use_tab) {
         const double bv = sc[S_ABV];
         for (int j = lt; j < D.n_rows; j += KT * MS) s_mubv[j] = vmx_exp(bv * D.lnmu[j]);     // mu^bv (midpoints, then nodes)
@@ -1022,7 +1034,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     bool bad = false;
     if (T.arinyo && use_tab) {
         // the Arinyo terms of this wavenumber were formed with the table (k_xtab): the batch shares them
-        const double* kk = D.xtab_k + (size_t)groups[blockIdx.y].xtab * 3 * D.nkp + ic;
+        const double* kk = D.xtab_k + (size_t)groups[blockIdx.y].xtab * 4 * D.nkp + ic;
         T.e0 += kk[0];
         T.e2 = kk[D.nkp];
         bad = kk[2 * D.nkp] != 0.0;
@@ -1083,7 +1095,12 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     // when a whole wave is past that bound.  exp(-200) ~ 1e-87 leaves > 60 decades of margin for the amplitudes.
     double e_max = T.e0 + fmax(T.e1, 0.0) + fmax(T.e2, 0.0);
     if (T.paired) e_max += fmax(T.p0 + fmax(T.p1, 0.0), 0.0);
-    const bool live_block = __syncthreads_or(!(e_max < -200.0)) != 0;     // block-uniform: the mu loops contain barriers
+    const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;     // block-uniform: the mu loops contain barriers
+    // the node rule (first mu_lo and last mu_hi midpoints plus the extra nodes) serves a tile whose wavenumbers are all
+    // within its range or negligible (VMX_PK_NEGLIGIBLE); block-uniform
+    const bool node_mode = GENERIC ? false : (D.n_extra > 0 && variant != PKV_GENERIC &&
+                                              __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0);
+    if (live_block && node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((int)(blockIdx.z + 1) * KT, D.nk));
     // the FFTLog product skips the wavenumbers past the last live block (their P_ell is exactly zero)
     if (live_block && threadIdx.x == 0) atomicMax(D.k_live, min((int)(blockIdx.z + 1) * KT, D.nk));
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1225,72 +1242,92 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
 // - so the kernel needs half the registers of k_pk_multipoles (its other loops carry the exponentials' constants) and
 // twice the waves hide the latency of the two table streams.  Block = KT wavenumbers x MS mu-slices of NW walkers (each
 // thread evaluates its nodes for NW walkers: one pair of table entries serves all of them).
-// grid = (ceil(B / NW), level-2 groups, k tiles); LDS: (mu^2, mu^4) of the midpoints and {mu, mu^2, mu^4, w} of the extra
-// nodes, reused as the [NW][8][256] reduction scratch.
+// grid = (ceil(B / NW), level-2 groups - the costlier cross groups first -, k tiles: the launch ends on the dead tiles); LDS: (mu^2, mu^4) of the midpoints and {mu, mu^2, mu^4, w} of the extra
+// nodes, reused as the [NW][8][KT MS] reduction scratch.
+// what k_pk_tab2 needs to know about a group, passed in the kernel arguments (no descriptor loads ahead of the set-up)
+struct Tab2Group { int32_t pipe, partner, xtab, cross, kind_s, kind_q, col_s, col_q, uvb, heii, lya1, lya2, damping_power, pad;
+                   double damping_scale; };
+#define VMX_TAB2_GROUPS 8
+struct Tab2Args { Tab2Group g[VMX_TAB2_GROUPS]; };
+
 template <int KT, int MS, int NW, bool CROSS>
-__device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const PkGroup& G, int B)
+__device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group& G, int B)
 {
     extern __shared__ double smem[];
+    constexpr int NT = KT * MS;
     // (the reduction scratch takes the place of the node tables once the loops are done: five or six blocks share a CU)
     double* s_red = smem;
     v2d* s_mu24 = (v2d*)smem;
     v4d* s_node = (v4d*)(smem + 2 * D.n_mu);
-    const int p = G.pipe, pp = G.peak_partner, xt = G.xtab;
+    const int p = G.pipe, pp = G.partner, xt = G.xtab;
     constexpr bool cross = CROSS;
-    const vmx_pipe_desc& d = D.pipes[p].d;
+    const int tile = blockIdx.z;
+    const unsigned long long t_start = D.pk_trace ? wall_clock64() : 0ull;
     const int kk = threadIdx.x % KT;
     const int ms = (KT == 64) ? __builtin_amdgcn_readfirstlane(threadIdx.x / KT) : (int)(threadIdx.x / KT);
-    const int i = blockIdx.z * KT + kk;
+    const int i = tile * KT + kk;
     const bool valid = i < D.nk;
     const int ic = valid ? i : D.nk - 1;
     const int n_mu = D.n_mu;
     const double inv_nmu = 1.0 / (double)n_mu;
-    // k tiles up to k_node_max take the node rule: the first mu_lo and the last mu_hi midpoints plus the extra nodes
-    const bool node_mode = D.n_extra > 0 && D.k[min((int)(blockIdx.z + 1) * KT, D.nk) - 1] <= D.k_node_max;
-    const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
-    for (int j = threadIdx.x; j < n_mu; j += 256)
-        if (j < lo_end || j >= hi_beg) { const double m = D.mu[j], m2 = m * m; s_mu24[j] = (v2d){m2, m2 * m2}; }
-    if (node_mode)
-        for (int j = threadIdx.x; j < D.n_extra; j += 256) {
-            const double m = D.mu[n_mu + j], m2 = m * m;
-            s_node[j] = (v4d){m, m2, m2 * m2, D.node_w[j]};
+    // the exponents are shared by the batch at this level: their bound over mu in (0, 1] came with the table (k_xtab).  A
+    // tile whose every value underflows is skipped (as in k_pk_multipoles) before anything else is loaded.
+    const double* kx = D.xtab_k + (size_t)xt * 4 * D.nkp + ic;
+    const double e_max = kx[3 * D.nkp];
+    const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;
+    if (!live_block) {
+        if (threadIdx.x >= KT || !valid) return;
+        const size_t ncols = (size_t)B * D.n_active;
+        for (int w = 0; w < NW; ++w) {
+            const int b = blockIdx.x * NW + w;
+            if (b >= B) continue;
+            for (int half = 0; half < 2; ++half)
+                for (int e = 0; e < D.n_ell; ++e)
+                    D.pl[((size_t)e * ncols + (size_t)b * D.n_active + (half ? G.col_q : G.col_s)) * D.nkp + i] = 0.0;
         }
-
+        return;
+    }
     const double k = D.k[ic], k2 = k * k;
     const double dmu = (double)MS * inv_nmu;
-    const double* kx = D.xtab_k + (size_t)xt * 3 * D.nkp + ic;
     const bool bad = kx[2 * D.nkp] != 0.0;
     double c01[NW], c11[NW], c02[NW], c12[NW], hb[NW], hbb[NW], fk[NW], Fq[NW], k2vd2[NW];
     bool ok[NW];
-    double e_max = -1e300;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         int b = blockIdx.x * NW + w;
         ok[w] = b < B;
         if (!ok[w]) b = B - 1;                        // a surplus walker slot shadows the last walker and stores nothing
         const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
-        const double* scp = D.scal + ((size_t)b * D.n_pipe + pp) * VMX_NS;
         c01[w] = sc[S_BIAS1]; c02[w] = sc[S_BIAS2]; c11[w] = sc[S_BB1]; c12[w] = sc[S_BB2];
-        if (d.uvb || d.heii) {
+        if (G.uvb || G.heii) {
             // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261)
             double add = 0.0;
-            if (d.uvb) { const double x = k * sc[S_UV_LAM]; const double W = atan(x) / x; add += sc[S_UV_BG] * W / (1.0 + sc[S_UV_BP] * W); }
-            if (d.heii) { const double x = k * sc[S_HE_LAM]; const double W = atan(x) / x; add += sc[S_HE_BG] * W / (1.0 + sc[S_UV_BP] * W); }
-            if (d.tracer[0].is_lya) c01[w] += add;
-            if (d.tracer[1].is_lya) c02[w] += add;
+            if (G.uvb) { const double x = k * sc[S_UV_LAM]; const double W = atan(x) / x; add += sc[S_UV_BG] * W / (1.0 + sc[S_UV_BP] * W); }
+            if (G.heii) { const double x = k * sc[S_HE_LAM]; const double W = atan(x) / x; add += sc[S_HE_BG] * W / (1.0 + sc[S_UV_BP] * W); }
+            if (G.lya1) c01[w] += add;
+            if (G.lya2) c02[w] += add;
         }
         hb[w] = sc[S_HCD_B]; hbb[w] = sc[S_HCD_BB];
         fk[w] = -sc[S_HCD_L0] * k;
         Fq[w] = vmx_exp(fk[w] * dmu);
         k2vd2[w] = k2 * sc[S_VD2];
-        // underflow bound of the exponents over mu in (0, 1] (as in k_pk_multipoles)
-        const double ga = sc[S_GA], gb = sc[S_GB], dga = scp[S_GA] - ga, dgb = scp[S_GB] - gb;
-        const double e0 = fma(-k2, gb, kx[0]), e1 = -k2 * (ga - gb), e2 = kx[D.nkp];
-        const double p0 = -k2 * dgb, p1 = -k2 * (dga - dgb);
-        e_max = fmax(e_max, e0 + fmax(e1, 0.0) + fmax(e2, 0.0) + fmax(p0 + fmax(p1, 0.0), 0.0));
     }
-    const bool live_block = __syncthreads_or(!(e_max < -200.0)) != 0;      // (also orders the LDS tables before the loops)
-    if (live_block && threadIdx.x == 0) atomicMax(D.k_live, min((int)(blockIdx.z + 1) * KT, D.nk));
+    if (threadIdx.x == 0) atomicMax(D.k_live, min((tile + 1) * KT, D.nk));
+    // the node rule (first mu_lo and last mu_hi midpoints plus the extra nodes) serves a tile whose wavenumbers are all
+    // within its range or negligible (VMX_PK_NEGLIGIBLE)
+    const bool node_mode = D.n_extra > 0 && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
+    if (node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((tile + 1) * KT, D.nk));
+    const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
+    {
+        for (int j = threadIdx.x; j < n_mu; j += NT)
+            if (j < lo_end || j >= hi_beg) { const double m = D.mu[j], m2 = m * m; s_mu24[j] = (v2d){m2, m2 * m2}; }
+        if (node_mode)
+            for (int j = threadIdx.x; j < D.n_extra; j += NT) {
+                const double m = D.mu[n_mu + j], m2 = m * m;
+                s_node[j] = (v4d){m, m2, m2 * m2, D.node_w[j]};
+            }
+    }
+    __syncthreads();
 
     double s[NW][4], q[NW][4];
 #pragma unroll
@@ -1298,7 +1335,7 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const PkGroup& 
 #pragma unroll
         for (int n = 0; n < 4; ++n) { s[w][n] = 0.0; q[w][n] = 0.0; }
 
-    if (live_block) {
+    {
         const size_t plane = (size_t)D.n_rows * D.nkp, row = (size_t)D.nkp, stride = (size_t)MS * D.nkp;
         const double* base = D.xtab + (size_t)xt * 2 * plane + (size_t)ms * row + ic;
         // one node for all NW walkers: AA = A1 A2 [/ sqrt(..)] [x weight]; the pipeline's table entry g, its partner's h
@@ -1394,16 +1431,21 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const PkGroup& 
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const double* m = half ? q[w] : s[w];
-            double* r = s_red + (size_t)w * 2048 + (half * 4) * 256 + threadIdx.x;
+            double* r = s_red + (size_t)w * 8 * NT + (half * 4) * NT + threadIdx.x;
             r[0] = m[0] * inv_nmu;
-            r[256] = (7.5 * m[1] - 2.5 * m[0]) * inv_nmu;
-            r[512] = (39.375 * m[2] - 33.75 * m[1] + 3.375 * m[0]) * inv_nmu;
-            r[768] = (187.6875 * m[3] - 255.9375 * m[2] + 85.3125 * m[1] - 4.0625 * m[0]) * inv_nmu;
+            r[NT] = (7.5 * m[1] - 2.5 * m[0]) * inv_nmu;
+            r[2 * NT] = (39.375 * m[2] - 33.75 * m[1] + 3.375 * m[0]) * inv_nmu;
+            r[3 * NT] = (187.6875 * m[3] - 255.9375 * m[2] + 85.3125 * m[1] - 4.0625 * m[0]) * inv_nmu;
         }
     __syncthreads();
+    if (D.pk_trace && threadIdx.x == 0) {
+        unsigned long long* tr = D.pk_trace + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        tr[0] = t_start; tr[1] = wall_clock64();
+        tr[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
     if (threadIdx.x >= KT || !valid) return;
     double damp = 1.0;
-    if (d.damping_scale > 0.0) damp = exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
+    if (G.damping_scale > 0.0) damp = exp(-G.damping_scale * G.damping_scale * pow(k, (double)G.damping_power) / 2.0);
     const size_t ncols = (size_t)B * D.n_active;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -1411,28 +1453,29 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const PkGroup& 
         const int b = blockIdx.x * NW + w;
         if (bad) atomicOr(&D.status[b], VMX_STATUS_ARINYO);
         for (int half = 0; half < 2; ++half) {
-            const int pipe = half ? pp : p;
-            const int kind = D.pipes[pipe].d.pk_lin_kind;
+            const int kind = half ? G.kind_q : G.kind_s;
             const double pk = damp * ((D.pk_direct && kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i]
                                                                                  : D.pklin[(size_t)kind * D.nkp + i]);
-            const size_t col = (size_t)b * D.n_active + D.pipes[pipe].col;
+            const size_t col = (size_t)b * D.n_active + (half ? G.col_q : G.col_s);
             for (int e = 0; e < D.n_ell; ++e) {
                 double sum = 0.0;
-                for (int qq = 0; qq < MS; ++qq) sum += s_red[(size_t)w * 2048 + (half * 4 + e) * 256 + qq * KT + kk];
+                for (int qq = 0; qq < MS; ++qq) sum += s_red[(size_t)w * 8 * NT + (half * 4 + e) * NT + qq * KT + kk];
                 D.pl[((size_t)e * ncols + col) * D.nkp + i] = pk * sum;
             }
         }
     }
 }
 
+// waves per SIMD the register allocation aims at (measured: three or four waves of the two-walker shape run the same)
 #ifndef VMX_TAB2_BLOCKS
-#define VMX_TAB2_BLOCKS 5
+#define VMX_TAB2_BLOCKS 4
+#define VMX_TAB2_W2 3
 #endif
 template <int KT, int MS, int NW>
-__global__ __launch_bounds__(256, NW == 1 ? VMX_TAB2_BLOCKS : 2) void k_pk_tab2(EngineDev D, const PkGroup* groups, const int32_t* tab_groups, int B)
+__global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : NW == 1 ? VMX_TAB2_BLOCKS : VMX_TAB2_W2) void k_pk_tab2(EngineDev D, Tab2Args A, int B)
 {
-    const PkGroup& G = groups[tab_groups[blockIdx.y]];
-    if (G.variant == PKV_CROSS_CORE) pk_tab2_body<KT, MS, NW, true>(D, G, B);
+    const Tab2Group& G = A.g[blockIdx.y];
+    if (G.cross) pk_tab2_body<KT, MS, NW, true>(D, G, B);
     else pk_tab2_body<KT, MS, NW, false>(D, G, B);
 }
 
