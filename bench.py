@@ -41,6 +41,9 @@ FP64_VALU_MEASURED_TF = 61.6   # v_fma_f64 at 4 waves / SIMD, the occupancy of k
 # Algorithmic flops per (k, mu) grid point of a paired peak+smooth group:
 # + - x count 1, FMA 2, every transcendental / rsqrt 1.
 FLOPS_PER_POINT = {'auto': 35, 'cross': 43}
+# ... when the batch shares its Gaussian factors (level-2 tables, k_pk_tab2): Kaiser + HCD amplitudes 8 (cross 9), table
+# products 2, mu^6 1, eight moment sums 14, the HCD progression 1; cross: + Lorentzian rsqrt 9
+FLOPS_PER_POINT_TAB2 = {'auto': 26, 'cross': 36}
 
 
 def build_problem(workload):
@@ -493,6 +496,7 @@ def main():
         two_lanes = {'lanes': nl, 'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
                      'note': f'{nl} independent engines per GPU, step i on lane i % {nl}, B={B} walkers per step'}
 
+    pk_state = engines[0].debug_read(4, 0, 5)       # live wavenumbers, node-rule tiles and table level of the timed steps
     exact_mu = None
     if not use_dist and not args.core_only:
         # the same steps with the reference's 1000-point mu loop itself instead of the node rule that reproduces its sums
@@ -540,12 +544,13 @@ def main():
             if kclass == 'pk_multipoles':
                 # (k, mu) points the stage evaluates per walker and item: the live wavenumbers of the step (blocks whose
                 # every value underflows are skipped) x the mu nodes of each - 276 where the node rule applies, 1000 above
-                k_live, k_node_max, n_nodes, k_rule = eng.debug_read(4, 0, 4)
+                k_live, k_node_max, n_nodes, k_rule, level = pk_state
                 points = float(np.where(np.arange(int(k_live)) < k_rule, n_nodes, 1000).sum())
+                per_point = FLOPS_PER_POINT_TAB2 if level >= 2 else FLOPS_PER_POINT
                 flops = 0.0
                 for item in prob.items.values():
                     kind = 'auto' if item.tracer1.name == item.tracer2.name else 'cross'
-                    flops += B * points * FLOPS_PER_POINT[kind]          # one paired pass per item
+                    flops += B * points * per_point[kind]          # one paired pass per item
                 bound, peak, reach = 'valu-fp64', FP64_VALU_PEAK_TF, FP64_VALU_MEASURED_TF
             elif kclass == 'quadratic_form_product':
                 # x'^T Q' x' in half form: nq^2 flops per walker and item, nq = n_model + additive post-distortion coefficients

@@ -24,8 +24,10 @@ if len(sys.argv) > 1:
 out = REPO / 'gpurun_out'
 ref = None
 import numpy as np
-for label, env in (('level1', {'VMX_NO_TAB2': '1'}), ('level2_nw1', {'VMX_PK_NW': '1'}), ('level2_nw2', {}), ('occ3', {'VMX_TAB2_LDS': '45000'}), ('occ2', {'VMX_TAB2_LDS': '60000'}), ('occ1', {'VMX_TAB2_LDS': '64000'}),
-                   ('B1024', {'PKB': '1024'}), ('B384', {'PKB': '384'})):
+MODES = {'level1': {'VMX_NO_TAB2': '1'}, 'level2_nw1': {'VMX_PK_NW': '1'}, 'default': {}, 'no_fused_chi2': {'VMX_NO_FUSED_CHI2': '1'},
+         'noload': {'VEGAMX_LIBRARY': str(REPO / 'build_exp' / 'libvegamx_noload.so')}, 'B1024': {'PKB': '1024'}}
+for label in (os.environ.get('PK_MODES', 'level1,default').split(',')):
+    env = MODES[label]
     f = out / f'pkmode_{label}.npy'
     r = subprocess.run([sys.executable, __file__, str(f)], env={**os.environ, **env}, capture_output=True, text=True)
     print(label, r.stdout.strip().split('\n')[-1] if r.stdout else r.stderr[-2000:])

@@ -191,10 +191,12 @@ struct vmx_engine {
     int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
     // work lists of the quadratic-form launches per batch size: entries, their count, per-row-tile slab counts
-    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg; int n_blocks = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; int seg_len = 0; };
+    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg; DevBuf<double> part; int n_blocks = 0; int rows = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; int seg_len = 0; };
     std::map<int, QuadList*> quad_lists;     // by number of walker tiles
     std::map<int, int> quad_seg_len;         // measured segment length by power-of-two class of that number
     bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
+    bool quad_fused_chi2 = true;     // VMX_NO_FUSED_CHI2: the list launch stores the product, k_chi2_quad contracts it
+    int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
     int xi_fused_max_b = 1 << 30;    // VMX_XI_FUSED_MAXB (an experiment knob: the fused kernel wins at every batch size)
     bool no_tab2 = false;            // VMX_NO_TAB2: level-1 tables only (the Gaussian factors stay in the mu loop)
     bool quad_band_xcd = false;      // VMX_XCD_BANDS: a K band per XCD (HBM traffic 1.96x -> 1.43x the algorithmic bytes, launch 6 % longer)
@@ -1124,6 +1126,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
     if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
+    if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
     if (const char* v = getenv("VMX_XI_FUSED_MAXB")) e->xi_fused_max_b = atoi(v);
     if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
@@ -1578,8 +1581,10 @@ static vmx_engine::QuadList* quad_build_list(vmx_engine* e, int B, int L)
                 work[(r * tn + nt) * 8 + xcd] = GemmWork{g.prob, g.mt, nt, g.kbeg, g.kend, g.seg};
         }
     ql->n_blocks = (int)work.size();
+    ql->rows = (int)rows;
     ql->seg_len = L;
-    if (ql->work.upload(work.data(), work.size()) || ql->nseg.upload(nseg_all.data(), nseg_all.size())) { delete ql; return nullptr; }
+    if (ql->work.upload(work.data(), work.size()) || ql->nseg.upload(nseg_all.data(), nseg_all.size()) ||
+        ql->part.alloc(work.size() * 128, true)) { delete ql; return nullptr; }
     return ql;
 }
 
@@ -1595,6 +1600,9 @@ static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, Sla
         g.M = d.nq; g.N = B; g.K = d.nq_pad; g.tri = 1; g.nsplit = 1; g.klen = d.nq_pad;
         g.d_slab = (int64_t)B * d.nq_pad;
         g.tm = (d.nq + GEMM_BM - 1) / GEMM_BM; g.tn = (B + GEMM_BN - 1) / GEMM_BN;
+        if (e->quad_fused_chi2 && GEMM44_THREADS == 256) {
+            g.part = ql->part.p; g.lin = it->q_lin.p; g.lin_row = e->mock_index.p; g.lin_pool = d.mock_pool ? 1 : 0;
+        }
         G.p[G.n++] = g;
         qs.z[q] = 0;
         qs.qseg_off[q] = ql->nseg_off[q];
@@ -1708,6 +1716,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
     EngineDev D = e->dev;
     // tab_mode: table level of the P(k,mu) stage (EngineDev::xtab_level)
     D.xtab_level = tab_mode;
+    e->last_tab_level = tab_mode;
     D.n_const_slots = tab_mode >= 2 ? (int)e->const_slots2.size() : tab_mode ? (int)e->const_slots.size() : 0;
     if (tab_mode >= 2) D.const_slots = e->d_const_slots2.p;
     if (zero_copy) {
@@ -1857,8 +1866,19 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             // balanced work list: every tile cut into K segments of about equal length
             vmx_engine::QuadList* ql = quad_work_list(e, B);
             if (!ql) return -2;
-            ScopedTimer t(e, KC_QUAD);
-            quad_launch_list(e, ql, B, qs);
+            {
+                ScopedTimer t(e, KC_QUAD);
+                quad_launch_list(e, ql, B, qs);
+            }
+            if (e->quad_fused_chi2 && GEMM44_THREADS == 256) {
+                // the launch left contraction partials instead of the product: a small kernel adds them up
+                ScopedTimer t(e, KC_CHI2);
+                hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, ql->part.p, (B + GEMM_BN - 1) / GEMM_BN, ql->rows);
+                HIP_OK(hipGetLastError());
+                e->last_B = B;
+                e->last_full = false;
+                return 0;
+            }
         } else if (B > 8 && e->items.size() <= VMX_MAX_GROUP) {
             GemmGroup G{};
             int tiles_total = 0, per_xcd_total = 0;
@@ -2448,7 +2468,8 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
         if (hipMemcpy(live, e->k_live.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }
         out[0] = live[0]; out[1] = e->dev.k_node_max; out[2] = e->mu_lo + e->mu_hi + e->n_extra;
         if (capacity >= 4) out[3] = live[1];
-        return capacity >= 4 ? 4 : 3;
+        if (capacity >= 5) out[4] = e->last_tab_level;
+        return capacity >= 5 ? 5 : capacity >= 4 ? 4 : 3;
     }
     else { fail(-1, "invalid argument: what"); return -1; }
     if (count > capacity) { fail(-1, "invalid argument: capacity too small"); return -1; }

@@ -1797,6 +1797,44 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
     }
 }
 
+// chi2 from the contraction partials of the quadratic-form launch (GemmArgs::part): walker b of walker tile nt adds, in
+// block order, the two wave-row sums of every list block of its tile - block index (row * tn + nt) * 8 + xcd.  One wave per
+// walker; padding blocks never wrote their (zero-initialised) slots.
+__global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const double* part, int tn, int rows)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int nt = b >> 6, nl = b & 63;
+    double acc = 0.0;
+    for (int j = lane; j < rows * 8; j += 64) {
+        const size_t blk = ((size_t)(j >> 3) * tn + nt) * 8 + (j & 7);
+        const double* pp = part + (blk * 64 + nl) * 2;
+        acc += pp[0] + pp[1];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane != 0) return;
+    const int mock = D.mock_index[b];
+    double c = acc;
+    for (int q = 0; q < D.n_items; ++q) {
+        const ItemDev& it = D.items[q];
+        c += it.q_c0[(mock >= 0 && it.mock_pool) ? 1 + mock : 0];
+    }
+    const double* t = D.theta + (size_t)b * D.n_params;
+    for (int q = 0; q < D.n_priors; ++q) {
+        const double dlt = t[D.prior_slot[q]] - D.prior_mean[q];
+        c += dlt * dlt / (D.prior_sigma[q] * D.prior_sigma[q]);
+    }
+    int st = D.status[b];
+    if (!(c == c) || c > 1e300 || c < -1e300) { st |= VMX_STATUS_NONFINITE; D.status[b] = st; }
+    D.chi2[b] = st ? 1e100 : c;
+    if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
+    if (D.status_host) D.status_host[b] = st;
+    if (b == 0) {
+        D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
+        xtab_key_store(D);
+    }
+}
+
 // set-up kernels of the quadratic form ----------------------------------------------------------
 // X[j][i] = DM'[mask_idx[i]][j]: the masked rows of [DM | post-add broadband basis], transposed (row j = column j of DM')
 __global__ void k_quad_gather(double* X, int ldx, const double* dm, int dm_ld, const int32_t* mask_idx, int n_masked,
@@ -1876,7 +1914,13 @@ struct GemmArgs {
     const int32_t* k_limit; // optional device scalar: operand columns >= *k_limit are zero and skipped (MFMA kernel)
     const int32_t* m_window; // optional device int[2]: only the rows [lo, hi] of the result are needed (MFMA and streaming kernels)
     int tri;                // A is lower triangular (zeros above the diagonal): row tile mt needs k < (mt + 1) BM only
+    // Quadratic-form launches (k_gemm_nt44<VMX_TAG_QUAD>, list mode) with `part` set do not store the product: the block
+    // contracts its tile with the walker vectors it multiplied - sum_m X[n][m] 2 (D[n][m] - lin[row(n)][m]), the linear
+    // term entering with the tile's first K segment - and leaves one partial sum per walker and wave row in
+    // part[(block * 64 + walker in tile) * 2 + wave row]; k_chi2_parts adds them in block order.
+    double* part; const double* lin; const int32_t* lin_row; int lin_pool;
 };
+#define VMX_TAG_QUAD 12
 
 // Work list of a grouped launch (k_gemm_nt44): one entry per block - a K segment of one 64 x 64 tile of one problem,
 // written to slab `slab` of that problem's output.  A triangular product has row tiles of very different K lengths;
@@ -2109,6 +2153,10 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     constexpr int NP = 16 / NW;             // DMA instructions per wave, operand and stage (each fills 4 rows)
     __shared__ double sA[2][BM * BK];
     __shared__ double sX[2][BN * BK];
+    // contraction epilogue of the quadratic form (GemmArgs::part): the linear term's row over the tile's own rows; the
+    // walker vectors over those rows follow by DMA into the stage buffer that falls free first (see the K loop)
+    constexpr bool QUAD = TAG == VMX_TAG_QUAD && NT == 256;
+    __shared__ double sL[QUAD ? 2 * BM : 1];
 
     const bool list = G.work != nullptr;
     GemmWork wk{};
@@ -2181,6 +2229,15 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     // the first stage of a pass is requested before the previous pass stores its results (a triangular problem has two
     // passes per block: the second one's pipeline fills behind the first one's epilogue)
     setup(0);
+    if constexpr (QUAD) {
+        if (list && g.part) {
+            if (wave == 0 && kbeg == 0 && !g.lin_pool) {
+                const unsigned loff = (unsigned)(m0 + 2 * lane < g.ldx ? (m0 + 2 * lane) * 8 : 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)g.lin + loff),
+                                                 (__attribute__((address_space(3))) void*)&sL[0], 16, 0, 0);
+            }
+        }
+    }
     if (!skip && kbeg < kend) dma_stage(kbeg, 0);
 
   for (int pass = 0; pass < npass; ++pass) {
@@ -2203,6 +2260,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
         lds_wait(a0, x0);
     }
     int buf = 0;
+    int epi_buf = -1;
     for (int k0 = kbeg_c; k0 < (c_skip ? kbeg_c : kend_c); k0 += BK) {
         // first half: MFMAs on f0(s), the reads of f1(s) spread between them (one read ahead of every group of MFMAs, so
         // the wave's MFMA stream is never held up by a burst of LDS instructions)
@@ -2223,6 +2281,23 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
         __builtin_amdgcn_sched_barrier(0);
         // second half: DMA of stage s + 2 into the buffer just released, MFMAs on f1(s) with the reads of f0(s + 1) between them
         if (k0 + 2 * BK < kend_c) dma_stage(k0 + 2 * BK, buf);
+        else if constexpr (QUAD) {
+            if (epi_buf < 0 && list && g.part) {
+                // no further stage: this buffer stays free.  It takes E[n][m] = X[n0 + n][m0 + m] for the contraction epilogue
+                // - walkers 0..31 in the A half, 32..63 in the X half; a wave instruction brings two rows (lane l: row l >> 5,
+                // chunk l & 31), chunks past the row's padded length are redirected to its start (never used)
+                epi_buf = buf;
+                const unsigned coff = (unsigned)(c_m0 + 2 * (lane & 31) < g.ldx ? (c_m0 + 2 * (lane & 31)) * 8 : 0);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int pr = p * NW + wave;
+                    int r = n0 + 2 * pr + (lane >> 5); if (r >= g.N) r = g.N - 1;
+                    double* dst = pr < 16 ? &sA[buf][2 * pr * BM] : &sX[buf][(2 * pr - 32) * BM];
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + ((unsigned)(r * g.ldx) * 8u + coff)),
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+            }
+        }
         // (after the last stage these reads fetch stale data that nothing uses: one code path, no branch)
         const unsigned a0p = fa + (unsigned)(buf ^ 1) * (BM * BK * 8) + frag0;
         const unsigned x0p = fx + (unsigned)(buf ^ 1) * (BM * BK * 8) + frag0;
@@ -2244,6 +2319,61 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
         if (!skip && kbeg < kend) dma_stage(kbeg, 0);
     }
     if (c_skip) continue;
+    if constexpr (TAG == VMX_TAG_QUAD && NT == 256) {
+        if (list && g.part) {
+            // contraction epilogue (see GemmArgs::part): lane (r, c) of group jg holds D[n][m] for n = n0 + wn + 4 i + r,
+            // m = c_m0 + wm + 16 jg + c after the rotations below
+            const int c = lane & 15, r = lane >> 4;
+            const bool first_seg = kbeg_c == 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                // E has landed for every wave
+            if (epi_buf < 0) {              // an empty K range (never a tile's first segment): nothing was multiplied
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (c == 0) g.part[((size_t)blockIdx.x * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = 0.0;
+                continue;
+            }
+            const double* sE0 = &sA[epi_buf][0];
+            const double* sE1 = &sX[epi_buf][0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = n0 + wn + 4 * i + r;
+                const int nc = n < g.N ? n : g.N - 1;
+                const int e_n = wn + 4 * i + r;                             // walker within the tile (block-half uniform per wave)
+                const double* e_row = (wn == 0 ? sE0 + e_n * BM : sE1 + (e_n - 32) * BM) + wm + c;     // + 16 jg: this lane's entries
+                const double* lin = g.lin;
+                if (first_seg && g.lin_pool) {          // per-walker data (mocks): the walker's own row of the linear term
+                    const int mock = g.lin_row[nc];
+                    lin += (size_t)(mock >= 0 ? 1 + mock : 0) * g.ldx;
+                }
+                double sum = 0.0;
+#pragma unroll
+                for (int jg = 0; jg < FJ / 4; ++jg) {
+                    double tot[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double v = acc[i][4 * jg + u];
+                        tot[u] = (v + dpp_row_rotate<0x120 + 4>(v)) + (dpp_row_rotate<0x120 + 8>(v) + dpp_row_rotate<0x120 + 12>(v));
+                    }
+                    double out = fb == 0 ? tot[0] : fb == 1 ? tot[1] : fb == 2 ? tot[2] : tot[3];
+                    const int m = c_m0 + wm + 16 * jg + c;
+#ifdef VMX_EXPERIMENT_NOLOAD
+                    sum = fma((double)m, 2.0 * out, sum);
+#else
+                    if (m < g.M) {
+                        if (first_seg) out -= g.lin_pool ? lin[m] : sL[wm + 16 * jg + c];
+                        sum = fma(e_row[16 * jg], 2.0 * out, sum);
+                    }
+#endif
+                }
+                // the 16 lanes of a row (same walker): total in every lane
+                sum = (sum + dpp_row_rotate<0x120 + 4>(sum)) + (dpp_row_rotate<0x120 + 8>(sum) + dpp_row_rotate<0x120 + 12>(sum));
+                sum = (sum + dpp_row_rotate<0x120 + 1>(sum)) + (dpp_row_rotate<0x120 + 2>(sum) + dpp_row_rotate<0x120 + 3>(sum));
+                if (c == 0) g.part[((size_t)blockIdx.x * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = n < g.N ? sum : 0.0;
+            }
+            continue;
+        }
+    }
     // result lane 16 r + 4 b + c of acc[i][j]: partial sum b of D^T[n0 + wn + 4 i + r][m0 + wm + 4 j + c].  After the
     // rotations every lane group b holds the total; group b then stores column block j = 4 jg + b, so that a row of 16
     // lanes writes 16 consecutive m.
