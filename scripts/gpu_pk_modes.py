@@ -24,7 +24,7 @@ if len(sys.argv) > 1:
 out = REPO / 'gpurun_out'
 ref = None
 import numpy as np
-MODES = {'level1': {'VMX_NO_TAB2': '1'}, 'level2_nw1': {'VMX_PK_NW': '1'}, 'default': {}, 'no_fused_chi2': {'VMX_NO_FUSED_CHI2': '1'},
+MODES = {'level1': {'VMX_NO_TAB2': '1'}, 'level2_nw1': {'VMX_PK_NW': '1'}, 'default': {}, 'no_fused_chi2': {'VMX_NO_FUSED_CHI2': '1'}, 'no_plain_pair': {'VMX_NO_PLAIN_PAIR': '1'},
          'noload': {'VEGAMX_LIBRARY': str(REPO / 'build_exp' / 'libvegamx_noload.so')}, 'B1024': {'PKB': '1024'}}
 for label in (os.environ.get('PK_MODES', 'level1,default').split(',')):
     env = MODES[label]

@@ -2144,6 +2144,22 @@ static int quad_build(vmx_engine* e)
             for (int c = 0; c < term.n_coef; ++c) { d.q_slot[na++] = term.slot[c]; boff.push_back(term.basis_off + (int64_t)c * d.d.n_dist); }
         }
         d.q_na = na; d.nq = d.d.n_model + na; d.nq_pad = vmx_pad(d.nq);
+        {
+            // k_xi_assemble_quad's lean path: both components are plain spline sums with the standard bias evolution
+            bool plain = d.d.pipe_peak != d.d.pipe_smooth && !getenv("VMX_NO_PLAIN_PAIR");
+            for (int pq : {d.d.pipe_peak, d.d.pipe_smooth}) {
+                const PipeDev& P = e->pipes[pq];
+                if (P.d.tracer[0].evol_kind != VMX_EVOL_STD || P.d.tracer[1].evol_kind != VMX_EVOL_STD || P.d.radiation ||
+                    P.d.uv_shotnoise || P.odd_rel || P.odd_asy || P.poly_basis >= 0) plain = false;
+            }
+            // ... on the same bins (each pipeline carries its own copy of the coordinates)
+            const PipeDev& Pp = e->pipes[d.d.pipe_peak];
+            const PipeDev& Ps = e->pipes[d.d.pipe_smooth];
+            if (Pp.split_evol != Ps.split_evol || Pp.n != Ps.n) plain = false;
+            for (const std::vector<double>* h : {&e->h_r, &e->h_mu_c, &e->h_lnrelz, &e->h_lnrelz2, &e->h_growth})
+                if (plain && std::memcmp(h->data() + Pp.coord_off, h->data() + Ps.coord_off, (size_t)Pp.n * sizeof(double)) != 0) plain = false;
+            d.plain_pair = plain ? 1 : 0;
+        }
         const int nq = d.nq, nqp = d.nq_pad;
         // reference vector x0' = [vec(theta_ref) ; (1 + bao) c_j(theta_ref)]
         std::vector<double> x0((size_t)nqp, 0.0);

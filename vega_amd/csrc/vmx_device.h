@@ -104,6 +104,7 @@ struct ItemDev {
     double* z;                                // [S][B][n_masked_pad] C^-1 residual slabs
     // static quadratic form of chi2 (k_assemble_quad / k_chi2_quad): x' = [pre-distortion vector ; additive
     // post-distortion broadband coefficients (1 + bao) c_j], expanded around the reference point x0'
+    int32_t plain_pair;                       // peak and smooth component are plain spline sums (k_xi_assemble_quad)
     int32_t nq, nq_pad, q_na;                 // n_model + q_na entries, padded stride
     int32_t q_slot[VMX_MAX_QUAD_COEF];        // theta column of coefficient j
     const double* q_x0;                       // [nq_pad]  reference vector
@@ -522,6 +523,29 @@ __device__ __forceinline__ double vmx_rsqrt(double x)
     const double y = __builtin_amdgcn_rsq(x);
     const double e = fma(-(x * y), y, 1.0);
     return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+// ln(x) for finite x > 0 (no special cases), |error| < 1 ulp: x = 2^k m with m in [sqrt(1/2), sqrt(2)), f = m - 1,
+// s = f / (2 + f), ln m = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-7 minimax polynomial R of the classic
+// formulation (coefficients Lg1..Lg7 of fdlibm's e_log.c); ~40 instructions against the library's ~100.
+__device__ __forceinline__ double vmx_log(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);              // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const int up = m < 0.70710678118654752440 ? 1 : 0;
+    m = ldexp(m, up); k -= up;                              // [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0, d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double sq = f * r;
+    sq = fma(fma(-d, sq, f), r, sq);                        // s = f / d
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+    return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(sq, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
 }
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -2711,7 +2735,7 @@ __device__ __forceinline__ double xi_bin_value(const EngineDev& D, int p, int b,
             rr2 = fma(rrp, rrp, rrt * rrt);
             if (rr2 != 0.0) rmu = rrp * vmx_rsqrt(rr2);
         }
-        if (rr2 != 0.0) xi = spline_legendre<MODE == 1>(D, P, b, nB, 0.5 * log(rr2), rmu, a0, a1, a2, oob);
+        if (rr2 != 0.0) xi = spline_legendre<MODE == 1>(D, P, b, nB, 0.5 * vmx_log(rr2), rmu, a0, a1, a2, oob);
     }
 
     // bias evolution (correlation_func.py:276-370) and growth (:143)
@@ -2838,8 +2862,35 @@ __global__ __launch_bounds__(256) void k_xi_assemble_quad(EngineDev D)
         const PipeDev& Pp = D.pipes[it.d.pipe_peak];
         const PipeDev& Ps = D.pipes[it.d.pipe_smooth];
         bool oob_p, oob_s;
-        const double xs = xi_bin_value<0>(D, it.d.pipe_smooth, b, i, nB, oob_s);
-        const double xp = xi_bin_value<0>(D, it.d.pipe_peak, b, i, nB, oob_p);
+        double xs, xp;
+        if (it.plain_pair) {
+            // Both components are plain spline sums with the standard bias evolution (the item's flag, set by the host: no
+            // radiation / shot-noise / odd-multipole term, no single multipole): everything that is not the spline itself -
+            // the evolution exponential, the growth factor, the coordinates - is formed once for the two of them.
+            const size_t c = Pp.coord_off + i;
+            const double r = D.cr[c], rp0 = D.crp[c], rt0 = D.crt[c];
+            const double* scp = D.scal + ((size_t)b * D.n_pipe + it.d.pipe_peak) * VMX_NS;
+            const double* scs = D.scal + ((size_t)b * D.n_pipe + it.d.pipe_smooth) * VMX_NS;
+            const double ev = (Pp.split_evol ? vmx_exp(fma(scp[S_EV1A], D.clnrelz[c], scp[S_EV2A] * D.clnrelz2[c]))
+                                             : vmx_exp((scp[S_EV1A] + scp[S_EV2A]) * D.clnrelz[c])) * D.cgrowth[c];
+            xs = 0.0; xp = 0.0; oob_p = false; oob_s = false;
+            if (r != 0.0) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const double* sc = half ? scp : scs;
+                    const double rrp = sc[S_AP] * (rp0 + sc[S_DRP]), rrt = sc[S_AT] * rt0;
+                    const double rr2 = fma(rrp, rrp, rrt * rrt);
+                    if (rr2 != 0.0) {
+                        const double v = spline_legendre<false>(D, half ? Pp : Ps, b, nB, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2),
+                                                                0.0, 0.0, 0.0, half ? oob_p : oob_s);
+                        if (half) xp = v * ev; else xs = v * ev;
+                    }
+                }
+            }
+        } else {
+            xs = xi_bin_value<0>(D, it.d.pipe_smooth, b, i, nB, oob_s);
+            xp = xi_bin_value<0>(D, it.d.pipe_peak, b, i, nB, oob_p);
+        }
         if (oob_p || oob_s) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
         D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + i] = xs;        // (the stage taps stay valid)
         D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + i] = xp;
