@@ -395,6 +395,7 @@ static int plan_gemm(vmx_engine* e, GemmArgs& g, int nbatch, int slab_rows_avail
     g.tm = tm; g.tn = tn; g.k_limit = k_limit; g.tri = tri ? 1 : 0;
     const int ngroups = 8 / nsplit;
     *per_xcd = ((tm_eff + ngroups - 1) / ngroups) * tn;
+    if (g.m_window && nsplit == 1 && e->gemm_44) *per_xcd = tm_eff * ((tn + 7) / 8);     // walker tiles over the XCDs (k_gemm_nt44: n_major)
     return nsplit;
 }
 

@@ -2196,8 +2196,13 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     const GemmArgs& g = G.p[pi];
     const int split = list ? wk.slab : xcd % g.nsplit, group = xcd / g.nsplit, ngroups = 8 / g.nsplit;
     const int tm_eff = g.tri ? (g.tm + 1) / 2 : g.tm;
-    const int mt0 = list ? wk.mt : (seq / g.tn) * ngroups + group, nt = list ? wk.nt : seq % g.tn;
-    if (!list && mt0 >= tm_eff) return;
+    // A problem with a row window spreads its WALKER tiles over the XCDs (XCD x takes nt = x, x + 8, ...): the live row tiles
+    // are a few consecutive ones, which the row-major order below would hand to as many XCDs and leave the others idle.
+    const bool n_major = !list && g.m_window != nullptr && g.nsplit == 1 && !g.tri;
+    const int tnx = (g.tn + 7) / 8;
+    const int mt0 = list ? wk.mt : n_major ? seq / tnx : (seq / g.tn) * ngroups + group;
+    const int nt = list ? wk.nt : n_major ? (seq % tnx) * 8 + xcd : seq % g.tn;
+    if (!list && (mt0 >= tm_eff || nt >= g.tn)) return;
     const int npass = (!list && g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
     const int batch = blockIdx.y;
     const char* A = (const char*)(g.A + batch * g.a_batch);
