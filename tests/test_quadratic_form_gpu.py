@@ -150,3 +150,62 @@ def test_quadratic_form_on_the_sixteen_by_sixteen_kernel():
         vega.close()
     finally:
         del os.environ['VMX_QUAD_44']
+
+
+def test_single_walker_chain_tables_and_host_side_sum():
+    """A single walker through the host entry: from the second call with the same shared (Arinyo / Gaussian-factor)
+    parameters on, the P(k,mu) stage runs against the persistent level-2 tables, and the streaming products of the
+    quadratic form leave per-block sums that the host adds up (no chi2 kernel).  Same chi2 as the batched paths, the full
+    chain and the oracle - with priors, with a mock as data, after the shared parameters change and come back."""
+    from oracle import vega_cpu as oc
+    from vega_amd import VegaInterface, synthetic
+    from vega_amd.montecarlo import create_mocks
+    prob = synth_joint_problem()
+    prob.priors = {'beta_LYA': np.array([1.5, 0.1]), 'ap': np.array([1.0, 0.05])}
+    try:
+        vega = VegaInterface(None, problem=prob, max_batch=32)
+    finally:
+        prob.priors = {}
+    eng = vega.engine
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 6, varied=VARIED, seed=12, scale=0.02)
+    prior = ((theta[:, eng.low.slot['beta_LYA']] - 1.5) / 0.1)**2 + ((theta[:, eng.low.slot['ap']] - 1.0) / 0.05)**2
+    batch = eng.eval(np.tile(theta, (4, 1))[:20])[0][:6]                 # B = 20: table kernel + contraction epilogue
+    full = eng.eval(theta, want_model=True)[0]                           # the full chain
+    np.testing.assert_allclose(batch, full, rtol=1e-11)
+    singles = np.array([[eng.eval(theta[i:i + 1])[0][0] for i in range(6)] for _ in range(3)])
+    # (first pass: the per-walker loops - the shared parameters have to come twice; then the tables)
+    np.testing.assert_allclose(singles[0], full, rtol=1e-11)
+    np.testing.assert_allclose(singles[1], full, rtol=1e-11)
+    np.testing.assert_array_equal(singles[2], singles[1])
+    for i in (0, 3):
+        assert singles[2][i] == pytest.approx(oc.chi2(vega.problem, dict(zip(eng.names, theta[i]))) + prior[i], rel=CHI2_RTOL)
+    # other smoothing for a while, then back
+    other = theta.copy()
+    other[:, eng.low.slot['par_sigma_smooth']] *= 1.2
+    ref_other = eng.eval(other, want_model=True)[0]
+    for _ in range(3):
+        got = np.array([eng.eval(other[i:i + 1])[0][0] for i in range(6)])
+        np.testing.assert_allclose(got, ref_other, rtol=1e-11)
+    assert np.abs(got / singles[2] - 1).max() > 1e-7
+    for _ in range(3):
+        got = np.array([eng.eval(theta[i:i + 1])[0][0] for i in range(6)])
+        np.testing.assert_allclose(got, full, rtol=1e-11)
+    # a mock as data for the single walker: the linear term's row and the constant follow the mock index
+    mocks = create_mocks(prob, vega.compute_model(), 3, seed=4)
+    for name, pool in mocks.items():
+        eng.set_mock_pool(name, pool)
+    eng.set_mock_index(np.array([2], dtype=np.int32))
+    with_mock = [eng.eval(theta[1:2])[0][0] for _ in range(3)]
+    eng.set_mock_index(np.array([2] * 20, dtype=np.int32))
+    np.testing.assert_allclose(with_mock, eng.eval(np.tile(theta[1:2], (20, 1)))[0][0], rtol=1e-10)
+    data = {n: mocks[n][2] for n in mocks}
+    assert with_mock[2] == pytest.approx(oc.chi2(prob, dict(zip(eng.names, theta[1])), data_override=data) + prior[1], rel=CHI2_RTOL)
+    eng.set_mock_index(None)
+    # an out-of-range walker keeps its sentinel and its status on this path
+    bad = theta[0:1].copy()
+    bad[0, eng.low.slot['ap']] = 400.0
+    for _ in range(3):
+        c, s, _ = eng.eval(bad)
+        assert c[0] == 1e100 and s[0] != 0
+    np.testing.assert_allclose(eng.eval(theta[0:1])[0][0], full[0], rtol=1e-11)
+    vega.close()

@@ -36,6 +36,9 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 namespace {
 
+static const uint64_t VMX_PART_SENTINEL = 0x7ff8dead0000beefull;      // a NaN payload no arithmetic produces (k_gemv1 MODE 2 slots)
+
+
 enum KernelClass {
     KC_PROLOGUE = 0, KC_PK, KC_FFTLOG, KC_XI, KC_METAL, KC_ASSEMBLE, KC_DISTORTION, KC_POST,
     KC_INVCOV, KC_CHI2, KC_MATVEC, KC_OTHER, KC_QUAD
@@ -108,6 +111,7 @@ struct ItemHost {
     // quadratic form of chi2 (vmx_device.h): W = DM'^T S^T C^-1 [nq][n_masked_pad] is kept so that new data / mocks only
     // redo the linear terms
     DevBuf<double> q_mat, q_w, q_lin, q_c0, q_x0, q_x, q_z;
+    std::vector<double> h_q_c0;         // host copy of q_c0 (the single-walker chain adds the constants on the host)
     DevBuf<int64_t> q_basis_off;
     int q_rows = 0;                     // rows of q_lin / q_c0 (1 + mocks)
     int n_templates = 0;
@@ -196,6 +200,9 @@ struct vmx_engine {
     std::map<int, int> quad_seg_len;         // measured segment length by power-of-two class of that number
     bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
     bool quad_fused_chi2 = true;     // VMX_NO_FUSED_CHI2: the list launch stores the product, k_chi2_quad contracts it
+    std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
+    bool host_key_valid = false, skip_xtab_once = false;
+    bool no_small_tab = false;       // VMX_NO_SMALL_TAB: batches below 16 walkers never use the tables
     int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
     int xi_fused_max_b = 1 << 30;    // VMX_XI_FUSED_MAXB (an experiment knob: the fused kernel wins at every batch size)
     bool no_tab2 = false;            // VMX_NO_TAB2: level-1 tables only (the Gaussian factors stay in the mu loop)
@@ -225,6 +232,10 @@ struct vmx_engine {
     DevBuf<double> d_blind;
     double* dpin_theta = nullptr; double* dpin_chi2 = nullptr; int32_t* dpin_status = nullptr;   // device views
     int64_t* pin_done = nullptr; int64_t* dpin_done = nullptr; int64_t done_seq = 0;          // completion word of single-walker calls
+    // single-walker quadratic form: one number per block of the last products (k_gemv1 MODE 2), added up by the host
+    double* pin_part = nullptr; double* dpin_part = nullptr;
+    int host_reduce_items = 0, host_reduce_blocks[VMX_MAX_GROUP] = {0};
+    bool no_host_reduce = false;     // VMX_NO_HOST_REDUCE
     std::map<int, hipGraphExec_t> graphs;
     bool use_graphs = true;
     bool graph_b1 = false;           // VMX_GRAPH_B1: replay a captured graph for single-walker host evaluations too
@@ -248,6 +259,7 @@ struct vmx_engine {
         if (pin_chi2) (void)hipHostFree(pin_chi2);
         if (pin_status) (void)hipHostFree(pin_status);
         if (pin_done) (void)hipHostFree(pin_done);
+        if (pin_part) (void)hipHostFree(pin_part);
         for (auto& a : aux) (void)hipStreamDestroy(a);
         for (auto& ev : ev_join) (void)hipEventDestroy(ev);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -497,11 +509,11 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
         dim3 grid(blocks, 1, nbatch), block(256);
         const size_t shmem = (size_t)K * sizeof(double);
         if (fused_item >= 0) {
-            if (K <= 2560) hipLaunchKernelGGL((k_gemv1<5, true>), grid, block, shmem, e->cur, g, e->dev, fused_item);
-            else hipLaunchKernelGGL((k_gemv1<10, true>), grid, block, shmem, e->cur, g, e->dev, fused_item);
+            if (K <= 2560) hipLaunchKernelGGL((k_gemv1<5, 1>), grid, block, shmem, e->cur, g, e->dev, fused_item);
+            else hipLaunchKernelGGL((k_gemv1<10, 1>), grid, block, shmem, e->cur, g, e->dev, fused_item);
         } else {
-            if (K <= 2560) hipLaunchKernelGGL((k_gemv1<5, false>), grid, block, shmem, e->cur, g, e->dev, 0);
-            else hipLaunchKernelGGL((k_gemv1<10, false>), grid, block, shmem, e->cur, g, e->dev, 0);
+            if (K <= 2560) hipLaunchKernelGGL((k_gemv1<5, 0>), grid, block, shmem, e->cur, g, e->dev, 0);
+            else hipLaunchKernelGGL((k_gemv1<10, 0>), grid, block, shmem, e->cur, g, e->dev, 0);
         }
         return 1;
     }
@@ -1127,6 +1139,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
     if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
+    if (getenv("VMX_NO_SMALL_TAB")) e->no_small_tab = true;
+    if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
     if (const char* v = getenv("VMX_XI_FUSED_MAXB")) e->xi_fused_max_b = atoi(v);
     if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
@@ -1315,6 +1329,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             std::vector<double> key((size_t)e->n_xtab * VMX_XTAB_KEY + 1, std::nan(""));
             if (e->d_xtab_pipe.upload(xp.data(), xp.size()) || e->d_xtab_partner.upload(xq.data(), xq.size()) ||
                 e->xtab_key.upload(key.data(), key.size())) return -2;
+            e->host_key_valid = false; e->pending_key.clear();
         }
         e->const_slots.push_back(-1);
         e->const_slots2.push_back(-1);
@@ -1484,6 +1499,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     HIP_OK(hipHostMalloc((void**)&e->pin_status, (size_t)Bm * sizeof(int32_t), hipHostMallocMapped));
     HIP_OK(hipHostMalloc((void**)&e->pin_done, sizeof(int64_t), hipHostMallocMapped));
     *e->pin_done = 0;
+    if (hipHostMalloc((void**)&e->pin_part, (size_t)VMX_MAX_GROUP * 1024 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&e->dpin_part, e->pin_part, 0) != hipSuccess) { (void)hipGetLastError(); e->dpin_part = nullptr; }
     if (getenv("VMX_NO_DONE_WORD") || hipHostGetDevicePointer((void**)&e->dpin_done, e->pin_done, 0) != hipSuccess) { (void)hipGetLastError(); e->dpin_done = nullptr; }
     if (!getenv("VMX_NO_ZERO_COPY") &&
         (hipHostGetDevicePointer((void**)&e->dpin_theta, e->pin_theta, 0) != hipSuccess ||
@@ -1760,7 +1777,9 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         int mu_tab_off = want_mu_tab ? (int)(shmem / sizeof(double)) : -1;
         if (want_mu_tab) shmem += (size_t)2 * e->n_mu * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
-        if (tab_mode)
+        const bool skip_xtab = e->skip_xtab_once;
+        e->skip_xtab_once = false;
+        if (tab_mode && !skip_xtab)
             hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, (e->n_rows + XTAB_ROWS - 1) / XTAB_ROWS, e->n_xtab), dim3(256), 0, e->stream, D);
         if (!e->pk_poly.empty())
             hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
@@ -1771,8 +1790,8 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             n_other = n_groups - e->n_xtab;
             const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
             if (getenv("VMX_PK_TRACE")) {
-                e->pk_trace_blocks = (size_t)B * ((e->nk + 15) / 16) * e->tab2_groups.size();     // (an upper bound: unused entries stay zero)
-                if (!e->pk_trace.p && e->pk_trace.alloc(4 * (size_t)e->max_batch * ((e->nk + 15) / 16) * e->tab2_groups.size(), true)) return -2;
+                e->pk_trace_blocks = (size_t)B * ((e->nk + 7) / 8) * e->tab2_groups.size();     // (an upper bound: unused entries stay zero)
+                if (!e->pk_trace.p && e->pk_trace.alloc(4 * (size_t)e->max_batch * ((e->nk + 7) / 8) * e->tab2_groups.size(), true)) return -2;
                 D.pk_trace = e->pk_trace.p;
             }
             for (size_t first = 0; first < e->tab2_groups.size(); first += VMX_TAB2_GROUPS) {
@@ -1784,7 +1803,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                         hipLaunchKernelGGL((k_pk_tab2<64, 4, 2>), dim3((B + 1) / 2, n, (e->nk + 63) / 64), dim3(256), std::max(sh1, (size_t)4096 * sizeof(double)), e->stream, D, A, B);
                     else
                         hipLaunchKernelGGL((k_pk_tab2<64, 4, 1>), dim3(B, n, (e->nk + 63) / 64), dim3(256), sh1, e->stream, D, A, B);
-                } else
+                } else      // (8 x 32 blocks for a single walker measured the same: 12 us)
                     hipLaunchKernelGGL((k_pk_tab2<16, 16, 1>), dim3(B, n, (e->nk + 15) / 16), dim3(256), sh1, e->stream, D, A, B);
             }
         }
@@ -1915,6 +1934,39 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             }
             ScopedTimer t(e, KC_QUAD);
             launch_gemm_group(e, KC_QUAD, G, per_xcd_total, 1);
+        } else if (B == 1 && D.done_host && e->dpin_part && !e->no_host_reduce && e->items.size() <= VMX_MAX_GROUP) {
+            // single walker through the host entry: every block of the streaming products leaves its share of the contraction
+            // in mapped host memory, the host adds them up (vmx_eval) - no chi2 kernel
+            bool ok = true;
+            for (auto* it : e->items) ok = ok && gemv1_applies(1, it->dev.nq_pad) && gemv1_blocks(it->dev.nq) <= 1024 && it->dev.nq_pad <= 2560 * 2;
+            if (ok) {
+                e->host_reduce_items = (int)e->items.size();
+                for (size_t q = 0; q < e->items.size(); ++q) {
+                    ItemHost* it = e->items[q];
+                    const ItemDev& d = it->dev;
+                    const int mock = (d.mock_pool && e->h_mock_index[0] >= 0) ? e->h_mock_index[0] : -1;
+                    GemmArgs g{};
+                    g.A = it->q_mat.p; g.lda = d.nq_pad; g.X = it->q_x.p; g.ldx = d.nq_pad; g.D = it->q_z.p; g.ldd = d.nq_pad;
+                    g.M = d.nq; g.N = 1; g.K = d.nq_pad; g.tri = 1; g.nsplit = 1; g.klen = d.nq_pad;
+                    g.part = e->dpin_part + q * 1024; g.lin = it->q_lin.p + (size_t)(mock >= 0 ? 1 + mock : 0) * d.nq_pad;
+                    const int blocks = gemv1_blocks(d.nq);
+                    e->host_reduce_blocks[q] = blocks;
+                    ScopedTimer t(e, KC_QUAD);
+                    const int last = q + 1 == e->items.size() ? 1 : 0;
+                    if (d.nq_pad <= 2560) hipLaunchKernelGGL((k_gemv1<5, 2>), dim3(blocks), dim3(256), (size_t)d.nq_pad * sizeof(double), e->stream, g, D, last);
+                    else hipLaunchKernelGGL((k_gemv1<10, 2>), dim3(blocks), dim3(256), (size_t)d.nq_pad * sizeof(double), e->stream, g, D, last);
+                }
+                HIP_OK(hipGetLastError());
+                e->last_B = B;
+                e->last_full = false;
+                return 0;
+            }
+            for (size_t q = 0; q < e->items.size(); ++q) {
+                ItemHost* it = e->items[q];
+                const ItemDev& d = it->dev;
+                qs.z[q] = launch_product(e, KC_QUAD, it->q_mat.p, d.nq_pad, 0, d.nq, d.nq_pad, it->q_x.p, d.nq_pad, 0, B,
+                                         it->q_z.p, d.nq_pad, 0, 1, e->slab_rows, nullptr, -1, true);
+            }
         } else {
             for (size_t q = 0; q < e->items.size(); ++q) {
                 ItemHost* it = e->items[q];
@@ -2220,6 +2272,8 @@ static int quad_build(vmx_engine* e)
         if (it->q_z.n < (size_t)e->slab_rows * nqp && it->q_z.alloc((size_t)e->slab_rows * nqp, true)) return -2;
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(e->stream));
+        it->h_q_c0.resize(rows);
+        HIP_OK(hipMemcpy(it->h_q_c0.data(), it->q_c0.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost));
         d.q_x0 = it->q_x0.p; d.q_lin = it->q_lin.p; d.q_c0 = it->q_c0.p; d.q_x = it->q_x.p; d.q_z = it->q_z.p;
     }
     std::vector<ItemDev> items;
@@ -2255,6 +2309,7 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     REQUIRE(e && e->finalized && d_theta, "vmx_eval_device");
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
+    e->host_key_valid = false;          // (device-resident walkers may rebuild the tables: the host no longer knows their key)
     bool quad = false;
     if (!d_model && quad_ready(e, &quad, B)) return -2;
     if (!e->blind_scale.empty()) {
@@ -2419,18 +2474,43 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     if (!zero_copy)
         HIP_OK(hipMemcpyAsync(e->theta.p, e->pin_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyHostToDevice, e->stream));
     // the D_NL * G table pays off once a batch shares its Arinyo parameters (checked here, on the host copy)
-    int tab_mode = (B >= 16 && e->n_xtab > 0) ? (e->no_tab2 ? 1 : 2) : 0;
+    int tab_mode = (e->n_xtab > 0) ? (e->no_tab2 ? 1 : 2) : 0;
     for (int b = 1; b < B && tab_mode; ++b) {
         for (int slot : e->const_slots)
             if (theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = 0; break; }
         for (int slot : e->const_slots2)
             if (tab_mode == 2 && theta[(size_t)b * e->n_params + slot] != theta[slot]) { tab_mode = 1; break; }
     }
+    // The tables outlive an evaluation (keyed on the shared parameters).  A small batch - a single walker of a minimiser or
+    // sampler above all - runs against level-2 tables once those parameters have come twice in a row; a caller that varies
+    // them from call to call keeps the per-walker loops (building tables costs more than one small evaluation).
+    bool tables_current = false;
+    {
+        std::vector<double> cur;
+        for (int slot : e->const_slots2) cur.push_back(theta[slot]);
+        tables_current = tab_mode == 2 && e->host_key_valid && cur == e->host_key;
+        if (B < 16 && tab_mode) {
+            if (tab_mode == 2 && !e->no_small_tab && (tables_current || cur == e->pending_key)) tab_mode = 2;
+            else { if (tab_mode == 2) e->pending_key = cur; tab_mode = 0; }
+        }
+        if (tab_mode == 2) { e->host_key = cur; e->host_key_valid = true; }
+        else if (tab_mode == 1) e->host_key_valid = false;       // (the device tables now hold level 1)
+    }
     const auto t_staged = std::chrono::steady_clock::now();
     // a single walker is latency-bound end to end: eager launches start the first kernel while the later ones are
     // still being enqueued, which a graph launch cannot (measured: 70 against 75 us per evaluation)
+    e->host_reduce_items = 0;
     if (B == 1 && !e->graph_b1) {
         const bool by_value = zero_copy && e->n_params <= VMX_THETA_ARG_MAX;
+        e->skip_xtab_once = tables_current;         // (the host knows the tables hold these parameters: no check launch)
+        if (quad && by_value && e->pin_part && e->dpin_part) {
+            // the slots the last products may fill (k_gemv1 MODE 2) start from a pattern no computation produces
+            for (size_t q = 0; q < e->items.size() && q < VMX_MAX_GROUP; ++q) {
+                const int blocks = gemv1_blocks(e->items[q]->dev.nq);
+                for (int i = 0; i < blocks && i < 1024; ++i) std::memcpy(&e->pin_part[q * 1024 + i], &VMX_PART_SENTINEL, sizeof(double));
+            }
+            e->pin_status[0] = -1;
+        }
         if (run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad, by_value ? e->pin_theta : nullptr)) return -2;
     }
     else if (run_chain_cached(e, B, tab_mode, zero_copy, quad)) return -2;
@@ -2439,7 +2519,42 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     if (model) HIP_OK(hipMemcpyAsync(model, e->model.p, (size_t)B * e->model_size * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     const auto t_enqueued = std::chrono::steady_clock::now();
     bool waited = false;
-    if (B == 1 && zero_copy && !model && !e->graph_b1 && e->dpin_done && !e->profiling && e->n_params <= VMX_THETA_ARG_MAX) {
+    if (e->host_reduce_items > 0) {
+        // the chain ended with the streaming products of the quadratic form: add up what their blocks left here
+        // (fixed order), the constants and the priors - vega_interface.py:316, :423-446
+        double c = 0.0;
+        bool complete = true;
+        for (int q = 0; q < e->host_reduce_items && complete; ++q) {
+            const volatile uint64_t* slot = (const volatile uint64_t*)(e->pin_part + (size_t)q * 1024);
+            for (int i = 0; i < e->host_reduce_blocks[q] && complete; ++i) {
+                int64_t spin = 0;
+                while (slot[i] == VMX_PART_SENTINEL && spin < ((int64_t)1 << 28)) ++spin;
+                uint64_t bits = slot[i];
+                if (bits == VMX_PART_SENTINEL) { complete = false; break; }
+                double v; std::memcpy(&v, &bits, sizeof(double));
+                c += v;
+            }
+        }
+        volatile int32_t* st_word = e->pin_status;
+        for (int64_t spin = 0; complete && *st_word == -1 && spin < ((int64_t)1 << 28); ++spin) {}
+        if (!complete || *st_word == -1) { e->host_reduce_items = 0; fail(-2, "single-walker chain: the device did not report back"); (void)vmx_sync(e); return -2; }
+        for (int q = 0; q < e->host_reduce_items; ++q) {
+            const ItemHost* it = e->items[q];
+            const int mock = (it->dev.mock_pool && e->h_mock_index[0] >= 0) ? e->h_mock_index[0] : -1;
+            c += it->h_q_c0[mock >= 0 ? 1 + mock : 0];
+        }
+        for (size_t q = 0; q < e->prior_slot.size(); ++q) {
+            const double dlt = e->pin_theta[e->prior_slot[q]] - e->prior_mean[q];
+            c += dlt * dlt / (e->prior_sigma[q] * e->prior_sigma[q]);
+        }
+        int32_t st = *st_word;
+        if (!(c == c) || c > 1e300 || c < -1e300) st |= VMX_STATUS_NONFINITE;
+        e->pin_status[0] = st;
+        e->pin_chi2[0] = st ? 1e100 : c;
+        e->host_reduce_items = 0;
+        waited = true;
+    }
+    if (!waited && B == 1 && zero_copy && !model && !e->graph_b1 && e->dpin_done && !e->profiling && e->n_params <= VMX_THETA_ARG_MAX) {
         // the last kernel of a single-walker chain publishes a sequence number after chi2 / status (system-scope fence):
         // the host waits on that word in mapped memory - a few microseconds sooner than the stream's completion signal
         const int64_t want = e->done_seq;

@@ -2543,9 +2543,15 @@ __global__ __launch_bounds__(256) void k_gemv(GemmArgs g)
 //   FUSED (distortion step of a single walker): x is assembled on the fly while it is staged (k_assemble's work, redone
 //   by every block - 10 bins per thread) and each finished row goes straight through k_post's epilogue, which
 //   removes two launches from a ~100 us latency-bound chain.
-template <int CPW, bool FUSED>
+// MODE 0: D = A x.  MODE 1 (FUSED): x assembled from the item's components while staging, the result goes through post_bin.
+// MODE 2: the single-walker quadratic form - the block contracts its rows with x, sum_r x[r] 2 (z[r] - lin[r]), and leaves
+// that ONE number in g.part[block] (mapped host memory: the host adds the blocks' numbers, constants and priors itself - no
+// reduction kernel at the end of a latency-bound chain); block 0 also hands over the status word and does the chain's
+// end-of-evaluation duties (item = 1: this is the last product of the chain).
+template <int CPW, int MODE>
 __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g, EngineDev D, int item)
 {
+    constexpr bool FUSED = MODE == 1;
     extern __shared__ double sx[];                 // [K]
     __shared__ double part[GEMV1_MAX_ROWS][4];
     const int batch = blockIdx.z;
@@ -2604,6 +2610,27 @@ __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g, EngineDev D, int item
     }
     if (n_rows & 1) reduce_row(bufa, row0 + (n_rows - 1) * G, n_rows - 1);
     __syncthreads();
+    if constexpr (MODE == 2) {
+        static_assert(GEMV1_MAX_ROWS <= 64, "the rows of a block are contracted by its first wave");
+        if (tid < 64) {
+            double pr = 0.0;
+            if (tid < t) {
+                const int r = blockIdx.x + tid * gridDim.x;
+                const double v = (part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]);
+                pr = sx[r] * (2.0 * (v - g.lin[r]));
+            }
+            for (int off = 32; off > 0; off >>= 1) pr += __shfl_down(pr, off, 64);
+            if (tid == 0) {
+                *(volatile double*)&g.part[blockIdx.x] = pr;
+                if (blockIdx.x == 0 && item) {
+                    *(volatile int32_t*)D.status_host = D.status[0];
+                    D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
+                    xtab_key_store(D);
+                }
+            }
+        }
+        return;
+    }
     if (tid < t) {
         const int r = blockIdx.x + tid * gridDim.x;
         const double v = (part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]);
