@@ -5,7 +5,10 @@
 //   k_prologue        parameters -> per-(walker, pipeline) scalars        utils.py:45-108, scale_parameters.py:38-230
 //   k_gk_table        G(k,mu) binning table (static)                       power_spectrum.py:481-502
 //   k_pk_multipoles   P(k,mu) and its Legendre projection, fused           power_spectrum.py:87-196 + pktoxi.py:138
-//   k_xtab            D_NL(k,mu)^p G(k,mu) of a batch that shares its non-linear parameters   power_spectrum.py:435-502
+//   k_xtab            per-batch tables: D_NL(k,mu)^p G(k,mu) of a batch that shares its non-linear parameters (level 1),
+//                     times the Gaussian smoothing / broadening factors, + a table for the peak component (level 2)
+//                                                                          power_spectrum.py:435-502, :382-417, :526-556
+//   k_pk_tab2         P(k,mu) and its projection for the core groups against level-2 tables   power_spectrum.py:163-380
 //   k_pk_poly         pipelines whose mu dependence is the Kaiser polynomial x static G: closed form
 //   k_gemm_nt44 / k_gemm_nt / k_gemv / k_gemv1   D = A . X for a static matrix and a batch of walker vectors
 //                     (4x4x4 four-block MFMA / 16x16x4 MFMA / streaming for <= 8 walkers / one walker):
@@ -17,6 +20,10 @@
 //   k_assemble        peak/smooth/metals combination + pre-distortion broadband   model.py:119-140,186, metals.py:331-334
 //   k_post            post-distortion broadband, model output, masked residual   model.py:147-149, vega_interface.py:310-315
 //   k_chi2            diff^T C^-1 diff + priors + error sentinel                  vega_interface.py:268-279,304,316-319
+//   chi2-only evaluations (static quadratic form, include/vegamx.h: vmx_set_quadratic_form):
+//   k_xi_assemble_quad / k_assemble_quad   bins of both components + the entry x' - x0'   (k_xi_bins + k_assemble)
+//   k_gemm_nt44<12> / k_gemv1<., 2>        Q' (x' - x0'), contracted with x' - x0' in the epilogue    model.py:143-144 + vega_interface.py:316
+//   k_chi2_parts / k_chi2_quad             the contraction's partial sums + constants + priors + sentinel
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
