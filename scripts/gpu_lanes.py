@@ -7,14 +7,14 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from vega_amd import VegaInterface, synthetic  # noqa: E402
 
-B = 256
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 prob = bench.build_problem('joint')
 dev = torch.device('cuda', 0)
-for lanes in (1, 2, 3):
+for lanes in (1, 2, 4):
     vegas = [VegaInterface(None, problem=prob, max_batch=B) for _ in range(lanes)]
     engs = [v.engine for v in vegas]
     for e in engs:
-        e.set_constant_nl_hint(True)
+        e.set_constant_nl_hint(True, gaussian=True)
     pools = [torch.from_numpy(synthetic.walkers(engs[0].low.theta0, engs[0].names, B, varied=bench.VARIED, seed=100 + i)).to(dev)
              for i in range(8)]
     outs = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(lanes)]

@@ -497,3 +497,24 @@ def test_wide_parameter_ranges_against_the_oracle():
         for name, sl in eng.model_slices.items():
             _assert_xi(model[i, sl], ref[name], f'walker {i} {name}')
     vega.close()
+
+
+def test_level2_tables_on_four_correlations_with_metals():
+    """Four correlations (two auto, two cross groups with tables) + metal pairs, an odd batch on the two-walkers-per-thread
+    shape: level-2 chi2 against the per-walker loops (the first small batch of an engine takes them) and the oracle."""
+    from oracle import vega_cpu as oc
+    from vega_amd import synthetic
+    vega = _engine('full4', max_batch=160)
+    eng = vega.engine
+    varied = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'bias_hcd', 'beta_hcd', 'L0_hcd']
+    varied = [n for n in varied if n in eng.low.slot]
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 131, varied=varied, seed=44, scale=0.02)
+    direct = eng.eval(theta[:8])[0]                      # first small batch: no tables yet
+    big, status, _ = eng.eval(theta)
+    assert not status.any()
+    np.testing.assert_allclose(big[:8], direct, rtol=1e-11)
+    np.testing.assert_allclose(eng.eval(theta[:40])[0], big[:40], rtol=1e-11)       # one walker per thread
+    np.testing.assert_allclose(eng.eval(theta, want_model=True)[0], big, rtol=1e-10)   # full chain, same tables
+    for i in (0, 77, 130):
+        assert big[i] == pytest.approx(oc.chi2(vega.problem, dict(zip(eng.names, theta[i]))), rel=CHI2_RTOL)
+    vega.close()
