@@ -367,7 +367,7 @@ void* vmx_stream(vmx_engine* e);
  * global order of vmx_item_add_metal).
  * 4 = {live wavenumbers of the P(k,mu) stage in the last evaluation, k up to which the mu node rule applies (0: off),
  * nodes per wavenumber of that rule, leading wavenumbers whose tiles took the rule in the last evaluation, table level of
- * the last evaluation (vmx_set_constant_nl_hint)}.
+ * the last evaluation (vmx_set_constant_nl_hint), first and last spline-coefficient row the last evaluation's bins read}.
  * Returns the number of doubles written (<= capacity) or a negative error. */
 int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, int64_t capacity);
 

@@ -19,13 +19,13 @@ if len(sys.argv) > 1:
         eng.eval(theta)
     t = eng.timings(reset=True)
     np.save(sys.argv[1], chi2)
-    print(json.dumps({k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in t.items() if v[1]}), list(eng.debug_read(4, 0, 4)))
+    print(json.dumps({k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in t.items() if v[1]}), list(eng.debug_read(4, 0, 7)))
     sys.exit(0)
 out = REPO / 'gpurun_out'
 ref = None
 import numpy as np
 MODES = {'level1': {'VMX_NO_TAB2': '1'}, 'level2_nw1': {'VMX_PK_NW': '1'}, 'default': {}, 'no_fused_chi2': {'VMX_NO_FUSED_CHI2': '1'}, 'no_plain_pair': {'VMX_NO_PLAIN_PAIR': '1'},
-         'noload': {'VEGAMX_LIBRARY': str(REPO / 'build_exp' / 'libvegamx_noload.so')}, 'B1024': {'PKB': '1024'}}
+         'noload': {'VEGAMX_LIBRARY': str(REPO / 'build_exp' / 'libvegamx_noload.so')}, 'B1024': {'PKB': '1024'}, 'fft_1cu': {'VMX_FFT_LDS': '24000'}, 'fft_wide': {'VMX_FFT_WIDE': '1'}, 'fft_wide_1cu': {'VMX_FFT_WIDE': '1', 'VMX_FFT_LDS': '24000'}}
 for label in (os.environ.get('PK_MODES', 'level1,default').split(',')):
     env = MODES[label]
     f = out / f'pkmode_{label}.npy'

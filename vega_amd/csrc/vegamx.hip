@@ -1439,7 +1439,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->metal_bias.alloc((size_t)Bm * 3 * (e->metals.size() + 1)) ||
         e->pl.alloc((size_t)VMX_MAX_ELL * acols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * acols * e->ncp) ||
         e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
-        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(2)) return -2;
+        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(4)) return -2;
     {
         const int32_t empty_window[2] = {0x7fffffff, -1};
         if (e->coef_win.upload(empty_window, 2)) return -2;
@@ -2596,12 +2596,13 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
         // [0] the number of leading wavenumbers with a live P(k,mu) block in the last evaluation (the rest are exact zeros),
         // [1] the wavenumber up to which the mu sums take the node rule (0: plain loop), [2] nodes per wavenumber of that rule
         if (capacity < 3) { fail(-1, "invalid argument: capacity too small"); return -1; }
-        int32_t live[2] = {0, 0};
-        if (hipMemcpy(live, e->k_live.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }
+        int32_t live[4] = {0, 0, 0, 0};
+        if (hipMemcpy(live, e->k_live.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }
         out[0] = live[0]; out[1] = e->dev.k_node_max; out[2] = e->mu_lo + e->mu_hi + e->n_extra;
         if (capacity >= 4) out[3] = live[1];
         if (capacity >= 5) out[4] = e->last_tab_level;
-        return capacity >= 5 ? 5 : capacity >= 4 ? 4 : 3;
+        if (capacity >= 7) { out[5] = live[2]; out[6] = live[3]; }
+        return capacity >= 7 ? 7 : capacity >= 5 ? 5 : capacity >= 4 ? 4 : 3;
     }
     else { fail(-1, "invalid argument: what"); return -1; }
     if (count > capacity) { fail(-1, "invalid argument: capacity too small"); return -1; }

@@ -199,7 +199,8 @@ struct EngineDev {
     // supplied per walker (e.g. by a Boltzmann code); no peak component, and additive terms enter once
     const double* pk_direct;    // [B][nkp] or null
     int32_t* k_live;            // [0] wavenumbers >= *k_live have P_ell = 0 for every walker and pipeline of the batch;
-                                // [1] wavenumbers < k_live[1] sat in tiles that took the mu node rule (a statistic)
+                                // [1] wavenumbers < k_live[1] sat in tiles that took the mu node rule (a statistic);
+                                // [2], [3] the spline-coefficient window of the last evaluation (a statistic)
     unsigned long long* pk_trace;   // debugging aid (VMX_PK_TRACE): per block of k_pk_tab2 {start, end (100 MHz ticks), hw id, xcc id}
     int32_t* coef_win;          // [2] first / last spline coefficient any bin of the batch reads (k_prologue; reset by k_chi2)
     const int32_t* mock_index;  // [B] row of the mock pool used as data by walker b, -1: the item's data vector
@@ -1822,7 +1823,7 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
         if (D.status_host) D.status_host[b] = st;
         if (D.done_host) { __threadfence_system(); *D.done_host = D.done_seq; }      // (set for single-walker calls only)
         if (b == 0) {
-            D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
+            D.k_live[2] = D.coef_win[0]; D.k_live[3] = D.coef_win[1]; D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
             xtab_key_store(D);
         }
     }
@@ -1861,7 +1862,7 @@ __global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const do
     if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
     if (D.status_host) D.status_host[b] = st;
     if (b == 0) {
-        D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
+        D.k_live[2] = D.coef_win[0]; D.k_live[3] = D.coef_win[1]; D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
         xtab_key_store(D);
     }
 }
@@ -2232,9 +2233,12 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     int m0 = 0, kbeg = 0, kend = 0;
     bool skip = false;
     unsigned oa[NP], ox[NP];
+    // (a windowed problem in walker-major order tiles its rows from the window's first row: 240 wanted rows are four tiles
+    // wherever they sit, not five)
+    const int m_base = n_major ? max(g.m_window[0], 0) : 0;
     auto setup = [&](int pass) {
         const int mt = pass == 0 ? mt0 : g.tm - 1 - mt0;
-        m0 = mt * BM;
+        m0 = m_base + mt * BM;
         if (list) { kbeg = wk.kbeg; kend = wk.kend; }
         else if (g.tri) {
             int kmax = ((mt + 1) * BM + BK - 1) / BK * BK; if (kmax > g.K) kmax = g.K;
@@ -2631,7 +2635,7 @@ __global__ __launch_bounds__(256) void k_gemv1(GemmArgs g, EngineDev D, int item
                 *(volatile double*)&g.part[blockIdx.x] = pr;
                 if (blockIdx.x == 0 && item) {
                     *(volatile int32_t*)D.status_host = D.status[0];
-                    D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
+                    D.k_live[2] = D.coef_win[0]; D.k_live[3] = D.coef_win[1]; D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
                     xtab_key_store(D);
                 }
             }
@@ -3000,7 +3004,7 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabI
         if (D.status_host) D.status_host[b] = st;
         if (D.done_host) { __threadfence_system(); *D.done_host = D.done_seq; }      // (set for single-walker calls only)
         if (b == 0) {       // the next evaluation starts from an empty window and clean table flags
-            D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
+            D.k_live[2] = D.coef_win[0]; D.k_live[3] = D.coef_win[1]; D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
             xtab_key_store(D);
         }
     }
