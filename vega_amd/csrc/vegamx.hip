@@ -144,6 +144,8 @@ struct vmx_engine {
     std::vector<int32_t> const_slots2;       // ... a level-2 table: + everything that enters a Gaussian factor
     DevBuf<int32_t> d_const_slots, d_const_slots2, d_xtab_pipe, d_xtab_partner;
     DevBuf<double> xtab_k;
+    DevBuf<unsigned long long> gemm_trace;   // VMX_GEMM_TRACE=<file>: block timeline of the last FFTLog product, written by vmx_sync
+    size_t gemm_trace_blocks = 0;
     DevBuf<unsigned long long> pk_trace;     // VMX_PK_TRACE=<file>: block timeline of the last k_pk_tab2 launch, written by vmx_sync
     size_t pk_trace_blocks = 0;
     std::vector<Tab2Group> tab2_groups;      // the groups with tables, as k_pk_tab2 takes them (cross groups first)
@@ -202,6 +204,7 @@ struct vmx_engine {
     bool quad_fused_chi2 = true;     // VMX_NO_FUSED_CHI2: the list launch stores the product, k_chi2_quad contracts it
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
+    bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
     bool no_small_tab = false;       // VMX_NO_SMALL_TAB: batches below 16 walkers never use the tables
     int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
     int xi_fused_max_b = 1 << 30;    // VMX_XI_FUSED_MAXB (an experiment knob: the fused kernel wins at every batch size)
@@ -476,7 +479,33 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
             case KC_QUAD: hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), grid, block, 0, e->cur, G); break;
             case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt44<KC_DISTORTION>), grid, block, 0, e->cur, G); break;
             case KC_METAL: hipLaunchKernelGGL((k_gemm_nt44<KC_METAL>), grid, block, 0, e->cur, G); break;
-            case KC_FFTLOG: hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G); break;
+            case KC_FFTLOG:
+                if (getenv("VMX_GEMM_TRACE")) {
+                    e->gemm_trace_blocks = (size_t)grid.x * grid.y;
+                    if (e->gemm_trace.n < 4 * e->gemm_trace_blocks) (void)e->gemm_trace.alloc(4 * e->gemm_trace_blocks, true);
+                    else (void)hipMemsetAsync(e->gemm_trace.p, 0, 4 * e->gemm_trace_blocks * sizeof(unsigned long long), e->cur);
+                    const_cast<GemmGroup&>(G).trace = e->gemm_trace.p;
+                }
+                // The four-stage ring pays when the launch has about one live tile per CU: a lone block then streams at its own
+                // pace (B = 256: 49 -> 44 us).  With fewer tiles its slower dispatch (128 KB of LDS per block) costs more than
+                // it gains (B = 64: 32 -> 35 us); with more, two resident two-buffer blocks hide each other's latencies better
+                // (B = 1024: 103 -> 138 us).  The live rows are device data: a third of the operator's rows is the estimate.
+                if (e->fft_ring && G.n == 1 && G.p[0].m_window) {
+                    const int64_t est = (int64_t)G.p[0].tn * nbatch * ((G.p[0].tm * 3 + 9) / 10);
+                    if (est < 160 || est > 320) { hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G); break; }
+                    constexpr size_t ring_bytes = (size_t)4 * (GEMM_BM + GEMM_BN) * GEMM_BK * sizeof(double);
+                    if (!e->fft_ring_attr) {
+                        if (hipFuncSetAttribute((const void*)k_gemm_nt44<KC_FFTLOG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes) != hipSuccess) {
+                            (void)hipGetLastError();
+                            e->fft_ring = false;
+                            hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G);
+                            break;
+                        }
+                        e->fft_ring_attr = true;
+                    }
+                    hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG, 4>), grid, block, ring_bytes, e->cur, G);
+                } else hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G);
+                break;
             default: hipLaunchKernelGGL((k_gemm_nt44<KC_OTHER>), grid, block, 0, e->cur, G); break;
         }
         return;
@@ -1140,6 +1169,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
     if (getenv("VMX_NO_SMALL_TAB")) e->no_small_tab = true;
+    if (getenv("VMX_NO_FFT_RING")) e->fft_ring = false;
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
     if (const char* v = getenv("VMX_XI_FUSED_MAXB")) e->xi_fused_max_b = atoi(v);
@@ -2444,6 +2474,11 @@ int vmx_sync(vmx_engine* e)
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     if (e->profiling) collect_spans(e);
+    if (e->gemm_trace.p && e->gemm_trace_blocks && getenv("VMX_GEMM_TRACE")) {
+        std::vector<unsigned long long> h(4 * e->gemm_trace_blocks);
+        HIP_OK(hipMemcpy(h.data(), e->gemm_trace.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("VMX_GEMM_TRACE"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
     if (e->pk_trace.p && e->pk_trace_blocks) {
         std::vector<unsigned long long> h(4 * e->pk_trace_blocks);
         HIP_OK(hipMemcpy(h.data(), e->pk_trace.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -2008,6 +2008,7 @@ __device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
 struct GemmGroup {
     GemmArgs p[VMX_MAX_GROUP]; int32_t n; int32_t seq_end[VMX_MAX_GROUP];
     const GemmWork* work;       // non-null: list mode (gridDim.x entries)
+    unsigned long long* trace;  // debugging aid (VMX_GEMM_TRACE): per block {start, first stage landed, K loop done, end} in 100 MHz ticks
 };
 
 // Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
@@ -2176,21 +2177,37 @@ __device__ __forceinline__ double dpp_row_rotate(double v)
 //     read f1(s)                                   | MFMAs on f0(s)
 //     drain LDS reads and the DMA of stage s + 1, barrier      (stage s + 1 visible, buffer s & 1 free)
 //     DMA stage s + 2 -> buffer s & 1, read f0(s + 1)          | MFMAs on f1(s)
-template <int TAG>
-__global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_nt44(GemmGroup G)
+//
+// NBUF = 2 (above) relies on a second resident block to cover the latency of its loads.  A launch with fewer tiles than
+// twice the CUs (the FFTLog product: ~256 tiles of 18 stages) gets NBUF = 4: a ring of four stage buffers in 128 KB of
+// dynamic LDS - one block per CU, loads three and a half stages ahead, counted waits (vmcnt) for the oldest stage only.
+template <int TAG, int NBUF = 2>
+__global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 1) void k_gemm_nt44(GemmGroup G)
 {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int NT = GEMM44_THREADS, NW = NT / 64;
     constexpr int FJ = 4 * 256 / NT * 2;    // A fragments per wave: 8 (4 waves, 32 x 32 wave tiles) or 4 (8 waves, 32 x 16)
     constexpr int NP = 16 / NW;             // DMA instructions per wave, operand and stage (each fills 4 rows)
-    __shared__ double sA[2][BM * BK];
-    __shared__ double sX[2][BN * BK];
+    __shared__ double sA_static[NBUF == 2 ? 2 : 1][NBUF == 2 ? BM * BK : 1];
+    __shared__ double sX_static[NBUF == 2 ? 2 : 1][NBUF == 2 ? BN * BK : 1];
+    extern __shared__ double s_ring[];          // NBUF > 2: [NBUF][BM * BK] A stages, then [NBUF][BN * BK] X stages
+    double (*sA)[BM * BK] = NBUF == 2 ? (double (*)[BM * BK])&sA_static[0][0] : (double (*)[BM * BK])s_ring;
+    double (*sX)[BN * BK] = NBUF == 2 ? (double (*)[BN * BK])&sX_static[0][0] : (double (*)[BN * BK])(s_ring + NBUF * BM * BK);
+    // waits until at most `ahead` younger stages' DMA instructions are outstanding (loads complete in order)
+    auto wait_stages = [](int ahead) {
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * 2 * NP) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NP) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * 2 * NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     // contraction epilogue of the quadratic form (GemmArgs::part): the linear term's row over the tile's own rows; the
     // walker vectors over those rows follow by DMA into the stage buffer that falls free first (see the K loop)
-    constexpr bool QUAD = TAG == VMX_TAG_QUAD && NT == 256;
+    constexpr bool QUAD = TAG == VMX_TAG_QUAD && NT == 256 && NBUF == 2;
     __shared__ double sL[QUAD ? 2 * BM : 1];
 
     const bool list = G.work != nullptr;
+    const unsigned long long t_start = G.trace ? wall_clock64() : 0ull;
+    unsigned long long t_first = 0ull, t_loop = 0ull;
     GemmWork wk{};
     if (list) { wk = G.work[blockIdx.x]; if (wk.prob < 0) return; }        // (padding entries of the list)
     const int xcd = blockIdx.x & 7;
@@ -2292,9 +2309,20 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
 
     double a0[FJ], x0[8], a1[FJ], x1[8];
     if (!c_skip && kbeg_c < kend_c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kbeg_c + BK < kend_c) dma_stage(kbeg_c + BK, 1);
+        if constexpr (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kbeg_c + BK < kend_c) dma_stage(kbeg_c + BK, 1);
+        } else {
+            // the ring starts full: stages 1 .. NBUF - 1 follow stage 0 at once; then wait for stage 0 alone
+            int ahead = 0;
+#pragma unroll
+            for (int q = 1; q < NBUF; ++q)
+                if (kbeg_c + q * BK < kend_c) { dma_stage(kbeg_c + q * BK, q); ++ahead; }
+            wait_stages(ahead);
+            __syncthreads();
+        }
+        if (G.trace) t_first = wall_clock64();
         lds_read_fragments<4 * BK * 8>(a0, fa + frag0);
         lds_read_fragments<4 * BK * 8>(x0, fx + frag0);
         lds_wait(a0, x0);
@@ -2302,6 +2330,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
     int buf = 0;
     int epi_buf = -1;
     for (int k0 = kbeg_c; k0 < (c_skip ? kbeg_c : kend_c); k0 += BK) {
+        const int nbuf = NBUF == 2 ? buf ^ 1 : (buf + 1 == NBUF ? 0 : buf + 1);        // the next stage's buffer
         // first half: MFMAs on f0(s), the reads of f1(s) spread between them (one read ahead of every group of MFMAs, so
         // the wave's MFMA stream is never held up by a burst of LDS instructions)
         const unsigned a1p = fa + (unsigned)buf * (BM * BK * 8) + (frag0 ^ 128u);
@@ -2316,11 +2345,16 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
         VMX_G44_FIRST(4) VMX_G44_FIRST(5) VMX_G44_FIRST(6) VMX_G44_FIRST(7)
 #undef VMX_G44_FIRST
         lds_wait(a1, x1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA of stage s + 1 has landed
+        if constexpr (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA of stage s + 1 has landed
+        else {
+            // ... of stage s + 1, while up to NBUF - 2 younger ones stay in flight
+            const int left = (kend_c - k0) / BK - 2;           // stages beyond s + 1 (K ranges are multiples of BK)
+            wait_stages(left < 0 ? 0 : left > NBUF - 2 ? NBUF - 2 : left);
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // second half: DMA of stage s + 2 into the buffer just released, MFMAs on f1(s) with the reads of f0(s + 1) between them
-        if (k0 + 2 * BK < kend_c) dma_stage(k0 + 2 * BK, buf);
+        // second half: DMA of stage s + NBUF into the buffer just released, MFMAs on f1(s) with the reads of f0(s + 1) between them
+        if (k0 + NBUF * BK < kend_c) dma_stage(k0 + NBUF * BK, buf);
         else if constexpr (QUAD) {
             if (epi_buf < 0 && list && g.part) {
                 // no further stage: this buffer stays free.  It takes E[n][m] = X[n0 + n][m0 + m] for the contraction epilogue
@@ -2339,8 +2373,8 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
             }
         }
         // (after the last stage these reads fetch stale data that nothing uses: one code path, no branch)
-        const unsigned a0p = fa + (unsigned)(buf ^ 1) * (BM * BK * 8) + frag0;
-        const unsigned x0p = fx + (unsigned)(buf ^ 1) * (BM * BK * 8) + frag0;
+        const unsigned a0p = fa + (unsigned)nbuf * (BM * BK * 8) + frag0;
+        const unsigned x0p = fx + (unsigned)nbuf * (BM * BK * 8) + frag0;
 #define VMX_G44_SECOND(i)                                                                                             \
         _Pragma("unroll") for (int j = 0; j < FJ; ++j)                                                                   \
             acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1[i], a1[j], acc[i][j], 0, 0, 0);                            \
@@ -2351,9 +2385,10 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
         VMX_G44_SECOND(4) VMX_G44_SECOND(5) VMX_G44_SECOND(6) VMX_G44_SECOND(7)
 #undef VMX_G44_SECOND
         lds_wait(a0, x0);
-        buf ^= 1;
+        buf = nbuf;
     }
 
+    if (G.trace) t_loop = wall_clock64();
     if (pass + 1 < npass) {             // every wave is past the last barrier of the K loop: both buffers are free
         setup(pass + 1);
         if (!skip && kbeg < kend) dma_stage(kbeg, 0);
@@ -2433,6 +2468,10 @@ __global__ __launch_bounds__(GEMM44_THREADS, GEMM44_THREADS / 128) void k_gemm_n
             if (n < g.N && m < g.M) Dp[(size_t)n * g.ldd + m] = out;
         }
   }
+    if (G.trace && threadIdx.x == 0 && !skip) {
+        unsigned long long* tr = G.trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        tr[0] = t_start; tr[1] = t_first; tr[2] = t_loop; tr[3] = wall_clock64();
+    }
 }
 
 // Distortion product with a CSR matrix (the reference keeps it as scipy csr_array: data.py:342-346, model.py:143-144):
