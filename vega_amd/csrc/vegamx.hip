@@ -1790,7 +1790,11 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         } else if (zero_copy)      // one block holds every walker of the (small) batch in LDS
             hipLaunchKernelGGL(k_prologue, dim3(1), dim3((n_thr + 63) / 64 * 64), desc_bytes + (size_t)B * e->n_params * sizeof(double), e->stream, D, B);
         else
-            hipLaunchKernelGGL(k_prologue, dim3((n_thr + 63) / 64), dim3(64), desc_bytes, e->stream, D, B);
+        {
+            // (+ the rows of the block's walkers, staged next to the descriptors when theta is read from a device buffer)
+            const size_t rows_bytes = (size_t)(64 / (n_pipe + 1) + 2) * e->n_params * sizeof(double);
+            hipLaunchKernelGGL(k_prologue, dim3((n_thr + 63) / 64), dim3(64), desc_bytes + rows_bytes, e->stream, D, B);
+        }
     }
     {
         ScopedTimer t(e, KC_PK);

@@ -283,13 +283,21 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
         t = s_theta + (size_t)b * D.n_params;
         t0 = s_theta;           // (no second trip over PCIe for walker 0)
     }
+    else if (!BYVAL && D.theta_host && !D.src_lds) {
+        // device entry: the caller's buffer is read in place.  The rows of this block's walkers are requested together with
+        // the descriptors (one round trip instead of two) and land in LDS; the copy the later kernels use leaves from there.
+        const int b_first = (int)(blockIdx.x * blockDim.x) / (D.n_pipe + 1);
+        const int b_last = min(B - 1, (int)(blockIdx.x * blockDim.x + blockDim.x - 1) / (D.n_pipe + 1));
+        const int count = (b_last - b_first + 1) * D.n_params;
+        const double* src = D.theta_host + (size_t)b_first * D.n_params;
+        for (int i = threadIdx.x; i < count; i += blockDim.x) {
+            const double v = src[i];
+            s_theta[i] = v; D.theta_copy[(size_t)b_first * D.n_params + i] = v;
+        }
+        if (b < B) t = s_theta + (size_t)(b - b_first) * D.n_params;
+    }
     __syncthreads();
     if (b >= B) return;
-    if (!BYVAL && D.theta_host && !D.src_lds) {
-        // the caller's device buffer is read in place; the threads of a walker leave the copy the later kernels use
-        t = D.theta_host + (size_t)b * D.n_params;
-        for (int i = slot; i < D.n_params; i += D.n_pipe + 1) D.theta_copy[(size_t)b * D.n_params + i] = t[i];
-    }
 
     if (slot < D.n_pipe) {
         const int p = slot;
