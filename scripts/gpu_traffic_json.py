@@ -14,10 +14,10 @@ NQ = [2500 + 12, 5000]           # quadratic form: n_model + additive post-disto
 CLASSES = {
     # chi2-only steps: one half-triangle product with Q' per item - half the matrix + the batch's vectors in; the product is
     # contracted in the epilogue (round 2: no vectors out, 16 bytes of partial sums per walker and block are negligible)
-    'quadratic_form_product': ('k_gemm_nt44<12>', sum(8 * n * n / 2 + 8 * B * n for n in NQ)),
-    'distortion_product': ('k_gemm_nt44<6>', sum(8 * m * n + 8 * B * (m + n) for m, n in SHAPES_DIST)),
+    'quadratic_form_product': ('k_gemm_nt44<12,', sum(8 * n * n / 2 + 8 * B * n for n in NQ)),
+    'distortion_product': ('k_gemm_nt44<6,', sum(8 * m * n + 8 * B * (m + n) for m, n in SHAPES_DIST)),
     'invcov_product': ('k_gemm_nt<64, 64, 32, 8>', sum(8 * m * n / 2 + 8 * B * (m + n) for m, n in SHAPES_COV)),
-    'fftlog_spline_product': ('k_gemm_nt44<2>', None),
+    'fftlog_spline_product': ('k_gemm_nt44<2,', None),
     'pk_multipoles': ('k_pk_tab2', None),
     'xi_bins': ('k_xi_assemble_quad', None),
     'chi2': ('k_chi2_parts', None),
