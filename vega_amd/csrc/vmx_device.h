@@ -2164,6 +2164,25 @@ __device__ __forceinline__ double dpp_row_rotate(double v)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// v of lane (l ^ MASK), MASK < 32: ds_swizzle in bit mode - an LDS-crossbar instruction (no LDS memory, no VALU slot; fp64
+// VALU instructions take no DPP modifier, so a DPP exchange of a double costs two v_mov_b32 on the VALU)
+template <int MASK>
+__device__ __forceinline__ double lane_xor(double v)
+{
+    const long long bits = __builtin_bit_cast(long long, v);
+    int lo = (int)bits, hi = (int)(bits >> 32);
+    lo = __builtin_amdgcn_ds_swizzle(lo, (MASK << 10) | 0x1f);
+    hi = __builtin_amdgcn_ds_swizzle(hi, (MASK << 10) | 0x1f);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// the four K-quarter partial sums of an accumulator sit in the lane groups b = (lane >> 2) & 3 of a 16-lane row: two
+// butterfly steps leave their sum in every lane - (v_b + v_{b^2}) + (v_{b^1} + v_{b^3}), the same value in all four
+__device__ __forceinline__ double sum_k_quarters(double v)
+{
+    v += lane_xor<8>(v);
+    return v + lane_xor<4>(v);
+}
+
 #ifndef GEMM44_THREADS
 #define GEMM44_THREADS 256
 #endif
@@ -2172,7 +2191,7 @@ __device__ __forceinline__ double dpp_row_rotate(double v)
 // interleaved quarters of a 16-deep K step of ONE 4 x 4 output tile (operand lane 16 kk + 4 b + row holds k = 4 kk + b
 // of block b), so a fragment is 4 rows x 16 k for both operands - one ds_read_b64 each, no rotated copies.  Each
 // accumulator keeps the four partial sums of its tile in the four lane groups of a row; they are added once, after the K
-// loop (three DPP row rotations).
+// loop (two butterfly steps across the lane groups, sum_k_quarters).
 //
 // Staging is direct global -> LDS (global_load_lds_dwordx4: no staging registers, no ds_write): one wave instruction
 // fills 4 rows x 32 doubles of a tile, lane-linear.  The 16-byte chunks of a row are stored XOR-swizzled with
@@ -2436,7 +2455,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const double v = acc[i][4 * jg + u];
-                        tot[u] = (v + dpp_row_rotate<0x120 + 4>(v)) + (dpp_row_rotate<0x120 + 8>(v) + dpp_row_rotate<0x120 + 12>(v));
+                        tot[u] = sum_k_quarters(v);
                     }
                     double out = fb == 0 ? tot[0] : fb == 1 ? tot[1] : fb == 2 ? tot[2] : tot[3];
                     const int m = c_m0 + wm + 16 * jg + c;
@@ -2450,8 +2469,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
 #endif
                 }
                 // the 16 lanes of a row (same walker): total in every lane
-                sum = (sum + dpp_row_rotate<0x120 + 4>(sum)) + (dpp_row_rotate<0x120 + 8>(sum) + dpp_row_rotate<0x120 + 12>(sum));
-                sum = (sum + dpp_row_rotate<0x120 + 1>(sum)) + (dpp_row_rotate<0x120 + 2>(sum) + dpp_row_rotate<0x120 + 3>(sum));
+                sum += lane_xor<8>(sum); sum += lane_xor<4>(sum); sum += lane_xor<2>(sum); sum += lane_xor<1>(sum);
                 if (c == 0) g.part[((size_t)blockIdx.x * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = n < g.N ? sum : 0.0;
             }
             continue;
@@ -2468,7 +2486,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double v = acc[i][4 * jg + u];
-                tot[u] = (v + dpp_row_rotate<0x120 + 4>(v)) + (dpp_row_rotate<0x120 + 8>(v) + dpp_row_rotate<0x120 + 12>(v));
+                tot[u] = sum_k_quarters(v);
             }
             const double out = fb == 0 ? tot[0] : fb == 1 ? tot[1] : fb == 2 ? tot[2] : tot[3];
             const int n = n0 + wn + 4 * i + (lane >> 4);
