@@ -2526,7 +2526,7 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     bool tables_current = false;
     {
         std::vector<double> cur;
-        for (int slot : e->const_slots2) cur.push_back(theta[slot]);
+        for (int slot : e->const_slots2) cur.push_back(e->pin_theta[slot]);      // (the transformed values: what the device sees)
         tables_current = tab_mode == 2 && e->host_key_valid && cur == e->host_key;
         if (B < 16 && tab_mode) {
             if (tab_mode == 2 && !e->no_small_tab && (tables_current || cur == e->pending_key)) tab_mode = 2;
