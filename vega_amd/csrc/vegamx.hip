@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <utility>
 #include <string>
@@ -35,6 +36,9 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     do { if (!(cond)) return fail(-1, std::string("invalid argument: ") + msg); } while (0)
 
 namespace {
+
+static std::mutex g_quad_len_mutex;
+static std::map<std::string, int> g_quad_len;        // measured segment lengths of the quadratic-form launch, by problem shape
 
 static const uint64_t VMX_PART_SENTINEL = 0x7ff8dead0000beefull;      // a NaN payload no arithmetic produces (k_gemv1 MODE 2 slots)
 
@@ -1675,6 +1679,15 @@ static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
     int cls = 1;
     while (cls < tn) cls *= 2;
     vmx_engine::QuadList* best = nullptr;
+    // (the measurement is a property of the problem's shape and the device, not of the engine: engines of the same shape in
+    // one process - a driver's second engine, a rebuilt engine - take it over)
+    std::string shape = std::to_string(e->device) + ":" + std::to_string(cls);
+    for (auto* it : e->items) shape += ":" + std::to_string(it->dev.nq);
+    {
+        std::lock_guard<std::mutex> lock(g_quad_len_mutex);
+        auto known = g_quad_len.find(shape);
+        if (known != g_quad_len.end() && !e->quad_seg_len.count(cls)) e->quad_seg_len[cls] = known->second;
+    }
     if (const char* force = getenv("VMX_QUAD_L")) best = quad_build_list(e, B, std::max(1, atoi(force)));
     else if (e->quad_seg_len.count(cls)) best = quad_build_list(e, B, e->quad_seg_len[cls]);
     else {
@@ -1699,7 +1712,11 @@ static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
         }
         (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     }
-    if (best) { e->quad_lists[tn] = best; e->quad_seg_len[cls] = best->seg_len; }
+    if (best) {
+        e->quad_lists[tn] = best; e->quad_seg_len[cls] = best->seg_len;
+        std::lock_guard<std::mutex> lock(g_quad_len_mutex);
+        g_quad_len[shape] = best->seg_len;
+    }
     return best;
 }
 
