@@ -15,7 +15,7 @@
 //                     FFTLog+spline operator (pktoxi.py:141-144), metal matrices (metals.py:338-367),
 //                     distortion matrix (model.py:143-144), inverse covariance (vega_interface.py:316)
 //   k_metal_kron      metal matrix in Kronecker form A (x) B (new_metals)  metals.py:338-367, :501-655
-//   k_xi_bins         spline evaluation on rescaled bins, Legendre sum, bias evolution, growth,
+//   k_xi_bins (+ _static, _geom; k_poly_bins, k_spline_geom at set-up)   spline evaluation on rescaled bins, Legendre sum, bias evolution, growth,
 //                     QSO radiation                                         pktoxi.py:144-162, correlation_func.py:117-236,276-349,446-489
 //   k_assemble        peak/smooth/metals combination + pre-distortion broadband   model.py:119-140,186, metals.py:331-334
 //   k_post            post-distortion broadband, model output, masked residual   model.py:147-149, vega_interface.py:310-315
