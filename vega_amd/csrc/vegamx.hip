@@ -147,14 +147,9 @@ struct vmx_engine {
     std::vector<int32_t> const_slots;        // parameters a level-1 table depends on (the Arinyo set)
     std::vector<int32_t> const_slots2;       // ... a level-2 table: + everything that enters a Gaussian factor
     DevBuf<int32_t> d_const_slots, d_const_slots2, d_xtab_pipe, d_xtab_partner;
-    DevBuf<double> xtab_k, geom_w;
-    DevBuf<int32_t> geom_j, d_geom_pipes;
+    DevBuf<double> xtab_k;
     std::vector<int32_t> xi_static_taps, xi_static_bins;     // k_xi_bins<true> / k_xi_bins_static launch lists (set by poly_basis_build)
     DevBuf<int32_t> d_xi_static_taps, d_xi_static_bins;
-    std::vector<int32_t> xi_general, xi_geom;    // k_xi_bins<false> / k_xi_bins_geom launch lists (set by spline_geom_build)
-    DevBuf<int32_t> d_xi_general, d_xi_geom;
-    std::vector<int32_t> geom_pipes;         // pipelines with a static spline geometry (PipeDev::geom_off)
-    int64_t geom_total = 0;
     DevBuf<unsigned long long> gemm_trace;   // VMX_GEMM_TRACE=<file>: block timeline of the last FFTLog product, written by vmx_sync
     size_t gemm_trace_blocks = 0;
     DevBuf<unsigned long long> pk_trace;     // VMX_PK_TRACE=<file>: block timeline of the last k_pk_tab2 launch, written by vmx_sync
@@ -774,7 +769,7 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     if (desc->n_smooth < 0 || desc->n_smooth > VMX_MAX_SMOOTH) return fail(-1, "invalid argument: n_smooth");
     PipeDev p{};
     p.d = *desc;
-    p.poly_basis = -1; p.col = -1; p.poly_bins_off = -1; p.geom_off = -1;
+    p.poly_basis = -1; p.col = -1; p.poly_bins_off = -1;
     // The P(k) stage is symmetric in the two tracers: keep the Lya-like tracer first (and a discrete
     // tracer last) so that the specialised mu loops see one canonical order.
     if (!p.d.same_tracer && ((!p.d.tracer[0].is_lya && p.d.tracer[1].is_lya) ||
@@ -1159,7 +1154,6 @@ int vmx_add_prior(vmx_engine* e, int32_t slot, double mean, double sigma)
 }
 
 static int poly_basis_build(vmx_engine* e);
-static int spline_geom_build(vmx_engine* e);
 
 int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 {
@@ -1406,22 +1400,9 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             }
             e->pk_poly.swap(keep);
             e->n_active = 0;
-            e->geom_pipes.clear();
-            e->geom_total = 0;
-            for (size_t pi = 0; pi < e->pipes.size(); ++pi) {
-                PipeDev& pd = e->pipes[pi];
-                const vmx_pipe_desc& d = pd.d;
-                pd.geom_off = -1;
-                if (pd.poly_basis >= 0) { pd.col = -1; continue; }
-                pd.col = e->n_active++;
-                // its own coefficient column, but static coordinates (metal pairs without delta_rp, an unscaled smooth
-                // component): the spline geometry of its bins is formed once (k_spline_geom)
-                if (d.scale_mode == VMX_SCALE_UNIT && d.drp_slot < 0 && !pd.odd_rel && !pd.odd_asy && d.radiation != 2 &&
-                    d.uv_shotnoise != 2 && !getenv("VMX_NO_STATIC_GEOM")) {
-                    pd.geom_off = e->geom_total;
-                    e->geom_total += vmx_pad(pd.n);
-                    e->geom_pipes.push_back((int32_t)pi);
-                }
+            for (auto& pd : e->pipes) {
+                if (pd.poly_basis >= 0) pd.col = -1;
+                else pd.col = e->n_active++;
             }
             for (auto& t : e->tab2_groups) { t.col_s = e->pipes[t.pipe].col; t.col_q = e->pipes[t.partner].col; }
             if (e->d_pipes.upload(e->pipes.data(), e->pipes.size())) return -2;
@@ -1583,12 +1564,12 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 
     HIP_OK(hipStreamSynchronize(e->stream));
     e->finalized = true;
-    if (poly_basis_build(e) || spline_geom_build(e)) { e->finalized = false; return -2; }
+    if (poly_basis_build(e)) { e->finalized = false; return -2; }
     if (getenv("VMX_DEBUG_PIPES"))
         for (size_t pi = 0; pi < e->pipes.size(); ++pi) {
             const PipeDev& pd = e->pipes[pi];
-            std::fprintf(stderr, "[vegamx] pipeline %zu: n %d col %d poly_basis %d poly_bins_off %lld geom_off %lld scale_mode %d drp_slot %d n_ell %d\n",
-                         pi, pd.n, pd.col, pd.poly_basis, (long long)pd.poly_bins_off, (long long)pd.geom_off, pd.d.scale_mode, pd.d.drp_slot, pd.d.n_ell);
+            std::fprintf(stderr, "[vegamx] pipeline %zu: n %d col %d poly_basis %d poly_bins_off %lld scale_mode %d drp_slot %d n_ell %d\n",
+                         pi, pd.n, pd.col, pd.poly_basis, (long long)pd.poly_bins_off, pd.d.scale_mode, pd.d.drp_slot, pd.d.n_ell);
         }
     return 0;
 }
@@ -1789,43 +1770,6 @@ static int poly_basis_build(vmx_engine* e)
     return 0;
 }
 
-// static spline geometry of the pipelines on static coordinates (PipeDev::geom_off), once at vmx_finalize
-static int spline_geom_lists(vmx_engine* e)
-{
-    e->xi_general.clear(); e->xi_geom.clear();
-    for (int p = 0; p < (int)e->pipes.size(); ++p) {
-        if (e->pipes[p].col < 0) continue;
-        (e->pipes[p].geom_off >= 0 ? e->xi_geom : e->xi_general).push_back(p);
-    }
-    std::vector<int32_t> a = e->xi_general, b = e->xi_geom;
-    a.push_back(-1); b.push_back(-1);
-    return (e->d_xi_general.upload(a.data(), a.size()) || e->d_xi_geom.upload(b.data(), b.size())) ? -2 : 0;
-}
-
-static int spline_geom_build(vmx_engine* e)
-{
-    const int ng = (int)e->geom_pipes.size();
-    if (ng == 0) return spline_geom_lists(e);
-    if (e->geom_j.alloc((size_t)e->geom_total * 4, true) || e->geom_w.alloc((size_t)e->geom_total * 16, true)) return -2;
-    std::vector<int32_t> list = e->geom_pipes, ok(ng, 1);
-    list.push_back(-1);
-    DevBuf<int32_t> d_ok;
-    if (e->d_geom_pipes.upload(list.data(), list.size()) || d_ok.upload(ok.data(), ok.size())) return -2;
-    int max_n = 0;
-    for (int p : e->geom_pipes) max_n = std::max(max_n, (int)e->pipes[p].n);
-    hipLaunchKernelGGL(k_spline_geom, dim3((max_n + 255) / 256, ng), dim3(256), 0, e->stream, e->dev, e->d_geom_pipes.p,
-                       e->geom_j.p, e->geom_w.p, d_ok.p);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(e->stream));
-    HIP_OK(hipMemcpy(ok.data(), d_ok.p, ok.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    bool changed = false;
-    for (int sb = 0; sb < ng; ++sb)
-        if (!ok[sb]) { e->pipes[e->geom_pipes[sb]].geom_off = -1; changed = true; }       // a bin outside the knots: per-walker form
-    if (changed) HIP_OK(hipMemcpy(e->d_pipes.p, e->pipes.data(), e->pipes.size() * sizeof(PipeDev), hipMemcpyHostToDevice));
-    e->dev.geom_j = e->geom_j.p; e->dev.geom_w = e->geom_w.p;
-    return spline_geom_lists(e);
-}
-
 // enqueue the whole kernel chain for the B parameter points already in e->theta
 // Kronecker-form metal matrices of an item: one launch, one block per (walker, metal) (k_metal_kron)
 static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, int B)
@@ -1981,13 +1925,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         int max_n = 0;
         for (auto& p : e->pipes) max_n = p.n > max_n ? p.n : max_n;
         if (e->n_active > 0)
-        {
-            // pipelines with their own coefficient column: the general form, and the ones on static coordinates
-            if (!e->xi_general.empty())
-                hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, (unsigned)e->xi_general.size(), B), dim3(256), 0, e->stream, D, e->d_xi_general.p);
-            if (!e->xi_geom.empty())
-                hipLaunchKernelGGL(k_xi_bins_geom, dim3((max_n + 255) / 256, (unsigned)e->xi_geom.size(), B), dim3(256), 0, e->stream, D, e->d_xi_geom.p);
-        }
+            hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, e->n_active, B), dim3(256), 0, e->stream, D, e->d_pipe_active.p);
         if (!e->pk_static.empty())
         {
             // static-basis pipelines: tap form, and the ones already evaluated on their (static) bins

@@ -15,7 +15,7 @@
 //                     FFTLog+spline operator (pktoxi.py:141-144), metal matrices (metals.py:338-367),
 //                     distortion matrix (model.py:143-144), inverse covariance (vega_interface.py:316)
 //   k_metal_kron      metal matrix in Kronecker form A (x) B (new_metals)  metals.py:338-367, :501-655
-//   k_xi_bins (+ _static, _geom; k_poly_bins, k_spline_geom at set-up)   spline evaluation on rescaled bins, Legendre sum, bias evolution, growth,
+//   k_xi_bins (+ _static; k_poly_bins at set-up)   spline evaluation on rescaled bins, Legendre sum, bias evolution, growth,
 //                     QSO radiation                                         pktoxi.py:144-162, correlation_func.py:117-236,276-349,446-489
 //   k_assemble        peak/smooth/metals combination + pre-distortion broadband   model.py:119-140,186, metals.py:331-334
 //   k_post            post-distortion broadband, model output, masked residual   model.py:147-149, vega_interface.py:310-315
@@ -60,8 +60,6 @@ struct PipeDev {
                           // coefficients are a0 C0 + a1 C1 + a2 C2 with the static vectors C (EngineDev::poly_coef): no
                           // P(k,mu), no FFTLog column per walker
     int64_t poly_bins_off; // >= 0: ... and its coordinates are static too: offset of Y[3][n_pad] in EngineDev::poly_bins
-    int64_t geom_off;     // >= 0: a pipeline with its own coefficient column on static coordinates (no rescaling, no delta_rp):
-                          // first bin of its static spline geometry in EngineDev::geom_j / geom_w (k_spline_geom)
     int32_t split_evol;   // new-bias-evolution: clnrelz holds tracer 1's ln(rel z), clnrelz2 tracer 2's
     int32_t tracers_swapped;   // vmx_add_pipeline put the caller's second tracer first (canonical order)
     // odd-multipole (relativistic / asymmetry) terms: static spline coefficients + amplitude slots
@@ -163,8 +161,6 @@ struct EngineDev {
     int32_t n_active;           // pipelines with a column in pl / coef (the others carry a static coefficient basis)
     const double* poly_coef;    // [n_ell][n_static][3][ncp]  FFTLog o spline of the Kaiser-basis spectra of those
     const double* poly_bins;    // per static-coordinate pipeline [3][n_pad]: the basis evaluated on its bins
-    const int32_t* geom_j;      // [bins][4]   knot index of every multipole at the bin's own ln r
-    const double* geom_w;       // [bins][16]  tap weights x Legendre factor / 6 of every multipole (0 for a multipole the pipeline lacks)
     int32_t n_static;
     const PipeDev* pipes;
     const double* crp; const double* crt;       // r mu and r sqrt(1 - mu^2) of every bin (static)
@@ -2809,7 +2805,7 @@ __device__ __forceinline__ void kaiser_coefficients(const vmx_pipe_desc& d, cons
 // xi of bin `bin` of pipeline p for walker b of a batch of nB (everything k_xi_bins computes); oob: the rescaled
 // separation left the spline's range.  MODE 0: per-walker spline coefficients; 1: static coefficient basis; 2: static
 // coefficient basis on static coordinates - the spline and Legendre sums of the three basis vectors were evaluated per
-// bin at set-up (k_poly_bins), three loads and three FMAs are left.  MODE 3: per-walker coefficients on static coordinates.
+// bin at set-up (k_poly_bins), three loads and three FMAs are left.
 template <int MODE>
 __device__ __forceinline__ double xi_bin_value(const EngineDev& D, int p, int b, int bin, int nB, bool& oob_out)
 {
@@ -2841,21 +2837,6 @@ __device__ __forceinline__ double xi_bin_value(const EngineDev& D, int p, int b,
     if (MODE == 2) {
         const double* y = D.poly_bins + P.poly_bins_off + bin;
         xi = fma(a2, y[2 * (size_t)P.n_pad], fma(a1, y[P.n_pad], a0 * y[0]));
-    } else if (MODE == 3) {
-        // static coordinates: knot indices and Legendre-weighted tap weights came with the set-up (k_spline_geom) - 16 taps
-        // of the walker's coefficients against 16 static weights
-        const size_t gb = (size_t)P.geom_off + bin;
-        const int32_t* gj = D.geom_j + 4 * gb;
-        const double* gw = D.geom_w + 16 * gb;
-        const size_t ncols = (size_t)nB * D.n_active;
-        const size_t col = (size_t)b * D.n_active + P.col;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ee = e < d.n_ell ? e : 0;
-            const double* cf = D.coef + ((size_t)ee * ncols + col) * D.ncp + gj[e];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xi = fma(cf[q], gw[4 * e + q], xi);
-        }
     } else {
         if (r != 0.0) {
             const double rrp = s_ap * (rp0 + drp), rrt = s_at * rt0;
@@ -2962,18 +2943,6 @@ __global__ __launch_bounds__(256) void k_xi_bins_static(EngineDev D, const int32
     D.xi[P.xi_off + (size_t)b * P.n_pad + bin] = xi_bin_value<2>(D, p, b, bin, (int)gridDim.z, oob);
 }
 
-// ... and the pipelines with their own coefficient column on static coordinates (PipeDev::geom_off >= 0): a third
-// instantiation for the same reason (44 registers against 78)
-__global__ __launch_bounds__(256) void k_xi_bins_geom(EngineDev D, const int32_t* pipes)
-{
-    const int p = pipes[blockIdx.y], b = blockIdx.z;
-    const PipeDev& P = D.pipes[p];
-    const int bin = blockIdx.x * 256 + threadIdx.x;
-    if (bin >= P.n) return;
-    bool oob;
-    D.xi[P.xi_off + (size_t)b * P.n_pad + bin] = xi_bin_value<3>(D, p, b, bin, (int)gridDim.z, oob);
-}
-
 // Set-up: static-basis pipelines on static coordinates (no rescaling, no delta_rp): Y_i[bin] = Legendre sum of the splines of
 // basis vector i at the bin's own (r, mu).  grid = (bins, static pipelines, 3); `ok` is cleared for a pipeline with a bin
 // outside the spline range (it then stays on the tap form, which flags walkers as the reference raises).
@@ -2995,47 +2964,6 @@ __global__ __launch_bounds__(256) void k_poly_bins(EngineDev D, const int32_t* p
     }
     if (oob) ok[sb] = 0;
     out[P.poly_bins_off + (size_t)i * P.n_pad + bin] = xi;
-}
-
-// Set-up: pipelines with their own coefficient column on static coordinates.  Per bin and multipole the knot index and the
-// four tap weights of the cubic B-spline at the bin's own ln r, times the Legendre factor of its own mu and 1 / 6
-// (pktoxi.py:144-162) - what spline_legendre would form for every walker.  grid = (bins, pipelines of the list); `ok` is
-// cleared for a pipeline with a bin outside the spline range (it stays on the per-walker form, which flags as the reference
-// raises).
-__global__ __launch_bounds__(256) void k_spline_geom(EngineDev D, const int32_t* pipes, int32_t* gj_out, double* gw_out, int32_t* ok)
-{
-    const int sb = blockIdx.y, p = pipes[sb];
-    const PipeDev& P = D.pipes[p];
-    const vmx_pipe_desc& d = P.d;
-    const int bin = blockIdx.x * 256 + threadIdx.x;
-    if (bin >= P.n || P.geom_off < 0) return;
-    const size_t c = P.coord_off + bin;
-    const double r = D.cr[c], rp0 = D.crp[c], rt0 = D.crt[c];
-    int32_t* gj = gj_out + 4 * ((size_t)P.geom_off + bin);
-    double* gw = gw_out + 16 * ((size_t)P.geom_off + bin);
-    for (int e = 0; e < 4; ++e) { gj[e] = 0; for (int q = 0; q < 4; ++q) gw[4 * e + q] = 0.0; }
-    if (r == 0.0) return;
-    const double rr2 = fma(rp0, rp0, rt0 * rt0);
-    if (rr2 == 0.0) return;
-    const double x = 0.5 * vmx_log(rr2), rmu = rp0 * vmx_rsqrt(rr2);
-    for (int e = 0; e < d.n_ell && e < 4; ++e) {
-        const bool inside = D.extrapolate || !(x < D.x0[e] || x > D.xlast[e]);
-        if (!inside) { ok[sb] = 0; continue; }
-        const double u = (x - D.x0[e]) * D.inv_h[e];
-        int j = (int)floor(u);
-        if (j < 0) j = 0;
-        if (j > D.n_coef - 4) j = D.n_coef - 4;
-        const double t = u - (double)j, t2 = t * t, t3 = t2 * t, omt = 1.0 - t;
-        double f;
-        if (d.single_ell >= 0) f = e == d.single_ell ? 1.0 : 0.0;      // one multipole, no Legendre factor
-        else f = legendre_even(e, rmu);
-        f *= 1.0 / 6.0;
-        gj[e] = j;
-        gw[4 * e + 0] = omt * omt * omt * f;
-        gw[4 * e + 1] = (3.0 * t3 - 6.0 * t2 + 4.0) * f;
-        gw[4 * e + 2] = (-3.0 * t3 + 3.0 * t2 + 3.0 * t + 1.0) * f;
-        gw[4 * e + 3] = t3 * f;
-    }
 }
 
 // Items without metal terms, chi2-only small batches: the bins of the peak and the smooth component and the entry
