@@ -25,7 +25,7 @@ out = REPO / 'gpurun_out'
 ref = None
 import numpy as np
 MODES = {'level1': {'VMX_NO_TAB2': '1'}, 'level2_nw1': {'VMX_PK_NW': '1'}, 'default': {}, 'no_fused_chi2': {'VMX_NO_FUSED_CHI2': '1'}, 'no_plain_pair': {'VMX_NO_PLAIN_PAIR': '1'},
-         'noload': {'VEGAMX_LIBRARY': str(REPO / 'build_exp' / 'libvegamx_noload.so')}, 'B1024': {'PKB': '1024'}, 'no_geom': {'VMX_NO_STATIC_GEOM': '1'}, 'pro128': {'VMX_PROLOGUE_THREADS': '128'}, 'pro512': {'VMX_PROLOGUE_THREADS': '512'}, 'no_ring': {'VMX_NO_FFT_RING': '1'}, 'B1024_no_ring': {'PKB': '1024', 'VMX_NO_FFT_RING': '1'}, 'B64': {'PKB': '64'}, 'B64_no_ring': {'PKB': '64', 'VMX_NO_FFT_RING': '1'}, 'fft_1cu': {'VMX_FFT_LDS': '24000'}, 'fft_wide': {'VMX_FFT_WIDE': '1'}, 'fft_wide_1cu': {'VMX_FFT_WIDE': '1', 'VMX_FFT_LDS': '24000'}}
+         'noload': {'VEGAMX_LIBRARY': str(REPO / 'build_exp' / 'libvegamx_noload.so')}, 'B1024': {'PKB': '1024'}, 'L32': {'VMX_QUAD_L': '32'}, 'L36': {'VMX_QUAD_L': '36'}, 'L40': {'VMX_QUAD_L': '40'}, 'L44': {'VMX_QUAD_L': '44'}, 'L48': {'VMX_QUAD_L': '48'}, 'L52': {'VMX_QUAD_L': '52'}, 'pro128': {'VMX_PROLOGUE_THREADS': '128'}, 'pro512': {'VMX_PROLOGUE_THREADS': '512'}, 'no_ring': {'VMX_NO_FFT_RING': '1'}, 'B1024_no_ring': {'PKB': '1024', 'VMX_NO_FFT_RING': '1'}, 'B64': {'PKB': '64'}, 'B64_no_ring': {'PKB': '64', 'VMX_NO_FFT_RING': '1'}, 'fft_1cu': {'VMX_FFT_LDS': '24000'}, 'fft_wide': {'VMX_FFT_WIDE': '1'}, 'fft_wide_1cu': {'VMX_FFT_WIDE': '1', 'VMX_FFT_LDS': '24000'}}
 for label in (os.environ.get('PK_MODES', 'level1,default').split(',')):
     env = MODES[label]
     f = out / f'pkmode_{label}.npy'
