@@ -1,10 +1,10 @@
-"""Block timeline of the FFTLog product at B=256 (VMX_GEMM_TRACE)."""
+"""Block timeline of the FFTLog product at B=256 (VMX_GEMM_TRACE), or of the quadratic-form launch (TRACE_WHICH=VMX_QUAD_TRACE)."""
 import os, sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 out = REPO / 'gpurun_out' / 'gemm_trace.bin'
-os.environ['VMX_GEMM_TRACE'] = str(out)
+os.environ[os.environ.get('TRACE_WHICH', 'VMX_GEMM_TRACE')] = str(out)
 import numpy as np
 from vega_amd import VegaInterface, synthetic
 B = int(os.environ.get('PKB', '256'))

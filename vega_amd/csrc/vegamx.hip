@@ -1670,6 +1670,12 @@ static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, Sla
         qs.qseg_off[q] = ql->nseg_off[q];
     }
     G.work = ql->work.p;
+    if (getenv("VMX_QUAD_TRACE")) {          // block timeline of this launch (debugging aid, written by vmx_sync as VMX_GEMM_TRACE is)
+        e->gemm_trace_blocks = (size_t)ql->n_blocks;
+        if (e->gemm_trace.n < 4 * e->gemm_trace_blocks) (void)e->gemm_trace.alloc(4 * e->gemm_trace_blocks, true);
+        else (void)hipMemsetAsync(e->gemm_trace.p, 0, 4 * e->gemm_trace_blocks * sizeof(unsigned long long), e->cur);
+        G.trace = e->gemm_trace.p;
+    }
     qs.qseg = ql->nseg.p;
     hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), dim3(ql->n_blocks, 1), dim3(GEMM44_THREADS), 0, e->cur, G);
 }
@@ -2518,10 +2524,11 @@ int vmx_sync(vmx_engine* e)
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     if (e->profiling) collect_spans(e);
-    if (e->gemm_trace.p && e->gemm_trace_blocks && getenv("VMX_GEMM_TRACE")) {
+    if (e->gemm_trace.p && e->gemm_trace_blocks && (getenv("VMX_GEMM_TRACE") || getenv("VMX_QUAD_TRACE"))) {
         std::vector<unsigned long long> h(4 * e->gemm_trace_blocks);
         HIP_OK(hipMemcpy(h.data(), e->gemm_trace.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(getenv("VMX_GEMM_TRACE"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+        const char* path = getenv("VMX_QUAD_TRACE") ? getenv("VMX_QUAD_TRACE") : getenv("VMX_GEMM_TRACE");
+        if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
     }
     if (e->pk_trace.p && e->pk_trace_blocks) {
         std::vector<unsigned long long> h(4 * e->pk_trace_blocks);
