@@ -154,6 +154,9 @@ struct vmx_engine {
     size_t gemm_trace_blocks = 0;
     DevBuf<unsigned long long> pk_trace;     // VMX_PK_TRACE=<file>: block timeline of the last k_pk_tab2 launch, written by vmx_sync
     size_t pk_trace_blocks = 0;
+    std::vector<int32_t> w_groups;           // shared-W groups (indices into pk_groups): k_pk_w for large batches
+    DevBuf<int32_t> d_w_groups;
+    bool no_pk_w = false;                    // VMX_NO_PK_W: the shared-W groups stay in k_pk_multipoles
     std::vector<Tab2Group> tab2_groups;      // the groups with tables, as k_pk_tab2 takes them (cross groups first)
     int pk_walkers_per_thread = 2;           // VMX_PK_NW (batches of 64 walkers or more)
     DevBuf<double> xtab_key;
@@ -1176,6 +1179,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
     if (getenv("VMX_NO_SMALL_TAB")) e->no_small_tab = true;
+    if (getenv("VMX_NO_PK_W")) e->no_pk_w = true;
     if (const char* v = getenv("VMX_PROLOGUE_THREADS")) e->prologue_threads = std::min(1024, std::max(64, atoi(v) / 64 * 64));
     if (getenv("VMX_NO_FFT_RING")) e->fft_ring = false;
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
@@ -1248,7 +1252,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     // G(k) tables
     const size_t gk_stride = (size_t)e->n_rows * e->nkp;
     if (!e->gk_tables.empty()) {
-        if (e->gk.alloc(gk_stride * e->gk_tables.size(), true)) return -2;
+        // (+ 16 rows: k_pk_w requests its table rows four steps ahead without checking for the end)
+        if (e->gk.alloc(gk_stride * e->gk_tables.size() + (size_t)16 * e->nkp, true)) return -2;
         for (size_t t = 0; t < e->gk_tables.size(); ++t) {
             dim3 grid((e->nkp + 255) / 256, e->n_rows), block(256);
             hipLaunchKernelGGL(k_gk_table, grid, block, 0, e->stream, e->gk.p + t * gk_stride, e->k.p, e->mu.p,
@@ -1418,6 +1423,13 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         if (e->d_pk_poly.upload(e->pk_poly.data(), e->pk_poly.size())) return -2;
         e->pk_poly.pop_back();
         if (e->d_pk_groups.upload(e->pk_groups.data(), e->pk_groups.size())) return -2;
+        {
+            e->w_groups.clear();
+            for (size_t gi = 0; gi < e->pk_groups.size(); ++gi) if (e->pk_groups[gi].variant == PKV_SHARED_W) e->w_groups.push_back((int32_t)gi);
+            std::vector<int32_t> wl = e->w_groups;
+            wl.push_back(-1);
+            if (e->d_w_groups.upload(wl.data(), wl.size())) return -2;
+        }
     }
 
     // metals
@@ -1857,7 +1869,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, (e->n_rows + XTAB_ROWS - 1) / XTAB_ROWS, e->n_xtab), dim3(256), 0, e->stream, D);
         if (!e->pk_poly.empty())
             hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
-        const int tm = tab_mode;
+        int tm = tab_mode;
         // level-2 groups run in their own kernel; the general one follows for whatever else the configuration has
         int n_other = n_groups;
         if (tab_mode >= 2 && e->n_xtab > 0) {
@@ -1880,6 +1892,17 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                 } else      // (8 x 32 blocks for a single walker measured the same: 12 us)
                     hipLaunchKernelGGL((k_pk_tab2<16, 16, 1>), dim3(B, n, (e->nk + 15) / 16), dim3(256), sh1, e->stream, D, A, B);
             }
+        }
+        // the shared-W groups in their own kernel (large batches)
+        const int n_w = ((int64_t)B * (int)e->w_groups.size() >= 24 && !e->no_pk_w) ? (int)e->w_groups.size() : 0;
+        if (n_w > 0) {
+            n_other -= n_w;
+            tm |= 32;
+            const size_t shw = std::max<size_t>((size_t)2 * 6 * 256, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
+            if (B >= 64)        // (four walkers per thread: 161 registers, 465 against 426 us for the stage at B = 512)
+                hipLaunchKernelGGL((k_pk_w<2>), dim3((B + 1) / 2, n_w, (e->nk + 63) / 64), dim3(256), shw, e->stream, D, e->d_pk_groups.p, e->d_pk_members.p, e->d_w_groups.p, B);
+            else
+                hipLaunchKernelGGL((k_pk_w<1>), dim3(B, n_w, (e->nk + 63) / 64), dim3(256), shw, e->stream, D, e->d_pk_groups.p, e->d_pk_members.p, e->d_w_groups.p, B);
         }
         if (n_other == 0) {}
         else {

@@ -10,6 +10,7 @@
 //                                                                          power_spectrum.py:435-502, :382-417, :526-556
 //   k_pk_tab2         P(k,mu) and its projection for the core groups against level-2 tables   power_spectrum.py:163-380
 //   k_pk_poly         pipelines whose mu dependence is the Kaiser polynomial x static G: closed form
+//   k_pk_w            shared-W groups (pipelines that differ in their Kaiser polynomials only) of large batches
 //   k_gemm_nt44 / k_gemm_nt / k_gemv / k_gemv1   D = A . X for a static matrix and a batch of walker vectors
 //                     (4x4x4 four-block MFMA / 16x16x4 MFMA / streaming for <= 8 walkers / one walker):
 //                     FFTLog+spline operator (pktoxi.py:141-144), metal matrices (metals.py:338-367),
@@ -989,6 +990,42 @@ __device__ __forceinline__ void pk_w_extra_nodes(const EngineDev& D, const PkThr
     wm[0] += m0; wm[1] += m1; wm[2] += m2; wm[3] += m3; wm[4] += m4; wm[5] += m5;
 }
 
+// Multipoles of the member pipelines of a shared-W group from the six even moments wm of W (power_spectrum.py:163-222 with
+// P = P_lin (c0_1 + c1_1 mu^2)(c0_2 + c1_2 mu^2) W): walker b, wavenumber index i (value k).
+__device__ __forceinline__ void w_members_store(const EngineDev& D, const PkGroup& G, const int32_t* members, int b, int B,
+                                                int i, double k, const double* wm)
+{
+    const double inv_nmu = 1.0 / (double)D.n_mu;
+    const size_t ncols = (size_t)B * D.n_active;
+    for (int mi = 0; mi < G.n_members; ++mi) {
+        const int pm = members[G.member_off + mi];
+        const vmx_pipe_desc& dm = D.pipes[pm].d;
+        const double* scm = D.scal + ((size_t)b * D.n_pipe + pm) * VMX_NS;
+        double c01 = scm[S_BIAS1], c02 = scm[S_BIAS2];
+        const double c11 = scm[S_BB1], c12 = scm[S_BB2];
+        if (dm.uvb || dm.heii) {
+            double add = 0.0;
+            if (dm.uvb) { const double x = k * scm[S_UV_LAM]; const double W = atan(x) / x; add += scm[S_UV_BG] * W / (1.0 + scm[S_UV_BP] * W); }
+            if (dm.heii) { const double x = k * scm[S_HE_LAM]; const double W = atan(x) / x; add += scm[S_HE_BG] * W / (1.0 + scm[S_UV_BP] * W); }
+            if (dm.tracer[0].is_lya) c01 += add;
+            if (dm.tracer[1].is_lya) c02 += add;
+        }
+        if (dm.same_tracer) c02 = c01;
+        const double c12e = dm.same_tracer ? c11 : c12;
+        const double a0 = c01 * c02, a1 = fma(c01, c12e, c11 * c02), a2 = c11 * c12e;
+        double mm[4];
+        for (int m = 0; m < 4; ++m) mm[m] = fma(a2, wm[m + 2], fma(a1, wm[m + 1], a0 * wm[m]));
+        double damp = 1.0;
+        if (dm.damping_scale > 0.0) damp = exp(-dm.damping_scale * dm.damping_scale * pow(k, (double)dm.damping_power) / 2.0);
+        const double pk = damp * D.pklin[(size_t)dm.pk_lin_kind * D.nkp + i] * inv_nmu;
+        const size_t col = (size_t)b * D.n_active + D.pipes[pm].col;
+        D.pl[((size_t)0 * ncols + col) * D.nkp + i] = pk * mm[0];
+        D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
+        D.pl[((size_t)2 * ncols + col) * D.nkp + i] = pk * (39.375 * mm[2] - 33.75 * mm[1] + 3.375 * mm[0]);
+        D.pl[((size_t)3 * ncols + col) * D.nkp + i] = pk * (187.6875 * mm[3] - 255.9375 * mm[2] + 85.3125 * mm[1] - 4.0625 * mm[0]);
+    }
+}
+
 // Block = KT wavenumbers x MS mu-slices x WB walkers (KT * MS * WB = 256).  WB > 1 lets the waves of a block share the
 // rows of the static table through the CU's L1 (94 % L1 hit rate measured with WB = 4); it did not shorten the kernel
 // on MI355X (L2 was not the limiter), so the engine launches WB = 1 shapes only.
@@ -1005,6 +1042,9 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     // (the tabulated-D_NL mode does not: a smaller footprint lets more blocks share a CU)
     double* s_red = smem;
     double* s_mubv = smem + 2048 + (size_t)wb * D.n_rows;      // [WB][n_rows]  mu^bv (Arinyo), one table per walker
+    // (tab_mode + 32: the shared-W groups run in k_pk_w and are skipped here; block-uniform)
+    if ((tab_mode & 32) && groups[blockIdx.y].variant == PKV_SHARED_W) return;
+    tab_mode &= 3;
     const bool use_tab = tab_mode && groups[blockIdx.y].xtab >= 0 &&
                          (groups[blockIdx.y].variant == PKV_AUTO_CORE || groups[blockIdx.y].variant == PKV_CROSS_CORE);
     if (tab_mode >= 2 && use_tab) return;             // (k_pk_tab2 serves this group; block-uniform)
@@ -1164,35 +1204,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
                 for (int qq = 0; qq < MS; ++qq) sum += s_red[n * 256 + (wb * MS + qq) * KT + kk];
                 wm[n] = sum;
             }
-            const PkGroup& G = groups[blockIdx.y];
-            const size_t ncols = (size_t)B * D.n_active;
-            for (int mi = 0; mi < G.n_members; ++mi) {
-                const int pm = members[G.member_off + mi];
-                const vmx_pipe_desc& dm = D.pipes[pm].d;
-                const double* scm = D.scal + ((size_t)b * D.n_pipe + pm) * VMX_NS;
-                double c01 = scm[S_BIAS1], c02 = scm[S_BIAS2];
-                const double c11 = scm[S_BB1], c12 = scm[S_BB2];
-                if (dm.uvb || dm.heii) {
-                    double add = 0.0;
-                    if (dm.uvb) { const double x = k * scm[S_UV_LAM]; const double W = atan(x) / x; add += scm[S_UV_BG] * W / (1.0 + scm[S_UV_BP] * W); }
-                    if (dm.heii) { const double x = k * scm[S_HE_LAM]; const double W = atan(x) / x; add += scm[S_HE_BG] * W / (1.0 + scm[S_UV_BP] * W); }
-                    if (dm.tracer[0].is_lya) c01 += add;
-                    if (dm.tracer[1].is_lya) c02 += add;
-                }
-                if (dm.same_tracer) c02 = c01;
-                const double c12e = dm.same_tracer ? c11 : c12;
-                const double a0 = c01 * c02, a1 = fma(c01, c12e, c11 * c02), a2 = c11 * c12e;
-                double mm[4];
-                for (int m = 0; m < 4; ++m) mm[m] = fma(a2, wm[m + 2], fma(a1, wm[m + 1], a0 * wm[m]));
-                double damp = 1.0;
-                if (dm.damping_scale > 0.0) damp = exp(-dm.damping_scale * dm.damping_scale * pow(k, (double)dm.damping_power) / 2.0);
-                const double pk = damp * D.pklin[(size_t)dm.pk_lin_kind * D.nkp + i] * inv_nmu;
-                const size_t col = (size_t)b * D.n_active + D.pipes[pm].col;
-                D.pl[((size_t)0 * ncols + col) * D.nkp + i] = pk * mm[0];
-                D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
-                D.pl[((size_t)2 * ncols + col) * D.nkp + i] = pk * (39.375 * mm[2] - 33.75 * mm[1] + 3.375 * mm[0]);
-                D.pl[((size_t)3 * ncols + col) * D.nkp + i] = pk * (187.6875 * mm[3] - 255.9375 * mm[2] + 85.3125 * mm[1] - 4.0625 * mm[0]);
-            }
+            w_members_store(D, groups[blockIdx.y], members, b, B, i, k, wm);
         }
         return;
     }
@@ -1517,6 +1529,160 @@ __global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : NW == 1 ? VMX_TAB2_BLOCKS :
     const Tab2Group& G = A.g[blockIdx.y];
     if (G.cross) pk_tab2_body<KT, MS, NW, true>(D, G, B);
     else pk_tab2_body<KT, MS, NW, false>(D, G, B);
+}
+
+// The shared-W groups (e.g. QSO x every metal line: pipelines that differ in their Kaiser polynomials only) in their own lean
+// kernel: six even moments of W(k, mu) = G(k, mu) exp(e0 + e1 mu^2) / sqrt((1 + (k mu s1)^2)(1 + (k mu s2)^2)) per walker
+// and wavenumber, NW walkers per thread (one entry of the static G table and one (mu^2, mu^4) pair serve all of them), then
+// every member's multipoles (w_members_store).  Block = 64 wavenumbers x 4 mu slices; grid = (ceil(B / NW), groups of the
+// list, k tiles); LDS as k_pk_tab2 (node tables, reused as the [NW][6][256] reduction scratch).
+template <int NW>
+__global__ __launch_bounds__(256, 4) void k_pk_w(EngineDev D, const PkGroup* groups, const int32_t* members, const int32_t* wlist, int B)
+{
+    extern __shared__ double smem[];
+    constexpr int KT = 64, MS = 4;
+    double* s_red = smem;
+    v2d* s_mu24 = (v2d*)smem;
+    v4d* s_node = (v4d*)(smem + 2 * D.n_mu);             // {mu^2, mu^4, mu^6, w} of the extra nodes
+    const PkGroup& G = groups[wlist[blockIdx.y]];
+    const int p = G.pipe;
+    const vmx_pipe_desc& d = D.pipes[p].d;
+    const int tile = blockIdx.z;
+    const int kk = threadIdx.x % KT;
+    const int ms = __builtin_amdgcn_readfirstlane(threadIdx.x / KT);
+    const int i = tile * KT + kk;
+    const bool valid = i < D.nk;
+    const int ic = valid ? i : D.nk - 1;
+    const int n_mu = D.n_mu;
+    const double inv_nmu = 1.0 / (double)n_mu;
+    const double k = D.k[ic], k2 = k * k;
+    double e0[NW], e1[NW], k2vd1[NW], k2vd2[NW];
+    bool noexp[NW];
+    double e_max = -1e300;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        int b = blockIdx.x * NW + w;
+        if (b >= B) b = B - 1;                        // a surplus walker slot shadows the last walker and stores nothing
+        const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+        const double ga = sc[S_GA], gb = sc[S_GB];
+        e0[w] = -k2 * gb; e1[w] = -k2 * (ga - gb);
+        noexp[w] = (ga == 0.0) && (gb == 0.0);
+        k2vd1[w] = k2 * sc[S_VD1]; k2vd2[w] = k2 * sc[S_VD2];
+        e_max = fmax(e_max, e0[w] + fmax(e1[w], 0.0));
+    }
+    const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;
+    if (live_block && threadIdx.x == 0) atomicMax(D.k_live, min((tile + 1) * KT, D.nk));
+    const bool node_mode = D.n_extra > 0 && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
+    if (live_block && node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((tile + 1) * KT, D.nk));
+    const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
+    if (live_block) {
+        for (int j = threadIdx.x; j < n_mu; j += 256)
+            if (j < lo_end || j >= hi_beg) { const double m = D.mu[j], m2 = m * m; s_mu24[j] = (v2d){m2, m2 * m2}; }
+        if (node_mode)
+            for (int j = threadIdx.x; j < D.n_extra; j += 256) {
+                const double m = D.mu[n_mu + j], m2 = m * m;
+                s_node[j] = (v4d){m2, m2 * m2, m2 * m2 * m2, D.node_w[j]};
+            }
+    }
+    __syncthreads();
+
+    double wm[NW][6];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int n = 0; n < 6; ++n) wm[w][n] = 0.0;
+    if (live_block) {
+        const bool has_g = d.gk_table >= 0;
+        const size_t row = (size_t)D.nkp, stride = (size_t)MS * D.nkp;
+        // (without a G table the stream reads the mu table's own storage: any finite values, multiplied out below)
+        const double* base = has_g ? D.gk + (size_t)d.gk_table * D.n_rows * D.nkp + (size_t)ms * row + ic : D.k + ic;
+        const size_t st = has_g ? stride : 0, rw = has_g ? row : 0;
+#define VMX_W_NODE(MU2, MU4, MU6, WGT, G_)                                                                            \
+        {                                                                                                             \
+            _Pragma("unroll")                                                                                         \
+            for (int w = 0; w < NW; ++w) {                                                                            \
+                double val = has_g ? (G_) : 1.0;                                                                      \
+                if (WGT) val *= wgt;                                                                                  \
+                if (!noexp[w]) val *= vmx_exp(fma(e1[w], (MU2), e0[w]));                                              \
+                if (k2vd1[w] != 0.0) val *= vmx_rsqrt(fma(k2vd1[w], (MU2), 1.0));                                     \
+                if (k2vd2[w] != 0.0) val *= vmx_rsqrt(fma(k2vd2[w], (MU2), 1.0));                                     \
+                wm[w][0] += val; wm[w][1] = fma((MU2), val, wm[w][1]); wm[w][2] = fma((MU4), val, wm[w][2]);          \
+                const double v6 = val * (MU6);                                                                        \
+                wm[w][3] += v6; wm[w][4] = fma((MU2), v6, wm[w][4]); wm[w][5] = fma((MU4), v6, wm[w][5]);             \
+            }                                                                                                         \
+        }
+        const double wgt = 1.0;
+        for (int rg = 0; rg < (node_mode ? 2 : 1); ++rg) {
+            const int j_lo = rg == 0 ? 0 : hi_beg, j_hi = rg == 0 ? lo_end : n_mu;
+            const double* tab = base + (size_t)j_lo * rw;
+            double g0 = *tab, g1 = tab[st], g2 = tab[2 * st], g3 = tab[3 * st];
+            tab += 4 * st;
+            const int steps = j_hi > j_lo + ms ? (j_hi - j_lo - ms + MS - 1) / MS : 0;
+#define VMX_W_STEP(GREG, J)                                                                                           \
+            {                                                                                                         \
+                const v2d mm = s_mu24[J];                                                                             \
+                const double g = GREG;                                                                                \
+                GREG = *tab; tab += st;     /* (rows past a range's end exist: other rows / padding) */               \
+                VMX_W_NODE(mm.x, mm.y, mm.x * mm.y, false, g)                                                         \
+            }
+            int j = j_lo + ms;
+            for (int it = 0; it < steps / 4; ++it, j += 4 * MS) {
+                VMX_W_STEP(g0, j)
+                VMX_W_STEP(g1, j + MS)
+                VMX_W_STEP(g2, j + 2 * MS)
+                VMX_W_STEP(g3, j + 3 * MS)
+            }
+            if (steps % 4 > 0) VMX_W_STEP(g0, j)
+            if (steps % 4 > 1) VMX_W_STEP(g1, j + MS)
+            if (steps % 4 > 2) VMX_W_STEP(g2, j + 2 * MS)
+#undef VMX_W_STEP
+        }
+        if (node_mode) {
+            const double* tab = base + (size_t)n_mu * rw;
+            double g0 = *tab, g1 = tab[st], g2 = tab[2 * st], g3 = tab[3 * st];
+            tab += 4 * st;
+            const int steps = D.n_extra > ms ? (D.n_extra - ms + MS - 1) / MS : 0;
+#define VMX_W_XSTEP(GREG, JJ)                                                                                         \
+            {                                                                                                         \
+                const v4d nd = s_node[JJ];                                                                            \
+                const double wgt = nd.w;                                                                              \
+                const double g = GREG;                                                                                \
+                GREG = *tab; tab += st;                                                                               \
+                VMX_W_NODE(nd.x, nd.y, nd.z, true, g)                                                                 \
+            }
+            int jj = ms;
+            for (int it = 0; it < steps / 4; ++it, jj += 4 * MS) {
+                VMX_W_XSTEP(g0, jj)
+                VMX_W_XSTEP(g1, jj + MS)
+                VMX_W_XSTEP(g2, jj + 2 * MS)
+                VMX_W_XSTEP(g3, jj + 3 * MS)
+            }
+            if (steps % 4 > 0) VMX_W_XSTEP(g0, jj)
+            if (steps % 4 > 1) VMX_W_XSTEP(g1, jj + MS)
+            if (steps % 4 > 2) VMX_W_XSTEP(g2, jj + 2 * MS)
+#undef VMX_W_XSTEP
+        }
+#undef VMX_W_NODE
+    }
+    __syncthreads();            // every wave is done with the node tables
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int n = 0; n < 6; ++n) s_red[(size_t)(w * 6 + n) * 256 + threadIdx.x] = wm[w][n];
+    __syncthreads();
+    if (threadIdx.x >= KT || !valid) return;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int b = blockIdx.x * NW + w;
+        if (b >= B) continue;
+        double tot[6];
+        for (int n = 0; n < 6; ++n) {
+            double sum = 0.0;
+            for (int qq = 0; qq < MS; ++qq) sum += s_red[(size_t)(w * 6 + n) * 256 + qq * KT + kk];
+            tot[n] = sum;
+        }
+        w_members_store(D, G, members, b, B, i, k, tot);
+    }
 }
 
 // Pipelines whose only mu dependence is the Kaiser polynomial times the static G table (metal pairs without
