@@ -69,6 +69,10 @@ WORKLOAD_TEXT = {
     'auto': 'auto: Lya x Lya auto-correlation only, B={B} walkers/GPU/step, dense synthetic 2500^2 distortion matrix',
 }
 
+# `general_walkers`: the same workload with walkers that ALSO differ in Arinyo, smoothing and peak-broadening parameters -
+# no per-batch table applies, every walker runs its own P(k,mu) loops (what a sampler that frees those parameters gets)
+GENERAL_EXTRA = ['dnl_arinyo_q1', 'par_sigma_smooth', 'per_sigma_smooth', 'sigmaNL_par']
+
 VARIED = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO', 'drp_QSO',
           'bias_hcd', 'beta_hcd', 'L0_hcd', 'bias_eta_SiII(1190)', 'bias_eta_SiII(1193)',
           'bias_eta_SiIII(1207)', 'bias_eta_SiII(1260)', 'bias_eta_CIV(eff)']
@@ -269,7 +273,7 @@ def _cpu_worker_eval(pars):
     return _CPU['oracle'].chi2(_CPU['prob'], pars)
 
 
-def cpu_baseline(workload, names, theta, repeats=7, warmups=2):
+def cpu_baseline(workload, names, theta, repeats=7, warmups=2, extra_theta=None):
     """The oracle (CPU restatement of the reference) on the host cores, SURVEY 8d: a pool of one worker per core
     (one BLAS thread each), every repeat evaluates one walker per worker; median of `repeats` after `warmups`; plus
     the single-core figure from one worker alone.  Runs BEFORE the GPU is initialised (worker processes are started
@@ -303,6 +307,9 @@ def cpu_baseline(workload, names, theta, repeats=7, warmups=2):
             for i in range(n_single):
                 pool.submit(_cpu_worker_eval, walkers[i % len(walkers)]).result()
             single = n_single / (time.perf_counter() - t0)
+            extra_vals = None
+            if extra_theta is not None:     # (untimed: the oracle's chi2 of the `general_walkers` sample)
+                extra_vals = list(pool.map(_cpu_worker_eval, [dict(zip(names, row)) for row in extra_theta], chunksize=1))
             total = time.perf_counter() - t_start
     finally:
         for k, v in saved.items():
@@ -316,7 +323,7 @@ def cpu_baseline(workload, names, theta, repeats=7, warmups=2):
             'one_core_value': single,
             'sample': f'{workers} worker processes (1 BLAS thread each) x 1 walker per repeat, median of {repeats} repeats '
                       f'after {warmups} warm-ups ({med * 1e3:.0f} ms per repeat), {len(done)} distinct walkers of the same '
-                      f'workload, oracle/vega_cpu.py chi2; {total:.1f} s in all'}, done, [vals[i] for i in done]
+                      f'workload, oracle/vega_cpu.py chi2; {total:.1f} s in all'}, done, [vals[i] for i in done], extra_vals
 
 
 def main():
@@ -369,9 +376,11 @@ def main():
     host_theta = synthetic.walkers(low.theta0, low.names, B, varied=VARIED, seed=synthetic.SEED + 1000 * rank)
 
     # the CPU baseline runs first, on rank 0 of the N = 1 run, before this process touches the GPU
-    cpu = cpu_idx = cpu_vals = None
+    cpu = cpu_idx = cpu_vals = general_vals = None
+    general_theta = synthetic.walkers(low.theta0, low.names, B, varied=VARIED + GENERAL_EXTRA, seed=synthetic.SEED + 555)
     if rank == 0 and world == 1 and not args.core_only and not args.no_cpu_baseline:
-        cpu, cpu_idx, cpu_vals = cpu_baseline(args.workload, low.names, host_theta)
+        cpu, cpu_idx, cpu_vals, general_vals = cpu_baseline(args.workload, low.names, host_theta,
+                                                            extra_theta=general_theta[:16])
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the vegamx engine has no CPU fallback')
@@ -497,6 +506,76 @@ def main():
                      'note': f'{nl} independent engines per GPU, step i on lane i % {nl}, B={B} walkers per step'}
 
     pk_state = engines[0].debug_read(4, 0, 5)       # live wavenumbers, node-rule tiles and table level of the timed steps
+    # the same K steps a few more times: `value` above is ONE region of K steps (the contract); the spread between regions
+    # of a few milliseconds each is reported beside it
+    regions = None
+    if not use_dist:
+        rates = []
+        for _ in range(5):
+            sync_all()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            sync_all()
+            torch.cuda.synchronize()
+            rates.append(B * args.steps / (time.perf_counter() - t0))
+        regions = {'evals_per_s_median': float(np.median(rates)), 'evals_per_s_min': min(rates), 'evals_per_s_max': max(rates),
+                   'regions': len(rates), 'steps_per_region': args.steps}
+
+    def rate_of(fn, reps):
+        for _ in range(3):
+            fn()
+        eng.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        eng.sync()
+        torch.cuda.synchronize()
+        return B * reps / (time.perf_counter() - t0)
+
+    other_paths = None
+    if not use_dist and not args.core_only and L == 1:
+        # The other ways through the same engine, same workload, same B (none of them is `value`):
+        #   general_walkers  walkers that also differ in Arinyo / smoothing / peak-broadening parameters (no tables)
+        #   full_chain       the model is asked for (compute_model_batch): distortion + C^-1 products instead of Q'
+        #   host_entry       vmx_eval: host theta in, host chi2 out (one 80 KB copy in, one synchronisation per step)
+        other_paths = {}
+        reps = max(args.steps // 2, 5)
+        d_general = torch.from_numpy(general_theta).to(dev)
+        out = torch.zeros(B, dtype=torch.float64, device=dev)
+        eng.set_constant_nl_hint(False)
+        rate = rate_of(lambda: eng.eval_device(d_general.data_ptr(), B, out.data_ptr()), reps)
+        level = int(eng.debug_read(4, 0, 5)[4])
+        entry = {'evals_per_s': rate, 'ms_per_step': B / rate * 1e3, 'table_level': level,
+                 'varied_in_addition': GENERAL_EXTRA}
+        if general_vals is not None:
+            got = out[:len(general_vals)].cpu().numpy()
+            entry['max_rel_chi2_diff_vs_oracle'] = float(np.max(np.abs(got - general_vals) / np.abs(general_vals)))
+            entry['oracle_walkers'] = len(general_vals)
+        other_paths['general_walkers'] = entry
+        eng.set_constant_nl_hint(True, gaussian=True)
+        d_model = torch.zeros(B, eng.model_size, dtype=torch.float64, device=dev)
+        rate = rate_of(lambda: eng.eval_device(pools[0].data_ptr(), B, out.data_ptr(), d_model.data_ptr()), reps)
+        entry = {'evals_per_s': rate, 'ms_per_step': B / rate * 1e3, 'model_doubles_per_walker': int(eng.model_size)}
+        if cpu is not None:
+            got = out.cpu().numpy()[cpu_idx]
+            entry['max_rel_chi2_diff_vs_oracle'] = float(np.max(np.abs(got - np.array(cpu_vals)) / np.abs(cpu_vals)))
+            entry['oracle_walkers'] = len(cpu_idx)
+        other_paths['full_chain'] = entry
+        host_out = {}
+
+        def host_step():
+            host_out['chi2'] = eng.eval(host_theta)[0]
+        rate = rate_of(host_step, reps)
+        entry = {'evals_per_s': rate, 'ms_per_step': B / rate * 1e3}
+        if cpu is not None:
+            got = host_out['chi2'][cpu_idx]
+            entry['max_rel_chi2_diff_vs_oracle'] = float(np.max(np.abs(got - np.array(cpu_vals)) / np.abs(cpu_vals)))
+            entry['oracle_walkers'] = len(cpu_idx)
+        other_paths['host_entry'] = entry
+
     exact_mu = None
     if not use_dist and not args.core_only:
         # the same steps with the reference's 1000-point mu loop itself instead of the node rule that reproduces its sums
@@ -634,7 +713,7 @@ def main():
                        'batch_per_gpu': B, 'lanes_per_gpu': L, 'pipelines_per_eval': len(eng.pipe_index),
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
-            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'distortion_csr': dist_csr, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'exact_mu_loop': exact_mu, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'distortion_csr': dist_csr, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'exact_mu_loop': exact_mu, 'regions': regions, 'other_paths': other_paths, 'cpu_baseline': cpu,
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
         }
         sys.stdout.flush()

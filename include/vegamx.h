@@ -252,7 +252,7 @@ int vmx_item_set_metal_kron(vmx_engine* e, int32_t item, int32_t index, const do
 int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index, int32_t rows,
                         int32_t cols, const double* dense);
 /* The distortion matrix in CSR form, as the reference holds it (scipy.sparse.csr_array: data.py:342-346, :456-459; the
- * product of model.py:143-144): indptr [rows + 1] (int64), indices [nnz] (int32, ascending within a row), values [nnz].
+ * product of model.py:143-144): indptr [rows + 1] (int64), indices [nnz] (int32, STRICTLY ascending within a row: no duplicates - checked), values [nnz].
  * Replaces vmx_item_set_matrix(VMX_MAT_DISTORTION) for matrices sparse enough that streaming 12 bytes per non-zero beats
  * 8 bytes per entry; every batch size takes the CSR kernel then (8 walkers per pass over the matrix).  Before
  * vmx_finalize. */
@@ -329,6 +329,13 @@ int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B);
  * that are not smooth in mu (exponential smoothing, Voigt / sinc HCD, McDonald), keep the plain loop.  node_rule = 0:
  * the 1000-point loop everywhere (VMX_EXACT_MU in the environment does the same).  Returns the setting in effect. */
 int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule);
+/* Applicability guard of that rule (before vmx_finalize).  The rule is validated on a parameter box - the prior limits
+ * of the reference's vega/parameters/default_values.txt for every parameter that shapes P(k,mu) other than polynomially,
+ * widened where the tests go further (tests/test_mu_quadrature.py: >= 100 draws incl. corners, 1e-12).  A walker with
+ * theta[slots[i]] outside [lo[i], hi[i]] (or NaN) is not trusted to it: its P(k,mu) blocks run the reference's 1000-point
+ * loop itself, decided per walker on the device (k_prologue), so a sampler that wanders off gets slower, never different.
+ * vmx_debug_read(what = 4)[7] counts such walkers since vmx_finalize.  n = 0: no guard. */
+int vmx_set_mu_rule_box(vmx_engine* e, int32_t n, const int32_t* slots, const double* lo, const double* hi);
 /* The extra nodes of that rule as the engine built them: mu[n], w[n] (weights in units of one midpoint); returns n
  * (also when the buffers are NULL or too small, without writing). */
 int vmx_get_mu_nodes(vmx_engine* e, double* mu, double* w, int32_t capacity);

@@ -10,8 +10,37 @@ if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
 
+_SPAWNER = None
+
+
+def run_programs(commands, envs, timeout=900):
+    """Run ``commands`` (argv lists) concurrently with the extra environments ``envs`` through the helper process that
+    was started before this session touched the GPU (tests/helpers/spawn_server.py); [(returncode, output)]."""
+    import json
+    import subprocess
+    if _SPAWNER is None:        # CPU-only session: nothing here holds a device, start them directly
+        procs = [subprocess.Popen(argv, env={**os.environ, **env}, cwd=str(REPO), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for argv, env in zip(commands, envs)]
+        return [(p.wait(timeout=timeout), p.stdout.read()) for p in procs]
+    _SPAWNER.stdin.write(json.dumps({'commands': commands, 'env': envs, 'cwd': str(REPO), 'timeout': timeout}) + '\n')
+    _SPAWNER.stdin.flush()
+    reply = json.loads(_SPAWNER.stdout.readline())
+    return [(r['returncode'], r['output']) for r in reply]
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # multi-process GPU tests start their ranks through a helper that never holds the device: it has to exist before
+    # this process initialises the GPU (counting devices does not initialise it)
+    global _SPAWNER
+    try:
+        import torch
+        if _SPAWNER is None and torch.cuda.device_count() > 0:
+            import subprocess
+            _SPAWNER = subprocess.Popen([sys.executable, str(REPO / 'tests' / 'helpers' / 'spawn_server.py')],
+                                        stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=str(REPO))
+    except Exception:       # pragma: no cover
+        _SPAWNER = None
     # torch bundles its own HIP runtime: when a test uses both torch device tensors and libvegamx.so, torch must
     # bring the runtime up first (as bench.py does), otherwise it finds no device in a process that already loaded
     # the system runtime through the engine.
@@ -231,3 +260,38 @@ def options2_problem(tmp_path, which):
         (cfg / f'{item_name}.ini').write_text(text)
     (cfg / 'main.ini').write_text(main)
     return build_problem(f'configs/opt2_{which}/main.ini', search_dirs=[tmp_path, GOLDEN])
+
+
+def mc_launcher_config(tmp_path, num_mocks=6, seed=3):
+    """configs/mc/main.ini under ``tmp_path``: the auto-correlation on a FITS data file that carries distortion matrix
+    and covariance, [control] run_montecarlo / num_mc_mocks / mc_seed, a [monte carlo] sampling table and
+    [mc parameters] - what scripts/run_mc_sharded.py (the reference's bin/run_vega_mc_mpi.py) reads."""
+    import re
+    from vega_amd import synthetic
+    from vega_amd.tables import read_tables
+    source = read_tables(GOLDEN / 'inputs' / 'cf_lya-exp.npz')
+    data_path = synthetic.write_data_file(tmp_path / 'cf_lya-synth.fits', source)
+    cfg = tmp_path / 'configs' / 'mc'
+    cfg.mkdir(parents=True)
+    main = (GOLDEN / 'configs' / 'auto' / 'main.ini').read_text()
+    main = re.sub(r'ini files = .*', 'ini files = configs/mc/lyalya_lyalya.ini', main)
+    main = re.sub(r'\[control\][^\[]*', '', main)
+    main = re.sub(r'\[sample\][^\[]*', '[sample]\nap = 0.5 1.5 1.0 0.01\nat = 0.5 1.5 1.0 0.01\n\n', main)
+    main += (f'\n[control]\nrun_montecarlo = True\nnum_mc_mocks = {num_mocks}\nmc_seed = {seed}\n\n[monte carlo]\n'
+             'ap = 0.5 1.5 1.0 0.01\nat = 0.5 1.5 1.0 0.01\nbias_eta_LYA = -1.0 0.0 -0.2 0.01\n\n[mc parameters]\nbeta_LYA = 1.8\n')
+    main = re.sub(r'(\[output\]\nfilename = ).*', rf'\g<1>{tmp_path}/out/result', main)
+    (cfg / 'main.ini').write_text(main)
+    item = (GOLDEN / 'configs' / 'auto' / 'lyalya_lyalya.ini').read_text()
+    (cfg / 'lyalya_lyalya.ini').write_text(re.sub(r'filename = .*', f'filename = {data_path}', item, count=1))
+    return 'configs/mc/main.ini'
+
+
+def pytest_unconfigure(config):
+    global _SPAWNER
+    if _SPAWNER is not None:
+        try:
+            _SPAWNER.stdin.close()
+            _SPAWNER.wait(timeout=10)
+        except Exception:       # pragma: no cover
+            _SPAWNER.kill()
+        _SPAWNER = None

@@ -75,6 +75,97 @@ def test_rule_reproduces_the_references_mu_sums_over_wide_parameter_ranges(monke
     assert worst <= 1e-12, worst
 
 
+def _box_draws(prob, n_draws, rng):
+    """Parameter points over the FULL box of the guard (vega_amd.mu_quadrature.RULE_BOX) and the reference's prior
+    limits of every other sampled-able parameter: the fiducial point, corners (every watched parameter at one of its
+    limits), then uniform draws."""
+    from oracle import vega_cpu as oc
+    from vega_amd.defaults import DEFAULT_VALUES
+    from vega_amd.mu_quadrature import rule_box
+    base = oc.local_params(prob)
+    box = rule_box(base.keys())
+    limits = {n: DEFAULT_VALUES[n][0] for n in base if n in DEFAULT_VALUES and n not in box}
+    limits.update(box)
+    draws = [dict(base)]
+    for i in range(1, n_draws):
+        pars = dict(base)
+        corner = i <= n_draws // 4
+        for name, (lo, hi) in limits.items():
+            if corner and name in box:
+                pars[name] = lo if rng.random() < 0.5 else hi
+            else:
+                pars[name] = rng.uniform(lo, hi)
+        draws.append(pars)
+    return draws, box
+
+
+def test_rule_over_the_full_guard_box_with_corners(monkeypatch):
+    """>= 100 draws over the whole box the engine trusts the rule on (the reference's default_values.txt limits, wider
+    for L0_hcd and dnl_arinyo_kp), corners included: all four moments, both items, peak and smooth, bar 1e-12 of the
+    largest k^3 M_n.  Outside this box the engine runs the plain loop (vmx_set_mu_rule_box)."""
+    from oracle import vega_cpu as oc
+    from vega_amd.mu_quadrature import node_rule
+    monkeypatch.setattr(oc, 'sinc', lambda x: np.sinc(np.asarray(x) / np.pi))
+    prob = load_problem('joint')
+    mu, w = node_rule()
+    full, nodes = oc.PkGrid(prob.k, 1000), _NodeGrid(prob.k, mu)
+    weight = prob.k**3 * (prob.k <= K_NODE_MAX)
+    draws, box = _box_draws(prob, 104, np.random.default_rng(20261005))
+    assert {'L0_hcd', 'sigmaNL_par', 'sigmaNL_per', 'par_sigma_smooth', 'per_sigma_smooth', 'dnl_arinyo_bv',
+            'sigma_velo_disp_lorentz_QSO'} <= set(box)
+    worst = 0.0
+    for pars in draws:
+        for item in prob.items.values():
+            for peak, pk_lin in ((False, prob.pk_smooth), (True, prob.pk_full - prob.pk_smooth)):
+                pp = dict(pars, peak=peak)
+                exact = oc.power_spectrum(item.core, full, pk_lin, prob.pk_fid, pp)
+                at_nodes = oc.power_spectrum(item.core, nodes, pk_lin, prob.pk_fid, pp)
+                for n in range(4):
+                    ref = np.sum(full.mu**(2 * n) * exact, axis=0)
+                    got = np.sum(w[:, None] * nodes.mu**(2 * n) * at_nodes, axis=0)
+                    scale = np.abs(ref * weight).max()
+                    if scale > 0:
+                        worst = max(worst, np.abs((got - ref) * weight).max() / scale)
+    assert worst <= 1e-12, worst
+
+
+@pytest.mark.gpu
+def test_rule_on_and_off_over_the_guard_box_on_the_gpu_and_the_fallback_outside_it():
+    """32 walkers drawn over the guard's box: rule on vs off, xi <= 1e-10 of the vector's scale; a walker pushed outside
+    the box is evaluated by the plain loop (bit-identical with the rule switched off), and counted."""
+    from vega_amd import VegaInterface
+    prob = load_problem('joint')
+    vega = VegaInterface(None, problem=prob, max_batch=32)
+    eng = vega.engine
+    draws, box = _box_draws(prob, 32, np.random.default_rng(99))
+    assert set(eng.mu_rule_box) == set(box)
+    theta = np.stack([eng.theta_from_params({k: v for k, v in p.items() if k in eng.low.slot}) for p in draws])
+    for sub in (theta, theta[:5]):
+        assert eng.set_mu_quadrature(True)
+        c_rule, s_rule, m_rule = eng.eval(sub, want_model=True)
+        assert not eng.set_mu_quadrature(False)
+        c_loop, s_loop, m_loop = eng.eval(sub, want_model=True)
+        eng.set_mu_quadrature(True)
+        np.testing.assert_array_equal(s_rule, s_loop)
+        ok = s_rule == 0
+        assert ok.sum() >= sub.shape[0] // 2
+        for name, sl in eng.model_slices.items():
+            scale = np.abs(m_loop[ok][:, sl]).max(axis=1, keepdims=True)
+            assert (np.abs(m_rule[ok][:, sl] - m_loop[ok][:, sl]) <= 1e-10 * scale).all(), name
+    assert eng.debug_read(4, 0, 8)[7] == 0          # nobody left the box so far
+    outside = theta[:6].copy()
+    outside[:, eng.low.slot['L0_hcd']] = 55.0       # beyond the validated 40 Mpc/h
+    eng.set_mu_quadrature(True)
+    c_guard, _, m_guard = eng.eval(outside, want_model=True)
+    assert eng.debug_read(4, 0, 8)[7] == 6
+    eng.set_mu_quadrature(False)
+    c_loop, _, m_loop = eng.eval(outside, want_model=True)
+    eng.set_mu_quadrature(True)
+    np.testing.assert_array_equal(m_guard, m_loop)
+    np.testing.assert_array_equal(c_guard, c_loop)
+    vega.close()
+
+
 @pytest.mark.gpu
 def test_engine_nodes_and_the_rule_against_the_plain_loop():
     from vega_amd import VegaInterface, synthetic

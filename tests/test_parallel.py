@@ -31,6 +31,11 @@ def _worker(rank, world, port, n, out_dir):
     lo, hi = shard_bounds(n, world, rank)
     assert calls == ([hi - lo] if hi > lo else [])
     np.save(os.path.join(out_dir, f'rank{rank}.npy'), full)
+    # tensors in -> tensor out (the device-resident form; CPU tensors under gloo)
+    import torch
+    as_tensor = chi2_sharded(lambda block: (block**2).sum(dim=1) + 3.0, torch.from_numpy(theta))
+    assert isinstance(as_tensor, torch.Tensor)
+    np.save(os.path.join(out_dir, f'rank{rank}_tensor.npy'), as_tensor.numpy())
     dist.destroy_process_group()
 
 
@@ -44,6 +49,7 @@ def test_sharded_chi2_gloo_world2(tmp_path, n):
     for rank in range(2):
         got = np.load(tmp_path / f'rank{rank}.npy')
         np.testing.assert_array_equal(got, expect)
+        np.testing.assert_array_equal(np.load(tmp_path / f'rank{rank}_tensor.npy'), expect)
 
 
 def test_shard_bounds_cover_everything():

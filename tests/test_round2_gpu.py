@@ -272,27 +272,12 @@ def test_sharded_monte_carlo_launcher_on_a_real_engine(tmp_path):
     [control] run_montecarlo / num_mc_mocks / mc_seed, [monte carlo] sampling table and [mc parameters], a data file that
     carries distortion matrix and covariance; the fiducial comes from a fit to the data, the result file has the
     reference's layout and the fits recover the template parameters."""
-    import re
     import sys
-    from conftest import REPO
-    from vega_amd import fitslite, synthetic
-    from vega_amd.tables import read_tables
+    from conftest import REPO, mc_launcher_config
+    from vega_amd import fitslite
     sys.path.insert(0, str(REPO / 'scripts'))
     import run_mc_sharded
-    source = read_tables(GOLDEN / 'inputs' / 'cf_lya-exp.npz')
-    data_path = synthetic.write_data_file(tmp_path / 'cf_lya-synth.fits', source)
-    cfg = tmp_path / 'configs' / 'mc'
-    cfg.mkdir(parents=True)
-    main = (GOLDEN / 'configs' / 'auto' / 'main.ini').read_text()
-    main = re.sub(r'ini files = .*', 'ini files = configs/mc/lyalya_lyalya.ini', main)
-    main = re.sub(r'\[control\][^\[]*', '', main)
-    main = re.sub(r'\[sample\][^\[]*', '[sample]\nap = 0.5 1.5 1.0 0.01\nat = 0.5 1.5 1.0 0.01\n\n', main)
-    main += ('\n[control]\nrun_montecarlo = True\nnum_mc_mocks = 6\nmc_seed = 3\n\n[monte carlo]\nap = 0.5 1.5 1.0 0.01\n'
-             'at = 0.5 1.5 1.0 0.01\nbias_eta_LYA = -1.0 0.0 -0.2 0.01\n\n[mc parameters]\nbeta_LYA = 1.8\n')
-    main = re.sub(r'(\[output\]\nfilename = ).*', rf'\g<1>{tmp_path}/out/result', main)
-    (cfg / 'main.ini').write_text(main)
-    item = (GOLDEN / 'configs' / 'auto' / 'lyalya_lyalya.ini').read_text()
-    (cfg / 'lyalya_lyalya.ini').write_text(re.sub(r'filename = .*', f'filename = {data_path}', item, count=1))
+    mc_launcher_config(tmp_path, num_mocks=6, seed=3)
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     mc, res, block = run_mc_sharded.run('configs/mc/main.ini', search_dirs=[tmp_path, GOLDEN], max_batch=128,
                                         print_func=lambda message: None)

@@ -37,9 +37,6 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 namespace {
 
-static std::mutex g_quad_len_mutex;
-static std::map<std::string, int> g_quad_len;        // measured segment lengths of the quadratic-form launch, by problem shape
-
 static const uint64_t VMX_PART_SENTINEL = 0x7ff8dead0000beefull;      // a NaN payload no arithmetic produces (k_gemv1 MODE 2 slots)
 
 
@@ -142,6 +139,8 @@ struct vmx_engine {
     int nk = 0, nkp = 0, n_mu = 0;
     int n_rows = 0, n_extra = 0, mu_lo = 0, mu_hi = 0;     // node rule of the mu sums (vmx_set_mu_quadrature)
     DevBuf<double> node_w;
+    std::vector<int32_t> rule_slot; std::vector<double> rule_lo, rule_hi;     // vmx_set_mu_rule_box
+    DevBuf<int32_t> d_rule_slot; DevBuf<double> d_rule_lo, d_rule_hi;
     double k_node_max = 0.0; bool mu_nodes_on = true;
     DevBuf<double> k, pklin, delta2, mu, sq1mmu2, lnmu, wl, gk, gk_mom, fv_x, fv_f, xtab;
     std::vector<int32_t> const_slots;        // parameters a level-1 table depends on (the Arinyo set)
@@ -207,21 +206,20 @@ struct vmx_engine {
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
     // work lists of the quadratic-form launches per batch size: entries, their count, per-row-tile slab counts
     struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg; DevBuf<double> part; int n_blocks = 0; int rows = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; int seg_len = 0; };
-    std::map<int, QuadList*> quad_lists;     // by number of walker tiles
-    std::map<int, int> quad_seg_len;         // measured segment length by power-of-two class of that number
+    std::map<int, QuadList*> quad_lists;     // by number of walker tiles (+ 1e6 (item + 1) for the per-item lists of forked streams)
     bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
     bool quad_fused_chi2 = true;     // VMX_NO_FUSED_CHI2: the list launch stores the product, k_chi2_quad contracts it
+    bool item_streams = true;        // VMX_NO_ITEM_STREAMS: the items of a large chi2-only batch share one stream (see run_items_forked)
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
     bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
-    int prologue_threads = 0;        // VMX_PROLOGUE_THREADS (64 .. 1024, a multiple of 64; 0: by the number of pipelines)
     bool no_small_tab = false;       // VMX_NO_SMALL_TAB: batches below 16 walkers never use the tables
     int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
-    int xi_fused_max_b = 1 << 30;    // VMX_XI_FUSED_MAXB (an experiment knob: the fused kernel wins at every batch size)
     bool no_tab2 = false;            // VMX_NO_TAB2: level-1 tables only (the Gaussian factors stay in the mu loop)
     bool quad_band_xcd = false;      // VMX_XCD_BANDS: a K band per XCD (HBM traffic 1.96x -> 1.43x the algorithmic bytes, launch 6 % longer)
     bool gemm_44 = true;             // products on the four-block 4x4x4 fp64 MFMA (VMX_GEMM_16: the 16x16x4 kernel everywhere)
     bool pk_small_attr = false;      // the single-walker P(k) shape asked for its > 64 KB of LDS
+    bool kron_attr = false;          // k_metal_kron asked for its dynamic LDS
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
     int64_t xi_total = 0, xim_total = 0;
     DevBuf<double> theta, scal, metal_bias, pl, coef, xi, xim, model, chi2;
@@ -1032,6 +1030,10 @@ int vmx_item_set_matrix_csr(vmx_engine* e, int32_t item, int32_t rows, int32_t c
     const int64_t nnz = indptr[rows];
     for (int r = 0; r < rows; ++r) REQUIRE(indptr[r + 1] >= indptr[r], "indptr must be non-decreasing");
     for (int64_t k = 0; k < nnz; ++k) REQUIRE(indices[k] >= 0 && indices[k] < cols, "column index out of range");
+    // canonical form: the quadratic form scatters the rows (k_quad_gather_csr: last write wins), the product adds them
+    for (int r = 0; r < rows; ++r)
+        for (int64_t k = indptr[r] + 1; k < indptr[r + 1]; ++k)
+            REQUIRE(indices[k] > indices[k - 1], "column indices must be strictly ascending within a row (no duplicates)");
     HIP_OK(hipSetDevice(e->device));
     if (it->csr_ptr.upload(indptr, (size_t)rows + 1) || it->csr_idx.upload(indices, (size_t)std::max<int64_t>(nnz, 1)) ||
         it->csr_val.upload(values, (size_t)std::max<int64_t>(nnz, 1))) return -2;
@@ -1180,11 +1182,10 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
     if (getenv("VMX_NO_SMALL_TAB")) e->no_small_tab = true;
     if (getenv("VMX_NO_PK_W")) e->no_pk_w = true;
-    if (const char* v = getenv("VMX_PROLOGUE_THREADS")) e->prologue_threads = std::min(1024, std::max(64, atoi(v) / 64 * 64));
     if (getenv("VMX_NO_FFT_RING")) e->fft_ring = false;
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
-    if (const char* v = getenv("VMX_XI_FUSED_MAXB")) e->xi_fused_max_b = atoi(v);
+    if (getenv("VMX_NO_ITEM_STREAMS")) e->item_streams = false;
     if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
     if (getenv("VMX_GRAPH_B1")) e->graph_b1 = true;
@@ -1489,7 +1490,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->metal_bias.alloc((size_t)Bm * 3 * (e->metals.size() + 1)) ||
         e->pl.alloc((size_t)VMX_MAX_ELL * acols * e->nkp) || e->coef.alloc((size_t)VMX_MAX_ELL * acols * e->ncp) ||
         e->xi.alloc((size_t)e->xi_total) || e->xim.alloc((size_t)e->xim_total) ||
-        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(4)) return -2;
+        e->model.alloc((size_t)Bm * e->model_size) || e->chi2.alloc(Bm) || e->status.alloc(Bm) || e->k_live.alloc(8)) return -2;
     {
         const int32_t empty_window[2] = {0x7fffffff, -1};
         if (e->coef_win.upload(empty_window, 2)) return -2;
@@ -1510,6 +1511,11 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         if (getenv("VMX_EXACT_MU") || e->n_extra == 0) e->mu_nodes_on = false;
         D.k_node_max = e->mu_nodes_on ? e->k_node_max : 0.0;
     }
+    for (int sl : e->rule_slot) REQUIRE(sl < n_params, "mu-rule box slot exceeds n_params");
+    if (!e->rule_slot.empty() && (e->d_rule_slot.upload(e->rule_slot.data(), e->rule_slot.size()) ||
+                                  e->d_rule_lo.upload(e->rule_lo.data(), e->rule_lo.size()) ||
+                                  e->d_rule_hi.upload(e->rule_hi.data(), e->rule_hi.size()))) return -2;
+    D.rule_slot = e->d_rule_slot.p; D.rule_lo = e->d_rule_lo.p; D.rule_hi = e->d_rule_hi.p; D.n_rule = (int)e->rule_slot.size();
     D.k = e->k.p; D.pklin = e->pklin.p; D.delta2 = e->delta2.p; D.mu = e->mu.p; D.sq1mmu2 = e->sq1mmu2.p; D.lnmu = e->lnmu.p;
     D.wl = e->wl.p; D.fv_x = e->fv_x.p; D.fv_f = e->fv_f.p; D.fv_n = e->fv_n; D.gk = e->gk.p; D.gk_mom = e->gk_mom.p; D.xtab = e->xtab.p; D.const_slots = e->d_const_slots.p; D.n_const_slots = 0; D.xtab_pipe = e->d_xtab_pipe.p; D.n_xtab = e->n_xtab; D.xtab_key = e->xtab_key.p; D.xtab_partner = e->d_xtab_partner.p; D.xtab_k = e->xtab_k.p; D.xtab_level = 0; D.n_gk = (int)e->gk_tables.size();
     D.n_coef = e->n_coef; D.ncp = e->ncp; D.extrapolate = e->extrapolate ? 1 : 0;
@@ -1577,12 +1583,6 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     HIP_OK(hipStreamSynchronize(e->stream));
     e->finalized = true;
     if (poly_basis_build(e)) { e->finalized = false; return -2; }
-    if (getenv("VMX_DEBUG_PIPES"))
-        for (size_t pi = 0; pi < e->pipes.size(); ++pi) {
-            const PipeDev& pd = e->pipes[pi];
-            std::fprintf(stderr, "[vegamx] pipeline %zu: n %d col %d poly_basis %d poly_bins_off %lld scale_mode %d drp_slot %d n_ell %d\n",
-                         pi, pd.n, pd.col, pd.poly_basis, (long long)pd.poly_bins_off, pd.d.scale_mode, pd.d.drp_slot, pd.d.n_ell);
-        }
     return 0;
 }
 
@@ -1597,7 +1597,7 @@ int vmx_pipeline_column(vmx_engine* e, int32_t pipeline)
 // Work list of the quadratic-form launch for B walkers with segments of about L stages (a stage = 32 columns): every
 // 64 x 64 tile of every item's half-triangle product is cut into ceil(stages / L) K segments of equal length.  The walker
 // tiles of one (row tile, segment) share their matrix tile: they get block indices 8 apart - the same XCD, back to back.
-static vmx_engine::QuadList* quad_build_list(vmx_engine* e, int B, int L)
+static vmx_engine::QuadList* quad_build_list(vmx_engine* e, int B, int L, int only_item = -1)
 {
     constexpr int BM = GEMM_BM, BK = GEMM_BK;
     const int tn = (B + GEMM_BN - 1) / GEMM_BN;
@@ -1611,6 +1611,7 @@ static vmx_engine::QuadList* quad_build_list(vmx_engine* e, int B, int L)
         const ItemDev& d = e->items[q]->dev;
         const int tm = (d.nq + BM - 1) / BM, kmax_all = d.nq_pad / BK;
         ql->nseg_off[q] = (int32_t)nseg_all.size();
+        if (only_item >= 0 && (int)q != only_item) continue;        // (a list of one item's tiles: the items run on forked streams)
         for (int mt = 0; mt < tm; ++mt) {
             const int stages = std::min(((mt + 1) * BM + BK - 1) / BK, kmax_all);
             const int nseg = std::min(max_slabs, (stages + L - 1) / L);
@@ -1692,32 +1693,30 @@ static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, Sla
     hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), dim3(ql->n_blocks, 1), dim3(GEMM44_THREADS), 0, e->cur, G);
 }
 
-// The segment length is MEASURED once per batch size: a CU keeps two blocks resident and issues from the older one first,
-// so a launch of ~1000 blocks of unequal length is neither list scheduling on 256 machines nor on 512 half-speed ones -
-// simulated choices were up to 20 % off (B = 256: 0.154 ms with 40-stage segments, 0.181 with 64, 0.157 with 80).  A fixed
-// candidate set is timed with HIP events on the engine's stream (three launches each, the minimum counts); the choice
-// only changes how the partial sums are grouped, never what is summed.  VMX_QUAD_L pins it.
-static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
+// Segment length of the quadratic-form work list: a PURE FUNCTION of the number of walker tiles (and of nothing
+// else - no timing, no process-wide state), so that every rank of a sharded run and every repeat of a run groups its
+// partial sums identically: chi2 of a walker is bit-for-bit the same wherever and whenever its batch is evaluated.
+// The table comes from measurements on MI355X (VMX_QUAD_AUTOTUNE=1 times the candidates 24..96 with HIP events and
+// reports the fastest on stderr - a development aid that never feeds back into a run that did not ask for it):
+// a CU keeps two blocks resident and issues from the older one first, so a launch of ~1000 blocks of unequal length is
+// neither list scheduling on 256 machines nor on 512 half-speed ones, and simulated choices were up to 20 % off.
+static int quad_segment_length(int tn)
 {
-    // a list depends on the batch size through its number of walker tiles only; the segment length is measured once per
-    // power-of-two class of that number (a fit driver calls with dozens of different batch sizes)
+    if (const char* force = getenv("VMX_QUAD_L")) return std::max(1, atoi(force));
+    // (walker tiles -> stages of 32 columns) B <= 256: 40 (0.151 ms at B = 256; 64: 0.181, 80: 0.157)
+    return tn <= 4 ? 40 : tn <= 8 ? 48 : 64;
+}
+
+static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B, int only_item = -1)
+{
+    // a list depends on the batch size through its number of walker tiles only
     const int tn = (B + GEMM_BN - 1) / GEMM_BN;
-    auto found = e->quad_lists.find(tn);
+    const int key = only_item < 0 ? tn : (only_item + 1) * 1000000 + tn;
+    auto found = e->quad_lists.find(key);
     if (found != e->quad_lists.end()) return found->second;
-    int cls = 1;
-    while (cls < tn) cls *= 2;
     vmx_engine::QuadList* best = nullptr;
-    // (the measurement is a property of the problem's shape and the device, not of the engine: engines of the same shape in
-    // one process - a driver's second engine, a rebuilt engine - take it over)
-    std::string shape = std::to_string(e->device) + ":" + std::to_string(cls);
-    for (auto* it : e->items) shape += ":" + std::to_string(it->dev.nq);
-    {
-        std::lock_guard<std::mutex> lock(g_quad_len_mutex);
-        auto known = g_quad_len.find(shape);
-        if (known != g_quad_len.end() && !e->quad_seg_len.count(cls)) e->quad_seg_len[cls] = known->second;
-    }
-    if (const char* force = getenv("VMX_QUAD_L")) best = quad_build_list(e, B, std::max(1, atoi(force)));
-    else if (e->quad_seg_len.count(cls)) best = quad_build_list(e, B, e->quad_seg_len[cls]);
+    if (only_item >= 0) best = quad_build_list(e, B, quad_segment_length(tn), only_item);
+    else if (!getenv("VMX_QUAD_AUTOTUNE")) best = quad_build_list(e, B, quad_segment_length(tn));
     else {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { fail(-2, "hipEventCreate"); return nullptr; }
@@ -1736,15 +1735,12 @@ static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
                 float t = 0.f;
                 if (rep > 0 && hipEventElapsedTime(&t, ev0, ev1) == hipSuccess) ms = std::min(ms, t);
             }
+            std::fprintf(stderr, "[vegamx] VMX_QUAD_AUTOTUNE: %d walker tiles, segments of %d stages: %.4f ms\n", tn, L, ms);
             if (ms < best_ms) { best_ms = ms; delete best; best = ql; } else delete ql;
         }
         (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     }
-    if (best) {
-        e->quad_lists[tn] = best; e->quad_seg_len[cls] = best->seg_len;
-        std::lock_guard<std::mutex> lock(g_quad_len_mutex);
-        g_quad_len[shape] = best->seg_len;
-    }
+    if (best) e->quad_lists[key] = best;
     return best;
 }
 
@@ -1802,9 +1798,90 @@ static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, i
     }
     if (shmem == 0) return;
     ScopedTimer t(e, KC_METAL);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_metal_kron, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    if (!e->kron_attr) { (void)hipFuncSetAttribute((const void*)k_metal_kron, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e->kron_attr = true; }
     hipLaunchKernelGGL(k_metal_kron, dim3(B, (unsigned)it->metals.size()), dim3(256), shmem, e->cur, D, item, B);
+}
+
+// chi2-only evaluation of a large batch whose every P(k,mu) group runs against level-2 tables (a sampler's batch): the
+// correlation items are independent from the prologue to the chi2 reduction - P(k,mu) group, FFTLog columns, bins +
+// quadratic-form entries, half-triangle product of one item touch nothing of another - so each item's chain goes on its own
+// stream (the reference walks `corr_items` one after the other: vega_interface.py:232-316).  A kernel of one item fills
+// the first / last block round of the other's (every kernel of a B = 256 chain spends 20 - 30 % of its launch there).  The
+// largest item is the critical path: main stream, enqueued first.  What is computed, and in which order it is summed, is
+// exactly the one-stream chain's: per-item work lists with the same segment length, partial sums added list by list.
+static bool items_can_fork(vmx_engine* e, int B, int tab_mode, bool quad, bool xi_fused)
+{
+    if (!e->item_streams || !quad || !xi_fused || B <= 8 || e->items.size() < 2 || e->items.size() > VMX_MAX_GROUP) return false;
+    if (!(e->quad_list_mode && e->quad_use_44 && e->gemm_44 && e->quad_fused_chi2 && GEMM44_THREADS == 256)) return false;
+    if (tab_mode < 2 || e->n_xtab == 0 || e->pk_groups.size() != e->tab2_groups.size() || !e->pk_poly.empty() || !e->pk_static.empty()) return false;
+    if (e->tab2_groups.size() != e->items.size() || getenv("VMX_PK_TRACE") || getenv("VMX_QUAD_TRACE") || getenv("VMX_GEMM_TRACE")) return false;
+    // full per-kernel profiling (bench.py's calibration pass) wants uncontended kernels: one stream
+    if (e->profiling && e->prof_mask == 0xffffffffu) return false;
+    for (auto* it : e->items) {
+        int found = 0;
+        for (auto& t : e->tab2_groups)
+            if (t.pipe == it->dev.d.pipe_smooth && t.partner == it->dev.d.pipe_peak && std::abs(t.col_s - t.col_q) == 1) ++found;
+        if (found != 1) return false;
+    }
+    return true;
+}
+
+static int run_items_forked(vmx_engine* e, const EngineDev& D, int B)
+{
+    const int tn = (B + GEMM_BN - 1) / GEMM_BN;
+    std::vector<size_t> order(e->items.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return e->items[a]->dev.nq > e->items[b]->dev.nq; });
+    HIP_OK(hipEventRecord(e->ev_fork, e->stream));
+    QuadParts qp{};
+    const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
+    const int64_t ncols = (int64_t)B * e->n_active;
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+        const int q = (int)order[oi];
+        ItemHost* it = e->items[q];
+        e->cur = oi == 0 ? e->stream : e->aux[oi - 1];
+        if (oi > 0) HIP_OK(hipStreamWaitEvent(e->cur, e->ev_fork, 0));
+        const Tab2Group* grp = nullptr;
+        for (auto& t : e->tab2_groups) if (t.pipe == it->dev.d.pipe_smooth) grp = &t;
+        {
+            ScopedTimer t(e, KC_PK);
+            Tab2Args A{};
+            A.g[0] = *grp;
+            if (e->pk_walkers_per_thread == 2 && B >= 64)
+                hipLaunchKernelGGL((k_pk_tab2<64, 4, 2>), dim3((B + 1) / 2, 1, (e->nk + 63) / 64), dim3(256), std::max(sh1, (size_t)4096 * sizeof(double)), e->cur, D, A, B);
+            else
+                hipLaunchKernelGGL((k_pk_tab2<64, 4, 1>), dim3(B, 1, (e->nk + 63) / 64), dim3(256), sh1, e->cur, D, A, B);
+        }
+        // FFTLog o spline of the item's two pipelines: 2 B consecutive columns (pipeline-major layout)
+        const int c0 = std::min(grp->col_s, grp->col_q);
+        launch_product(e, KC_FFTLOG, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
+                       e->pl.p + (size_t)c0 * B * e->nkp, e->nkp, ncols * e->nkp, 2 * B, e->coef.p + (size_t)c0 * B * e->ncp, e->ncp,
+                       ncols * e->ncp, VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
+        {
+            ScopedTimer t(e, KC_XI);
+            hipLaunchKernelGGL(k_xi_assemble_quad, dim3((it->dev.nq_pad + 255) / 256, B, 1), dim3(256), 0, e->cur, D, q);
+        }
+        vmx_engine::QuadList* ql = quad_work_list(e, B, q);
+        if (!ql) return -2;
+        {
+            ScopedTimer t(e, KC_QUAD);
+            SlabInfo qs{};
+            quad_launch_list(e, ql, B, qs);
+        }
+        qp.part[q] = ql->part.p; qp.rows[q] = ql->rows;       // (added in item order, whatever the launch order)
+        if (oi > 0) HIP_OK(hipEventRecord(e->ev_join[oi - 1], e->cur));
+    }
+    qp.n = (int)e->items.size();
+    e->cur = e->stream;
+    for (size_t oi = 1; oi < order.size(); ++oi) HIP_OK(hipStreamWaitEvent(e->stream, e->ev_join[oi - 1], 0));
+    {
+        ScopedTimer t(e, KC_CHI2);
+        hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, qp, tn);
+    }
+    HIP_OK(hipGetLastError());
+    e->last_B = B;
+    e->last_full = false;
+    return 0;
 }
 
 static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
@@ -1843,9 +1920,22 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         {
             // (+ the rows of the block's walkers, staged next to the descriptors when theta is read from a device buffer)
             // (blocks of PRO_T threads: the descriptors are staged once per block)
-            const int PRO_T = e->prologue_threads > 0 ? e->prologue_threads : (n_pipe >= 8 ? 256 : 64);     // (measured: 19 against 22 us with 5 slots per walker, 40 against 44 with 24)
+            const int PRO_T = n_pipe >= 8 ? 256 : 64;     // (measured: 19 against 22 us with 5 slots per walker, 40 against 44 with 24)
             const size_t rows_bytes = (size_t)(PRO_T / (n_pipe + 1) + 2) * e->n_params * sizeof(double);
             hipLaunchKernelGGL(k_prologue, dim3((n_thr + PRO_T - 1) / PRO_T), dim3(PRO_T), desc_bytes + rows_bytes, e->stream, D, B);
+        }
+    }
+    {
+        bool fused = quad && (size_t)n_pipe == 2 * e->items.size();
+        for (auto* it : e->items) if (!it->metals.empty() || it->dev.d.pipe_peak == it->dev.d.pipe_smooth) fused = false;
+        if (items_can_fork(e, B, tab_mode, quad, fused)) {
+            const bool skip_xtab = e->skip_xtab_once;
+            e->skip_xtab_once = false;
+            if (!skip_xtab) {
+                ScopedTimer t(e, KC_PK);
+                hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, (e->n_rows + XTAB_ROWS - 1) / XTAB_ROWS, e->n_xtab), dim3(256), 0, e->stream, D);
+            }
+            return run_items_forked(e, D, B);
         }
     }
     {
@@ -1942,13 +2032,13 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                            VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
     }
     // chi2-only small batches of items without metal terms: bins + quadratic-form entries in one kernel
-    bool xi_fused = quad && B <= e->xi_fused_max_b && (size_t)n_pipe == 2 * e->items.size();
+    bool xi_fused = quad && (size_t)n_pipe == 2 * e->items.size();
     for (auto* it : e->items) if (!it->metals.empty() || it->dev.d.pipe_peak == it->dev.d.pipe_smooth) xi_fused = false;
     if (xi_fused) {
         ScopedTimer t(e, KC_XI);
         int max_nq = 0;
         for (auto* it : e->items) max_nq = std::max(max_nq, (int)it->dev.nq_pad);
-        hipLaunchKernelGGL(k_xi_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->stream, D);
+        hipLaunchKernelGGL(k_xi_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, 0);
     } else {
         ScopedTimer t(e, KC_XI);
         int max_n = 0;
@@ -1996,7 +2086,9 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             if (e->quad_fused_chi2 && GEMM44_THREADS == 256) {
                 // the launch left contraction partials instead of the product: a small kernel adds them up
                 ScopedTimer t(e, KC_CHI2);
-                hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, ql->part.p, (B + GEMM_BN - 1) / GEMM_BN, ql->rows);
+                QuadParts qp{};
+                qp.part[0] = ql->part.p; qp.rows[0] = ql->rows; qp.n = 1;
+                hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, qp, (B + GEMM_BN - 1) / GEMM_BN);
                 HIP_OK(hipGetLastError());
                 e->last_B = B;
                 e->last_full = false;
@@ -2401,7 +2493,11 @@ static int quad_ready(vmx_engine* e, bool* use, int B)
         if (!e->quad_eligible) return 0;
     }
     // (device allocations must not happen inside a stream capture: the work list of this batch size is built here)
-    if (B > 8 && e->items.size() <= VMX_MAX_GROUP && e->quad_list_mode && e->quad_use_44 && e->gemm_44 && !quad_work_list(e, B)) return -2;
+    if (B > 8 && e->items.size() <= VMX_MAX_GROUP && e->quad_list_mode && e->quad_use_44 && e->gemm_44) {
+        if (!quad_work_list(e, B)) return -2;
+        if (e->item_streams && e->items.size() >= 2)
+            for (size_t q = 0; q < e->items.size(); ++q) if (!quad_work_list(e, B, (int)q)) return -2;
+    }
     *use = true;
     return 0;
 }
@@ -2511,6 +2607,17 @@ int vmx_get_mu_nodes(vmx_engine* e, double* mu, double* w, int32_t capacity)
     return e->n_extra;
 }
 
+int vmx_set_mu_rule_box(vmx_engine* e, int32_t n, const int32_t* slots, const double* lo, const double* hi)
+{
+    REQUIRE(e && !e->finalized && n >= 0 && (n == 0 || (slots && lo && hi)), "vmx_set_mu_rule_box (before vmx_finalize)");
+    e->rule_slot.clear(); e->rule_lo.clear(); e->rule_hi.clear();
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(slots[i] >= 0 && lo[i] <= hi[i], "mu-rule box entry");
+        e->rule_slot.push_back(slots[i]); e->rule_lo.push_back(lo[i]); e->rule_hi.push_back(hi[i]);
+    }
+    return 0;
+}
+
 int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule)
 {
     REQUIRE(e && e->finalized, "vmx_set_mu_quadrature (after vmx_finalize)");
@@ -2520,7 +2627,7 @@ int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule)
     e->dev.k_node_max = e->mu_nodes_on ? e->k_node_max : 0.0;
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);      // (captured graphs hold the previous setting)
     e->graphs.clear();
-    e->quad_mat_dirty = true;       // the quadratic form's reference point is re-evaluated with the new rule
+    e->quad_lin_dirty = true;       // the reference point (x0', m0) is re-evaluated with the new rule; Q' and W do not depend on it
     return e->mu_nodes_on ? 1 : 0;
 }
 
@@ -2631,22 +2738,36 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     if (e->host_reduce_items > 0) {
         // the chain ended with the streaming products of the quadratic form: add up what their blocks left here
         // (fixed order), the constants and the priors - vega_interface.py:316, :423-446
+        // The wait is bounded by TIME (~200 us of spinning on the mapped words); when that runs out - a GPU shared with another
+        // process, a profiler serialising the launches, a slow first launch - the stream is drained and the words are read
+        // again: once the stream is empty they are guaranteed to be written, so only a sentinel that survives the drain is an error.
         double c = 0.0;
-        bool complete = true;
-        for (int q = 0; q < e->host_reduce_items && complete; ++q) {
-            const volatile uint64_t* slot = (const volatile uint64_t*)(e->pin_part + (size_t)q * 1024);
-            for (int i = 0; i < e->host_reduce_blocks[q] && complete; ++i) {
-                int64_t spin = 0;
-                while (slot[i] == VMX_PART_SENTINEL && spin < ((int64_t)1 << 28)) ++spin;
-                uint64_t bits = slot[i];
-                if (bits == VMX_PART_SENTINEL) { complete = false; break; }
-                double v; std::memcpy(&v, &bits, sizeof(double));
-                c += v;
-            }
-        }
+        bool complete = false;
         volatile int32_t* st_word = e->pin_status;
-        for (int64_t spin = 0; complete && *st_word == -1 && spin < ((int64_t)1 << 28); ++spin) {}
-        if (!complete || *st_word == -1) { e->host_reduce_items = 0; fail(-2, "single-walker chain: the device did not report back"); (void)vmx_sync(e); return -2; }
+        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+        for (int attempt = 0; attempt < 2 && !complete; ++attempt) {
+            if (attempt == 1) HIP_OK(hipStreamSynchronize(e->stream));
+            complete = true;
+            c = 0.0;
+            for (int q = 0; q < e->host_reduce_items && complete; ++q) {
+                const volatile uint64_t* slot = (const volatile uint64_t*)(e->pin_part + (size_t)q * 1024);
+                for (int i = 0; i < e->host_reduce_blocks[q] && complete; ++i) {
+                    int spin = 0;
+                    while (slot[i] == VMX_PART_SENTINEL && attempt == 0) {
+                        if ((++spin & 255) == 0 && std::chrono::steady_clock::now() > spin_until) break;
+                    }
+                    uint64_t bits = slot[i];
+                    if (bits == VMX_PART_SENTINEL) { complete = false; break; }
+                    double v; std::memcpy(&v, &bits, sizeof(double));
+                    c += v;
+                }
+            }
+            for (int spin = 0; complete && *st_word == -1 && attempt == 0;) {
+                if ((++spin & 255) == 0 && std::chrono::steady_clock::now() > spin_until) break;
+            }
+            if (*st_word == -1) complete = false;
+        }
+        if (!complete) { e->host_reduce_items = 0; return fail(-2, "single-walker chain: the device left a result slot unwritten after the stream drained"); }
         for (int q = 0; q < e->host_reduce_items; ++q) {
             const ItemHost* it = e->items[q];
             const int mock = (it->dev.mock_pool && e->h_mock_index[0] >= 0) ? e->h_mock_index[0] : -1;
@@ -2705,12 +2826,13 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
         // [0] the number of leading wavenumbers with a live P(k,mu) block in the last evaluation (the rest are exact zeros),
         // [1] the wavenumber up to which the mu sums take the node rule (0: plain loop), [2] nodes per wavenumber of that rule
         if (capacity < 3) { fail(-1, "invalid argument: capacity too small"); return -1; }
-        int32_t live[4] = {0, 0, 0, 0};
-        if (hipMemcpy(live, e->k_live.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }
+        int32_t live[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpy(live, e->k_live.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { fail(-2, "hipMemcpy"); return -2; }
         out[0] = live[0]; out[1] = e->dev.k_node_max; out[2] = e->mu_lo + e->mu_hi + e->n_extra;
         if (capacity >= 4) out[3] = live[1];
         if (capacity >= 5) out[4] = e->last_tab_level;
         if (capacity >= 7) { out[5] = live[2]; out[6] = live[3]; }
+        if (capacity >= 8) { out[7] = live[4]; return 8; }       // walkers that left the mu rule's box since vmx_finalize
         return capacity >= 7 ? 7 : capacity >= 5 ? 5 : capacity >= 4 ? 4 : 3;
     }
     else { fail(-1, "invalid argument: what"); return -1; }

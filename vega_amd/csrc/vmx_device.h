@@ -35,6 +35,7 @@
 #define VMX_MAX_BB 32        // broadband terms per item and position
 #define VMX_MAX_METALS 64
 #define VMX_MAX_QUAD_COEF 64 // additive post-distortion broadband coefficients the quadratic form of chi2 can carry
+#define VMX_MAX_GROUP 8      // independent products in one grouped launch (GemmGroup)
 
 enum {
     S_BIAS1 = 0, S_BB1, S_BIAS2, S_BB2,
@@ -44,7 +45,8 @@ enum {
     S_AQ1, S_AQ2, S_AKV, S_AAV, S_ABV, S_AKP,
     S_VD1, S_VD2,
     S_AP, S_AT, S_DRP, S_EV1A, S_EV1B, S_EV2A, S_EV2B,
-    S_RAD_S, S_RAD_A, S_RAD_L, S_RAD_D, S_RAD_IL, S_RAD_ID        // (IL, ID: reciprocals of the lifetime and decrease lengths)
+    S_RAD_S, S_RAD_A, S_RAD_L, S_RAD_D, S_RAD_IL, S_RAD_ID,       // (IL, ID: reciprocals of the lifetime and decrease lengths)
+    S_NO_RULE                   // != 0: this walker lies outside the box the mu node rule was validated on -> plain midpoint loop
 };
 
 static inline int vmx_pad(int n) { return (n + VMX_PAD - 1) / VMX_PAD * VMX_PAD; }
@@ -132,6 +134,9 @@ struct EngineDev {
     int32_t n_rows, n_extra, mu_lo, mu_hi;
     const double* node_w;       // [n_extra]
     double k_node_max;          // k tiles up to this wavenumber use the node rule (0: the midpoint sums everywhere)
+    // applicability guard of the node rule (vmx_set_mu_rule_box): a walker with theta[rule_slot[i]] outside
+    // [rule_lo[i], rule_hi[i]] - the box the rule is validated on, tests/test_mu_quadrature.py - takes the plain loop
+    const int32_t* rule_slot; const double* rule_lo; const double* rule_hi; int32_t n_rule;
     const double* k;            // [nkp]
     const double* pklin;        // [3][nkp]
     const double* delta2;       // [nkp]
@@ -189,8 +194,8 @@ struct EngineDev {
     double* scal;               // [B][n_pipe][VMX_NS]
     double* metal_bias;         // [B][3][n_metals_total]: bias product x multiplicity, beta1 + beta2, beta1 * beta2
     double beta_override; int32_t beta_override_on;      // set-up hook: betas of the bias-free metal pipelines
-    double* pl;                 // [n_ell][B*n_pipe][nkp]
-    double* coef;               // [n_ell][B*n_pipe][ncp]
+    double* pl;                 // [n_ell][n_active][B][nkp]   (pipeline-major columns: column = PipeDev::col * B + walker)
+    double* coef;               // [n_ell][n_active][B][ncp]
     double* xi;                 // per pipeline [B][n]
     double* xim;                // metal matrix products
     double* model;              // [B][model_size]
@@ -418,6 +423,17 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[S_RAD_S + i] = t[d.rad_slot[i]];
             s[S_RAD_IL] = 1.0 / s[S_RAD_L]; s[S_RAD_ID] = 1.0 / s[S_RAD_D];
+        }
+        {
+            // the node rule of the mu sums is trusted inside the parameter box it was validated on; outside (or NaN) the
+            // walker's P(k,mu) blocks run the reference's midpoint loop itself
+            bool outside = false;
+            for (int q = 0; q < D.n_rule; ++q) {
+                const double v = t[D.rule_slot[q]];
+                outside = outside || !(v >= D.rule_lo[q] && v <= D.rule_hi[q]);
+            }
+            s[S_NO_RULE] = outside ? 1.0 : 0.0;
+            if (outside && p == 0) atomicAdd(D.k_live + 4, 1);          // (a statistic: walkers that left the box, cumulative)
         }
         double* out = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
 #pragma unroll
@@ -1018,7 +1034,7 @@ __device__ __forceinline__ void w_members_store(const EngineDev& D, const PkGrou
         double damp = 1.0;
         if (dm.damping_scale > 0.0) damp = exp(-dm.damping_scale * dm.damping_scale * pow(k, (double)dm.damping_power) / 2.0);
         const double pk = damp * D.pklin[(size_t)dm.pk_lin_kind * D.nkp + i] * inv_nmu;
-        const size_t col = (size_t)b * D.n_active + D.pipes[pm].col;
+        const size_t col = (size_t)D.pipes[pm].col * B + b;
         D.pl[((size_t)0 * ncols + col) * D.nkp + i] = pk * mm[0];
         D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
         D.pl[((size_t)2 * ncols + col) * D.nkp + i] = pk * (39.375 * mm[2] - 33.75 * mm[1] + 3.375 * mm[0]);
@@ -1178,7 +1194,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;     // block-uniform: the mu loops contain barriers
     // the node rule (first mu_lo and last mu_hi midpoints plus the extra nodes) serves a tile whose wavenumbers are all
     // within its range or negligible (VMX_PK_NEGLIGIBLE); block-uniform
-    const bool node_mode = GENERIC ? false : (D.n_extra > 0 && variant != PKV_GENERIC &&
+    const bool node_mode = GENERIC ? false : (D.n_extra > 0 && variant != PKV_GENERIC && sc[S_NO_RULE] == 0.0 &&
                                               __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0);
     if (live_block && node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((int)(blockIdx.z + 1) * KT, D.nk));
     // the FFTLog product skips the wavenumbers past the last live block (their P_ell is exactly zero)
@@ -1277,7 +1293,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
             const int kind = D.pipes[pipe].d.pk_lin_kind;
             const double pk = damp * ((D.pk_direct && kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i]
                                                                                  : D.pklin[(size_t)kind * D.nkp + i]);
-            const size_t col = (size_t)b * D.n_active + D.pipes[pipe].col;
+            const size_t col = (size_t)D.pipes[pipe].col * B + b;
             for (int e = 0; e < D.n_ell; ++e) {
                 double sum = 0.0;
                 for (int qq = 0; qq < MS; ++qq) sum += s_red[(half * 4 + e) * 256 + (wb * MS + qq) * KT + kk];
@@ -1335,7 +1351,7 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
             if (b >= B) continue;
             for (int half = 0; half < 2; ++half)
                 for (int e = 0; e < D.n_ell; ++e)
-                    D.pl[((size_t)e * ncols + (size_t)b * D.n_active + (half ? G.col_q : G.col_s)) * D.nkp + i] = 0.0;
+                    D.pl[((size_t)e * ncols + (size_t)(half ? G.col_q : G.col_s) * B + b) * D.nkp + i] = 0.0;
         }
         return;
     }
@@ -1344,6 +1360,7 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
     const bool bad = kx[2 * D.nkp] != 0.0;
     double c01[NW], c11[NW], c02[NW], c12[NW], hb[NW], hbb[NW], fk[NW], Fq[NW], k2vd2[NW];
     bool ok[NW];
+    bool in_box = true;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         int b = blockIdx.x * NW + w;
@@ -1363,11 +1380,12 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
         fk[w] = -sc[S_HCD_L0] * k;
         Fq[w] = vmx_exp(fk[w] * dmu);
         k2vd2[w] = k2 * sc[S_VD2];
+        in_box = in_box && sc[S_NO_RULE] == 0.0;
     }
     if (threadIdx.x == 0) atomicMax(D.k_live, min((tile + 1) * KT, D.nk));
     // the node rule (first mu_lo and last mu_hi midpoints plus the extra nodes) serves a tile whose wavenumbers are all
-    // within its range or negligible (VMX_PK_NEGLIGIBLE)
-    const bool node_mode = D.n_extra > 0 && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
+    // within its range or negligible (VMX_PK_NEGLIGIBLE) - and whose walkers lie in the box the rule is validated on
+    const bool node_mode = D.n_extra > 0 && in_box && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
     if (node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((tile + 1) * KT, D.nk));
     const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
     {
@@ -1508,7 +1526,7 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
             const int kind = half ? G.kind_q : G.kind_s;
             const double pk = damp * ((D.pk_direct && kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i]
                                                                                  : D.pklin[(size_t)kind * D.nkp + i]);
-            const size_t col = (size_t)b * D.n_active + (half ? G.col_q : G.col_s);
+            const size_t col = (size_t)(half ? G.col_q : G.col_s) * B + b;
             for (int e = 0; e < D.n_ell; ++e) {
                 double sum = 0.0;
                 for (int qq = 0; qq < MS; ++qq) sum += s_red[(size_t)w * 8 * NT + (half * 4 + e) * NT + qq * KT + kk];
@@ -1559,6 +1577,7 @@ __global__ __launch_bounds__(256, 4) void k_pk_w(EngineDev D, const PkGroup* gro
     double e0[NW], e1[NW], k2vd1[NW], k2vd2[NW];
     bool noexp[NW];
     double e_max = -1e300;
+    bool in_box = true;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         int b = blockIdx.x * NW + w;
@@ -1569,10 +1588,11 @@ __global__ __launch_bounds__(256, 4) void k_pk_w(EngineDev D, const PkGroup* gro
         noexp[w] = (ga == 0.0) && (gb == 0.0);
         k2vd1[w] = k2 * sc[S_VD1]; k2vd2[w] = k2 * sc[S_VD2];
         e_max = fmax(e_max, e0[w] + fmax(e1[w], 0.0));
+        in_box = in_box && sc[S_NO_RULE] == 0.0;
     }
     const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;
     if (live_block && threadIdx.x == 0) atomicMax(D.k_live, min((tile + 1) * KT, D.nk));
-    const bool node_mode = D.n_extra > 0 && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
+    const bool node_mode = D.n_extra > 0 && in_box && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
     if (live_block && node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((tile + 1) * KT, D.nk));
     const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
     if (live_block) {
@@ -1694,7 +1714,7 @@ __global__ __launch_bounds__(256) void k_pk_poly(EngineDev D, const int32_t* pol
     const vmx_pipe_desc& d = D.pipes[p].d;
     const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
     const double inv_nmu = 1.0 / (double)D.n_mu;
-    const size_t ncols = (size_t)B * D.n_active, col = (size_t)b * D.n_active + D.pipes[p].col;
+    const size_t ncols = (size_t)B * D.n_active, col = (size_t)D.pipes[p].col * B + b;
     const double* mg0 = D.gk_mom + (size_t)(d.gk_table >= 0 ? d.gk_table : D.n_gk) * 6 * D.nkp;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(D.k_live, D.nk);     // no damping factor: every wavenumber is live
     for (int i = threadIdx.x; i < D.nk; i += 256) {
@@ -2003,19 +2023,26 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
     }
 }
 
-// chi2 from the contraction partials of the quadratic-form launch (GemmArgs::part): walker b of walker tile nt adds, in
-// block order, the two wave-row sums of every list block of its tile - block index (row * tn + nt) * 8 + xcd.  One wave per
-// walker; padding blocks never wrote their (zero-initialised) slots.
-__global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const double* part, int tn, int rows)
+// chi2 from the contraction partials of the quadratic-form launches (GemmArgs::part): walker b of walker tile nt adds, list
+// by list and in block order, the two wave-row sums of every list block of its tile - block index (row * tn + nt) * 8 + xcd.
+// One wave per walker; padding blocks never wrote their (zero-initialised) slots.  (One list covers every item, or - items
+// on forked streams - one list per item.)
+struct QuadParts { const double* part[VMX_MAX_GROUP]; int32_t rows[VMX_MAX_GROUP]; int32_t n; };
+__global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, QuadParts Q, int tn)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const int nt = b >> 6, nl = b & 63;
     double acc = 0.0;
-    for (int j = lane; j < rows * 8; j += 64) {
-        const size_t blk = ((size_t)(j >> 3) * tn + nt) * 8 + (j & 7);
-        const double* pp = part + (blk * 64 + nl) * 2;
-        acc += pp[0] + pp[1];
+    for (int l = 0; l < Q.n; ++l) {
+        const double* part = Q.part[l];
+        double sub = 0.0;
+        for (int j = lane; j < Q.rows[l] * 8; j += 64) {
+            const size_t blk = ((size_t)(j >> 3) * tn + nt) * 8 + (j & 7);
+            const double* pp = part + (blk * 64 + nl) * 2;
+            sub += pp[0] + pp[1];
+        }
+        acc += sub;
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane != 0) return;
@@ -2178,7 +2205,6 @@ __device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
 
 // Several independent products in one launch (the distortion products of all correlation items, then their C^-1
 // products): every tile of every problem is in flight at once, so the small problems fill the tail of the large one.
-#define VMX_MAX_GROUP 8
 struct GemmGroup {
     GemmArgs p[VMX_MAX_GROUP]; int32_t n; int32_t seq_end[VMX_MAX_GROUP];
     const GemmWork* work;       // non-null: list mode (gridDim.x entries)
@@ -2625,14 +2651,10 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
                     }
                     double out = fb == 0 ? tot[0] : fb == 1 ? tot[1] : fb == 2 ? tot[2] : tot[3];
                     const int m = c_m0 + wm + 16 * jg + c;
-#ifdef VMX_EXPERIMENT_NOLOAD
-                    sum = fma((double)m, 2.0 * out, sum);
-#else
                     if (m < g.M) {
                         if (first_seg) out -= g.lin_pool ? lin[m] : sL[wm + 16 * jg + c];
                         sum = fma(e_row[16 * jg], 2.0 * out, sum);
                     }
-#endif
                 }
                 // the 16 lanes of a row (same walker): total in every lane
                 sum += lane_xor<8>(sum); sum += lane_xor<4>(sum); sum += lane_xor<2>(sum); sum += lane_xor<1>(sum);
@@ -2907,7 +2929,7 @@ __device__ __forceinline__ double spline_legendre(const EngineDev& D, const Pipe
     const vmx_pipe_desc& d = P.d;
     const int n_ell = d.n_ell, single_ell = d.single_ell;
     const size_t ncols = (size_t)nB * D.n_active;
-    const size_t col = (size_t)b * D.n_active + (P.col >= 0 ? P.col : 0);
+    const size_t col = (size_t)(P.col >= 0 ? P.col : 0) * nB + b;       // pipeline-major: a pipeline's walkers are consecutive columns
     // knot index and taps of every multipole first (a multipole the pipeline does not have reads the taps of ell = 0
     // and is dropped), then the 16 coefficient loads in one go, then the arithmetic
     const double* cf[4];
@@ -3134,9 +3156,9 @@ __global__ __launch_bounds__(256) void k_poly_bins(EngineDev D, const int32_t* p
 
 // Items without metal terms, chi2-only small batches: the bins of the peak and the smooth component and the entry
 // x' - x0' of the quadratic form in one kernel (one launch less in a latency-bound chain).  grid = (bins, walkers, items).
-__global__ __launch_bounds__(256) void k_xi_assemble_quad(EngineDev D)
+__global__ __launch_bounds__(256) void k_xi_assemble_quad(EngineDev D, int item0)
 {
-    const ItemDev& it = D.items[blockIdx.z];
+    const ItemDev& it = D.items[item0 + blockIdx.z];
     const int b = blockIdx.y, nB = gridDim.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= it.nq_pad) return;

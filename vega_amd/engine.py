@@ -142,6 +142,7 @@ def load_library():
     lib.vmx_set_quadratic_form.argtypes = [C.c_void_p, dptr]
     lib.vmx_set_mu_quadrature.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_get_mu_nodes.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
+    lib.vmx_set_mu_rule_box.argtypes = [C.c_void_p, C.c_int32, iptr, dptr, dptr]
     lib.vmx_stream.argtypes = [C.c_void_p]
     lib.vmx_stream.restype = C.c_void_p
     lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
@@ -172,7 +173,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_mu_quadrature', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -679,7 +680,8 @@ class Engine:
                 dm = item.distortion
                 if hasattr(dm, 'tocsr') and dm.nnz < self.csr_threshold * dm.shape[0] * dm.shape[1]:
                     # the reference's own representation (scipy csr_array, vega/data.py:342-346), kept as is
-                    csr = dm.tocsr()
+                    csr = dm.tocsr().copy()
+                    csr.sum_duplicates()        # canonical form: sorted, one entry per (row, column)
                     csr.sort_indices()
                     ptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)
                     idx = np.ascontiguousarray(csr.indices, dtype=np.int32)
@@ -712,6 +714,15 @@ class Engine:
             self._check(lib.vmx_set_global_invcov(self._h, _dp(g), g.shape[0]))
         for pname, (mean, sigma) in prob.priors.items():
             self._check(lib.vmx_add_prior(self._h, low.need(pname), float(mean), float(sigma)))
+        # applicability guard of the mu node rule: the box it is validated on (mu_quadrature.rule_box)
+        from .mu_quadrature import rule_box
+        box = rule_box(low.names)
+        if box:
+            slots = np.array([low.slot[n] for n in box], dtype=np.int32)
+            lo = _f64([box[n][0] for n in box])
+            hi = _f64([box[n][1] for n in box])
+            self._check(lib.vmx_set_mu_rule_box(self._h, slots.size, _ip(slots), _dp(lo), _dp(hi)))
+        self.mu_rule_box = box
         self._check(lib.vmx_finalize(self._h, self.n_params, self.max_batch))
         self.model_size = self._check(lib.vmx_model_size(self._h))
         # chi2-only evaluations run as a static quadratic form around the configured parameter values when the
@@ -813,14 +824,16 @@ class Engine:
         n_cols = None
         for pid in range(self.n_pipelines):
             col = self.lib.vmx_pipeline_column(self._h, pid)
+            if -3 < col < 0:            # (-1 / -2: an error code; <= -3 encodes "no column" and the column count)
+                raise EngineError(self.lib.vmx_last_error().decode())
             if col < -2:
                 n_cols = -3 - col
                 continue
             out[pid] = col
         if n_cols is None:
             n_cols = len(out)
-        pl = self.debug_read(0, 0, 4 * B * n_cols * nkp).reshape(4, B, n_cols, nkp)
-        return {pid: np.ascontiguousarray(pl[:, :, col, :nk].transpose(1, 0, 2)) for pid, col in out.items()}
+        pl = self.debug_read(0, 0, 4 * B * n_cols * nkp).reshape(4, n_cols, B, nkp)      # pipeline-major columns
+        return {pid: np.ascontiguousarray(pl[:, col, :, :nk].transpose(1, 0, 2)) for pid, col in out.items()}
 
     def metal_xi(self, item_name, pair_index):
         """Correlation of one metal pair in the last evaluation (walker 0): after its metal matrix, before the

@@ -415,6 +415,32 @@ class VegaInterface:
             res = res + (coeff,)
         return res if len(res) > 1 else res[0]
 
+    def chi2_batch_device(self, theta, out=None):
+        """chi2 of walkers that are already in HBM: ``theta`` a CUDA float64 tensor [n, n_params] (column order
+        ``self.param_names``) on the engine's device -> CUDA tensor [n].  Nothing crosses PCIe: chunks of ``max_batch``
+        go through ``vmx_eval_device`` on the engine's stream, which is ordered after the caller's current torch stream
+        and before whatever that stream does next (events, no host synchronisation).  Failed walkers carry the
+        reference's 1e100 sentinel.  Frozen-metal pins are the caller's contract here (no host copy to check)."""
+        import torch
+        if not (theta.is_cuda and theta.dtype == torch.float64 and theta.dim() == 2 and theta.is_contiguous()
+                and theta.shape[1] == len(self.param_names)):
+            raise ValueError(f'theta: contiguous CUDA float64 tensor [n, {len(self.param_names)}]')
+        if not self._metals_frozen:
+            self.freeze_metals(theta[0].cpu().numpy())      # fast_metals: one walker plays the reference's first call
+        self._sync_monte_carlo()
+        eng = self.engine
+        n = theta.shape[0]
+        if out is None:
+            out = torch.empty(n, dtype=torch.float64, device=theta.device)
+        stream = torch.cuda.ExternalStream(eng.stream_handle(), device=theta.device)
+        stream.wait_event(torch.cuda.current_stream(theta.device).record_event())
+        mb = eng.max_batch
+        for lo in range(0, n, mb):
+            hi = min(lo + mb, n)
+            eng.eval_device(theta[lo:hi].data_ptr(), hi - lo, out[lo:hi].data_ptr())
+        torch.cuda.current_stream(theta.device).wait_event(stream.record_event())
+        return out
+
     def log_lik_batch(self, params_list):
         return self._log_norm() - 0.5 * self.chi2_batch(params_list)
 
@@ -469,9 +495,23 @@ class VegaInterface:
             raise ValueError('No Monte Carlo config provided: add a [monte carlo] section')
         control = self.main_config['control'] if 'control' in self.main_config else {}
         mc_params = dict(self.problem.mc_config['params'])
-        if control.get('mc_start_from_fit', None) is not None:
-            raise NotImplementedError('mc_start_from_fit (reading a previous fit file) is not supported')
-        if self.sample_params['limits']:
+        start_from_fit = control.get('mc_start_from_fit', None)
+        if start_from_fit is not None:
+            # reference vega_interface.py:465-472: the best-fit values of an existing fit file (its BESTFIT table:
+            # vega/postprocess/fit_results.py:47-53) under the [mc parameters]
+            from .tables import find_file, read_tables
+            print_func(f'Reading input fit {start_from_fit}')
+            bestfit = None
+            for table in read_tables(find_file(start_from_fit, self.problem.search_dirs)):
+                if str(table.header.get('EXTNAME', '')).strip().upper() == 'BESTFIT':
+                    bestfit = table
+            if bestfit is None:
+                raise ValueError(f'{start_from_fit}: no BESTFIT table')
+            fit_names = [n.decode() if isinstance(n, bytes) else str(n) for n in bestfit.data['names']]
+            fit_values = np.asarray(bestfit.data['values'], dtype=float).reshape(len(fit_names), -1)[:, 0]
+            mc_params = {**{n.strip(): float(v) for n, v in zip(fit_names, fit_values)}, **mc_params}
+            print_func(f'Set template parameters to {mc_params}.')
+        elif self.sample_params['limits']:
             print_func('Running initial fit')
             res = self.minimize()
             mc_params = {**res.as_dict(), **mc_params}
@@ -484,6 +524,40 @@ class VegaInterface:
         if getattr(control, 'getboolean', None) and control.getboolean('use_full_pk_for_mc', False):
             return self.compute_model(mc_params, direct_pk=self.fiducial['pk_full'])
         return self.compute_model(mc_params)
+
+    def initialize_monte_carlo(self, scale=None, print_func=print):
+        """One mock per correlation around the Monte-Carlo fiducial, installed as the data every following chi2 / fit
+        reads (reference VegaInterface.initialize_monte_carlo, vega/vega_interface.py:505-544).  The ONLY place that
+        reads ``[control] global_cov_rescale`` (:531-533) - ``run_monte_carlo`` passes its scale through unchanged, as
+        ``Analysis.run_monte_carlo`` -> ``create_global_monte_carlo(scale=None)`` does."""
+        from .montecarlo import MonteCarlo, item_scales
+        self.freeze_metals()
+        fiducial_model = self.get_fiducial_for_monte_carlo(print_func)
+        control = self.main_config['control']
+        if self.problem.mc_config is not None:
+            self.sample_params = self.problem.mc_config['sample']       # "Reset the minimizer" (:523-525)
+        forecast = control.getboolean('forecast', False)
+        seed = control.getint('mc_seed', 0)
+        if self._use_global_cov and scale is None and 'global_cov_rescale' in control:
+            scale = control.getfloat('global_cov_rescale')
+        self.analysis = MonteCarlo(self)
+        mocks = self.analysis.create_mocks(fiducial_model, 1, seed=seed, scale=scale, forecast=forecast,
+                                           reseed_per_item=True)
+        out = {}
+        scales = item_scales(self.problem, scale)
+        for name, pool in mocks.items():
+            view, item = self.data[name], self.problem.items[name]
+            view.masked_mc_mock = np.array(pool[0])
+            if not self._use_global_cov and item.cov is not None and scales[name] != 1.:
+                # reference data.py:717-719: the mock's covariance scale carries over to the fit (its log-determinant
+                # term as the reference writes it: log(scale) + log det C)
+                view.scaled_inv_masked_cov = item.chi2_matrix / scales[name]
+                view.scaled_log_cov_det = np.log(scales[name]) + item.log_cov_det
+            full = np.full(item.data_vec.size, np.nan)
+            full[item.data_mask] = pool[0]
+            out[name] = full
+        self.monte_carlo = True
+        return out
 
     def close(self):
         self.engine.close()

@@ -55,9 +55,12 @@ def _default_matmul(L, Z):
     return Z @ L.T
 
 
-def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecast=False, matmul=None):
+def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecast=False, matmul=None,
+                 reseed_per_item=False):
     """dict name -> [num_mocks, n_masked] masked mock data vectors of independent correlations, in the reference's
-    draw order.  ``matmul(L, Z) -> Z @ L.T`` (default: NumPy) applies the Cholesky factor to all draws of an item at
+    draw order.  ``reseed_per_item``: every item's draw starts from ``seed`` again - what
+    ``create_monte_carlo_sim(seed=seed)`` does when ``initialize_monte_carlo`` calls it (reference analysis.py:159-160 ->
+    data.py:735-736), as opposed to the one seeding of ``run_monte_carlo`` (analysis.py:246).  ``matmul(L, Z) -> Z @ L.T`` (default: NumPy) applies the Cholesky factor to all draws of an item at
     once - the driver passes the engine's product so that the only O(n^2) step per mock runs on the GPU."""
     if problem.global_cov is not None:
         raise ValueError('this problem has a global covariance: its mocks come from create_global_mocks')
@@ -84,6 +87,8 @@ def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecas
     draws = {name: np.empty((num_mocks, chol[name].shape[0])) for name in problem.items}
     for i in range(num_mocks):
         for name in problem.items:
+            if reseed_per_item:
+                np.random.seed(seed)
             draws[name][i] = np.random.randn(chol[name].shape[0])
     out = {}
     for name, item in problem.items.items():
@@ -168,22 +173,22 @@ class MonteCarlo:
         self._fixed = tuple(n for n in names if sp.get('fix', {}).get(n, False))
         return BatchedMinimizer(evaluate, names, start, errors, limits, tol=tol)
 
-    def create_mocks(self, fiducial_model, num_mocks=1, seed=0, scale=None, forecast=False):
+    def create_mocks(self, fiducial_model, num_mocks=1, seed=0, scale=None, forecast=False, reseed_per_item=False):
         """dict name -> [num_mocks, n_masked]: the reference's mocks for ``seed``, per item or - when the problem has a
         global covariance - split from the global draw (kept whole in ``mc_mocks['global']``)."""
         vega = self.vega
         prob = vega.problem
         if prob.global_cov is not None:
-            if scale is None and prob.main_config is not None and 'control' in prob.main_config:
-                # reference vega_interface.py:531-533
-                scale = prob.main_config['control'].getfloat('global_cov_rescale', None)
+            # (scale = None means 1 here, as in Analysis.create_global_monte_carlo: `[control] global_cov_rescale` is read by
+            # VegaInterface.initialize_monte_carlo only - reference vega_interface.py:531-533 - not by run_monte_carlo /
+            # bin/run_vega_mc_mpi.py)
             whole = create_global_mocks(prob, fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast,
                                         matmul=vega.engine.matmul_host)
             self.mc_mocks = {'global': whole}
             self.current_mc_mock = whole[-1]
             return split_global(prob, whole)
         mocks = create_mocks(prob, fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast,
-                             matmul=vega.engine.matmul_host)
+                             matmul=vega.engine.matmul_host, reseed_per_item=reseed_per_item)
         self.mc_mocks = mocks
         return mocks
 

@@ -45,3 +45,30 @@ def node_rule(n_mu=N_MU, lo=LO, hi=HI, **kw):
     kept = np.concatenate([np.arange(lo), np.arange(n_mu - hi, n_mu)])
     mu_x, w_x = extra_nodes(n_mu, lo, hi, **kw)
     return np.concatenate([(kept + 0.5) / n_mu, mu_x]), np.concatenate([np.ones(kept.size), w_x])
+
+
+# ---- applicability guard ---------------------------------------------------------------------------------------------
+# Parameters that shape P(k, mu) other than through polynomials in mu^2 (the Kaiser / HCD amplitudes, which the panels
+# integrate exactly): name or name prefix -> the interval the rule is validated on.  The limits are the reference's prior
+# limits (vega/parameters/default_values.txt, restated in vega_amd/defaults.py), widened where the tests go further
+# (tests/test_mu_quadrature.py draws over exactly this table, corners included).  A walker outside takes the plain
+# 1000-point loop (include/vegamx.h: vmx_set_mu_rule_box).
+RULE_BOX = {
+    'L0_hcd': (0.0, 40.0),
+    'sigmaNL_par': (0.0, 15.0), 'sigmaNL_per': (0.0, 15.0),
+    'par_sigma_smooth': (0.0, 10.0), 'per_sigma_smooth': (0.0, 10.0),
+    'sigma_velo_disp_gauss': (0.0, 15.0), 'sigma_velo_disp_lorentz': (0.0, 15.0),
+    'growth_rate': (0.0, 2.0),               # (sigmaNL_per follows from sigmaNL_par / (1 + f) when only one is given)
+    'dnl_arinyo_q1': (0.0, 2.0), 'dnl_arinyo_q2': (-1.0, 1.0), 'dnl_arinyo_kv': (0.1, 4.0), 'dnl_arinyo_av': (0.1, 1.0),
+    'dnl_arinyo_bv': (1.0, 2.0), 'dnl_arinyo_kp': (7.0, 40.0),
+}
+
+
+def rule_box(names):
+    """{parameter name: (lo, hi)} for the names of ``names`` the guard watches (exact name, or prefix + '_<tracer>')."""
+    out = {}
+    for name in names:
+        for key, limits in RULE_BOX.items():
+            if name == key or name.startswith(key + '_'):
+                out[name] = limits
+    return out
