@@ -41,6 +41,9 @@ def main():
     vega = VegaInterface(None, problem=build_problem('joint_metals'), max_batch=MAX_BATCH, device=0)
     theta = walkers(vega, n_walkers)
     host = chi2_sharded(vega.chi2_batch, theta)
+    # device-resident walkers: the caller vouches for what the host entry detects by itself - these walkers share their
+    # Arinyo / smoothing parameters (a violation would be flagged per walker), so both entries take the same kernels
+    vega.engine.set_constant_nl_hint(True, gaussian=True)
     dev = chi2_sharded(vega.chi2_batch_device, torch.from_numpy(theta).to('cuda:0'))
     np.save(out_dir / f'chi2_host_{rank}.npy', host)
     np.save(out_dir / f'chi2_device_{rank}.npy', dev.cpu().numpy())

@@ -205,11 +205,14 @@ struct vmx_engine {
     int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
     // work lists of the quadratic-form launches per batch size: entries, their count, per-row-tile slab counts
-    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg; DevBuf<double> part; int n_blocks = 0; int rows = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; int seg_len = 0; };
+    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg, queue, nt_off; DevBuf<double> part; int n_blocks = 0; int rows = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; int seg_len = 0; bool persistent = false; int n_entries = 0; };
     std::map<int, QuadList*> quad_lists;     // by number of walker tiles (+ 1e6 (item + 1) for the per-item lists of forked streams)
     bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
+    bool quad_persistent = true;     // VMX_NO_PERSISTENT: one block per list entry (equal-length segments) instead of the tape
+    int quad_blocks = 0;             // persistent blocks of the quadratic-form launch: 2 per CU
+    double quad_overhead = 4.0;      // cost of starting / finishing an entry, in K stages (VMX_QUAD_OVH)
     bool quad_fused_chi2 = true;     // VMX_NO_FUSED_CHI2: the list launch stores the product, k_chi2_quad contracts it
-    bool item_streams = true;        // VMX_NO_ITEM_STREAMS: the items of a large chi2-only batch share one stream (see run_items_forked)
+    bool item_streams = false;       // VMX_ITEM_STREAMS=1: the items of a large chi2-only batch on forked streams (see run_items_forked; measured slower)
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
     bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
@@ -229,6 +232,7 @@ struct vmx_engine {
     std::vector<int32_t> h_mock_index;
     int last_B = 0;
     bool last_full = false;          // the last evaluation ran the full chain (model and residuals are valid)
+    bool last_taps = true;           // ... wrote the per-pipeline bins (vmx_debug_read what = 1)
     // quadratic form of chi2: used when only chi2 is asked for (see vmx_set_quadratic_form)
     std::vector<double> theta_ref;
     bool quad_eligible = false, quad_mat_dirty = true, quad_lin_dirty = true, no_fuse = false;
@@ -1179,13 +1183,21 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
     if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
     if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
+    if (getenv("VMX_NO_PERSISTENT")) e->quad_persistent = false;
+    if (const char* v = getenv("VMX_QUAD_OVH")) e->quad_overhead = atof(v);
+    {
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+        e->quad_blocks = 2 * cus;
+        if (const char* v = getenv("VMX_QUAD_BLOCKS")) e->quad_blocks = std::max(8, atoi(v));
+    }
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
     if (getenv("VMX_NO_SMALL_TAB")) e->no_small_tab = true;
     if (getenv("VMX_NO_PK_W")) e->no_pk_w = true;
     if (getenv("VMX_NO_FFT_RING")) e->fft_ring = false;
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
-    if (getenv("VMX_NO_ITEM_STREAMS")) e->item_streams = false;
+    if (const char* v = getenv("VMX_ITEM_STREAMS")) e->item_streams = atoi(v) != 0;
     if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
     if (getenv("VMX_GRAPH_B1")) e->graph_b1 = true;
@@ -1663,6 +1675,92 @@ static vmx_engine::QuadList* quad_build_list(vmx_engine* e, int B, int L, int on
     return ql;
 }
 
+// Persistent form of the work list ("stream-K"): every (row tile, walker tile) K range of every item's half-triangle product
+// is laid on ONE tape - long rows first, the walker tiles of a row next to each other - and the tape is cut into as many
+// pieces of equal cost as there are resident blocks (2 per CU), cost = K stages + a fixed charge per entry (pipeline fill and
+// contraction epilogue, `quad_overhead` stages).  A piece boundary inside a K range splits it into two entries: the launch
+// has (ranges + blocks - 1) entries at most, every block the same work to a stage, and no last round - where the
+// equal-length segments of quad_build_list left 1024 blocks of unequal length for 512 slots.  Block p takes piece
+// (p % 8) * (blocks / 8) + p / 8: neighbouring pieces - the same or adjacent row tiles - share an XCD and its L2.
+// The cut is a pure function of (problem shapes, walker tiles, blocks): partial sums are grouped identically on every rank
+// and in every run.  Slots are numbered per walker tile in tape order; k_chi2_parts adds them in that order.
+static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item = -1)
+{
+    constexpr int BM = GEMM_BM, BK = GEMM_BK;
+    const int tn = (B + GEMM_BN - 1) / GEMM_BN;
+    const int P = e->quad_blocks / 8 * 8;
+    struct Range { int prob, mt, stages; };
+    std::vector<Range> ranges;
+    for (size_t q = 0; q < e->items.size(); ++q) {
+        if (only_item >= 0 && (int)q != only_item) continue;
+        const ItemDev& d = e->items[q]->dev;
+        const int tm = (d.nq + BM - 1) / BM, kmax_all = d.nq_pad / BK;
+        for (int mt = 0; mt < tm; ++mt) ranges.push_back({(int)q, mt, std::min(((mt + 1) * BM + BK - 1) / BK, kmax_all)});
+    }
+    std::stable_sort(ranges.begin(), ranges.end(), [](const Range& a, const Range& b) { return a.stages > b.stages; });
+    const double ovh = e->quad_overhead;
+    double stages_total = 0.0;
+    for (auto& r : ranges) stages_total += (double)r.stages * tn;
+    constexpr int MIN_SEG = 2;                  // no entry shorter than this many stages (but for ranges that short)
+    struct Entry { GemmWork w; int piece; };
+    std::vector<Entry> entries;
+    // every cut adds an entry and its fixed charge: the piece size follows from the number of entries, which follows from the
+    // piece size - three rounds of the fixed point are plenty (first guess: one cut per piece boundary)
+    size_t n_entries = ranges.size() * tn + P - 1;
+    for (int round = 0; round < 3; ++round) {
+        const double piece = (stages_total + ovh * (double)n_entries) / P;
+        entries.clear();
+        int pc = 0;
+        double room = piece;
+        for (auto& r : ranges)
+            for (int nt = 0; nt < tn; ++nt) {
+                int k = 0, left = r.stages;
+                while (left > 0) {
+                    if (pc < P - 1 && room < ovh + std::min(left, MIN_SEG)) { ++pc; room += piece; }
+                    int take = pc == P - 1 ? left : std::min(left, std::max(MIN_SEG, (int)(room - ovh)));
+                    if (left - take > 0 && left - take < MIN_SEG) take = left;          // no sliver behind the cut
+                    entries.push_back({GemmWork{r.prob, r.mt, nt, k * BK, (k + take) * BK, 0, 0, 0}, pc});
+                    room -= take + ovh;
+                    k += take; left -= take;
+                }
+            }
+        if (entries.size() == n_entries) break;
+        n_entries = entries.size();
+    }
+    // slots: per walker tile, tape order
+    std::vector<int32_t> nt_off(tn + 1, 0);
+    for (auto& en : entries) ++nt_off[en.w.nt + 1];
+    for (int nt = 0; nt < tn; ++nt) nt_off[nt + 1] += nt_off[nt];
+    {
+        std::vector<int32_t> next(nt_off.begin(), nt_off.end() - 1);
+        for (auto& en : entries) en.w.slot = next[en.w.nt]++;
+    }
+    // queues: block p <- piece (p % 8) * (P / 8) + p / 8
+    std::vector<int32_t> queue(P + 1, 0);
+    std::vector<std::vector<GemmWork>> by_piece(P);
+    for (auto& en : entries) by_piece[en.piece].push_back(en.w);
+    std::vector<GemmWork> work;
+    work.reserve(entries.size());
+    for (int p = 0; p < P; ++p) {
+        const int pcs = (p % 8) * (P / 8) + p / 8;
+        queue[p] = (int32_t)work.size();
+        for (auto& w : by_piece[pcs]) work.push_back(w);
+    }
+    queue[P] = (int32_t)work.size();
+    auto* ql = new vmx_engine::QuadList();
+    ql->persistent = true;
+    ql->n_blocks = P;
+    ql->n_entries = (int)work.size();
+    ql->rows = 0;
+    ql->seg_len = 0;
+    for (size_t q = 0; q < e->items.size() && q < 16; ++q) ql->nseg_off[q] = 0;
+    if (work.empty()) work.push_back(GemmWork{-1, 0, 0, 0, 0, 0, 0, 0});
+    if (ql->work.upload(work.data(), work.size()) || ql->queue.upload(queue.data(), queue.size()) ||
+        ql->nt_off.upload(nt_off.data(), nt_off.size()) || ql->nseg.alloc(1, true) ||
+        ql->part.alloc(std::max<size_t>(entries.size(), 1) * 128, true)) { delete ql; return nullptr; }
+    return ql;
+}
+
 // the launch itself; fills the slab description of the consumer (k_chi2_quad)
 static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, SlabInfo& qs)
 {
@@ -1683,6 +1781,7 @@ static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, Sla
         qs.qseg_off[q] = ql->nseg_off[q];
     }
     G.work = ql->work.p;
+    G.queue = ql->persistent ? ql->queue.p : nullptr;
     if (getenv("VMX_QUAD_TRACE")) {          // block timeline of this launch (debugging aid, written by vmx_sync as VMX_GEMM_TRACE is)
         e->gemm_trace_blocks = (size_t)ql->n_blocks;
         if (e->gemm_trace.n < 4 * e->gemm_trace_blocks) (void)e->gemm_trace.alloc(4 * e->gemm_trace_blocks, true);
@@ -1715,7 +1814,8 @@ static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B, int only_item 
     auto found = e->quad_lists.find(key);
     if (found != e->quad_lists.end()) return found->second;
     vmx_engine::QuadList* best = nullptr;
-    if (only_item >= 0) best = quad_build_list(e, B, quad_segment_length(tn), only_item);
+    if (e->quad_persistent && e->quad_fused_chi2 && GEMM44_THREADS == 256 && !e->quad_band_xcd) best = quad_build_tape(e, B, only_item);
+    else if (only_item >= 0) best = quad_build_list(e, B, quad_segment_length(tn), only_item);
     else if (!getenv("VMX_QUAD_AUTOTUNE")) best = quad_build_list(e, B, quad_segment_length(tn));
     else {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1805,10 +1905,14 @@ static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, i
 // chi2-only evaluation of a large batch whose every P(k,mu) group runs against level-2 tables (a sampler's batch): the
 // correlation items are independent from the prologue to the chi2 reduction - P(k,mu) group, FFTLog columns, bins +
 // quadratic-form entries, half-triangle product of one item touch nothing of another - so each item's chain goes on its own
-// stream (the reference walks `corr_items` one after the other: vega_interface.py:232-316).  A kernel of one item fills
-// the first / last block round of the other's (every kernel of a B = 256 chain spends 20 - 30 % of its launch there).  The
-// largest item is the critical path: main stream, enqueued first.  What is computed, and in which order it is summed, is
-// exactly the one-stream chain's: per-item work lists with the same segment length, partial sums added list by list.
+// stream (the reference walks `corr_items` one after the other: vega_interface.py:232-316), the largest item - the critical
+// path - on the main stream, enqueued first.  What is computed, and in which order it is summed, is exactly the one-stream
+// chain's: per-item work lists with the same segment length, partial sums added list by list.
+// MEASURED (round 3, B = 256, rocprofv3 kernel trace profiles/r03_item_streams_timeline.txt): the two items' kernels do run
+// side by side, but a step takes 0.396 ms against 0.383 - 0.40 on one stream: co-running kernels share the fp64 datapath,
+// every stage of the shorter chain still waits for its own predecessor, and two cross-queue dependencies per step cost more
+// than the block rounds they fill.  Hence OFF by default (VMX_ITEM_STREAMS=1 switches it on; tests/test_knobs_gpu.py keeps
+// it honest).  Independent BATCHES in flight are what recovers the idle rounds (vmx_set_lanes).
 static bool items_can_fork(vmx_engine* e, int B, int tab_mode, bool quad, bool xi_fused)
 {
     if (!e->item_streams || !quad || !xi_fused || B <= 8 || e->items.size() < 2 || e->items.size() > VMX_MAX_GROUP) return false;
@@ -1834,6 +1938,7 @@ static int run_items_forked(vmx_engine* e, const EngineDev& D, int B)
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return e->items[a]->dev.nq > e->items[b]->dev.nq; });
     HIP_OK(hipEventRecord(e->ev_fork, e->stream));
     QuadParts qp{};
+    e->last_taps = false;
     const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
     const int64_t ncols = (int64_t)B * e->n_active;
     for (size_t oi = 0; oi < order.size(); ++oi) {
@@ -1859,7 +1964,7 @@ static int run_items_forked(vmx_engine* e, const EngineDev& D, int B)
                        ncols * e->ncp, VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
         {
             ScopedTimer t(e, KC_XI);
-            hipLaunchKernelGGL(k_xi_assemble_quad, dim3((it->dev.nq_pad + 255) / 256, B, 1), dim3(256), 0, e->cur, D, q);
+            hipLaunchKernelGGL(k_xi_assemble_quad, dim3((it->dev.nq_pad + 255) / 256, B, 1), dim3(256), 0, e->cur, D, q, 0);
         }
         vmx_engine::QuadList* ql = quad_work_list(e, B, q);
         if (!ql) return -2;
@@ -1868,7 +1973,7 @@ static int run_items_forked(vmx_engine* e, const EngineDev& D, int B)
             SlabInfo qs{};
             quad_launch_list(e, ql, B, qs);
         }
-        qp.part[q] = ql->part.p; qp.rows[q] = ql->rows;       // (added in item order, whatever the launch order)
+        qp.part[q] = ql->part.p; qp.rows[q] = ql->rows; qp.nt_off[q] = ql->persistent ? ql->nt_off.p : nullptr;       // (added in item order, whatever the launch order)
         if (oi > 0) HIP_OK(hipEventRecord(e->ev_join[oi - 1], e->cur));
     }
     qp.n = (int)e->items.size();
@@ -2034,11 +2139,12 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
     // chi2-only small batches of items without metal terms: bins + quadratic-form entries in one kernel
     bool xi_fused = quad && (size_t)n_pipe == 2 * e->items.size();
     for (auto* it : e->items) if (!it->metals.empty() || it->dev.d.pipe_peak == it->dev.d.pipe_smooth) xi_fused = false;
+    e->last_taps = !(xi_fused && B > 8);
     if (xi_fused) {
         ScopedTimer t(e, KC_XI);
         int max_nq = 0;
         for (auto* it : e->items) max_nq = std::max(max_nq, (int)it->dev.nq_pad);
-        hipLaunchKernelGGL(k_xi_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, 0);
+        hipLaunchKernelGGL(k_xi_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, 0, B <= 8 ? 1 : 0);
     } else {
         ScopedTimer t(e, KC_XI);
         int max_n = 0;
@@ -2087,7 +2193,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                 // the launch left contraction partials instead of the product: a small kernel adds them up
                 ScopedTimer t(e, KC_CHI2);
                 QuadParts qp{};
-                qp.part[0] = ql->part.p; qp.rows[0] = ql->rows; qp.n = 1;
+                qp.part[0] = ql->part.p; qp.rows[0] = ql->rows; qp.nt_off[0] = ql->persistent ? ql->nt_off.p : nullptr; qp.n = 1;
                 hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, qp, (B + GEMM_BN - 1) / GEMM_BN);
                 HIP_OK(hipGetLastError());
                 e->last_B = B;
@@ -2813,6 +2919,7 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
     if (what == 0) { src = e->pl.p; count = (int64_t)VMX_MAX_ELL * B * e->n_active * e->nkp; }
     else if (what == 1) {
         if (index < 0 || index >= (int)e->pipes.size()) { fail(-1, "invalid argument: pipeline index"); return -1; }
+        if (!e->last_taps) { fail(-1, "the last evaluation (chi2 only, more than 8 walkers, no metal terms) did not store the per-pipeline bins: ask for a model"); return -1; }
         src = e->xi.p + e->pipes[index].xi_off; count = (int64_t)B * e->pipes[index].n_pad;
     } else if (what == 2) { src = e->coef.p; count = (int64_t)VMX_MAX_ELL * B * e->n_active * e->ncp; }
     else if (what == 3) {

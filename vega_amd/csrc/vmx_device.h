@@ -2027,7 +2027,8 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
 // by list and in block order, the two wave-row sums of every list block of its tile - block index (row * tn + nt) * 8 + xcd.
 // One wave per walker; padding blocks never wrote their (zero-initialised) slots.  (One list covers every item, or - items
 // on forked streams - one list per item.)
-struct QuadParts { const double* part[VMX_MAX_GROUP]; int32_t rows[VMX_MAX_GROUP]; int32_t n; };
+// (nt_off[l] non-null: list l is a persistent launch - its slots are numbered per walker tile, [nt_off[nt], nt_off[nt + 1]))
+struct QuadParts { const double* part[VMX_MAX_GROUP]; int32_t rows[VMX_MAX_GROUP]; const int32_t* nt_off[VMX_MAX_GROUP]; int32_t n; };
 __global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, QuadParts Q, int tn)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -2037,6 +2038,13 @@ __global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, QuadPart
     for (int l = 0; l < Q.n; ++l) {
         const double* part = Q.part[l];
         double sub = 0.0;
+        if (Q.nt_off[l]) {
+            const int s0 = Q.nt_off[l][nt], s1 = Q.nt_off[l][nt + 1];
+            for (int j = s0 + lane; j < s1; j += 64) {
+                const double* pp = part + ((size_t)j * 64 + nl) * 2;
+                sub += pp[0] + pp[1];
+            }
+        } else
         for (int j = lane; j < Q.rows[l] * 8; j += 64) {
             const size_t blk = ((size_t)(j >> 3) * tn + nt) * 8 + (j & 7);
             const double* pp = part + (blk * 64 + nl) * 2;
@@ -2160,7 +2168,11 @@ struct GemmArgs {
 // cutting every tile into segments of about equal length (host: quad_work_list) balances the launch where whole-problem
 // K splits cannot.  Blocks take entry blockIdx.x; the host orders the entries so that the segments of a row tile meet on
 // one XCD (block -> XCD is round-robin on the index).
-struct GemmWork { int32_t prob, mt, nt, kbeg, kend, slab; };
+struct GemmWork { int32_t prob, mt, nt, kbeg, kend, slab, slot, pad; };
+// Persistent form of a list launch (GemmGroup::queue): block p walks the entries queue[p] .. queue[p + 1] - 1 one after the
+// other (the first stage of the next entry is requested behind the epilogue of the current one), and the contraction
+// partials of entry w go to slot work[w].slot - numbered per walker tile in a canonical order, so that the consumer
+// (k_chi2_parts) adds them in an order that does not depend on which block computed what.
 
 // LDS reads as explicit ds_read_b64 (2 LDS cycles per wave, banks (a/4) mod 64): left to the compiler, pairs of them
 // are merged into ds_read2_b64, which costs twice the cycles and banks modulo 32.  The compiler does not count these
@@ -2208,6 +2220,7 @@ __device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
 struct GemmGroup {
     GemmArgs p[VMX_MAX_GROUP]; int32_t n; int32_t seq_end[VMX_MAX_GROUP];
     const GemmWork* work;       // non-null: list mode (gridDim.x entries)
+    const int32_t* queue;       // non-null (with work): persistent blocks, entries [queue[blockIdx.x], queue[blockIdx.x + 1])
     unsigned long long* trace;  // debugging aid (VMX_GEMM_TRACE): per block {start, first stage landed, K loop done, end} in 100 MHz ticks
 };
 
@@ -2425,10 +2438,13 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     __shared__ double sL[QUAD ? 2 * BM : 1];
 
     const bool list = G.work != nullptr;
+    const bool persist = QUAD && list && G.queue != nullptr;
     const unsigned long long t_start = G.trace ? wall_clock64() : 0ull;
     unsigned long long t_first = 0ull, t_loop = 0ull;
     GemmWork wk{};
-    if (list) { wk = G.work[blockIdx.x]; if (wk.prob < 0) return; }        // (padding entries of the list)
+    int w_first = blockIdx.x, w_count = 1;
+    if (persist) { w_first = G.queue[blockIdx.x]; w_count = G.queue[blockIdx.x + 1] - w_first; if (w_count <= 0) return; }
+    if (list) { wk = G.work[w_first]; if (wk.prob < 0) return; }        // (padding entries of the list)
     const int xcd = blockIdx.x & 7;
     int seq = blockIdx.x >> 3;
     int pi = 0;
@@ -2437,7 +2453,10 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         while (pi < G.n - 1 && seq >= G.seq_end[pi]) ++pi;
         if (pi > 0) seq -= G.seq_end[pi - 1];
     }
-    const GemmArgs& g = G.p[pi];
+    // (`g`: the problem of the current work entry - fixed for a block, except for a persistent block, whose entries may
+    // belong to different problems)
+    const GemmArgs* gp = &G.p[pi];
+#define g (*gp)
     const int split = list ? wk.slab : xcd % g.nsplit, group = xcd / g.nsplit, ngroups = 8 / g.nsplit;
     const int tm_eff = g.tri ? (g.tm + 1) / 2 : g.tm;
     // A problem with a row window spreads its WALKER tiles over the XCDs (XCD x takes nt = x, x + 8, ...): the live row tiles
@@ -2447,7 +2466,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     const int mt0 = list ? wk.mt : n_major ? seq / tnx : (seq / g.tn) * ngroups + group;
     const int nt = list ? wk.nt : n_major ? (seq % tnx) * 8 + xcd : seq % g.tn;
     if (!list && (mt0 >= tm_eff || nt >= g.tn)) return;
-    const int npass = (!list && g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
+    const int npass = persist ? w_count : (!list && g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
     const int batch = blockIdx.y;
     const char* A = (const char*)(g.A + batch * g.a_batch);
     const char* X = (const char*)(g.X + batch * g.x_batch);
@@ -2463,17 +2482,26 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     // DMA: lane l of a wave instruction brings row (l >> 4) of its 4-row group, LDS chunk l & 15 <- source chunk (l & 15) ^ (4 (l >> 4))
     const int drow = lane >> 4;
     const unsigned dchunk = (unsigned)(((lane & 15) ^ (4 * drow)) * 16);
-    const int n0 = nt * BN;
+    int n0 = nt * BN;
 
     // per-pass state: tile origin, K range, DMA source offsets (32-bit byte offsets from the scalar operand bases)
     int m0 = 0, kbeg = 0, kend = 0;
+    int slot = blockIdx.x;          // where the contraction partials of the current entry go (GemmArgs::part)
     bool skip = false;
     unsigned oa[NP], ox[NP];
     // (a windowed problem in walker-major order tiles its rows from the window's first row: 240 wanted rows are four tiles
     // wherever they sit, not five)
     const int m_base = n_major ? max(g.m_window[0], 0) : 0;
     auto setup = [&](int pass) {
-        const int mt = pass == 0 ? mt0 : g.tm - 1 - mt0;
+        if (persist) {
+            // the block's next entry: its problem, walker tile, row tile, K segment and output slot
+            wk = G.work[w_first + pass];
+            gp = &G.p[wk.prob];
+            A = (const char*)g.A; X = (const char*)g.X;
+            n0 = wk.nt * BN;
+            slot = wk.slot;
+        }
+        const int mt = persist ? wk.mt : pass == 0 ? mt0 : g.tm - 1 - mt0;
         m0 = m_base + mt * BM;
         if (list) { kbeg = wk.kbeg; kend = wk.kend; }
         else if (g.tri) {
@@ -2505,20 +2533,14 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     // the first stage of a pass is requested before the previous pass stores its results (a triangular problem has two
     // passes per block: the second one's pipeline fills behind the first one's epilogue)
     setup(0);
-    if constexpr (QUAD) {
-        if (list && g.part) {
-            if (wave == 0 && kbeg == 0 && !g.lin_pool) {
-                const unsigned loff = (unsigned)(m0 + 2 * lane < g.ldx ? (m0 + 2 * lane) * 8 : 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)g.lin + loff),
-                                                 (__attribute__((address_space(3))) void*)&sL[0], 16, 0, 0);
-            }
-        }
-    }
-    if (!skip && kbeg < kend) dma_stage(kbeg, 0);
+    int first_buf = 0;              // stage buffer of the pass's first K stage
+    if (!skip && kbeg < kend) dma_stage(kbeg, first_buf);
 
   for (int pass = 0; pass < npass; ++pass) {
-    const int c_m0 = m0, kbeg_c = kbeg, kend_c = kend;
+    const int c_m0 = m0, kbeg_c = kbeg, kend_c = kend, c_n0 = n0, c_slot = slot, c_first = first_buf;
     const bool c_skip = skip;
+    const GemmArgs* const c_gp = gp;            // (setup(pass + 1) moves gp / n0 / slot on before this pass's epilogue)
+    const char* const c_X = X;
 
     double acc[8][FJ];
 #pragma unroll
@@ -2530,8 +2552,16 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     if (!c_skip && kbeg_c < kend_c) {
         if constexpr (NBUF == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kbeg_c + BK < kend_c) dma_stage(kbeg_c + BK, 1);
+            __syncthreads();            // (every wave has left the previous pass's epilogue: sL and its E buffer are free)
+            if (kbeg_c + BK < kend_c) dma_stage(kbeg_c + BK, c_first ^ 1);
+            if constexpr (QUAD) {
+                // the linear term's row over this tile's rows (a tile's first K segment subtracts it in the epilogue)
+                if (list && g.part && wave == 0 && kbeg_c == 0 && !g.lin_pool) {
+                    const unsigned loff = (unsigned)(c_m0 + 2 * lane < g.ldx ? (c_m0 + 2 * lane) * 8 : 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)g.lin + loff),
+                                                     (__attribute__((address_space(3))) void*)&sL[0], 16, 0, 0);
+                }
+            }
         } else {
             // the ring starts full: stages 1 .. NBUF - 1 follow stage 0 at once; then wait for stage 0 alone
             int ahead = 0;
@@ -2542,11 +2572,11 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
             __syncthreads();
         }
         if (G.trace) t_first = wall_clock64();
-        lds_read_fragments<4 * BK * 8>(a0, fa + frag0);
-        lds_read_fragments<4 * BK * 8>(x0, fx + frag0);
+        lds_read_fragments<4 * BK * 8>(a0, fa + (unsigned)c_first * (BM * BK * 8) + frag0);
+        lds_read_fragments<4 * BK * 8>(x0, fx + (unsigned)c_first * (BM * BK * 8) + frag0);
         lds_wait(a0, x0);
     }
-    int buf = 0;
+    int buf = NBUF == 2 ? c_first : 0;
     int epi_buf = -1;
     for (int k0 = kbeg_c; k0 < (c_skip ? kbeg_c : kend_c); k0 += BK) {
         const int nbuf = NBUF == 2 ? buf ^ 1 : (buf + 1 == NBUF ? 0 : buf + 1);        // the next stage's buffer
@@ -2608,13 +2638,17 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     }
 
     if (G.trace) t_loop = wall_clock64();
-    if (pass + 1 < npass) {             // every wave is past the last barrier of the K loop: both buffers are free
+    if (pass + 1 < npass) {
+        // every wave is past the last barrier of the K loop: both buffers are free - but for the one that took the E tile of
+        // the contraction epilogue (the other one held the last K stage)
+        first_buf = (NBUF == 2 && epi_buf >= 0) ? epi_buf ^ 1 : 0;
         setup(pass + 1);
-        if (!skip && kbeg < kend) dma_stage(kbeg, 0);
+        if (!skip && kbeg < kend) dma_stage(kbeg, first_buf);
     }
     if (c_skip) continue;
     if constexpr (TAG == VMX_TAG_QUAD && NT == 256) {
-        if (list && g.part) {
+        const GemmArgs& cg = *c_gp;         // (this pass's problem)
+        if (list && cg.part) {
             // contraction epilogue (see GemmArgs::part): lane (r, c) of group jg holds D[n][m] for n = n0 + wn + 4 i + r,
             // m = c_m0 + wm + 16 jg + c after the rotations below
             const int c = lane & 15, r = lane >> 4;
@@ -2624,21 +2658,21 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
             if (epi_buf < 0) {              // an empty K range (never a tile's first segment): nothing was multiplied
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (c == 0) g.part[((size_t)blockIdx.x * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = 0.0;
+                    if (c == 0) cg.part[((size_t)c_slot * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = 0.0;
                 continue;
             }
             const double* sE0 = &sA[epi_buf][0];
             const double* sE1 = &sX[epi_buf][0];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int n = n0 + wn + 4 * i + r;
-                const int nc = n < g.N ? n : g.N - 1;
+                const int n = c_n0 + wn + 4 * i + r;
+                const int nc = n < cg.N ? n : cg.N - 1;
                 const int e_n = wn + 4 * i + r;                             // walker within the tile (block-half uniform per wave)
                 const double* e_row = (wn == 0 ? sE0 + e_n * BM : sE1 + (e_n - 32) * BM) + wm + c;     // + 16 jg: this lane's entries
-                const double* lin = g.lin;
-                if (first_seg && g.lin_pool) {          // per-walker data (mocks): the walker's own row of the linear term
-                    const int mock = g.lin_row[nc];
-                    lin += (size_t)(mock >= 0 ? 1 + mock : 0) * g.ldx;
+                const double* lin = cg.lin;
+                if (first_seg && cg.lin_pool) {          // per-walker data (mocks): the walker's own row of the linear term
+                    const int mock = cg.lin_row[nc];
+                    lin += (size_t)(mock >= 0 ? 1 + mock : 0) * cg.ldx;
                 }
                 double sum = 0.0;
 #pragma unroll
@@ -2651,14 +2685,14 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
                     }
                     double out = fb == 0 ? tot[0] : fb == 1 ? tot[1] : fb == 2 ? tot[2] : tot[3];
                     const int m = c_m0 + wm + 16 * jg + c;
-                    if (m < g.M) {
-                        if (first_seg) out -= g.lin_pool ? lin[m] : sL[wm + 16 * jg + c];
+                    if (m < cg.M) {
+                        if (first_seg) out -= cg.lin_pool ? lin[m] : sL[wm + 16 * jg + c];
                         sum = fma(e_row[16 * jg], 2.0 * out, sum);
                     }
                 }
                 // the 16 lanes of a row (same walker): total in every lane
                 sum += lane_xor<8>(sum); sum += lane_xor<4>(sum); sum += lane_xor<2>(sum); sum += lane_xor<1>(sum);
-                if (c == 0) g.part[((size_t)blockIdx.x * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = n < g.N ? sum : 0.0;
+                if (c == 0) cg.part[((size_t)c_slot * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = n < cg.N ? sum : 0.0;
             }
             continue;
         }
@@ -2686,6 +2720,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         unsigned long long* tr = G.trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
         tr[0] = t_start; tr[1] = t_first; tr[2] = t_loop; tr[3] = wall_clock64();
     }
+#undef g
 }
 
 // Distortion product with a CSR matrix (the reference keeps it as scipy csr_array: data.py:342-346, model.py:143-144):
@@ -3156,7 +3191,9 @@ __global__ __launch_bounds__(256) void k_poly_bins(EngineDev D, const int32_t* p
 
 // Items without metal terms, chi2-only small batches: the bins of the peak and the smooth component and the entry
 // x' - x0' of the quadratic form in one kernel (one launch less in a latency-bound chain).  grid = (bins, walkers, items).
-__global__ __launch_bounds__(256) void k_xi_assemble_quad(EngineDev D, int item0)
+// store_xi = 0: the per-pipeline bins (the stage taps behind vmx_debug_read) are not written - two of the three stores
+// per bin, 31 of the launch's 46 MB of writes at B = 256, which nothing reads in a chi2-only evaluation.
+__global__ __launch_bounds__(256) void k_xi_assemble_quad(EngineDev D, int item0, int store_xi)
 {
     const ItemDev& it = D.items[item0 + blockIdx.z];
     const int b = blockIdx.y, nB = gridDim.y;
@@ -3198,8 +3235,10 @@ __global__ __launch_bounds__(256) void k_xi_assemble_quad(EngineDev D, int item0
             xp = xi_bin_value<0>(D, it.d.pipe_peak, b, i, nB, oob_p);
         }
         if (oob_p || oob_s) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
-        D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + i] = xs;        // (the stage taps stay valid)
-        D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + i] = xp;
+        if (store_xi) {                                         // (the stage taps stay valid)
+            D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + i] = xs;
+            D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + i] = xp;
+        }
         // assemble_bin without metals (model.py:119-140,186)
         const double bao = t[it.d.bao_amp_slot];
         v = fma(bao, xp, xs);
