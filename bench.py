@@ -338,8 +338,9 @@ def main():
                     help='calibration + warm-up + timed steps only (the command the rocprofv3 summaries in profiles/ use)')
     ap.add_argument('--no-static-metals', action='store_true', help='keep every metal pair on its own pipeline')
     ap.add_argument('--force-dist', action='store_true', help='run the collective path even with one rank')
-    ap.add_argument('--lanes', type=int, default=1,
-                    help='independent engines per GPU; step i runs on lane i %% lanes, so consecutive steps overlap')
+    ap.add_argument('--lanes', type=int, default=2, choices=[1, 2],
+                    help='batches in flight inside the engine (vmx_set_lanes): with 2, consecutive steps alternate between two '
+                         'per-batch workspaces that share every static tensor, and overlap on the GPU')
     args = ap.parse_args()
 
     # stdout carries the one JSON line and nothing else: whatever libraries print there (RCCL's version banner when a
@@ -395,9 +396,7 @@ def main():
 
     dev = torch.device('cuda', local_rank)
     vegas = []
-    # the two-lane section below (two engines, consecutive steps overlapping) needs a second engine
-    n_engines = max(args.lanes, 1) if args.core_only or world > 1 else max(args.lanes, 2)
-    for _ in range(n_engines):
+    for _ in range(1):
         v = VegaInterface(None, problem=prob, max_batch=B, device=local_rank)
         v.freeze_metals()           # fast_metals workloads: the first evaluation (fiducial point) fills the metal caches
         if not args.no_static_metals:
@@ -408,8 +407,9 @@ def main():
         vegas.append(v)
     vega = vegas[0]
     eng = vega.engine
-    engines = [v.engine for v in vegas]
+    engines = [eng]
     L = max(args.lanes, 1)
+    eng.set_lanes(L)
 
     # distinct walker batches per step and per rank, resident in HBM before timing
     assert eng.names == low.names
@@ -420,26 +420,31 @@ def main():
                                                          seed=synthetic.SEED + 1000 * rank + i)
         pools.append(torch.from_numpy(th).to(dev))
     # two output / gather buffer pairs: the collective of step i runs on its own stream while step i + 1 computes
-    nslot = 2 * len(engines)
+    nslot = 4
     chi2_bufs = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(nslot)]
     gathered = [torch.zeros(world * B, dtype=torch.float64, device=dev) for _ in range(nslot)] if use_dist else None
-    eng_streams = [torch.cuda.ExternalStream(e.stream_handle(), device=dev) for e in engines]
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     comm_done = [None] * nslot
+    ext_streams = {}
+
+    def stream_of_last_eval():
+        h = eng.last_stream_handle()
+        if h not in ext_streams:
+            ext_streams[h] = torch.cuda.ExternalStream(h, device=dev)
+        return ext_streams[h]
 
     def sync_all():
         for e in engines:
             e.sync()
 
-    def step(i, lanes=L):
+    def step(i):
         slot = i % nslot
-        lane = i % lanes
         if use_dist and comm_done[slot] is not None:
-            eng_streams[lane].wait_event(comm_done[slot])   # the gather that last read this buffer pair has finished
-        engines[lane].eval_device(pools[i % n_pool].data_ptr(), B, chi2_bufs[slot].data_ptr())
+            comm_done[slot].synchronize()       # the gather that last read this buffer pair (four steps ago) has finished
+        eng.eval_device(pools[i % n_pool].data_ptr(), B, chi2_bufs[slot].data_ptr())
         if use_dist:
-            # one all_gather of chi2 per step, ordered after the evaluation by an event: no host synchronisation
-            comm_stream.wait_event(eng_streams[lane].record_event())
+            # one all_gather of chi2 per step, ordered after the evaluation by an event on the lane's stream
+            comm_stream.wait_event(stream_of_last_eval().record_event())
             with torch.cuda.stream(comm_stream):
                 dist.all_gather_into_tensor(gathered[slot], chi2_bufs[slot])
                 comm_done[slot] = comm_stream.record_event()
@@ -451,13 +456,13 @@ def main():
     for i in range(max(args.warmup, 3) * L):
         step(i)
     sync_all()
-    eng.set_profiling(True)
+    eng.set_profiling(True)         # (every class timed: the engine keeps one batch in flight - uncontended kernel durations)
     for i in range(3):
-        step(i * L)                 # lane 0 alone: uncontended kernel durations
+        step(i)
     eng.sync()
     eng.timings(reset=True)
     for i in range(5):
-        step(i * L)
+        step(i)
     eng.sync()
     breakdown = eng.timings(reset=True)
     dominant = max((k for k, v in breakdown.items() if v[1]), key=lambda k: breakdown[k][0])
@@ -486,24 +491,29 @@ def main():
     timings = eng.timings(reset=True)
     eng.set_profiling(False)
 
-    two_lanes = None
-    if len(engines) > L and not use_dist:
-        # Two engines on the same GPU, consecutive steps alternating between them: one lane's launch tails and small
-        # kernels are filled by the other's work.  Reported beside `value`, not as it: co-running kernels share the
-        # chip, so per-launch durations (and with them the roofline fraction above) are only clean with one lane.
-        nl = len(engines)
-        for i in range(2 * nl):
-            step(i, nl)
+    single_lane = None
+    if L > 1 and not use_dist:
+        # the same steps with ONE batch in flight (vmx_set_lanes(1)): what a caller gets whose next batch depends on this one's
+        # chi2.  With two lanes (`value`) consecutive batches overlap: one lane's launch tails and small kernels are filled
+        # by the other's work; co-running kernels share the chip, so per-launch durations (and with them the live roofline
+        # fraction) are only clean with one lane - the calibration pass above runs that way.
+        eng.set_lanes(1)
+        for i in range(4):
+            step(i)
         sync_all()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(i, nl)
+            step(i)
         sync_all()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        two_lanes = {'lanes': nl, 'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
-                     'note': f'{nl} independent engines per GPU, step i on lane i % {nl}, B={B} walkers per step'}
+        single_lane = {'lanes': 1, 'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
+                       'note': 'one batch in flight: step i + 1 is enqueued behind step i on the same workspace'}
+        eng.set_lanes(L)
+        for i in range(4):
+            step(i)
+        sync_all()
 
     pk_state = engines[0].debug_read(4, 0, 5)       # live wavenumbers, node-rule tiles and table level of the timed steps
     # the same K steps a few more times: `value` above is ONE region of K steps (the contract); the spread between regions
@@ -536,7 +546,7 @@ def main():
         return B * reps / (time.perf_counter() - t0)
 
     other_paths = None
-    if not use_dist and not args.core_only and L == 1:
+    if not use_dist and not args.core_only:
         # The other ways through the same engine, same workload, same B (none of them is `value`):
         #   general_walkers  walkers that also differ in Arinyo / smoothing / peak-broadening parameters (no tables)
         #   full_chain       the model is asked for (compute_model_batch): distortion + C^-1 products instead of Q'
@@ -583,15 +593,15 @@ def main():
         ref_chi2 = chi2_bufs[(args.steps - 1) % nslot].clone()
         if eng.set_mu_quadrature(False) is False:
             for i in range(3):
-                step(i, 1)
+                step(i)
             sync_all()
             t0 = time.perf_counter()
             for i in range(args.steps):
-                step(i, 1)
+                step(i)
             sync_all()
             dt = time.perf_counter() - t0
             loop_chi2 = chi2_bufs[(args.steps - 1) % nslot]
-            rel = float(((loop_chi2 - ref_chi2).abs() / ref_chi2.abs()).max()) if L == 1 else None
+            rel = float(((loop_chi2 - ref_chi2).abs() / ref_chi2.abs()).max())
             exact_mu = {'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
                         'max_rel_chi2_diff_vs_node_rule': rel,
                         'note': 'mu sums as the plain 1000-point loop (vmx_set_mu_quadrature(0)); `value` uses the '
@@ -682,7 +692,7 @@ def main():
             roofline['timing'] = 'HIP events on the launch stream, over the timed region'
             if L > 1:
                 # the lanes' kernels share the chip, so a launch timed live is slower than the same launch alone
-                roofline['timing'] += f' (lane 0 of {L}; the other lanes run concurrently)'
+                roofline['timing'] += f' (lane 0 of {L}; the other lane runs concurrently: `alone` = the calibration pass, one batch in flight)'
                 roofline['alone'] = {k: roofline_for(roof_class, kernels[roof_class]['ms_per_launch'])[k]
                                      for k in ('achieved', 'frac', 'ms_per_launch', 'frac_of_issue_ceiling')}
         roofline_other = []
@@ -710,10 +720,10 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': WORKLOAD_TEXT[args.workload].format(B=B, total=B * world),
-                       'batch_per_gpu': B, 'lanes_per_gpu': L, 'pipelines_per_eval': len(eng.pipe_index),
+                       'batch_per_gpu': B, 'batches_in_flight': L, 'pipelines_per_eval': len(eng.pipe_index),
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
-            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'distortion_csr': dist_csr, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'two_lanes': two_lanes, 'exact_mu_loop': exact_mu, 'regions': regions, 'other_paths': other_paths, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'distortion_csr': dist_csr, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'single_lane': single_lane, 'exact_mu_loop': exact_mu, 'regions': regions, 'other_paths': other_paths, 'cpu_baseline': cpu,
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
         }
         sys.stdout.flush()

@@ -340,6 +340,20 @@ int vmx_set_mu_rule_box(vmx_engine* e, int32_t n, const int32_t* slots, const do
  * (also when the buffers are NULL or too small, without writing). */
 int vmx_get_mu_nodes(vmx_engine* e, double* mu, double* w, int32_t capacity);
 
+/* Lanes.  lanes = 2: chi2-only vmx_eval_device calls (model == NULL, 64 walkers or more, the quadratic form in use)
+ * alternate between the engine's own per-batch workspace and a second one - a clone that BORROWS every static tensor
+ * (matrices, tables, operators; no copy) and owns its workspace, its per-batch tables and its stream - so that two
+ * independent batches are in flight and the kernels of one fill the partly idle first / last block rounds of the other's
+ * (an ensemble sampler's half-ensembles, Monte-Carlo realisations, nested-sampling threads; the reference's
+ * bin/run_vega_mc_mpi.py:54-65 gives every rank such independent work).  Per batch the arithmetic, and therefore every bit
+ * of chi2, is that of one lane.  A call returns once its kernels are enqueued, as before; vmx_sync waits for both lanes;
+ * vmx_last_stream is the stream of the last vmx_eval_device (to order a consumer after it with an event; vmx_stream stays
+ * the first lane's).  Any call that changes what an evaluation computes (data, mocks, covariances, parameter transform,
+ * quadrature, ...) or needs the first lane's buffers (vmx_eval, model output) waits for / retires the second lane - it is
+ * re-made on demand.  lanes = 1 (the default): one batch in flight. */
+int vmx_set_lanes(vmx_engine* e, int32_t lanes);
+void* vmx_last_stream(vmx_engine* e);
+
 /* chi2-only evaluations (model == NULL) as a static quadratic form.  Without a multiplicative post-distortion
  * broadband the model on the fitted bins is linear in x' = [pre-distortion vector ; additive post-distortion broadband
  * coefficients], model = S DM' x' (model.py:143-149), so

@@ -53,6 +53,11 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool borrowed = false;      // a copy of a DevBuf is a non-owning view (the second lane of an engine shares the static tensors)
+    DevBuf() = default;
+    DevBuf(const DevBuf& o) : p(o.p), n(o.n), borrowed(true) {}
+    DevBuf& operator=(const DevBuf& o) { if (this != &o) { release(); p = o.p; n = o.n; borrowed = true; } return *this; }
+    void forget() { if (borrowed) { p = nullptr; n = 0; borrowed = false; } }
     int alloc(size_t count, bool zero = true) {
         release();
         if (count == 0) count = 1;
@@ -71,7 +76,7 @@ struct DevBuf {
         if (err != hipSuccess) return fail(-2, std::string("hipMemcpy: ") + hipGetErrorString(err));
         return 0;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; n = 0; borrowed = false; }
     ~DevBuf() { release(); }
 };
 
@@ -135,6 +140,12 @@ struct vmx_engine {
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
     bool finalized = false;
+    // Second lane (vmx_set_lanes): a clone that borrows every static tensor and owns its per-batch workspace and stream;
+    // chi2-only device evaluations alternate between the two, so that independent batches overlap on the GPU.
+    vmx_engine* lane = nullptr;
+    int n_lanes = 1;
+    int64_t lane_calls = 0;
+    hipStream_t last_stream = nullptr;      // the stream the last vmx_eval_device ran on
 
     int nk = 0, nkp = 0, n_mu = 0;
     int n_rows = 0, n_extra = 0, mu_lo = 0, mu_hi = 0;     // node rule of the mu sums (vmx_set_mu_quadrature)
@@ -265,6 +276,7 @@ struct vmx_engine {
     int64_t launches[VMX_N_KERNELS] = {0};
 
     ~vmx_engine() {
+        if (lane) { (void)hipStreamSynchronize(lane->stream); delete lane; lane = nullptr; }
         for (auto* it : items) delete it;
         for (auto* m : metals) delete m;
         for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -283,6 +295,17 @@ struct vmx_engine {
 };
 
 namespace {
+
+// Anything that changes what an evaluation computes retires the second lane (it borrows the static tensors and copies
+// the host-side state at the moment it is made); the next two-lane evaluation makes a fresh one.
+static void drop_lane(vmx_engine* e)
+{
+    if (!e || !e->lane) return;
+    (void)hipStreamSynchronize(e->lane->stream);
+    delete e->lane;
+    e->lane = nullptr;
+}
+static void wait_lane(vmx_engine* e) { if (e && e->lane) (void)hipStreamSynchronize(e->lane->stream); }
 
 struct ScopedTimer {
     vmx_engine* e; int idx = -1;
@@ -933,6 +956,7 @@ int vmx_item_set_metal_basis(vmx_engine* e, int32_t item, int32_t index, const d
 int vmx_set_parameter_transform(vmx_engine* e, const double* scale, const double* shift)
 {
     REQUIRE(e && e->finalized, "vmx_set_parameter_transform");
+    drop_lane(e);
     REQUIRE((scale == nullptr) == (shift == nullptr), "scale and shift are given together");
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
@@ -949,6 +973,7 @@ int vmx_set_parameter_transform(vmx_engine* e, const double* scale, const double
 int vmx_set_metal_beta_override(vmx_engine* e, int32_t enabled, double beta)
 {
     REQUIRE(e && e->finalized, "vmx_set_metal_beta_override");
+    drop_lane(e);
     e->dev.beta_override_on = enabled ? 1 : 0;
     e->dev.beta_override = beta;
     // captured graphs hold the previous value: drop them
@@ -984,6 +1009,7 @@ int vmx_item_set_matrix(vmx_engine* e, int32_t item, int32_t kind, int32_t index
                         const double* dense)
 {
     REQUIRE(e && dense, "vmx_item_set_matrix");
+    drop_lane(e);
     REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
     HIP_OK(hipSetDevice(e->device));
     ItemHost* it = e->items[item];
@@ -1090,6 +1116,7 @@ int vmx_item_set_mask(vmx_engine* e, int32_t item, const int32_t* idx, int32_t n
 int vmx_item_set_data(vmx_engine* e, int32_t item, const double* masked_data, int32_t n_masked)
 {
     REQUIRE(e && masked_data, "vmx_item_set_data");
+    drop_lane(e);
     REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
     ItemHost* it = e->items[item];
     REQUIRE(it->has_mask && n_masked == it->dev.n_masked, "data size must match the mask");
@@ -1108,6 +1135,7 @@ int vmx_item_set_data(vmx_engine* e, int32_t item, const double* masked_data, in
 int vmx_item_set_mock_pool(vmx_engine* e, int32_t item, const double* pool, int32_t n_mocks, int32_t n_masked)
 {
     REQUIRE(e && e->finalized && pool, "vmx_item_set_mock_pool (after vmx_finalize)");
+    drop_lane(e);
     REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
     ItemHost* it = e->items[item];
     REQUIRE(n_mocks > 0 && n_masked == it->dev.n_masked, "mock pool shape");
@@ -1125,6 +1153,7 @@ int vmx_item_set_mock_pool(vmx_engine* e, int32_t item, const double* pool, int3
 int vmx_set_mock_index(vmx_engine* e, const int32_t* index, int32_t B)
 {
     REQUIRE(e && e->finalized, "vmx_set_mock_index (after vmx_finalize)");
+    drop_lane(e);
     REQUIRE(B >= 0 && B <= e->max_batch, "batch exceeds max_batch");
     HIP_OK(hipSetDevice(e->device));
     for (int b = 0; b < e->max_batch; ++b) e->h_mock_index[b] = -1;
@@ -1142,6 +1171,7 @@ int vmx_set_mock_index(vmx_engine* e, const int32_t* index, int32_t B)
 int vmx_set_global_invcov(vmx_engine* e, const double* invcov, int32_t n)
 {
     REQUIRE(e && invcov && n > 0, "vmx_set_global_invcov");
+    drop_lane(e);
     HIP_OK(hipSetDevice(e->device));
     const std::vector<double> half = half_form(invcov, n);
     if (e->finalized) {
@@ -1698,28 +1728,35 @@ static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item
         for (int mt = 0; mt < tm; ++mt) ranges.push_back({(int)q, mt, std::min(((mt + 1) * BM + BK - 1) / BK, kmax_all)});
     }
     std::stable_sort(ranges.begin(), ranges.end(), [](const Range& a, const Range& b) { return a.stages > b.stages; });
+    // Blocks work in lock-step groups of `gs` (4 when the walker tiles allow it): the members of a group walk the SAME
+    // entries, each for its own walker tile, side by side on one XCD - the matrix tile of an entry is then fetched from HBM
+    // once and found in that XCD's L2 by the other members (without the lock-step every block streams its own copy: 1 GB of
+    // L2 misses per launch, and the launch is bandwidth-bound).  The tape therefore carries (row tile, group of gs walker
+    // tiles) ranges and is cut into P / gs pieces.
+    const int gs = tn % 4 == 0 ? 4 : tn % 2 == 0 ? 2 : 1;
+    const int n_groups = tn / gs, n_pieces = P / gs;
     const double ovh = e->quad_overhead;
     double stages_total = 0.0;
-    for (auto& r : ranges) stages_total += (double)r.stages * tn;
+    for (auto& r : ranges) stages_total += (double)r.stages * n_groups;
     constexpr int MIN_SEG = 2;                  // no entry shorter than this many stages (but for ranges that short)
-    struct Entry { GemmWork w; int piece; };
+    struct Entry { GemmWork w; int piece; };    // (w.nt: the group's first walker tile)
     std::vector<Entry> entries;
     // every cut adds an entry and its fixed charge: the piece size follows from the number of entries, which follows from the
     // piece size - three rounds of the fixed point are plenty (first guess: one cut per piece boundary)
-    size_t n_entries = ranges.size() * tn + P - 1;
+    size_t n_entries = ranges.size() * n_groups + n_pieces - 1;
     for (int round = 0; round < 3; ++round) {
-        const double piece = (stages_total + ovh * (double)n_entries) / P;
+        const double piece = (stages_total + ovh * (double)n_entries) / n_pieces;
         entries.clear();
         int pc = 0;
         double room = piece;
         for (auto& r : ranges)
-            for (int nt = 0; nt < tn; ++nt) {
+            for (int grp = 0; grp < n_groups; ++grp) {
                 int k = 0, left = r.stages;
                 while (left > 0) {
-                    if (pc < P - 1 && room < ovh + std::min(left, MIN_SEG)) { ++pc; room += piece; }
-                    int take = pc == P - 1 ? left : std::min(left, std::max(MIN_SEG, (int)(room - ovh)));
+                    if (pc < n_pieces - 1 && room < ovh + std::min(left, MIN_SEG)) { ++pc; room += piece; }
+                    int take = pc == n_pieces - 1 ? left : std::min(left, std::max(MIN_SEG, (int)(room - ovh)));
                     if (left - take > 0 && left - take < MIN_SEG) take = left;          // no sliver behind the cut
-                    entries.push_back({GemmWork{r.prob, r.mt, nt, k * BK, (k + take) * BK, 0, 0, 0}, pc});
+                    entries.push_back({GemmWork{r.prob, r.mt, grp * gs, k * BK, (k + take) * BK, 0, 0, 0}, pc});
                     room -= take + ovh;
                     k += take; left -= take;
                 }
@@ -1727,37 +1764,48 @@ static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item
         if (entries.size() == n_entries) break;
         n_entries = entries.size();
     }
-    // slots: per walker tile, tape order
+    // slots: per walker tile, tape order (entry j of walker-tile group grp is slot (its rank within the group) of every member)
     std::vector<int32_t> nt_off(tn + 1, 0);
-    for (auto& en : entries) ++nt_off[en.w.nt + 1];
+    for (auto& en : entries)
+        for (int m = 0; m < gs; ++m) ++nt_off[en.w.nt + m + 1];
     for (int nt = 0; nt < tn; ++nt) nt_off[nt + 1] += nt_off[nt];
     {
-        std::vector<int32_t> next(nt_off.begin(), nt_off.end() - 1);
-        for (auto& en : entries) en.w.slot = next[en.w.nt]++;
+        std::vector<int32_t> next(n_groups, 0);
+        for (auto& en : entries) en.w.slot = next[en.w.nt / gs]++;          // (rank within the group: + nt_off[nt] per member)
     }
-    // queues: block p <- piece (p % 8) * (P / 8) + p / 8
+    // queues: block p = 8 i + xcd is member i / (P / 8 / gs) of the group that takes piece xcd * (P / 8 / gs) + i % (P / 8 / gs).
+    // (NOT member i % gs: the dispatcher fills a CU's two block slots with consecutive blocks of an XCD, and two members of one
+    // group reach their fill and epilogue phases together - the CU's MFMA pipes then idle through every one of them, ~10 us per
+    // entry.  Neighbours from different groups are out of phase and cover each other.)
     std::vector<int32_t> queue(P + 1, 0);
-    std::vector<std::vector<GemmWork>> by_piece(P);
+    std::vector<std::vector<GemmWork>> by_piece(n_pieces);
     for (auto& en : entries) by_piece[en.piece].push_back(en.w);
     std::vector<GemmWork> work;
-    work.reserve(entries.size());
+    work.reserve(entries.size() * gs);
     for (int p = 0; p < P; ++p) {
-        const int pcs = (p % 8) * (P / 8) + p / 8;
+        const int xcd = p % 8, i = p / 8, per_xcd = P / 8 / gs;
+        const int member = getenv("VMX_QUAD_INPHASE") ? i % gs : i / per_xcd;
+        const int pcs = xcd * per_xcd + (getenv("VMX_QUAD_INPHASE") ? i / gs : i % per_xcd);
         queue[p] = (int32_t)work.size();
-        for (auto& w : by_piece[pcs]) work.push_back(w);
+        for (auto w : by_piece[pcs]) {
+            w.nt += member;
+            w.slot += nt_off[w.nt];
+            work.push_back(w);
+        }
     }
     queue[P] = (int32_t)work.size();
+    const size_t n_slots = (size_t)nt_off[tn];
     auto* ql = new vmx_engine::QuadList();
     ql->persistent = true;
     ql->n_blocks = P;
-    ql->n_entries = (int)work.size();
+    ql->n_entries = (int)n_slots;
     ql->rows = 0;
     ql->seg_len = 0;
     for (size_t q = 0; q < e->items.size() && q < 16; ++q) ql->nseg_off[q] = 0;
     if (work.empty()) work.push_back(GemmWork{-1, 0, 0, 0, 0, 0, 0, 0});
     if (ql->work.upload(work.data(), work.size()) || ql->queue.upload(queue.data(), queue.size()) ||
         ql->nt_off.upload(nt_off.data(), nt_off.size()) || ql->nseg.alloc(1, true) ||
-        ql->part.alloc(std::max<size_t>(entries.size(), 1) * 128, true)) { delete ql; return nullptr; }
+        ql->part.alloc(std::max<size_t>(n_slots, 1) * 128, true)) { delete ql; return nullptr; }
     return ql;
 }
 
@@ -2469,6 +2517,7 @@ static int run_chain_cached(vmx_engine* e, int B, int tab_mode, bool zero_copy =
 // negative code; a reference point the model cannot be evaluated at switches the form off (the full chain then runs).
 static int quad_build(vmx_engine* e)
 {
+    drop_lane(e);           // (the tensors of the form are re-made: a second lane would keep views of the old ones)
     HIP_OK(hipStreamSynchronize(e->stream));
     const int P = e->n_params;
     std::vector<double> tref(e->theta_ref);
@@ -2608,6 +2657,81 @@ static int quad_ready(vmx_engine* e, bool* use, int B)
     return 0;
 }
 
+// The second lane of an engine: every static tensor borrowed (DevBuf copies are views), the per-batch workspace, the
+// tables of the batch's shared parameters, the work lists' partial-sum buffers, stream and events its own.
+static vmx_engine* clone_lane(vmx_engine* e)
+{
+    auto* L = new vmx_engine(*e);
+    // what the copy must not share (or free)
+    L->lane = nullptr; L->n_lanes = 1; L->lane_calls = 0;
+    L->stream = nullptr; L->cur = nullptr; L->aux.clear(); L->ev_join.clear(); L->ev_fork = nullptr;
+    L->graphs.clear(); L->quad_lists.clear(); L->spans.clear(); L->span_used = 0; L->profiling = false;
+    L->pin_theta = nullptr; L->pin_chi2 = nullptr; L->pin_status = nullptr; L->pin_done = nullptr; L->pin_part = nullptr;
+    L->dpin_theta = nullptr; L->dpin_chi2 = nullptr; L->dpin_status = nullptr; L->dpin_done = nullptr; L->dpin_part = nullptr;
+    L->host_key_valid = false; L->pending_key.clear();
+    std::map<MetalHost*, MetalHost*> metal_map;
+    L->metals.clear();
+    for (auto* m : e->metals) { auto* c = new MetalHost(*m); metal_map[m] = c; L->metals.push_back(c); }
+    L->items.clear();
+    for (auto* it : e->items) {
+        auto* c = new ItemHost(*it);
+        for (auto*& m : c->metals) m = metal_map[m];
+        L->items.push_back(c);
+    }
+    auto fail_out = [&]() -> vmx_engine* { delete L; return nullptr; };
+    if (hipStreamCreate(&L->stream) != hipSuccess) return fail_out();
+    L->cur = L->stream;
+    for (size_t q = 1; q < L->items.size(); ++q) {
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        if (hipStreamCreate(&st) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail_out();
+        L->aux.push_back(st); L->ev_join.push_back(ev);
+    }
+    if (hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming) != hipSuccess) return fail_out();
+    // per-batch workspace (sizes as in vmx_finalize)
+    const int Bm = e->max_batch, n_pipe = (int)e->pipes.size();
+    const size_t ncols = (size_t)Bm * n_pipe, acols = (size_t)Bm * std::max(e->n_active, 1);
+    for (auto* b : {&L->theta, &L->scal, &L->metal_bias, &L->pl, &L->coef, &L->xi, &L->xim, &L->model, &L->chi2, &L->xtab, &L->xtab_k,
+                    &L->xtab_key, &L->gres, &L->gz, &L->mv_part, &L->pk_direct}) b->forget();
+    for (auto* b : {&L->status, &L->k_live, &L->coef_win}) b->forget();
+    L->gemm_trace.forget(); L->pk_trace.forget(); L->d_items.forget();
+    if (L->theta.alloc((size_t)Bm * e->n_params) || L->scal.alloc(ncols * VMX_NS) ||
+        L->metal_bias.alloc((size_t)Bm * 3 * (e->metals.size() + 1)) ||
+        L->pl.alloc((size_t)VMX_MAX_ELL * acols * e->nkp) || L->coef.alloc((size_t)VMX_MAX_ELL * acols * e->ncp) ||
+        L->xi.alloc((size_t)e->xi_total) || L->xim.alloc((size_t)e->xim_total) ||
+        L->model.alloc((size_t)Bm * e->model_size) || L->chi2.alloc(Bm) || L->status.alloc(Bm) || L->k_live.alloc(8)) return fail_out();
+    {
+        const int32_t empty_window[2] = {0x7fffffff, -1};
+        if (L->coef_win.upload(empty_window, 2)) return fail_out();
+    }
+    if (e->n_xtab > 0) {
+        std::vector<double> key((size_t)e->n_xtab * VMX_XTAB_KEY + 1, std::nan(""));
+        if (L->xtab.alloc(((size_t)e->n_xtab * 2 * e->n_rows + 128) * e->nkp, true) || L->xtab_k.alloc((size_t)e->n_xtab * 4 * e->nkp, true) ||
+            L->xtab_key.upload(key.data(), key.size())) return fail_out();
+    }
+    if (e->gcinv.p && (L->gres.alloc((size_t)Bm * e->g_ld, true) || L->gz.alloc((size_t)e->slab_rows * e->g_ld, true))) return fail_out();
+    std::vector<ItemDev> items;
+    for (auto* it : L->items) {
+        ItemDev& d = it->dev;
+        for (auto* b : {&it->vec, &it->dist, &it->res, &it->z, &it->marg_out, &it->q_x, &it->q_z}) {
+            const size_t n = b->n;
+            b->forget();
+            if (n > 0 && b != &it->marg_out && b->alloc(n, true)) return fail_out();
+        }
+        d.vec = it->vec.p; d.dist = it->dist.p; d.res = it->res.p; d.z = it->z.p; d.q_x = it->q_x.p; d.q_z = it->q_z.p;
+        items.push_back(d);
+    }
+    if (L->d_items.upload(items.data(), items.size())) return fail_out();
+    EngineDev& D = L->dev;
+    D.xtab = L->xtab.p; D.xtab_key = L->xtab_key.p; D.xtab_k = L->xtab_k.p;
+    D.items = L->d_items.p;
+    D.theta = L->theta.p; D.scal = L->scal.p; D.metal_bias = L->metal_bias.p; D.pl = L->pl.p; D.coef = L->coef.p;
+    D.xi = L->xi.p; D.xim = L->xim.p; D.model = L->model.p; D.chi2 = L->chi2.p; D.status = L->status.p; D.k_live = L->k_live.p;
+    D.coef_win = L->coef_win.p; D.pk_trace = nullptr; D.gres = L->gres.p; D.gz = L->gz.p; D.pk_direct = nullptr;
+    L->direct = false;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail_out();
+    return L;
+}
+
 int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2, double* d_model,
                     int32_t* d_status)
 {
@@ -2617,6 +2741,25 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     e->host_key_valid = false;          // (device-resident walkers may rebuild the tables: the host no longer knows their key)
     bool quad = false;
     if (!d_model && quad_ready(e, &quad, B)) return -2;
+    e->last_stream = e->stream;
+    // two lanes: independent chi2-only batches alternate between this engine's workspace and its clone's, each on its own
+    // stream - the kernels of one batch fill the first and last block rounds of the other's (every kernel of a B = 256
+    // chain spends 20 - 30 % of its launch there).  Anything else waits for the second lane first.
+    const bool two_lanes = e->n_lanes > 1 && quad && !d_model && e->blind_scale.empty() && B >= 64 && !e->direct &&
+                           !(e->profiling && e->prof_mask == 0xffffffffu);
+    if (!two_lanes) wait_lane(e);
+    else if ((e->lane_calls++ & 1) == 1) {
+        if (!e->lane && !(e->lane = clone_lane(e))) return fail(-2, "could not create the second lane");
+        vmx_engine* L = e->lane;
+        L->const_hint = e->const_hint;
+        bool lq = false;
+        if (quad_ready(L, &lq, B)) return -2;       // (its work lists: the tensors are the borrowed ones)
+        if (!lq) return fail(-2, "the second lane cannot take the quadratic form");
+        const int tab = (B >= 16 && L->n_xtab > 0) ? L->const_hint : 0;
+        if (run_chain(L, B, tab, false, d_theta, d_chi2, d_status, true)) return -2;
+        e->last_stream = L->stream;
+        return 0;
+    }
     if (!e->blind_scale.empty()) {
         // parameter-level blinding: the walkers are transformed in the engine's own copy
         HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
@@ -2641,10 +2784,22 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
 }
 
 void* vmx_stream(vmx_engine* e) { return e ? (void*)e->stream : nullptr; }
+void* vmx_last_stream(vmx_engine* e) { return e ? (void*)(e->last_stream ? e->last_stream : e->stream) : nullptr; }
+
+int vmx_set_lanes(vmx_engine* e, int32_t lanes)
+{
+    REQUIRE(e && e->finalized && (lanes == 1 || lanes == 2), "vmx_set_lanes: 1 or 2 (after vmx_finalize)");
+    HIP_OK(hipSetDevice(e->device));
+    if (lanes == 1) drop_lane(e);
+    e->n_lanes = lanes;
+    e->lane_calls = 0;
+    return 0;
+}
 
 int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk)
 {
     REQUIRE(e && e->finalized, "vmx_set_direct_pk");
+    drop_lane(e);
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     if (!pk) { e->direct = false; e->dev.pk_direct = nullptr; return 0; }
@@ -2660,6 +2815,7 @@ int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk)
 int vmx_set_linear_spectra(vmx_engine* e, const double* pk_peak, const double* pk_smooth, const double* pk_full, int32_t nk)
 {
     REQUIRE(e && e->finalized && pk_peak && pk_smooth && pk_full, "vmx_set_linear_spectra (after vmx_finalize)");
+    drop_lane(e);
     REQUIRE(nk == e->nk, "linear spectra must live on the template's k grid");
     for (auto& p : e->pipes) REQUIRE(!p.odd_rel && !p.odd_asy, "the odd-multipole terms hold static splines of the template's spectra");
     HIP_OK(hipSetDevice(e->device));
@@ -2685,6 +2841,7 @@ int vmx_item_set_marg_matrix(vmx_engine* e, int32_t item, const double* m, int32
 int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B)
 {
     REQUIRE(e && e->finalized && out, "vmx_marg_coeff");
+    wait_lane(e);
     REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
     ItemHost* it = e->items[item];
     REQUIRE(it->n_templates > 0, "no marginalisation matrix was set for this item");
@@ -2727,6 +2884,7 @@ int vmx_set_mu_rule_box(vmx_engine* e, int32_t n, const int32_t* slots, const do
 int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule)
 {
     REQUIRE(e && e->finalized, "vmx_set_mu_quadrature (after vmx_finalize)");
+    drop_lane(e);
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     e->mu_nodes_on = node_rule != 0 && e->n_extra > 0;
@@ -2740,6 +2898,7 @@ int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule)
 int vmx_set_quadratic_form(vmx_engine* e, const double* theta_ref)
 {
     REQUIRE(e && e->finalized, "vmx_set_quadratic_form (after vmx_finalize)");
+    drop_lane(e);
     e->theta_ref.clear();
     if (theta_ref) e->theta_ref.assign(theta_ref, theta_ref + e->n_params);
     e->quad_mat_dirty = true;       // (a new reference point: everything is rebuilt at the next chi2-only evaluation)
@@ -2759,6 +2918,7 @@ int vmx_sync(vmx_engine* e)
     REQUIRE(e, "vmx_sync");
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->lane) HIP_OK(hipStreamSynchronize(e->lane->stream));
     if (e->profiling) collect_spans(e);
     if (e->gemm_trace.p && e->gemm_trace_blocks && (getenv("VMX_GEMM_TRACE") || getenv("VMX_QUAD_TRACE"))) {
         std::vector<unsigned long long> h(4 * e->gemm_trace_blocks);
@@ -2777,6 +2937,7 @@ int vmx_sync(vmx_engine* e)
 int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double* model, int32_t* status)
 {
     REQUIRE(e && e->finalized && theta, "vmx_eval");
+    wait_lane(e);
     REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
     const auto t_begin = std::chrono::steady_clock::now();
     HIP_OK(hipSetDevice(e->device));
@@ -2914,6 +3075,7 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
 {
     if (!e || !e->finalized || !out || e->last_B <= 0) { fail(-1, "invalid argument: vmx_debug_read"); return -1; }
     if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) { fail(-2, "hip sync"); return -2; }
+    wait_lane(e);
     const int B = e->last_B;
     const double* src = nullptr; int64_t count = 0;
     if (what == 0) { src = e->pl.p; count = (int64_t)VMX_MAX_ELL * B * e->n_active * e->nkp; }
@@ -2952,6 +3114,7 @@ int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t co
                       double* d_y)
 {
     REQUIRE(e && d_A && d_x && d_y, "vmx_matvec_device");
+    wait_lane(e);
     REQUIRE(rows > 0 && cols > 0 && cols % VMX_PAD == 0, "cols (leading dimension) must be a multiple of 32, zero padded");
     REQUIRE(B > 0, "vmx_matvec_device: B > 0");
     HIP_OK(hipSetDevice(e->device));
@@ -2975,6 +3138,7 @@ int vmx_matvec_device(vmx_engine* e, const double* d_A, int32_t rows, int32_t co
 int vmx_matmul_host(vmx_engine* e, const double* A, int32_t rows, int32_t cols, const double* X, int32_t B, double* Y)
 {
     REQUIRE(e && A && X && Y && rows > 0 && cols > 0 && B > 0, "vmx_matmul_host");
+    wait_lane(e);
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     const int ld = vmx_pad(cols), ldy = vmx_pad(rows);
@@ -2990,6 +3154,7 @@ int vmx_matmul_host(vmx_engine* e, const double* A, int32_t rows, int32_t cols, 
 int vmx_set_profiling(vmx_engine* e, int32_t enabled)
 {
     REQUIRE(e, "vmx_set_profiling");
+    wait_lane(e);
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     if (e->profiling) collect_spans(e);
@@ -3008,6 +3173,7 @@ int vmx_set_profiling(vmx_engine* e, int32_t enabled)
 int vmx_set_profiling_mask(vmx_engine* e, uint32_t kernel_class_mask)
 {
     REQUIRE(e, "vmx_set_profiling_mask");
+    wait_lane(e);
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     if (e->profiling) collect_spans(e);
@@ -3018,6 +3184,7 @@ int vmx_set_profiling_mask(vmx_engine* e, uint32_t kernel_class_mask)
 int vmx_get_timings(vmx_engine* e, double* ms, int64_t* launches, int32_t reset)
 {
     REQUIRE(e && ms && launches, "vmx_get_timings");
+    wait_lane(e);
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
     collect_spans(e);

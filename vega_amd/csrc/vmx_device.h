@@ -2453,10 +2453,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         while (pi < G.n - 1 && seq >= G.seq_end[pi]) ++pi;
         if (pi > 0) seq -= G.seq_end[pi - 1];
     }
-    // (`g`: the problem of the current work entry - fixed for a block, except for a persistent block, whose entries may
-    // belong to different problems)
-    const GemmArgs* gp = &G.p[pi];
-#define g (*gp)
+    const GemmArgs& g = G.p[pi];
     const int split = list ? wk.slab : xcd % g.nsplit, group = xcd / g.nsplit, ngroups = 8 / g.nsplit;
     const int tm_eff = g.tri ? (g.tm + 1) / 2 : g.tm;
     // A problem with a row window spreads its WALKER tiles over the XCDs (XCD x takes nt = x, x + 8, ...): the live row tiles
@@ -2471,6 +2468,13 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     const char* A = (const char*)(g.A + batch * g.a_batch);
     const char* X = (const char*)(g.X + batch * g.x_batch);
     double* Dp = g.D + batch * g.d_batch + split * g.d_slab;
+    // what the K loop and the contraction epilogue read of the current entry's problem: scalars, so that a persistent block
+    // (whose entries may belong to different problems) reloads a dozen values per entry - a pointer into the kernel
+    // arguments that moves would send the whole GemmGroup to scratch memory
+    int p_M = g.M, p_N = g.N, p_lda = g.lda, p_ldx = g.ldx, p_lin_pool = g.lin_pool;
+    double* p_part = g.part;
+    const double* p_lin = g.lin;
+    const int32_t* p_lin_row = g.lin_row;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2496,8 +2500,10 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         if (persist) {
             // the block's next entry: its problem, walker tile, row tile, K segment and output slot
             wk = G.work[w_first + pass];
-            gp = &G.p[wk.prob];
-            A = (const char*)g.A; X = (const char*)g.X;
+            const GemmArgs& q = G.p[__builtin_amdgcn_readfirstlane(wk.prob)];
+            A = (const char*)q.A; X = (const char*)q.X;
+            p_M = q.M; p_N = q.N; p_lda = q.lda; p_ldx = q.ldx; p_lin_pool = q.lin_pool;
+            p_part = q.part; p_lin = q.lin; p_lin_row = q.lin_row;
             n0 = wk.nt * BN;
             slot = wk.slot;
         }
@@ -2515,10 +2521,10 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         skip = g.m_window && (m0 + BM <= g.m_window[0] || m0 > g.m_window[1]);      // block-uniform
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            int r = m0 + (p * NW + wave) * 4 + drow; if (r >= g.M) r = g.M - 1;
-            oa[p] = (unsigned)(r * g.lda) * 8u + dchunk;
-            r = n0 + (p * NW + wave) * 4 + drow; if (r >= g.N) r = g.N - 1;
-            ox[p] = (unsigned)(r * g.ldx) * 8u + dchunk;
+            int r = m0 + (p * NW + wave) * 4 + drow; if (r >= p_M) r = p_M - 1;
+            oa[p] = (unsigned)(r * p_lda) * 8u + dchunk;
+            r = n0 + (p * NW + wave) * 4 + drow; if (r >= p_N) r = p_N - 1;
+            ox[p] = (unsigned)(r * p_ldx) * 8u + dchunk;
         }
     };
     auto dma_stage = [&](int k, int buf) {
@@ -2537,10 +2543,13 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     if (!skip && kbeg < kend) dma_stage(kbeg, first_buf);
 
   for (int pass = 0; pass < npass; ++pass) {
+    // (setup(pass + 1) moves the entry's values on before this pass's epilogue: the epilogue reads these copies)
     const int c_m0 = m0, kbeg_c = kbeg, kend_c = kend, c_n0 = n0, c_slot = slot, c_first = first_buf;
+    const int c_M = p_M, c_N = p_N, c_ldx = p_ldx, c_lin_pool = p_lin_pool;
+    double* const c_part = p_part;
+    const double* const c_lin = p_lin;
+    const int32_t* const c_lin_row = p_lin_row;
     const bool c_skip = skip;
-    const GemmArgs* const c_gp = gp;            // (setup(pass + 1) moves gp / n0 / slot on before this pass's epilogue)
-    const char* const c_X = X;
 
     double acc[8][FJ];
 #pragma unroll
@@ -2556,9 +2565,9 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
             if (kbeg_c + BK < kend_c) dma_stage(kbeg_c + BK, c_first ^ 1);
             if constexpr (QUAD) {
                 // the linear term's row over this tile's rows (a tile's first K segment subtracts it in the epilogue)
-                if (list && g.part && wave == 0 && kbeg_c == 0 && !g.lin_pool) {
-                    const unsigned loff = (unsigned)(c_m0 + 2 * lane < g.ldx ? (c_m0 + 2 * lane) * 8 : 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)g.lin + loff),
+                if (list && c_part && wave == 0 && kbeg_c == 0 && !c_lin_pool) {
+                    const unsigned loff = (unsigned)(c_m0 + 2 * lane < c_ldx ? (c_m0 + 2 * lane) * 8 : 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)c_lin + loff),
                                                      (__attribute__((address_space(3))) void*)&sL[0], 16, 0, 0);
                 }
             }
@@ -2605,18 +2614,18 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         // second half: DMA of stage s + NBUF into the buffer just released, MFMAs on f1(s) with the reads of f0(s + 1) between them
         if (k0 + NBUF * BK < kend_c) dma_stage(k0 + NBUF * BK, buf);
         else if constexpr (QUAD) {
-            if (epi_buf < 0 && list && g.part) {
+            if (epi_buf < 0 && list && c_part) {
                 // no further stage: this buffer stays free.  It takes E[n][m] = X[n0 + n][m0 + m] for the contraction epilogue
                 // - walkers 0..31 in the A half, 32..63 in the X half; a wave instruction brings two rows (lane l: row l >> 5,
                 // chunk l & 31), chunks past the row's padded length are redirected to its start (never used)
                 epi_buf = buf;
-                const unsigned coff = (unsigned)(c_m0 + 2 * (lane & 31) < g.ldx ? (c_m0 + 2 * (lane & 31)) * 8 : 0);
+                const unsigned coff = (unsigned)(c_m0 + 2 * (lane & 31) < c_ldx ? (c_m0 + 2 * (lane & 31)) * 8 : 0);
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     const int pr = p * NW + wave;
-                    int r = n0 + 2 * pr + (lane >> 5); if (r >= g.N) r = g.N - 1;
+                    int r = c_n0 + 2 * pr + (lane >> 5); if (r >= c_N) r = c_N - 1;
                     double* dst = pr < 16 ? &sA[buf][2 * pr * BM] : &sX[buf][(2 * pr - 32) * BM];
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + ((unsigned)(r * g.ldx) * 8u + coff)),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + ((unsigned)(r * c_ldx) * 8u + coff)),
                                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
                 }
             }
@@ -2647,8 +2656,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     }
     if (c_skip) continue;
     if constexpr (TAG == VMX_TAG_QUAD && NT == 256) {
-        const GemmArgs& cg = *c_gp;         // (this pass's problem)
-        if (list && cg.part) {
+        if (list && c_part) {
             // contraction epilogue (see GemmArgs::part): lane (r, c) of group jg holds D[n][m] for n = n0 + wn + 4 i + r,
             // m = c_m0 + wm + 16 jg + c after the rotations below
             const int c = lane & 15, r = lane >> 4;
@@ -2658,7 +2666,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
             if (epi_buf < 0) {              // an empty K range (never a tile's first segment): nothing was multiplied
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (c == 0) cg.part[((size_t)c_slot * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = 0.0;
+                    if (c == 0) c_part[((size_t)c_slot * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = 0.0;
                 continue;
             }
             const double* sE0 = &sA[epi_buf][0];
@@ -2666,13 +2674,13 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int n = c_n0 + wn + 4 * i + r;
-                const int nc = n < cg.N ? n : cg.N - 1;
+                const int nc = n < c_N ? n : c_N - 1;
                 const int e_n = wn + 4 * i + r;                             // walker within the tile (block-half uniform per wave)
                 const double* e_row = (wn == 0 ? sE0 + e_n * BM : sE1 + (e_n - 32) * BM) + wm + c;     // + 16 jg: this lane's entries
-                const double* lin = cg.lin;
-                if (first_seg && cg.lin_pool) {          // per-walker data (mocks): the walker's own row of the linear term
-                    const int mock = cg.lin_row[nc];
-                    lin += (size_t)(mock >= 0 ? 1 + mock : 0) * cg.ldx;
+                const double* lin = c_lin;
+                if (first_seg && c_lin_pool) {          // per-walker data (mocks): the walker's own row of the linear term
+                    const int mock = c_lin_row[nc];
+                    lin += (size_t)(mock >= 0 ? 1 + mock : 0) * c_ldx;
                 }
                 double sum = 0.0;
 #pragma unroll
@@ -2685,14 +2693,14 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
                     }
                     double out = fb == 0 ? tot[0] : fb == 1 ? tot[1] : fb == 2 ? tot[2] : tot[3];
                     const int m = c_m0 + wm + 16 * jg + c;
-                    if (m < cg.M) {
-                        if (first_seg) out -= cg.lin_pool ? lin[m] : sL[wm + 16 * jg + c];
+                    if (m < c_M) {
+                        if (first_seg) out -= c_lin_pool ? lin[m] : sL[wm + 16 * jg + c];
                         sum = fma(e_row[16 * jg], 2.0 * out, sum);
                     }
                 }
                 // the 16 lanes of a row (same walker): total in every lane
                 sum += lane_xor<8>(sum); sum += lane_xor<4>(sum); sum += lane_xor<2>(sum); sum += lane_xor<1>(sum);
-                if (c == 0) cg.part[((size_t)c_slot * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = n < cg.N ? sum : 0.0;
+                if (c == 0) c_part[((size_t)c_slot * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = n < c_N ? sum : 0.0;
             }
             continue;
         }
@@ -2720,7 +2728,6 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         unsigned long long* tr = G.trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
         tr[0] = t_start; tr[1] = t_first; tr[2] = t_loop; tr[3] = wall_clock64();
     }
-#undef g
 }
 
 // Distortion product with a CSR matrix (the reference keeps it as scipy csr_array: data.py:342-346, model.py:143-144):

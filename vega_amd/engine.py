@@ -145,6 +145,9 @@ def load_library():
     lib.vmx_set_mu_rule_box.argtypes = [C.c_void_p, C.c_int32, iptr, dptr, dptr]
     lib.vmx_stream.argtypes = [C.c_void_p]
     lib.vmx_stream.restype = C.c_void_p
+    lib.vmx_last_stream.argtypes = [C.c_void_p]
+    lib.vmx_last_stream.restype = C.c_void_p
+    lib.vmx_set_lanes.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dptr, C.c_int64]
     lib.vmx_debug_read.restype = C.c_int64
     lib.vmx_matvec_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -173,7 +176,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -438,6 +441,7 @@ class Engine:
         self.n_params = len(self.names)
         self.max_batch = int(max_batch)
         self._small_io = None
+        self.lanes = 1
         self._h = C.c_void_p()
         self._gk = {}
         self._check(self.lib.vmx_create(C.byref(self._h), int(device)))
@@ -783,6 +787,16 @@ class Engine:
     def stream_handle(self):
         """hipStream_t of the engine as an integer (for ``torch.cuda.ExternalStream``)."""
         return int(self.lib.vmx_stream(self._h))
+
+    def last_stream_handle(self):
+        """hipStream_t of the last ``eval_device`` (with two lanes: the lane it ran on)."""
+        return int(self.lib.vmx_last_stream(self._h))
+
+    def set_lanes(self, lanes):
+        """1 or 2 batches in flight for chi2-only ``eval_device`` calls (include/vegamx.h: vmx_set_lanes); the second lane
+        borrows every static tensor of the engine."""
+        self._check(self.lib.vmx_set_lanes(self._h, int(lanes)))
+        self.lanes = int(lanes)
 
     def set_data(self, name, masked_data):
         qi = self.item_names.index(name)

@@ -432,13 +432,17 @@ class VegaInterface:
         n = theta.shape[0]
         if out is None:
             out = torch.empty(n, dtype=torch.float64, device=theta.device)
-        stream = torch.cuda.ExternalStream(eng.stream_handle(), device=theta.device)
-        stream.wait_event(torch.cuda.current_stream(theta.device).record_event())
+        current = torch.cuda.current_stream(theta.device)
+        if getattr(eng, 'lanes', 1) > 1:
+            current.synchronize()       # (two lanes, two streams: the walkers are complete before either lane reads them)
+        else:
+            torch.cuda.ExternalStream(eng.stream_handle(), device=theta.device).wait_event(current.record_event())
         mb = eng.max_batch
         for lo in range(0, n, mb):
             hi = min(lo + mb, n)
             eng.eval_device(theta[lo:hi].data_ptr(), hi - lo, out[lo:hi].data_ptr())
-        torch.cuda.current_stream(theta.device).wait_event(stream.record_event())
+            # (with two lanes consecutive chunks run on alternating streams: the caller's stream waits for each)
+            current.wait_event(torch.cuda.ExternalStream(eng.last_stream_handle(), device=theta.device).record_event())
         return out
 
     def log_lik_batch(self, params_list):
