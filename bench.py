@@ -211,19 +211,24 @@ def metals_throughput(device, batch=512, steps=10):
         eng.set_constant_nl_hint(True, gaussian=True)
         pools = [torch.from_numpy(synthetic.walkers(eng.low.theta0, eng.names, batch, varied=VARIED,
                                                     seed=synthetic.SEED + 77 + i)).to(dev) for i in range(4)]
-        chi2 = torch.zeros(batch, dtype=torch.float64, device=dev)
-        for i in range(5):
-            eng.eval_device(pools[i % 4].data_ptr(), batch, chi2.data_ptr())
-        eng.sync()
-        dt = float('inf')
-        for _ in range(2):              # best of two blocks: a one-off stall (module load, clock ramp) is not the rate
-            t0 = time.perf_counter()
-            for i in range(steps):
-                eng.eval_device(pools[i % 4].data_ptr(), batch, chi2.data_ptr())
+        chi2 = [torch.zeros(batch, dtype=torch.float64, device=dev) for _ in range(4)]
+        out[label] = {'pipelines_per_eval': len(eng.pipe_index)}
+        for lanes, key in ((2, 'evals_per_s'), (1, 'one_batch_in_flight_evals_per_s')):
+            eng.set_lanes(lanes)
+            for i in range(40):
+                eng.eval_device(pools[i % 4].data_ptr(), batch, chi2[i % 4].data_ptr())
             eng.sync()
-            dt = min(dt, time.perf_counter() - t0)
-        out[label] = {'evals_per_s': batch * steps / dt, 'ms_per_step': dt / steps * 1e3,
-                      'pipelines_per_eval': len(eng.pipe_index)}
+            dt = float('inf')
+            for _ in range(3):              # best of three blocks: a one-off stall (module load, clock ramp) is not the rate
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    eng.eval_device(pools[i % 4].data_ptr(), batch, chi2[i % 4].data_ptr())
+                eng.sync()
+                dt = min(dt, time.perf_counter() - t0)
+            out[label][key] = batch * steps / dt
+            if lanes == 2:
+                out[label]['ms_per_step'] = dt / steps * 1e3
+                out[label]['batches_in_flight'] = 2
         vega.close()
     return out
 
@@ -334,6 +339,8 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--workload', default='joint', choices=['joint', 'auto', 'joint_metals', 'joint_metals_fast'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ramp-steps', type=int, default=150, help='untimed steps before the calibration pass (clock ramp); half as many again before the W warm-up steps')
+    ap.add_argument('--event-stride', type=int, default=2, help='HIP-event pairs around every n-th launch of the roofline kernel in the timed region')
     ap.add_argument('--core-only', action='store_true',
                     help='calibration + warm-up + timed steps only (the command the rocprofv3 summaries in profiles/ use)')
     ap.add_argument('--no-static-metals', action='store_true', help='keep every metal pair on its own pipeline')
@@ -453,7 +460,11 @@ def main():
     # the dominant class.  Event pairs around all ~20 launches of a step cost ~7 % of throughput, so the timed
     # region below keeps them around the dominant class only (< 1 %): its launch durations are still measured live,
     # over the timed region, on the streams the kernels run on.
-    for i in range(max(args.warmup, 3) * L):
+    # Clock ramp (untimed, before anything is measured): the part needs tens of milliseconds of sustained load to reach
+    # the clocks it then holds - a 20-step region entered after 5 warm-up steps alone runs ~8 % below the steady state
+    # every later region shows (`regions`).  The W warm-up steps of the contract follow further down, right before the
+    # timed region.
+    for i in range(max(args.warmup, 3) * L + args.ramp_steps):
         step(i)
     sync_all()
     eng.set_profiling(True)         # (every class timed: the engine keeps one batch in flight - uncontended kernel durations)
@@ -470,9 +481,11 @@ def main():
     # ... which chi2-only steps run as the quadratic-form product (one half-triangle MFMA product per item in place
     # of the distortion and C^-1 products, include/vegamx.h: vmx_set_quadratic_form)
     roof_class = next((k for k in ('quadratic_form_product', 'distortion_product') if breakdown.get(k, (0, 0))[1]), dominant)
-    eng.set_profiling_classes(sorted({roof_class, dominant}))
+    # ... and around every second launch of it: with K = 20 steps on two lanes that is still five live samples of the
+    # roofline kernel inside the timed region, at half the perturbation
+    eng.set_profiling_classes(sorted({roof_class, dominant}), stride=args.event_stride)
 
-    for i in range(args.warmup):
+    for i in range(args.ramp_steps // 2 + args.warmup):       # (the calibration pass idles the queue between its event pairs)
         step(i)
     sync_all()
     torch.cuda.synchronize()
@@ -492,26 +505,32 @@ def main():
     eng.set_profiling(False)
 
     single_lane = None
+    single_timings = None
     if L > 1 and not use_dist:
         # the same steps with ONE batch in flight (vmx_set_lanes(1)): what a caller gets whose next batch depends on this one's
         # chi2.  With two lanes (`value`) consecutive batches overlap: one lane's launch tails and small kernels are filled
         # by the other's work; co-running kernels share the chip, so per-launch durations (and with them the live roofline
         # fraction) are only clean with one lane - the calibration pass above runs that way.
         eng.set_lanes(1)
-        for i in range(4):
+        eng.set_profiling(True)
+        eng.set_profiling_classes(sorted({roof_class, dominant}))       # event pairs around every launch of the roofline kernel
+        for i in range(40):
             step(i)
         sync_all()
         torch.cuda.synchronize()
+        eng.timings(reset=True)
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
         sync_all()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        single_timings = eng.timings(reset=True)
+        eng.set_profiling(False)
         single_lane = {'lanes': 1, 'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
                        'note': 'one batch in flight: step i + 1 is enqueued behind step i on the same workspace'}
         eng.set_lanes(L)
-        for i in range(4):
+        for i in range(40):
             step(i)
         sync_all()
 
@@ -534,7 +553,7 @@ def main():
                    'regions': len(rates), 'steps_per_region': args.steps}
 
     def rate_of(fn, reps):
-        for _ in range(3):
+        for _ in range(20):
             fn()
         eng.sync()
         torch.cuda.synchronize()
@@ -592,7 +611,7 @@ def main():
         # (include/vegamx.h: vmx_set_mu_quadrature) - reported beside `value`, and the two must agree
         ref_chi2 = chi2_bufs[(args.steps - 1) % nslot].clone()
         if eng.set_mu_quadrature(False) is False:
-            for i in range(3):
+            for i in range(30):
                 step(i)
             sync_all()
             t0 = time.perf_counter()
@@ -678,6 +697,15 @@ def main():
                     'ms_per_launch': ms_per_launch, 'instruction_issue_ceiling': reach,
                     'frac_of_issue_ceiling': tf / reach}
 
+        # The roofline kernel is timed live (HIP events on its stream) in BOTH timed regions.  With two batches in flight a
+        # launch shares the chip with the other lane's kernels, so its duration there says what the lanes do to each other, not
+        # what the kernel reaches: `roofline` is the one-batch-in-flight region (`single_lane`: the same K steps, same events),
+        # `roofline.two_lane_region` the same launch inside the region `value` is measured on.
+        live2 = None
+        if single_timings is not None and single_timings[roof_class][1]:
+            live2 = live
+            live = {k: {'ms_per_launch': single_timings[k][0] / single_timings[k][1], 'launches': single_timings[k][1]}
+                    for k in {roof_class, dominant}}
         roofline = roofline_for(roof_class, live[roof_class]['ms_per_launch'])
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of `bench.py --core-only` (a counter pass
         # cannot run inside this process): the committed summary of the latest collection is attached when present
@@ -690,11 +718,15 @@ def main():
         if roofline is not None:
             roofline['launches_timed'] = live[roof_class]['launches']
             roofline['timing'] = 'HIP events on the launch stream, over the timed region'
-            if L > 1:
-                # the lanes' kernels share the chip, so a launch timed live is slower than the same launch alone
-                roofline['timing'] += f' (lane 0 of {L}; the other lane runs concurrently: `alone` = the calibration pass, one batch in flight)'
-                roofline['alone'] = {k: roofline_for(roof_class, kernels[roof_class]['ms_per_launch'])[k]
-                                     for k in ('achieved', 'frac', 'ms_per_launch', 'frac_of_issue_ceiling')}
+            if live2 is not None:
+                roofline['timing'] = (f'HIP events on the launch stream over the {args.steps} timed steps of the one-batch-in-flight '
+                                      'region (`single_lane`); `two_lane_region`: the same events inside the region `value` '
+                                      'is measured on (every second launch of lane 0), where the other lane\'s kernels share the chip')
+                r2 = roofline_for(roof_class, live2[roof_class]['ms_per_launch'])
+                roofline['two_lane_region'] = {k: r2[k] for k in ('achieved', 'frac', 'ms_per_launch', 'frac_of_issue_ceiling')}
+                roofline['two_lane_region']['launches_timed'] = live2[roof_class]['launches']
+                roofline['calibration_pass'] = {k: roofline_for(roof_class, kernels[roof_class]['ms_per_launch'])[k]
+                                                for k in ('achieved', 'frac', 'ms_per_launch')}
         roofline_other = []
         for k, v in kernels.items():
             if k == roof_class:

@@ -932,13 +932,14 @@ class Engine:
     def set_profiling(self, on):
         self._check(self.lib.vmx_set_profiling(self._h, int(bool(on))))
 
-    def set_profiling_classes(self, names):
-        """Time only the named kernel classes (see timings()) while profiling is on."""
+    def set_profiling_classes(self, names, stride=1):
+        """Time only the named kernel classes (see timings()) while profiling is on - every ``stride``-th launch of them
+        (1 .. 16)."""
         index = {self.lib.vmx_kernel_name(i).decode(): i for i in range(VMX_N_KERNELS)}
         mask = 0
         for name in names:
             mask |= 1 << index[name]
-        self._check(self.lib.vmx_set_profiling_mask(self._h, mask))
+        self._check(self.lib.vmx_set_profiling_mask(self._h, mask | ((min(max(int(stride), 1), 16) - 1) << 28)))
 
     def timings(self, reset=True):
         ms = np.zeros(VMX_N_KERNELS)
