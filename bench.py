@@ -485,7 +485,20 @@ def main():
     # roofline kernel inside the timed region, at half the perturbation
     eng.set_profiling_classes(sorted({roof_class, dominant}), stride=args.event_stride)
 
-    for i in range(args.ramp_steps // 2 + args.warmup):       # (the calibration pass idles the queue between its event pairs)
+    # (the calibration pass idles the queue between its event pairs: ramp again, until two consecutive 20-step blocks agree
+    # to 1 % - the clocks have settled -, at most `ramp_steps` blocks; then the W warm-up steps of the contract)
+    previous, settled = 0.0, 0
+    for _ in range(max(args.ramp_steps, 1)):
+        tb = time.perf_counter()
+        for i in range(20):
+            step(i)
+        sync_all()
+        rate = 20 / (time.perf_counter() - tb)
+        settled = settled + 1 if abs(rate - previous) < 0.01 * rate else 0
+        previous = rate
+        if settled >= 2:
+            break
+    for i in range(args.warmup):
         step(i)
     sync_all()
     torch.cuda.synchronize()
