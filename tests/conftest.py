@@ -286,6 +286,34 @@ def mc_launcher_config(tmp_path, num_mocks=6, seed=3):
     return 'configs/mc/main.ini'
 
 
+def fits_problem(tmp_path):
+    """The fit scenario of tests/golden/make_golden.py::dump_fits: the auto-correlation with [sample] ap, at, bias_eta_LYA,
+    beta_LYA, a [chi2 scan] over (ap, at), [control] / [monte carlo] / [mc parameters], the synthetic distortion matrix and
+    covariance, and as data the reference's own model at the fixture's truth (`expected_fits.npz`: data/<name>)."""
+    import re
+    import numpy as np
+    from vega_amd import synthetic
+    from vega_amd.setup import build_problem
+    cfg = tmp_path / 'configs' / 'fits'
+    cfg.mkdir(parents=True, exist_ok=True)
+    main = (GOLDEN / 'configs' / 'auto' / 'main.ini').read_text()
+    main = re.sub(r'ini files = .*', 'ini files = configs/fits/lyalya_lyalya.ini', main)
+    main = re.sub(r'\[control\][^\[]*', '', main)
+    main = re.sub(r'\[sample\][^\[]*', '[sample]\nap = 0.5 1.5 1.05 0.01\nat = 0.5 1.5 0.95 0.01\nbias_eta_LYA = True\n'
+                  'beta_LYA = True\n\n', main)
+    main += ('\n[chi2 scan]\nap = 0.99 1.07 3\nat = 0.93 0.97 2\n\n[control]\nrun_montecarlo = True\nmc_seed = 11\n\n'
+             '[monte carlo]\nap = 0.5 1.5 1.05 0.01\nat = 0.5 1.5 0.95 0.01\n\n[mc parameters]\nbeta_LYA = 1.8\n')
+    (cfg / 'main.ini').write_text(main)
+    (cfg / 'lyalya_lyalya.ini').write_text((GOLDEN / 'configs' / 'auto' / 'lyalya_lyalya.ini').read_text())
+    prob = build_problem('configs/fits/main.ini', search_dirs=[tmp_path, GOLDEN])
+    exp = np.load(GOLDEN / 'expected_fits.npz')
+    for name, item in prob.items.items():
+        item.distortion = synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt)
+        item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt))
+        item.data_vec = np.array(exp[f'data/{name}'])
+    return prob
+
+
 def pytest_unconfigure(config):
     global _SPAWNER
     if _SPAWNER is not None:

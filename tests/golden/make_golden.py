@@ -905,6 +905,95 @@ def dump_options2(VegaInterface):
           'model_pk shape', out['model_pk/fid/lyalya_lyalya'].shape)
 
 
+FITS_SAMPLE = ('[sample]\nap = 0.5 1.5 1.05 0.01\nat = 0.5 1.5 0.95 0.01\nbias_eta_LYA = True\nbeta_LYA = True\n\n')
+FITS_SCAN = '[chi2 scan]\nap = 0.99 1.07 3\nat = 0.93 0.97 2\n\n'
+FITS_MC = ('[control]\nrun_montecarlo = True\nmc_seed = 11\n\n[monte carlo]\nap = 0.5 1.5 1.05 0.01\nat = 0.5 1.5 0.95 0.01\n\n'
+           '[mc parameters]\nbeta_LYA = 1.8\n\n')
+
+
+FITS_TRUTH = {'ap': 1.03, 'at': 0.97, 'bias_eta_LYA': -0.21, 'beta_LYA': 1.6}
+
+
+def _fit_scenario(vega, items):
+    """Synthetic distortion matrix + covariance, and as DATA the reference's own model at FITS_TRUTH (the test file's data
+    vector is a noiseless model without distortion - against the synthetic matrices a fit would run into the limits)."""
+    _inject_synthetic(vega, items)
+    truth = vega.compute_model(dict(FITS_TRUTH), run_init=False)
+    for name in items:
+        data = vega.data[name]
+        vec = np.array(truth[name])
+        mask = data.dist_model_coordinates.get_mask_to_other(data.data_coordinates)
+        data._data_vec = vec[mask] if vec.size != data.data_vec.size else vec
+        data._masked_data_vec = None
+    _reset_caches(vega)
+    return {name: np.array(vega.data[name].data_vec) for name in items}
+
+
+def dump_fits(VegaInterface):
+    """The reference's fit DRIVERS on the auto-correlation (no metals): `minimize` (bias pre-fit + full fit,
+    vega/minimizer.py:39-103), `Analysis.chi2_scan` (vega/analysis.py:53-122), `initialize_monte_carlo`
+    (vega/vega_interface.py:505-544) and `Analysis.run_monte_carlo` (vega/analysis.py:224-308) - walked by the unmodified
+    reference with the repo's MIGRAD restatement behind the iminuit surface (tools/refshim/iminuit).  What these fixtures
+    pin is everything AROUND the minimiser: which parameters are pinned at which grid values, start values, the order
+    of the scan, seeding and scaling of the mocks, which results are kept."""
+    os.chdir(REF / 'tests')
+    items = ['lyalya_lyalya']
+    with tempfile.TemporaryDirectory() as tmp:
+        main_path = Path(_ref_main(tmp, items, False))
+        main = main_path.read_text()
+        main = re.sub(r'\[sample\][^\[]*', FITS_SAMPLE, main)
+        main = re.sub(r'\[control\][^\[]*', '', main)
+        main_path.write_text(main + '\n' + FITS_SCAN + FITS_MC)
+        vega = VegaInterface(str(main_path))
+        data_vecs = _fit_scenario(vega, items)
+        out = {'sample_names': np.array(list(vega.sample_params['limits']))}
+        for name in items:
+            out[f'data/{name}'] = data_vecs[name]
+        vega.minimize()
+        m = vega.minimizer
+        out['fit/names'] = np.array(list(m.values))
+        out['fit/values'] = np.array(list(m.values.values()))
+        out['fit/errors'] = np.array([m.errors[n] for n in m.values])
+        out['fit/covariance'] = np.array(m.covariance)
+        out['fit/fval'] = m.fmin.fval
+        out['fit/nfcn'] = m.fmin.nfcn
+        print('fits: minimize', dict(m.values), m.fmin)
+        scan = vega.analysis.chi2_scan()
+        out['scan/grid_names'] = np.array(list(vega.analysis.grids))
+        for k, g in vega.analysis.grids.items():
+            out[f'scan/grid/{k}'] = g
+        keys = list(scan[0])
+        out['scan/keys'] = np.array(keys)
+        out['scan/results'] = np.array([[r[k] for k in keys] for r in scan])
+        print('fits: scan', out['scan/results'])
+        # Monte Carlo: fiducial from a fit to the data + [mc parameters], one mock per correlation installed as data
+        vega2 = VegaInterface(str(main_path))
+        _fit_scenario(vega2, items)
+        mocks = vega2.initialize_monte_carlo()
+        for name, mock in mocks.items():
+            out[f'mcinit/mock/{name}'] = np.array(mock)
+        _reset_caches(vega2)
+        out['mcinit/chi2'] = vega2.chi2()
+        out['mcinit/log_lik'] = vega2.log_lik()
+        vega3 = VegaInterface(str(main_path))
+        _fit_scenario(vega3, items)
+        fid = vega3.get_fiducial_for_monte_carlo()
+        vega3.monte_carlo = True                # (bin/run_vega_mc_mpi.py:44)
+        for name in items:
+            out[f'mc/fiducial/{name}'] = np.array(fid[name])
+        vega3.analysis.run_monte_carlo(fid, num_mocks=2, seed=5)
+        an = vega3.analysis
+        out['mc/names'] = np.array(list(an.mc_bestfits))
+        out['mc/bestfits'] = np.array([an.mc_bestfits[n] for n in an.mc_bestfits])
+        out['mc/chisq'] = np.array(an.mc_chisq)
+        out['mc/valid'] = np.array(an.mc_valid_minima)
+        for name in items:
+            out[f'mc/mocks/{name}'] = np.array(an.mc_mocks[name])
+        np.savez_compressed(HERE / 'expected_fits.npz', **out)
+        print('fits: mc bestfits', out['mc/bestfits'], out['mc/chisq'])
+
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -912,12 +1001,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -958,3 +1047,5 @@ if __name__ == '__main__':
         dump_model_compute(VI)
     if 'options2' in what:
         dump_options2(VI)
+    if 'fits' in what:
+        dump_fits(VI)

@@ -460,7 +460,7 @@ class VegaInterface:
         return {name: model[:, sl] for name, sl in self.engine.model_slices.items()}
 
     # ------------------------------------------------------------------ fits (SURVEY section 8f "next" #1, #2)
-    def minimize(self, params=None, tol=0.1):
+    def minimize(self, params=None, tol=0.1, method='migrad'):
         """Fit the sampled parameters to the data (reference VegaInterface.minimize -> Minimizer.minimize,
         vega/vega_interface.py:581, vega/minimizer.py:39-103).  Returns a FitResult with one fit; the best fit
         is also kept in ``self.bestfit``."""
@@ -474,12 +474,20 @@ class VegaInterface:
             if params is not None and key in params:
                 sample[key].update({n: v for n, v in params[key].items() if n in sample['limits']})
         driver = MonteCarlo(self)
-        fitter = driver.minimizer(sample, tol=tol)
+        fitter = driver.minimizer(sample, tol=tol, method=method)
         self.bestfit = fitter.minimize(n_fits=1, fixed=driver._fixed)
         return self.bestfit
 
+    def chi2_scan(self, method='migrad'):
+        """``[chi2 scan]`` of the reference (vega/analysis.py:53-122; ``vega.analysis.chi2_scan()`` there): every grid point's
+        fit in lock-step - see :meth:`vega_amd.montecarlo.MonteCarlo.chi2_scan`."""
+        from .montecarlo import MonteCarlo
+        if getattr(self, 'analysis', None) is None:
+            self.analysis = MonteCarlo(self)
+        return self.analysis.chi2_scan(method=method)
+
     def run_monte_carlo(self, fiducial_model=None, num_mocks=1, seed=0, scale=None, forecast=False,
-                        run_mc_fits=True, sample_params=None):
+                        run_mc_fits=True, sample_params=None, method='migrad'):
         """Create ``num_mocks`` mocks around ``fiducial_model`` (default: the model at the current parameters)
         and fit them all in lock-step (reference Analysis.run_monte_carlo, vega/analysis.py:224-308)."""
         from .montecarlo import MonteCarlo
@@ -489,7 +497,7 @@ class VegaInterface:
         self.analysis = MonteCarlo(self)
         return self.analysis.run_monte_carlo(fiducial_model, num_mocks=num_mocks, seed=seed, scale=scale,
                                              forecast=forecast, run_mc_fits=run_mc_fits,
-                                             sample_params=sample_params)
+                                             sample_params=sample_params, method=method)
 
     def get_fiducial_for_monte_carlo(self, print_func=print):
         """The fiducial model the mocks are drawn around (reference vega_interface.py:448-503): the [mc parameters]

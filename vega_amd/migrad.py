@@ -1,0 +1,694 @@
+"""MIGRAD, restated: the variable-metric minimiser the reference runs through iminuit (reference vega/minimizer.py:66-97:
+``iminuit.Minuit(...).migrad(ncall=100000)`` with ``errordef = 1``, limits, the configured step sizes; optional
+bias-only pre-fit first).
+
+iminuit (>= 2.0, i.e. Minuit2 with strategy 1 and tolerance 0.1) is absent from this image, so the algorithm is restated
+here from its published description - the MINUIT reference manual (F. James, CERN D506) and the Minuit2 user's guide -
+step by step, because the reference's fit result IS MIGRAD's stopping point, not the minimum: the pinned value
+``fmin.fval = 0.6409716347033996`` (reference tests/test_vega.py:18) lies 1.1e-4 above the bounded minimum.  What is
+reproduced:
+
+* internal coordinates: sine transform for two-sided limits, square-root transforms for one-sided ones, with Minuit's
+  guards next to a limit; machine precision eps = 4 * DBL_EPSILON, eps2 = 2 sqrt(eps);
+* seed: step-derived first / second derivatives (g2 = 2 up / dirin^2), refined by the two-point gradient with Minuit's
+  step control (strategy 1: at most 3 cycles, step tolerance 0.3, gradient tolerance 0.05), diagonal 1 / g2 as first
+  metric, dcovar = 1;
+* iteration: Newton step -V g, Minuit's parabolic line search (first step 1, at most 12 evaluations, 5 % tolerance, step
+  growth limits 5 and 2), gradient at the new point starting from the previous steps, EDM = g^T V g / 2 with the OLD
+  metric, Davidon's rank-two update (rank-one correction when delgam > gvg), dcovar = (dcovar + |update| / |V|) / 2, loop
+  while EDM (1 + 3 dcovar) > 0.002 * tol * up;
+* strategy 1: HESSE (diagonal second derivatives with step adaptation, refined gradient, off-diagonal elements, forced
+  positive-definiteness) when dcovar > 0.05 at convergence, and another round of iterations when its EDM exceeds the goal;
+* errors and covariance in external coordinates as Minuit reports them (2 up V through the transform's Jacobian; for
+  limited parameters the average of the two one-sided excursions).
+
+The function is evaluated in BATCHES: a fit is a coroutine that asks for the points of its next stage (the 2 n points of a
+gradient cycle, one line-search trial, the n (n - 1) / 2 off-diagonal points of HESSE) and many fits advance in lock-step,
+their requests joined into one engine call - Minuit's sequence of function VALUES per fit is unchanged, only the order in
+which the engine sees the points is.  ``MIGRAD parity``: the stopping point on the reference's pinned fit, see
+tests/test_minimizer_gpu.py; the trajectory itself cannot be compared (no iminuit here).
+"""
+import math
+
+import numpy as np
+
+from .minimizer import FitResult, SENTINEL
+
+EPS = 4.0 * np.finfo(float).eps           # MnMachinePrecision::Eps
+EPS2 = 2.0 * math.sqrt(EPS)               # ... Eps2
+
+
+class Transform:
+    """Minuit's parameter transformations, one parameter at a time (external limits lo / hi, None = unbounded)."""
+
+    def __init__(self, limits):
+        self.lo = [None if lim is None or lim[0] is None or not np.isfinite(lim[0]) else float(lim[0]) for lim in limits]
+        self.hi = [None if lim is None or lim[1] is None or not np.isfinite(lim[1]) else float(lim[1]) for lim in limits]
+
+    def has_limits(self, i):
+        return self.lo[i] is not None or self.hi[i] is not None
+
+    def ext2int(self, i, value):
+        lo, hi = self.lo[i], self.hi[i]
+        if lo is not None and hi is not None:
+            distnn = 8. * math.sqrt(EPS2)
+            yy = 2. * (value - lo) / (hi - lo) - 1.
+            if yy * yy > 1. - EPS2:
+                return -0.5 * math.pi + distnn if yy < 0. else 0.5 * math.pi - distnn
+            return math.asin(yy)
+        if lo is not None:
+            yy = value - lo + 1.
+            return 8. * math.sqrt(EPS2) if yy * yy < 1. + EPS2 else math.sqrt(yy * yy - 1.)
+        if hi is not None:
+            yy = hi - value + 1.
+            return 8. * math.sqrt(EPS2) if yy * yy < 1. + EPS2 else math.sqrt(yy * yy - 1.)
+        return value
+
+    def int2ext(self, i, value):
+        lo, hi = self.lo[i], self.hi[i]
+        if lo is not None and hi is not None:
+            return lo + 0.5 * (hi - lo) * (math.sin(value) + 1.)
+        if lo is not None:
+            return lo - 1. + math.sqrt(value * value + 1.)
+        if hi is not None:
+            return hi + 1. - math.sqrt(value * value + 1.)
+        return value
+
+    def dint2ext(self, i, value):
+        lo, hi = self.lo[i], self.hi[i]
+        if lo is not None and hi is not None:
+            return 0.5 * abs((hi - lo) * math.cos(value))
+        if lo is not None:
+            return value / math.sqrt(value * value + 1.)
+        if hi is not None:
+            return -value / math.sqrt(value * value + 1.)
+        return 1.
+
+
+def _sum_abs_packed(m):
+    """Sum of |elements| of the packed upper triangle (Minuit2's sum_of_elements of a symmetric matrix)."""
+    return float(np.abs(m[np.triu_indices(m.shape[0])]).sum())
+
+
+def _make_posdef(mat):
+    """MnPosDef: (matrix, made_posdef)."""
+    err = np.array(mat, dtype=float)
+    n = err.shape[0]
+    if n == 1:
+        if err[0, 0] < EPS:
+            return np.array([[1.0]]), True
+        return err, False
+    epspdf = max(1e-6, EPS2)
+    dgmin = err.diagonal().min()
+    dg = 0.5 + epspdf - dgmin if dgmin <= 0 else 0.
+    d = err.diagonal() + dg
+    d = np.where(d < 0., 1., d)
+    err[np.diag_indices(n)] = d
+    s = 1. / np.sqrt(d)
+    p = err * s[:, None] * s[None, :]
+    ev = np.linalg.eigvalsh(p)
+    pmin, pmax = ev[0], max(abs(ev[-1]), 1.)
+    if pmin > epspdf * pmax:
+        return err, False
+    padd = 0.001 * pmax - pmin
+    err[np.diag_indices(n)] = err.diagonal() * (1. + padd)
+    return err, True
+
+
+class _Fit:
+    """One MIGRAD fit as a coroutine over batches of internal points (``run`` yields [m, n] arrays, receives [m] values)."""
+
+    # strategy 1
+    GRAD_NCYCLES, GRAD_STEP_TOL, GRAD_TOL = 3, 0.3, 0.05
+    HESS_NCYCLES, HESS_STEP_TOL, HESS_G2_TOL, HESS_GRAD_NCYCLES = 5, 0.3, 0.05, 2
+
+    def __init__(self, ext_start, ext_errors, limits_free, up=1.0, tol=0.1, maxfcn=100000):
+        self.trafo = Transform(limits_free)
+        self.n = len(ext_start)
+        self.ext_errors = np.asarray(ext_errors, dtype=float)
+        self.x0 = np.array([self.trafo.ext2int(i, v) for i, v in enumerate(ext_start)])
+        self.up = up
+        self.edmval = 0.002 * max(tol * up, EPS2)
+        self.maxfcn = maxfcn
+        self.nfcn = 0
+        self.n_iter = 0
+        self.result = None
+
+    # ---- function values through the driver
+    def _eval(self, pts):
+        pts = np.atleast_2d(np.asarray(pts, dtype=float))
+        vals = yield pts
+        self.nfcn += pts.shape[0]
+        return np.asarray(vals, dtype=float)
+
+    def to_external(self, x):
+        return np.array([self.trafo.int2ext(i, v) for i, v in enumerate(x)])
+
+    # ---- gradients
+    def _initial_gradient(self, x):
+        n = self.n
+        grd, g2, gstep = np.zeros(n), np.zeros(n), np.zeros(n)
+        for i in range(n):
+            var = x[i]
+            werr = self.ext_errors[i]
+            sav = self.trafo.int2ext(i, var)
+            sav2 = sav + werr
+            if self.trafo.hi[i] is not None and sav2 > self.trafo.hi[i]:
+                sav2 = self.trafo.hi[i]
+            vplu = self.trafo.ext2int(i, sav2) - var
+            sav2 = sav - werr
+            if self.trafo.lo[i] is not None and sav2 < self.trafo.lo[i]:
+                sav2 = self.trafo.lo[i]
+            vmin = self.trafo.ext2int(i, sav2) - var
+            gsmin = 8. * EPS2 * (abs(var) + EPS2)
+            dirin = max(0.5 * (abs(vplu) + abs(vmin)), gsmin)
+            g2[i] = 2.0 * self.up / (dirin * dirin)
+            gstep[i] = max(gsmin, 0.1 * dirin)
+            grd[i] = g2[i] * dirin
+            if self.trafo.has_limits(i) and gstep[i] > 0.5:
+                gstep[i] = 0.5
+        return grd, g2, gstep
+
+    def _gradient(self, x, fval, grd, g2, gstep):
+        """Numerical2PGradientCalculator: the parameters are independent of each other, so cycle j of all of them is one
+        batch; each keeps Minuit's own sequence of steps and stops on its own criteria."""
+        n = self.n
+        grd, g2, gstep = grd.copy(), g2.copy(), gstep.copy()
+        dfmin = 8. * EPS2 * (abs(fval) + self.up)
+        vrysml = 8. * EPS * EPS
+        stepb4 = np.zeros(n)
+        active = np.ones(n, dtype=bool)
+        for _ in range(self.GRAD_NCYCLES):
+            todo, steps = [], []
+            for i in np.flatnonzero(active):
+                epspri = EPS2 + abs(grd[i] * EPS2)
+                optstp = math.sqrt(dfmin / (abs(g2[i]) + epspri))
+                step = max(optstp, abs(0.1 * gstep[i]))
+                if self.trafo.has_limits(i) and step > 0.5:
+                    step = 0.5
+                step = min(step, 10. * abs(gstep[i]))
+                step = max(step, max(vrysml, 8. * abs(EPS2 * x[i])))
+                if abs((step - stepb4[i]) / step) < self.GRAD_STEP_TOL:
+                    active[i] = False
+                    continue
+                gstep[i] = step
+                stepb4[i] = step
+                todo.append(i)
+                steps.append(step)
+            if not todo:
+                break
+            pts = np.repeat(x[None, :], 2 * len(todo), axis=0)
+            for q, (i, step) in enumerate(zip(todo, steps)):
+                pts[2 * q, i] += step
+                pts[2 * q + 1, i] -= step
+            vals = yield from self._eval(pts)
+            for q, (i, step) in enumerate(zip(todo, steps)):
+                fs1, fs2 = vals[2 * q], vals[2 * q + 1]
+                grdb4 = grd[i]
+                grd[i] = 0.5 * (fs1 - fs2) / step
+                g2[i] = (fs1 + fs2 - 2. * fval) / step / step
+                if abs(grdb4 - grd[i]) / (abs(grd[i]) + dfmin / step) < self.GRAD_TOL:
+                    active[i] = False
+        return grd, g2, gstep
+
+    # ---- line search (MnLineSearch)
+    def _line_search(self, x, f0, step, gdel):
+        overal, undral, toler, slambg, alpha, maxiter = 1000., -100., 0.05, 5., 2., 12
+        niter = 1
+        slamin = 0.
+        for i in range(self.n):
+            if step[i] == 0:
+                continue
+            ratio = abs(x[i] / step[i])
+            if slamin == 0 or ratio < slamin:
+                slamin = ratio
+        if abs(slamin) < EPS:
+            slamin = EPS
+        slamin *= EPS2
+
+        f1 = (yield from self._eval(x + step))[0]
+        niter += 1
+        fvmin, xvmin = f0, 0.
+        if f1 < f0:
+            fvmin, xvmin = f1, 1.
+        toler8, slamax, flast, slam = toler, slambg, f1, 1.
+        p0, p1 = (0., f0), (slam, flast)
+        f2 = 0.
+        while True:
+            iterate = False
+            denom = 2. * (flast - f0 - gdel * slam) / (slam * slam)
+            if denom != 0:
+                slam = -gdel / denom
+            else:
+                slam = 1.
+            if slam < 0.:
+                slam = slamax
+            if slam > slamax:
+                slam = slamax
+            if slam < toler8:
+                slam = toler8
+            if slam < slamin:
+                return xvmin, fvmin
+            if abs(slam - 1.) < toler8 and p1[1] < p0[1]:
+                return xvmin, fvmin
+            if abs(slam - 1.) < toler8:
+                slam = 1. + toler8
+            f2 = (yield from self._eval(x + slam * step))[0]
+            niter += 1
+            if f2 < fvmin:
+                fvmin, xvmin = f2, slam
+            if abs(p0[1] - fvmin) < abs(fvmin) * EPS:
+                iterate = True
+                flast = f2
+                toler8 = toler * slam
+                overal = slam - toler8
+                slamax = overal
+                p1 = (slam, flast)
+            if not (iterate and niter < maxiter):
+                break
+        if niter >= maxiter:
+            return xvmin, fvmin
+        p2 = (slam, f2)
+
+        while True:
+            slamax = max(slamax, alpha * abs(xvmin))
+            # parabola through p0, p1, p2: y = a x^2 + b x + c
+            (x1, y1), (x2, y2), (x3, y3) = p0, p1, p2
+            dx12, dx13, dx23 = x1 - x2, x1 - x3, x2 - x3
+            xm = (x1 + x2 + x3) / 3.
+            dx1, dx2, dx3 = x1 - xm, x2 - xm, x3 - xm
+            dx12b, dx13b, dx23b = dx1 - dx2, dx1 - dx3, dx2 - dx3
+            a = y1 / (dx12b * dx13b) - y2 / (dx12b * dx23b) + y3 / (dx13b * dx23b)
+            b = -y1 * (dx2 + dx3) / (dx12b * dx13b) + y2 * (dx1 + dx3) / (dx12b * dx23b) - y3 * (dx1 + dx2) / (dx13b * dx23b)
+            c = y1 - a * dx1 * dx1 - b * dx1
+            c += xm * (xm * a - b)
+            b -= 2. * xm * a
+            del dx12, dx13, dx23, c
+            if a < EPS2:
+                slopem = 2. * a * xvmin + b
+                slam = xvmin + slamax if slopem < 0. else xvmin - slamax
+            else:
+                slam = -b / (2. * a)
+                if slam > xvmin + slamax:
+                    slam = xvmin + slamax
+                if slam < xvmin - slamax:
+                    slam = xvmin - slamax
+            if slam > 0.:
+                if slam > overal:
+                    slam = overal
+            elif slam < undral:
+                slam = undral
+
+            f3 = 0.
+            while True:
+                iterate = False
+                toler9 = max(toler8, abs(toler8 * slam))
+                if abs(p0[0] - slam) < toler9 or abs(p1[0] - slam) < toler9 or abs(p2[0] - slam) < toler9:
+                    return xvmin, fvmin
+                f3 = (yield from self._eval(x + slam * step))[0]
+                if f3 > p0[1] and f3 > p1[1] and f3 > p2[1]:
+                    if slam > xvmin:
+                        overal = min(overal, slam - toler8)
+                    if slam < xvmin:
+                        undral = max(undral, slam + toler8)
+                    slam = 0.5 * (slam + xvmin)
+                    iterate = True
+                    niter += 1
+                if not (iterate and niter < maxiter):
+                    break
+            if niter >= maxiter:
+                return xvmin, fvmin
+            p3 = (slam, f3)
+            if p0[1] > p1[1] and p0[1] > p2[1]:
+                p0 = p3
+            elif p1[1] > p0[1] and p1[1] > p2[1]:
+                p1 = p3
+            else:
+                p2 = p3
+            if f3 < fvmin:
+                fvmin, xvmin = f3, slam
+            else:
+                if slam > xvmin:
+                    overal = min(overal, slam - toler8)
+                if slam < xvmin:
+                    undral = max(undral, slam + toler8)
+            niter += 1
+            if niter >= maxiter:
+                break
+        return xvmin, fvmin
+
+    # ---- HESSE (MnHesse, strategy 1)
+    def _hesse(self, x, state):
+        n = self.n
+        amin = (yield from self._eval(x))[0]
+        aimsag = math.sqrt(EPS2) * (abs(amin) + self.up)
+        g2, gst, grd = state['g2'].copy(), state['gstep'].copy(), state['grd'].copy()
+        dirin = gst.copy()
+        yy = np.zeros(n)
+        vhmat = np.zeros((n, n))
+        failed = False
+        for i in range(n):
+            xtf = x[i]
+            dmin = 8. * EPS2 * (abs(xtf) + EPS2)
+            d = max(abs(gst[i]), dmin)
+            for _ in range(self.HESS_NCYCLES):
+                sag = fs1 = fs2 = 0.
+                ok = False
+                for _m in range(5):
+                    pts = np.repeat(x[None, :], 2, axis=0)
+                    pts[0, i] = xtf + d
+                    pts[1, i] = xtf - d
+                    fs1, fs2 = (yield from self._eval(pts))
+                    sag = 0.5 * (fs1 + fs2 - 2. * amin)
+                    if sag > EPS2:
+                        ok = True
+                        break
+                    if self.trafo.has_limits(i):
+                        if d > 0.5:
+                            break
+                        d *= 10.
+                        if d > 0.5:
+                            d = 0.51
+                        continue
+                    d *= 10.
+                if not ok:
+                    failed = True
+                    break
+                g2bfor = g2[i]
+                g2[i] = 2. * sag / (d * d)
+                grd[i] = (fs1 - fs2) / (2. * d)
+                gst[i] = d
+                dirin[i] = d
+                yy[i] = fs1
+                dlast = d
+                d = math.sqrt(2. * aimsag / abs(g2[i]))
+                if self.trafo.has_limits(i):
+                    d = min(0.5, d)
+                if d < dmin:
+                    d = dmin
+                if abs((d - dlast) / d) < self.HESS_STEP_TOL:
+                    break
+                if abs((g2[i] - g2bfor) / g2[i]) < self.HESS_G2_TOL:
+                    break
+                d = min(d, 10. * dlast)
+                d = max(d, 0.1 * dlast)
+            if failed:
+                break
+            vhmat[i, i] = g2[i]
+        if failed:
+            return dict(state, hesse_failed=True, fval=amin)
+        # refine the first derivatives (HessianGradientCalculator)
+        dfmin = 4. * EPS2 * (abs(amin) + self.up)
+        for i in range(n):
+            xtf = x[i]
+            dmin = 4. * EPS2 * (xtf + EPS2)
+            epspri = EPS2 + abs(grd[i] * EPS2)
+            optstp = math.sqrt(dfmin / (abs(g2[i]) + epspri))
+            d = 0.2 * abs(gst[i])
+            if d > optstp:
+                d = optstp
+            if d < dmin:
+                d = dmin
+            chgold = 10000.
+            for j in range(self.HESS_GRAD_NCYCLES):
+                pts = np.repeat(x[None, :], 2, axis=0)
+                pts[0, i] = xtf + d
+                pts[1, i] = xtf - d
+                fs1, fs2 = (yield from self._eval(pts))
+                grdold = grd[i]
+                grdnew = (fs1 - fs2) / (2. * d)
+                dgmin = EPS * (abs(fs1) + abs(fs2)) / d
+                if abs(grdnew) < EPS:
+                    break
+                change = abs((grdold - grdnew) / grdnew)
+                if change > chgold and j > 1:
+                    break
+                chgold = change
+                grd[i] = grdnew
+                gst[i] = d
+                if change < 0.05:
+                    break
+                if abs(grdold - grdnew) < dgmin:
+                    break
+                if d < dmin:
+                    break
+                d *= 0.2
+        # off-diagonal elements: one batch
+        pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+        if pairs:
+            pts = np.repeat(x[None, :], len(pairs), axis=0)
+            for q, (i, j) in enumerate(pairs):
+                pts[q, i] += dirin[i]
+                pts[q, j] += dirin[j]
+            vals = yield from self._eval(pts)
+            for q, (i, j) in enumerate(pairs):
+                vhmat[i, j] = vhmat[j, i] = (vals[q] + amin - yy[i] - yy[j]) / (dirin[i] * dirin[j])
+        hmat, made = _make_posdef(vhmat)
+        try:
+            V = np.linalg.inv(hmat)
+        except np.linalg.LinAlgError:
+            return dict(state, hesse_failed=True, fval=amin)
+        edm = 0.5 * float(grd @ V @ grd)
+        return dict(x=x.copy(), fval=amin, grd=grd, g2=g2, gstep=gst, V=V, dcovar=0., edm=edm, made_posdef=made,
+                    hesse_failed=False, accurate=not made)
+
+    # ---- the whole fit
+    def run(self, run_hesse_at_end=True):
+        n = self.n
+        x = self.x0.copy()
+        fval = (yield from self._eval(x))[0]
+        if not np.isfinite(fval):
+            self.result = dict(x=x, fval=np.inf, edm=np.inf, V=np.zeros((n, n)), valid=False, hesse_failed=True,
+                               accurate=False, above_max_edm=True)
+            return
+        grd, g2, gstep = self._initial_gradient(x)
+        grd, g2, gstep = yield from self._gradient(x, fval, grd, g2, gstep)
+        V = np.diag([1. / g2[i] if abs(g2[i]) > EPS2 else 1. for i in range(n)])
+        state = dict(x=x, fval=fval, grd=grd, g2=g2, gstep=gstep, V=V, dcovar=1., edm=0.5 * float(grd @ V @ grd),
+                     made_posdef=False, hesse_failed=False, accurate=False)
+        if (g2 <= 0).any():
+            state = yield from self._negative_g2(state)
+        maxfcn_eff = self.maxfcn
+        ipass = 0
+        reached_limit = False
+        while True:
+            iterate = False
+            state, reached_limit = yield from self._iterate(state, maxfcn_eff)
+            if reached_limit:
+                break
+            edm = state['edm']
+            if state['dcovar'] > 0.05:
+                st = yield from self._hesse(state['x'], state)
+                if not st.get('hesse_failed'):
+                    state = st
+                    edm = st['edm']
+                    if edm > self.edmval and edm >= abs(EPS2 * state['fval']):
+                        iterate = True
+                else:
+                    state = st
+                    break
+            if ipass == 0:
+                maxfcn_eff = int(self.maxfcn * 1.3)
+            ipass += 1
+            if not iterate:
+                break
+        hesse_failed = bool(state.get('hesse_failed'))
+        self.result = dict(x=state['x'], fval=state['fval'], edm=state['edm'], V=state['V'],
+                           valid=(not reached_limit) and state['edm'] <= 10 * self.edmval and not hesse_failed
+                           and np.isfinite(state['fval']),
+                           hesse_failed=hesse_failed, accurate=bool(state.get('accurate')),
+                           above_max_edm=state['edm'] > 10 * self.edmval)
+
+    def _negative_g2(self, state):
+        """NegativeG2LineSearch: walk along every direction with a negative second derivative until it turns positive."""
+        x, fval, grd, g2, gstep = state['x'].copy(), state['fval'], state['grd'].copy(), state['g2'].copy(), state['gstep'].copy()
+        n = self.n
+        for _ in range(2 * n):
+            i_neg = [i for i in range(n) if g2[i] <= 0]
+            if not i_neg:
+                break
+            for i in i_neg:
+                if abs(gstep[i]) < EPS2:
+                    continue
+                step = np.zeros(n)
+                step[i] = gstep[i] * (-1. if grd[i] > 0 else 1.)
+                gdel = step[i] * grd[i]
+                lam, fmin = yield from self._line_search(x, fval, step, gdel)
+                x = x + lam * step
+                fval = fmin
+                grd, g2, gstep = yield from self._gradient(x, fval, grd, g2, gstep)
+                break
+        V = np.diag([1. / g2[i] if abs(g2[i]) > EPS2 else 1. for i in range(n)])
+        return dict(state, x=x, fval=fval, grd=grd, g2=g2, gstep=gstep, V=V, dcovar=1., edm=0.5 * float(grd @ V @ grd))
+
+    def _iterate(self, s0, maxfcn):
+        edm = s0['edm']
+        while True:
+            step = -s0['V'] @ s0['grd']
+            gdel = float(step @ s0['grd'])
+            if gdel > 0.:
+                V, _ = _make_posdef(s0['V'])
+                s0 = dict(s0, V=V)
+                step = -V @ s0['grd']
+                gdel = float(step @ s0['grd'])
+                if gdel > 0.:
+                    return s0, False
+            lam, fnew = yield from self._line_search(s0['x'], s0['fval'], step, gdel)
+            if abs(fnew - s0['fval']) <= abs(s0['fval']) * EPS:
+                break           # no improvement
+            x = s0['x'] + lam * step
+            grd, g2, gstep = yield from self._gradient(x, fnew, s0['grd'], s0['g2'], s0['gstep'])
+            edm = 0.5 * float(grd @ s0['V'] @ grd)
+            if edm != edm:
+                return s0, False
+            if edm < 0.:
+                V, _ = _make_posdef(s0['V'])
+                s0 = dict(s0, V=V)
+                edm = 0.5 * float(grd @ V @ grd)
+                if edm < 0.:
+                    return s0, False
+            # Davidon's update
+            v0 = s0['V']
+            dx = x - s0['x']
+            dg = grd - s0['grd']
+            delgam = float(dx @ dg)
+            gvg = float(dg @ v0 @ dg)
+            if delgam == 0. or gvg <= 0.:
+                V, dcov = v0, s0['dcovar']
+            else:
+                vg = v0 @ dg
+                upd = np.outer(dx, dx) / delgam - np.outer(vg, vg) / gvg
+                if delgam > gvg:
+                    w = dx / delgam - vg / gvg
+                    upd += gvg * np.outer(w, w)
+                sum_upd = _sum_abs_packed(upd)
+                V = v0 + upd
+                dcov = 0.5 * (s0['dcovar'] + sum_upd / _sum_abs_packed(V))
+            s0 = dict(x=x, fval=fnew, grd=grd, g2=g2, gstep=gstep, V=V, dcovar=dcov, edm=edm, made_posdef=False,
+                      hesse_failed=False, accurate=False)
+            self.n_iter += 1
+            edm_test = edm * (1. + 3. * dcov)
+            if not (edm_test > self.edmval and self.nfcn < maxfcn):
+                break
+        return s0, self.nfcn >= maxfcn
+
+    # ---- results in external coordinates (MnUserParameterState / MnUserCovariance)
+    def external(self):
+        r = self.result
+        x = r['x']
+        n = self.n
+        values = self.to_external(x)
+        cov_int = 2. * self.up * r['V']
+        jac = np.array([self.trafo.dint2ext(i, x[i]) for i in range(n)])
+        cov = cov_int * jac[:, None] * jac[None, :]
+        errors = np.zeros(n)
+        for i in range(n):
+            dx = math.sqrt(max(cov_int[i, i], 0.))
+            if self.trafo.has_limits(i):
+                ui = values[i]
+                du1 = self.trafo.int2ext(i, x[i] + dx) - ui
+                du2 = self.trafo.int2ext(i, x[i] - dx) - ui
+                if dx > 1. and self.trafo.lo[i] is not None and self.trafo.hi[i] is not None:
+                    du1 = self.trafo.hi[i] - self.trafo.lo[i]
+                errors[i] = 0.5 * (abs(du1) + abs(du2))
+            else:
+                errors[i] = dx
+        return values, errors, cov
+
+
+def _drive(fits, evaluate_internal):
+    """Advance the coroutines in lock-step: one joined evaluation per round."""
+    gens = [(k, f.run()) for k, f in enumerate(fits)]
+    pending = {}
+    for k, g in gens:
+        try:
+            pending[k] = (g, next(g))
+        except StopIteration:
+            pass
+    while pending:
+        keys = list(pending)
+        pts = np.concatenate([pending[k][1] for k in keys])
+        owner = np.concatenate([np.full(pending[k][1].shape[0], k) for k in keys])
+        vals = evaluate_internal(pts, owner)
+        nxt = {}
+        off = 0
+        for k in keys:
+            g, req = pending[k]
+            m = req.shape[0]
+            try:
+                nxt[k] = (g, g.send(vals[off:off + m]))
+            except StopIteration:
+                pass
+            off += m
+        pending = nxt
+
+
+class MigradMinimizer:
+    """Drop-in for :class:`vega_amd.minimizer.BatchedMinimizer` with MIGRAD's own sequence of steps per fit.
+
+    ``evaluate(theta_ext [m, P], fit_index [m]) -> chi2 [m]``."""
+
+    def __init__(self, evaluate, names, start, errors, limits, tol=0.1, errordef=1.0, maxfcn=100000):
+        self.evaluate = evaluate
+        self.names = list(names)
+        self.start = np.asarray(start, dtype=float)
+        self.step = np.asarray(errors, dtype=float)
+        self.limits = [tuple(lim) if lim is not None else (None, None) for lim in limits]
+        self.tol, self.errordef, self.maxfcn = tol, errordef, maxfcn
+
+    def _stage(self, ext0, free, fit_ids):
+        """One Minuit object per fit over the parameters ``free`` (the others held at ext0)."""
+        free = np.asarray(free, dtype=int)
+        fits = [_Fit(ext0[f][free], self.step[free], [self.limits[j] for j in free], up=self.errordef, tol=self.tol,
+                     maxfcn=self.maxfcn) for f in range(ext0.shape[0])]
+
+        def evaluate_internal(pts, owner):
+            theta = ext0[owner].copy()
+            for q in range(pts.shape[0]):
+                theta[q, free] = fits[owner[q]].to_external(pts[q])
+            vals = np.asarray(self.evaluate(theta, fit_ids[owner]), dtype=float)
+            return np.where(np.isfinite(vals) & (vals < SENTINEL), vals, np.inf)
+        _drive(fits, evaluate_internal)
+        return fits
+
+    def minimize(self, n_fits=1, start=None, fixed=(), prefit_bias=True):
+        P = len(self.names)
+        F = int(n_fits)
+        ext = np.tile(self.start, (F, 1)) if start is None else np.array(start, dtype=float).reshape(F, P)
+        fit_ids = np.arange(F)
+        free_all = np.array([j for j, n in enumerate(self.names) if n not in fixed], dtype=int)
+        nfcn = np.zeros(F, dtype=np.int64)
+        n_iter = np.zeros(F, dtype=int)
+        # the reference first minimises over the bias parameters alone, a Minuit object of its own (vega/minimizer.py:66-86)
+        bias = np.array([j for j in free_all if 'bias' in self.names[j]], dtype=int)
+        if prefit_bias and bias.size > 0:
+            pre = self._stage(ext, bias, fit_ids)
+            for f, fit in enumerate(pre):
+                nfcn[f] += fit.nfcn
+                n_iter[f] += fit.n_iter
+                if fit.result is not None and np.isfinite(fit.result['fval']):
+                    ext[f, bias] = fit.external()[0]
+        fits = self._stage(ext, free_all, fit_ids)
+        values = ext.copy()
+        errors = np.zeros((F, P))
+        cov = np.zeros((F, P, P))
+        fval, edm = np.full(F, np.inf), np.full(F, np.inf)
+        valid, hesse_failed = np.zeros(F, dtype=bool), np.zeros(F, dtype=bool)
+        accurate = np.zeros(F, dtype=bool)
+        for f, fit in enumerate(fits):
+            nfcn[f] += fit.nfcn
+            n_iter[f] += fit.n_iter
+            r = fit.result
+            if r is None or not np.isfinite(r['fval']):
+                hesse_failed[f] = True
+                continue
+            v, e, c = fit.external()
+            values[f, free_all] = v
+            errors[f, free_all] = e
+            cov[f][np.ix_(free_all, free_all)] = c
+            fval[f], edm[f] = r['fval'], r['edm']
+            valid[f], hesse_failed[f], accurate[f] = r['valid'], r['hesse_failed'], r['accurate']
+        res = FitResult(names=self.names, values=values, errors=errors, covariance=cov, fval=fval, edm=edm, is_valid=valid,
+                        hesse_failed=hesse_failed, nfcn=nfcn, n_iter=n_iter)
+        res.has_accurate_covar = accurate
+        return res

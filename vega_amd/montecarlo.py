@@ -141,8 +141,11 @@ class MonteCarlo:
         self.has_monte_carlo = False
         self.current_mc_mock = None
 
-    def minimizer(self, sample_params=None, tol=0.1):
-        """BatchedMinimizer over ``sample_params`` (default: the interface's [sample] section) whose objective
+    def minimizer(self, sample_params=None, tol=0.1, method='migrad'):
+        """Minimiser over ``sample_params`` (default: the interface's [sample] section) - ``method='migrad'``: MIGRAD's own
+        sequence of steps per fit (vega_amd/migrad.py: what the reference runs through iminuit, vega/minimizer.py:66-97),
+        ``'bfgs'``: the vectorised variable-metric minimiser of vega_amd/minimizer.py (Minuit conventions, not its
+        trajectory; fewer Python steps per fit) - whose objective
         is the engine: walkers = defaults with the sampled columns replaced, data = the walker's mock."""
         vega = self.vega
         sp = vega.sample_params if sample_params is None else sample_params
@@ -171,7 +174,55 @@ class MonteCarlo:
         errors = [sp['errors'][n] for n in names]
         limits = [sp['limits'][n] for n in names]
         self._fixed = tuple(n for n in names if sp.get('fix', {}).get(n, False))
+        if method == 'migrad':
+            from .migrad import MigradMinimizer
+            return MigradMinimizer(evaluate, names, start, errors, limits, tol=tol)
+        if method != 'bfgs':
+            raise ValueError("method: 'migrad' or 'bfgs'")
         return BatchedMinimizer(evaluate, names, start, errors, limits, tol=tol)
+
+    def chi2_scan(self, method='migrad'):
+        """chi2 scan over the one or two parameters of the ``[chi2 scan]`` section (``name = start end num_points``;
+        reference Analysis.chi2_scan, vega/analysis.py:53-122): at every grid point the scanned parameters are pinned
+        (``fix`` / ``values`` overrides of the sampling table, errors 0) and the others are fitted from their configured
+        start values.  The reference runs one MIGRAD after the other; here ALL grid points' fits advance in lock-step, their
+        trial points joined into engine batches.  Returns the reference's list of dicts (best-fit values + ``'fval'``),
+        first parameter outermost; ``self.grids`` keeps the grids."""
+        vega = self.vega
+        config = vega.main_config
+        if config is None or 'chi2 scan' not in config:
+            raise ValueError('Called chi2_scan, but no config specified in main.ini. Add a "[chi2 scan]" section to main.')
+        self.grids = {}
+        for param, value in config.items('chi2 scan'):
+            start, end, num = value.split()[:3]
+            self.grids[param] = np.linspace(float(start), float(end), int(num))
+        if len(self.grids) > 2:
+            raise ValueError('chi2_scan only supports one/two parameter scans')
+        sp = vega.sample_params
+        names = list(sp['limits'].keys())
+        for param in self.grids:
+            if param not in names:
+                raise KeyError(f'{param}: a scanned parameter must be listed under [sample] (the scan pins it there)')
+        grid_names = list(self.grids)
+        mesh = np.meshgrid(*[self.grids[g] for g in grid_names], indexing='ij')
+        points = np.stack([m.ravel() for m in mesh], axis=1)            # first parameter outermost
+        vega.freeze_metals()
+        vega._sync_monte_carlo()
+        sample = {key: dict(sp.get(key, {})) for key in ('limits', 'values', 'errors', 'fix')}
+        for g in grid_names:
+            sample['fix'][g] = True
+        fitter = self.minimizer(sample, method=method)
+        start = np.tile([sample['values'][n] for n in names], (points.shape[0], 1))
+        for c, g in enumerate(grid_names):
+            start[:, names.index(g)] = points[:, c]
+        res = fitter.minimize(n_fits=points.shape[0], start=start, fixed=self._fixed)
+        self.scan_fits = res
+        self.scan_results = []
+        for i in range(points.shape[0]):
+            row = {n: float(res.values[i, j]) for j, n in enumerate(names)}
+            row['fval'] = float(res.fval[i])
+            self.scan_results.append(row)
+        return self.scan_results
 
     def create_mocks(self, fiducial_model, num_mocks=1, seed=0, scale=None, forecast=False, reseed_per_item=False):
         """dict name -> [num_mocks, n_masked]: the reference's mocks for ``seed``, per item or - when the problem has a
@@ -193,7 +244,7 @@ class MonteCarlo:
         return mocks
 
     def run_monte_carlo(self, fiducial_model, num_mocks=1, seed=0, scale=None, forecast=False,
-                        run_mc_fits=True, sample_params=None):
+                        run_mc_fits=True, sample_params=None, method='migrad'):
         vega = self.vega
         eng = vega.engine
         prob = vega.problem
@@ -210,7 +261,7 @@ class MonteCarlo:
                 if prob.items[name].marginalize_in_fit:
                     raise NotImplementedError('a rescaled covariance with marginalize-in-fit is not supported')
                 eng.set_invcov(name, prob.items[name].chi2_matrix / scales[name])
-        fitter = self.minimizer(sample_params)
+        fitter = self.minimizer(sample_params, method=method)
         self._mock_rows = np.arange(num_mocks, dtype=np.int32)
         try:
             res = fitter.minimize(n_fits=num_mocks, fixed=self._fixed)
