@@ -43,7 +43,8 @@ def test_minimize_scan_and_monte_carlo_against_the_references_drivers(tmp_path):
     np.testing.assert_allclose(res.values[0], exp['fit/values'], rtol=1e-6)
     np.testing.assert_allclose(res.errors[0], exp['fit/errors'], rtol=1e-4)
     np.testing.assert_allclose(res.covariance[0], exp['fit/covariance'], rtol=1e-3, atol=1e-9)
-    assert abs(int(res.nfcn[0]) - int(exp['fit/nfcn'])) <= 4          # (the pre-fit's evaluations are counted here too)
+    # (the full fit's evaluations, as the reference's last Minuit object counts them, + the 18 of the bias pre-fit)
+    assert int(res.nfcn[0]) == int(exp['fit/nfcn']) + 18
     # chi2 scan: grids, order, pinned values, every grid point's fit
     scan = vega.chi2_scan()
     grid_names = [str(n) for n in exp['scan/grid_names']]
@@ -88,7 +89,9 @@ def test_minimize_scan_and_monte_carlo_against_the_references_drivers(tmp_path):
         ref = exp[f'mc/mocks/{name}'][:, prob.items[name].data_mask]       # (the reference keeps mocks on the full grid)
         np.testing.assert_allclose(np.asarray(mc.mc_mocks[name]), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
     bestfits = np.array([mc.mc_bestfits[n] for n in mc_names])
-    np.testing.assert_allclose(bestfits[:, :, 0], exp['mc/bestfits'][:, :, 0], rtol=1e-5)
-    np.testing.assert_allclose(bestfits[:, :, 1], exp['mc/bestfits'][:, :, 1], rtol=1e-3)
+    # (chi2 values that differ in the 15th digit can send one line search of a fit down another branch: the stopping points
+    # then differ by a small fraction of MIGRAD's own EDM tolerance - 1e-3 of the reported errors here - not bit for bit)
+    assert (np.abs(bestfits[:, :, 0] - exp['mc/bestfits'][:, :, 0]) <= 2e-3 * exp['mc/bestfits'][:, :, 1]).all()
+    np.testing.assert_allclose(bestfits[:, :, 1], exp['mc/bestfits'][:, :, 1], rtol=5e-3)
     np.testing.assert_allclose(mc.mc_chisq, exp['mc/chisq'], rtol=1e-7)
     vega.close()

@@ -74,6 +74,20 @@ class Transform:
             return hi + 1. - math.sqrt(value * value + 1.)
         return value
 
+    def int2ext_array(self, pts):
+        """int2ext of whole rows at once ([m, n] internal -> external): the engine-facing side of a batch of trial points."""
+        pts = np.asarray(pts, dtype=float)
+        out = pts.copy()
+        for i in range(pts.shape[1]):
+            lo, hi = self.lo[i], self.hi[i]
+            if lo is not None and hi is not None:
+                out[:, i] = lo + 0.5 * (hi - lo) * (np.sin(pts[:, i]) + 1.)
+            elif lo is not None:
+                out[:, i] = lo - 1. + np.sqrt(pts[:, i] * pts[:, i] + 1.)
+            elif hi is not None:
+                out[:, i] = hi + 1. - np.sqrt(pts[:, i] * pts[:, i] + 1.)
+        return out
+
     def dint2ext(self, i, value):
         lo, hi = self.lo[i], self.hi[i]
         if lo is not None and hi is not None:
@@ -642,10 +656,11 @@ class MigradMinimizer:
         fits = [_Fit(ext0[f][free], self.step[free], [self.limits[j] for j in free], up=self.errordef, tol=self.tol,
                      maxfcn=self.maxfcn) for f in range(ext0.shape[0])]
 
+        trafo = Transform([self.limits[j] for j in free])       # (the fits of a stage share their limits)
+
         def evaluate_internal(pts, owner):
-            theta = ext0[owner].copy()
-            for q in range(pts.shape[0]):
-                theta[q, free] = fits[owner[q]].to_external(pts[q])
+            theta = ext0[owner]
+            theta[:, free] = trafo.int2ext_array(pts)
             vals = np.asarray(self.evaluate(theta, fit_ids[owner]), dtype=float)
             return np.where(np.isfinite(vals) & (vals < SENTINEL), vals, np.inf)
         _drive(fits, evaluate_internal)
