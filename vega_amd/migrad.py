@@ -99,9 +99,15 @@ class Transform:
         return 1.
 
 
+_TRIU = {}
+
+
 def _sum_abs_packed(m):
     """Sum of |elements| of the packed upper triangle (Minuit2's sum_of_elements of a symmetric matrix)."""
-    return float(np.abs(m[np.triu_indices(m.shape[0])]).sum())
+    n = m.shape[0]
+    if n not in _TRIU:
+        _TRIU[n] = np.triu_indices(n)
+    return float(np.abs(m[_TRIU[n]]).sum())
 
 
 def _make_posdef(mat):
@@ -361,54 +367,64 @@ class _Fit:
         yy = np.zeros(n)
         vhmat = np.zeros((n, n))
         failed = False
-        for i in range(n):
-            xtf = x[i]
-            dmin = 8. * EPS2 * (abs(xtf) + EPS2)
-            d = max(abs(gst[i]), dmin)
-            for _ in range(self.HESS_NCYCLES):
-                sag = fs1 = fs2 = 0.
-                ok = False
-                for _m in range(5):
-                    pts = np.repeat(x[None, :], 2, axis=0)
-                    pts[0, i] = xtf + d
-                    pts[1, i] = xtf - d
-                    fs1, fs2 = (yield from self._eval(pts))
-                    sag = 0.5 * (fs1 + fs2 - 2. * amin)
-                    if sag > EPS2:
-                        ok = True
-                        break
+        # (the parameters are independent of each other - every trial point differs from x in ONE coordinate - so the steps of all
+        # of them travel together: each parameter keeps Minuit's own sequence of step sizes and stops on its own criteria)
+        dmin = np.array([8. * EPS2 * (abs(x[i]) + EPS2) for i in range(n)])
+        d = np.maximum(np.abs(gst), dmin)
+        open_ = list(range(n))              # parameters whose step adaptation goes on
+        cyc = np.zeros(n, dtype=int)
+        mult = np.zeros(n, dtype=int)       # widening attempts of the current cycle
+        while open_ and not failed:
+            pts = np.repeat(x[None, :], 2 * len(open_), axis=0)
+            for q, i in enumerate(open_):
+                pts[2 * q, i] = x[i] + d[i]
+                pts[2 * q + 1, i] = x[i] - d[i]
+            vals = yield from self._eval(pts)
+            nxt = []
+            for q, i in enumerate(open_):
+                fs1, fs2 = vals[2 * q], vals[2 * q + 1]
+                sag = 0.5 * (fs1 + fs2 - 2. * amin)
+                if not sag > EPS2:
+                    # flat or negative curvature at this step: widen it (at most five times per cycle)
+                    mult[i] += 1
                     if self.trafo.has_limits(i):
-                        if d > 0.5:
+                        if d[i] > 0.5 or mult[i] >= 5:
+                            failed = True
                             break
-                        d *= 10.
-                        if d > 0.5:
-                            d = 0.51
-                        continue
-                    d *= 10.
-                if not ok:
-                    failed = True
-                    break
+                        d[i] *= 10.
+                        if d[i] > 0.5:
+                            d[i] = 0.51
+                    else:
+                        if mult[i] >= 5:
+                            failed = True
+                            break
+                        d[i] *= 10.
+                    nxt.append(i)
+                    continue
+                mult[i] = 0
                 g2bfor = g2[i]
-                g2[i] = 2. * sag / (d * d)
-                grd[i] = (fs1 - fs2) / (2. * d)
-                gst[i] = d
-                dirin[i] = d
+                g2[i] = 2. * sag / (d[i] * d[i])
+                grd[i] = (fs1 - fs2) / (2. * d[i])
+                gst[i] = d[i]
+                dirin[i] = d[i]
                 yy[i] = fs1
-                dlast = d
-                d = math.sqrt(2. * aimsag / abs(g2[i]))
+                dlast = d[i]
+                dn = math.sqrt(2. * aimsag / abs(g2[i]))
                 if self.trafo.has_limits(i):
-                    d = min(0.5, d)
-                if d < dmin:
-                    d = dmin
-                if abs((d - dlast) / d) < self.HESS_STEP_TOL:
-                    break
-                if abs((g2[i] - g2bfor) / g2[i]) < self.HESS_G2_TOL:
-                    break
-                d = min(d, 10. * dlast)
-                d = max(d, 0.1 * dlast)
-            if failed:
-                break
-            vhmat[i, i] = g2[i]
+                    dn = min(0.5, dn)
+                if dn < dmin[i]:
+                    dn = dmin[i]
+                cyc[i] += 1
+                done = abs((dn - dlast) / dn) < self.HESS_STEP_TOL or abs((g2[i] - g2bfor) / g2[i]) < self.HESS_G2_TOL \
+                    or cyc[i] >= self.HESS_NCYCLES
+                if done:
+                    vhmat[i, i] = g2[i]
+                    continue
+                dn = min(dn, 10. * dlast)
+                dn = max(dn, 0.1 * dlast)
+                d[i] = dn
+                nxt.append(i)
+            open_ = nxt
         if failed:
             return dict(state, hesse_failed=True, fval=amin)
         # refine the first derivatives (HessianGradientCalculator)
