@@ -642,7 +642,7 @@ def main():
             exact_mu = {'value': B * args.steps / dt, 'unit': 'evals/s', 'ms_per_step': dt / args.steps * 1e3,
                         'max_rel_chi2_diff_vs_node_rule': rel,
                         'note': 'mu sums as the plain 1000-point loop (vmx_set_mu_quadrature(0)); `value` uses the '
-                                '276-node rule that reproduces those sums to ~1e-13'}
+                                '178-node rule that reproduces those sums to ~1e-13'}
         eng.set_mu_quadrature(True)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -669,7 +669,7 @@ def main():
         def roofline_for(kclass, ms_per_launch):
             if kclass == 'pk_multipoles':
                 # (k, mu) points the stage evaluates per walker and item: the live wavenumbers of the step (blocks whose
-                # every value underflows are skipped) x the mu nodes of each - 276 where the node rule applies, 1000 above
+                # every value underflows are skipped) x the mu nodes of each - 178 where the node rule applies, 1000 above
                 k_live, k_node_max, n_nodes, k_rule, level = pk_state
                 points = float(np.where(np.arange(int(k_live)) < k_rule, n_nodes, 1000).sum())
                 per_point = FLOPS_PER_POINT_TAB2 if level >= 2 else FLOPS_PER_POINT

@@ -322,10 +322,11 @@ int vmx_marg_coeff(vmx_engine* e, int32_t item, double* out, int32_t B);
 
 /* The mu sums of the P(k,mu) stage.  The reference sums P(k,mu) L_ell(mu) over 1000 midpoints in mu
  * (power_spectrum.py:76-77, pktoxi.py:138).  node_rule != 0 (the default): for wavenumbers up to 24 / (largest bin size)
- * the engine evaluates the first 96 and the last 96 of those midpoints and 84 fixed nodes in between - two 32-point
- * Gauss-Legendre panels for the integral plus one-sided finite-difference stencils for the h^2 and h^4 end corrections of
- * the Euler-Maclaurin formula - which reproduces the 1000-point sums, not the integral, to <= 1.2e-13 of the largest
- * k^3 P_ell over the tested parameter ranges (tests/test_mu_quadrature.py); larger wavenumbers, and the model options
+ * the engine evaluates the first 48 and the last 48 of those midpoints and 82 fixed nodes in between - two 32-point
+ * Gauss-Legendre panels for the integral plus ONE one-sided nine-point finite-difference stencil per end for the h^2, h^4
+ * and h^6 end corrections of the Euler-Maclaurin formula - which reproduces the 1000-point sums, not the integral, to
+ * <= 1e-13 of the largest k^3 P_ell over the whole parameter box of vmx_set_mu_rule_box (tests/test_mu_quadrature.py: the
+ * reference's prior limits and wider, corners included); larger wavenumbers, and the model options
  * that are not smooth in mu (exponential smoothing, Voigt / sinc HCD, McDonald), keep the plain loop.  node_rule = 0:
  * the 1000-point loop everywhere (VMX_EXACT_MU in the environment does the same).  Returns the setting in effect. */
 int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule);

@@ -683,8 +683,11 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
     // the plain midpoint loop above it and for the rarely used model options that are not smooth in mu.
     std::vector<double> node_mu, node_w;
     if (n_mu == 1000) {
-        const int lo = 96, hi = 96, panels = 2, ngl = 32;
-        const double h = 1.0 / n_mu, a = lo * h, b = (n_mu - hi) * h, eps1 = 1e-3, eps3 = 2e-3;
+        // (round 3: 48 + 48 kept midpoints, two 32-point panels and ONE nine-point one-sided stencil per end that carries the
+        // first, third and fifth derivative terms of the Euler-Maclaurin formula at once - 178 nodes, 7e-14 of the largest
+        // k^3 M_n over the guard's whole parameter box; round 2's 96 + 96 + 84 with five-point stencils reached 1e-13)
+        const int lo = 48, hi = 48, panels = 2, ngl = 32, npts = 9;
+        const double h = 1.0 / n_mu, a = lo * h, b = (n_mu - hi) * h, eps = 1e-3;
         std::vector<double> gx(ngl), gw(ngl);
         for (int i = 0; i < ngl; ++i) {            // Gauss-Legendre nodes by Newton's iteration on P_ngl
             double x = std::cos(M_PI * (i + 0.75) / (ngl + 0.5)), dp = 1.0;
@@ -702,15 +705,44 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
             const double pa = a + (b - a) * pnl / panels, pb = a + (b - a) * (pnl + 1) / panels;
             for (int i = 0; i < ngl; ++i) { node_mu.push_back(0.5 * (pb - pa) * gx[i] + 0.5 * (pa + pb)); node_w.push_back(0.5 * (pb - pa) * gw[i] / h); }
         }
-        const double c1[5] = {-25.0 / 12, 48.0 / 12, -36.0 / 12, 16.0 / 12, -3.0 / 12};       // Df(x)    ~ sum c1_i f(x + i e) / e
-        const double c3[5] = {-5.0 / 2, 18.0 / 2, -24.0 / 2, 14.0 / 2, -3.0 / 2};              // D^3 f(x) ~ sum c3_i f(x + i e) / e^3
-        const double t1 = h / 24.0, t3 = 7.0 * h * h * h / 5760.0;
-        for (int i = 0; i < 5; ++i) {
-            // backward stencils at b (odd derivatives: - sum c_i f(b - i e) / e^n), forward ones at a
-            node_mu.push_back(b - i * eps1); node_w.push_back(-t1 * (-c1[i] / eps1));
-            node_mu.push_back(a + i * eps1); node_w.push_back(+t1 * (c1[i] / eps1));
-            node_mu.push_back(b - i * eps3); node_w.push_back(+t3 * (-c3[i] / (eps3 * eps3 * eps3)));
-            node_mu.push_back(a + i * eps3); node_w.push_back(-t3 * (c3[i] / (eps3 * eps3 * eps3)));
+        // Finite-difference weights of the derivatives 0 .. 5 at x = 0 on the points 0, 1, .. npts - 1 (Fornberg's recursion):
+        // D^k f(x) ~ sum_i c[i][k] f(x + i e) / e^k
+        constexpr int MD = 5;
+        std::vector<std::vector<double>> c(npts, std::vector<double>(MD + 1, 0.0));
+        {
+            double c1 = 1.0, c4 = 0.0;
+            c[0][0] = 1.0;
+            for (int i = 1; i < npts; ++i) {
+                const int mn = std::min(i, MD);
+                double c2 = 1.0;
+                const double c5 = c4;
+                c4 = (double)i;
+                for (int j = 0; j < i; ++j) {
+                    const double c3 = (double)(i - j);
+                    c2 *= c3;
+                    if (j == i - 1) {
+                        for (int k = mn; k >= 1; --k) c[i][k] = c1 * (k * c[i - 1][k - 1] - c5 * c[i - 1][k]) / c2;
+                        c[i][0] = -c1 * c5 * c[i - 1][0] / c2;
+                    }
+                    for (int k = mn; k >= 1; --k) c[j][k] = (c4 * c[j][k] - k * c[j][k - 1]) / c3;
+                    c[j][0] = c4 * c[j][0] / c3;
+                }
+                c1 = c2;
+            }
+        }
+        // midpoint sum = (1/h) int - (h/24) [Df] + (7 h^3/5760) [D^3 f] - (31 h^5/967680) [D^5 f],  [g] = g(b) - g(a);
+        // backward stencil at b: D^k f(b) ~ -sum_i c[i][k] f(b - i e) / e^k for odd k
+        const double coef[3] = {-h / 24.0, 7.0 * h * h * h / 5760.0, -31.0 * h * h * h * h * h / 967680.0};
+        const int order[3] = {1, 3, 5};
+        for (int i = 0; i < npts; ++i) {
+            double wb = 0.0, wa = 0.0;
+            for (int q = 0; q < 3; ++q) {
+                const double scaled = c[i][order[q]] / std::pow(eps, order[q]);
+                wb += coef[q] * (-scaled);
+                wa += -coef[q] * scaled;
+            }
+            node_mu.push_back(b - i * eps); node_w.push_back(wb);
+            node_mu.push_back(a + i * eps); node_w.push_back(wa);
         }
         e->mu_lo = lo; e->mu_hi = hi;
     }

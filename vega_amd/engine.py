@@ -882,7 +882,7 @@ class Engine:
         return mu, w
 
     def set_mu_quadrature(self, node_rule=True):
-        """True: the node rule that reproduces the reference's 1000-point mu sums from 276 evaluations (default);
+        """True: the node rule that reproduces the reference's 1000-point mu sums from 178 evaluations (default);
         False: the 1000-point loop itself.  Returns the setting in effect."""
         return bool(self._check(self.lib.vmx_set_mu_quadrature(self._h, int(bool(node_rule)))))
 

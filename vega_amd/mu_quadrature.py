@@ -10,20 +10,49 @@ the two differ by ~1e-7, an order of magnitude above the parity bar.  For an int
 
 with h = 1 / n_mu.  The rule keeps the first ``lo`` and the last ``hi`` midpoints as they are (the sharp features of the
 model sit at the ends of the mu range), integrates the middle with ``panels`` Gauss-Legendre panels of ``n_gl`` nodes, and
-forms the two derivative terms with one-sided five-point finite-difference stencils - every piece is a fixed set of nodes
-with fixed weights: ``sum_j W_j mu_j^(2n) P(k, mu_j)`` over 96 + 96 + 84 nodes instead of 1000.
+forms three derivative terms (the formula's next one is - (31 h^5 / 967680) [D^5 f]) with ONE one-sided nine-point
+finite-difference stencil per end - every piece is a fixed set of nodes
+with fixed weights: ``sum_j W_j mu_j^(2n) P(k, mu_j)`` over 48 + 48 + 82 nodes instead of 1000 (round 2: 96 + 96 + 84 with
+five-point stencils and two derivative terms).
 """
 import numpy as np
 
-N_MU, LO, HI, PANELS, N_GL, EPS1, EPS3 = 1000, 96, 96, 2, 32, 1e-3, 2e-3
-# five-point one-sided stencils: f'(x) ~ sum c1_i f(x + i e) / e,  f'''(x) ~ sum c3_i f(x + i e) / e^3
-C1 = np.array([-25., 48., -36., 16., -3.]) / 12.
-C3 = np.array([-5., 18., -24., 14., -3.]) / 2.
+N_MU, LO, HI, PANELS, N_GL, EPS, N_STENCIL = 1000, 48, 48, 2, 32, 1e-3, 9
+# midpoint sum = (1/h) int f - (h/24) [Df] + (7 h^3/5760) [D^3 f] - (31 h^5/967680) [D^5 f] + O(h^7 D^7 f),  [g] = g(b) - g(a)
+EM_ORDERS = (1, 3, 5)
 
 
-def extra_nodes(n_mu=N_MU, lo=LO, hi=HI, panels=PANELS, n_gl=N_GL, eps1=EPS1, eps3=EPS3):
+def em_coefficient(order, h):
+    return {1: -h / 24., 3: 7. * h**3 / 5760., 5: -31. * h**5 / 967680.}[order]
+
+
+def fd_weights(n_points, max_order=5):
+    """c[i][k]: D^k f(x) ~ sum_i c[i][k] f(x + i e) / e^k on the points x, x + e, .., x + (n_points - 1) e (Fornberg's
+    recursion, the same sequence of operations as the engine's host code)."""
+    c = np.zeros((n_points, max_order + 1))
+    c1, c4 = 1.0, 0.0
+    c[0, 0] = 1.0
+    for i in range(1, n_points):
+        mn = min(i, max_order)
+        c2, c5, c4 = 1.0, c4, float(i)
+        for j in range(i):
+            c3 = float(i - j)
+            c2 *= c3
+            if j == i - 1:
+                for k in range(mn, 0, -1):
+                    c[i, k] = c1 * (k * c[i - 1, k - 1] - c5 * c[i - 1, k]) / c2
+                c[i, 0] = -c1 * c5 * c[i - 1, 0] / c2
+            for k in range(mn, 0, -1):
+                c[j, k] = (c4 * c[j, k] - k * c[j, k - 1]) / c3
+            c[j, 0] = c4 * c[j, 0] / c3
+        c1 = c2
+    return c
+
+
+def extra_nodes(n_mu=N_MU, lo=LO, hi=HI, panels=PANELS, n_gl=N_GL, eps=EPS, n_stencil=N_STENCIL):
     """(mu, w) of the nodes that replace the midpoints lo .. n_mu - hi - 1, in the engine's order: the Gauss-Legendre
-    panels, then per stencil point i the four entries (first derivative at b, at a, third derivative at b, at a)."""
+    panels, then per stencil point i the two entries (b - i eps, a + i eps) - ONE one-sided stencil per end carries all the
+    derivative terms."""
     h = 1.0 / n_mu
     a, b = lo * h, (n_mu - hi) * h
     x, wx = np.polynomial.legendre.leggauss(n_gl)
@@ -33,10 +62,15 @@ def extra_nodes(n_mu=N_MU, lo=LO, hi=HI, panels=PANELS, n_gl=N_GL, eps1=EPS1, ep
         pa, pb = a + (b - a) * p / panels, a + (b - a) * (p + 1) / panels
         mu += list(0.5 * (pb - pa) * x + 0.5 * (pa + pb))
         w += list(0.5 * (pb - pa) * wx / h)
-    t1, t3 = h / 24., 7. * h**3 / 5760.
-    for i in range(5):
-        mu += [b - i * eps1, a + i * eps1, b - i * eps3, a + i * eps3]
-        w += [-t1 * (-C1[i] / eps1), t1 * (C1[i] / eps1), t3 * (-C3[i] / eps3**3), -t3 * (C3[i] / eps3**3)]
+    c = fd_weights(n_stencil)
+    for i in range(n_stencil):
+        wb = wa = 0.0
+        for order in EM_ORDERS:
+            scaled = c[i, order] / eps**order
+            wb += em_coefficient(order, h) * (-scaled)          # backward stencil at b (odd derivative: minus)
+            wa += -em_coefficient(order, h) * scaled
+        mu += [b - i * eps, a + i * eps]
+        w += [wb, wa]
     return np.array(mu), np.array(w)
 
 
