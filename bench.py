@@ -350,7 +350,7 @@ def main():
                     help='calibration + warm-up + timed steps only (the command the rocprofv3 summaries in profiles/ use)')
     ap.add_argument('--no-static-metals', action='store_true', help='keep every metal pair on its own pipeline')
     ap.add_argument('--force-dist', action='store_true', help='run the collective path even with one rank')
-    ap.add_argument('--lanes', type=int, default=2, choices=[1, 2],
+    ap.add_argument('--lanes', type=int, default=2, choices=[1, 2, 3, 4],
                     help='batches in flight inside the engine (vmx_set_lanes): with 2, consecutive steps alternate between two '
                          'per-batch workspaces that share every static tensor, and overlap on the GPU')
     args = ap.parse_args()

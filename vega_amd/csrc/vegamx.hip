@@ -142,7 +142,7 @@ struct vmx_engine {
     bool finalized = false;
     // Second lane (vmx_set_lanes): a clone that borrows every static tensor and owns its per-batch workspace and stream;
     // chi2-only device evaluations alternate between the two, so that independent batches overlap on the GPU.
-    vmx_engine* lane = nullptr;
+    std::vector<vmx_engine*> lanes;        // lanes 1 .. n_lanes - 1 (lane 0 is this engine), made on demand
     int n_lanes = 1;
     int64_t lane_calls = 0;
     hipStream_t last_stream = nullptr;      // the stream the last vmx_eval_device ran on
@@ -277,7 +277,8 @@ struct vmx_engine {
     int64_t launches[VMX_N_KERNELS] = {0};
 
     ~vmx_engine() {
-        if (lane) { (void)hipStreamSynchronize(lane->stream); delete lane; lane = nullptr; }
+        for (auto* l : lanes) { (void)hipStreamSynchronize(l->stream); delete l; }
+        lanes.clear();
         for (auto* it : items) delete it;
         for (auto* m : metals) delete m;
         for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -301,12 +302,11 @@ namespace {
 // the host-side state at the moment it is made); the next two-lane evaluation makes a fresh one.
 static void drop_lane(vmx_engine* e)
 {
-    if (!e || !e->lane) return;
-    (void)hipStreamSynchronize(e->lane->stream);
-    delete e->lane;
-    e->lane = nullptr;
+    if (!e) return;
+    for (auto* l : e->lanes) { (void)hipStreamSynchronize(l->stream); delete l; }
+    e->lanes.clear();
 }
-static void wait_lane(vmx_engine* e) { if (e && e->lane) (void)hipStreamSynchronize(e->lane->stream); }
+static void wait_lane(vmx_engine* e) { if (e) for (auto* l : e->lanes) (void)hipStreamSynchronize(l->stream); }
 
 struct ScopedTimer {
     vmx_engine* e; int idx = -1;
@@ -2697,7 +2697,7 @@ static vmx_engine* clone_lane(vmx_engine* e)
 {
     auto* L = new vmx_engine(*e);
     // what the copy must not share (or free)
-    L->lane = nullptr; L->n_lanes = 1; L->lane_calls = 0;
+    L->lanes.clear(); L->n_lanes = 1; L->lane_calls = 0;
     L->stream = nullptr; L->cur = nullptr; L->aux.clear(); L->ev_join.clear(); L->ev_fork = nullptr;
     L->graphs.clear(); L->quad_lists.clear(); L->spans.clear(); L->span_used = 0; L->profiling = false;
     L->pin_theta = nullptr; L->pin_chi2 = nullptr; L->pin_status = nullptr; L->pin_done = nullptr; L->pin_part = nullptr;
@@ -2782,9 +2782,13 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     const bool two_lanes = e->n_lanes > 1 && quad && !d_model && e->blind_scale.empty() && B >= 64 && !e->direct &&
                            !(e->profiling && e->prof_mask == 0xffffffffu);
     if (!two_lanes) wait_lane(e);
-    else if ((e->lane_calls++ & 1) == 1) {
-        if (!e->lane && !(e->lane = clone_lane(e))) return fail(-2, "could not create the second lane");
-        vmx_engine* L = e->lane;
+    else if (const int which = (int)(e->lane_calls++ % e->n_lanes)) {
+        while ((int)e->lanes.size() < which) {
+            vmx_engine* made = clone_lane(e);
+            if (!made) return fail(-2, "could not create another lane");
+            e->lanes.push_back(made);
+        }
+        vmx_engine* L = e->lanes[which - 1];
         L->const_hint = e->const_hint;
         bool lq = false;
         if (quad_ready(L, &lq, B)) return -2;       // (its work lists: the tensors are the borrowed ones)
@@ -2822,9 +2826,9 @@ void* vmx_last_stream(vmx_engine* e) { return e ? (void*)(e->last_stream ? e->la
 
 int vmx_set_lanes(vmx_engine* e, int32_t lanes)
 {
-    REQUIRE(e && e->finalized && (lanes == 1 || lanes == 2), "vmx_set_lanes: 1 or 2 (after vmx_finalize)");
+    REQUIRE(e && e->finalized && lanes >= 1 && lanes <= 4, "vmx_set_lanes: 1 .. 4 (after vmx_finalize)");
     HIP_OK(hipSetDevice(e->device));
-    if (lanes == 1) drop_lane(e);
+    if (lanes < e->n_lanes) drop_lane(e);
     e->n_lanes = lanes;
     e->lane_calls = 0;
     return 0;
@@ -2952,7 +2956,7 @@ int vmx_sync(vmx_engine* e)
     REQUIRE(e, "vmx_sync");
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->stream));
-    if (e->lane) HIP_OK(hipStreamSynchronize(e->lane->stream));
+    for (auto* l : e->lanes) HIP_OK(hipStreamSynchronize(l->stream));
     if (e->profiling) collect_spans(e);
     if (e->gemm_trace.p && e->gemm_trace_blocks && (getenv("VMX_GEMM_TRACE") || getenv("VMX_QUAD_TRACE"))) {
         std::vector<unsigned long long> h(4 * e->gemm_trace_blocks);

@@ -2369,8 +2369,7 @@ __device__ __forceinline__ double dpp_row_rotate(double v)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-// v of lane (l ^ MASK), MASK < 32: ds_swizzle in bit mode - an LDS-crossbar instruction (no LDS memory, no VALU slot; fp64
-// VALU instructions take no DPP modifier, so a DPP exchange of a double costs two v_mov_b32 on the VALU)
+// v of lane (l ^ MASK), MASK < 32: ds_swizzle in bit mode - an LDS-crossbar instruction (no LDS memory, no VALU slot)
 template <int MASK>
 __device__ __forceinline__ double lane_xor(double v)
 {
@@ -2380,12 +2379,35 @@ __device__ __forceinline__ double lane_xor(double v)
     hi = __builtin_amdgcn_ds_swizzle(hi, (MASK << 10) | 0x1f);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// A DPP move of a double: two v_mov_b32 with a lane-select modifier (fp64 VALU instructions take none themselves).  The
+// reductions below take these, not ds_swizzle: a swizzle answers after an LDS round trip and the compiler waits for each
+// one before the add that needs it - a chain of 72 per walker row made the contraction epilogue 5.6 us long; the DPP moves
+// are plain VALU instructions with a two-cycle hazard.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const long long bits = __builtin_bit_cast(long long, v);
+    int lo = (int)bits, hi = (int)(bits >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 16 lanes of a row, the total in every lane: row rotations by 8 and 4 (after the first step lanes l and
+// l ^ 8 agree, so rotating by 4 adds the same value as l ^ 4 would), then the quad permutations [2,3,0,1] and [1,0,3,2]
+// - bit for bit the butterfly v += v[l^8]; v += v[l^4]; v += v[l^2]; v += v[l^1]
+__device__ __forceinline__ double row_sum16(double v)
+{
+    v += dpp_move<0x128>(v);        // row_ror:8
+    v += dpp_move<0x124>(v);        // row_ror:4
+    v += dpp_move<0x4e>(v);         // quad_perm:[2,3,0,1]
+    return v + dpp_move<0xb1>(v);   // quad_perm:[1,0,3,2]
+}
 // the four K-quarter partial sums of an accumulator sit in the lane groups b = (lane >> 2) & 3 of a 16-lane row: two
-// butterfly steps leave their sum in every lane - (v_b + v_{b^2}) + (v_{b^1} + v_{b^3}), the same value in all four
+// steps leave their sum in every lane - (v_b + v_{b^2}) + (v_{b^1} + v_{b^3}), the same value in all four
 __device__ __forceinline__ double sum_k_quarters(double v)
 {
-    v += lane_xor<8>(v);
-    return v + lane_xor<4>(v);
+    v += dpp_move<0x128>(v);
+    return v + dpp_move<0x124>(v);
 }
 
 #ifndef GEMM44_THREADS
@@ -2699,7 +2721,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
                     }
                 }
                 // the 16 lanes of a row (same walker): total in every lane
-                sum += lane_xor<8>(sum); sum += lane_xor<4>(sum); sum += lane_xor<2>(sum); sum += lane_xor<1>(sum);
+                sum = row_sum16(sum);
                 if (c == 0) c_part[((size_t)c_slot * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = n < c_N ? sum : 0.0;
             }
             continue;
