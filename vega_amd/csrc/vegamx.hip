@@ -227,6 +227,7 @@ struct vmx_engine {
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
     bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
+    bool ring_allowed = true;        // one batch in flight only: a 128 KB block leaves the other lane's kernels no room on its CU
     bool no_small_tab = false;       // VMX_NO_SMALL_TAB: batches below 16 walkers never use the tables
     int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
     bool no_tab2 = false;            // VMX_NO_TAB2: level-1 tables only (the Gaussian factors stay in the mu loop)
@@ -527,7 +528,7 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
                 // pace (B = 256: 49 -> 44 us).  With fewer tiles its slower dispatch (128 KB of LDS per block) costs more than
                 // it gains (B = 64: 32 -> 35 us); with more, two resident two-buffer blocks hide each other's latencies better
                 // (B = 1024: 103 -> 138 us).  The live rows are device data: a third of the operator's rows is the estimate.
-                if (e->fft_ring && G.n == 1 && G.p[0].m_window) {
+                if (e->fft_ring && e->ring_allowed && G.n == 1 && G.p[0].m_window) {
                     const int64_t est = (int64_t)G.p[0].tn * nbatch * ((G.p[0].tm * 3 + 9) / 10);
                     if (est < 160 || est > 320) { hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G); break; }
                     constexpr size_t ring_bytes = (size_t)4 * (GEMM_BM + GEMM_BN) * GEMM_BK * sizeof(double);
@@ -2830,6 +2831,9 @@ int vmx_set_lanes(vmx_engine* e, int32_t lanes)
     HIP_OK(hipSetDevice(e->device));
     if (lanes < e->n_lanes) drop_lane(e);
     e->n_lanes = lanes;
+    // (the four-stage ring of the FFTLog product wins 5 us when its launch has the chip to itself; with two batches in flight
+    // its 128 KB blocks keep the other lane's kernels off their CUs: 831k against 849k evaluations / s at B = 256)
+    e->ring_allowed = lanes == 1;
     e->lane_calls = 0;
     return 0;
 }
