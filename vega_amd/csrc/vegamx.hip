@@ -127,6 +127,7 @@ struct ItemHost {
     int64_t csr_nnz = 0; bool has_csr = false;
     std::vector<int32_t> mask_idx;
     bool has_dm = false, has_cinv = false, has_mask = false, has_data = false;
+    bool lean_pair = false;             // k_xi_quad_plain applies: plain_pair, or that but for a radiation term on the smooth component
 };
 
 }  // namespace
@@ -227,6 +228,7 @@ struct vmx_engine {
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
     bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
+    int xi_plain_nw = 2;             // walkers per thread of k_xi_quad_plain (VMX_XI_PLAIN_NW: 0 = the general kernel, 1, 2, 4)
     bool ring_allowed = true;        // one batch in flight only: a 128 KB block leaves the other lane's kernels no room on its CU
     bool no_small_tab = false;       // VMX_NO_SMALL_TAB: batches below 16 walkers never use the tables
     int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
@@ -1262,6 +1264,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_FFT_RING")) e->fft_ring = false;
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
+    if (const char* v = getenv("VMX_XI_PLAIN_NW")) e->xi_plain_nw = atoi(v);
     if (const char* v = getenv("VMX_ITEM_STREAMS")) e->item_streams = atoi(v) != 0;
     if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
@@ -2072,6 +2075,27 @@ static int run_items_forked(vmx_engine* e, const EngineDev& D, int B)
     return 0;
 }
 
+// k_xi_quad_plain serves items that are plain peak / smooth pairs without additive template or pre-distortion broadband
+static bool xi_plain_args(vmx_engine* e, XiPlainArgs& A)
+{
+    if (e->items.size() > VMX_MAX_GROUP || e->extrapolate || e->direct) return false;
+    for (size_t q = 0; q < e->items.size(); ++q) {
+        const ItemHost* it = e->items[q];
+        const ItemDev& d = it->dev;
+        if (!it->lean_pair || d.add_vec || d.n_bb[VMX_BB_PRE_MUL] || d.n_bb[VMX_BB_PRE_ADD]) return false;
+        const PipeDev& Ps = e->pipes[d.d.pipe_smooth];
+        const PipeDev& Pp = e->pipes[d.d.pipe_peak];
+        if (Ps.d.n_ell != Pp.d.n_ell || Ps.d.single_ell >= 0 || Pp.d.single_ell >= 0 || Ps.col < 0 || Pp.col < 0) return false;
+        XiPlainItem& I = A.it[q];
+        I.coord_off = Pp.coord_off; I.q_x0 = it->q_x0.p; I.q_x = it->q_x.p;
+        I.n_model = d.d.n_model; I.nq = d.nq; I.nq_pad = d.nq_pad; I.pipe_s = d.d.pipe_smooth; I.pipe_p = d.d.pipe_peak;
+        I.col_s = Ps.col; I.col_p = Pp.col; I.n_ell = Ps.d.n_ell; I.split_evol = Pp.split_evol; I.bao_slot = d.d.bao_amp_slot;
+        I.item = (int32_t)q;
+        I.radiation = Ps.d.radiation;
+    }
+    return true;
+}
+
 static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
                      double* d_chi2 = nullptr, int32_t* d_status = nullptr, bool quad = false,
                      const double* theta_by_value = nullptr)
@@ -2227,6 +2251,14 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         ScopedTimer t(e, KC_XI);
         int max_nq = 0;
         for (auto* it : e->items) max_nq = std::max(max_nq, (int)it->dev.nq_pad);
+        XiPlainArgs XA{};
+        const int nw = e->xi_plain_nw;
+        if (B > 8 && nw > 0 && xi_plain_args(e, XA)) {
+            const unsigned ni = (unsigned)e->items.size();
+            if (nw >= 4) hipLaunchKernelGGL(k_xi_quad_plain<4>, dim3((max_nq + 255) / 256, (B + 3) / 4, ni), dim3(256), 0, e->stream, D, XA, 0, B);
+            else if (nw == 2) hipLaunchKernelGGL(k_xi_quad_plain<2>, dim3((max_nq + 255) / 256, (B + 1) / 2, ni), dim3(256), 0, e->stream, D, XA, 0, B);
+            else hipLaunchKernelGGL(k_xi_quad_plain<1>, dim3((max_nq + 255) / 256, B, ni), dim3(256), 0, e->stream, D, XA, 0, B);
+        } else
         hipLaunchKernelGGL(k_xi_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, 0, B <= 8 ? 1 : 0);
     } else {
         ScopedTimer t(e, KC_XI);
@@ -2585,18 +2617,21 @@ static int quad_build(vmx_engine* e)
         {
             // k_xi_assemble_quad's lean path: both components are plain spline sums with the standard bias evolution
             bool plain = d.d.pipe_peak != d.d.pipe_smooth && !getenv("VMX_NO_PLAIN_PAIR");
+            bool lean = plain;
             for (int pq : {d.d.pipe_peak, d.d.pipe_smooth}) {
                 const PipeDev& P = e->pipes[pq];
-                if (P.d.tracer[0].evol_kind != VMX_EVOL_STD || P.d.tracer[1].evol_kind != VMX_EVOL_STD || P.d.radiation ||
-                    P.d.uv_shotnoise || P.odd_rel || P.odd_asy || P.poly_basis >= 0) plain = false;
+                if (P.d.tracer[0].evol_kind != VMX_EVOL_STD || P.d.tracer[1].evol_kind != VMX_EVOL_STD ||
+                    P.d.uv_shotnoise || P.odd_rel || P.odd_asy || P.poly_basis >= 0) { plain = false; lean = false; }
+                if (P.d.radiation) plain = false;
             }
             // ... on the same bins (each pipeline carries its own copy of the coordinates)
             const PipeDev& Pp = e->pipes[d.d.pipe_peak];
             const PipeDev& Ps = e->pipes[d.d.pipe_smooth];
-            if (Pp.split_evol != Ps.split_evol || Pp.n != Ps.n) plain = false;
+            if (Pp.split_evol != Ps.split_evol || Pp.n != Ps.n) { plain = false; lean = false; }
             for (const std::vector<double>* h : {&e->h_r, &e->h_mu_c, &e->h_lnrelz, &e->h_lnrelz2, &e->h_growth})
-                if (plain && std::memcmp(h->data() + Pp.coord_off, h->data() + Ps.coord_off, (size_t)Pp.n * sizeof(double)) != 0) plain = false;
+                if ((plain || lean) && std::memcmp(h->data() + Pp.coord_off, h->data() + Ps.coord_off, (size_t)Pp.n * sizeof(double)) != 0) { plain = false; lean = false; }
             d.plain_pair = plain ? 1 : 0;
+            it->lean_pair = lean;
         }
         const int nq = d.nq, nqp = d.nq_pad;
         // reference vector x0' = [vec(theta_ref) ; (1 + bao) c_j(theta_ref)]

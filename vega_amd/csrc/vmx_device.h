@@ -3281,6 +3281,131 @@ __global__ __launch_bounds__(256) void k_xi_assemble_quad(EngineDev D, int item0
     it.q_x[(size_t)b * it.nq_pad + i] = v;
 }
 
+// The same for the common case, lean: every item a plain peak / smooth pair (ItemDev::plain_pair) without additive template or
+// pre-distortion broadband, large chi2-only batch.  What the kernel needs of an item travels in its ARGUMENTS (no descriptor
+// load ahead of the first coordinate load), and a thread evaluates its bin for NW walkers: the bin's coordinates, evolution
+// logarithm, growth factor and reference entry are loaded once, and the walkers' independent chains (logarithm -> knot index
+// -> 16 coefficient loads -> spline and Legendre sums) hide each other's latencies.  grid = (bins, ceil(B / NW), items).
+struct XiPlainItem { int64_t coord_off; const double* q_x0; double* q_x; int32_t n_model, nq, nq_pad, pipe_s, pipe_p, col_s, col_p,
+                     n_ell, split_evol, bao_slot, item, radiation; };     // radiation: of the smooth component (0, 1, 2 = rescaled coordinates)
+struct XiPlainArgs { XiPlainItem it[VMX_MAX_GROUP]; };
+
+// cubic B-spline multipoles of one (walker, pipeline) at ln r' = x, Legendre-summed at mu' = rmu (pktoxi.py:144-162)
+__device__ __forceinline__ double xi_plain_spline(const EngineDev& D, const double* coef_col, size_t ell_stride, int n_ell, double x,
+                                                  double rmu, bool& oob)
+{
+    const double* cf[4];
+    double tt[4];
+    bool on[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ee = e < n_ell ? e : 0;
+        const bool inside = !(x < D.x0[ee] || x > D.xlast[ee]);     // VegaBoundsError (pktoxi.py:149-152)
+        on[e] = e < n_ell && inside;
+        if (e < n_ell && !inside) oob = true;
+        const double u = (x - D.x0[ee]) * D.inv_h[ee];
+        int j = (int)floor(u);
+        if (j < 0) j = 0;
+        if (j > D.n_coef - 4) j = D.n_coef - 4;
+        if (!(u == u)) j = 0;
+        tt[e] = u - (double)j;
+        cf[e] = coef_col + (size_t)ee * ell_stride + j;
+    }
+    double tap[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tap[e][q] = cf[e][q];
+    double xi = 0.0;
+    const double x2 = rmu * rmu;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double t = tt[e], t2 = t * t, t3 = t2 * t;
+        const double omt = 1.0 - t;
+        const double w0 = omt * omt * omt;
+        const double w1 = 3.0 * t3 - 6.0 * t2 + 4.0;
+        const double w2 = -3.0 * t3 + 3.0 * t2 + 3.0 * t + 1.0;
+        const double sp = (tap[e][0] * w0 + tap[e][1] * w1 + tap[e][2] * w2 + tap[e][3] * t3) * (1.0 / 6.0);
+        const double leg = e == 0 ? 1.0 : e == 1 ? 0.5 * (3.0 * x2 - 1.0) : e == 2 ? 0.125 * ((35.0 * x2 - 30.0) * x2 + 3.0)
+                                        : 0.0625 * (((231.0 * x2 - 315.0) * x2 + 105.0) * x2 - 5.0);
+        if (on[e]) xi += sp * leg;
+    }
+    return xi;
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void k_xi_quad_plain(EngineDev D, XiPlainArgs A, int item0, int B)
+{
+    const XiPlainItem& I = A.it[item0 + blockIdx.z];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= I.nq_pad) return;
+    const int b0 = blockIdx.y * NW;
+    if (i >= I.n_model) {
+        // the additive post-distortion broadband coefficients (and the zero padding behind them)
+        const ItemDev& it = D.items[I.item];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int b = b0 + w;
+            if (b >= B) break;
+            const double* t = D.theta + (size_t)b * D.n_params;
+            double v = 0.0;
+            if (i < I.nq) v = (1.0 + t[I.bao_slot]) * t[it.q_slot[i - I.n_model]] - I.q_x0[i];
+            I.q_x[(size_t)b * I.nq_pad + i] = v;
+        }
+        return;
+    }
+    const size_t c = (size_t)I.coord_off + i;
+    const double r = D.cr[c], rp0 = D.crp[c], rt0 = D.crt[c], lnz = D.clnrelz[c], growth = D.cgrowth[c], x0v = I.q_x0[i];
+    const double lnz2 = I.split_evol ? D.clnrelz2[c] : 0.0;
+    const size_t ncols = (size_t)B * D.n_active, ell_stride = ncols * D.ncp;
+    double out[NW];
+    bool oob[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int b = min(b0 + w, B - 1);           // (a surplus walker slot shadows the last walker and stores nothing)
+        const double* scs = D.scal + ((size_t)b * D.n_pipe + I.pipe_s) * VMX_NS;
+        const double* scp = D.scal + ((size_t)b * D.n_pipe + I.pipe_p) * VMX_NS;
+        const double ev = (I.split_evol ? vmx_exp(fma(scp[S_EV1A], lnz, scp[S_EV2A] * lnz2)) : vmx_exp((scp[S_EV1A] + scp[S_EV2A]) * lnz)) * growth;
+        double xs = 0.0, xp = 0.0;
+        oob[w] = false;
+        if (r != 0.0) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const double* sc = half ? scp : scs;
+                const double rrp = sc[S_AP] * (rp0 + sc[S_DRP]), rrt = sc[S_AT] * rt0;
+                const double rr2 = fma(rrp, rrp, rrt * rrt);
+                if (rr2 != 0.0) {
+                    const double* col = D.coef + ((size_t)(half ? I.col_p : I.col_s) * B + b) * D.ncp;
+                    const double v = xi_plain_spline(D, col, ell_stride, I.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), oob[w]);
+                    if (half) xp = v * ev; else xs = v * ev;
+                }
+            }
+        }
+        if (I.radiation) {
+            // QSO radiation on the smooth component (correlation_func.py:446-489), as xi_bin_value forms it
+            const bool resc = I.radiation == 2;
+            const double drp = scs[S_DRP];
+            const double rp = resc ? fma(scs[S_AP], rp0 + drp, drp) : rp0 + drp;
+            const double rtr = resc ? scs[S_AT] * rt0 : rt0;
+            const double rs2 = fma(rp, rp, rtr * rtr);
+            const double irs = vmx_rsqrt(rs2);
+            const double rs = rs2 * irs, ms = rp * irs;
+            double xr = scs[S_RAD_S] * (irs * irs) * (1.0 - scs[S_RAD_A] * (1.0 - ms * ms));
+            xr *= vmx_exp(-rs * fma(1.0 + ms, scs[S_RAD_IL], scs[S_RAD_ID]));
+            xs += xr;
+        }
+        const double bao = D.theta[(size_t)b * D.n_params + I.bao_slot];
+        out[w] = fma(bao, xp, xs) - x0v;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int b = b0 + w;
+        if (b >= B) break;
+        if (oob[w]) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
+        I.q_x[(size_t)b * I.nq_pad + i] = out[w];
+    }
+}
+
 // chi2 = sum_items diff^T (C^-1 diff) + priors; sentinel on failure
 // (1024 threads per walker: the kernel is a bandwidth-bound reduction with one block per walker)
 __global__ __launch_bounds__(CHI2_THREADS) void k_chi2(EngineDev D, int B, SlabInfo slabs)
