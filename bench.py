@@ -727,11 +727,11 @@ def main():
         roofline = roofline_for(roof_class, live[roof_class]['ms_per_launch'])
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of `bench.py --core-only` (a counter pass
         # cannot run inside this process): the committed summary of the latest collection is attached when present
-        traffic_file = REPO / 'profiles' / 'r02_bench_core_traffic.json'
+        traffic_file = REPO / 'profiles' / 'r03_bench_core_traffic.json'
         traffic = json.loads(traffic_file.read_text())['kernels'] if traffic_file.exists() else {}
         if roofline is not None and roof_class in traffic and args.workload == 'joint' and B == 256:
             roofline['traffic'] = traffic[roof_class]['hbm_bytes_per_launch']
-            roofline['traffic_unit'] = 'bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r02_bench_core_traffic.json)'
+            roofline['traffic_unit'] = 'bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r03_bench_core_traffic.json)'
             roofline['algorithmic_bytes_per_launch'] = traffic[roof_class]['algorithmic_bytes_per_launch']
         if roofline is not None:
             roofline['launches_timed'] = live[roof_class]['launches']

@@ -19,7 +19,7 @@ CLASSES = {
     'invcov_product': ('k_gemm_nt<64, 64, 32, 8>', sum(8 * m * n / 2 + 8 * B * (m + n) for m, n in SHAPES_COV)),
     'fftlog_spline_product': ('k_gemm_nt44<2,', None),
     'pk_multipoles': ('k_pk_tab2', None),
-    'xi_bins': ('k_xi_assemble_quad', None),
+    'xi_bins': ('k_xi_quad_plain', None),
     'chi2': ('k_chi2_parts', None),
 }
 

@@ -1811,10 +1811,12 @@ static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item
         std::vector<int32_t> next(n_groups, 0);
         for (auto& en : entries) en.w.slot = next[en.w.nt / gs]++;          // (rank within the group: + nt_off[nt] per member)
     }
-    // queues: block p = 8 i + xcd is member i / (P / 8 / gs) of the group that takes piece xcd * (P / 8 / gs) + i % (P / 8 / gs).
-    // (NOT member i % gs: the dispatcher fills a CU's two block slots with consecutive blocks of an XCD, and two members of one
-    // group reach their fill and epilogue phases together - the CU's MFMA pipes then idle through every one of them, ~10 us per
-    // entry.  Neighbours from different groups are out of phase and cover each other.)
+    // queues: block p = 8 i + xcd is member i % gs of the group that takes piece xcd * (P / 8 / gs) + i / gs: the members of a
+    // group are neighbouring blocks of one XCD (the dispatcher hands them to one or two CUs), start together and stay close
+    // - 496 MB of L2 misses per launch at B = 256 and 149.7 us.  Spreading a group's members over the XCD's CUs (member =
+    // i / (P / 8 / gs): co-resident blocks then belong to different groups and are out of phase) was meant to keep the MFMA
+    // pipes busy through the epilogues; measured: 616 MB and 153.4 us - the members drift apart and the matrix tile is fetched
+    // again.  VMX_QUAD_DEPHASE=1 selects that mapping.
     std::vector<int32_t> queue(P + 1, 0);
     std::vector<std::vector<GemmWork>> by_piece(n_pieces);
     for (auto& en : entries) by_piece[en.piece].push_back(en.w);
@@ -1822,8 +1824,9 @@ static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item
     work.reserve(entries.size() * gs);
     for (int p = 0; p < P; ++p) {
         const int xcd = p % 8, i = p / 8, per_xcd = P / 8 / gs;
-        const int member = getenv("VMX_QUAD_INPHASE") ? i % gs : i / per_xcd;
-        const int pcs = xcd * per_xcd + (getenv("VMX_QUAD_INPHASE") ? i / gs : i % per_xcd);
+        const bool dephase = getenv("VMX_QUAD_DEPHASE") != nullptr;
+        const int member = dephase ? i / per_xcd : i % gs;
+        const int pcs = xcd * per_xcd + (dephase ? i % per_xcd : i / gs);
         queue[p] = (int32_t)work.size();
         for (auto w : by_piece[pcs]) {
             w.nt += member;
