@@ -229,6 +229,7 @@ struct vmx_engine {
     bool host_key_valid = false, skip_xtab_once = false;
     bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
     int xi_plain_nw = 2;             // walkers per thread of k_xi_quad_plain (VMX_XI_PLAIN_NW: 0 = the general kernel, 1, 2, 4)
+    bool fft_narrow = true;          // VMX_NO_FFT_NARROW: never the 64 x 32 tiles for the FFTLog product
     bool ring_allowed = true;        // one batch in flight only: a 128 KB block leaves the other lane's kernels no room on its CU
     bool no_small_tab = false;       // VMX_NO_SMALL_TAB: batches below 16 walkers never use the tables
     int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
@@ -521,7 +522,7 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
             case KC_METAL: hipLaunchKernelGGL((k_gemm_nt44<KC_METAL>), grid, block, 0, e->cur, G); break;
             case KC_FFTLOG:
                 if (getenv("VMX_GEMM_TRACE")) {
-                    e->gemm_trace_blocks = (size_t)grid.x * grid.y;
+                    e->gemm_trace_blocks = (size_t)2 * grid.x * grid.y;       // (the 64 x 32 tiling has up to twice the blocks)
                     if (e->gemm_trace.n < 4 * e->gemm_trace_blocks) (void)e->gemm_trace.alloc(4 * e->gemm_trace_blocks, true);
                     else (void)hipMemsetAsync(e->gemm_trace.p, 0, 4 * e->gemm_trace_blocks * sizeof(unsigned long long), e->cur);
                     const_cast<GemmGroup&>(G).trace = e->gemm_trace.p;
@@ -530,6 +531,22 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
                 // pace (B = 256: 49 -> 44 us).  With fewer tiles its slower dispatch (128 KB of LDS per block) costs more than
                 // it gains (B = 64: 32 -> 35 us); with more, two resident two-buffer blocks hide each other's latencies better
                 // (B = 1024: 103 -> 138 us).  The live rows are device data: a third of the operator's rows is the estimate.
+                if (e->fft_narrow && G.n == 1 && G.p[0].m_window && G.p[0].nsplit == 1 && !G.p[0].tri) {
+                    // about one live 64 x 64 tile per CU (the operator's live rows are device data: a third of them is the
+                    // estimate): 64 x 32 tiles instead - twice the blocks, two per CU, each covering the other's bubbles
+                    const int64_t est = (int64_t)G.p[0].tn * nbatch * ((G.p[0].tm * 3 + 9) / 10);
+                    if (est >= 96 && est <= 384) {
+                        GemmGroup G2 = G;
+                        const int tn32 = (G.p[0].N + 31) / 32;
+                        G2.p[0].tn = tn32;
+                        const dim3 grid2(8 * G.p[0].tm * ((tn32 + 7) / 8), nbatch);
+                        // (+ 24 KB of unused dynamic LDS: 72 KB per block = two per CU.  With its own 48 KB the dispatcher packs three
+                        // blocks on a CU before it moves on and leaves a third of the CUs empty.)
+                        const size_t pad = getenv("VMX_FFT_NARROW_PAD") ? (size_t)atoi(getenv("VMX_FFT_NARROW_PAD")) : 24 * 1024;
+                        hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG, 2, 32>), grid2, block, pad, e->cur, G2);
+                        break;
+                    }
+                }
                 if (e->fft_ring && e->ring_allowed && G.n == 1 && G.p[0].m_window) {
                     const int64_t est = (int64_t)G.p[0].tn * nbatch * ((G.p[0].tm * 3 + 9) / 10);
                     if (est < 160 || est > 320) { hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G); break; }
@@ -1262,6 +1279,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_SMALL_TAB")) e->no_small_tab = true;
     if (getenv("VMX_NO_PK_W")) e->no_pk_w = true;
     if (getenv("VMX_NO_FFT_RING")) e->fft_ring = false;
+    if (getenv("VMX_NO_FFT_NARROW")) e->fft_narrow = false;
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
     if (const char* v = getenv("VMX_XI_PLAIN_NW")) e->xi_plain_nw = atoi(v);

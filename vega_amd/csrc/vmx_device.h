@@ -2208,6 +2208,12 @@ __device__ __forceinline__ void lds_wait(double (&a)[4], double (&b)[8])
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
                    "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
 }
+__device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
 __device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
 {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -2435,13 +2441,20 @@ __device__ __forceinline__ double sum_k_quarters(double v)
 // NBUF = 2 (above) relies on a second resident block to cover the latency of its loads.  A launch with fewer tiles than
 // twice the CUs (the FFTLog product: ~256 tiles of 18 stages) gets NBUF = 4: a ring of four stage buffers in 128 KB of
 // dynamic LDS - one block per CU, loads three and a half stages ahead, counted waits (vmcnt) for the oldest stage only.
-template <int TAG, int NBUF = 2>
+// BNT = 32 (four waves only): block tile 64 matrix rows x 32 walkers, wave tiles 32 x 16 - half the MFMA work per stage and
+// 48 KB of LDS per block.  For launches with about one 64 x 64 tile per CU (the FFTLog product at B = 256: 256 live tiles of
+// 18 stages) it doubles the blocks, so that every CU holds two and each fills the other's barrier and latency bubbles.
+template <int TAG, int NBUF = 2, int BNT = 64>
 __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 1) void k_gemm_nt44(GemmGroup G)
 {
-    constexpr int BM = 64, BN = 64, BK = 32;
+    constexpr int BM = 64, BN = BNT, BK = 32;
     constexpr int NT = GEMM44_THREADS, NW = NT / 64;
+    static_assert(BN == 64 || (BN == 32 && NT == 256 && NBUF == 2), "the 32-walker tile exists for the four-wave, two-buffer kernel");
     constexpr int FJ = 4 * 256 / NT * 2;    // A fragments per wave: 8 (4 waves, 32 x 32 wave tiles) or 4 (8 waves, 32 x 16)
-    constexpr int NP = 16 / NW;             // DMA instructions per wave, operand and stage (each fills 4 rows)
+    constexpr int NI = BN == 64 ? 8 : 4;    // X fragments per wave (4 walkers each)
+    constexpr int AR = BN == 64 ? 1 : 2;    // A fragments read per X fragment in the interleaved read / MFMA steps
+    constexpr int NP = 16 / NW;             // DMA instructions per wave and stage for the matrix operand (each fills 4 rows)
+    constexpr int NPX = BN / 4 / NW;        // ... for the walker operand
     __shared__ double sA_static[NBUF == 2 ? 2 : 1][NBUF == 2 ? BM * BK : 1];
     __shared__ double sX_static[NBUF == 2 ? 2 : 1][NBUF == 2 ? BN * BK : 1];
     extern __shared__ double s_ring[];          // NBUF > 2: [NBUF][BM * BK] A stages, then [NBUF][BN * BK] X stages
@@ -2456,7 +2469,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     };
     // contraction epilogue of the quadratic form (GemmArgs::part): the linear term's row over the tile's own rows; the
     // walker vectors over those rows follow by DMA into the stage buffer that falls free first (see the K loop)
-    constexpr bool QUAD = TAG == VMX_TAG_QUAD && NT == 256 && NBUF == 2;
+    constexpr bool QUAD = TAG == VMX_TAG_QUAD && NT == 256 && NBUF == 2 && BN == 64;
     __shared__ double sL[QUAD ? 2 * BM : 1];
 
     const bool list = G.work != nullptr;
@@ -2482,8 +2495,21 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     // are a few consecutive ones, which the row-major order below would hand to as many XCDs and leave the others idle.
     const bool n_major = !list && g.m_window != nullptr && g.nsplit == 1 && !g.tri;
     const int tnx = (g.tn + 7) / 8;
-    const int mt0 = list ? wk.mt : n_major ? seq / tnx : (seq / g.tn) * ngroups + group;
-    const int nt = list ? wk.nt : n_major ? (seq % tnx) * 8 + xcd : seq % g.tn;
+    // (... and consecutive blocks take consecutive ROW tiles: the few live row tiles are then spread evenly over the launch
+    // order, and with them over the CUs - with the walker tiles innermost the live blocks were one contiguous run of the grid
+    // that the dispatcher packed onto a fraction of the CUs)
+    // ... and the blocks are numbered over the LIVE row tiles only (the window is device data, the grid is sized for every row
+    // tile): the first blocks of the launch are all live, the surplus ones come last in launch order and leave at once - with
+    // the dead row tiles' blocks in between, each held a slot for the ~3 us of its window load and a fifth of the live blocks
+    // started a round late.
+    int tm_live = tm_eff;
+    if (n_major) {
+        const int w_lo = max(g.m_window[0], 0), w_hi = min(g.m_window[1], g.M - 1);
+        tm_live = w_hi >= w_lo ? (w_hi - w_lo) / BM + 1 : 0;
+        if (tm_live == 0) return;
+    }
+    const int mt0 = list ? wk.mt : n_major ? seq % tm_live : (seq / g.tn) * ngroups + group;
+    const int nt = list ? wk.nt : n_major ? (seq / tm_live) * 8 + xcd : seq % g.tn;
     if (!list && (mt0 >= tm_eff || nt >= g.tn)) return;
     const int npass = persist ? w_count : (!list && g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
     const int batch = blockIdx.y;
@@ -2500,7 +2526,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = NT == 256 ? (wave & 1) * 32 : (wave & 3) * 16, wn = NT == 256 ? (wave >> 1) * 32 : (wave >> 2) * 32;
+    const int wm = NT == 256 ? (wave & 1) * 32 : (wave & 3) * 16, wn = NT == 256 ? (wave >> 1) * (BN / 2) : (wave >> 2) * 32;
     const int fq = lane & 3, fb = (lane >> 2) & 3, fkk = lane >> 4;
     // fragment read: row (4 f + fq), k = ks + 4 fkk + fb -> chunk (k / 2) ^ (4 fq), half k & 1
     const unsigned frag0 = (unsigned)(((2 * fkk + (fb >> 1)) ^ (4 * fq)) * 16 + (fb & 1) * 8);      // ks = 0; ks = 16 is ^ 128
@@ -2514,7 +2540,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     int m0 = 0, kbeg = 0, kend = 0;
     int slot = blockIdx.x;          // where the contraction partials of the current entry go (GemmArgs::part)
     bool skip = false;
-    unsigned oa[NP], ox[NP];
+    unsigned oa[NP], ox[NPX];
     // (a windowed problem in walker-major order tiles its rows from the window's first row: 240 wanted rows are four tiles
     // wherever they sit, not five)
     const int m_base = n_major ? max(g.m_window[0], 0) : 0;
@@ -2545,7 +2571,10 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         for (int p = 0; p < NP; ++p) {
             int r = m0 + (p * NW + wave) * 4 + drow; if (r >= p_M) r = p_M - 1;
             oa[p] = (unsigned)(r * p_lda) * 8u + dchunk;
-            r = n0 + (p * NW + wave) * 4 + drow; if (r >= p_N) r = p_N - 1;
+        }
+#pragma unroll
+        for (int p = 0; p < NPX; ++p) {
+            int r = n0 + (p * NW + wave) * 4 + drow; if (r >= p_N) r = p_N - 1;
             ox[p] = (unsigned)(r * p_ldx) * 8u + dchunk;
         }
     };
@@ -2554,8 +2583,9 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         for (int p = 0; p < NP; ++p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (oa[p] + (unsigned)k * 8u)),
                                              (__attribute__((address_space(3))) void*)&sA[buf][(p * NW + wave) * 4 * BK], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (ox[p] + (unsigned)k * 8u)),
-                                             (__attribute__((address_space(3))) void*)&sX[buf][(p * NW + wave) * 4 * BK], 16, 0, 0);
+            if (p < NPX)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (ox[p] + (unsigned)k * 8u)),
+                                                 (__attribute__((address_space(3))) void*)&sX[buf][(p * NW + wave) * 4 * BK], 16, 0, 0);
         }
     };
     // the first stage of a pass is requested before the previous pass stores its results (a triangular problem has two
@@ -2573,13 +2603,13 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     const int32_t* const c_lin_row = p_lin_row;
     const bool c_skip = skip;
 
-    double acc[8][FJ];
+    double acc[NI][FJ];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < FJ; ++j) acc[i][j] = 0.0;
 
-    double a0[FJ], x0[8], a1[FJ], x1[8];
+    double a0[FJ], x0[NI], a1[FJ], x1[NI];
     if (!c_skip && kbeg_c < kend_c) {
         if constexpr (NBUF == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2604,7 +2634,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         }
         if (G.trace) t_first = wall_clock64();
         lds_read_fragments<4 * BK * 8>(a0, fa + (unsigned)c_first * (BM * BK * 8) + frag0);
-        lds_read_fragments<4 * BK * 8>(x0, fx + (unsigned)c_first * (BM * BK * 8) + frag0);
+        lds_read_fragments<4 * BK * 8>(x0, fx + (unsigned)c_first * (BN * BK * 8) + frag0);
         lds_wait(a0, x0);
     }
     int buf = NBUF == 2 ? c_first : 0;
@@ -2614,13 +2644,16 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         // first half: MFMAs on f0(s), the reads of f1(s) spread between them (one read ahead of every group of MFMAs, so
         // the wave's MFMA stream is never held up by a burst of LDS instructions)
         const unsigned a1p = fa + (unsigned)buf * (BM * BK * 8) + (frag0 ^ 128u);
-        const unsigned x1p = fx + (unsigned)buf * (BM * BK * 8) + (frag0 ^ 128u);
+        const unsigned x1p = fx + (unsigned)buf * (BN * BK * 8) + (frag0 ^ 128u);
 #define VMX_G44_FIRST(i)                                                                                              \
-        if constexpr (i < FJ) a1[i] = lds_read_b64<i * 4 * BK * 8>(a1p);                                                 \
-        x1[i] = lds_read_b64<i * 4 * BK * 8>(x1p);                                                                       \
-        _Pragma("unroll") for (int j = 0; j < FJ; ++j)                                                                   \
-            acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0[i], a0[j], acc[i][j], 0, 0, 0);                            \
-        __builtin_amdgcn_sched_barrier(0);      /* keeps this order: the waits are placed by hand */
+        if constexpr (i < NI) {                                                                                           \
+            if constexpr (AR * i < FJ) a1[AR * i] = lds_read_b64<AR * i * 4 * BK * 8>(a1p);                               \
+            if constexpr (AR == 2) a1[AR * i + 1] = lds_read_b64<(AR * i + 1) * 4 * BK * 8>(a1p);                        \
+            x1[i] = lds_read_b64<i * 4 * BK * 8>(x1p);                                                                   \
+            _Pragma("unroll") for (int j = 0; j < FJ; ++j)                                                               \
+                acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0[i], a0[j], acc[i][j], 0, 0, 0);                        \
+            __builtin_amdgcn_sched_barrier(0);      /* keeps this order: the waits are placed by hand */                  \
+        }
         VMX_G44_FIRST(0) VMX_G44_FIRST(1) VMX_G44_FIRST(2) VMX_G44_FIRST(3)
         VMX_G44_FIRST(4) VMX_G44_FIRST(5) VMX_G44_FIRST(6) VMX_G44_FIRST(7)
 #undef VMX_G44_FIRST
@@ -2654,13 +2687,16 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
         }
         // (after the last stage these reads fetch stale data that nothing uses: one code path, no branch)
         const unsigned a0p = fa + (unsigned)nbuf * (BM * BK * 8) + frag0;
-        const unsigned x0p = fx + (unsigned)nbuf * (BM * BK * 8) + frag0;
+        const unsigned x0p = fx + (unsigned)nbuf * (BN * BK * 8) + frag0;
 #define VMX_G44_SECOND(i)                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < FJ; ++j)                                                                   \
-            acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1[i], a1[j], acc[i][j], 0, 0, 0);                            \
-        if constexpr (i < FJ) a0[i] = lds_read_b64<i * 4 * BK * 8>(a0p);                                                 \
-        x0[i] = lds_read_b64<i * 4 * BK * 8>(x0p);                                                                       \
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i < NI) {                                                                                           \
+            _Pragma("unroll") for (int j = 0; j < FJ; ++j)                                                               \
+                acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1[i], a1[j], acc[i][j], 0, 0, 0);                        \
+            if constexpr (AR * i < FJ) a0[AR * i] = lds_read_b64<AR * i * 4 * BK * 8>(a0p);                               \
+            if constexpr (AR == 2) a0[AR * i + 1] = lds_read_b64<(AR * i + 1) * 4 * BK * 8>(a0p);                        \
+            x0[i] = lds_read_b64<i * 4 * BK * 8>(x0p);                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+        }
         VMX_G44_SECOND(0) VMX_G44_SECOND(1) VMX_G44_SECOND(2) VMX_G44_SECOND(3)
         VMX_G44_SECOND(4) VMX_G44_SECOND(5) VMX_G44_SECOND(6) VMX_G44_SECOND(7)
 #undef VMX_G44_SECOND
@@ -2731,7 +2767,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     // rotations every lane group b holds the total; group b then stores column block j = 4 jg + b, so that a row of 16
     // lanes writes 16 consecutive m.
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int jg = 0; jg < FJ / 4; ++jg) {
             double tot[4];
