@@ -501,7 +501,11 @@ def main():
         rate = 20 / (time.perf_counter() - tb)
         settled = settled + 1 if abs(rate - previous) < 0.01 * rate else 0
         previous = rate
-        if settled >= 2:
+        if use_dist:
+            # (the steps carry a collective: every rank has to run the same number of them - eight blocks, no early exit)
+            if _ >= 7:
+                break
+        elif settled >= 2:
             break
     for i in range(args.warmup):
         step(i)
@@ -524,7 +528,8 @@ def main():
 
     single_lane = None
     single_timings = None
-    if L > 1 and not use_dist:
+    if L > 1:
+        # (with N > 1 ranks every rank runs this section too: the steps carry the collective, so the ranks stay in step)
         # the same steps with ONE batch in flight (vmx_set_lanes(1)): what a caller gets whose next batch depends on this one's
         # chi2.  With two lanes (`value`) consecutive batches overlap: one lane's launch tails and small kernels are filled
         # by the other's work; co-running kernels share the chip, so per-launch durations (and with them the live roofline
