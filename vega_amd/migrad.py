@@ -658,8 +658,9 @@ class MigradMinimizer:
 
     ``evaluate(theta_ext [m, P], fit_index [m]) -> chi2 [m]``."""
 
-    def __init__(self, evaluate, names, start, errors, limits, tol=0.1, errordef=1.0, maxfcn=100000):
+    def __init__(self, evaluate, names, start, errors, limits, tol=0.1, errordef=1.0, maxfcn=100000, vectorised=True):
         self.evaluate = evaluate
+        self.vectorised = vectorised        # False: one coroutine per fit for every stage (`_Fit.run`, the readable reference)
         self.names = list(names)
         self.start = np.asarray(start, dtype=float)
         self.step = np.asarray(errors, dtype=float)
@@ -667,20 +668,63 @@ class MigradMinimizer:
         self.tol, self.errordef, self.maxfcn = tol, errordef, maxfcn
 
     def _stage(self, ext0, free, fit_ids):
-        """One Minuit object per fit over the parameters ``free`` (the others held at ext0)."""
+        """One Minuit object per fit over the parameters ``free`` (the others held at ext0): dict of per-fit arrays."""
         free = np.asarray(free, dtype=int)
-        fits = [_Fit(ext0[f][free], self.step[free], [self.limits[j] for j in free], up=self.errordef, tol=self.tol,
-                     maxfcn=self.maxfcn) for f in range(ext0.shape[0])]
-
-        trafo = Transform([self.limits[j] for j in free])       # (the fits of a stage share their limits)
+        F = ext0.shape[0]
+        limits = [self.limits[j] for j in free]
+        trafo = _VecTransform(limits)
 
         def evaluate_internal(pts, owner):
             theta = ext0[owner]
-            theta[:, free] = trafo.int2ext_array(pts)
+            theta[:, free] = trafo.int2ext(np.atleast_2d(pts))
             vals = np.asarray(self.evaluate(theta, fit_ids[owner]), dtype=float)
             return np.where(np.isfinite(vals) & (vals < SENTINEL), vals, np.inf)
-        _drive(fits, evaluate_internal)
-        return fits
+
+        if self.vectorised:
+            batch = _Batch(ext0[:, free], self.step[free], limits, evaluate_internal, up=self.errordef, tol=self.tol,
+                           maxfcn=self.maxfcn)
+            S = batch.run()
+            x, V, fval, edm = S['x'], S['V'], S['fval'], S['edm']
+            hesse_failed, accurate = S['hesse_failed'].copy(), S['accurate'].copy()
+            valid = batch.alive & ~S['limit'] & (edm <= 10 * batch.edmval) & ~hesse_failed & np.isfinite(fval)
+            nfcn, n_iter = batch.nfcn.copy(), batch.n_iter.copy()
+            redo = batch.slow
+        else:
+            x = np.zeros((F, free.size)); V = np.zeros((F, free.size, free.size)); fval = np.full(F, np.inf); edm = np.full(F, np.inf)
+            hesse_failed = np.zeros(F, dtype=bool); accurate = np.zeros(F, dtype=bool); valid = np.zeros(F, dtype=bool)
+            nfcn = np.zeros(F, dtype=np.int64); n_iter = np.zeros(F, dtype=int)
+            redo = list(range(F))
+        if redo:
+            # the reference implementation, one coroutine per fit: everything when not vectorised, else the fits that left the
+            # common path (a negative second derivative at the seed, a metric that lost positive-definiteness)
+            redo = np.array(redo, dtype=int)
+            fits = [_Fit(ext0[f][free], self.step[free], limits, up=self.errordef, tol=self.tol, maxfcn=self.maxfcn) for f in redo]
+            _drive(fits, lambda pts, owner: evaluate_internal(pts, redo[owner]))
+            for f, fit in zip(redo, fits):
+                r = fit.result
+                nfcn[f] = fit.nfcn          # (Minuit's count of this fit; what the common path spent on it before is not part of it)
+                n_iter[f] = fit.n_iter
+                if r is None or not np.isfinite(r['fval']):
+                    fval[f], edm[f], valid[f], hesse_failed[f] = np.inf, np.inf, False, True
+                    continue
+                x[f], V[f], fval[f], edm[f] = r['x'], r['V'], r['fval'], r['edm']
+                valid[f], hesse_failed[f], accurate[f] = r['valid'], r['hesse_failed'], r['accurate']
+        # external values, errors, covariance (MnUserParameterState / MnUserCovariance)
+        values = trafo.int2ext(x)
+        cov_int = 2. * self.errordef * V
+        jac = trafo.dint2ext(x)
+        cov = cov_int * jac[:, :, None] * jac[:, None, :]
+        dxs = np.sqrt(np.clip(np.einsum('fii->fi', cov_int), 0., None))
+        errors = dxs.copy()
+        for i in range(free.size):
+            if trafo.has_limits[i]:
+                du1 = trafo.int2ext_col(i, x[:, i] + dxs[:, i]) - values[:, i]
+                du2 = trafo.int2ext_col(i, x[:, i] - dxs[:, i]) - values[:, i]
+                if trafo.lo[i] is not None and trafo.hi[i] is not None:
+                    du1 = np.where(dxs[:, i] > 1., trafo.hi[i] - trafo.lo[i], du1)
+                errors[:, i] = 0.5 * (np.abs(du1) + np.abs(du2))
+        return dict(values=values, errors=errors, cov=cov, fval=fval, edm=edm, valid=valid, hesse_failed=hesse_failed,
+                    accurate=accurate, nfcn=nfcn, n_iter=n_iter)
 
     def minimize(self, n_fits=1, start=None, fixed=(), prefit_bias=True):
         P = len(self.names)
@@ -694,32 +738,439 @@ class MigradMinimizer:
         bias = np.array([j for j in free_all if 'bias' in self.names[j]], dtype=int)
         if prefit_bias and bias.size > 0:
             pre = self._stage(ext, bias, fit_ids)
-            for f, fit in enumerate(pre):
-                nfcn[f] += fit.nfcn
-                n_iter[f] += fit.n_iter
-                if fit.result is not None and np.isfinite(fit.result['fval']):
-                    ext[f, bias] = fit.external()[0]
-        fits = self._stage(ext, free_all, fit_ids)
+            nfcn += pre['nfcn']
+            n_iter += pre['n_iter']
+            ok = np.isfinite(pre['fval'])
+            ext[np.ix_(ok, bias)] = pre['values'][ok]
+        res = self._stage(ext, free_all, fit_ids)
+        nfcn += res['nfcn']
+        n_iter += res['n_iter']
+        ok = np.isfinite(res['fval'])
         values = ext.copy()
         errors = np.zeros((F, P))
         cov = np.zeros((F, P, P))
-        fval, edm = np.full(F, np.inf), np.full(F, np.inf)
-        valid, hesse_failed = np.zeros(F, dtype=bool), np.zeros(F, dtype=bool)
-        accurate = np.zeros(F, dtype=bool)
-        for f, fit in enumerate(fits):
-            nfcn[f] += fit.nfcn
-            n_iter[f] += fit.n_iter
-            r = fit.result
-            if r is None or not np.isfinite(r['fval']):
-                hesse_failed[f] = True
+        values[np.ix_(ok, free_all)] = res['values'][ok]
+        errors[np.ix_(ok, free_all)] = res['errors'][ok]
+        for f in np.flatnonzero(ok):
+            cov[f][np.ix_(free_all, free_all)] = res['cov'][f]
+        out = FitResult(names=self.names, values=values, errors=errors, covariance=cov, fval=np.where(ok, res['fval'], np.inf),
+                        edm=np.where(ok, res['edm'], np.inf), is_valid=res['valid'] & ok, hesse_failed=res['hesse_failed'] | ~ok,
+                        nfcn=nfcn, n_iter=n_iter)
+        out.has_accurate_covar = res['accurate'] & ok
+        return out
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same algorithm, array-oriented: every stage but the line search runs for all fits at once (NumPy over fits), the
+# line searches are per-fit coroutines (MnLineSearch is a small state machine of scalar decisions) advanced in rounds.
+# A fit's sequence of function values is that of `_Fit.run`; what changes is who does the bookkeeping.  `_Fit.run` stays
+# as the readable reference (tests/test_migrad.py compares the two) and takes over the rare branches (a negative second
+# derivative at the seed, a metric that lost positive-definiteness).
+# ---------------------------------------------------------------------------------------------------------------------
+class _VecTransform:
+    """Minuit's transformations for arrays [F, n] (column i has the limits of parameter i)."""
+
+    def __init__(self, limits):
+        t = Transform(limits)
+        self.lo, self.hi = t.lo, t.hi
+        self.n = len(limits)
+        self.has_limits = np.array([t.has_limits(i) for i in range(self.n)])
+
+    def ext2int_col(self, i, v):
+        lo, hi = self.lo[i], self.hi[i]
+        d = 8. * math.sqrt(EPS2)
+        if lo is not None and hi is not None:
+            yy = 2. * (v - lo) / (hi - lo) - 1.
+            edge = yy * yy > 1. - EPS2
+            return np.where(edge, np.where(yy < 0., -0.5 * math.pi + d, 0.5 * math.pi - d), np.arcsin(np.clip(yy, -1., 1.)))
+        if lo is not None:
+            yy = v - lo + 1.
+            return np.where(yy * yy < 1. + EPS2, d, np.sqrt(np.maximum(yy * yy - 1., 0.)))
+        if hi is not None:
+            yy = hi - v + 1.
+            return np.where(yy * yy < 1. + EPS2, d, np.sqrt(np.maximum(yy * yy - 1., 0.)))
+        return np.array(v, dtype=float)
+
+    def int2ext_col(self, i, v):
+        lo, hi = self.lo[i], self.hi[i]
+        if lo is not None and hi is not None:
+            return lo + 0.5 * (hi - lo) * (np.sin(v) + 1.)
+        if lo is not None:
+            return lo - 1. + np.sqrt(v * v + 1.)
+        if hi is not None:
+            return hi + 1. - np.sqrt(v * v + 1.)
+        return np.array(v, dtype=float)
+
+    def int2ext(self, x):
+        return np.stack([self.int2ext_col(i, x[:, i]) for i in range(self.n)], axis=1) if self.n else x.copy()
+
+    def dint2ext(self, x):
+        out = np.ones_like(x)
+        for i in range(self.n):
+            lo, hi = self.lo[i], self.hi[i]
+            v = x[:, i]
+            if lo is not None and hi is not None:
+                out[:, i] = 0.5 * np.abs((hi - lo) * np.cos(v))
+            elif lo is not None:
+                out[:, i] = v / np.sqrt(v * v + 1.)
+            elif hi is not None:
+                out[:, i] = -v / np.sqrt(v * v + 1.)
+        return out
+
+
+def _triu_abs_sum(m):
+    n = m.shape[-1]
+    if n not in _TRIU:
+        _TRIU[n] = np.triu_indices(n)
+    iu = _TRIU[n]
+    return np.abs(m[:, iu[0], iu[1]]).sum(axis=1)
+
+
+class _Batch:
+    """F fits over the same n free parameters; ``evaluate(pts [m, n] internal, owner [m]) -> values [m]``."""
+
+    G_NC, G_STOL, G_TOL = _Fit.GRAD_NCYCLES, _Fit.GRAD_STEP_TOL, _Fit.GRAD_TOL
+    H_NC, H_STOL, H_G2TOL, HG_NC = _Fit.HESS_NCYCLES, _Fit.HESS_STEP_TOL, _Fit.HESS_G2_TOL, _Fit.HESS_GRAD_NCYCLES
+
+    def __init__(self, ext0, ext_errors, limits, evaluate, up=1.0, tol=0.1, maxfcn=100000):
+        self.F, self.n = ext0.shape
+        self.T = _VecTransform(limits)
+        self.limits = limits
+        self.err = np.asarray(ext_errors, dtype=float)
+        self.evaluate = evaluate
+        self.up, self.tol, self.maxfcn = up, tol, maxfcn
+        self.edmval = 0.002 * max(tol * up, EPS2)
+        self.nfcn = np.zeros(self.F, dtype=np.int64)
+        self.n_iter = np.zeros(self.F, dtype=int)
+        self.x0 = np.stack([self.T.ext2int_col(i, ext0[:, i]) for i in range(self.n)], axis=1)
+        self.ext0, self.ext_errors = ext0, ext_errors
+
+    def _f(self, pts, owner):
+        vals = np.asarray(self.evaluate(pts, owner), dtype=float)
+        np.add.at(self.nfcn, owner, 1)
+        return vals
+
+    # ---- seed
+    def _initial_gradient(self, x):
+        F, n = x.shape
+        grd, g2, gstep = np.zeros((F, n)), np.zeros((F, n)), np.zeros((F, n))
+        for i in range(n):
+            var = x[:, i]
+            werr = self.err[i]
+            sav = self.T.int2ext_col(i, var)
+            sav2 = sav + werr
+            if self.T.hi[i] is not None:
+                sav2 = np.where(sav2 > self.T.hi[i], self.T.hi[i], sav2)
+            vplu = self.T.ext2int_col(i, sav2) - var
+            sav2 = sav - werr
+            if self.T.lo[i] is not None:
+                sav2 = np.where(sav2 < self.T.lo[i], self.T.lo[i], sav2)
+            vmin = self.T.ext2int_col(i, sav2) - var
+            gsmin = 8. * EPS2 * (np.abs(var) + EPS2)
+            dirin = np.maximum(0.5 * (np.abs(vplu) + np.abs(vmin)), gsmin)
+            g2[:, i] = 2.0 * self.up / (dirin * dirin)
+            gs = np.maximum(gsmin, 0.1 * dirin)
+            if self.T.has_limits[i]:
+                gs = np.minimum(gs, 0.5)
+            gstep[:, i] = gs
+            grd[:, i] = g2[:, i] * dirin
+        return grd, g2, gstep
+
+    # ---- two-point gradient of the fits `idx` at x (rows aligned with idx), starting from (grd, g2, gstep)
+    def _gradient(self, idx, x, fval, grd, g2, gstep):
+        m, n = x.shape
+        grd, g2, gstep = grd.copy(), g2.copy(), gstep.copy()
+        dfmin = 8. * EPS2 * (np.abs(fval) + self.up)
+        vrysml = 8. * EPS * EPS
+        stepb4 = np.zeros((m, n))
+        active = np.ones((m, n), dtype=bool)
+        lim = self.T.has_limits[None, :]
+        for _ in range(self.G_NC):
+            epspri = EPS2 + np.abs(grd * EPS2)
+            optstp = np.sqrt(dfmin[:, None] / (np.abs(g2) + epspri))
+            step = np.maximum(optstp, np.abs(0.1 * gstep))
+            step = np.where(lim & (step > 0.5), 0.5, step)
+            step = np.minimum(step, 10. * np.abs(gstep))
+            step = np.maximum(step, np.maximum(vrysml, 8. * np.abs(EPS2 * x)))
+            with np.errstate(invalid='ignore', divide='ignore'):
+                conv = np.abs((step - stepb4) / step) < self.G_STOL
+            active &= ~conv
+            if not active.any():
+                break
+            r, c = np.nonzero(active)
+            gstep[r, c] = step[r, c]
+            stepb4[r, c] = step[r, c]
+            pts = np.repeat(x[r], 2, axis=0)
+            k = np.arange(r.size)
+            pts[2 * k, c] += step[r, c]
+            pts[2 * k + 1, c] -= step[r, c]
+            vals = self._f(pts, np.repeat(idx[r], 2))
+            fs1, fs2 = vals[0::2], vals[1::2]
+            st = step[r, c]
+            grdb4 = grd[r, c]
+            gnew = 0.5 * (fs1 - fs2) / st
+            grd[r, c] = gnew
+            g2[r, c] = (fs1 + fs2 - 2. * fval[r]) / st / st
+            with np.errstate(invalid='ignore', divide='ignore'):
+                done = np.abs(grdb4 - gnew) / (np.abs(gnew) + dfmin[r] / st) < self.G_TOL
+            active[r[done], c[done]] = False
+        return grd, g2, gstep
+
+    # ---- line searches of the fits idx: per-fit coroutines, joined evaluations
+    def _line_searches(self, idx, x, f0, step, gdel):
+        helpers = [self._ls_helper] * idx.size
+        gens, lam, fnew = {}, np.zeros(idx.size), np.array(f0, dtype=float)
+        pending = {}
+        for q in range(idx.size):
+            g = helpers[q]._line_search(x[q], f0[q], step[q], gdel[q])
+            try:
+                pending[q] = (g, next(g))
+            except StopIteration as stop:
+                lam[q], fnew[q] = stop.value
+        while pending:
+            keys = list(pending)
+            pts = np.concatenate([pending[q][1] for q in keys])
+            owner = np.concatenate([np.full(pending[q][1].shape[0], idx[q]) for q in keys])
+            vals = self._f(pts, owner)
+            nxt, off = {}, 0
+            for q in keys:
+                g, req = pending[q]
+                mq = req.shape[0]
+                try:
+                    nxt[q] = (g, g.send(vals[off:off + mq]))
+                except StopIteration as stop:
+                    lam[q], fnew[q] = stop.value
+                off += mq
+            pending = nxt
+        return lam, fnew
+
+    # ---- the iterations (VariableMetricBuilder) for the fits `act`, until each converges
+    def _iterate(self, act, S, maxfcn):
+        ls = _Fit(self.ext0[0], self.ext_errors, self.limits, up=self.up, tol=self.tol)
+        self._ls_helper = ls
+        act = np.array(act, dtype=int)
+        slow = []
+        while act.size:
+            V, g = S['V'][act], S['grd'][act]
+            step = -np.einsum('fij,fj->fi', V, g)
+            gdel = np.einsum('fi,fi->f', step, g)
+            bad = gdel > 0.
+            if bad.any():           # a metric that is not positive definite: the reference implementation takes the fit over
+                slow += list(act[bad])
+                act, step, gdel = act[~bad], step[~bad], gdel[~bad]
+                if not act.size:
+                    break
+            x0, f0 = S['x'][act], S['fval'][act]
+            lam, fnew = self._line_searches(act, x0, f0, step, gdel)
+            improved = ~(np.abs(fnew - f0) <= np.abs(f0) * EPS)
+            act_i = act[improved]
+            if act_i.size:
+                x1 = x0[improved] + lam[improved, None] * step[improved]
+                f1 = fnew[improved]
+                g1, g21, gs1 = self._gradient(act_i, x1, f1, S['grd'][act_i], S['g2'][act_i], S['gstep'][act_i])
+                V0 = S['V'][act_i]
+                edm = 0.5 * np.einsum('fi,fij,fj->f', g1, V0, g1)
+                weird = ~(edm >= 0.)            # NaN or negative: the reference implementation's business
+                dx = x1 - S['x'][act_i]
+                dg = g1 - S['grd'][act_i]
+                delgam = np.einsum('fi,fi->f', dx, dg)
+                vg = np.einsum('fij,fj->fi', V0, dg)
+                gvg = np.einsum('fi,fi->f', dg, vg)
+                ok = ~((delgam == 0.) | (gvg <= 0.))
+                with np.errstate(invalid='ignore', divide='ignore'):
+                    upd = dx[:, :, None] * dx[:, None, :] / delgam[:, None, None] - vg[:, :, None] * vg[:, None, :] / gvg[:, None, None]
+                    w = dx / delgam[:, None] - vg / gvg[:, None]
+                    upd = np.where((delgam > gvg)[:, None, None], upd + gvg[:, None, None] * (w[:, :, None] * w[:, None, :]), upd)
+                    V1 = V0 + upd
+                    dcov = 0.5 * (S['dcovar'][act_i] + _triu_abs_sum(upd) / _triu_abs_sum(V1))
+                V1 = np.where(ok[:, None, None], V1, V0)
+                dcov = np.where(ok, dcov, S['dcovar'][act_i])
+                S['x'][act_i], S['fval'][act_i] = x1, f1
+                S['grd'][act_i], S['g2'][act_i], S['gstep'][act_i] = g1, g21, gs1
+                S['V'][act_i], S['dcovar'][act_i], S['edm'][act_i] = V1, dcov, edm
+                self.n_iter[act_i] += 1
+                if weird.any():
+                    slow += list(act_i[weird])
+                go_on = (edm * (1. + 3. * dcov) > self.edmval) & (self.nfcn[act_i] < maxfcn) & ~weird
+                S['limit'][act_i] = self.nfcn[act_i] >= maxfcn
+                act = act_i[go_on]
+            else:
+                act = act_i
+        return slow
+
+    # ---- HESSE for the fits idx (state S is updated in place); returns the mask of failures
+    def _hesse(self, idx, S):
+        idx = np.array(idx, dtype=int)
+        m, n = idx.size, self.n
+        x = S['x'][idx].copy()
+        amin = self._f(x, idx)
+        aimsag = math.sqrt(EPS2) * (np.abs(amin) + self.up)
+        g2, gst, grd = S['g2'][idx].copy(), S['gstep'][idx].copy(), S['grd'][idx].copy()
+        dirin, yy = gst.copy(), np.zeros((m, n))
+        vh = np.zeros((m, n, n))
+        failed = np.zeros(m, dtype=bool)
+        lim = self.T.has_limits
+        dmin = 8. * EPS2 * (np.abs(x) + EPS2)
+        d = np.maximum(np.abs(gst), dmin)
+        open_ = np.ones((m, n), dtype=bool)
+        cyc, mult = np.zeros((m, n), dtype=int), np.zeros((m, n), dtype=int)
+        while open_.any():
+            open_ &= ~failed[:, None]
+            r, c = np.nonzero(open_)
+            if not r.size:
+                break
+            k = np.arange(r.size)
+            pts = np.repeat(x[r], 2, axis=0)
+            pts[2 * k, c] = x[r, c] + d[r, c]
+            pts[2 * k + 1, c] = x[r, c] - d[r, c]
+            vals = self._f(pts, np.repeat(idx[r], 2))
+            fs1, fs2 = vals[0::2], vals[1::2]
+            for q in range(r.size):             # (scalar decisions per parameter, as MnHesse takes them)
+                f_, i = r[q], c[q]
+                if failed[f_]:
+                    continue
+                sag = 0.5 * (fs1[q] + fs2[q] - 2. * amin[f_])
+                if not sag > EPS2:
+                    mult[f_, i] += 1
+                    if lim[i]:
+                        if d[f_, i] > 0.5 or mult[f_, i] >= 5:
+                            failed[f_] = True
+                            continue
+                        d[f_, i] *= 10.
+                        if d[f_, i] > 0.5:
+                            d[f_, i] = 0.51
+                    else:
+                        if mult[f_, i] >= 5:
+                            failed[f_] = True
+                            continue
+                        d[f_, i] *= 10.
+                    continue
+                mult[f_, i] = 0
+                g2bfor = g2[f_, i]
+                di = d[f_, i]
+                g2[f_, i] = 2. * sag / (di * di)
+                grd[f_, i] = (fs1[q] - fs2[q]) / (2. * di)
+                gst[f_, i] = di
+                dirin[f_, i] = di
+                yy[f_, i] = fs1[q]
+                dn = math.sqrt(2. * aimsag[f_] / abs(g2[f_, i]))
+                if lim[i]:
+                    dn = min(0.5, dn)
+                if dn < dmin[f_, i]:
+                    dn = dmin[f_, i]
+                cyc[f_, i] += 1
+                if abs((dn - di) / dn) < self.H_STOL or abs((g2[f_, i] - g2bfor) / g2[f_, i]) < self.H_G2TOL \
+                        or cyc[f_, i] >= self.H_NC:
+                    vh[f_, i, i] = g2[f_, i]
+                    open_[f_, i] = False
+                    continue
+                dn = min(dn, 10. * di)
+                dn = max(dn, 0.1 * di)
+                d[f_, i] = dn
+        good = ~failed
+        # refined first derivatives (HessianGradientCalculator), all parameters of all fits together
+        dfmin = 4. * EPS2 * (np.abs(amin) + self.up)
+        dminh = 4. * EPS2 * (x + EPS2)
+        epspri = EPS2 + np.abs(grd * EPS2)
+        optstp = np.sqrt(dfmin[:, None] / (np.abs(g2) + epspri))
+        dd = 0.2 * np.abs(gst)
+        dd = np.where(dd > optstp, optstp, dd)
+        dd = np.where(dd < dminh, dminh, dd)
+        chgold = np.full((m, n), 10000.)
+        open_ = np.repeat(good[:, None], n, axis=1)
+        for j in range(self.HG_NC):
+            r, c = np.nonzero(open_)
+            if not r.size:
+                break
+            k = np.arange(r.size)
+            pts = np.repeat(x[r], 2, axis=0)
+            pts[2 * k, c] = x[r, c] + dd[r, c]
+            pts[2 * k + 1, c] = x[r, c] - dd[r, c]
+            vals = self._f(pts, np.repeat(idx[r], 2))
+            fs1, fs2 = vals[0::2], vals[1::2]
+            dq = dd[r, c]
+            grdold = grd[r, c]
+            grdnew = (fs1 - fs2) / (2. * dq)
+            dgmin = EPS * (np.abs(fs1) + np.abs(fs2)) / dq
+            tiny = np.abs(grdnew) < EPS
+            with np.errstate(invalid='ignore', divide='ignore'):
+                change = np.abs((grdold - grdnew) / grdnew)
+            worse = (change > chgold[r, c]) & (j > 1)
+            take = ~tiny & ~worse
+            chgold[r[take], c[take]] = change[take]
+            grd[r[take], c[take]] = grdnew[take]
+            gst[r[take], c[take]] = dq[take]
+            stop = tiny | worse | (change < 0.05) | (np.abs(grdold - grdnew) < dgmin) | (dq < dminh[r, c])
+            open_[r[stop], c[stop]] = False
+            dd[r[~stop], c[~stop]] *= 0.2
+        # off-diagonal elements: one batch
+        pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+        if pairs and good.any():
+            gi = np.flatnonzero(good)
+            pts = np.repeat(x[gi], len(pairs), axis=0).reshape(gi.size, len(pairs), n)
+            for q, (i, j) in enumerate(pairs):
+                pts[:, q, i] += dirin[gi, i]
+                pts[:, q, j] += dirin[gi, j]
+            vals = self._f(pts.reshape(-1, n), np.repeat(idx[gi], len(pairs))).reshape(gi.size, len(pairs))
+            for q, (i, j) in enumerate(pairs):
+                el = (vals[:, q] + amin[gi] - yy[gi, i] - yy[gi, j]) / (dirin[gi, i] * dirin[gi, j])
+                vh[gi, i, j] = el
+                vh[gi, j, i] = el
+        for q in np.flatnonzero(good):
+            hmat, made = _make_posdef(vh[q])
+            try:
+                Vq = np.linalg.inv(hmat)
+            except np.linalg.LinAlgError:
+                failed[q] = True
                 continue
-            v, e, c = fit.external()
-            values[f, free_all] = v
-            errors[f, free_all] = e
-            cov[f][np.ix_(free_all, free_all)] = c
-            fval[f], edm[f] = r['fval'], r['edm']
-            valid[f], hesse_failed[f], accurate[f] = r['valid'], r['hesse_failed'], r['accurate']
-        res = FitResult(names=self.names, values=values, errors=errors, covariance=cov, fval=fval, edm=edm, is_valid=valid,
-                        hesse_failed=hesse_failed, nfcn=nfcn, n_iter=n_iter)
-        res.has_accurate_covar = accurate
-        return res
+            f_ = idx[q]
+            S['x'][f_], S['fval'][f_] = x[q], amin[q]
+            S['grd'][f_], S['g2'][f_], S['gstep'][f_] = grd[q], g2[q], gst[q]
+            S['V'][f_], S['dcovar'][f_] = Vq, 0.
+            S['edm'][f_] = 0.5 * float(grd[q] @ Vq @ grd[q])
+            S['accurate'][f_] = not made
+        S['hesse_failed'][idx[failed]] = True
+        S['fval'][idx[failed]] = amin[failed]
+        return failed
+
+    # ---- the whole thing
+    def run(self):
+        F, n = self.F, self.n
+        all_idx = np.arange(F)
+        x = self.x0.copy()
+        fval = self._f(x, all_idx)
+        S = dict(x=x, fval=fval, grd=np.zeros((F, n)), g2=np.zeros((F, n)), gstep=np.zeros((F, n)), V=np.zeros((F, n, n)),
+                 dcovar=np.ones(F), edm=np.full(F, np.inf), limit=np.zeros(F, dtype=bool), hesse_failed=np.zeros(F, dtype=bool),
+                 accurate=np.zeros(F, dtype=bool))
+        alive = np.isfinite(fval)
+        idx = np.flatnonzero(alive)
+        slow = []
+        if idx.size:
+            grd, g2, gstep = self._initial_gradient(x[idx])
+            grd, g2, gstep = self._gradient(idx, x[idx], fval[idx], grd, g2, gstep)
+            S['grd'][idx], S['g2'][idx], S['gstep'][idx] = grd, g2, gstep
+            diag = np.where(np.abs(g2) > EPS2, 1. / np.where(g2 != 0, g2, 1.), 1.)
+            V = np.zeros((idx.size, n, n))
+            V[:, np.arange(n), np.arange(n)] = diag
+            S['V'][idx] = V
+            S['edm'][idx] = 0.5 * np.einsum('fi,fij,fj->f', grd, V, grd)
+            neg = (g2 <= 0).any(axis=1)
+            slow += list(idx[neg])
+            todo = idx[~neg]
+            maxfcn_eff = self.maxfcn
+            for ipass in range(20):
+                slow += self._iterate(todo, S, maxfcn_eff)
+                todo = np.array([f for f in todo if f not in set(slow) and not S['limit'][f]], dtype=int)
+                need = todo[S['dcovar'][todo] > 0.05]
+                again = []
+                if need.size:
+                    failed = self._hesse(need, S)
+                    okk = need[~failed]
+                    e = S['edm'][okk]
+                    again = list(okk[(e > self.edmval) & (e >= np.abs(EPS2 * S['fval'][okk]))])
+                if ipass == 0:
+                    maxfcn_eff = int(self.maxfcn * 1.3)
+                todo = np.array(again, dtype=int)
+                if not todo.size:
+                    break
+        self.S, self.alive, self.slow = S, alive, sorted(set(int(f) for f in slow))
+        return S
