@@ -228,6 +228,9 @@ struct vmx_engine {
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
     bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
+    bool xi_lean = true;             // VMX_NO_XI_LEAN: every per-walker pipeline's bins by the general k_xi_bins
+    std::vector<int32_t> xi_lean_pipes, xi_rest_pipes;      // the active pipelines k_xi_bins_lean serves / the others
+    DevBuf<int32_t> d_xi_rest_pipes;
     int xi_plain_nw = 2;             // walkers per thread of k_xi_quad_plain (VMX_XI_PLAIN_NW: 0 = the general kernel, 1, 2, 4)
     bool fft_narrow = true;          // VMX_NO_FFT_NARROW: never the 64 x 32 tiles for the FFTLog product
     bool ring_allowed = true;        // one batch in flight only: a 128 KB block leaves the other lane's kernels no room on its CU
@@ -1283,6 +1286,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
     if (const char* v = getenv("VMX_XI_PLAIN_NW")) e->xi_plain_nw = atoi(v);
+    if (getenv("VMX_NO_XI_LEAN")) e->xi_lean = false;
     if (const char* v = getenv("VMX_ITEM_STREAMS")) e->item_streams = atoi(v) != 0;
     if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
@@ -1515,6 +1519,21 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             e->pk_static.pop_back();
             std::vector<int32_t> active;
             for (int p = 0; p < (int)e->pipes.size(); ++p) if (e->pipes[p].col >= 0) active.push_back(p);
+            // ... of which k_xi_bins_lean takes those that are a spline sum with the standard evolution (+ radiation)
+            e->xi_lean_pipes.clear(); e->xi_rest_pipes.clear();
+            for (int p : active) {
+                const PipeDev& P = e->pipes[p];
+                const vmx_pipe_desc& d = P.d;
+                const bool lean = e->xi_lean && !e->extrapolate && d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD &&
+                                  !d.uv_shotnoise && !P.odd_rel && !P.odd_asy && d.single_ell < 0 && (!d.radiation || !d.is_peak) &&
+                                  (int)e->xi_lean_pipes.size() < VMX_XI_LEAN_MAX;
+                (lean ? e->xi_lean_pipes : e->xi_rest_pipes).push_back(p);
+            }
+            {
+                std::vector<int32_t> rest = e->xi_rest_pipes;
+                rest.push_back(-1);
+                if (e->d_xi_rest_pipes.upload(rest.data(), rest.size())) return -2;
+            }
             active.push_back(-1);
             if (e->d_pipe_active.upload(active.data(), active.size())) return -2;
         }
@@ -2285,7 +2304,18 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         ScopedTimer t(e, KC_XI);
         int max_n = 0;
         for (auto& p : e->pipes) max_n = p.n > max_n ? p.n : max_n;
-        if (e->n_active > 0)
+        if (B > 8 && !e->direct && !e->xi_lean_pipes.empty()) {
+            XiLeanArgs LA{};
+            for (size_t q = 0; q < e->xi_lean_pipes.size(); ++q) {
+                const PipeDev& P = e->pipes[e->xi_lean_pipes[q]];
+                XiLeanPipe& L = LA.p[q];
+                L.coord_off = P.coord_off; L.xi_off = P.xi_off; L.n = P.n; L.n_pad = P.n_pad; L.pipe = e->xi_lean_pipes[q]; L.col = P.col;
+                L.n_ell = P.d.n_ell; L.split_evol = P.split_evol; L.radiation = P.d.is_peak ? 0 : P.d.radiation;
+            }
+            hipLaunchKernelGGL(k_xi_bins_lean<2>, dim3((max_n + 255) / 256, (unsigned)e->xi_lean_pipes.size(), (B + 1) / 2), dim3(256), 0, e->stream, D, LA, B);
+            if (!e->xi_rest_pipes.empty())
+                hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, (unsigned)e->xi_rest_pipes.size(), B), dim3(256), 0, e->stream, D, e->d_xi_rest_pipes.p);
+        } else if (e->n_active > 0)
             hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, e->n_active, B), dim3(256), 0, e->stream, D, e->d_pipe_active.p);
         if (!e->pk_static.empty())
         {

@@ -438,11 +438,12 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
         double* out = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
 #pragma unroll
         for (int i = 0; i < VMX_NS; ++i) out[i] = s[i];
-        return;
     }
 
     // metal bias products (reference metals.py:295-313, :331-332) and the Kaiser coefficients of the static-basis metals
-    for (int m = 0; m < D.n_metals_total; ++m) {
+    // (the walker's n_pipe + 1 threads share the metals: one serial chain of 19 bias / beta look-ups per walker was a third of
+    // this kernel at 23 pipelines)
+    for (int m = slot; m < D.n_metals_total; m += D.n_pipe + 1) {
         const vmx_metal_desc& d = D.metals[m].d;
         double f = d.multiplicity;
         const double gr = th(t, d.growth_rate_slot, d.growth_rate_default);
@@ -456,6 +457,8 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
         mb[D.n_metals_total + m] = be1 + be2;
         mb[2 * D.n_metals_total + m] = be1 * be2;
     }
+    if (slot < D.n_pipe) return;
+
     int st = 0;
     for (int q = 0; q < D.n_const_slots; ++q)
         if (t[D.const_slots[q]] != t0[D.const_slots[q]]) st = VMX_STATUS_NOT_CONSTANT;
@@ -3439,6 +3442,65 @@ __global__ __launch_bounds__(256) void k_xi_quad_plain(EngineDev D, XiPlainArgs 
         if (b >= B) break;
         if (oob[w]) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
         I.q_x[(size_t)b * I.nq_pad + i] = out[w];
+    }
+}
+
+// k_xi_bins for the pipelines that need nothing but the spline sum, the standard bias evolution, growth and (smooth component)
+// the QSO radiation term - every pipeline of the joint + metals fit that forms its multipoles per walker: the pipeline's fields
+// in the kernel ARGUMENTS, NW walkers per thread (coordinates, evolution logarithm and growth loaded once; NW independent
+// spline chains in flight).  grid = (bins, pipelines of the list, ceil(B / NW)).
+struct XiLeanPipe { int64_t coord_off, xi_off; int32_t n, n_pad, pipe, col, n_ell, split_evol, radiation, pad; };
+#define VMX_XI_LEAN_MAX 24
+struct XiLeanArgs { XiLeanPipe p[VMX_XI_LEAN_MAX]; };
+
+template <int NW>
+__global__ __launch_bounds__(256) void k_xi_bins_lean(EngineDev D, XiLeanArgs A, int B)
+{
+    const XiLeanPipe& P = A.p[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n) return;
+    const int b0 = blockIdx.z * NW;
+    const size_t c = (size_t)P.coord_off + i;
+    const double r = D.cr[c], rp0 = D.crp[c], rt0 = D.crt[c], lnz = D.clnrelz[c], growth = D.cgrowth[c];
+    const double lnz2 = P.split_evol ? D.clnrelz2[c] : 0.0;
+    const size_t ell_stride = (size_t)B * D.n_active * D.ncp;
+    double out[NW];
+    bool oob[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int b = min(b0 + w, B - 1);
+        const double* sc = D.scal + ((size_t)b * D.n_pipe + P.pipe) * VMX_NS;
+        const double ev = (P.split_evol ? vmx_exp(fma(sc[S_EV1A], lnz, sc[S_EV2A] * lnz2)) : vmx_exp((sc[S_EV1A] + sc[S_EV2A]) * lnz)) * growth;
+        double xi = 0.0;
+        oob[w] = false;
+        if (r != 0.0) {
+            const double rrp = sc[S_AP] * (rp0 + sc[S_DRP]), rrt = sc[S_AT] * rt0;
+            const double rr2 = fma(rrp, rrp, rrt * rrt);
+            if (rr2 != 0.0) {
+                const double* col = D.coef + ((size_t)P.col * B + b) * D.ncp;
+                xi = xi_plain_spline(D, col, ell_stride, P.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), oob[w]) * ev;
+            }
+        }
+        if (P.radiation) {
+            const bool resc = P.radiation == 2;
+            const double drp = sc[S_DRP];
+            const double rp = resc ? fma(sc[S_AP], rp0 + drp, drp) : rp0 + drp;
+            const double rtr = resc ? sc[S_AT] * rt0 : rt0;
+            const double rs2 = fma(rp, rp, rtr * rtr);
+            const double irs = vmx_rsqrt(rs2);
+            const double rs = rs2 * irs, ms = rp * irs;
+            double xr = sc[S_RAD_S] * (irs * irs) * (1.0 - sc[S_RAD_A] * (1.0 - ms * ms));
+            xr *= vmx_exp(-rs * fma(1.0 + ms, sc[S_RAD_IL], sc[S_RAD_ID]));
+            xi += xr;
+        }
+        out[w] = xi;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int b = b0 + w;
+        if (b >= B) break;
+        if (oob[w]) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
+        D.xi[P.xi_off + (size_t)b * P.n_pad + i] = out[w];
     }
 }
 
