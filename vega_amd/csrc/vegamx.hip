@@ -228,6 +228,7 @@ struct vmx_engine {
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
     bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
+    int xi_lean_nw = 2, xi_static_nw = 4;     // VMX_XI_LEAN_NW / VMX_XI_STATIC_NW: walkers per thread of the two kernels (1, 2, 4)
     bool xi_lean = true;             // VMX_NO_XI_LEAN: every per-walker pipeline's bins by the general k_xi_bins
     std::vector<int32_t> xi_lean_pipes, xi_rest_pipes;      // the active pipelines k_xi_bins_lean serves / the others
     DevBuf<int32_t> d_xi_rest_pipes;
@@ -276,7 +277,7 @@ struct vmx_engine {
     // profiling
     bool profiling = false;
     uint32_t prof_mask = 0xffffffffu;     // kernel classes that get event pairs while profiling
-    int prof_stride = 1; int64_t prof_count = 0;      // ... every prof_stride-th launch of them (vmx_set_profiling_mask)
+    int prof_stride = 1; int64_t prof_count[32] = {};      // ... every prof_stride-th launch of each of them (vmx_set_profiling_mask)
     struct Span { hipEvent_t a, b; int kc; };
     std::vector<Span> spans;
     size_t span_used = 0;
@@ -319,7 +320,7 @@ struct ScopedTimer {
     vmx_engine* e; int idx = -1;
     ScopedTimer(vmx_engine* eng, int kc) : e(eng) {
         if (!e->profiling || !((e->prof_mask >> kc) & 1u)) return;
-        if (e->prof_stride > 1 && (e->prof_count++ % e->prof_stride) != 0) return;
+        if (e->prof_stride > 1 && (e->prof_count[kc]++ % e->prof_stride) != 0) return;
         if (e->span_used == e->spans.size()) {
             vmx_engine::Span s{};
             if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
@@ -1287,6 +1288,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
     if (const char* v = getenv("VMX_XI_PLAIN_NW")) e->xi_plain_nw = atoi(v);
     if (getenv("VMX_NO_XI_LEAN")) e->xi_lean = false;
+    if (const char* v = getenv("VMX_XI_LEAN_NW")) e->xi_lean_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
+    if (const char* v = getenv("VMX_XI_STATIC_NW")) e->xi_static_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
     if (const char* v = getenv("VMX_ITEM_STREAMS")) e->item_streams = atoi(v) != 0;
     if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
@@ -1525,7 +1528,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
                 const PipeDev& P = e->pipes[p];
                 const vmx_pipe_desc& d = P.d;
                 const bool lean = e->xi_lean && !e->extrapolate && d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD &&
-                                  !d.uv_shotnoise && !P.odd_rel && !P.odd_asy && d.single_ell < 0 && (!d.radiation || !d.is_peak) &&
+                                  !d.uv_shotnoise && !P.odd_rel && !P.odd_asy && d.single_ell < 0 && (!d.radiation || !d.is_peak) &&      // (the radiating pair's peak: faster by the general kernel)
                                   (int)e->xi_lean_pipes.size() < VMX_XI_LEAN_MAX;
                 (lean ? e->xi_lean_pipes : e->xi_rest_pipes).push_back(p);
             }
@@ -2312,7 +2315,11 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                 L.coord_off = P.coord_off; L.xi_off = P.xi_off; L.n = P.n; L.n_pad = P.n_pad; L.pipe = e->xi_lean_pipes[q]; L.col = P.col;
                 L.n_ell = P.d.n_ell; L.split_evol = P.split_evol; L.radiation = P.d.is_peak ? 0 : P.d.radiation;
             }
-            hipLaunchKernelGGL(k_xi_bins_lean<2>, dim3((max_n + 255) / 256, (unsigned)e->xi_lean_pipes.size(), (B + 1) / 2), dim3(256), 0, e->stream, D, LA, B);
+            const int nw = e->xi_lean_nw;
+            const dim3 grid((max_n + 255) / 256, (unsigned)e->xi_lean_pipes.size(), (B + nw - 1) / nw);
+            if (nw == 4) hipLaunchKernelGGL(k_xi_bins_lean<4>, grid, dim3(256), 0, e->stream, D, LA, B);
+            else if (nw == 2) hipLaunchKernelGGL(k_xi_bins_lean<2>, grid, dim3(256), 0, e->stream, D, LA, B);
+            else hipLaunchKernelGGL(k_xi_bins_lean<1>, grid, dim3(256), 0, e->stream, D, LA, B);
             if (!e->xi_rest_pipes.empty())
                 hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, (unsigned)e->xi_rest_pipes.size(), B), dim3(256), 0, e->stream, D, e->d_xi_rest_pipes.p);
         } else if (e->n_active > 0)
@@ -2322,8 +2329,30 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             // static-basis pipelines: tap form, and the ones already evaluated on their (static) bins
             if (!e->xi_static_taps.empty())
                 hipLaunchKernelGGL(k_xi_bins<true>, dim3((max_n + 255) / 256, (unsigned)e->xi_static_taps.size(), B), dim3(256), 0, e->stream, D, e->d_xi_static_taps.p);
-            if (!e->xi_static_bins.empty())
-                hipLaunchKernelGGL(k_xi_bins_static, dim3((max_n + 255) / 256, (unsigned)e->xi_static_bins.size(), B), dim3(256), 0, e->stream, D, e->d_xi_static_bins.p);
+            if (!e->xi_static_bins.empty()) {
+                bool lean = e->xi_lean && B > 8 && (int)e->xi_static_bins.size() <= VMX_XI_LEAN_MAX;
+                for (int p : e->xi_static_bins) {
+                    const PipeDev& P = e->pipes[p];
+                    const vmx_pipe_desc& d = P.d;
+                    lean = lean && d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD && !d.uv_shotnoise &&
+                           !P.odd_rel && !P.odd_asy && (!d.radiation || d.is_peak);
+                }
+                if (lean) {
+                    XiLeanArgs LA{};
+                    for (size_t q = 0; q < e->xi_static_bins.size(); ++q) {
+                        const PipeDev& P = e->pipes[e->xi_static_bins[q]];
+                        XiLeanPipe& L = LA.p[q];
+                        L.coord_off = P.coord_off; L.xi_off = P.xi_off; L.poly_off = P.poly_bins_off; L.n = P.n; L.n_pad = P.n_pad;
+                        L.pipe = e->xi_static_bins[q]; L.split_evol = P.split_evol; L.same_tracer = P.d.same_tracer;
+                    }
+                    const int nw = e->xi_static_nw;
+                    const dim3 grid((max_n + 255) / 256, (unsigned)e->xi_static_bins.size(), (B + nw - 1) / nw);
+                    if (nw == 4) hipLaunchKernelGGL(k_xi_bins_static_nw<4>, grid, dim3(256), 0, e->stream, D, LA, B);
+                    else if (nw == 2) hipLaunchKernelGGL(k_xi_bins_static_nw<2>, grid, dim3(256), 0, e->stream, D, LA, B);
+                    else hipLaunchKernelGGL(k_xi_bins_static_nw<1>, grid, dim3(256), 0, e->stream, D, LA, B);
+                } else
+                    hipLaunchKernelGGL(k_xi_bins_static, dim3((max_n + 255) / 256, (unsigned)e->xi_static_bins.size(), B), dim3(256), 0, e->stream, D, e->d_xi_static_bins.p);
+            }
         }
     }
     // dense metal-matrix products of an item (no split-K: the consumer reads one slab)
@@ -3310,7 +3339,7 @@ int vmx_set_profiling_mask(vmx_engine* e, uint32_t kernel_class_mask)
     // pair costs the queue a few microseconds, ~4 % of a B = 256 step when it sits around one kernel of every step)
     e->prof_stride = kernel_class_mask == 0xffffffffu ? 1 : 1 + (int)(kernel_class_mask >> 28);
     e->prof_mask = kernel_class_mask == 0xffffffffu ? kernel_class_mask : (kernel_class_mask & 0x0fffffffu);
-    e->prof_count = 0;
+    for (auto& c : e->prof_count) c = 0;
     return 0;
 }
 

@@ -3449,7 +3449,7 @@ __global__ __launch_bounds__(256) void k_xi_quad_plain(EngineDev D, XiPlainArgs 
 // the QSO radiation term - every pipeline of the joint + metals fit that forms its multipoles per walker: the pipeline's fields
 // in the kernel ARGUMENTS, NW walkers per thread (coordinates, evolution logarithm and growth loaded once; NW independent
 // spline chains in flight).  grid = (bins, pipelines of the list, ceil(B / NW)).
-struct XiLeanPipe { int64_t coord_off, xi_off; int32_t n, n_pad, pipe, col, n_ell, split_evol, radiation, pad; };
+struct XiLeanPipe { int64_t coord_off, xi_off, poly_off; int32_t n, n_pad, pipe, col, n_ell, split_evol, radiation, same_tracer; };
 #define VMX_XI_LEAN_MAX 24
 struct XiLeanArgs { XiLeanPipe p[VMX_XI_LEAN_MAX]; };
 
@@ -3502,6 +3502,39 @@ __global__ __launch_bounds__(256) void k_xi_bins_lean(EngineDev D, XiLeanArgs A,
         if (oob[w]) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
         D.xi[P.xi_off + (size_t)b * P.n_pad + i] = out[w];
     }
+}
+
+// k_xi_bins_static, NW walkers per thread: one walker per thread re-reads the three basis values and the two per-bin
+// factors from L2 for every walker (8 loads per stored value, 2.3 GB of L2 reads per joint + metals step); here they are loaded
+// once for NW walkers.  Pipelines with the standard bias evolution and no additive term (the host's list).
+template <int NW>
+__global__ __launch_bounds__(256) void k_xi_bins_static_nw(EngineDev D, XiLeanArgs A, int B)
+{
+    const XiLeanPipe& P = A.p[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n) return;
+    const int b0 = blockIdx.z * NW;
+    const size_t c = (size_t)P.coord_off + i;
+    const double lnz = D.clnrelz[c], growth = D.cgrowth[c];
+    const double lnz2 = P.split_evol ? D.clnrelz2[c] : 0.0;
+    const double* y = D.poly_bins + P.poly_off + i;
+    const double y0 = y[0], y1 = y[P.n_pad], y2 = y[2 * (size_t)P.n_pad];
+    double out[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int b = min(b0 + w, B - 1);
+        const double* sc = D.scal + ((size_t)b * D.n_pipe + P.pipe) * VMX_NS;
+        double c01 = sc[S_BIAS1], c02 = sc[S_BIAS2];
+        const double c11 = sc[S_BB1], c12 = P.same_tracer ? sc[S_BB1] : sc[S_BB2];
+        if (P.same_tracer) c02 = c01;
+        const double a0 = c01 * c02, a1 = fma(c01, c12, c11 * c02), a2 = c11 * c12;
+        double xi = fma(a2, y2, fma(a1, y1, a0 * y0));
+        xi *= P.split_evol ? vmx_exp(fma(sc[S_EV1A], lnz, sc[S_EV2A] * lnz2)) : vmx_exp((sc[S_EV1A] + sc[S_EV2A]) * lnz);
+        out[w] = xi * growth;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        if (b0 + w < B) D.xi[P.xi_off + (size_t)(b0 + w) * P.n_pad + i] = out[w];
 }
 
 // chi2 = sum_items diff^T (C^-1 diff) + priors; sentinel on failure
