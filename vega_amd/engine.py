@@ -526,18 +526,18 @@ class Engine:
         for it in prob.items.values():
             n_mu |= {m.pipeline.pk.n_mu for m in it.metals}
         if len(n_mu) != 1:
-            raise NotImplementedError('all correlations must share num_bins_muk')
+            raise NotImplementedError('one engine holds one mu grid: correlations with different num_bins_muk go through engine_group.make_engine')
         self._check(lib.vmx_set_template(self._h, k.size, _dp(k), _dp(pk_peak), _dp(_f64(prob.pk_smooth)),
                                          _dp(_f64(prob.pk_full)), _dp(delta2), n_mu.pop()))
         old = {p.xi.old_fftlog for it in prob.items.values() for p in [it.core] + [m.pipeline for m in it.metals]}
         if len(old) != 1:
-            raise NotImplementedError('old_fftlog must be the same for every correlation')
+            raise NotImplementedError('one engine holds one transform: correlations with different old_fftlog go through engine_group.make_engine')
         self.old_fftlog = old.pop()
         if self.old_fftlog:
             self._check(lib.vmx_set_spline_extrapolation(self._h, 1))
         lowring = {p.xi.fht_lowring for it in prob.items.values() for p in [it.core] + [m.pipeline for m in it.metals]}
         if len(lowring) != 1:
-            raise NotImplementedError('fht_lowring must be the same for every correlation')
+            raise NotImplementedError('one engine holds one operator set: correlations with different fht_lowring go through engine_group.make_engine')
         lowring = lowring.pop()
         for i, ell in enumerate((0, 2, 4, 6)):
             op, x0, h, n_knots = fftlog_op.hamilton_xi_operator(k, ell) if self.old_fftlog else \

@@ -1,0 +1,220 @@
+"""Correlations whose `[model]` sections disagree on the transform settings: one engine per distinct setting.
+
+In the reference every correlation item owns its operators - `num_bins_muk` sizes its (k, mu) grid
+(vega/power_spectrum.py:52-58), `old_fftlog` / `fht_lowring` choose its P(k) -> xi transform (vega/pktoxi.py:36-60) -
+and nothing couples the items before the chi2 sum (vega/vega_interface.py:232-316).  A vegamx engine holds ONE mu grid
+and ONE FFTLog operator set in HBM, which is what every real configuration needs (the settings come from a shared
+template); here the rare mixed configuration is served by partitioning the items by setting and giving each part its
+own engine on the same GPU: chi2 is the sum of the parts' chi2 (the priors enter once, through the first part), a model
+is the concatenation of the parts' models in the configured item order.
+
+``make_engine`` returns a plain ``Engine`` when the settings agree - the group is never on the hot path of BASELINE.json's
+configurations.
+"""
+import copy
+
+import numpy as np
+
+from .engine import Engine
+
+SENTINEL = 1e100
+
+
+def item_settings(item):
+    """(num_bins_muk, old_fftlog, fht_lowring) of a correlation item; its metal pipelines read the same `[model]`
+    section in the reference (vega/metals.py:60-75), so a disagreement inside one item is a set-up error."""
+    pipes = [item.core] + [m.pipeline for m in item.metals]
+    keys = {(p.pk.n_mu, bool(p.xi.old_fftlog), bool(p.xi.fht_lowring)) for p in pipes}
+    if len(keys) != 1:
+        raise ValueError(f'the pipelines of one correlation item disagree on num_bins_muk / old_fftlog / fht_lowring: {sorted(keys)}')
+    return keys.pop()
+
+
+def setting_groups(problem):
+    """Item names partitioned by ``item_settings``, groups and members in the configured order."""
+    groups = {}
+    for name, item in problem.items.items():
+        groups.setdefault(item_settings(item), []).append(name)
+    return list(groups.values())
+
+
+def make_engine(problem, **kwargs):
+    groups = setting_groups(problem)
+    if len(groups) == 1:
+        return Engine(problem, **kwargs)
+    return EngineGroup(problem, groups, **kwargs)
+
+
+class EngineGroup:
+    """The ``Engine`` surface over one engine per setting group (see the module text)."""
+
+    def __init__(self, problem, groups, **kwargs):
+        if problem.global_cov is not None:
+            raise NotImplementedError('a global covariance couples correlations with different num_bins_muk / old_fftlog / '
+                                      'fht_lowring: one engine cannot hold them and separate engines cannot share it')
+        self.prob = problem
+        self.groups = [list(g) for g in groups]
+        self.children = []
+        try:
+            for gi, names in enumerate(self.groups):
+                sub = copy.copy(problem)
+                sub.items = {n: problem.items[n] for n in names}
+                if gi > 0:
+                    sub.priors = {}             # (the Gaussian priors are part of the first engine's chi2 only)
+                self.children.append(Engine(sub, **kwargs))
+        except Exception:
+            self.close()
+            raise
+        first = self.children[0]
+        self.lib, self.low, self.names, self.n_params, self.max_batch = first.lib, first.low, first.names, first.n_params, first.max_batch
+        assert all(c.names == self.names for c in self.children)
+        self.lanes = 1
+        self.item_names = list(problem.items)
+        self._owner = {n: c for c, names in zip(self.children, self.groups) for n in names}
+        # models in the configured item order
+        self.model_slices, self._gather = {}, []
+        off = 0
+        for name in self.item_names:
+            c = self._owner[name]
+            sl = c.model_slices[name]
+            self.model_slices[name] = slice(off, off + sl.stop - sl.start)
+            self._gather.append((self.children.index(c), sl, self.model_slices[name]))
+            off += sl.stop - sl.start
+        self.model_size = off
+        self.pipe_index = {key: (ci, pid) for ci, c in enumerate(self.children) for key, pid in c.pipe_index.items()}
+        self.metal_source = {key: v for c in self.children for key, v in c.metal_source.items()}
+        self.csr_items = [n for c in self.children for n in c.csr_items]
+        self._dev_bufs = None
+
+    # ---- evaluation
+    def theta_from_params(self, params=None):
+        return self.children[0].theta_from_params(params)
+
+    def eval(self, theta, want_model=False):
+        theta = np.asarray(theta, dtype=np.float64)
+        if theta.ndim == 1:
+            theta = theta[None, :]
+        parts = [c.eval(theta, want_model) for c in self.children]
+        status = parts[0][1].copy()
+        for p in parts[1:]:
+            status |= p[1]
+        chi2 = np.where(status != 0, SENTINEL, sum(p[0] for p in parts))
+        model = None
+        if want_model:
+            model = np.empty((theta.shape[0], self.model_size))
+            for ci, src, dst in self._gather:
+                model[:, dst] = parts[ci][2][:, src]
+        return chi2, status, model
+
+    def eval_device_tensor(self, theta, out):
+        """``theta`` CUDA float64 [B, n_params] -> ``out`` CUDA float64 [B]: every engine evaluates the walkers on its own
+        stream into its own buffer; the sum is formed on the caller's stream after the engines have drained."""
+        import torch
+        B = theta.shape[0]
+        if self._dev_bufs is None or self._dev_bufs.shape[1] < B:
+            self._dev_bufs = torch.empty((len(self.children), max(B, self.max_batch)), dtype=torch.float64, device=theta.device)
+        torch.cuda.current_stream(theta.device).synchronize()
+        for ci, c in enumerate(self.children):
+            c.eval_device(theta.data_ptr(), B, self._dev_bufs[ci].data_ptr())
+        for c in self.children:
+            c.sync()
+        parts = self._dev_bufs[:, :B]
+        total = parts.sum(dim=0)
+        out.copy_(torch.where(parts.max(dim=0).values >= SENTINEL, torch.full_like(total, SENTINEL), total))
+
+    def eval_device(self, *args, **kwargs):
+        raise NotImplementedError('an engine group evaluates device walkers through eval_device_tensor')
+
+    def sync(self):
+        for c in self.children:
+            c.sync()
+
+    def stream_handle(self):
+        return self.children[0].stream_handle()
+
+    def last_stream_handle(self):
+        return self.children[-1].last_stream_handle()
+
+    def set_lanes(self, lanes):
+        if int(lanes) != 1:
+            raise NotImplementedError('an engine group keeps one batch in flight per engine')
+
+    # ---- per item
+    def set_data(self, name, masked_data):
+        self._owner[name].set_data(name, masked_data)
+
+    def set_mock_pool(self, name, pool):
+        self._owner[name].set_mock_pool(name, pool)
+
+    def set_invcov(self, name, invcov):
+        self._owner[name].set_invcov(name, invcov)
+
+    def marg_coeff(self, name, B):
+        return self._owner[name].marg_coeff(name, B)
+
+    def metal_xi(self, item_name, pair_index):
+        return self._owner[item_name].metal_xi(item_name, pair_index)
+
+    # ---- every engine
+    def _all(self, method, *args, **kwargs):
+        return [getattr(c, method)(*args, **kwargs) for c in self.children]
+
+    def set_mock_index(self, index=None):
+        self._all('set_mock_index', index)
+
+    def set_constant_nl_hint(self, on=True, gaussian=False):
+        self._all('set_constant_nl_hint', on, gaussian)
+
+    def set_direct_pk(self, pk=None):
+        self._all('set_direct_pk', pk)
+
+    def set_quadratic_form(self, on=True):
+        return all(self._all('set_quadratic_form', on))
+
+    def set_mu_quadrature(self, node_rule=True):
+        self._all('set_mu_quadrature', node_rule)
+
+    def set_linear_spectra(self, pk_full, pk_smooth):
+        self._all('set_linear_spectra', pk_full, pk_smooth)
+
+    def set_parameter_transform(self, scale=None, shift=None):
+        self._all('set_parameter_transform', scale, shift)
+
+    def set_metal_beta_override(self, beta=None):
+        self._all('set_metal_beta_override', beta)
+
+    def set_profiling(self, on):
+        self._all('set_profiling', on)
+
+    def set_profiling_classes(self, names, stride=1):
+        self._all('set_profiling_classes', names, stride)
+
+    def timings(self, reset=True):
+        total = {}
+        for t in self._all('timings', reset):
+            for k, (ms, n) in t.items():
+                a = total.get(k, (0.0, 0))
+                total[k] = (a[0] + ms, a[1] + n)
+        return total
+
+    def pk_multipoles(self, B=1):
+        """dict (engine index, pipeline id) -> [B, 4, nk], the keys ``pipe_index`` holds."""
+        return {(ci, pid): v for ci, c in enumerate(self.children) for pid, v in c.pk_multipoles(B).items()}
+
+    def mu_nodes(self):
+        return self.children[0].mu_nodes()
+
+    # ---- products on the first engine's kernels
+    def matvec_device(self, *args):
+        self.children[0].matvec_device(*args)
+
+    def matmul_host(self, A, X):
+        return self.children[0].matmul_host(A, X)
+
+    def debug_read(self, *args, **kwargs):
+        raise NotImplementedError('stage taps are per engine: read them from EngineGroup.children')
+
+    def close(self):
+        for c in self.children:
+            c.close()
+        self.children = []

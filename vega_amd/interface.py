@@ -11,7 +11,7 @@ import copy
 import numpy as np
 
 from . import metals_plan
-from .engine import Engine
+from .engine_group import make_engine
 from .setup import build_problem
 
 
@@ -85,7 +85,7 @@ class VegaInterface:
         from .setup import init_blinding
         self._blind, _ = init_blinding(self.problem.items, self.sample_params)
         self._rnsps = None
-        self.engine = Engine(self.problem, **self._engine_args)
+        self.engine = make_engine(self.problem, **self._engine_args)
         self.param_names = self.engine.names
         # fast_metals: the reference fills its metal caches at the first evaluation (metals_plan.py)
         self._metals_frozen = not metals_plan.needs_freeze(self.problem)
@@ -147,7 +147,7 @@ class VegaInterface:
         boot.eval(theta[None, :])
         plan, pinned = metals_plan.fast_metal_plan(self.problem, dict(zip(boot.names, theta)), boot.metal_xi)
         boot.close()
-        self.engine = Engine(self.problem, metal_plan=plan, **self._engine_args)
+        self.engine = make_engine(self.problem, metal_plan=plan, **self._engine_args)
         assert self.engine.names == self.param_names
         self._push_blinding()
         self._pinned_slots = np.array([self.engine.low.slot[n] for n in pinned], dtype=np.int64)
@@ -171,7 +171,7 @@ class VegaInterface:
         if not pinned and plan == old.metal_plan:
             return
         old.close()
-        self.engine = Engine(self.problem, metal_plan=plan, **self._engine_args)
+        self.engine = make_engine(self.problem, metal_plan=plan, **self._engine_args)
         assert self.engine.names == self.param_names
         self._push_blinding()
         merged = dict(zip(self._pinned_names, self._pinned_values))
@@ -438,6 +438,10 @@ class VegaInterface:
         else:
             torch.cuda.ExternalStream(eng.stream_handle(), device=theta.device).wait_event(current.record_event())
         mb = eng.max_batch
+        if hasattr(eng, 'eval_device_tensor'):      # (one engine per transform setting: engine_group.py)
+            for lo in range(0, n, mb):
+                eng.eval_device_tensor(theta[lo:lo + mb], out[lo:lo + mb])
+            return out
         for lo in range(0, n, mb):
             hi = min(lo + mb, n)
             eng.eval_device(theta[lo:hi].data_ptr(), hi - lo, out[lo:hi].data_ptr())
