@@ -779,6 +779,7 @@ def main():
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
             'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'distortion_csr': dist_csr, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'single_lane': single_lane, 'exact_mu_loop': exact_mu, 'regions': regions, 'other_paths': other_paths, 'cpu_baseline': cpu,
+            'pk_stage': dict(zip(('k_live', 'k_node_max', 'mu_nodes', 'k_on_node_rule', 'table_level'), [float(v) for v in pk_state])),
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
         }
         sys.stdout.flush()
