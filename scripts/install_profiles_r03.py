@@ -1,0 +1,46 @@
+"""Copy the summaries of scripts/gpu_refresh_profiles_r03.sh (gpurun_out/refresh/) into profiles/ under their committed names;
+the raw per-kernel counter means of the joint + metals and B = 1 passes are reduced to bytes per launch on the way
+(FETCH_SIZE / WRITE_SIZE are KiB; FETCH x 2 per the gfx950 note of MI355X_MICROARCH.md's HBM section)."""
+import json
+import shutil
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+SRC = Path(sys.argv[1]) if len(sys.argv) > 1 else REPO / 'gpurun_out' / 'refresh'
+DST = REPO / 'profiles'
+
+COPIES = {'bench_full.json': 'r03_bench_full.json', 'bench_core.json': 'r03_bench_core.json',
+          'kernel_stats.csv': 'r03_bench_core_kernel_stats.csv', 'traffic.json': 'r03_bench_core_traffic.json',
+          'quad_pmc.json': 'r03_quad_pmc.json', 'jm_kernel_stats.csv': 'r03_joint_metals_kernel_stats.csv',
+          'gemv_kernel_stats.csv': 'r03_distortion_gemv_kernel_stats.csv', 'b1_kernel_stats.csv': 'r03_single_point_chain_kernel_stats.csv'}
+for src, dst in COPIES.items():
+    text = (SRC / src).read_text()
+    if src.startswith('bench_'):
+        text = text.strip().splitlines()[-1] + '\n'         # (the JSON line only)
+    (DST / dst).write_text(text)
+
+
+def reduce(raw_name, how, keep=None):
+    raw = json.loads((SRC / raw_name).read_text())
+    out = {}
+    for kernel, rec in raw.items():
+        if keep and not any(k in kernel for k in keep):
+            continue
+        c = rec.get('counters_mean_per_launch', {})
+        entry = {'runs': rec.get('runs')}
+        if 'FETCH_SIZE' in c:
+            entry['fetch_bytes_per_launch'] = c['FETCH_SIZE'] * 1024 * 2
+        if 'WRITE_SIZE' in c:
+            entry['write_bytes_per_launch'] = c['WRITE_SIZE'] * 1024
+        out[kernel] = entry
+    return {'_how': how, 'kernels': out}
+
+
+jm = reduce('jm_traffic_raw.json', 'FETCH_SIZE / WRITE_SIZE passes (KiB; FETCH x 2 per the gfx950 note of MI355X_MICROARCH.md) of '
+            '`bench.py --core-only --workload joint_metals --batch 512 --lanes 1 --no-static-metals`')
+(DST / 'r03_joint_metals_traffic.json').write_text(json.dumps(jm, indent=1, sort_keys=True) + '\n')
+gemv = reduce('gemv_traffic_raw.json', 'FETCH_SIZE pass of scripts/gpu_matvec_only.py (B = 1 product, 2500^2, 8 distinct matrices '
+              'round-robin then one reused); KiB x 2', keep=('k_gemv1',))
+(DST / 'r03_distortion_gemv_traffic.json').write_text(json.dumps(gemv, indent=1, sort_keys=True) + '\n')
+print('installed', len(COPIES) + 2, 'files into', DST)
