@@ -43,4 +43,21 @@ jm = reduce('jm_traffic_raw.json', 'FETCH_SIZE / WRITE_SIZE passes (KiB; FETCH x
 gemv = reduce('gemv_traffic_raw.json', 'FETCH_SIZE pass of scripts/gpu_matvec_only.py (B = 1 product, 2500^2, 8 distinct matrices '
               'round-robin then one reused); KiB x 2', keep=('k_gemv1',))
 (DST / 'r03_distortion_gemv_traffic.json').write_text(json.dumps(gemv, indent=1, sort_keys=True) + '\n')
+# the figures DESIGN section 5 quotes, derived from the counter means (1024 SIMDs, 32 shader engines on the part)
+pmc = json.loads((SRC / 'quad_pmc.json').read_text())
+derived = {}
+for tag, needle in (('quadratic_form_product', 'k_gemm_nt44<12'), ('pk_tab2', 'k_pk_tab2<64')):
+    name = next(k for k in pmc if needle in k)
+    c, runs = pmc[name]['counters_mean_per_launch'], pmc[name]['runs']
+    cycles = c['SQ_BUSY_CYCLES'] / 32
+    us = runs[0]['avg_us']
+    d = {'kernel': name, 'cycles_per_launch': cycles, 'avg_us_of_that_pass': us, 'clock_GHz': cycles / us / 1e3,
+         'valu_wave_instructions': c['SQ_INSTS_VALU'], 'valu_issue_slot_fraction': c['SQ_INSTS_VALU'] / 1024 * 4 / cycles,
+         'lds_bank_conflict_cycles': c['SQ_LDS_BANK_CONFLICT'], 'wave_cycles': c['SQ_WAVE_CYCLES']}
+    if c.get('SQ_INSTS_MFMA'):
+        d.update(mfma_instructions=c['SQ_INSTS_MFMA'], mfma_busy_cycles_per_simd=c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024,
+                 mfma_busy_fraction=c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cycles)
+    derived[tag] = d
+pmc = {'derived': derived, **pmc}
+(DST / 'r03_quad_pmc.json').write_text(json.dumps(pmc, indent=1) + '\n')
 print('installed', len(COPIES) + 2, 'files into', DST)
