@@ -125,8 +125,13 @@ def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
     algo_bytes = 8.0 * (n * n + n + n)          # 8 (N_out N_in + B N_in + B N_out)
     cold = algo_bytes / (ms / launches * 1e-3) / 1e9
     hot = algo_bytes / (ms_hot / launches_hot * 1e-3) / 1e9
-    traffic_file = REPO / 'profiles' / 'r01_distortion_gemv_traffic.json'
-    traffic = json.loads(traffic_file.read_text())['fetch_bytes_per_launch'] if traffic_file.exists() and n == 2500 else None
+    # (FETCH_SIZE pass of the same product under rocprofv3, scripts/gpu_matvec_only.py: the committed summary)
+    traffic = None
+    traffic_file = REPO / 'profiles' / 'r03_distortion_gemv_traffic.json'
+    if traffic_file.exists() and n == 2500:
+        for name, rec in json.loads(traffic_file.read_text())['kernels'].items():
+            if 'k_gemv1' in name:
+                traffic = rec.get('fetch_bytes_per_launch')
     return {'shape': [n, n], 'batch': 1, 'bound': 'hbm', 'algorithmic_bytes': algo_bytes, 'traffic': traffic,
             'us_per_launch': ms / launches * 1e3, 'achieved': cold, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': cold / HBM_PEAK_GBS, 'achieved_cache_resident': hot, 'max_rel_err': err,
@@ -738,6 +743,12 @@ def main():
             roofline['traffic'] = traffic[roof_class]['hbm_bytes_per_launch']
             roofline['traffic_unit'] = 'bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r03_bench_core_traffic.json)'
             roofline['algorithmic_bytes_per_launch'] = traffic[roof_class]['algorithmic_bytes_per_launch']
+            # the counter passes belong to the kernel as it was when they were collected: their launch duration travels with
+            # them, and a live duration that has moved away from it says the file is due for a refresh
+            collected_us = traffic[roof_class].get('avg_us_kernel_trace_run')
+            if collected_us:
+                roofline['traffic_collected_at_us_per_launch'] = collected_us
+                roofline['traffic_stale'] = bool(abs(live[roof_class]['ms_per_launch'] * 1e3 / collected_us - 1.0) > 0.1)
         if roofline is not None:
             roofline['launches_timed'] = live[roof_class]['launches']
             roofline['timing'] = 'HIP events on the launch stream, over the timed region'
