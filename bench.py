@@ -252,7 +252,9 @@ def monte_carlo_fits(prob, device, n_mocks=1024):
     sample = {'limits': limits, 'values': {n: vega.params[n] for n in names}, 'errors': errors,
               'fix': {n: False for n in names}}
     truth = np.array([vega.params[n] for n in names])
-    out = {'workload': f'{n_mocks} mocks x {len(names)}-parameter fits (mock generation + minimisation + Hessian)'}
+    out = {'workload': f'{n_mocks} mocks x {len(names)}-parameter fits (mock generation + minimisation + Hessian), after an untimed '
+                       '128-mock run of the same call (buffers of the mock pool, clocks)'}
+    vega.run_monte_carlo(num_mocks=128, seed=5, sample_params=sample, method='migrad')
     # 'migrad': MIGRAD's own sequence of steps per fit (vega_amd/migrad.py - what the reference runs through iminuit), the fits
     # advancing in lock-step; 'bfgs': the vectorised variable-metric minimiser (Minuit's conventions, not its trajectory)
     for method in ('migrad', 'bfgs'):

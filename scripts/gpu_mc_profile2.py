@@ -12,7 +12,7 @@ pr = cProfile.Profile()
 pr.enable()
 out = bench.monte_carlo_fits(prob, 0, n_mocks=1024)
 pr.disable()
-print(out['fits_per_s'], out['seconds'])
+print({m: (out[m]['fits_per_s'], out[m]['seconds']) for m in ('migrad', 'bfgs')})
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(28)
-print(s.getvalue()[:6000])
+pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
+print(s.getvalue()[:9000])
