@@ -59,3 +59,29 @@ def test_group_keeps_the_priors_once():
     pars = dict(prob.params)
     assert vega.chi2(pars) == pytest.approx(oc.chi2(prob, pars), rel=CHI2_RTOL)
     vega.close()
+
+
+def test_two_voigt_tables():
+    """`fvoigt_model` per correlation (reference vega/power_spectrum.py:310-340): two tables, two engines."""
+    from oracle import vega_cpu as oc
+    from vega_amd import VegaInterface
+    from vega_amd.engine_group import EngineGroup
+    from vega_amd.setup import load_fvoigt_table
+    from conftest import GOLDEN
+    prob = synth_joint_problem()
+    table = load_fvoigt_table('fvoigt_models/Fvoigt_exp.txt', [GOLDEN / 'inputs'])
+    other = table.copy()
+    other[:, 1] = other[:, 1]**1.3
+    for item, tab in zip(prob.items.values(), (table, other)):
+        item.core.pk.hcd_model = 'fvoigt'
+        item.core.pk.fvoigt_table = tab
+    prob.params['L0_fvoigt'] = 0.8
+    vega = VegaInterface(None, problem=prob, max_batch=4)
+    assert isinstance(vega.engine, EngineGroup)
+    pars = dict(prob.params)
+    model = vega.compute_model(pars)
+    ref = oc.compute_model(prob, pars)
+    for name in prob.items:
+        assert np.abs(model[name] - ref[name]).max() <= XI_RTOL * np.abs(ref[name]).max(), name
+    assert vega.chi2(pars) == pytest.approx(oc.chi2(prob, pars), rel=CHI2_RTOL)
+    vega.close()

@@ -1,10 +1,10 @@
 """Correlations whose `[model]` sections disagree on the transform settings: one engine per distinct setting.
 
 In the reference every correlation item owns its operators - `num_bins_muk` sizes its (k, mu) grid
-(vega/power_spectrum.py:52-58), `old_fftlog` / `fht_lowring` choose its P(k) -> xi transform (vega/pktoxi.py:36-60) -
-and nothing couples the items before the chi2 sum (vega/vega_interface.py:232-316).  A vegamx engine holds ONE mu grid
-and ONE FFTLog operator set in HBM, which is what every real configuration needs (the settings come from a shared
-template); here the rare mixed configuration is served by partitioning the items by setting and giving each part its
+(vega/power_spectrum.py:52-58), `old_fftlog` / `fht_lowring` choose its P(k) -> xi transform (vega/pktoxi.py:36-60), an
+`fvoigt_model` names its Voigt-profile table (vega/power_spectrum.py:310-340) - and nothing couples the items before the
+chi2 sum (vega/vega_interface.py:232-316).  A vegamx engine holds ONE mu grid, ONE FFTLog operator set and ONE Voigt table
+in HBM, which is what every real configuration needs (the settings come from a shared template); here the rare mixed configuration is served by partitioning the items by setting and giving each part its
 own engine on the same GPU: chi2 is the sum of the parts' chi2 (the priors enter once, through the first part), a model
 is the concatenation of the parts' models in the configured item order.
 
@@ -20,14 +20,25 @@ from .engine import Engine
 SENTINEL = 1e100
 
 
+def _fvoigt_key(pipe):
+    """The Voigt-profile table of an `fvoigt` HCD model (`fvoigt_model`, vega/power_spectrum.py:310-340; one table per engine),
+    as a hashable: None when the pipeline has none."""
+    table = getattr(pipe.pk, 'fvoigt_table', None)
+    return None if table is None else hash(np.ascontiguousarray(table).tobytes())
+
+
 def item_settings(item):
-    """(num_bins_muk, old_fftlog, fht_lowring) of a correlation item; its metal pipelines read the same `[model]`
-    section in the reference (vega/metals.py:60-75), so a disagreement inside one item is a set-up error."""
+    """(num_bins_muk, old_fftlog, fht_lowring, Fvoigt table) of a correlation item; its metal pipelines read the same
+    `[model]` section in the reference (vega/metals.py:60-75), so a disagreement on the transform inside one item is a
+    set-up error.  (Pipelines without a Voigt table go with whatever table their item's other pipelines use.)"""
     pipes = [item.core] + [m.pipeline for m in item.metals]
     keys = {(p.pk.n_mu, bool(p.xi.old_fftlog), bool(p.xi.fht_lowring)) for p in pipes}
     if len(keys) != 1:
         raise ValueError(f'the pipelines of one correlation item disagree on num_bins_muk / old_fftlog / fht_lowring: {sorted(keys)}')
-    return keys.pop()
+    tables = {k for k in map(_fvoigt_key, pipes) if k is not None}
+    if len(tables) > 1:
+        raise NotImplementedError('one correlation item with two different Fvoigt tables')
+    return keys.pop() + (tables.pop() if tables else None,)
 
 
 def setting_groups(problem):
@@ -35,7 +46,17 @@ def setting_groups(problem):
     groups = {}
     for name, item in problem.items.items():
         groups.setdefault(item_settings(item), []).append(name)
-    return list(groups.values())
+    # an item without a Voigt table can share an engine with one that has one (same transform settings)
+    merged = {}
+    for key, names in groups.items():
+        if key[3] is None:
+            host = next((k for k in groups if k[:3] == key[:3] and k[3] is not None), key)
+            merged.setdefault(host, []).extend(names)
+        else:
+            merged.setdefault(key, []).extend(names)
+    order = {name: i for i, name in enumerate(problem.items)}
+    out = [sorted(names, key=order.get) for names in merged.values()]
+    return sorted(out, key=lambda names: order[names[0]])
 
 
 def make_engine(problem, **kwargs):
