@@ -16,6 +16,8 @@ H_ell is written down from the FFTLog's circulant structure: with the zero-padde
 low-ringing offset ln(xy) and the kernel's Mellin transform U_ell, the transform of a unit impulse
 is one row of ``hfft(u)/N``.
 """
+import functools
+
 import numpy as np
 from scipy.special import loggamma
 
@@ -54,9 +56,11 @@ def fftlog_matrix(k, ell, q=1.5, lowring=True):
     return post[:, None] * circ * pre[None, :], ln_r
 
 
+@functools.lru_cache(maxsize=4)
 def notaknot_bspline_matrix(n):
     """S ((n+2) x n): knot values on a uniform grid -> uniform cubic B-spline coefficients of the
-    not-a-knot interpolating spline.  Coefficient i multiplies the B-spline centred on knot i-1."""
+    not-a-knot interpolating spline.  Coefficient i multiplies the B-spline centred on knot i-1.
+    (A function of the knot count alone - the four multipoles of an engine share it; cached, read-only.)"""
     M = np.zeros((n + 2, n + 2))
     idx = np.arange(n)
     M[idx, idx] = 1.0 / 6.0
@@ -67,7 +71,9 @@ def notaknot_bspline_matrix(n):
     M[n + 1, n - 3:n + 2] = stencil     # ... and at knot n-2
     rhs = np.zeros((n + 2, n))
     rhs[idx, idx] = 1.0
-    return np.linalg.solve(M, rhs)
+    S = np.linalg.solve(M, rhs)
+    S.setflags(write=False)
+    return S
 
 
 def xi_operator(k, ell, lowring=True):

@@ -232,7 +232,9 @@ class _Fit:
         return grd, g2, gstep
 
     # ---- line search (MnLineSearch)
-    def _line_search(self, x, f0, step, gdel):
+    def _line_search(self, x, f0, step, gdel, lam_only=False):
+        # lam_only: the coroutine asks for f(x + lam step) by yielding lam alone and is sent the value - the batch driver forms the
+        # points of all its fits in one array operation (no per-request arrays)
         overal, undral, toler, slambg, alpha, maxiter = 1000., -100., 0.05, 5., 2., 12
         niter = 1
         slamin = 0.
@@ -246,7 +248,7 @@ class _Fit:
             slamin = EPS
         slamin *= EPS2
 
-        f1 = (yield from self._eval(x + step))[0]
+        f1 = (yield 1.) if lam_only else (yield from self._eval(x + step))[0]
         niter += 1
         fvmin, xvmin = f0, 0.
         if f1 < f0:
@@ -273,7 +275,7 @@ class _Fit:
                 return xvmin, fvmin
             if abs(slam - 1.) < toler8:
                 slam = 1. + toler8
-            f2 = (yield from self._eval(x + slam * step))[0]
+            f2 = (yield slam) if lam_only else (yield from self._eval(x + slam * step))[0]
             niter += 1
             if f2 < fvmin:
                 fvmin, xvmin = f2, slam
@@ -325,7 +327,7 @@ class _Fit:
                 toler9 = max(toler8, abs(toler8 * slam))
                 if abs(p0[0] - slam) < toler9 or abs(p1[0] - slam) < toler9 or abs(p2[0] - slam) < toler9:
                     return xvmin, fvmin
-                f3 = (yield from self._eval(x + slam * step))[0]
+                f3 = (yield slam) if lam_only else (yield from self._eval(x + slam * step))[0]
                 if f3 > p0[1] and f3 > p1[1] and f3 > p2[1]:
                     if slam > xvmin:
                         overal = min(overal, slam - toler8)
@@ -917,30 +919,30 @@ class _Batch:
 
     # ---- line searches of the fits idx: per-fit coroutines, joined evaluations
     def _line_searches(self, idx, x, f0, step, gdel):
-        helpers = [self._ls_helper] * idx.size
-        gens, lam, fnew = {}, np.zeros(idx.size), np.array(f0, dtype=float)
-        pending = {}
-        for q in range(idx.size):
-            g = helpers[q]._line_search(x[q], f0[q], step[q], gdel[q])
+        ls = self._ls_helper
+        m = idx.size
+        lam, fnew = np.zeros(m), np.array(f0, dtype=float)
+        gens, want = [None] * m, np.zeros(m)
+        live = []
+        for q in range(m):
+            g = ls._line_search(x[q], float(f0[q]), step[q], float(gdel[q]), lam_only=True)
             try:
-                pending[q] = (g, next(g))
+                want[q] = next(g)
+                gens[q] = g
+                live.append(q)
             except StopIteration as stop:
                 lam[q], fnew[q] = stop.value
-        while pending:
-            keys = list(pending)
-            pts = np.concatenate([pending[q][1] for q in keys])
-            owner = np.concatenate([np.full(pending[q][1].shape[0], idx[q]) for q in keys])
-            vals = self._f(pts, owner)
-            nxt, off = {}, 0
-            for q in keys:
-                g, req = pending[q]
-                mq = req.shape[0]
+        while live:
+            keys = np.array(live, dtype=int)
+            vals = self._f(x[keys] + want[keys, None] * step[keys], idx[keys]).tolist()
+            nxt = []
+            for q, v in zip(live, vals):
                 try:
-                    nxt[q] = (g, g.send(vals[off:off + mq]))
+                    want[q] = gens[q].send(v)
+                    nxt.append(q)
                 except StopIteration as stop:
                     lam[q], fnew[q] = stop.value
-                off += mq
-            pending = nxt
+            live = nxt
         return lam, fnew
 
     # ---- the iterations (VariableMetricBuilder) for the fits `act`, until each converges
