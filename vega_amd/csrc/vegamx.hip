@@ -228,6 +228,16 @@ struct vmx_engine {
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
     bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
+    // pre-summed bins (xi_sum_plan): groups of the lean / static-coordinate pipelines of an item, and what assemble_bin is told
+    bool xi_sums = true;             // VMX_NO_XI_SUMS: one array per pipeline, as the general kernels write them
+    bool sums_dirty = true;
+    std::vector<XiLeanGroup> lean_groups; std::vector<XiStaticGroup> static_groups;
+    std::vector<int32_t> static_single;              // static-coordinate pipelines that keep their own array
+    DevBuf<XiLeanGroup> d_lean_groups; DevBuf<XiStaticGroup> d_static_groups; DevBuf<ItemSums> d_item_sums;
+    DevBuf<int32_t> d_static_single;
+    bool sums_any = false;
+    int xi_group_size = VMX_XI_GROUP_MEMBERS, xi_sgroup_size = VMX_XI_SGROUP_MEMBERS;      // VMX_XI_GROUP / VMX_XI_SGROUP: members per array
+    int xi_static_group_nw = 2;      // VMX_XI_STATIC_NW: walkers per thread of k_xi_bins_static_group (k_xi_bins_static_nw: 4)
     int xi_lean_nw = 2, xi_static_nw = 4;     // VMX_XI_LEAN_NW / VMX_XI_STATIC_NW: walkers per thread of the two kernels (1, 2, 4)
     bool xi_lean = true;             // VMX_NO_XI_LEAN: every per-walker pipeline's bins by the general k_xi_bins
     std::vector<int32_t> xi_lean_pipes, xi_rest_pipes;      // the active pipelines k_xi_bins_lean serves / the others
@@ -1251,6 +1261,7 @@ int vmx_add_prior(vmx_engine* e, int32_t slot, double mean, double sigma)
 }
 
 static int poly_basis_build(vmx_engine* e);
+static int xi_sum_plan(vmx_engine* e);
 
 int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 {
@@ -1288,8 +1299,11 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
     if (const char* v = getenv("VMX_XI_PLAIN_NW")) e->xi_plain_nw = atoi(v);
     if (getenv("VMX_NO_XI_LEAN")) e->xi_lean = false;
+    if (getenv("VMX_NO_XI_SUMS")) e->xi_sums = false;
+    if (const char* v = getenv("VMX_XI_GROUP")) e->xi_group_size = std::min(std::max(atoi(v), 2), VMX_XI_GROUP_MEMBERS);
+    if (const char* v = getenv("VMX_XI_SGROUP")) e->xi_sgroup_size = std::min(std::max(atoi(v), 2), VMX_XI_SGROUP_MEMBERS);
     if (const char* v = getenv("VMX_XI_LEAN_NW")) e->xi_lean_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
-    if (const char* v = getenv("VMX_XI_STATIC_NW")) e->xi_static_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
+    if (const char* v = getenv("VMX_XI_STATIC_NW")) e->xi_static_group_nw = e->xi_static_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
     if (const char* v = getenv("VMX_ITEM_STREAMS")) e->item_streams = atoi(v) != 0;
     if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
     if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
@@ -1702,7 +1716,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 
     HIP_OK(hipStreamSynchronize(e->stream));
     e->finalized = true;
-    if (poly_basis_build(e)) { e->finalized = false; return -2; }
+    if (poly_basis_build(e) || xi_sum_plan(e)) { e->finalized = false; return -2; }
     return 0;
 }
 
@@ -1980,6 +1994,7 @@ static int poly_basis_build(vmx_engine* e)
     e->poly_dirty = false;
     const int ns = (int)e->pk_static.size();
     e->xi_static_taps.clear(); e->xi_static_bins.clear();
+    e->sums_dirty = true;
     if (ns == 0) return 0;
     DevBuf<double> V;
     const int64_t rows = (int64_t)ns * 3;
@@ -2137,6 +2152,133 @@ static bool xi_plain_args(vmx_engine* e, XiPlainArgs& A)
         I.radiation = Ps.d.radiation;
     }
     return true;
+}
+
+// Which bins arrive pre-summed (ItemSums): per item, the lean per-walker pipelines in groups of four and the static-coordinate
+// pipelines in groups of sixteen, each member with the factor it enters the item's vector with.  A pipeline with a second
+// reader of its own array - another metal pair (fast_metals sharing), a metal matrix product - keeps that array (a group of
+// one, presum = 0).  A pure function of the engine's configuration; rebuilt when the static basis is.
+static int xi_sum_plan(vmx_engine* e)
+{
+    e->sums_dirty = false;
+    e->lean_groups.clear(); e->static_groups.clear(); e->static_single.clear();
+    e->sums_any = false;
+    const int np = (int)e->pipes.size();
+    struct Role { int item = -1, fkind = 0, findex = 0, metal = -1, refs = 0; bool plain = true; };
+    std::vector<Role> role(np);
+    int metal_base = 0;
+    for (int q = 0; q < (int)e->items.size(); ++q) {
+        const ItemHost* it = e->items[q];
+        const vmx_item_desc& d = it->dev.d;
+        auto take = [&](int p, int fkind, int findex, int metal, bool plain) {
+            if (p < 0 || p >= np) return;
+            Role& r = role[p];
+            r.refs += 1; r.item = q; r.fkind = fkind; r.findex = findex; r.metal = metal; r.plain = r.plain && plain;
+        };
+        take(d.pipe_smooth, 0, 0, -1, true);
+        if (d.pipe_peak != d.pipe_smooth) take(d.pipe_peak, 1, d.bao_amp_slot, -1, true);
+        else role[d.pipe_smooth].plain = false;
+        for (int m = 0; m < (int)it->metals.size(); ++m) {
+            const MetalDev& md = it->metals[m]->dev;
+            if (md.d.pipeline >= 0) take(md.d.pipeline, 2, metal_base + m, m, !md.basis && !md.svec && md.mat_off < 0 && m < 64);
+        }
+        metal_base += (int)it->metals.size();
+    }
+    std::vector<ItemSums> sums(e->items.size());
+    for (size_t q = 0; q < sums.size(); ++q) { sums[q] = ItemSums{}; sums[q].n_pad = e->items[q]->dev.n_model_pad; }
+    auto member_of = [&](int p) {
+        const PipeDev& P = e->pipes[p];
+        XiMember M{};
+        M.coord_off = P.coord_off; M.poly_off = P.poly_bins_off; M.pipe = p; M.col = P.col; M.n_ell = P.d.n_ell;
+        M.split_evol = P.split_evol; M.radiation = P.d.is_peak ? 0 : P.d.radiation; M.same_tracer = P.d.same_tracer;
+        M.fkind = role[p].fkind; M.findex = role[p].findex;
+        return M;
+    };
+    auto groupable = [&](int p) {
+        const Role& r = role[p];
+        return e->xi_sums && r.refs == 1 && r.plain && r.item >= 0 && e->pipes[p].n_pad == e->items[r.item]->dev.n_model_pad &&
+               sums[r.item].n_arrays < 8;
+    };
+    auto mark = [&](int p) {
+        const Role& r = role[p];
+        ItemSums& sm = sums[r.item];
+        if (r.fkind == 0) sm.core_smooth = 1;
+        else if (r.fkind == 1) sm.core_peak = 1;
+        else sm.metal_mask |= 1ull << r.metal;
+    };
+    // the lean per-walker pipelines
+    for (int q = 0; q < (int)e->items.size(); ++q) {
+        XiLeanGroup G{};
+        auto flush = [&]() {
+            if (G.n_members == 0) return;
+            if (G.n_members == 1) G.presum = 0;        // (a sum of one: the plain array, read with its factor as before)
+            else {
+                sums[q].off[sums[q].n_arrays++] = G.out_off;
+                for (int m = 0; m < G.n_members; ++m) mark(G.m[m].pipe);
+                e->sums_any = true;
+            }
+            e->lean_groups.push_back(G);
+            G = XiLeanGroup{};
+        };
+        for (int p : e->xi_lean_pipes) {
+            if (role[p].item != q || !groupable(p)) continue;
+            const PipeDev& P = e->pipes[p];
+            if (G.n_members == 0) { G.out_off = P.xi_off; G.n = P.n; G.n_pad = P.n_pad; G.presum = 1; }
+            G.m[G.n_members++] = member_of(p);
+            if (G.n_members == e->xi_group_size || sums[q].n_arrays >= 7) flush();
+        }
+        flush();
+    }
+    for (int p : e->xi_lean_pipes) {
+        bool placed = false;
+        for (auto& G : e->lean_groups) for (int m = 0; m < G.n_members; ++m) placed = placed || G.m[m].pipe == p;
+        if (placed) continue;
+        const PipeDev& P = e->pipes[p];
+        XiLeanGroup G{};
+        G.out_off = P.xi_off; G.n = P.n; G.n_pad = P.n_pad; G.presum = 0; G.n_members = 1; G.m[0] = member_of(p);
+        e->lean_groups.push_back(G);
+    }
+    // the static-coordinate pipelines (standard evolution, nothing added: what k_xi_bins_static_nw serves)
+    auto static_lean = [&](int p) {
+        const PipeDev& P = e->pipes[p];
+        const vmx_pipe_desc& d = P.d;
+        return d.tracer[0].evol_kind == VMX_EVOL_STD && d.tracer[1].evol_kind == VMX_EVOL_STD && !d.uv_shotnoise && !P.odd_rel && !P.odd_asy &&
+               (!d.radiation || d.is_peak);
+    };
+    for (int q = 0; q < (int)e->items.size(); ++q) {
+        XiStaticGroup G{};
+        auto flush = [&]() {
+            if (G.n_members == 0) return;
+            if (G.n_members == 1) { e->static_single.push_back(G.m[0].pipe); G = XiStaticGroup{}; return; }
+            sums[q].off[sums[q].n_arrays++] = G.out_off;
+            for (int m = 0; m < G.n_members; ++m) mark(G.m[m].pipe);
+            e->sums_any = true;
+            e->static_groups.push_back(G);
+            G = XiStaticGroup{};
+        };
+        for (int p : e->xi_static_bins) {
+            if (role[p].item != q || !groupable(p) || !static_lean(p)) continue;
+            const PipeDev& P = e->pipes[p];
+            if (G.n_members == 0) { G.out_off = P.xi_off; G.n = P.n; G.n_pad = P.n_pad; G.presum = 1; }
+            G.m[G.n_members++] = member_of(p);
+            if (G.n_members == e->xi_sgroup_size) flush();
+        }
+        flush();
+    }
+    for (int p : e->xi_static_bins) {
+        bool placed = false;
+        for (auto& G : e->static_groups) for (int m = 0; m < G.n_members; ++m) placed = placed || G.m[m].pipe == p;
+        for (int s1 : e->static_single) placed = placed || s1 == p;
+        if (!placed) e->static_single.push_back(p);
+    }
+    HIP_OK(hipSetDevice(e->device));
+    if (!e->lean_groups.empty() && e->d_lean_groups.upload(e->lean_groups.data(), e->lean_groups.size())) return -2;
+    if (!e->static_groups.empty() && e->d_static_groups.upload(e->static_groups.data(), e->static_groups.size())) return -2;
+    if (e->d_item_sums.upload(sums.data(), sums.size())) return -2;
+    std::vector<int32_t> single = e->static_single;
+    single.push_back(-1);
+    if (e->d_static_single.upload(single.data(), single.size())) return -2;
+    return 0;
 }
 
 static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false, const double* d_theta = nullptr,
@@ -2307,7 +2449,19 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         ScopedTimer t(e, KC_XI);
         int max_n = 0;
         for (auto& p : e->pipes) max_n = p.n > max_n ? p.n : max_n;
-        if (B > 8 && !e->direct && !e->xi_lean_pipes.empty()) {
+        // bins that arrive pre-summed (xi_sum_plan): large chi2-only or model batches of engines with lean pipelines
+        const bool use_sums = B > 8 && !e->direct && e->xi_lean && e->xi_sums && !e->extrapolate;
+        const bool sums_on = use_sums && e->sums_any && !e->sums_dirty;      // (the plan is made with the static basis, outside any capture)
+        if (sums_on) { D.sums = e->d_item_sums.p; D.sums_on = 1; e->last_taps = false; }
+        if (sums_on && !e->lean_groups.empty()) {
+            const int nw = e->xi_lean_nw;
+            const dim3 grid((max_n + 255) / 256, (unsigned)e->lean_groups.size(), (B + nw - 1) / nw);
+            if (nw == 4) hipLaunchKernelGGL(k_xi_bins_group<4>, grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
+            else if (nw == 2) hipLaunchKernelGGL(k_xi_bins_group<2>, grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
+            else hipLaunchKernelGGL(k_xi_bins_group<1>, grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
+            if (!e->xi_rest_pipes.empty())
+                hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, (unsigned)e->xi_rest_pipes.size(), B), dim3(256), 0, e->stream, D, e->d_xi_rest_pipes.p);
+        } else if (B > 8 && !e->direct && !e->xi_lean_pipes.empty()) {
             XiLeanArgs LA{};
             for (size_t q = 0; q < e->xi_lean_pipes.size(); ++q) {
                 const PipeDev& P = e->pipes[e->xi_lean_pipes[q]];
@@ -2329,7 +2483,17 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             // static-basis pipelines: tap form, and the ones already evaluated on their (static) bins
             if (!e->xi_static_taps.empty())
                 hipLaunchKernelGGL(k_xi_bins<true>, dim3((max_n + 255) / 256, (unsigned)e->xi_static_taps.size(), B), dim3(256), 0, e->stream, D, e->d_xi_static_taps.p);
-            if (!e->xi_static_bins.empty()) {
+            if (sums_on && !e->xi_static_bins.empty()) {
+                const int nw = e->xi_static_group_nw;
+                if (!e->static_groups.empty()) {
+                    const dim3 grid((max_n + 255) / 256, (unsigned)e->static_groups.size(), (B + nw - 1) / nw);
+                    if (nw == 4) hipLaunchKernelGGL(k_xi_bins_static_group<4>, grid, dim3(256), 0, e->stream, D, e->d_static_groups.p, B);
+                    else if (nw == 2) hipLaunchKernelGGL(k_xi_bins_static_group<2>, grid, dim3(256), 0, e->stream, D, e->d_static_groups.p, B);
+                    else hipLaunchKernelGGL(k_xi_bins_static_group<1>, grid, dim3(256), 0, e->stream, D, e->d_static_groups.p, B);
+                }
+                if (!e->static_single.empty())
+                    hipLaunchKernelGGL(k_xi_bins_static, dim3((max_n + 255) / 256, (unsigned)e->static_single.size(), B), dim3(256), 0, e->stream, D, e->d_static_single.p);
+            } else if (!e->xi_static_bins.empty()) {
                 bool lean = e->xi_lean && B > 8 && (int)e->xi_static_bins.size() <= VMX_XI_LEAN_MAX;
                 for (int p : e->xi_static_bins) {
                     const PipeDev& P = e->pipes[p];
@@ -2980,7 +3144,8 @@ int vmx_set_linear_spectra(vmx_engine* e, const double* pk_peak, const double* p
     const double* src[3] = {pk_peak, pk_smooth, pk_full};
     for (int i = 0; i < 3; ++i)
         HIP_OK(hipMemcpy(e->pklin.p + (size_t)i * e->nkp, src[i], (size_t)nk * sizeof(double), hipMemcpyHostToDevice));
-    return poly_basis_build(e);
+    if (poly_basis_build(e)) return -2;
+    return xi_sum_plan(e);
 }
 
 int vmx_item_set_marg_matrix(vmx_engine* e, int32_t item, const double* m, int32_t n_templates, int32_t n_masked)

@@ -125,6 +125,16 @@ struct ItemDev {
 };
 
 
+// Bins that arrive pre-summed: a group kernel adds the contributions of up to four (static-coordinate pipelines: sixteen)
+// pipelines of an item - each times its walker's factor: 1, bao_amp or the metal pair's bias product - and stores ONE array,
+// in the bins slot of the group's first pipeline.  assemble_bin adds those arrays and skips the members.
+struct ItemSums {
+    int32_t n_arrays, n_pad;
+    int32_t core_peak, core_smooth;     // 1: the item's peak / smooth component is inside one of the arrays
+    uint64_t metal_mask;                // bit m: metal pair m of the item is
+    int64_t off[8];                     // offsets of the arrays in the bins buffer (per-walker stride n_pad)
+};
+
 struct EngineDev {
     // template
     int32_t nk, nkp, n_mu, n_ell;
@@ -197,6 +207,8 @@ struct EngineDev {
     double* pl;                 // [n_ell][n_active][B][nkp]   (pipeline-major columns: column = PipeDev::col * B + walker)
     double* coef;               // [n_ell][n_active][B][ncp]
     double* xi;                 // per pipeline [B][n]
+    // pre-summed bins (k_xi_bins_group / k_xi_bins_static_group; null / 0: every contribution of an item in its own array)
+    const struct ItemSums* sums; int32_t sums_on;
     double* xim;                // metal matrix products
     double* model;              // [B][model_size]
     double* chi2;               // [B]
@@ -1864,9 +1876,18 @@ __device__ inline double assemble_bin(const EngineDev& D, const ItemDev& it, int
     const PipeDev& Pp = D.pipes[it.d.pipe_peak];
     const PipeDev& Ps = D.pipes[it.d.pipe_smooth];
     const bool direct = D.pk_direct != nullptr;
-    double v = D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
-    if (!direct) v = fma(bao, D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin], v);
+    double v = 0.0;
+    uint64_t summed = 0;
+    bool peak_in = false, smooth_in = false;
+    if (D.sums_on) {
+        const ItemSums& sm = D.sums[&it - D.items];
+        for (int a = 0; a < sm.n_arrays; ++a) v += D.xi[sm.off[a] + (size_t)b * sm.n_pad + bin];
+        summed = sm.metal_mask; peak_in = sm.core_peak != 0; smooth_in = sm.core_smooth != 0;
+    }
+    if (!smooth_in) v += D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
+    if (!direct && !peak_in) v = fma(bao, D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin], v);
     for (int m = 0; m < (direct ? 0 : it.n_metals); ++m) {
+        if ((summed >> m) & 1) continue;
         const MetalDev& md = D.metals[it.metal_begin + m];
         const double* mb = D.metal_bias + (size_t)b * 3 * D.n_metals_total + it.metal_begin + m;
         const double f = mb[0];
@@ -3502,6 +3523,123 @@ __global__ __launch_bounds__(256) void k_xi_bins_lean(EngineDev D, XiLeanArgs A,
         if (oob[w]) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
         D.xi[P.xi_off + (size_t)b * P.n_pad + i] = out[w];
     }
+}
+
+// The lean bins kernel over GROUPS of pipelines of one item (descriptors in device memory, one array per group): a thread adds
+// its bin's value of every member, times the member's walker factor, and stores the sum - the per-pipeline arrays of the
+// members are never written nor read back by k_assemble_quad (joint + metals: 42 arrays of 15 MB per step become 10).
+// presum = 0: a single member whose plain bins are wanted (its array has another reader).  grid = (bins, groups, ceil(B / NW)).
+#define VMX_XI_GROUP_MEMBERS 4
+#define VMX_XI_SGROUP_MEMBERS 16
+struct XiMember { int64_t coord_off, poly_off; int32_t pipe, col, n_ell, split_evol, radiation, same_tracer, fkind, findex; };
+struct XiLeanGroup { int64_t out_off; int32_t n, n_pad, n_members, presum; XiMember m[VMX_XI_GROUP_MEMBERS]; };
+struct XiStaticGroup { int64_t out_off; int32_t n, n_pad, n_members, presum; XiMember m[VMX_XI_SGROUP_MEMBERS]; };
+
+// the factor a member's bins enter the item's vector with: 1 (smooth component), bao_amp (peak component), the metal pair's
+// bias product times its multiplicity (k_prologue's metal_bias)
+__device__ __forceinline__ double xi_member_factor(const EngineDev& D, const XiMember& P, int b)
+{
+    if (P.fkind == 1) return D.theta[(size_t)b * D.n_params + P.findex];
+    if (P.fkind == 2) return D.metal_bias[(size_t)b * 3 * D.n_metals_total + P.findex];
+    return 1.0;
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void k_xi_bins_group(EngineDev D, const XiLeanGroup* groups, int B)
+{
+    const XiLeanGroup& G = groups[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G.n) return;
+    const int b0 = blockIdx.z * NW;
+    const size_t ell_stride = (size_t)B * D.n_active * D.ncp;
+    double out[NW];
+    bool oob[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { out[w] = 0.0; oob[w] = false; }
+    // (unrolled: the members' chains of dependent lookups are independent of each other and run interleaved)
+#pragma unroll
+    for (int m = 0; m < VMX_XI_GROUP_MEMBERS; ++m) {
+        if (m >= G.n_members) break;
+        const XiMember& P = G.m[m];
+        const size_t c = (size_t)P.coord_off + i;
+        const double r = D.cr[c], rp0 = D.crp[c], rt0 = D.crt[c], lnz = D.clnrelz[c], growth = D.cgrowth[c];
+        const double lnz2 = P.split_evol ? D.clnrelz2[c] : 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int b = min(b0 + w, B - 1);
+            const double* sc = D.scal + ((size_t)b * D.n_pipe + P.pipe) * VMX_NS;
+            const double ev = (P.split_evol ? vmx_exp(fma(sc[S_EV1A], lnz, sc[S_EV2A] * lnz2)) : vmx_exp((sc[S_EV1A] + sc[S_EV2A]) * lnz)) * growth;
+            double xi = 0.0;
+            if (r != 0.0) {
+                const double rrp = sc[S_AP] * (rp0 + sc[S_DRP]), rrt = sc[S_AT] * rt0;
+                const double rr2 = fma(rrp, rrp, rrt * rrt);
+                if (rr2 != 0.0) {
+                    const double* col = D.coef + ((size_t)P.col * B + b) * D.ncp;
+                    bool o = false;
+                    xi = xi_plain_spline(D, col, ell_stride, P.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), o) * ev;
+                    oob[w] = oob[w] || o;
+                }
+            }
+            if (P.radiation) {
+                const bool resc = P.radiation == 2;
+                const double drp = sc[S_DRP];
+                const double rp = resc ? fma(sc[S_AP], rp0 + drp, drp) : rp0 + drp;
+                const double rtr = resc ? sc[S_AT] * rt0 : rt0;
+                const double rs2 = fma(rp, rp, rtr * rtr);
+                const double irs = vmx_rsqrt(rs2);
+                const double rs = rs2 * irs, ms = rp * irs;
+                double xr = sc[S_RAD_S] * (irs * irs) * (1.0 - sc[S_RAD_A] * (1.0 - ms * ms));
+                xr *= vmx_exp(-rs * fma(1.0 + ms, sc[S_RAD_IL], sc[S_RAD_ID]));
+                xi += xr;
+            }
+            out[w] = G.presum ? fma(xi_member_factor(D, P, b), xi, out[w]) : xi;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int b = b0 + w;
+        if (b >= B) break;
+        if (oob[w]) atomicOr(&D.status[b], VMX_STATUS_BOUNDS);
+        D.xi[G.out_off + (size_t)b * G.n_pad + i] = out[w];
+    }
+}
+
+// ... and the static-coordinate pipelines of an item (three basis values per bin and member), NW walkers per thread
+template <int NW>
+__global__ __launch_bounds__(256) void k_xi_bins_static_group(EngineDev D, const XiStaticGroup* groups, int B)
+{
+    const XiStaticGroup& G = groups[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G.n) return;
+    const int b0 = blockIdx.z * NW;
+    double out[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) out[w] = 0.0;
+#pragma unroll 4
+    for (int m = 0; m < G.n_members; ++m) {
+        const XiMember& P = G.m[m];
+        const size_t c = (size_t)P.coord_off + i;
+        const double lnz = D.clnrelz[c], growth = D.cgrowth[c];
+        const double lnz2 = P.split_evol ? D.clnrelz2[c] : 0.0;
+        const double* y = D.poly_bins + P.poly_off + i;
+        const double y0 = y[0], y1 = y[G.n_pad], y2 = y[2 * (size_t)G.n_pad];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int b = min(b0 + w, B - 1);
+            const double* sc = D.scal + ((size_t)b * D.n_pipe + P.pipe) * VMX_NS;
+            double c01 = sc[S_BIAS1], c02 = sc[S_BIAS2];
+            const double c11 = sc[S_BB1], c12 = P.same_tracer ? sc[S_BB1] : sc[S_BB2];
+            if (P.same_tracer) c02 = c01;
+            const double a0 = c01 * c02, a1 = fma(c01, c12, c11 * c02), a2 = c11 * c12;
+            double xi = fma(a2, y2, fma(a1, y1, a0 * y0));
+            xi *= P.split_evol ? vmx_exp(fma(sc[S_EV1A], lnz, sc[S_EV2A] * lnz2)) : vmx_exp((sc[S_EV1A] + sc[S_EV2A]) * lnz);
+            xi *= growth;
+            out[w] = G.presum ? fma(xi_member_factor(D, P, b), xi, out[w]) : xi;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        if (b0 + w < B) D.xi[G.out_off + (size_t)(b0 + w) * G.n_pad + i] = out[w];
 }
 
 // k_xi_bins_static, NW walkers per thread: one walker per thread re-reads the three basis values and the two per-bin
