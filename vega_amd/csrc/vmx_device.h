@@ -3527,7 +3527,7 @@ __global__ __launch_bounds__(256) void k_xi_bins_lean(EngineDev D, XiLeanArgs A,
 
 // The lean bins kernel over GROUPS of pipelines of one item (descriptors in device memory, one array per group): a thread adds
 // its bin's value of every member, times the member's walker factor, and stores the sum - the per-pipeline arrays of the
-// members are never written nor read back by k_assemble_quad (joint + metals: 42 arrays of 15 MB per step become 10).
+// members are never written nor read back by k_assemble_quad (joint + metals: one array per group instead of one of the 42 arrays of 15 MB per pipeline and step).
 // presum = 0: a single member whose plain bins are wanted (its array has another reader).  grid = (bins, groups, ceil(B / NW)).
 #define VMX_XI_GROUP_MEMBERS 4
 #define VMX_XI_SGROUP_MEMBERS 16
