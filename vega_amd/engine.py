@@ -274,7 +274,8 @@ class Lowering:
         if xi.single_multipole >= 0 and (xi.single_multipole % 2 or xi.single_multipole > xi.ell_max):
             raise ValueError(f'single_multipole = {xi.single_multipole} is not one of the even multipoles <= ell_max')
         if (xi.relativistic or xi.asymmetry) and self.prob.scale.two_alpha_smooth:
-            raise NotImplementedError('odd multipoles with two-alpha-smooth are not accelerated')
+            raise NotImplementedError('odd multipoles with two-alpha-smooth: the reference looks up alpha_smooth_None for these terms '
+                                      '(vega/correlation_func.py:514, vega/scale_parameters.py:155-156) - there is nothing to reproduce')
         if xi.ell_max not in (0, 2, 4, 6):
             raise NotImplementedError(f'ell_max = {xi.ell_max} is not supported (even, <= 6)')
         is_peak = component == 'peak'
