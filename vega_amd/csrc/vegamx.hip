@@ -236,7 +236,8 @@ struct vmx_engine {
     DevBuf<XiLeanGroup> d_lean_groups; DevBuf<XiStaticGroup> d_static_groups; DevBuf<ItemSums> d_item_sums;
     DevBuf<int32_t> d_static_single;
     bool sums_any = false;
-    int xi_group_size = VMX_XI_GROUP_MEMBERS, xi_sgroup_size = VMX_XI_SGROUP_MEMBERS;      // VMX_XI_GROUP / VMX_XI_SGROUP: members per array
+    // (members per array: four lean, sixteen static-coordinate pipelines - measured at B = 512: groups of 2 / 3 lean members
+    // 462k / 477k evaluations / s against 474k, 4 / 8 static members 472k / 473k)
     int xi_static_group_nw = 2;      // VMX_XI_STATIC_NW: walkers per thread of k_xi_bins_static_group (k_xi_bins_static_nw: 4)
     int xi_lean_nw = 2, xi_static_nw = 4;     // VMX_XI_LEAN_NW / VMX_XI_STATIC_NW: walkers per thread of the two kernels (1, 2, 4)
     bool xi_lean = true;             // VMX_NO_XI_LEAN: every per-walker pipeline's bins by the general k_xi_bins
@@ -1300,8 +1301,6 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (const char* v = getenv("VMX_XI_PLAIN_NW")) e->xi_plain_nw = atoi(v);
     if (getenv("VMX_NO_XI_LEAN")) e->xi_lean = false;
     if (getenv("VMX_NO_XI_SUMS")) e->xi_sums = false;
-    if (const char* v = getenv("VMX_XI_GROUP")) e->xi_group_size = std::min(std::max(atoi(v), 2), VMX_XI_GROUP_MEMBERS);
-    if (const char* v = getenv("VMX_XI_SGROUP")) e->xi_sgroup_size = std::min(std::max(atoi(v), 2), VMX_XI_SGROUP_MEMBERS);
     if (const char* v = getenv("VMX_XI_LEAN_NW")) e->xi_lean_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
     if (const char* v = getenv("VMX_XI_STATIC_NW")) e->xi_static_group_nw = e->xi_static_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
     if (const char* v = getenv("VMX_ITEM_STREAMS")) e->item_streams = atoi(v) != 0;
@@ -2225,7 +2224,7 @@ static int xi_sum_plan(vmx_engine* e)
             const PipeDev& P = e->pipes[p];
             if (G.n_members == 0) { G.out_off = P.xi_off; G.n = P.n; G.n_pad = P.n_pad; G.presum = 1; }
             G.m[G.n_members++] = member_of(p);
-            if (G.n_members == e->xi_group_size || sums[q].n_arrays >= 7) flush();
+            if (G.n_members == VMX_XI_GROUP_MEMBERS || sums[q].n_arrays >= 7) flush();
         }
         flush();
     }
@@ -2261,7 +2260,7 @@ static int xi_sum_plan(vmx_engine* e)
             const PipeDev& P = e->pipes[p];
             if (G.n_members == 0) { G.out_off = P.xi_off; G.n = P.n; G.n_pad = P.n_pad; G.presum = 1; }
             G.m[G.n_members++] = member_of(p);
-            if (G.n_members == e->xi_sgroup_size) flush();
+            if (G.n_members == VMX_XI_SGROUP_MEMBERS) flush();
         }
         flush();
     }
