@@ -1832,28 +1832,39 @@ static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item
     constexpr int MIN_SEG = 2;                  // no entry shorter than this many stages (but for ranges that short)
     struct Entry { GemmWork w; int piece; };    // (w.nt: the group's first walker tile)
     std::vector<Entry> entries;
-    // every cut adds an entry and its fixed charge: the piece size follows from the number of entries, which follows from the
-    // piece size - three rounds of the fixed point are plenty (first guess: one cut per piece boundary)
-    size_t n_entries = ranges.size() * n_groups + n_pieces - 1;
-    for (int round = 0; round < 3; ++round) {
-        const double piece = (stages_total + ovh * (double)n_entries) / n_pieces;
-        entries.clear();
+    // A piece may cost at most `cap` = its K stages + the fixed charge of each of its entries; the tape is filled greedily -
+    // a piece takes what fits, a cut inside a K range opens an entry on either side - and `cap` is the smallest capacity for
+    // which n_pieces pieces suffice (bisection: the piece count is monotone in cap).  Every piece then costs cap to within a
+    // stage, but for the last one, which holds what is left.  (Round 3's first tape sized the pieces from an estimate of the
+    // entry count and let the last piece absorb the error: pieces between 63.6 and 74.1 stage-equivalents for a mean of 69.0 at
+    // B = 256 - the launch lasts as long as its largest piece - and up to 97 for unlucky values of the charge.)
+    auto fill = [&](double cap, bool keep) {
+        if (keep) entries.clear();
         int pc = 0;
-        double room = piece;
+        double cur = 0.0;
         for (auto& r : ranges)
             for (int grp = 0; grp < n_groups; ++grp) {
                 int k = 0, left = r.stages;
                 while (left > 0) {
-                    if (pc < n_pieces - 1 && room < ovh + std::min(left, MIN_SEG)) { ++pc; room += piece; }
-                    int take = pc == n_pieces - 1 ? left : std::min(left, std::max(MIN_SEG, (int)(room - ovh)));
-                    if (left - take > 0 && left - take < MIN_SEG) take = left;          // no sliver behind the cut
-                    entries.push_back({GemmWork{r.prob, r.mt, grp * gs, k * BK, (k + take) * BK, 0, 0, 0}, pc});
-                    room -= take + ovh;
+                    const double avail = cap - cur - ovh;
+                    if (cur > 0.0 && avail < (double)std::min(left, MIN_SEG)) { ++pc; cur = 0.0; continue; }
+                    int take = std::min(left, std::max(MIN_SEG, (int)std::floor(avail + 1e-9)));
+                    const int rem = left - take;
+                    if (rem > 0 && rem < MIN_SEG) take = (take - (MIN_SEG - rem) >= MIN_SEG) ? take - (MIN_SEG - rem) : left;     // no sliver behind the cut
+                    if (keep) entries.push_back({GemmWork{r.prob, r.mt, grp * gs, k * BK, (k + take) * BK, 0, 0, 0}, std::min(pc, n_pieces - 1)});
+                    cur += take + ovh;
                     k += take; left -= take;
                 }
             }
-        if (entries.size() == n_entries) break;
-        n_entries = entries.size();
+        return pc + 1;
+    };
+    {
+        double lo = stages_total / n_pieces, hi = lo + ovh * (double)(ranges.size() * n_groups) / n_pieces + 4.0 * ovh + 256.0;
+        for (int it = 0; it < 48; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (fill(mid, false) <= n_pieces) hi = mid; else lo = mid;
+        }
+        (void)fill(hi, true);
     }
     // slots: per walker tile, tape order (entry j of walker-tile group grp is slot (its rank within the group) of every member)
     std::vector<int32_t> nt_off(tn + 1, 0);
