@@ -8,9 +8,8 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(round(d['value']), round(d['ms_per_step'],4), {k: round(v['ms_per_step']*1e3,1) for k,v in d.get('kernels',{}).items()})
 " >> $O; }
 run A=1
-run VMX_NO_XI_SUMS=1
-run VMX_NO_XI_LEAN=1
-run VMX_XI_LEAN_NW=1
-run VMX_XI_STATIC_NW=4
+run VMX_QUAD_SKEW=0
+run VMX_QUAD_SKEW=0.2
 run A=1
+run VMX_QUAD_SKEW=0
 cat $O

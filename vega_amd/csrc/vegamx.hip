@@ -223,6 +223,7 @@ struct vmx_engine {
     bool quad_persistent = true;     // VMX_NO_PERSISTENT: one block per list entry (equal-length segments) instead of the tape
     int quad_blocks = 0;             // persistent blocks of the quadratic-form launch: 2 per CU
     double quad_overhead = 4.0;      // cost of starting / finishing an entry, in K stages (VMX_QUAD_OVH)
+    double quad_skew = 0.12;         // VMX_QUAD_SKEW (B = 256: 145.1 us at 0, 142.6 at 0.12 - 0.16, 144.0 at 0.2, 149.6 at 0.4): the first-dispatched half of the blocks takes (1 + skew) of a piece, the second (1 - skew)
     bool quad_fused_chi2 = true;     // VMX_NO_FUSED_CHI2: the list launch stores the product, k_chi2_quad contracts it
     bool item_streams = false;       // VMX_ITEM_STREAMS=1: the items of a large chi2-only batch on forked streams (see run_items_forked; measured slower)
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
@@ -1285,6 +1286,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
     if (getenv("VMX_NO_PERSISTENT")) e->quad_persistent = false;
     if (const char* v = getenv("VMX_QUAD_OVH")) e->quad_overhead = atof(v);
+    if (const char* v = getenv("VMX_QUAD_SKEW")) e->quad_skew = std::min(std::max(atof(v), -0.5), 0.5);
     {
         int cus = 256;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
@@ -1838,16 +1840,21 @@ static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item
     // stage, but for the last one, which holds what is left.  (Round 3's first tape sized the pieces from an estimate of the
     // entry count and let the last piece absorb the error: pieces between 63.6 and 74.1 stage-equivalents for a mean of 69.0 at
     // B = 256 - the launch lasts as long as its largest piece - and up to 97 for unlucky values of the charge.)
-    auto fill = [&](double cap, bool keep) {
+    // (a CU issues from its older resident block first: of two equal pieces the one dispatched first ends earlier and leaves the
+    // other alone on the CU - block p = 8 i + xcd takes piece xcd * per_xcd + i / gs, so the first half of an XCD's pieces belongs
+    // to the blocks dispatched first; `quad_skew` shifts work to them)
+    const int per_xcd_pieces = n_pieces / 8;
+    auto weight = [&](int pc) { return (pc % per_xcd_pieces) < per_xcd_pieces / 2 ? 1.0 + e->quad_skew : 1.0 - e->quad_skew; };
+    auto fill = [&](double cap0, bool keep) {
         if (keep) entries.clear();
         int pc = 0;
-        double cur = 0.0;
+        double cur = 0.0, cap = cap0 * weight(0);
         for (auto& r : ranges)
             for (int grp = 0; grp < n_groups; ++grp) {
                 int k = 0, left = r.stages;
                 while (left > 0) {
                     const double avail = cap - cur - ovh;
-                    if (cur > 0.0 && avail < (double)std::min(left, MIN_SEG)) { ++pc; cur = 0.0; continue; }
+                    if (cur > 0.0 && avail < (double)std::min(left, MIN_SEG)) { ++pc; cur = 0.0; cap = cap0 * weight(std::min(pc, n_pieces - 1)); continue; }
                     int take = std::min(left, std::max(MIN_SEG, (int)std::floor(avail + 1e-9)));
                     const int rem = left - take;
                     if (rem > 0 && rem < MIN_SEG) take = (take - (MIN_SEG - rem) >= MIN_SEG) ? take - (MIN_SEG - rem) : left;     // no sliver behind the cut
