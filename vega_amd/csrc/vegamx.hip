@@ -532,6 +532,10 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
     // blocks hide each other's start and end (0.093 against 0.103 - 0.126 ms: two short passes per block)
     if (e->gemm_44 && kc != KC_INVCOV && !(kc == KC_QUAD && !e->quad_use_44)) {
         block = dim3(GEMM44_THREADS);
+        // (a windowed FFTLog launch carries its batch - the multipoles - inside grid.x: GemmGroup::batch_in_x)
+        GemmGroup Gx = G;
+        dim3 gridx = grid;
+        if (kc == KC_FFTLOG && G.n == 1 && G.p[0].m_window && G.work == nullptr && nbatch > 1) { Gx.batch_in_x = nbatch; gridx = dim3(grid.x * nbatch, 1); }
         switch (kc) {
             case KC_QUAD: hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), grid, block, 0, e->cur, G); break;
             case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt44<KC_DISTORTION>), grid, block, 0, e->cur, G); break;
@@ -555,7 +559,8 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
                         GemmGroup G2 = G;
                         const int tn32 = (G.p[0].N + 31) / 32;
                         G2.p[0].tn = tn32;
-                        const dim3 grid2(8 * G.p[0].tm * ((tn32 + 7) / 8), nbatch);
+                        const dim3 grid2(8 * G.p[0].tm * ((tn32 + 7) / 8) * nbatch, 1);
+                        G2.batch_in_x = nbatch;         // (the live blocks of all multipoles first in launch order)
                         // (+ 24 KB of unused dynamic LDS: 72 KB per block = two per CU.  With its own 48 KB the dispatcher packs three
                         // blocks on a CU before it moves on and leaves a third of the CUs empty.)
                         const size_t pad = getenv("VMX_FFT_NARROW_PAD") ? (size_t)atoi(getenv("VMX_FFT_NARROW_PAD")) : 24 * 1024;
@@ -565,19 +570,19 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
                 }
                 if (e->fft_ring && e->ring_allowed && G.n == 1 && G.p[0].m_window) {
                     const int64_t est = (int64_t)G.p[0].tn * nbatch * ((G.p[0].tm * 3 + 9) / 10);
-                    if (est < 160 || est > 320) { hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G); break; }
+                    if (est < 160 || est > 320) { hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), gridx, block, 0, e->cur, Gx); break; }
                     constexpr size_t ring_bytes = (size_t)4 * (GEMM_BM + GEMM_BN) * GEMM_BK * sizeof(double);
                     if (!e->fft_ring_attr) {
                         if (hipFuncSetAttribute((const void*)k_gemm_nt44<KC_FFTLOG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes) != hipSuccess) {
                             (void)hipGetLastError();
                             e->fft_ring = false;
-                            hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G);
+                            hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), gridx, block, 0, e->cur, Gx);
                             break;
                         }
                         e->fft_ring_attr = true;
                     }
-                    hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG, 4>), grid, block, ring_bytes, e->cur, G);
-                } else hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), grid, block, 0, e->cur, G);
+                    hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG, 4>), gridx, block, ring_bytes, e->cur, Gx);
+                } else hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG>), gridx, block, 0, e->cur, Gx);
                 break;
             default: hipLaunchKernelGGL((k_gemm_nt44<KC_OTHER>), grid, block, 0, e->cur, G); break;
         }

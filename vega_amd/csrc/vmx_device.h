@@ -2186,6 +2186,7 @@ struct GemmArgs {
     double* part; const double* lin; const int32_t* lin_row; int lin_pool;
 };
 #define VMX_TAG_QUAD 12
+#define VMX_TAG_FFTLOG 2
 
 // Work list of a grouped launch (k_gemm_nt44): one entry per block - a K segment of one 64 x 64 tile of one problem,
 // written to slab `slab` of that problem's output.  A triangular product has row tiles of very different K lengths;
@@ -2252,6 +2253,9 @@ struct GemmGroup {
     const GemmWork* work;       // non-null: list mode (gridDim.x entries)
     const int32_t* queue;       // non-null (with work): persistent blocks, entries [queue[blockIdx.x], queue[blockIdx.x + 1])
     unsigned long long* trace;  // debugging aid (VMX_GEMM_TRACE): per block {start, first stage landed, K loop done, end} in 100 MHz ticks
+    int32_t batch_in_x;         // > 0 (the FFTLog product's windowed launch): a one-dimensional grid, block x = ((seq * batches + batch) << 3) | xcd
+                                // - the live blocks of EVERY batch member come first in launch order (with the batch on grid.y the live
+                                // blocks of the last multipole sat behind three multipoles' dead blocks and started 8 us late)
 };
 
 // Block tile BM (matrix rows) x BN (walkers), K step BK; 4 waves in a 2 x 2 arrangement, each owning a
@@ -2501,11 +2505,15 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     const unsigned long long t_start = G.trace ? wall_clock64() : 0ull;
     unsigned long long t_first = 0ull, t_loop = 0ull;
     GemmWork wk{};
-    int w_first = blockIdx.x, w_count = 1;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (TAG == VMX_TAG_FFTLOG) {
+        if (G.batch_in_x > 0) { const int s2 = bx >> 3; by = s2 % G.batch_in_x; bx = ((s2 / G.batch_in_x) << 3) | (bx & 7); }
+    }
+    int w_first = bx, w_count = 1;
     if (persist) { w_first = G.queue[blockIdx.x]; w_count = G.queue[blockIdx.x + 1] - w_first; if (w_count <= 0) return; }
     if (list) { wk = G.work[w_first]; if (wk.prob < 0) return; }        // (padding entries of the list)
-    const int xcd = blockIdx.x & 7;
-    int seq = blockIdx.x >> 3;
+    const int xcd = bx & 7;
+    int seq = bx >> 3;
     int pi = 0;
     if (list) pi = wk.prob;
     else {
@@ -2536,7 +2544,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     const int nt = list ? wk.nt : n_major ? (seq / tm_live) * 8 + xcd : seq % g.tn;
     if (!list && (mt0 >= tm_eff || nt >= g.tn)) return;
     const int npass = persist ? w_count : (!list && g.tri && g.tm - 1 - mt0 != mt0) ? 2 : 1;
-    const int batch = blockIdx.y;
+    const int batch = by;
     const char* A = (const char*)(g.A + batch * g.a_batch);
     const char* X = (const char*)(g.X + batch * g.x_batch);
     double* Dp = g.D + batch * g.d_batch + split * g.d_slab;
