@@ -40,3 +40,18 @@ for lo in edges:
 last = np.zeros(cuid.max() + 1)
 np.maximum.at(last, cuid, end)
 print('per-CU last end: min', last[last > 0].min(), 'median', np.median(last[last > 0]), 'max', last.max())
+# durations by (item, k tile): block index = (z * grid.y + y) * grid.x + x with x = walker pairs, y = item group, z = k tile
+raw = np.fromfile(out, dtype=np.uint64).reshape(-1, 4)
+nx = (B + 1) // 2
+ny = 2
+nz = len(raw) // (nx * ny)
+r = raw[:nx * ny * nz].reshape(nz, ny, nx, 4).astype(np.float64)
+for y in range(ny):
+    row = []
+    for z in range(nz):
+        m = r[z, y, :, 0] > 0
+        if m.any():
+            d = (r[z, y, m, 1] - r[z, y, m, 0]) / 100.0
+            s0 = (r[z, y, m, 0].min() - float(t0)) / 100.0
+            row.append(f'{d.mean():5.1f}@{s0:4.0f}')
+    print('item group', y, 'mean duration @ first start per k tile:', ' '.join(row))
