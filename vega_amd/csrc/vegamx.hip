@@ -535,7 +535,9 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
         // (a windowed FFTLog launch carries its batch - the multipoles - inside grid.x: GemmGroup::batch_in_x)
         GemmGroup Gx = G;
         dim3 gridx = grid;
-        if (kc == KC_FFTLOG && G.n == 1 && G.p[0].m_window && G.work == nullptr && nbatch > 1) { Gx.batch_in_x = nbatch; gridx = dim3(grid.x * nbatch, 1); }
+        // (when the launch has the chip to itself; with several batches in flight the late starters fill the other lane's gaps)
+        const bool batch_x = e->ring_allowed && getenv("VMX_NO_FFT_BATCH_X") == nullptr;
+        if (batch_x && kc == KC_FFTLOG && G.n == 1 && G.p[0].m_window && G.work == nullptr && nbatch > 1) { Gx.batch_in_x = nbatch; gridx = dim3(grid.x * nbatch, 1); }
         switch (kc) {
             case KC_QUAD: hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), grid, block, 0, e->cur, G); break;
             case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt44<KC_DISTORTION>), grid, block, 0, e->cur, G); break;
@@ -559,8 +561,8 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
                         GemmGroup G2 = G;
                         const int tn32 = (G.p[0].N + 31) / 32;
                         G2.p[0].tn = tn32;
-                        const dim3 grid2(8 * G.p[0].tm * ((tn32 + 7) / 8) * nbatch, 1);
-                        G2.batch_in_x = nbatch;         // (the live blocks of all multipoles first in launch order)
+                        const dim3 grid2 = batch_x ? dim3(8 * G.p[0].tm * ((tn32 + 7) / 8) * nbatch, 1) : dim3(8 * G.p[0].tm * ((tn32 + 7) / 8), nbatch);
+                        G2.batch_in_x = batch_x ? nbatch : 0;         // (the live blocks of all multipoles first in launch order)
                         // (+ 24 KB of unused dynamic LDS: 72 KB per block = two per CU.  With its own 48 KB the dispatcher packs three
                         // blocks on a CU before it moves on and leaves a third of the CUs empty.)
                         const size_t pad = getenv("VMX_FFT_NARROW_PAD") ? (size_t)atoi(getenv("VMX_FFT_NARROW_PAD")) : 24 * 1024;
@@ -1849,7 +1851,10 @@ static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item
     // other alone on the CU - block p = 8 i + xcd takes piece xcd * per_xcd + i / gs, so the first half of an XCD's pieces belongs
     // to the blocks dispatched first; `quad_skew` shifts work to them)
     const int per_xcd_pieces = n_pieces / 8;
-    auto weight = [&](int pc) { return (pc % per_xcd_pieces) < per_xcd_pieces / 2 ? 1.0 + e->quad_skew : 1.0 - e->quad_skew; };
+    // (the same tape whatever the number of batches in flight - a walker's chi2 must not depend on it, and the cut points decide
+    // how its partial sums are grouped; with two batches in flight the skew neither helps nor hurts beyond the run-to-run noise)
+    const double skew = e->quad_skew;
+    auto weight = [&](int pc) { return (pc % per_xcd_pieces) < per_xcd_pieces / 2 ? 1.0 + skew : 1.0 - skew; };
     auto fill = [&](double cap0, bool keep) {
         if (keep) entries.clear();
         int pc = 0;
