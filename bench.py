@@ -1,8 +1,10 @@
 """Benchmark of the model + chi2 hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (N > 1, no WORLD_SIZE in the environment: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --dist-backend gloo --ranks-share-gpu --core-only     (rehearsal of the N > 1 path on ONE GPU)
 
 A "step" evaluates one batch of B synthetic walkers (parameter points) of BASELINE.json configs[2]:
 the joint Lya x Lya + QSO x Lya fit (two correlation items, shared parameters, 4 P(k)->xi pipelines
@@ -343,6 +345,56 @@ def cpu_baseline(workload, names, theta, repeats=7, warmups=2, extra_theta=None)
                       f'workload, oracle/vega_cpu.py chi2; {total:.1f} s in all'}, done, [vals[i] for i in done], extra_vals
 
 
+def launch_ranks(args):
+    """`--gpus N`, N > 1, and no WORLD_SIZE in the environment: start the N ranks here - fresh child processes of a parent
+    that has made NO GPU call (no torch import, the library only compiled, never loaded), one per GPU, the environment
+    torchrun would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; the reference's mpirun ranks,
+    bin/run_vega_mc_mpi.py:17-25).  Rank 0's stdout carries the one JSON line, which is relayed; the other ranks' stdout and
+    everybody's stderr go to this process's stderr.  Returns the exit code: non-zero when any rank failed (the ranks still
+    running are then ended - the exact processes started here)."""
+    import socket
+    import subprocess
+    import __graft_entry__ as entry
+    entry.compile_library()             # once, here: the ranks find it built
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if args.ranks_share_gpu else r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # the host driver only supports dmabuf IPC (RCCL needs it)
+        env.setdefault('OMP_NUM_THREADS', '1')
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env, cwd=str(REPO),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs[1:]):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        # (rank 0 writes one line: the pipe cannot fill up while it is not read)
+        time.sleep(0.2)
+    line = b''
+    if failed is None:
+        line, _ = procs[0].communicate()
+        failed = next((r for r, p in enumerate(procs) if p.wait() != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        sys.stderr.write(f'bench.py: rank {failed} exited with code {procs[failed].returncode}\n')
+        return procs[failed].returncode or 1
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -357,10 +409,18 @@ def main():
                     help='calibration + warm-up + timed steps only (the command the rocprofv3 summaries in profiles/ use)')
     ap.add_argument('--no-static-metals', action='store_true', help='keep every metal pair on its own pipeline')
     ap.add_argument('--force-dist', action='store_true', help='run the collective path even with one rank')
-    ap.add_argument('--lanes', type=int, default=2, choices=[1, 2, 3, 4],
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl = RCCL over xGMI (one rank per GPU); gloo: the gather is staged through pinned host memory - '
+                         'the rehearsal backend, with --ranks-share-gpu the whole N > 1 path runs on a one-GPU box')
+    ap.add_argument('--ranks-share-gpu', action='store_true', help='every rank on GPU 0 (gloo only: RCCL refuses two ranks on one device)')
+    ap.add_argument('--lanes', type=int, default=2, choices=[1, 2],
                     help='batches in flight inside the engine (vmx_set_lanes): with 2, consecutive steps alternate between two '
                          'per-batch workspaces that share every static tensor, and overlap on the GPU')
     args = ap.parse_args()
+    if args.ranks_share_gpu and args.dist_backend != 'gloo':
+        ap.error('--ranks-share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
 
     # stdout carries the one JSON line and nothing else: whatever libraries print there (RCCL's version banner when a
     # communicator is first used, for one) goes to stderr until the line is written
@@ -370,7 +430,10 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = 0 if args.ranks_share_gpu else int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: start it as `python bench.py --gpus N` (it '
+                         'launches its own ranks) or under torchrun with --nproc-per-node equal to --gpus')
 
     # torch bundles its own HIP runtime: it has to be loaded before libvegamx.so brings in the system one (importing it
     # does not touch the GPU; the first CUDA call below does, after the CPU baseline has finished)
@@ -406,10 +469,14 @@ def main():
         raise SystemExit('bench.py needs a GPU: the vegamx engine has no CPU fallback')
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    on_rccl = args.dist_backend == 'nccl'
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if on_rccl:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from vega_amd import VegaInterface
 
@@ -441,9 +508,14 @@ def main():
     # two output / gather buffer pairs: the collective of step i runs on its own stream while step i + 1 computes
     nslot = 4
     chi2_bufs = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(nslot)]
-    gathered = [torch.zeros(world * B, dtype=torch.float64, device=dev) for _ in range(nslot)] if use_dist else None
+    # RCCL gathers device buffers; a gloo group (the rehearsal backend) gathers pinned host buffers the chi2 vector is
+    # copied into on the communication stream
+    gather_dev = dev if on_rccl else torch.device('cpu')
+    gathered = [torch.zeros(world * B, dtype=torch.float64, device=gather_dev) for _ in range(nslot)] if use_dist else None
+    staged = [torch.zeros(B, dtype=torch.float64).pin_memory() for _ in range(nslot)] if use_dist and not on_rccl else None
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     comm_done = [None] * nslot
+    pending = []            # gloo: (slot, event of the device -> host copy) of the steps whose gather has not run yet
     ext_streams = {}
 
     def stream_of_last_eval():
@@ -452,9 +524,18 @@ def main():
             ext_streams[h] = torch.cuda.ExternalStream(h, device=dev)
         return ext_streams[h]
 
+    def finish_gathers(keep=0):
+        """gloo: run the host gathers of all but the last `keep` enqueued steps (the copy's event first)."""
+        while len(pending) > keep:
+            slot, copied = pending.pop(0)
+            copied.synchronize()
+            dist.all_gather_into_tensor(gathered[slot], staged[slot])
+
     def sync_all():
         for e in engines:
             e.sync()
+        if use_dist and not on_rccl:
+            finish_gathers()
 
     def step(i):
         slot = i % nslot
@@ -465,8 +546,16 @@ def main():
             # one all_gather of chi2 per step, ordered after the evaluation by an event on the lane's stream
             comm_stream.wait_event(stream_of_last_eval().record_event())
             with torch.cuda.stream(comm_stream):
-                dist.all_gather_into_tensor(gathered[slot], chi2_bufs[slot])
-                comm_done[slot] = comm_stream.record_event()
+                if on_rccl:
+                    dist.all_gather_into_tensor(gathered[slot], chi2_bufs[slot])
+                    comm_done[slot] = comm_stream.record_event()
+                else:
+                    # the host gather of step i runs once step i + 1 is enqueued: the lanes stay busy while the host waits
+                    staged[slot].copy_(chi2_bufs[slot], non_blocking=True)
+                    comm_done[slot] = comm_stream.record_event()
+                    pending.append((slot, comm_done[slot]))
+            if not on_rccl:
+                finish_gathers(keep=1)
 
     # Calibration pass (untimed): HIP-event pairs around every kernel class give the per-kernel breakdown and name
     # the dominant class.  Event pairs around all ~20 launches of a step cost ~7 % of throughput, so the timed
@@ -657,18 +746,39 @@ def main():
                                 '178-node rule that reproduces those sums to ~1e-13'}
         eng.set_mu_quadrature(True)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev if use_dist else dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    communicator = None
     if use_dist:
-        # the gathered vector holds every rank's chi2 of the last step, rank-major
+        # the gathered vector holds every rank's chi2 of the last step, rank-major: this rank's block must be its own
+        # vector, and - the ranks draw their walkers from different seeds - the blocks must differ from rank to rank
         torch.cuda.synchronize()
         last = (args.steps - 1) % nslot
-        mine = gathered[last][rank * B:(rank + 1) * B]
-        if not torch.equal(mine, chi2_bufs[last]) or not bool(torch.isfinite(gathered[last]).all()):
+        got = gathered[last].to(dev).view(world, B)
+        if not torch.equal(got[rank], chi2_bufs[last]) or not bool(torch.isfinite(got).all()):
             raise SystemExit('all_gather of chi2 returned unexpected values')
+        distinct = len({tuple(row[:8].tolist()) for row in got.cpu()})
+        if distinct != world:
+            raise SystemExit(f'all_gather of chi2: {distinct} distinct rank blocks for {world} ranks')
+        # what the communicator itself reports
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, (rank, local_rank, torch.cuda.get_device_properties(dev).name))
+        communicator = {'op': 'one all_gather_into_tensor of chi2 [B] per rank and step', 'backend': dist.get_backend(),
+                        'world_size': dist.get_world_size(), 'ranks': [r[0] for r in ranks_seen],
+                        'devices': [r[1] for r in ranks_seen], 'device_name': ranks_seen[0][2],
+                        'distinct_rank_blocks_in_last_gather': distinct, 'ranks_share_gpu': bool(args.ranks_share_gpu),
+                        'bytes_per_rank_per_step': 8 * B}
+        if on_rccl:
+            try:
+                communicator['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as exc:        # pragma: no cover
+                communicator['rccl_version'] = f'unavailable ({exc})'
+        else:
+            communicator['note'] = ('rehearsal backend: chi2 is copied to pinned host memory on the communication stream and '
+                                    'gathered there, one step behind the evaluations')
     if rank == 0:
         total_evals = B * args.steps * world
         value = total_evals / elapsed
@@ -790,7 +900,10 @@ def main():
             'config': {'workload': WORKLOAD_TEXT[args.workload].format(B=B, total=B * world),
                        'batch_per_gpu': B, 'batches_in_flight': L, 'pipelines_per_eval': len(eng.pipe_index),
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
-                       'collective': 'one all_gather of chi2 per step' if use_dist else 'none'},
+                       'collective': communicator if use_dist else 'none',
+                       'steady_state': f'untimed before the timed region: {args.ramp_steps} ramp steps, a calibration pass, 20-step '
+                                       f'blocks until two agree to 1 % (clock ramp), then the {args.warmup} warm-up steps - '
+                                       '`value` is a warmed steady state'},
             'roofline': roofline, 'roofline_other_kernels': roofline_other, 'distortion': distortion, 'distortion_csr': dist_csr, 'single_point': single, 'metals': metals, 'monte_carlo_fits': mc_fits, 'single_lane': single_lane, 'exact_mu_loop': exact_mu, 'regions': regions, 'other_paths': other_paths, 'cpu_baseline': cpu,
             'pk_stage': dict(zip(('k_live', 'k_node_max', 'mu_nodes', 'k_on_node_rule', 'table_level'), [float(v) for v in pk_state])),
             'kernels': kernels, 'kernels_note': 'calibration pass before the timed region, event pairs around every kernel',
