@@ -368,6 +368,14 @@ void* vmx_last_stream(vmx_engine* e);
  * broadband, direct_pk, or when a model output is requested (those run the full chain).  Returns 1 when the
  * configuration is eligible, 0 when it is not (the call is then a no-op). */
 int vmx_set_quadratic_form(vmx_engine* e, const double* theta_ref);
+/* Which form of that quadratic form the chi2-only evaluations take.  With C^-1 = U^T U (the library factors the inverse
+ * covariance it was given) the same chi2 is || U r0 - F dx ||^2 with the static F = U S DM' [n_masked][nq]: 2 n_masked nq flops per
+ * walker instead of the nq^2 of the half-form Q'.  kind = 0 (default): the cheaper one per engine - Q' for model grids that are the
+ * data grid (2500 / 5000 bins against 1590 / 3180 fitted ones), the factored form when the model grid is much finer (a
+ * `distortion-file` with COEFMOD >= 2, reference vega/data.py:441-473: nq = 10 000 against 1590); 1: Q'; 2: the factored form.
+ * The two agree to rounding (the sum of squares has no cancellation at all); vmx_debug_read(what = 4)[8] reports the form the last
+ * evaluation took (0: full chain, 1: Q', 2: factored).  After vmx_finalize; the tensors are rebuilt at the next chi2-only call. */
+int vmx_set_quadratic_form_kind(vmx_engine* e, int32_t kind);
 
 /* Samplers usually keep the Arinyo non-linear parameters fixed.  When they are identical for every walker of a
  * batch the factor D_NL(k,mu) G(k,mu) is tabulated once per batch instead of being exponentiated per walker and
@@ -389,7 +397,8 @@ void* vmx_stream(vmx_engine* e);
  * global order of vmx_item_add_metal).
  * 4 = {live wavenumbers of the P(k,mu) stage in the last evaluation, k up to which the mu node rule applies (0: off),
  * nodes per wavenumber of that rule, leading wavenumbers whose tiles took the rule in the last evaluation, table level of
- * the last evaluation (vmx_set_constant_nl_hint), first and last spline-coefficient row the last evaluation's bins read}.
+ * the last evaluation (vmx_set_constant_nl_hint), first and last spline-coefficient row the last evaluation's bins read,
+ * walkers that left the mu rule's box since vmx_finalize, form of the last evaluation (vmx_set_quadratic_form_kind)}.
  * Returns the number of doubles written (<= capacity) or a negative error. */
 int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, int64_t capacity);
 

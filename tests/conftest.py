@@ -93,6 +93,16 @@ def fits_ingest_problem(tmp_path):
     return build_problem('configs/ingest/main.ini', search_dirs=[tmp_path, GOLDEN])
 
 
+def dmat_file_problem(tmp_path, coef=2, marg_options=None, config='auto'):
+    """The auto-correlation config with its distortion matrix in a separate `distortion-file` (model grid COEFMOD times
+    finer than the data grid) and a `covariance-file` - the files tests/golden/make_golden.py::dump_dmat_file gave the
+    reference (reference vega/data.py:441-473)."""
+    from vega_amd import synthetic
+    from vega_amd.setup import build_problem
+    main = synthetic.dmat_file_configs(tmp_path, GOLDEN, config=config, coef=coef, item_options=marg_options)
+    return build_problem(main, search_dirs=[tmp_path, GOLDEN])
+
+
 def blinding_problem(tmp_path, sample_extra=''):
     """The auto-correlation config on a `desi_dr3` data file (BLINDING header, DA_BLIND column next to DA; the file
     tests/golden/make_golden.py::dump_blinding gave the reference) with a prior on a sampled parameter."""

@@ -624,6 +624,59 @@ def dump_marginalization(VegaInterface):
     np.savez_compressed(HERE / 'expected_marginalization.npz', **out)
 
 
+def dump_dmat_file(VegaInterface):
+    """The ingestion branch DESI production files use (reference vega/data.py:441-473): the distortion matrix in its own
+    file with a model grid COEFMOD = 2 times finer than the data grid (DM is 2500 x 10000, HDU 2 carries the 100 x 100
+    model-grid coordinates, the distorted-model grid is the regular 50 x 50 one) and the covariance in a `covariance-file`,
+    both written by vega_amd.synthetic.write_dmat_file_case; fiducial point + 8 walkers through the unmodified reference,
+    plus the small-scale marginalisation on that finer grid (templates of COEFMOD^2 model bins per distorted bin,
+    vega/data.py:762-828)."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        source = read_tables(REF / 'tests/data/cf_lya-exp.fits.gz')
+        dmat, cov = synthetic.write_dmat_file_case(tmp, source, coef=2)
+        main = _ref_main(tmp, ['lyalya_lyalya'], False)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        base = item.read_text().replace('[data]', f'[data]\ndistortion-file = {dmat}\ncovariance-file = {cov}', 1)
+        item.write_text(base)
+        vega = VegaInterface(main)
+        data = vega.data['lyalya_lyalya']
+        assert data.coeff_binning_model == 2 and data.distortion_mat.shape == (2500, 10000)
+        assert data.model_coordinates.rp_grid.size == 10000 and data.dist_model_coordinates.rp_grid.size == 2500
+        out['fid/chi2'] = vega.chi2()
+        out['fid/log_lik'] = vega.log_lik()
+        out['fid/model'] = vega.compute_model(run_init=False)['lyalya_lyalya']
+        out['log_cov_det'] = data.log_cov_det
+        names, walkers = make_walkers(vega.params, N_WALKERS, seed=WALKER_SEED + 11)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+        chi2, loglik, models = [], [], []
+        for w in walkers:
+            _reset_caches(vega)
+            chi2.append(vega.chi2(w))
+            _reset_caches(vega)
+            loglik.append(vega.log_lik(w))
+            _reset_caches(vega)
+            models.append(vega.compute_model(w, run_init=False)['lyalya_lyalya'])
+        out['walkers/chi2'] = np.array(chi2)
+        out['walkers/log_lik'] = np.array(loglik)
+        out['walkers/model'] = np.array(models)
+        print('dmat file: chi2', out['fid/chi2'], 'log_lik', out['fid/log_lik'], out['walkers/chi2'][:3])
+        item.write_text(base.replace('[model]', '[model]\nmarginalize-below-rtmax = 16.0\nmarginalize-prior-sigma = 5.0'))
+        vega = VegaInterface(main)
+        data = vega.data['lyalya_lyalya']
+        out['marg/chi2'] = vega.chi2()
+        out['marg/log_lik'] = vega.log_lik()
+        out['marg/num_marg_modes'] = data.num_marg_modes
+        out['marg/cov_update_trace'] = np.trace(data.cov_marg_update)
+        _reset_caches(vega)
+        out['marg/walker0/chi2'] = vega.chi2(walkers[0])
+        print('  marginalised:', out['marg/chi2'], out['marg/log_lik'], data.num_marg_modes, out['marg/walker0/chi2'])
+    np.savez_compressed(HERE / 'expected_dmat_file.npz', **out)
+
+
 def direct_pk_vector(k, pk_full):
     """A stand-in for a Boltzmann-code spectrum: the fiducial one tilted and rescaled."""
     return 1.07 * pk_full * (k / 0.1)**0.03
@@ -1001,12 +1054,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1049,3 +1102,5 @@ if __name__ == '__main__':
         dump_options2(VI)
     if 'fits' in what:
         dump_fits(VI)
+    if 'dmat_file' in what:
+        dump_dmat_file(VI)

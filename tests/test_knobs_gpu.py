@@ -19,12 +19,9 @@ XI_RTOL = 1e-8
 CHI2_RTOL = 1e-6
 
 KNOBS = [
-    ('VMX_NO_QUAD', '1'), ('VMX_NO_TAB2', '1'), ('VMX_NO_SMALL_TAB', '1'), ('VMX_EXACT_MU', '1'),
-    ('VMX_NO_WORK_LIST', '1'), ('VMX_NO_FFT_RING', '1'), ('VMX_NO_GRAPH', '1'), ('VMX_NO_ZERO_COPY', '1'),
-    ('VMX_NO_DONE_WORD', '1'), ('VMX_NO_FUSED_CHI2', '1'), ('VMX_NO_HOST_REDUCE', '1'), ('VMX_NO_STATIC_POLY', '1'),
-    ('VMX_NO_STATIC_BINS', '1'), ('VMX_NO_PK_W', '1'), ('VMX_PK_NW', '1'), ('VMX_XCD_BANDS', '1'), ('VMX_GEMM_16', '1'),
-    ('VMX_QUAD_44', '0'), ('VMX_NO_PLAIN_PAIR', '1'), ('VMX_GEMM_SPLIT', '2'), ('VMX_QUAD_L', '64'), ('VMX_GRAPH_B1', '1'),
-    ('VMX_ITEM_STREAMS', '1'), ('VMX_NO_PERSISTENT', '1'), ('VMX_NO_FFT_NARROW', '1'), ('VMX_XI_PLAIN_NW', '0'), ('VMX_XI_PLAIN_NW', '1'), ('VMX_XI_PLAIN_NW', '4'), ('VMX_NO_XI_LEAN', '1'), ('VMX_XI_LEAN_NW', '1'), ('VMX_XI_LEAN_NW', '4'), ('VMX_XI_STATIC_NW', '1'), ('VMX_XI_STATIC_NW', '2'), ('VMX_NO_XI_SUMS', '1'), ('VMX_QUAD_SKEW', '0'), ('VMX_QUAD_SKEW', '0.3'), ('VMX_NO_FFT_BATCH_X', '1'),
+    ('VMX_NO_QUAD', '1'), ('VMX_NO_TAB2', '1'), ('VMX_EXACT_MU', '1'), ('VMX_NO_GRAPH', '1'), ('VMX_NO_ZERO_COPY', '1'),
+    ('VMX_NO_DONE_WORD', '1'), ('VMX_NO_HOST_REDUCE', '1'), ('VMX_NO_STATIC_POLY', '1'), ('VMX_NO_STATIC_BINS', '1'),
+    ('VMX_NO_PK_W', '1'), ('VMX_NO_XI_LEAN', '1'), ('VMX_NO_XI_SUMS', '1'),
 ]
 SHARED_VARIED = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO', 'drp_QSO', 'bias_hcd',
                  'beta_hcd', 'L0_hcd', 'bias_eta_SiII(1190)', 'bias_eta_SiII(1193)', 'bias_eta_SiIII(1207)',

@@ -45,31 +45,3 @@ def test_ragged_products_every_batch_regime():
         for batch in BATCHES:
             _check(vega.engine, torch, m, k, batch, seed=17 * i + batch)
     vega.close()
-
-
-@pytest.mark.parametrize('split', [1, 2, 4, 8])
-def test_forced_split_k(split):
-    """Split-K partial sums go to separate slabs that the consumer adds in a fixed order: every factor gives the same
-    product to rounding, and the same factor twice gives it bitwise."""
-    import torch
-    os.environ['VMX_GEMM_SPLIT'] = str(split)
-    try:
-        vega = _engine()
-        for m, k, batch in ((257, 300, 37), (2500, 2500, 130)):
-            _check(vega.engine, torch, m, k, batch, seed=split)
-        vega.close()
-    finally:
-        del os.environ['VMX_GEMM_SPLIT']
-
-
-def test_sixteen_by_sixteen_kernel_still_agrees():
-    """`VMX_GEMM_16` routes every product to the 16x16x4 MFMA kernel (the one the C^-1 products use)."""
-    import torch
-    os.environ['VMX_GEMM_16'] = '1'
-    try:
-        vega = _engine()
-        for m, k, batch in ((257, 300, 37), (1000, 1000, 256)):
-            _check(vega.engine, torch, m, k, batch, seed=3)
-        vega.close()
-    finally:
-        del os.environ['VMX_GEMM_16']

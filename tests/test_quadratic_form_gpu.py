@@ -66,13 +66,16 @@ def test_quadratic_form_equals_the_full_chain_and_the_reference(batch):
     vega.close()
 
 
-def test_quadratic_form_with_mocks_rescaled_covariance_and_new_data():
+@pytest.mark.parametrize('kind', ['q', 'factored'])
+def test_quadratic_form_with_mocks_rescaled_covariance_and_new_data(kind):
+    """Both shapes of the form (include/vegamx.h: vmx_set_quadratic_form_kind): the half-form Q' and || U r0 - F dx ||^2."""
     from oracle import vega_cpu as oc
     from vega_amd import VegaInterface, synthetic
     from vega_amd.montecarlo import create_mocks
     prob = synth_joint_problem()
     vega = VegaInterface(None, problem=prob, max_batch=32)
     eng = vega.engine
+    eng.set_quadratic_form_kind(kind)
     fid = vega.compute_model()
     mocks = create_mocks(prob, fid, 5, seed=3)
     for name, pool in mocks.items():
@@ -81,6 +84,7 @@ def test_quadratic_form_with_mocks_rescaled_covariance_and_new_data():
     index = np.array([0, 1, 2, 3, 4, -1, 2, 2, 0, 4] * 2, dtype=np.int32)
     eng.set_mock_index(index)
     quad = eng.eval(theta)[0]
+    assert eng.last_form() == kind
     full = eng.eval(theta, want_model=True)[0]
     np.testing.assert_allclose(quad, full, rtol=1e-10)
     # chi2 ~ n_data against its own mocks, ~6e7 against the data: the same relative agreement for both
@@ -135,21 +139,6 @@ def test_quadratic_form_eligibility_and_golden_configs():
     assert not vega.engine.quadratic_form and not vega.engine.set_quadratic_form(True)
     assert not _took_quadratic_path(vega.engine, vega.engine.low.theta0[None, :])
     vega.close()
-
-
-def test_quadratic_form_on_the_sixteen_by_sixteen_kernel():
-    """`VMX_QUAD_44=0`: the half-triangle products on the 16x16x4 fp64 MFMA kernel instead of the four-block one."""
-    from vega_amd import VegaInterface
-    os.environ['VMX_QUAD_44'] = '0'
-    try:
-        prob = synth_joint_problem()
-        vega = VegaInterface(None, problem=prob, max_batch=64)
-        theta = np.tile(vega.engine.low.theta0, (64, 1))
-        theta[:, vega.engine.low.slot['ap']] = np.linspace(0.9, 1.1, 64)
-        np.testing.assert_allclose(vega.engine.eval(theta)[0], vega.engine.eval(theta, want_model=True)[0], rtol=1e-11)
-        vega.close()
-    finally:
-        del os.environ['VMX_QUAD_44']
 
 
 def test_single_walker_chain_tables_and_host_side_sum():

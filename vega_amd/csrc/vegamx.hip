@@ -117,6 +117,9 @@ struct ItemHost {
     // quadratic form of chi2 (vmx_device.h): W = DM'^T S^T C^-1 [nq][n_masked_pad] is kept so that new data / mocks only
     // redo the linear terms
     DevBuf<double> q_mat, q_w, q_lin, q_c0, q_x0, q_x, q_z;
+    // ... in its factored form (vmx_set_quadratic_form_kind): U with C^-1 = U^T U [n_masked][n_masked_pad], F = U S DM'
+    // [n_masked][nq_pad], u0 = U r0 per data vector / mock [rows][n_masked_pad], slabs of F dx [slab_rows][n_masked_pad]
+    DevBuf<double> q_u, q_f, q_u0, q_y;
     std::vector<double> h_q_c0;         // host copy of q_c0 (the single-walker chain adds the constants on the host)
     DevBuf<int64_t> q_basis_off;
     int q_rows = 0;                     // rows of q_lin / q_c0 (1 + mocks)
@@ -169,7 +172,6 @@ struct vmx_engine {
     DevBuf<int32_t> d_w_groups;
     bool no_pk_w = false;                    // VMX_NO_PK_W: the shared-W groups stay in k_pk_multipoles
     std::vector<Tab2Group> tab2_groups;      // the groups with tables, as k_pk_tab2 takes them (cross groups first)
-    int pk_walkers_per_thread = 2;           // VMX_PK_NW (batches of 64 walkers or more)
     DevBuf<double> xtab_key;
     int n_xtab = 0;
     int const_hint = 0;              // vmx_set_constant_nl_hint: table level the caller vouches for (device-resident theta)
@@ -214,21 +216,14 @@ struct vmx_engine {
     int g_n = 0, g_ld = 0;
 
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
-    int gemm_split_override = 0;     // tuning knob (VMX_GEMM_SPLIT), 0 = automatic
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
-    // work lists of the quadratic-form launches per batch size: entries, their count, per-row-tile slab counts
-    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> nseg, queue, nt_off; DevBuf<double> part; int n_blocks = 0; int rows = 0; int32_t nseg_off[16] = {0}; int max_seg = 1; int seg_len = 0; bool persistent = false; int n_entries = 0; };
-    std::map<int, QuadList*> quad_lists;     // by number of walker tiles (+ 1e6 (item + 1) for the per-item lists of forked streams)
-    bool quad_list_mode = true;      // VMX_NO_WORK_LIST: whole-problem K splits instead
-    bool quad_persistent = true;     // VMX_NO_PERSISTENT: one block per list entry (equal-length segments) instead of the tape
+    // tapes of the quadratic-form launches per number of walker tiles: the blocks' entries, their queues, the partial-sum slots
+    struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> queue, nt_off; DevBuf<double> part; int n_blocks = 0; int n_entries = 0; };
+    std::map<int, QuadList*> quad_lists;     // by number of walker tiles
     int quad_blocks = 0;             // persistent blocks of the quadratic-form launch: 2 per CU
-    double quad_overhead = 4.0;      // cost of starting / finishing an entry, in K stages (VMX_QUAD_OVH)
-    double quad_skew = 0.12;         // VMX_QUAD_SKEW (B = 256: 145.1 us at 0, 142.6 at 0.12 - 0.16, 144.0 at 0.2, 149.6 at 0.4): the first-dispatched half of the blocks takes (1 + skew) of a piece, the second (1 - skew)
-    bool quad_fused_chi2 = true;     // VMX_NO_FUSED_CHI2: the list launch stores the product, k_chi2_quad contracts it
-    bool item_streams = false;       // VMX_ITEM_STREAMS=1: the items of a large chi2-only batch on forked streams (see run_items_forked; measured slower)
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
-    bool fft_ring = true, fft_ring_attr = false;     // VMX_NO_FFT_RING: the FFTLog product on the two-buffer kernel
+    bool fft_ring = true, fft_ring_attr = false;     // (false: the device refused the ring's 128 KB of LDS - the two-buffer kernel then)
     // pre-summed bins (xi_sum_plan): groups of the lean / static-coordinate pipelines of an item, and what assemble_bin is told
     bool xi_sums = true;             // VMX_NO_XI_SUMS: one array per pipeline, as the general kernels write them
     bool sums_dirty = true;
@@ -239,19 +234,12 @@ struct vmx_engine {
     bool sums_any = false;
     // (members per array: four lean, sixteen static-coordinate pipelines - measured at B = 512: groups of 2 / 3 lean members
     // 462k / 477k evaluations / s against 474k, 4 / 8 static members 472k / 473k)
-    int xi_static_group_nw = 2;      // VMX_XI_STATIC_NW: walkers per thread of k_xi_bins_static_group (k_xi_bins_static_nw: 4)
-    int xi_lean_nw = 2, xi_static_nw = 4;     // VMX_XI_LEAN_NW / VMX_XI_STATIC_NW: walkers per thread of the two kernels (1, 2, 4)
     bool xi_lean = true;             // VMX_NO_XI_LEAN: every per-walker pipeline's bins by the general k_xi_bins
     std::vector<int32_t> xi_lean_pipes, xi_rest_pipes;      // the active pipelines k_xi_bins_lean serves / the others
     DevBuf<int32_t> d_xi_rest_pipes;
-    int xi_plain_nw = 2;             // walkers per thread of k_xi_quad_plain (VMX_XI_PLAIN_NW: 0 = the general kernel, 1, 2, 4)
-    bool fft_narrow = true;          // VMX_NO_FFT_NARROW: never the 64 x 32 tiles for the FFTLog product
     bool ring_allowed = true;        // one batch in flight only: a 128 KB block leaves the other lane's kernels no room on its CU
-    bool no_small_tab = false;       // VMX_NO_SMALL_TAB: batches below 16 walkers never use the tables
     int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
     bool no_tab2 = false;            // VMX_NO_TAB2: level-1 tables only (the Gaussian factors stay in the mu loop)
-    bool quad_band_xcd = false;      // VMX_XCD_BANDS: a K band per XCD (HBM traffic 1.96x -> 1.43x the algorithmic bytes, launch 6 % longer)
-    bool gemm_44 = true;             // products on the four-block 4x4x4 fp64 MFMA (VMX_GEMM_16: the 16x16x4 kernel everywhere)
     bool pk_small_attr = false;      // the single-walker P(k) shape asked for its > 64 KB of LDS
     bool kron_attr = false;          // k_metal_kron asked for its dynamic LDS
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
@@ -267,9 +255,11 @@ struct vmx_engine {
     // quadratic form of chi2: used when only chi2 is asked for (see vmx_set_quadratic_form)
     std::vector<double> theta_ref;
     bool quad_eligible = false, quad_mat_dirty = true, quad_lin_dirty = true, no_fuse = false;
+    int quad_kind = 0;               // vmx_set_quadratic_form_kind: 0 = the cheaper form, 1 = Q', 2 = factored
+    bool quad_factored = false;      // the form the tensors were built for
+    int last_form = 0;               // form of the last evaluation: 0 full chain, 1 Q', 2 factored (vmx_debug_read 4 [8])
     // VMX_TRACE_HOST: host-side phases of vmx_eval accumulated in nanoseconds (staging, enqueue, wait), printed at destroy
     bool trace_host = false; double host_ns[3] = {0, 0, 0}; int64_t host_calls = 0;
-    int quad_use_44 = 1;             // the Q' products run on the four-block MFMA kernel (VMX_QUAD_44=0: the 16x16x4 kernel)
     EngineDev dev{};
 
     // host path: pinned staging buffers and one captured graph per batch size
@@ -284,7 +274,6 @@ struct vmx_engine {
     bool no_host_reduce = false;     // VMX_NO_HOST_REDUCE
     std::map<int, hipGraphExec_t> graphs;
     bool use_graphs = true;
-    bool graph_b1 = false;           // VMX_GRAPH_B1: replay a captured graph for single-walker host evaluations too
 
     // profiling
     bool profiling = false;
@@ -459,7 +448,6 @@ static int plan_gemm(vmx_engine* e, GemmArgs& g, int nbatch, int slab_rows_avail
     int nsplit = 1;
     while (nsplit < 8 && tiles * nsplit < 512) nsplit *= 2;
     if (forced_split > 0) nsplit = forced_split;
-    if (e->gemm_split_override > 0) nsplit = e->gemm_split_override;
     while (nsplit > 1 && (int64_t)nsplit * g.N > slab_rows_avail) nsplit /= 2;
     int klen = ((g.K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
     while (nsplit > 1 && (int64_t)klen * (nsplit - 1) >= g.K) { nsplit /= 2; klen = ((g.K + nsplit - 1) / nsplit + BK - 1) / BK * BK; }
@@ -467,7 +455,7 @@ static int plan_gemm(vmx_engine* e, GemmArgs& g, int nbatch, int slab_rows_avail
     g.tm = tm; g.tn = tn; g.k_limit = k_limit; g.tri = tri ? 1 : 0;
     const int ngroups = 8 / nsplit;
     *per_xcd = ((tm_eff + ngroups - 1) / ngroups) * tn;
-    if (g.m_window && nsplit == 1 && e->gemm_44) *per_xcd = tm_eff * ((tn + 7) / 8);     // walker tiles over the XCDs (k_gemm_nt44: n_major)
+    if (g.m_window && nsplit == 1) *per_xcd = tm_eff * ((tn + 7) / 8);     // walker tiles over the XCDs (k_gemm_nt44: n_major)
     return nsplit;
 }
 
@@ -530,13 +518,13 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
     // the four-block 4x4x4 MFMA kernel runs every full product (distortion and metal matrices, FFTLog o spline,
     // stand-alone products); the short triangular C^-1 products are faster on the 16x16x4 kernel, whose two resident
     // blocks hide each other's start and end (0.093 against 0.103 - 0.126 ms: two short passes per block)
-    if (e->gemm_44 && kc != KC_INVCOV && !(kc == KC_QUAD && !e->quad_use_44)) {
+    if (kc != KC_INVCOV) {
         block = dim3(GEMM44_THREADS);
         // (a windowed FFTLog launch carries its batch - the multipoles - inside grid.x: GemmGroup::batch_in_x)
         GemmGroup Gx = G;
         dim3 gridx = grid;
         // (when the launch has the chip to itself; with several batches in flight the late starters fill the other lane's gaps)
-        const bool batch_x = e->ring_allowed && getenv("VMX_NO_FFT_BATCH_X") == nullptr;
+        const bool batch_x = e->ring_allowed;
         if (batch_x && kc == KC_FFTLOG && G.n == 1 && G.p[0].m_window && G.work == nullptr && nbatch > 1) { Gx.batch_in_x = nbatch; gridx = dim3(grid.x * nbatch, 1); }
         switch (kc) {
             case KC_QUAD: hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), grid, block, 0, e->cur, G); break;
@@ -553,7 +541,7 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
                 // pace (B = 256: 49 -> 44 us).  With fewer tiles its slower dispatch (128 KB of LDS per block) costs more than
                 // it gains (B = 64: 32 -> 35 us); with more, two resident two-buffer blocks hide each other's latencies better
                 // (B = 1024: 103 -> 138 us).  The live rows are device data: a third of the operator's rows is the estimate.
-                if (e->fft_narrow && G.n == 1 && G.p[0].m_window && G.p[0].nsplit == 1 && !G.p[0].tri) {
+                if (G.n == 1 && G.p[0].m_window && G.p[0].nsplit == 1 && !G.p[0].tri) {
                     // about one live 64 x 64 tile per CU (the operator's live rows are device data: a third of them is the
                     // estimate): 64 x 32 tiles instead - twice the blocks, two per CU, each covering the other's bubbles
                     const int64_t est = (int64_t)G.p[0].tn * nbatch * ((G.p[0].tm * 3 + 9) / 10);
@@ -565,7 +553,7 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
                         G2.batch_in_x = batch_x ? nbatch : 0;         // (the live blocks of all multipoles first in launch order)
                         // (+ 24 KB of unused dynamic LDS: 72 KB per block = two per CU.  With its own 48 KB the dispatcher packs three
                         // blocks on a CU before it moves on and leaves a third of the CUs empty.)
-                        const size_t pad = getenv("VMX_FFT_NARROW_PAD") ? (size_t)atoi(getenv("VMX_FFT_NARROW_PAD")) : 24 * 1024;
+                        const size_t pad = 24 * 1024;
                         hipLaunchKernelGGL((k_gemm_nt44<KC_FFTLOG, 2, 32>), grid2, block, pad, e->cur, G2);
                         break;
                     }
@@ -590,13 +578,7 @@ static void launch_gemm_group(vmx_engine* e, int kc, const GemmGroup& G, int per
         }
         return;
     }
-    switch (kc) {
-        case KC_DISTORTION: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_DISTORTION>), grid, block, 0, e->cur, G); break;
-        case KC_INVCOV: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_INVCOV>), grid, block, 0, e->cur, G); break;
-        case KC_QUAD: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_QUAD>), grid, block, 0, e->cur, G); break;
-        case KC_FFTLOG: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_FFTLOG>), grid, block, 0, e->cur, G); break;
-        default: hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_OTHER>), grid, block, 0, e->cur, G); break;
-    }
+    hipLaunchKernelGGL((k_gemm_nt<BM, BN, BK, KC_INVCOV>), grid, block, 0, e->cur, G);
 }
 
 // D[n][m] = sum_k A[m][k] X[n][k]; returns the number of K slabs written (consumer sums them).
@@ -1133,14 +1115,10 @@ int vmx_item_set_matrix_csr(vmx_engine* e, int32_t item, int32_t rows, int32_t c
     ItemHost* it = e->items[item];
     REQUIRE(rows == it->dev.d.n_dist && cols == it->dev.d.n_model, "distortion matrix shape");
     REQUIRE(!it->has_dm, "the item already has a dense distortion matrix");
-    REQUIRE(indptr[0] == 0, "indptr[0] must be 0");
+    // validity and canonical form (vmx_plan.h: the set-up of the quadratic form scatters the rows - last write wins - where
+    // the product adds them, so duplicates would disagree)
+    if (const char* why = vmx_plan::csr_problem(rows, cols, indptr, indices); why[0]) return fail(-1, std::string("invalid argument: CSR matrix: ") + why);
     const int64_t nnz = indptr[rows];
-    for (int r = 0; r < rows; ++r) REQUIRE(indptr[r + 1] >= indptr[r], "indptr must be non-decreasing");
-    for (int64_t k = 0; k < nnz; ++k) REQUIRE(indices[k] >= 0 && indices[k] < cols, "column index out of range");
-    // canonical form: the quadratic form scatters the rows (k_quad_gather_csr: last write wins), the product adds them
-    for (int r = 0; r < rows; ++r)
-        for (int64_t k = indptr[r] + 1; k < indptr[r + 1]; ++k)
-            REQUIRE(indices[k] > indices[k - 1], "column indices must be strictly ascending within a row (no duplicates)");
     HIP_OK(hipSetDevice(e->device));
     if (it->csr_ptr.upload(indptr, (size_t)rows + 1) || it->csr_idx.upload(indices, (size_t)std::max<int64_t>(nnz, 1)) ||
         it->csr_val.upload(values, (size_t)std::max<int64_t>(nnz, 1))) return -2;
@@ -1286,36 +1264,18 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     // split-K slabs are re-read by the consumer kernels: at most 1024 walker rows of slabs per product (measured
     // best in the full chain, where the items overlap on separate streams and fill the chip anyway)
     e->slab_rows = Bm > 1024 ? Bm : 1024;
-    if (const char* ov = getenv("VMX_GEMM_SPLIT")) e->gemm_split_override = atoi(ov);
-    if (getenv("VMX_GEMM_16")) e->gemm_44 = false;
     if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
     if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
-    if (getenv("VMX_NO_WORK_LIST")) e->quad_list_mode = false;
-    if (getenv("VMX_NO_PERSISTENT")) e->quad_persistent = false;
-    if (const char* v = getenv("VMX_QUAD_OVH")) e->quad_overhead = atof(v);
-    if (const char* v = getenv("VMX_QUAD_SKEW")) e->quad_skew = std::min(std::max(atof(v), -0.5), 0.5);
     {
         int cus = 256;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
         e->quad_blocks = 2 * cus;
-        if (const char* v = getenv("VMX_QUAD_BLOCKS")) e->quad_blocks = std::max(8, atoi(v));
     }
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
-    if (getenv("VMX_NO_SMALL_TAB")) e->no_small_tab = true;
     if (getenv("VMX_NO_PK_W")) e->no_pk_w = true;
-    if (getenv("VMX_NO_FFT_RING")) e->fft_ring = false;
-    if (getenv("VMX_NO_FFT_NARROW")) e->fft_narrow = false;
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
-    if (getenv("VMX_NO_FUSED_CHI2")) e->quad_fused_chi2 = false;
-    if (const char* v = getenv("VMX_XI_PLAIN_NW")) e->xi_plain_nw = atoi(v);
     if (getenv("VMX_NO_XI_LEAN")) e->xi_lean = false;
     if (getenv("VMX_NO_XI_SUMS")) e->xi_sums = false;
-    if (const char* v = getenv("VMX_XI_LEAN_NW")) e->xi_lean_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
-    if (const char* v = getenv("VMX_XI_STATIC_NW")) e->xi_static_group_nw = e->xi_static_nw = atoi(v) >= 4 ? 4 : atoi(v) >= 2 ? 2 : 1;
-    if (const char* v = getenv("VMX_ITEM_STREAMS")) e->item_streams = atoi(v) != 0;
-    if (const char* nw = getenv("VMX_PK_NW")) e->pk_walkers_per_thread = atoi(nw) == 1 ? 1 : 2;
-    if (getenv("VMX_XCD_BANDS")) e->quad_band_xcd = true;
-    if (getenv("VMX_GRAPH_B1")) e->graph_b1 = true;
 
     // every slot must index a theta column and the combinations the kernels rely on must be present
     auto slot_ok = [&](int s) { return s < n_params; };
@@ -1720,7 +1680,6 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         if (na > VMX_MAX_QUAD_COEF) e->quad_eligible = false;
     }
     if (getenv("VMX_NO_QUAD")) e->quad_eligible = false;
-    if (const char* q44 = getenv("VMX_QUAD_44")) e->quad_use_44 = atoi(q44);
 
     HIP_OK(hipStreamSynchronize(e->stream));
     e->finalized = true;
@@ -1736,203 +1695,32 @@ int vmx_pipeline_column(vmx_engine* e, int32_t pipeline)
     return e->pipes[pipeline].col >= 0 ? e->pipes[pipeline].col : -3 - e->n_active;     // (< -2: no column; the count is -3 - value)
 }
 
-// Work list of the quadratic-form launch for B walkers with segments of about L stages (a stage = 32 columns): every
-// 64 x 64 tile of every item's half-triangle product is cut into ceil(stages / L) K segments of equal length.  The walker
-// tiles of one (row tile, segment) share their matrix tile: they get block indices 8 apart - the same XCD, back to back.
-static vmx_engine::QuadList* quad_build_list(vmx_engine* e, int B, int L, int only_item = -1)
+// The quadratic-form launch as a persistent tape ("stream-K"): the cut, the slot numbering and the block queues are planned by
+// vmx_plan::plan_quad_tape (vmx_plan.h - plain C++, run under sanitizers by tests/test_planner_host.py), a pure function of
+// (problem shapes, walker tiles, blocks).
+// cost of starting / finishing an entry in K stages (fitted from the block trace: duration = 1.98 us stages + 7.3 us entries
+// + 9.8), and the share of a piece moved from the blocks dispatched second to those dispatched first (B = 256: 145.1 us at 0,
+// 142.6 at 0.12 - 0.16, 144.0 at 0.2, 149.6 at 0.4)
+constexpr double QUAD_ENTRY_STAGES = 4.0, QUAD_SKEW = 0.12;
+
+static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B)
 {
-    constexpr int BM = GEMM_BM, BK = GEMM_BK;
     const int tn = (B + GEMM_BN - 1) / GEMM_BN;
-    // (the list serves every batch size with this many walker tiles: slabs sized for the largest of them)
-    const int max_slabs = std::max(1, std::min(8, e->slab_rows / (tn * GEMM_BN)));
+    std::vector<vmx_plan::TapeProblem> probs;
+    for (auto* it : e->items) probs.push_back({it->dev.nq, it->dev.nq_pad});
+    vmx_plan::Tape T = vmx_plan::plan_quad_tape(probs, tn, e->quad_blocks, QUAD_ENTRY_STAGES, QUAD_SKEW, GEMM_BM, GEMM_BK);
     auto* ql = new vmx_engine::QuadList();
-    struct Group { int prob, mt, seg, kbeg, kend; };
-    std::vector<Group> groups;
-    std::vector<int32_t> nseg_all;
-    for (size_t q = 0; q < e->items.size(); ++q) {
-        const ItemDev& d = e->items[q]->dev;
-        const int tm = (d.nq + BM - 1) / BM, kmax_all = d.nq_pad / BK;
-        ql->nseg_off[q] = (int32_t)nseg_all.size();
-        if (only_item >= 0 && (int)q != only_item) continue;        // (a list of one item's tiles: the items run on forked streams)
-        for (int mt = 0; mt < tm; ++mt) {
-            const int stages = std::min(((mt + 1) * BM + BK - 1) / BK, kmax_all);
-            const int nseg = std::min(max_slabs, (stages + L - 1) / L);
-            const int len = (stages + nseg - 1) / nseg;
-            nseg_all.push_back(nseg);
-            ql->max_seg = std::max(ql->max_seg, nseg);
-            for (int sg = 0; sg < nseg; ++sg) {
-                const int kb = sg * len * BK, ke = std::min((sg + 1) * len, stages) * BK;
-                groups.push_back({(int)q, mt, sg, kb, std::max(kb, ke)});
-            }
-        }
-    }
-    // Default: longest segments first, dealt round-robin to the XCDs.  Option (VMX_XCD_BANDS): XCD x takes a band of K - every
-    // XCD has its own L2, and the slice of the walker operand a band touches (all walkers x the band's columns) then stays
-    // resident there instead of being fetched by all eight; band edges cut the triangle into eight pieces of equal work.
-    // Measured: HBM traffic 306 -> 223 MB per launch (1.96x -> 1.43x the algorithmic bytes), but the launch takes 6 % longer
-    // (the kernel is MFMA-issue bound at 1.6 TB/s; the bands cost balance) - so not the default.
-    std::vector<std::vector<Group>> per_xcd(8);
-    if (e->quad_band_xcd) {
-        std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) {
-            return a.prob != b.prob ? a.prob < b.prob : (a.kbeg != b.kbeg ? a.kbeg < b.kbeg : a.mt < b.mt); });
-        double total = 0.0, cum = 0.0;
-        for (auto& g : groups) total += (g.kend - g.kbeg) / BK;
-        for (auto& g : groups) {
-            per_xcd[std::min(7, (int)(cum / total * 8.0))].push_back(g);
-            cum += (g.kend - g.kbeg) / BK;
-        }
-    } else {
-        std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.kend - a.kbeg > b.kend - b.kbeg; });
-        for (size_t j = 0; j < groups.size(); ++j) per_xcd[j % 8].push_back(groups[j]);
-    }
-    size_t rows = 0;
-    for (auto& v : per_xcd) {
-        std::stable_sort(v.begin(), v.end(), [](const Group& a, const Group& b) { return a.kend - a.kbeg > b.kend - b.kbeg; });
-        rows = std::max(rows, v.size());
-    }
-    std::vector<GemmWork> work(rows * tn * 8, GemmWork{-1, 0, 0, 0, 0, 0});
-    for (int xcd = 0; xcd < 8; ++xcd)
-        for (size_t r = 0; r < per_xcd[xcd].size(); ++r) {
-            const Group& g = per_xcd[xcd][r];
-            for (int nt = 0; nt < tn; ++nt)
-                work[(r * tn + nt) * 8 + xcd] = GemmWork{g.prob, g.mt, nt, g.kbeg, g.kend, g.seg};
-        }
-    ql->n_blocks = (int)work.size();
-    ql->rows = (int)rows;
-    ql->seg_len = L;
-    if (ql->work.upload(work.data(), work.size()) || ql->nseg.upload(nseg_all.data(), nseg_all.size()) ||
-        ql->part.alloc(work.size() * 128, true)) { delete ql; return nullptr; }
+    ql->n_blocks = T.n_blocks;
+    ql->n_entries = (int)T.n_slots;
+    if (T.work.empty()) T.work.push_back(GemmWork{-1, 0, 0, 0, 0, 0, 0, 0});
+    if (ql->work.upload(T.work.data(), T.work.size()) || ql->queue.upload(T.queue.data(), T.queue.size()) ||
+        ql->nt_off.upload(T.nt_off.data(), T.nt_off.size()) ||
+        ql->part.alloc(std::max<size_t>((size_t)T.n_slots, 1) * 128, true)) { delete ql; return nullptr; }
     return ql;
 }
 
-// Persistent form of the work list ("stream-K"): every (row tile, walker tile) K range of every item's half-triangle product
-// is laid on ONE tape - long rows first, the walker tiles of a row next to each other - and the tape is cut into as many
-// pieces of equal cost as there are resident blocks (2 per CU), cost = K stages + a fixed charge per entry (pipeline fill and
-// contraction epilogue, `quad_overhead` stages).  A piece boundary inside a K range splits it into two entries: the launch
-// has (ranges + blocks - 1) entries at most, every block the same work to a stage, and no last round - where the
-// equal-length segments of quad_build_list left 1024 blocks of unequal length for 512 slots.  Block p takes piece
-// (p % 8) * (blocks / 8) + p / 8: neighbouring pieces - the same or adjacent row tiles - share an XCD and its L2.
-// The cut is a pure function of (problem shapes, walker tiles, blocks): partial sums are grouped identically on every rank
-// and in every run.  Slots are numbered per walker tile in tape order; k_chi2_parts adds them in that order.
-static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B, int only_item = -1)
-{
-    constexpr int BM = GEMM_BM, BK = GEMM_BK;
-    const int tn = (B + GEMM_BN - 1) / GEMM_BN;
-    const int P = e->quad_blocks / 8 * 8;
-    struct Range { int prob, mt, stages; };
-    std::vector<Range> ranges;
-    for (size_t q = 0; q < e->items.size(); ++q) {
-        if (only_item >= 0 && (int)q != only_item) continue;
-        const ItemDev& d = e->items[q]->dev;
-        const int tm = (d.nq + BM - 1) / BM, kmax_all = d.nq_pad / BK;
-        for (int mt = 0; mt < tm; ++mt) ranges.push_back({(int)q, mt, std::min(((mt + 1) * BM + BK - 1) / BK, kmax_all)});
-    }
-    std::stable_sort(ranges.begin(), ranges.end(), [](const Range& a, const Range& b) { return a.stages > b.stages; });
-    // Blocks work in lock-step groups of `gs` (4 when the walker tiles allow it): the members of a group walk the SAME
-    // entries, each for its own walker tile, side by side on one XCD - the matrix tile of an entry is then fetched from HBM
-    // once and found in that XCD's L2 by the other members (without the lock-step every block streams its own copy: 1 GB of
-    // L2 misses per launch, and the launch is bandwidth-bound).  The tape therefore carries (row tile, group of gs walker
-    // tiles) ranges and is cut into P / gs pieces.
-    const int gs = tn % 4 == 0 ? 4 : tn % 2 == 0 ? 2 : 1;
-    const int n_groups = tn / gs, n_pieces = P / gs;
-    const double ovh = e->quad_overhead;
-    double stages_total = 0.0;
-    for (auto& r : ranges) stages_total += (double)r.stages * n_groups;
-    constexpr int MIN_SEG = 2;                  // no entry shorter than this many stages (but for ranges that short)
-    struct Entry { GemmWork w; int piece; };    // (w.nt: the group's first walker tile)
-    std::vector<Entry> entries;
-    // A piece may cost at most `cap` = its K stages + the fixed charge of each of its entries; the tape is filled greedily -
-    // a piece takes what fits, a cut inside a K range opens an entry on either side - and `cap` is the smallest capacity for
-    // which n_pieces pieces suffice (bisection: the piece count is monotone in cap).  Every piece then costs cap to within a
-    // stage, but for the last one, which holds what is left.  (Round 3's first tape sized the pieces from an estimate of the
-    // entry count and let the last piece absorb the error: pieces between 63.6 and 74.1 stage-equivalents for a mean of 69.0 at
-    // B = 256 - the launch lasts as long as its largest piece - and up to 97 for unlucky values of the charge.)
-    // (a CU issues from its older resident block first: of two equal pieces the one dispatched first ends earlier and leaves the
-    // other alone on the CU - block p = 8 i + xcd takes piece xcd * per_xcd + i / gs, so the first half of an XCD's pieces belongs
-    // to the blocks dispatched first; `quad_skew` shifts work to them)
-    const int per_xcd_pieces = n_pieces / 8;
-    // (the same tape whatever the number of batches in flight - a walker's chi2 must not depend on it, and the cut points decide
-    // how its partial sums are grouped; with two batches in flight the skew neither helps nor hurts beyond the run-to-run noise)
-    const double skew = e->quad_skew;
-    auto weight = [&](int pc) { return (pc % per_xcd_pieces) < per_xcd_pieces / 2 ? 1.0 + skew : 1.0 - skew; };
-    auto fill = [&](double cap0, bool keep) {
-        if (keep) entries.clear();
-        int pc = 0;
-        double cur = 0.0, cap = cap0 * weight(0);
-        for (auto& r : ranges)
-            for (int grp = 0; grp < n_groups; ++grp) {
-                int k = 0, left = r.stages;
-                while (left > 0) {
-                    const double avail = cap - cur - ovh;
-                    if (cur > 0.0 && avail < (double)std::min(left, MIN_SEG)) { ++pc; cur = 0.0; cap = cap0 * weight(std::min(pc, n_pieces - 1)); continue; }
-                    int take = std::min(left, std::max(MIN_SEG, (int)std::floor(avail + 1e-9)));
-                    const int rem = left - take;
-                    if (rem > 0 && rem < MIN_SEG) take = (take - (MIN_SEG - rem) >= MIN_SEG) ? take - (MIN_SEG - rem) : left;     // no sliver behind the cut
-                    if (keep) entries.push_back({GemmWork{r.prob, r.mt, grp * gs, k * BK, (k + take) * BK, 0, 0, 0}, std::min(pc, n_pieces - 1)});
-                    cur += take + ovh;
-                    k += take; left -= take;
-                }
-            }
-        return pc + 1;
-    };
-    {
-        double lo = stages_total / n_pieces, hi = lo + ovh * (double)(ranges.size() * n_groups) / n_pieces + 4.0 * ovh + 256.0;
-        for (int it = 0; it < 48; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (fill(mid, false) <= n_pieces) hi = mid; else lo = mid;
-        }
-        (void)fill(hi, true);
-    }
-    // slots: per walker tile, tape order (entry j of walker-tile group grp is slot (its rank within the group) of every member)
-    std::vector<int32_t> nt_off(tn + 1, 0);
-    for (auto& en : entries)
-        for (int m = 0; m < gs; ++m) ++nt_off[en.w.nt + m + 1];
-    for (int nt = 0; nt < tn; ++nt) nt_off[nt + 1] += nt_off[nt];
-    {
-        std::vector<int32_t> next(n_groups, 0);
-        for (auto& en : entries) en.w.slot = next[en.w.nt / gs]++;          // (rank within the group: + nt_off[nt] per member)
-    }
-    // queues: block p = 8 i + xcd is member i % gs of the group that takes piece xcd * (P / 8 / gs) + i / gs: the members of a
-    // group are neighbouring blocks of one XCD (the dispatcher hands them to one or two CUs), start together and stay close
-    // - 496 MB of L2 misses per launch at B = 256 and 149.7 us.  Spreading a group's members over the XCD's CUs (member =
-    // i / (P / 8 / gs): co-resident blocks then belong to different groups and are out of phase) was meant to keep the MFMA
-    // pipes busy through the epilogues; measured: 616 MB and 153.4 us - the members drift apart and the matrix tile is fetched
-    // again.  VMX_QUAD_DEPHASE=1 selects that mapping.
-    std::vector<int32_t> queue(P + 1, 0);
-    std::vector<std::vector<GemmWork>> by_piece(n_pieces);
-    for (auto& en : entries) by_piece[en.piece].push_back(en.w);
-    std::vector<GemmWork> work;
-    work.reserve(entries.size() * gs);
-    for (int p = 0; p < P; ++p) {
-        const int xcd = p % 8, i = p / 8, per_xcd = P / 8 / gs;
-        const bool dephase = getenv("VMX_QUAD_DEPHASE") != nullptr;
-        const int member = dephase ? i / per_xcd : i % gs;
-        const int pcs = xcd * per_xcd + (dephase ? i % per_xcd : i / gs);
-        queue[p] = (int32_t)work.size();
-        for (auto w : by_piece[pcs]) {
-            w.nt += member;
-            w.slot += nt_off[w.nt];
-            work.push_back(w);
-        }
-    }
-    queue[P] = (int32_t)work.size();
-    const size_t n_slots = (size_t)nt_off[tn];
-    auto* ql = new vmx_engine::QuadList();
-    ql->persistent = true;
-    ql->n_blocks = P;
-    ql->n_entries = (int)n_slots;
-    ql->rows = 0;
-    ql->seg_len = 0;
-    for (size_t q = 0; q < e->items.size() && q < 16; ++q) ql->nseg_off[q] = 0;
-    if (work.empty()) work.push_back(GemmWork{-1, 0, 0, 0, 0, 0, 0, 0});
-    if (ql->work.upload(work.data(), work.size()) || ql->queue.upload(queue.data(), queue.size()) ||
-        ql->nt_off.upload(nt_off.data(), nt_off.size()) || ql->nseg.alloc(1, true) ||
-        ql->part.alloc(std::max<size_t>(n_slots, 1) * 128, true)) { delete ql; return nullptr; }
-    return ql;
-}
-
-// the launch itself; fills the slab description of the consumer (k_chi2_quad)
-static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, SlabInfo& qs)
+// the launch itself: every block walks its queue of the tape and leaves contraction partials in the tape's slots
+static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B)
 {
     GemmGroup G{};
     for (size_t q = 0; q < e->items.size(); ++q) {
@@ -1943,75 +1731,29 @@ static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B, Sla
         g.M = d.nq; g.N = B; g.K = d.nq_pad; g.tri = 1; g.nsplit = 1; g.klen = d.nq_pad;
         g.d_slab = (int64_t)B * d.nq_pad;
         g.tm = (d.nq + GEMM_BM - 1) / GEMM_BM; g.tn = (B + GEMM_BN - 1) / GEMM_BN;
-        if (e->quad_fused_chi2 && GEMM44_THREADS == 256) {
-            g.part = ql->part.p; g.lin = it->q_lin.p; g.lin_row = e->mock_index.p; g.lin_pool = d.mock_pool ? 1 : 0;
-        }
+        g.part = ql->part.p; g.lin = it->q_lin.p; g.lin_row = e->mock_index.p; g.lin_pool = d.mock_pool ? 1 : 0;
         G.p[G.n++] = g;
-        qs.z[q] = 0;
-        qs.qseg_off[q] = ql->nseg_off[q];
     }
     G.work = ql->work.p;
-    G.queue = ql->persistent ? ql->queue.p : nullptr;
+    G.queue = ql->queue.p;
     if (getenv("VMX_QUAD_TRACE")) {          // block timeline of this launch (debugging aid, written by vmx_sync as VMX_GEMM_TRACE is)
         e->gemm_trace_blocks = (size_t)ql->n_blocks;
         if (e->gemm_trace.n < 4 * e->gemm_trace_blocks) (void)e->gemm_trace.alloc(4 * e->gemm_trace_blocks, true);
         else (void)hipMemsetAsync(e->gemm_trace.p, 0, 4 * e->gemm_trace_blocks * sizeof(unsigned long long), e->cur);
         G.trace = e->gemm_trace.p;
     }
-    qs.qseg = ql->nseg.p;
     hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), dim3(ql->n_blocks, 1), dim3(GEMM44_THREADS), 0, e->cur, G);
 }
 
-// Segment length of the quadratic-form work list: a PURE FUNCTION of the number of walker tiles (and of nothing
-// else - no timing, no process-wide state), so that every rank of a sharded run and every repeat of a run groups its
-// partial sums identically: chi2 of a walker is bit-for-bit the same wherever and whenever its batch is evaluated.
-// The table comes from measurements on MI355X (VMX_QUAD_AUTOTUNE=1 times the candidates 24..96 with HIP events and
-// reports the fastest on stderr - a development aid that never feeds back into a run that did not ask for it):
-// a CU keeps two blocks resident and issues from the older one first, so a launch of ~1000 blocks of unequal length is
-// neither list scheduling on 256 machines nor on 512 half-speed ones, and simulated choices were up to 20 % off.
-static int quad_segment_length(int tn)
+static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
 {
-    if (const char* force = getenv("VMX_QUAD_L")) return std::max(1, atoi(force));
-    // (walker tiles -> stages of 32 columns) B <= 256: 40 (0.151 ms at B = 256; 64: 0.181, 80: 0.157)
-    return tn <= 4 ? 40 : tn <= 8 ? 48 : 64;
-}
-
-static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B, int only_item = -1)
-{
-    // a list depends on the batch size through its number of walker tiles only
+    // a tape depends on the batch size through its number of walker tiles only
     const int tn = (B + GEMM_BN - 1) / GEMM_BN;
-    const int key = only_item < 0 ? tn : (only_item + 1) * 1000000 + tn;
-    auto found = e->quad_lists.find(key);
+    auto found = e->quad_lists.find(tn);
     if (found != e->quad_lists.end()) return found->second;
-    vmx_engine::QuadList* best = nullptr;
-    if (e->quad_persistent && e->quad_fused_chi2 && GEMM44_THREADS == 256 && !e->quad_band_xcd) best = quad_build_tape(e, B, only_item);
-    else if (only_item >= 0) best = quad_build_list(e, B, quad_segment_length(tn), only_item);
-    else if (!getenv("VMX_QUAD_AUTOTUNE")) best = quad_build_list(e, B, quad_segment_length(tn));
-    else {
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { fail(-2, "hipEventCreate"); return nullptr; }
-        float best_ms = 1e30f;
-        e->cur = e->stream;
-        for (int L : {24, 32, 40, 48, 56, 64, 80, 96}) {
-            vmx_engine::QuadList* ql = quad_build_list(e, B, L);
-            if (!ql) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); delete best; return nullptr; }
-            float ms = 1e30f;
-            for (int rep = 0; rep < 4; ++rep) {
-                SlabInfo qs{};
-                (void)hipEventRecord(ev0, e->stream);
-                quad_launch_list(e, ql, B, qs);
-                (void)hipEventRecord(ev1, e->stream);
-                (void)hipEventSynchronize(ev1);
-                float t = 0.f;
-                if (rep > 0 && hipEventElapsedTime(&t, ev0, ev1) == hipSuccess) ms = std::min(ms, t);
-            }
-            std::fprintf(stderr, "[vegamx] VMX_QUAD_AUTOTUNE: %d walker tiles, segments of %d stages: %.4f ms\n", tn, L, ms);
-            if (ms < best_ms) { best_ms = ms; delete best; best = ql; } else delete ql;
-        }
-        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-    }
-    if (best) e->quad_lists[key] = best;
-    return best;
+    vmx_engine::QuadList* ql = quad_build_tape(e, B);
+    if (ql) e->quad_lists[tn] = ql;
+    return ql;
 }
 
 // static spline-coefficient basis of the polynomial pipelines: C[ell][basis][i] = OP_ell . V_i[ell] (k_poly_basis), with the
@@ -2071,93 +1813,6 @@ static void launch_metal_kron(vmx_engine* e, const EngineDev& D, ItemHost* it, i
     ScopedTimer t(e, KC_METAL);
     if (!e->kron_attr) { (void)hipFuncSetAttribute((const void*)k_metal_kron, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e->kron_attr = true; }
     hipLaunchKernelGGL(k_metal_kron, dim3(B, (unsigned)it->metals.size()), dim3(256), shmem, e->cur, D, item, B);
-}
-
-// chi2-only evaluation of a large batch whose every P(k,mu) group runs against level-2 tables (a sampler's batch): the
-// correlation items are independent from the prologue to the chi2 reduction - P(k,mu) group, FFTLog columns, bins +
-// quadratic-form entries, half-triangle product of one item touch nothing of another - so each item's chain goes on its own
-// stream (the reference walks `corr_items` one after the other: vega_interface.py:232-316), the largest item - the critical
-// path - on the main stream, enqueued first.  What is computed, and in which order it is summed, is exactly the one-stream
-// chain's: per-item work lists with the same segment length, partial sums added list by list.
-// MEASURED (round 3, B = 256, rocprofv3 kernel trace profiles/r03_item_streams_timeline.txt): the two items' kernels do run
-// side by side, but a step takes 0.396 ms against 0.383 - 0.40 on one stream: co-running kernels share the fp64 datapath,
-// every stage of the shorter chain still waits for its own predecessor, and two cross-queue dependencies per step cost more
-// than the block rounds they fill.  Hence OFF by default (VMX_ITEM_STREAMS=1 switches it on; tests/test_knobs_gpu.py keeps
-// it honest).  Independent BATCHES in flight are what recovers the idle rounds (vmx_set_lanes).
-static bool items_can_fork(vmx_engine* e, int B, int tab_mode, bool quad, bool xi_fused)
-{
-    if (!e->item_streams || !quad || !xi_fused || B <= 8 || e->items.size() < 2 || e->items.size() > VMX_MAX_GROUP) return false;
-    if (!(e->quad_list_mode && e->quad_use_44 && e->gemm_44 && e->quad_fused_chi2 && GEMM44_THREADS == 256)) return false;
-    if (tab_mode < 2 || e->n_xtab == 0 || e->pk_groups.size() != e->tab2_groups.size() || !e->pk_poly.empty() || !e->pk_static.empty()) return false;
-    if (e->tab2_groups.size() != e->items.size() || getenv("VMX_PK_TRACE") || getenv("VMX_QUAD_TRACE") || getenv("VMX_GEMM_TRACE")) return false;
-    // full per-kernel profiling (bench.py's calibration pass) wants uncontended kernels: one stream
-    if (e->profiling && e->prof_mask == 0xffffffffu) return false;
-    for (auto* it : e->items) {
-        int found = 0;
-        for (auto& t : e->tab2_groups)
-            if (t.pipe == it->dev.d.pipe_smooth && t.partner == it->dev.d.pipe_peak && std::abs(t.col_s - t.col_q) == 1) ++found;
-        if (found != 1) return false;
-    }
-    return true;
-}
-
-static int run_items_forked(vmx_engine* e, const EngineDev& D, int B)
-{
-    const int tn = (B + GEMM_BN - 1) / GEMM_BN;
-    std::vector<size_t> order(e->items.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return e->items[a]->dev.nq > e->items[b]->dev.nq; });
-    HIP_OK(hipEventRecord(e->ev_fork, e->stream));
-    QuadParts qp{};
-    e->last_taps = false;
-    const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
-    const int64_t ncols = (int64_t)B * e->n_active;
-    for (size_t oi = 0; oi < order.size(); ++oi) {
-        const int q = (int)order[oi];
-        ItemHost* it = e->items[q];
-        e->cur = oi == 0 ? e->stream : e->aux[oi - 1];
-        if (oi > 0) HIP_OK(hipStreamWaitEvent(e->cur, e->ev_fork, 0));
-        const Tab2Group* grp = nullptr;
-        for (auto& t : e->tab2_groups) if (t.pipe == it->dev.d.pipe_smooth) grp = &t;
-        {
-            ScopedTimer t(e, KC_PK);
-            Tab2Args A{};
-            A.g[0] = *grp;
-            if (e->pk_walkers_per_thread == 2 && B >= 64)
-                hipLaunchKernelGGL((k_pk_tab2<64, 4, 2>), dim3((B + 1) / 2, 1, (e->nk + 63) / 64), dim3(256), std::max(sh1, (size_t)4096 * sizeof(double)), e->cur, D, A, B);
-            else
-                hipLaunchKernelGGL((k_pk_tab2<64, 4, 1>), dim3(B, 1, (e->nk + 63) / 64), dim3(256), sh1, e->cur, D, A, B);
-        }
-        // FFTLog o spline of the item's two pipelines: 2 B consecutive columns (pipeline-major layout)
-        const int c0 = std::min(grp->col_s, grp->col_q);
-        launch_product(e, KC_FFTLOG, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
-                       e->pl.p + (size_t)c0 * B * e->nkp, e->nkp, ncols * e->nkp, 2 * B, e->coef.p + (size_t)c0 * B * e->ncp, e->ncp,
-                       ncols * e->ncp, VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
-        {
-            ScopedTimer t(e, KC_XI);
-            hipLaunchKernelGGL(k_xi_assemble_quad, dim3((it->dev.nq_pad + 255) / 256, B, 1), dim3(256), 0, e->cur, D, q, 0);
-        }
-        vmx_engine::QuadList* ql = quad_work_list(e, B, q);
-        if (!ql) return -2;
-        {
-            ScopedTimer t(e, KC_QUAD);
-            SlabInfo qs{};
-            quad_launch_list(e, ql, B, qs);
-        }
-        qp.part[q] = ql->part.p; qp.rows[q] = ql->rows; qp.nt_off[q] = ql->persistent ? ql->nt_off.p : nullptr;       // (added in item order, whatever the launch order)
-        if (oi > 0) HIP_OK(hipEventRecord(e->ev_join[oi - 1], e->cur));
-    }
-    qp.n = (int)e->items.size();
-    e->cur = e->stream;
-    for (size_t oi = 1; oi < order.size(); ++oi) HIP_OK(hipStreamWaitEvent(e->stream, e->ev_join[oi - 1], 0));
-    {
-        ScopedTimer t(e, KC_CHI2);
-        hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, qp, tn);
-    }
-    HIP_OK(hipGetLastError());
-    e->last_B = B;
-    e->last_full = false;
-    return 0;
 }
 
 // k_xi_quad_plain serves items that are plain peak / smooth pairs without additive template or pre-distortion broadband
@@ -2350,19 +2005,6 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         }
     }
     {
-        bool fused = quad && (size_t)n_pipe == 2 * e->items.size();
-        for (auto* it : e->items) if (!it->metals.empty() || it->dev.d.pipe_peak == it->dev.d.pipe_smooth) fused = false;
-        if (items_can_fork(e, B, tab_mode, quad, fused)) {
-            const bool skip_xtab = e->skip_xtab_once;
-            e->skip_xtab_once = false;
-            if (!skip_xtab) {
-                ScopedTimer t(e, KC_PK);
-                hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, (e->n_rows + XTAB_ROWS - 1) / XTAB_ROWS, e->n_xtab), dim3(256), 0, e->stream, D);
-            }
-            return run_items_forked(e, D, B);
-        }
-    }
-    {
         ScopedTimer t(e, KC_PK);
         // reduction scratch + (unless every looping group runs against its D_NL table) the mu^bv tables
         bool need_mubv = false;
@@ -2399,7 +2041,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                 const int n = (int)std::min<size_t>(VMX_TAB2_GROUPS, e->tab2_groups.size() - first);
                 for (int q = 0; q < n; ++q) A.g[q] = e->tab2_groups[first + q];
                 if ((int64_t)B * e->n_xtab >= 24) {
-                    if (e->pk_walkers_per_thread == 2 && B >= 64)
+                    if (B >= 64)
                         hipLaunchKernelGGL((k_pk_tab2<64, 4, 2>), dim3((B + 1) / 2, n, (e->nk + 63) / 64), dim3(256), std::max(sh1, (size_t)4096 * sizeof(double)), e->stream, D, A, B);
                     else
                         hipLaunchKernelGGL((k_pk_tab2<64, 4, 1>), dim3(B, n, (e->nk + 63) / 64), dim3(256), sh1, e->stream, D, A, B);
@@ -2464,13 +2106,10 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         int max_nq = 0;
         for (auto* it : e->items) max_nq = std::max(max_nq, (int)it->dev.nq_pad);
         XiPlainArgs XA{};
-        const int nw = e->xi_plain_nw;
-        if (B > 8 && nw > 0 && xi_plain_args(e, XA)) {
-            const unsigned ni = (unsigned)e->items.size();
-            if (nw >= 4) hipLaunchKernelGGL(k_xi_quad_plain<4>, dim3((max_nq + 255) / 256, (B + 3) / 4, ni), dim3(256), 0, e->stream, D, XA, 0, B);
-            else if (nw == 2) hipLaunchKernelGGL(k_xi_quad_plain<2>, dim3((max_nq + 255) / 256, (B + 1) / 2, ni), dim3(256), 0, e->stream, D, XA, 0, B);
-            else hipLaunchKernelGGL(k_xi_quad_plain<1>, dim3((max_nq + 255) / 256, B, ni), dim3(256), 0, e->stream, D, XA, 0, B);
-        } else
+        // (two walkers per thread: 41 us at B = 256 against 53 with one; four measured the same as two)
+        if (B > 8 && xi_plain_args(e, XA))
+            hipLaunchKernelGGL(k_xi_quad_plain<2>, dim3((max_nq + 255) / 256, (B + 1) / 2, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, XA, 0, B);
+        else
         hipLaunchKernelGGL(k_xi_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, 0, B <= 8 ? 1 : 0);
     } else {
         ScopedTimer t(e, KC_XI);
@@ -2481,11 +2120,9 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         const bool sums_on = use_sums && e->sums_any && !e->sums_dirty;      // (the plan is made with the static basis, outside any capture)
         if (sums_on) { D.sums = e->d_item_sums.p; D.sums_on = 1; e->last_taps = false; }
         if (sums_on && !e->lean_groups.empty()) {
-            const int nw = e->xi_lean_nw;
-            const dim3 grid((max_n + 255) / 256, (unsigned)e->lean_groups.size(), (B + nw - 1) / nw);
-            if (nw == 4) hipLaunchKernelGGL(k_xi_bins_group<4>, grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
-            else if (nw == 2) hipLaunchKernelGGL(k_xi_bins_group<2>, grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
-            else hipLaunchKernelGGL(k_xi_bins_group<1>, grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
+            // (walkers per thread of the lean kernels: 1 / 2 / 4 measured the same - the stage is bound by its dependent lookups)
+            const dim3 grid((max_n + 255) / 256, (unsigned)e->lean_groups.size(), (B + 1) / 2);
+            hipLaunchKernelGGL(k_xi_bins_group<2>, grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
             if (!e->xi_rest_pipes.empty())
                 hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, (unsigned)e->xi_rest_pipes.size(), B), dim3(256), 0, e->stream, D, e->d_xi_rest_pipes.p);
         } else if (B > 8 && !e->direct && !e->xi_lean_pipes.empty()) {
@@ -2496,11 +2133,8 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                 L.coord_off = P.coord_off; L.xi_off = P.xi_off; L.n = P.n; L.n_pad = P.n_pad; L.pipe = e->xi_lean_pipes[q]; L.col = P.col;
                 L.n_ell = P.d.n_ell; L.split_evol = P.split_evol; L.radiation = P.d.is_peak ? 0 : P.d.radiation;
             }
-            const int nw = e->xi_lean_nw;
-            const dim3 grid((max_n + 255) / 256, (unsigned)e->xi_lean_pipes.size(), (B + nw - 1) / nw);
-            if (nw == 4) hipLaunchKernelGGL(k_xi_bins_lean<4>, grid, dim3(256), 0, e->stream, D, LA, B);
-            else if (nw == 2) hipLaunchKernelGGL(k_xi_bins_lean<2>, grid, dim3(256), 0, e->stream, D, LA, B);
-            else hipLaunchKernelGGL(k_xi_bins_lean<1>, grid, dim3(256), 0, e->stream, D, LA, B);
+            const dim3 grid((max_n + 255) / 256, (unsigned)e->xi_lean_pipes.size(), (B + 1) / 2);
+            hipLaunchKernelGGL(k_xi_bins_lean<2>, grid, dim3(256), 0, e->stream, D, LA, B);
             if (!e->xi_rest_pipes.empty())
                 hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, (unsigned)e->xi_rest_pipes.size(), B), dim3(256), 0, e->stream, D, e->d_xi_rest_pipes.p);
         } else if (e->n_active > 0)
@@ -2511,12 +2145,9 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             if (!e->xi_static_taps.empty())
                 hipLaunchKernelGGL(k_xi_bins<true>, dim3((max_n + 255) / 256, (unsigned)e->xi_static_taps.size(), B), dim3(256), 0, e->stream, D, e->d_xi_static_taps.p);
             if (sums_on && !e->xi_static_bins.empty()) {
-                const int nw = e->xi_static_group_nw;
                 if (!e->static_groups.empty()) {
-                    const dim3 grid((max_n + 255) / 256, (unsigned)e->static_groups.size(), (B + nw - 1) / nw);
-                    if (nw == 4) hipLaunchKernelGGL(k_xi_bins_static_group<4>, grid, dim3(256), 0, e->stream, D, e->d_static_groups.p, B);
-                    else if (nw == 2) hipLaunchKernelGGL(k_xi_bins_static_group<2>, grid, dim3(256), 0, e->stream, D, e->d_static_groups.p, B);
-                    else hipLaunchKernelGGL(k_xi_bins_static_group<1>, grid, dim3(256), 0, e->stream, D, e->d_static_groups.p, B);
+                    const dim3 grid((max_n + 255) / 256, (unsigned)e->static_groups.size(), (B + 1) / 2);
+                    hipLaunchKernelGGL(k_xi_bins_static_group<2>, grid, dim3(256), 0, e->stream, D, e->d_static_groups.p, B);
                 }
                 if (!e->static_single.empty())
                     hipLaunchKernelGGL(k_xi_bins_static, dim3((max_n + 255) / 256, (unsigned)e->static_single.size(), B), dim3(256), 0, e->stream, D, e->d_static_single.p);
@@ -2536,11 +2167,9 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                         L.coord_off = P.coord_off; L.xi_off = P.xi_off; L.poly_off = P.poly_bins_off; L.n = P.n; L.n_pad = P.n_pad;
                         L.pipe = e->xi_static_bins[q]; L.split_evol = P.split_evol; L.same_tracer = P.d.same_tracer;
                     }
-                    const int nw = e->xi_static_nw;
-                    const dim3 grid((max_n + 255) / 256, (unsigned)e->xi_static_bins.size(), (B + nw - 1) / nw);
-                    if (nw == 4) hipLaunchKernelGGL(k_xi_bins_static_nw<4>, grid, dim3(256), 0, e->stream, D, LA, B);
-                    else if (nw == 2) hipLaunchKernelGGL(k_xi_bins_static_nw<2>, grid, dim3(256), 0, e->stream, D, LA, B);
-                    else hipLaunchKernelGGL(k_xi_bins_static_nw<1>, grid, dim3(256), 0, e->stream, D, LA, B);
+                    // (four walkers per thread load the three basis values and the two per-bin factors once: 96 -> 51 us at B = 512)
+                    const dim3 grid((max_n + 255) / 256, (unsigned)e->xi_static_bins.size(), (B + 3) / 4);
+                    hipLaunchKernelGGL(k_xi_bins_static_nw<4>, grid, dim3(256), 0, e->stream, D, LA, B);
                 } else
                     hipLaunchKernelGGL(k_xi_bins_static, dim3((max_n + 255) / 256, (unsigned)e->xi_static_bins.size(), B), dim3(256), 0, e->stream, D, e->d_xi_static_bins.p);
             }
@@ -2567,61 +2196,82 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         }
         SlabInfo qs{};
         for (size_t q = 0; q < e->items.size(); ++q) qs.z[q] = 1;
-        if (B > 8 && e->items.size() <= VMX_MAX_GROUP && e->quad_list_mode && e->quad_use_44 && e->gemm_44) {
-            // balanced work list: every tile cut into K segments of about equal length
+        if (e->quad_factored) {
+            // chi2 = sum over items of || u0 - F dx ||^2: one rectangular product per item (all of them in one launch for B > 8,
+            // split-K slabs summed in fixed order by the reduction), then the sum of squares
+            if (B > 8 && e->items.size() <= VMX_MAX_GROUP) {
+                GemmGroup G{};
+                int tiles_total = 0, per_xcd_total = 0;
+                for (auto* it : e->items) tiles_total += gemm_tiles(it->dev.n_masked, B, false);
+                std::vector<size_t> by_size(e->items.size());
+                for (size_t q = 0; q < by_size.size(); ++q) by_size[q] = q;
+                std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) {
+                    const ItemDev& da = e->items[a]->dev; const ItemDev& db = e->items[b]->dev;
+                    return (int64_t)da.n_masked * da.nq > (int64_t)db.n_masked * db.nq; });
+                std::vector<int>& splits = e->group_splits[3 * 100000 + B];
+                if (splits.empty()) {
+                    std::vector<SplitProblem> sp;
+                    for (size_t q : by_size) {
+                        const ItemDev& d = e->items[q]->dev;
+                        int max_split = 1;
+                        while (max_split < 8 && (int64_t)max_split * 2 * B <= e->slab_rows) max_split *= 2;
+                        sp.push_back({gemm_tiles(d.n_masked, B, false), (d.nq_pad + GEMM_BK - 1) / GEMM_BK, (int64_t)B * d.n_masked_pad * 8, max_split});
+                    }
+                    splits = choose_group_splits(sp);
+                    if (splits.empty()) splits.push_back(0);
+                }
+                size_t gi = 0;
+                for (size_t q : by_size) {
+                    ItemHost* it = e->items[q];
+                    const ItemDev& d = it->dev;
+                    GemmArgs g{};
+                    g.A = it->q_f.p; g.lda = d.nq_pad; g.X = it->q_x.p; g.ldx = d.nq_pad; g.D = it->q_y.p; g.ldd = d.n_masked_pad;
+                    g.M = d.n_masked; g.N = B; g.K = d.nq_pad;
+                    int per_xcd = 0;
+                    const int forced = gi < splits.size() ? splits[gi] : 0;
+                    ++gi;
+                    qs.z[q] = plan_gemm(e, g, 1, e->slab_rows, nullptr, false, tiles_total - gemm_tiles(d.n_masked, B, false), &per_xcd, forced);
+                    per_xcd_total += per_xcd;
+                    G.p[G.n] = g; G.seq_end[G.n] = per_xcd_total; ++G.n;
+                }
+                ScopedTimer t(e, KC_QUAD);
+                launch_gemm_group(e, KC_QUAD, G, per_xcd_total, 1);
+            } else {
+                for (size_t q = 0; q < e->items.size(); ++q) {
+                    ItemHost* it = e->items[q];
+                    const ItemDev& d = it->dev;
+                    qs.z[q] = launch_product(e, KC_QUAD, it->q_f.p, d.nq_pad, 0, d.n_masked, d.nq_pad, it->q_x.p, d.nq_pad, 0, B,
+                                             it->q_y.p, d.n_masked_pad, 0, 1, e->slab_rows);
+                }
+            }
+            {
+                ScopedTimer t(e, KC_CHI2);
+                hipLaunchKernelGGL(k_chi2_quad<true>, dim3(B), dim3(CHI2_THREADS), 0, e->stream, D, B, qs);
+            }
+            HIP_OK(hipGetLastError());
+            e->last_B = B;
+            e->last_full = false;
+            e->last_form = 2;
+            return 0;
+        }
+        e->last_form = 1;
+        if (B > 8 && e->items.size() <= VMX_MAX_GROUP) {
+            // the persistent tape: every block the same work to a stage, contraction partials in the tape's slots
             vmx_engine::QuadList* ql = quad_work_list(e, B);
             if (!ql) return -2;
             {
                 ScopedTimer t(e, KC_QUAD);
-                quad_launch_list(e, ql, B, qs);
+                quad_launch_list(e, ql, B);
             }
-            if (e->quad_fused_chi2 && GEMM44_THREADS == 256) {
-                // the launch left contraction partials instead of the product: a small kernel adds them up
-                ScopedTimer t(e, KC_CHI2);
-                QuadParts qp{};
-                qp.part[0] = ql->part.p; qp.rows[0] = ql->rows; qp.nt_off[0] = ql->persistent ? ql->nt_off.p : nullptr; qp.n = 1;
-                hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, qp, (B + GEMM_BN - 1) / GEMM_BN);
-                HIP_OK(hipGetLastError());
-                e->last_B = B;
-                e->last_full = false;
-                return 0;
-            }
-        } else if (B > 8 && e->items.size() <= VMX_MAX_GROUP) {
-            GemmGroup G{};
-            int tiles_total = 0, per_xcd_total = 0;
-            for (auto* it : e->items) tiles_total += gemm_tiles(it->dev.nq, B, true);
-            std::vector<size_t> by_size(e->items.size());
-            for (size_t q = 0; q < by_size.size(); ++q) by_size[q] = q;
-            std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return e->items[a]->dev.nq > e->items[b]->dev.nq; });
-            std::vector<int>& splits = e->group_splits[2 * 100000 + B];
-            if (splits.empty()) {
-                std::vector<SplitProblem> sp;
-                for (size_t q : by_size) {
-                    const ItemDev& d = e->items[q]->dev;
-                    int max_split = 1;
-                    while (max_split < 8 && (int64_t)max_split * 2 * B <= e->slab_rows) max_split *= 2;
-                    sp.push_back({gemm_tiles(d.nq, B, true), (d.nq_pad + GEMM_BK - 1) / GEMM_BK, (int64_t)B * d.nq_pad * 8, max_split});
-                }
-                splits = choose_group_splits(sp);
-                if (splits.empty()) splits.push_back(0);
-            }
-            size_t gi = 0;
-            for (size_t q : by_size) {
-                ItemHost* it = e->items[q];
-                const ItemDev& d = it->dev;
-                GemmArgs g{};
-                g.A = it->q_mat.p; g.lda = d.nq_pad; g.X = it->q_x.p; g.ldx = d.nq_pad; g.D = it->q_z.p; g.ldd = d.nq_pad;
-                g.M = d.nq; g.N = B; g.K = d.nq_pad;
-                int per_xcd = 0;
-                const int forced = gi < splits.size() ? splits[gi] : 0;
-                ++gi;
-                qs.z[q] = plan_gemm(e, g, 1, e->slab_rows, nullptr, true, tiles_total - gemm_tiles(d.nq, B, true), &per_xcd, forced);
-                per_xcd_total += per_xcd;
-                G.p[G.n] = g; G.seq_end[G.n] = per_xcd_total; ++G.n;
-            }
-            ScopedTimer t(e, KC_QUAD);
-            launch_gemm_group(e, KC_QUAD, G, per_xcd_total, 1);
-        } else if (B == 1 && D.done_host && e->dpin_part && !e->no_host_reduce && e->items.size() <= VMX_MAX_GROUP) {
+            // the launch left contraction partials instead of the product: a small kernel adds them up
+            ScopedTimer t(e, KC_CHI2);
+            hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, (const double*)ql->part.p,
+                               (const int32_t*)ql->nt_off.p);
+            HIP_OK(hipGetLastError());
+            e->last_B = B;
+            e->last_full = false;
+            return 0;
+        } else if (B == 1 && D.done_host && e->dpin_part && !e->no_host_reduce && e->items.size() <= VMX_MAX_GROUP) {     // (Q' form)
             // single walker through the host entry: every block of the streaming products leaves its share of the contraction
             // in mapped host memory, the host adds them up (vmx_eval) - no chi2 kernel
             bool ok = true;
@@ -2664,13 +2314,14 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         }
         {
             ScopedTimer t(e, KC_CHI2);
-            hipLaunchKernelGGL(k_chi2_quad, dim3(B), dim3(CHI2_THREADS), 0, e->stream, D, B, qs);
+            hipLaunchKernelGGL(k_chi2_quad<false>, dim3(B), dim3(CHI2_THREADS), 0, e->stream, D, B, qs);
         }
         HIP_OK(hipGetLastError());
         e->last_B = B;
         e->last_full = false;
         return 0;
     }
+    e->last_form = 0;
     SlabInfo slabs{};
     for (size_t q = 0; q < e->items.size(); ++q) slabs.z[q] = 1;
     const bool grouped = B > 8 && e->items.size() <= VMX_MAX_GROUP;
@@ -2706,7 +2357,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                 return stage == 0 ? (int64_t)da.d.n_dist * da.d.n_model > (int64_t)db.d.n_dist * db.d.n_model : da.n_masked > db.n_masked; });
             // K splits of the group: simulated once per (stage, batch size)
             std::vector<int>& splits = e->group_splits[stage * 100000 + B];
-            if (splits.empty() && stage == 0 && e->gemm_44) {        // (the model describes the self-pipelined 4x4x4 kernel)
+            if (splits.empty() && stage == 0) {        // (the model describes the self-pipelined 4x4x4 kernel)
                 std::vector<SplitProblem> sp;
                 for (size_t q : by_size) {
                     ItemHost* it = e->items[q];
@@ -2875,6 +2526,20 @@ static int quad_build(vmx_engine* e)
         return 0;
     }
     e->cur = e->stream;
+    // Which form: Q' costs nq^2 flops per walker and item (half form), the factored form 2 n_masked nq.  The tape of the Q'
+    // product runs at 0.7 of the MFMA peak and needs no reduction of slabs, the factored product is a plain grouped launch:
+    // it has to win by a third to be taken (nq > 2.67 n_masked: a model grid finer than the data grid, COEFMOD >= 2).
+    {
+        double cost_q = 0.0, cost_f = 0.0;
+        for (auto* it : e->items) {
+            int na = 0;
+            for (int q = 0; q < it->dev.n_bb[VMX_BB_POST_ADD]; ++q) na += it->dev.bb[VMX_BB_POST_ADD][q].n_coef;
+            const double nq = it->dev.d.n_model + na;
+            cost_q += nq * nq; cost_f += 2.0 * it->dev.n_masked * nq;
+        }
+        const bool fact = e->quad_kind == 2 || (e->quad_kind == 0 && cost_f < 0.75 * cost_q);
+        if (fact != e->quad_factored) { e->quad_factored = fact; e->quad_mat_dirty = true; }
+    }
     for (auto* it : e->items) {
         ItemDev& d = it->dev;
         const int nm = d.n_masked, nmp = d.n_masked_pad;
@@ -2887,7 +2552,7 @@ static int quad_build(vmx_engine* e)
         d.q_na = na; d.nq = d.d.n_model + na; d.nq_pad = vmx_pad(d.nq);
         {
             // k_xi_assemble_quad's lean path: both components are plain spline sums with the standard bias evolution
-            bool plain = d.d.pipe_peak != d.d.pipe_smooth && !getenv("VMX_NO_PLAIN_PAIR");
+            bool plain = d.d.pipe_peak != d.d.pipe_smooth;
             bool lean = plain;
             for (int pq : {d.d.pipe_peak, d.d.pipe_smooth}) {
                 const PipeDev& P = e->pipes[pq];
@@ -2918,7 +2583,42 @@ static int quad_build(vmx_engine* e)
             if (cfull.alloc((size_t)nm * nmp, true)) return -2;
             hipLaunchKernelGGL(k_sym_from_half, dim3((nm + 255) / 256, nm), dim3(256), 0, e->stream, cfull.p, it->cinv.p, nm, nmp);
         }
-        if (e->quad_mat_dirty || it->q_mat.p == nullptr) {
+        if (e->quad_factored && (e->quad_mat_dirty || it->q_f.p == nullptr)) {
+            // F = U X^T with C^-1 = U^T U: the Cholesky factor of the inverse covariance on the host (vmx_plan.h; n^3 / 3 flops,
+            // a second for n = 3180 - set-up, redone only when the covariance changes)
+            std::vector<double> hu((size_t)nm * nmp, 0.0);
+            if (it->has_cinv) {
+                std::vector<double> hc((size_t)nm * nmp);
+                HIP_OK(hipStreamSynchronize(e->stream));
+                HIP_OK(hipMemcpy(hc.data(), cfull.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost));
+                if (!vmx_plan::cholesky_lower(hc.data(), nm, nmp)) {
+                    std::fprintf(stderr, "[vegamx] the inverse covariance of an item is not positive definite: chi2 keeps the Q' form\n");
+                    e->quad_kind = 1;
+                    return quad_build(e);
+                }
+                for (int i = 0; i < nm; ++i)
+                    for (int m = 0; m <= i; ++m) hu[(size_t)m * nmp + i] = hc[(size_t)i * nmp + m];       // U = L^T
+            } else
+                for (int i = 0; i < nm; ++i) hu[(size_t)i * nmp + i] = 1.0;
+            if (it->q_u.p == nullptr && it->q_u.alloc((size_t)nm * nmp, true)) return -2;
+            HIP_OK(hipMemcpy(it->q_u.p, hu.data(), hu.size() * sizeof(double), hipMemcpyHostToDevice));
+            DevBuf<double> X;
+            DevBuf<int64_t>& bo = it->q_basis_off;
+            boff.push_back(0);
+            if (bo.upload(boff.data(), boff.size())) return -2;
+            if (X.alloc((size_t)nq * nmp, true)) return -2;
+            hipLaunchKernelGGL(k_quad_gather, dim3((nm + 255) / 256, nq), dim3(256), 0, e->stream, X.p, nmp,
+                               it->has_dm ? it->dm.p : (const double*)nullptr, d.n_model_pad, midx.p, nm, (int)d.d.n_model, nq,
+                               e->bb_basis.p, bo.p, (int)d.d.n_dist, it->has_csr ? 1 : 0);
+            if (it->has_csr)
+                hipLaunchKernelGGL(k_quad_gather_csr, dim3(nm), dim3(256), 0, e->stream, X.p, nmp, it->csr_ptr.p, it->csr_idx.p,
+                                   it->csr_val.p, midx.p, nm);
+            // F[m][j] = sum_i X[j][i] U[m][i]  (allocated once: captured graphs hold the pointer)
+            if (it->q_f.p == nullptr && it->q_f.alloc((size_t)nm * nqp, true)) return -2;
+            launch_product(e, KC_OTHER, X.p, nmp, 0, nq, nmp, it->q_u.p, nmp, 0, nm, it->q_f.p, nqp, 0, 1, nm);
+            HIP_OK(hipStreamSynchronize(e->stream));        // X is released here
+        }
+        if (!e->quad_factored && (e->quad_mat_dirty || it->q_mat.p == nullptr)) {
             DevBuf<double> X, qfull;
             DevBuf<int64_t>& bo = it->q_basis_off;
             boff.push_back(0);
@@ -2950,8 +2650,16 @@ static int quad_build(vmx_engine* e)
                            (const double*)(e->model.p + d.model_off), midx.p, it->data.p,
                            it->n_mocks ? it->mock_pool.p : (const double*)nullptr, nm, rows);
         if (it->q_lin.alloc((size_t)rows * nqp, true) || it->q_c0.alloc(rows, true)) return -2;
+        if (e->quad_factored) {
+            // u0 = U r0 per data vector / mock
+            if (it->q_u0.alloc((size_t)rows * nmp, true)) return -2;
+            launch_product(e, KC_OTHER, it->q_u.p, nmp, 0, nm, nmp, R0.p, nmp, 0, rows, it->q_u0.p, nmp, 0, 1, rows);
+            if (it->q_y.n < (size_t)e->slab_rows * nmp && it->q_y.alloc((size_t)e->slab_rows * nmp, true)) return -2;
+            d.q_u0 = it->q_u0.p; d.q_y = it->q_y.p;
+        } else
         launch_product(e, KC_OTHER, it->q_w.p, nmp, 0, nq, nmp, R0.p, nmp, 0, rows, it->q_lin.p, nqp, 0, 1, rows);
-        if (it->has_cinv) {
+        if (e->quad_factored) {}
+        else if (it->has_cinv) {
             if (T.alloc((size_t)rows * nmp, true)) return -2;
             launch_product(e, KC_OTHER, cfull.p, nmp, 0, nm, nmp, R0.p, nmp, 0, rows, T.p, nmp, 0, 1, rows);
             hipLaunchKernelGGL(k_rowdot, dim3(rows), dim3(256), 0, e->stream, it->q_c0.p, R0.p, T.p, nmp, nm);
@@ -2960,7 +2668,7 @@ static int quad_build(vmx_engine* e)
         }
         it->q_rows = rows;
         if (it->q_x.n < (size_t)e->max_batch * nqp && it->q_x.alloc((size_t)e->max_batch * nqp, true)) return -2;
-        if (it->q_z.n < (size_t)e->slab_rows * nqp && it->q_z.alloc((size_t)e->slab_rows * nqp, true)) return -2;
+        if (!e->quad_factored && it->q_z.n < (size_t)e->slab_rows * nqp && it->q_z.alloc((size_t)e->slab_rows * nqp, true)) return -2;
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(e->stream));
         it->h_q_c0.resize(rows);
@@ -2989,11 +2697,7 @@ static int quad_ready(vmx_engine* e, bool* use, int B)
         if (!e->quad_eligible) return 0;
     }
     // (device allocations must not happen inside a stream capture: the work list of this batch size is built here)
-    if (B > 8 && e->items.size() <= VMX_MAX_GROUP && e->quad_list_mode && e->quad_use_44 && e->gemm_44) {
-        if (!quad_work_list(e, B)) return -2;
-        if (e->item_streams && e->items.size() >= 2)
-            for (size_t q = 0; q < e->items.size(); ++q) if (!quad_work_list(e, B, (int)q)) return -2;
-    }
+    if (B > 8 && e->items.size() <= VMX_MAX_GROUP && !quad_work_list(e, B)) return -2;
     *use = true;
     return 0;
 }
@@ -3053,12 +2757,12 @@ static vmx_engine* clone_lane(vmx_engine* e)
     std::vector<ItemDev> items;
     for (auto* it : L->items) {
         ItemDev& d = it->dev;
-        for (auto* b : {&it->vec, &it->dist, &it->res, &it->z, &it->marg_out, &it->q_x, &it->q_z}) {
+        for (auto* b : {&it->vec, &it->dist, &it->res, &it->z, &it->marg_out, &it->q_x, &it->q_z, &it->q_y}) {
             const size_t n = b->n;
             b->forget();
             if (n > 0 && b != &it->marg_out && b->alloc(n, true)) return fail_out();
         }
-        d.vec = it->vec.p; d.dist = it->dist.p; d.res = it->res.p; d.z = it->z.p; d.q_x = it->q_x.p; d.q_z = it->q_z.p;
+        d.vec = it->vec.p; d.dist = it->dist.p; d.res = it->res.p; d.z = it->z.p; d.q_x = it->q_x.p; d.q_z = it->q_z.p; d.q_y = it->q_y.p;
         items.push_back(d);
     }
     if (L->d_items.upload(items.data(), items.size())) return fail_out();
@@ -3133,7 +2837,7 @@ void* vmx_last_stream(vmx_engine* e) { return e ? (void*)(e->last_stream ? e->la
 
 int vmx_set_lanes(vmx_engine* e, int32_t lanes)
 {
-    REQUIRE(e && e->finalized && lanes >= 1 && lanes <= 4, "vmx_set_lanes: 1 .. 4 (after vmx_finalize)");
+    REQUIRE(e && e->finalized && lanes >= 1 && lanes <= 2, "vmx_set_lanes: 1 or 2 (after vmx_finalize)");
     HIP_OK(hipSetDevice(e->device));
     if (lanes < e->n_lanes) drop_lane(e);
     e->n_lanes = lanes;
@@ -3244,6 +2948,13 @@ int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule)
     return e->mu_nodes_on ? 1 : 0;
 }
 
+int vmx_set_quadratic_form_kind(vmx_engine* e, int32_t kind)
+{
+    REQUIRE(e && e->finalized && kind >= 0 && kind <= 2, "vmx_set_quadratic_form_kind: 0 (cheaper), 1 (Q'), 2 (factored), after vmx_finalize");
+    if (kind != e->quad_kind) { e->quad_kind = kind; e->quad_mat_dirty = true; }
+    return 0;
+}
+
 int vmx_set_quadratic_form(vmx_engine* e, const double* theta_ref)
 {
     REQUIRE(e && e->finalized, "vmx_set_quadratic_form (after vmx_finalize)");
@@ -3322,7 +3033,7 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
         for (int slot : e->const_slots2) cur.push_back(e->pin_theta[slot]);      // (the transformed values: what the device sees)
         tables_current = tab_mode == 2 && e->host_key_valid && cur == e->host_key;
         if (B < 16 && tab_mode) {
-            if (tab_mode == 2 && !e->no_small_tab && (tables_current || cur == e->pending_key)) tab_mode = 2;
+            if (tab_mode == 2 && (tables_current || cur == e->pending_key)) tab_mode = 2;
             else { if (tab_mode == 2) e->pending_key = cur; tab_mode = 0; }
         }
         if (tab_mode == 2) { e->host_key = cur; e->host_key_valid = true; }
@@ -3332,7 +3043,7 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
     // a single walker is latency-bound end to end: eager launches start the first kernel while the later ones are
     // still being enqueued, which a graph launch cannot (measured: 70 against 75 us per evaluation)
     e->host_reduce_items = 0;
-    if (B == 1 && !e->graph_b1) {
+    if (B == 1) {
         const bool by_value = zero_copy && e->n_params <= VMX_THETA_ARG_MAX;
         e->skip_xtab_once = tables_current;         // (the host knows the tables hold these parameters: no check launch)
         if (quad && by_value && e->pin_part && e->dpin_part) {
@@ -3400,7 +3111,7 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
         e->host_reduce_items = 0;
         waited = true;
     }
-    if (!waited && B == 1 && zero_copy && !model && !e->graph_b1 && e->dpin_done && !e->profiling && e->n_params <= VMX_THETA_ARG_MAX) {
+    if (!waited && B == 1 && zero_copy && !model && e->dpin_done && !e->profiling && e->n_params <= VMX_THETA_ARG_MAX) {
         // the last kernel of a single-walker chain publishes a sequence number after chi2 / status (system-scope fence):
         // the host waits on that word in mapped memory - a few microseconds sooner than the stream's completion signal
         const int64_t want = e->done_seq;
@@ -3450,7 +3161,8 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
         if (capacity >= 4) out[3] = live[1];
         if (capacity >= 5) out[4] = e->last_tab_level;
         if (capacity >= 7) { out[5] = live[2]; out[6] = live[3]; }
-        if (capacity >= 8) { out[7] = live[4]; return 8; }       // walkers that left the mu rule's box since vmx_finalize
+        if (capacity >= 9) out[8] = e->last_form;               // 0: full chain, 1: the quadratic form Q', 2: its factored form
+        if (capacity >= 8) { out[7] = live[4]; return capacity >= 9 ? 9 : 8; }       // walkers that left the mu rule's box since vmx_finalize
         return capacity >= 7 ? 7 : capacity >= 5 ? 5 : capacity >= 4 ? 4 : 3;
     }
     else { fail(-1, "invalid argument: what"); return -1; }

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/vegamx.h"
+#include "vmx_plan.h"
 
 #define VMX_NS 40            // scalars per (walker, pipeline)
 #define VMX_PAD 32           // leading dimensions are multiples of 32 doubles
@@ -122,6 +123,10 @@ struct ItemDev {
     const double* q_c0;                       // [1 + n_mocks]  r0^T C^-1 r0
     double* q_x;                              // [B][nq_pad]  x' - x0'
     double* q_z;                              // [S][B][nq_pad]  slabs of L' (x' - x0')
+    // factored form of the same chi2 (vmx_set_quadratic_form_kind): chi2 = || u0 - F dx ||^2 with C^-1 = U^T U,
+    // F = U S DM' [n_masked][nq_pad], u0 = U r0 - the cheaper one when the model grid is much finer than the data grid
+    const double* q_u0;                       // [1 + n_mocks][n_masked_pad]  U (d - S DM' x0')
+    double* q_y;                              // [S][B][n_masked_pad]  slabs of F (x' - x0')
 };
 
 
@@ -230,9 +235,8 @@ struct EngineDev {
     volatile int64_t* done_host; int64_t done_seq;
 };
 
-// split-K slab counts of a product per item (+ the global one); z[q] = 0: a work-list launch, whose row tile t of item q
-// has qseg[qseg_off[q] + t] slabs
-struct SlabInfo { int32_t z[16]; int32_t g; const int32_t* qseg; int32_t qseg_off[16]; };
+// split-K slab counts of a product per item (+ the global one)
+struct SlabInfo { int32_t z[16]; int32_t g; };
 #define CHI2_THREADS 1024                        // k_chi2 / k_chi2_quad: one block per walker
 
 // ------------------------------------------------------------------------------------------------
@@ -1999,6 +2003,9 @@ __global__ __launch_bounds__(256) void k_assemble_quad(EngineDev D)
     it.q_x[(size_t)b * it.nq_pad + i] = v;
 }
 
+// FACTORED: the same chi2 as a sum of squares, || u0 - F dx ||^2 per item (the slabs hold F dx): what the quadratic form costs
+// when nq >> n_masked (a model grid COEFMOD times finer than the data grid: 2 n_masked nq instead of nq^2 flops per walker)
+template <bool FACTORED>
 __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, SlabInfo slabs)
 {
     __shared__ double red[CHI2_THREADS / 64];
@@ -2008,11 +2015,21 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
     for (int q = 0; q < D.n_items; ++q) {
         const ItemDev& it = D.items[q];
         const int row = (mock >= 0 && it.mock_pool) ? 1 + mock : 0;
+        if constexpr (FACTORED) {
+            const double* u0 = it.q_u0 + (size_t)row * it.n_masked_pad;
+            const int ns = slabs.z[q];
+            for (int i = threadIdx.x; i < it.n_masked; i += CHI2_THREADS) {
+                double y = 0.0;
+                for (int s = 0; s < ns; ++s) y += it.q_y[((size_t)s * B + b) * it.n_masked_pad + i];       // fixed order
+                const double d = u0[i] - y;
+                acc = fma(d, d, acc);
+            }
+            continue;
+        }
         const double* g = it.q_lin + (size_t)row * it.nq_pad;
-        const int ns_all = slabs.z[q];
+        const int ns = slabs.z[q];
         for (int i = threadIdx.x; i < it.nq; i += CHI2_THREADS) {
             const double x = it.q_x[(size_t)b * it.nq_pad + i];
-            const int ns = ns_all > 0 ? ns_all : slabs.qseg[slabs.qseg_off[q] + (i >> 6)];     // (0: work-list launch)
             double zs[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) zs[s] = it.q_z[((size_t)(s < ns ? s : 0) * B + b) * it.nq_pad + i];
@@ -2047,34 +2064,19 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
     }
 }
 
-// chi2 from the contraction partials of the quadratic-form launches (GemmArgs::part): walker b of walker tile nt adds, list
-// by list and in block order, the two wave-row sums of every list block of its tile - block index (row * tn + nt) * 8 + xcd.
-// One wave per walker; padding blocks never wrote their (zero-initialised) slots.  (One list covers every item, or - items
-// on forked streams - one list per item.)
-// (nt_off[l] non-null: list l is a persistent launch - its slots are numbered per walker tile, [nt_off[nt], nt_off[nt + 1]))
-struct QuadParts { const double* part[VMX_MAX_GROUP]; int32_t rows[VMX_MAX_GROUP]; const int32_t* nt_off[VMX_MAX_GROUP]; int32_t n; };
-__global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, QuadParts Q, int tn)
+// chi2 from the contraction partials of the quadratic-form launch (GemmArgs::part): the slots of a persistent launch are
+// numbered per walker tile in tape order, [nt_off[nt], nt_off[nt + 1]); walker b of tile nt adds the two wave-row sums of
+// every slot of its tile in that order - an order that does not depend on which block computed what.  One wave per walker.
+__global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const double* part, const int32_t* nt_off)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const int nt = b >> 6, nl = b & 63;
     double acc = 0.0;
-    for (int l = 0; l < Q.n; ++l) {
-        const double* part = Q.part[l];
-        double sub = 0.0;
-        if (Q.nt_off[l]) {
-            const int s0 = Q.nt_off[l][nt], s1 = Q.nt_off[l][nt + 1];
-            for (int j = s0 + lane; j < s1; j += 64) {
-                const double* pp = part + ((size_t)j * 64 + nl) * 2;
-                sub += pp[0] + pp[1];
-            }
-        } else
-        for (int j = lane; j < Q.rows[l] * 8; j += 64) {
-            const size_t blk = ((size_t)(j >> 3) * tn + nt) * 8 + (j & 7);
-            const double* pp = part + (blk * 64 + nl) * 2;
-            sub += pp[0] + pp[1];
-        }
-        acc += sub;
+    const int s0 = nt_off[nt], s1 = nt_off[nt + 1];
+    for (int j = s0 + lane; j < s1; j += 64) {
+        const double* pp = part + ((size_t)j * 64 + nl) * 2;
+        acc += pp[0] + pp[1];
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane != 0) return;
@@ -2188,16 +2190,11 @@ struct GemmArgs {
 #define VMX_TAG_QUAD 12
 #define VMX_TAG_FFTLOG 2
 
-// Work list of a grouped launch (k_gemm_nt44): one entry per block - a K segment of one 64 x 64 tile of one problem,
-// written to slab `slab` of that problem's output.  A triangular product has row tiles of very different K lengths;
-// cutting every tile into segments of about equal length (host: quad_work_list) balances the launch where whole-problem
-// K splits cannot.  Blocks take entry blockIdx.x; the host orders the entries so that the segments of a row tile meet on
-// one XCD (block -> XCD is round-robin on the index).
-struct GemmWork { int32_t prob, mt, nt, kbeg, kend, slab, slot, pad; };
-// Persistent form of a list launch (GemmGroup::queue): block p walks the entries queue[p] .. queue[p + 1] - 1 one after the
-// other (the first stage of the next entry is requested behind the epilogue of the current one), and the contraction
-// partials of entry w go to slot work[w].slot - numbered per walker tile in a canonical order, so that the consumer
-// (k_chi2_parts) adds them in an order that does not depend on which block computed what.
+// The persistent form of a grouped launch (GemmGroup::work / queue; the quadratic-form tape - GemmWork and its planner live
+// in vmx_plan.h): block p walks the entries queue[p] .. queue[p + 1] - 1 one after the other (the first stage of the next
+// entry is requested behind the epilogue of the current one), and the contraction partials of entry w go to slot
+// work[w].slot - numbered per walker tile in a canonical order, so that the consumer (k_chi2_parts) adds them in an order
+// that does not depend on which block computed what.
 
 // LDS reads as explicit ds_read_b64 (2 LDS cycles per wave, banks (a/4) mod 64): left to the compiler, pairs of them
 // are merged into ds_read2_b64, which costs twice the cycles and banks modulo 32.  The compiler does not count these
@@ -2250,8 +2247,8 @@ __device__ __forceinline__ void lds_wait(double (&a)[8], double (&b)[8])
 // products): every tile of every problem is in flight at once, so the small problems fill the tail of the large one.
 struct GemmGroup {
     GemmArgs p[VMX_MAX_GROUP]; int32_t n; int32_t seq_end[VMX_MAX_GROUP];
-    const GemmWork* work;       // non-null: list mode (gridDim.x entries)
-    const int32_t* queue;       // non-null (with work): persistent blocks, entries [queue[blockIdx.x], queue[blockIdx.x + 1])
+    const GemmWork* work;       // non-null (with queue): the persistent tape of the quadratic form - block p walks the entries
+    const int32_t* queue;       //   work[queue[p]] .. work[queue[p + 1] - 1] one after the other
     unsigned long long* trace;  // debugging aid (VMX_GEMM_TRACE): per block {start, first stage landed, K loop done, end} in 100 MHz ticks
     int32_t batch_in_x;         // > 0 (the FFTLog product's windowed launch): a one-dimensional grid, block x = ((seq * batches + batch) << 3) | xcd
                                 // - the live blocks of EVERY batch member come first in launch order (with the batch on grid.y the live
@@ -2500,8 +2497,9 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     constexpr bool QUAD = TAG == VMX_TAG_QUAD && NT == 256 && NBUF == 2 && BN == 64;
     __shared__ double sL[QUAD ? 2 * BM : 1];
 
-    const bool list = G.work != nullptr;
-    const bool persist = QUAD && list && G.queue != nullptr;
+    // list mode = the persistent tape of the quadratic form (GemmGroup::work / queue): block p walks its queue's entries
+    const bool persist = QUAD && G.work != nullptr && G.queue != nullptr;
+    const bool list = persist;
     const unsigned long long t_start = G.trace ? wall_clock64() : 0ull;
     unsigned long long t_first = 0ull, t_loop = 0ull;
     GemmWork wk{};

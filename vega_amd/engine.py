@@ -140,6 +140,7 @@ def load_library():
     lib.vmx_item_set_marg_matrix.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32]
     lib.vmx_marg_coeff.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_quadratic_form.argtypes = [C.c_void_p, dptr]
+    lib.vmx_set_quadratic_form_kind.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_mu_quadrature.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_get_mu_nodes.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_set_mu_rule_box.argtypes = [C.c_void_p, C.c_int32, iptr, dptr, dptr]
@@ -176,7 +177,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -867,6 +868,18 @@ class Engine:
             return
         pk = _f64(np.atleast_2d(pk))
         self._check(self.lib.vmx_set_direct_pk(self._h, _dp(pk), pk.shape[0], pk.shape[1]))
+
+    QUADRATIC_FORM_KINDS = {'auto': 0, 'q': 1, 'factored': 2}
+
+    def set_quadratic_form_kind(self, kind='auto'):
+        """'auto' (the cheaper form per engine), 'q' (the half-form matrix Q', nq^2 flops per walker) or 'factored'
+        (|| U r0 - F dx ||^2, 2 n_masked nq flops: model grids much finer than the data grid) - include/vegamx.h:
+        vmx_set_quadratic_form_kind."""
+        self._check(self.lib.vmx_set_quadratic_form_kind(self._h, self.QUADRATIC_FORM_KINDS[kind]))
+
+    def last_form(self):
+        """Form the last evaluation took: 'full' (distortion + C^-1 products), 'q' or 'factored'."""
+        return ('full', 'q', 'factored')[int(self.debug_read(4, 0, 9)[8])]
 
     def set_quadratic_form(self, on=True):
         """Switch the quadratic form of chi2-only evaluations on (expansion point: the configured parameter values) or

@@ -35,6 +35,122 @@ def distortion_matrix(rp, rt, seed=SEED, dense_fraction=0.65):
     return dm
 
 
+def fine_model_grid(rp_min, rp_max, rt_max, n_p, n_t, coef, z_ref=2.3):
+    """Bin centres of a model grid `coef` times finer than the data grid (what a DESI distortion file's HDU 2 carries:
+    reference vega/data.py:463-468), rp-major like the reference's regular grids, with a slowly varying redshift."""
+    n_p, n_t = int(n_p) * int(coef), int(n_t) * int(coef)
+    dp, dt = (rp_max - rp_min) / n_p, rt_max / n_t
+    rp = np.repeat(rp_min + dp * (np.arange(n_p) + 0.5), n_t)
+    rt = np.tile(dt * (np.arange(n_t) + 0.5), n_p)
+    # (bin centres jittered like measured pair-weighted coordinates are: the grids of a real file are not the regular ones)
+    rng = np.random.default_rng(SEED + n_p * n_t)
+    rp = rp + 0.1 * dp * rng.uniform(-1, 1, rp.size)
+    rt = rt + 0.1 * dt * rng.uniform(-1, 1, rt.size)
+    z = z_ref + 4e-4 * (np.abs(rp) - 100.) - 2e-4 * (rt - 100.)
+    return rp, rt, z
+
+
+def distortion_matrix_rect(rp_data, rt_data, rp_model, rt_model, coef, seed=SEED, dense_fraction=0.65):
+    """Rectangular distortion matrix [n_data][n_model] for a model grid `coef` times finer than the data grid (the
+    `distortion-file` + COEFMOD case, reference vega/data.py:441-473): ``DM = A - W`` with A the average over the coef^2
+    model bins inside each data bin (both grids rp-major) and W as in :func:`distortion_matrix` between data-bin and
+    model-bin centres (rows of W sum to 0.3, 35 % of the far-off-band entries zeroed)."""
+    rp_d, rt_d = np.asarray(rp_data, dtype=float), np.asarray(rt_data, dtype=float)
+    rp_m, rt_m = np.asarray(rp_model, dtype=float), np.asarray(rt_model, dtype=float)
+    nd, nm = rp_d.size, rp_m.size
+    rng = np.random.default_rng(seed + nd + nm)
+    w_col = rng.uniform(0.5, 1.5, size=nm)
+    d_rt = rt_d[:, None] - rt_m[None, :]
+    W = np.exp(-d_rt**2 / (2 * 8.**2))
+    off_band = np.abs(d_rt) > 24
+    del d_rt
+    W /= 1 + np.abs(rp_d[:, None] - rp_m[None, :]) / 20.
+    W *= w_col[None, :]
+    W[off_band & (rng.random((nd, nm)) > dense_fraction)] = 0.
+    del off_band
+    W *= 0.3 / W.sum(axis=1, keepdims=True)
+    dm = -W
+    return dm
+
+
+def add_bin_average(dm, n_p, n_t, coef):
+    """dm[n_p n_t][coef n_p coef n_t] += the average of the coef^2 model bins inside each data bin."""
+    n_tm = n_t * coef
+    rows = np.arange(n_p * n_t)
+    ip, it = rows // n_t, rows % n_t
+    for a in range(coef):
+        for b in range(coef):
+            dm[rows, (coef * ip + a) * n_tm + coef * it + b] += 1. / coef**2
+    return dm
+
+
+def write_distortion_file(path, grid_header, coef, dm, rp, rt, z, blinding=None):
+    """A separate distortion-matrix file as the reference reads it (vega/data.py:441-473): HDU 1 = the vector column DM
+    [n_data rows][n_model] with RPMIN / RPMAX / RTMAX / NP / NT of the DATA grid and COEFMOD, HDU 2 = RP, RT, Z of the
+    model grid (NP COEFMOD x NT COEFMOD bins)."""
+    from . import fitslite
+    dm = np.asarray(dm, dtype=float)
+    hdr = {k: grid_header[k] for k in ('RPMIN', 'RPMAX', 'RTMAX', 'NP', 'NT')}
+    hdr['COEFMOD'] = int(coef)
+    if blinding is not None:
+        hdr['BLINDING'] = blinding
+    fitslite.write_tables(str(path), [
+        ('DMAT', [('DM', f'{dm.shape[1]}D', dm)], hdr),
+        ('ATTRI', [('RP', 'D', rp), ('RT', 'D', rt), ('Z', 'D', z)])], overwrite=True)
+    return path
+
+
+def write_covariance_file(path, cov):
+    """A separate `covariance-file`: HDU 1 with the vector column CO (reference vega/data.py:349-352)."""
+    from . import fitslite
+    cov = np.asarray(cov, dtype=float)
+    fitslite.write_tables(str(path), [('COV', [('CO', f'{cov.shape[1]}D', cov)])], overwrite=True)
+    return path
+
+
+def write_dmat_file_case(directory, source, coef=2):
+    """The three files of the `distortion-file` case for one correlation: returns (distortion path, covariance path) for
+    the data grid of ``source`` (a reference-format table list); the data vector stays in the item's own data file."""
+    from pathlib import Path
+    t1 = source[0]
+    h = t1.header
+    rp_d, rt_d = np.asarray(t1.data['RP'], dtype=float), np.asarray(t1.data['RT'], dtype=float)
+    rp, rt, z = fine_model_grid(h['RPMIN'], h['RPMAX'], h['RTMAX'], h['NP'], h['NT'], coef,
+                                z_ref=float(np.mean(t1.data['Z'])))
+    dm = add_bin_average(distortion_matrix_rect(rp_d, rt_d, rp, rt, coef), int(h['NP']), int(h['NT']), coef)
+    directory = Path(directory)
+    dmat = write_distortion_file(directory / f'dmat_coef{coef}_{rp_d.size}.fits', h, coef, dm, rp, rt, z)
+    cov = write_covariance_file(directory / f'cov_{rp_d.size}.fits', covariance(rp_d, rt_d))
+    return dmat, cov
+
+
+def dmat_file_configs(directory, golden, config='auto', coef=2, item_options=None):
+    """Configuration files of the `distortion-file` case: the golden config ``config`` (tests/golden/configs/<config>) with
+    every correlation pointed at its own distortion file (model grid ``coef`` times finer than its data grid) and covariance
+    file, written under ``directory`` by :func:`write_dmat_file_case`.  ``item_options``: text added to every [model]
+    section.  Returns the main file's path relative to ``directory`` (a search directory for build_problem)."""
+    import re
+    from pathlib import Path
+    from .tables import read_tables
+    directory, golden = Path(directory), Path(golden)
+    cfg = directory / 'configs' / f'dmatfile_{config}'
+    cfg.mkdir(parents=True, exist_ok=True)
+    main = (golden / 'configs' / config / 'main.ini').read_text()
+    items = re.search(r'ini files = (.*)', main).group(1).split()
+    names = [Path(i).name for i in items]
+    main = re.sub(r'ini files = .*', 'ini files = ' + ' '.join(f'configs/dmatfile_{config}/{n}' for n in names), main)
+    (cfg / 'main.ini').write_text(main)
+    for name in names:
+        text = (golden / 'configs' / config / name).read_text()
+        data_file = re.search(r'filename = (.*)', text).group(1).strip()
+        dmat, cov = write_dmat_file_case(directory, read_tables(golden / data_file), coef=coef)
+        text = text.replace('[data]', f'[data]\ndistortion-file = {dmat}\ncovariance-file = {cov}', 1)
+        if item_options:
+            text = text.replace('[model]', '[model]\n' + item_options)
+        (cfg / name).write_text(text)
+    return f'configs/dmatfile_{config}/main.ini'
+
+
 def covariance(rp, rt):
     """SPD covariance: variance ~ 1/r^2, Kronecker-exponential correlations in (rp, rt)."""
     rp = np.asarray(rp, dtype=float)
