@@ -240,6 +240,77 @@ def metals_throughput(device, batch=512, steps=10):
     return out
 
 
+def coefmod_throughput(device, batch=256, steps=10, coef=2):
+    """The joint fit with `distortion-file`s whose model grids are COEFMOD = 2 times finer than the data grids (what DESI
+    production files look like, reference vega/data.py:441-473): 10 000 and 20 000 model bins against 1590 and 3180 fitted
+    ones.  The quadratic form of chi2 in its two shapes - the half-form Q' (nq^2 flops per walker and item) and the factored
+    form || U r0 - F dx ||^2 (2 n_masked nq), which the engine picks by itself on such grids - and the full chain, same
+    walkers, resident in HBM."""
+    import tempfile
+    import torch
+    from vega_amd import VegaInterface, synthetic
+    from vega_amd.setup import build_problem as bp
+    dev = torch.device('cuda', device)
+    with tempfile.TemporaryDirectory() as tmp:
+        main = synthetic.dmat_file_configs(tmp, REPO / 'tests' / 'golden', config='joint', coef=coef)
+        prob = bp(main, search_dirs=[tmp, REPO / 'tests' / 'golden'])
+    vega = VegaInterface(None, problem=prob, max_batch=batch, device=device)
+    eng = vega.engine
+    eng.set_constant_nl_hint(True, gaussian=True)
+    pools = [torch.from_numpy(synthetic.walkers(eng.low.theta0, eng.names, batch, varied=VARIED, seed=synthetic.SEED + 31 + i)).to(dev)
+             for i in range(4)]
+    chi2 = [torch.zeros(batch, dtype=torch.float64, device=dev) for _ in range(4)]
+    nq = {n: int(it.model_grid.size) + sum(len(range(t.r1[0], t.r1[1] + 1, t.r1[2])) * len(range(t.r2[0], t.r2[1] + 1, t.r2[2]))
+                                           for t in it.broadband if t.pos == 'post' and t.kind == 'add') for n, it in prob.items.items()}
+    nm = {n: int(it.data_size) for n, it in prob.items.items()}
+    out = {'workload': f'joint fit with COEFMOD = {coef} distortion files: model grids {[int(it.model_grid.size) for it in prob.items.values()]}, '
+                       f'fitted bins {list(nm.values())}, B={batch} walkers/step',
+           'flops_per_walker': {'q': float(sum(v * v for v in nq.values())), 'factored': float(sum(2 * nm[n] * nq[n] for n in nq))}}
+
+    def rate(lanes, model=None):
+        eng.set_lanes(lanes)
+        for i in range(12):
+            eng.eval_device(pools[i % 4].data_ptr(), batch, chi2[i % 4].data_ptr(), *([model.data_ptr()] if model is not None else []))
+        eng.sync()
+        best = float('inf')
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                eng.eval_device(pools[i % 4].data_ptr(), batch, chi2[i % 4].data_ptr(), *([model.data_ptr()] if model is not None else []))
+            eng.sync()
+            best = min(best, time.perf_counter() - t0)
+        return batch * steps / best
+
+    results = {}
+    for kind in ('factored', 'q'):
+        eng.set_quadratic_form_kind(kind)
+        entry = {'evals_per_s': rate(2), 'one_batch_in_flight_evals_per_s': rate(1)}
+        assert eng.last_form() == kind
+        eng.set_profiling(True)
+        eng.timings(reset=True)
+        for i in range(4):
+            eng.eval_device(pools[i % 4].data_ptr(), batch, chi2[i % 4].data_ptr())
+        eng.sync()
+        tm = eng.timings(reset=True)
+        eng.set_profiling(False)
+        ms = tm['quadratic_form_product'][0] / tm['quadratic_form_product'][1]
+        tf = out['flops_per_walker'][kind] * batch / (ms * 1e-3) / 1e12
+        entry['product'] = {'ms_per_launch': ms, 'TFLOP/s': tf, 'frac_of_fp64_mfma_peak': tf / FP64_MFMA_PEAK_TF}
+        results[kind] = (entry, chi2[3].clone())
+        out[kind] = entry
+    eng.set_quadratic_form_kind('auto')
+    d_model = torch.zeros(batch, eng.model_size, dtype=torch.float64, device=dev)
+    out['full_chain'] = {'evals_per_s': rate(1, d_model)}
+    full = chi2[3].clone()
+    for kind in ('factored', 'q'):
+        out[kind]['max_rel_chi2_diff_vs_full_chain'] = float(((results[kind][1] - full).abs() / full.abs()).max())
+    eng.eval_device(pools[0].data_ptr(), batch, chi2[0].data_ptr())
+    eng.sync()
+    out['chosen_by_the_engine'] = eng.last_form()
+    vega.close()
+    return out
+
+
 def monte_carlo_fits(prob, device, n_mocks=1024):
     """One GPU's share of BASELINE configs[4] (8192 mocks over 8 GPUs): n_mocks Monte-Carlo realisations of the
     bench workload, each fitted over (ap, at, bias_eta_LYA, beta_LYA, beta_QSO, bias_hcd) by the batched minimiser,
@@ -889,6 +960,8 @@ def main():
         dist_csr = distortion_csr(local_rank) if extras else None
         mc_fits = monte_carlo_fits(prob, local_rank) if extras and args.workload == 'joint' else None
         metals = metals_throughput(local_rank) if extras and args.workload == 'joint' else None
+        if other_paths is not None and extras and args.workload == 'joint':
+            other_paths['coefmod2'] = coefmod_throughput(local_rank)
         if cpu is not None:
             got = vega.chi2_batch(host_theta[cpu_idx])
             cpu['max_rel_chi2_diff_vs_gpu'] = float(np.max(np.abs(got - np.array(cpu_vals)) / np.abs(cpu_vals)))
