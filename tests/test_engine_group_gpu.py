@@ -85,3 +85,33 @@ def test_two_voigt_tables():
         assert np.abs(model[name] - ref[name]).max() <= XI_RTOL * np.abs(ref[name]).max(), name
     assert vega.chi2(pars) == pytest.approx(oc.chi2(prob, pars), rel=CHI2_RTOL)
     vega.close()
+
+
+def test_group_with_metals_freezes_static_metals_and_serves_device_walkers():
+    """`freeze_static_metals` (reads the engine's metal plan) and `chi2_batch_device` in several chunks on a mixed-setting
+    problem WITH metals: one engine per setting behind the same surface, against the oracle and the unfrozen group."""
+    import torch
+    from oracle import vega_cpu as oc
+    from conftest import load_problem
+    import copy
+    from vega_amd import VegaInterface, synthetic
+    from vega_amd.engine_group import EngineGroup
+    prob = copy.deepcopy(load_problem('joint_metals'))
+    name = [n for n, it in prob.items.items() if it.tracer1.name != it.tracer2.name][0]
+    for pipe in [prob.items[name].core] + [m.pipeline for m in prob.items[name].metals]:
+        pipe.xi.fht_lowring = False
+    vega = VegaInterface(None, problem=prob, max_batch=8)
+    assert isinstance(vega.engine, EngineGroup) and vega.engine.metal_plan == {}
+    varied = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'bias_hcd', 'bias_eta_SiII(1190)', 'bias_eta_CIV(eff)']
+    theta = synthetic.walkers(vega.engine.low.theta0, vega.engine.names, 20, varied=varied, seed=12)
+    before = vega.chi2_batch(theta)
+    for i in (0, 19):
+        assert before[i] == pytest.approx(oc.chi2(prob, dict(zip(vega.engine.names, theta[i]))), rel=CHI2_RTOL)
+    vega.freeze_static_metals()
+    assert isinstance(vega.engine, EngineGroup)
+    assert any(kind == 'basis' for entries in vega.engine.metal_plan.values() for kind, _ in entries)
+    np.testing.assert_allclose(vega.chi2_batch(theta), before, rtol=1e-9)
+    # device walkers, three chunks of max_batch: the chunks reuse the group's buffers, ordered by events only
+    dev = vega.chi2_batch_device(torch.as_tensor(theta, device='cuda'))
+    np.testing.assert_allclose(dev.cpu().numpy(), before, rtol=1e-9)
+    vega.close()

@@ -86,6 +86,8 @@ class EngineGroup:
         except Exception:
             self.close()
             raise
+        # (fast_metals / static-basis plans are keyed by item name: every engine picks its own items' entries)
+        self.metal_plan = kwargs.get('metal_plan') or {}
         first = self.children[0]
         self.lib, self.low, self.names, self.n_params, self.max_batch = first.lib, first.low, first.names, first.n_params, first.max_batch
         assert all(c.names == self.names for c in self.children)
@@ -129,19 +131,33 @@ class EngineGroup:
 
     def eval_device_tensor(self, theta, out):
         """``theta`` CUDA float64 [B, n_params] -> ``out`` CUDA float64 [B]: every engine evaluates the walkers on its own
-        stream into its own buffer; the sum is formed on the caller's stream after the engines have drained."""
+        stream into its own buffer, ordered after the caller's stream by an event; the sum is formed on the caller's stream
+        behind one event per engine - no host synchronisation anywhere."""
         import torch
         B = theta.shape[0]
         if self._dev_bufs is None or self._dev_bufs.shape[1] < B:
             self._dev_bufs = torch.empty((len(self.children), max(B, self.max_batch)), dtype=torch.float64, device=theta.device)
-        torch.cuda.current_stream(theta.device).synchronize()
+        mine = torch.cuda.current_stream(theta.device)
+        ready = mine.record_event()                 # theta (and the previous reader of the buffers) are done by then
+        done = []
         for ci, c in enumerate(self.children):
+            stream = self._stream_of(c.stream_handle(), theta.device)
+            stream.wait_event(ready)
             c.eval_device(theta.data_ptr(), B, self._dev_bufs[ci].data_ptr())
-        for c in self.children:
-            c.sync()
+            done.append(self._stream_of(c.last_stream_handle(), theta.device).record_event())
+        for ev in done:
+            mine.wait_event(ev)
         parts = self._dev_bufs[:, :B]
         total = parts.sum(dim=0)
         out.copy_(torch.where(parts.max(dim=0).values >= SENTINEL, torch.full_like(total, SENTINEL), total))
+
+    def _stream_of(self, handle, device):
+        import torch
+        if not hasattr(self, '_ext_streams'):
+            self._ext_streams = {}
+        if handle not in self._ext_streams:
+            self._ext_streams[handle] = torch.cuda.ExternalStream(handle, device=device)
+        return self._ext_streams[handle]
 
     def eval_device(self, *args, **kwargs):
         raise NotImplementedError('an engine group evaluates device walkers through eval_device_tensor')
