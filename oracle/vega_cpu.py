@@ -782,10 +782,12 @@ def compute_marg_coeff(prob, model, data_override=None):
     return out
 
 
-def chi2(prob, params=None, data_override=None, direct_pk=None, return_marg_coeff=False):
+def chi2(prob, params=None, data_override=None, direct_pk=None, return_marg_coeff=False, cov_scale=None):
     """VegaInterface.chi2 (reference vega_interface.py:250-325); 1e100 on a model error.  ``return_marg_coeff``:
     the tuple (chi2, coefficients) of :281-286, :321-322 ((1e100, None) on a model error: the oracle keeps no
-    ``_random_marg_coeff`` history)."""
+    ``_random_marg_coeff`` history).  ``cov_scale`` (with ``data_override``: the Monte-Carlo branch, :311-313): a number or
+    {item: number} - chi2 then uses scaled_inv_masked_cov = C^-1 / scale (data.py:711-722); the marginalisation coefficients
+    keep the map built from the unscaled covariance, as the reference's do."""
     try:
         model = compute_model(prob, params, direct_pk=direct_pk)
     except OracleModelError:
@@ -808,7 +810,8 @@ def chi2(prob, params=None, data_override=None, direct_pk=None, return_marg_coef
         for name, item in prob.items.items():
             data = item.masked_data_vec if data_override is None else data_override[name]
             diff = data - model[name][item.model_mask]
-            total += diff.T.dot(item.inv_masked_cov.dot(diff))
+            scale = 1.0 if cov_scale is None else cov_scale[name] if isinstance(cov_scale, dict) else cov_scale
+            total += diff.T.dot((item.inv_masked_cov / scale).dot(diff))
     total += prior_chi2(prob, params)
     if return_marg_coeff:
         return float(total), coeffs

@@ -677,6 +677,45 @@ def dump_dmat_file(VegaInterface):
     np.savez_compressed(HERE / 'expected_dmat_file.npz', **out)
 
 
+def dump_marg_mc(VegaInterface):
+    """`marginalize-in-fit` together with a rescaled covariance in Monte Carlo (reference vega/vega_interface.py:282-292,
+    :311-313; vega/data.py:711-722): the template coefficients come from the residual against the MOCK through the map built
+    with the unscaled covariance, chi2 uses scaled_inv_masked_cov = C^-1 / scale.  One mock of scale 4 on the data file of
+    dump_marginalization; chi2 at the fiducial point and one walker, with the coefficients."""
+    from vega_amd.tables import read_tables
+    os.chdir(REF / 'tests')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        source = read_tables(REF / 'tests/data/cf_lya-exp.fits.gz')
+        data_path = synthetic.write_data_file(Path(tmp) / 'cf_lya-synth.fits', source)
+        main = _ref_main(tmp, ['lyalya_lyalya'], False)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        text = re.sub(r'filename = .*', f'filename = {data_path}', item.read_text(), count=1)
+        item.write_text(text.replace('[model]', '[model]\nmarginalize-below-rtmax = 16.0\nmarginalize-prior-sigma = 5.0'))
+        mp = Path(main)
+        mp.write_text(mp.read_text().replace('[control]', '[control]\nmarginalize-in-fit = True'))
+        vega = VegaInterface(main)
+        assert vega.marginalize_in_fit
+        fid = vega.compute_model(run_init=False)
+        np.random.seed(23)
+        vega.monte_carlo = True
+        vega.analysis.create_monte_carlo_sim(fid, seed=None, scale=4.0)
+        data = vega.data['lyalya_lyalya']
+        out['scale'] = 4.0
+        out['mock'] = data.masked_mc_mock.copy()
+        np.testing.assert_allclose(data.scaled_inv_masked_cov, data.inv_masked_cov / 4.0)
+        _reset_caches(vega)
+        chi2, coeff = vega.chi2(return_marg_coeff=True)
+        out['fid/chi2'], out['fid/coeff'] = chi2, coeff['lyalya_lyalya']
+        names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 17)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[walkers[0][n] for n in names]])
+        _reset_caches(vega)
+        out['walker0/chi2'] = vega.chi2(walkers[0])
+        print('marg + rescaled MC: chi2', out['fid/chi2'], out['walker0/chi2'], 'data size', data.data_size)
+    np.savez_compressed(HERE / 'expected_marg_mc.npz', **out)
+
+
 def direct_pk_vector(k, pk_full):
     """A stand-in for a Boltzmann-code spectrum: the fiducial one tilted and rescaled."""
     return 1.07 * pk_full * (k / 0.1)**0.03
@@ -1054,12 +1093,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1104,3 +1143,5 @@ if __name__ == '__main__':
         dump_fits(VI)
     if 'dmat_file' in what:
         dump_dmat_file(VI)
+    if 'marg_mc' in what:
+        dump_marg_mc(VI)

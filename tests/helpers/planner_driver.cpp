@@ -43,6 +43,20 @@ static void tape_cases()
                 const bool same = a.work.size() == b.work.size() && a.queue == b.queue && a.nt_off == b.nt_off &&
                                   (a.work.empty() || std::memcmp(a.work.data(), b.work.data(), a.work.size() * sizeof(GemmWork)) == 0);
                 expect(same, "identical inputs give identical tapes");
+                // K bands per XCD: the same pieces on other blocks - every invariant holds, and entry for entry the same
+                // (problem, tile, K range) -> slot map, i.e. the same sums bit for bit
+                {
+                    const Tape k = plan_quad_tape(probs, tn, blocks, 4.0, 0.12, 64, 32, true);
+                    const std::string whyk = check_quad_tape(k, probs, tn, 4.0, 0.12);
+                    std::snprintf(label, sizeof label, "banded tape nq0=%d items=%zu B=%d blocks=%d: %s", sh[0], sh.size(), B, blocks, whyk.c_str());
+                    expect(whyk.empty(), label);
+                    auto key = [](const GemmWork& w) { return std::vector<int32_t>{w.prob, w.mt, w.nt, w.kbeg, w.kend, w.slot}; };
+                    std::vector<std::vector<int32_t>> ka, kk;
+                    for (auto& w : a.work) ka.push_back(key(w));
+                    for (auto& w : k.work) kk.push_back(key(w));
+                    std::sort(ka.begin(), ka.end()); std::sort(kk.begin(), kk.end());
+                    expect(ka == kk && a.nt_off == k.nt_off, "the banded tape carries the same entries with the same slots");
+                }
                 // the plan depends on B through the number of walker tiles only
                 if (B % 64) {
                     const Tape c = plan_quad_tape(probs, tn, blocks, 4.0, 0.12);

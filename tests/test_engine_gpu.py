@@ -521,3 +521,33 @@ def test_level2_tables_on_four_correlations_with_metals():
     for i in (0, 77, 130):
         assert big[i] == pytest.approx(oc.chi2(vega.problem, dict(zip(eng.names, theta[i]))), rel=CHI2_RTOL)
     vega.close()
+
+
+def test_rescaled_covariance_with_marginalize_in_fit_through_the_engine(tmp_path):
+    """`marginalize-in-fit` + a Monte-Carlo covariance scale (reference vega/vega_interface.py:282-292, :311-313): through the
+    reference's own switches (`monte_carlo`, `data[name].masked_mc_mock`, `scaled_inv_masked_cov`) and through the Monte-Carlo
+    driver's mock pool, against what the unmodified reference computed (tests/golden/make_golden.py::dump_marg_mc)."""
+    from conftest import marginalization_problem, MARGINALIZATION_CASES
+    from vega_amd import VegaInterface
+    exp = np.load(GOLDEN / 'expected_marg_mc.npz')
+    prob = marginalization_problem(tmp_path, MARGINALIZATION_CASES['rtmax'], in_fit=True)
+    vega = VegaInterface(None, problem=prob, max_batch=4)
+    plain = vega.chi2()
+    view = vega.data['lyalya_lyalya']
+    view.masked_mc_mock = exp['mock']
+    view.scaled_inv_masked_cov = view.inv_masked_cov / float(exp['scale'])
+    vega.monte_carlo = True
+    chi2, coeff = vega.chi2(return_marg_coeff=True)
+    assert chi2 == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    scale = np.abs(exp['fid/coeff']).max()
+    np.testing.assert_allclose(coeff['lyalya_lyalya'], exp['fid/coeff'], rtol=0, atol=5e-6 * scale)
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert vega.chi2(pars) == pytest.approx(float(exp['walker0/chi2']), rel=CHI2_RTOL)
+    vega.monte_carlo = False
+    assert vega.chi2() == pytest.approx(plain, rel=1e-12)          # back on the data and the unscaled covariance
+    # the Monte-Carlo driver: a pool of mocks with the scale applied to the engine's matrix
+    res = vega.run_monte_carlo(num_mocks=3, seed=5, scale=4.0, sample_params={
+        'limits': {'ap': (0.5, 1.5), 'at': (0.5, 1.5)}, 'values': {n: vega.params[n] for n in ('ap', 'at')},
+        'errors': {'ap': 0.01, 'at': 0.01}, 'fix': {'ap': False, 'at': False}})
+    assert res.is_valid.all() and np.all(res.fval < 3 * 1590)
+    vega.close()

@@ -4,8 +4,12 @@
 
 `expected_fits.npz` was written by the UNMODIFIED reference walking those drivers with the MIGRAD restatement of
 vega_amd/migrad.py behind the iminuit surface (tools/refshim/iminuit): it pins everything around the minimiser - grids,
-pinned parameters, start values, seeding of the mocks, what is kept.  MIGRAD's own arithmetic is pinned by the reference's
-golden fit value (tests/test_vega.py:18), below.
+pinned parameters, start values, seeding of the mocks, what is kept.  The expected fit values in it are therefore
+SELF-GENERATED as far as the minimiser goes: an error inside vega_amd/migrad.py would be on both sides of these comparisons.
+MIGRAD's own arithmetic is anchored elsewhere - by the reference's golden fit value (tests/test_vega.py:18), below, and by
+outcomes known independently of this repository (analytic minima, MINUIT's error definition, EDM criterion, limits, the
+`iterate` loop: tests/test_migrad_analytic.py, CPU), with `method='bfgs'` + SciPy on the oracle as a second witness
+(tests/test_minimizer_gpu.py).
 """
 from math import isclose
 

@@ -167,6 +167,44 @@ def test_rule_on_and_off_over_the_guard_box_on_the_gpu_and_the_fallback_outside_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['joint', 'joint_metals'])
+def test_a_walker_s_mu_rule_does_not_depend_on_its_neighbours(tag):
+    """The rule's applicability guard is the WALKER's (include/vegamx.h: vmx_set_mu_rule_box; vega_amd/parallel.py: chi2 does
+    not depend on how the walkers are sharded): in the two-walkers-per-thread kernels (level-2 tables: k_pk_tab2; the
+    shared-W groups of the metals: k_pk_w) a block whose walkers disagree runs both ways.  In-box walkers interleaved with
+    out-of-box ones return, bit for bit, what they return among in-box walkers only - and the out-of-box ones what the plain
+    loop gives them."""
+    import torch
+    from vega_amd import VegaInterface, synthetic
+    vega = VegaInterface(None, problem=load_problem(tag), max_batch=128)
+    eng = vega.engine
+    varied = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'bias_hcd', 'beta_hcd', 'L0_hcd']
+    inside = synthetic.walkers(eng.low.theta0, eng.names, 128, varied=varied, seed=77)
+    mixed = inside.copy()
+    stray = np.arange(128) % 2 == 1                     # every second walker: each block of the paired kernels is mixed
+    stray[64:] = False                                  # ... in the first half of the batch; the second half is untouched
+    mixed[stray, eng.low.slot['L0_hcd']] = 55.0         # beyond the validated 40 Mpc/h
+    eng.set_constant_nl_hint(True, gaussian=True)       # (shared Arinyo / smoothing parameters: the level-2 table kernels)
+
+    def device_chi2(theta):
+        out = torch.zeros(theta.shape[0], dtype=torch.float64, device='cuda')
+        eng.eval_device(torch.from_numpy(theta).cuda().data_ptr(), theta.shape[0], out.data_ptr())
+        eng.sync()
+        return out.cpu().numpy()
+    alone = device_chi2(inside)
+    assert int(eng.debug_read(4, 0, 5)[4]) == 2
+    both = device_chi2(mixed)
+    np.testing.assert_array_equal(both[~stray], alone[~stray])
+    eng.set_mu_quadrature(False)
+    loop = device_chi2(mixed)
+    eng.set_mu_quadrature(True)
+    # (switching the rule off re-evaluates the quadratic form's expansion point: the last bit of chi2 may move)
+    np.testing.assert_allclose(both[stray], loop[stray], rtol=1e-13)
+    assert np.all(both[stray] != alone[stray])
+    vega.close()
+
+
+@pytest.mark.gpu
 def test_engine_nodes_and_the_rule_against_the_plain_loop():
     from vega_amd import VegaInterface, synthetic
     from vega_amd.mu_quadrature import extra_nodes

@@ -215,3 +215,18 @@ def test_oracle_on_the_xi_stage_options_of_round_2(tmp_path):
     _assert_xi_elementwise(oc.compute_model(prob)['lyalya_lyalya'], exp['auto/fid/model'],
                            prob.items['lyalya_lyalya'].model_mask, 'auto fid')
     assert oc.chi2(prob, {'ap': 1.03, 'at': 0.96, 'uv_shotnoise_amp': 0.03}) == pytest.approx(float(exp['auto/walker/chi2']), rel=1e-9)
+
+
+def test_oracle_rescaled_covariance_with_marginalize_in_fit(tmp_path):
+    """`marginalize-in-fit` + a Monte-Carlo covariance scale (reference vega/vega_interface.py:282-292, :311-313): the oracle
+    against what the unmodified reference computed for the mock of tests/golden/make_golden.py::dump_marg_mc."""
+    from oracle import vega_cpu as oc
+    exp = np.load(GOLDEN / 'expected_marg_mc.npz')
+    prob = marginalization_problem(tmp_path, MARGINALIZATION_CASES['rtmax'], in_fit=True)
+    mock = {'lyalya_lyalya': exp['mock']}
+    chi2, coeff = oc.chi2(prob, data_override=mock, cov_scale=float(exp['scale']), return_marg_coeff=True)
+    assert chi2 == pytest.approx(float(exp['fid/chi2']), rel=1e-9)
+    scale = np.abs(exp['fid/coeff']).max()
+    np.testing.assert_allclose(coeff['lyalya_lyalya'], exp['fid/coeff'], rtol=0, atol=5e-6 * scale)
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    assert oc.chi2(prob, pars, data_override=mock, cov_scale=float(exp['scale'])) == pytest.approx(float(exp['walker0/chi2']), rel=1e-9)

@@ -1708,7 +1708,8 @@ static vmx_engine::QuadList* quad_build_tape(vmx_engine* e, int B)
     const int tn = (B + GEMM_BN - 1) / GEMM_BN;
     std::vector<vmx_plan::TapeProblem> probs;
     for (auto* it : e->items) probs.push_back({it->dev.nq, it->dev.nq_pad});
-    vmx_plan::Tape T = vmx_plan::plan_quad_tape(probs, tn, e->quad_blocks, QUAD_ENTRY_STAGES, QUAD_SKEW, GEMM_BM, GEMM_BK);
+    const bool k_bands = getenv("VMX_QUAD_KBANDS") ? atoi(getenv("VMX_QUAD_KBANDS")) != 0 : false;
+    vmx_plan::Tape T = vmx_plan::plan_quad_tape(probs, tn, e->quad_blocks, QUAD_ENTRY_STAGES, QUAD_SKEW, GEMM_BM, GEMM_BK, k_bands);
     auto* ql = new vmx_engine::QuadList();
     ql->n_blocks = T.n_blocks;
     ql->n_entries = (int)T.n_slots;

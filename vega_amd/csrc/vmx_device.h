@@ -1337,7 +1337,12 @@ struct Tab2Group { int32_t pipe, partner, xtab, cross, kind_s, kind_q, col_s, co
 #define VMX_TAB2_GROUPS 8
 struct Tab2Args { Tab2Group g[VMX_TAB2_GROUPS]; };
 
-template <int KT, int MS, int NW, bool CROSS>
+// MODE: whose choice the mu rule is.  0: every walker of the block agrees (the common case: this instantiation is the
+// kernel's hot path) - the rule when all lie in its box, the reference's loop when none does.  A block whose walkers DISAGREE
+// (a sampler's stray point next to an ordinary one) runs the body twice: MODE 1 = the rule, stored for the walkers inside
+// only; MODE 2 = the loop, stored for those outside - so that a walker's arithmetic never depends on its neighbours in the
+// batch: bitwise the same alone, paired, or on another rank (vega_amd/parallel.py).
+template <int KT, int MS, int NW, bool CROSS, int MODE = 0>
 __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group& G, int B)
 {
     extern __shared__ double smem[];
@@ -1399,8 +1404,13 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
         fk[w] = -sc[S_HCD_L0] * k;
         Fq[w] = vmx_exp(fk[w] * dmu);
         k2vd2[w] = k2 * sc[S_VD2];
-        in_box = in_box && sc[S_NO_RULE] == 0.0;
+        const bool inside = sc[S_NO_RULE] == 0.0;
+        in_box = in_box && inside;
+        if (MODE == 1) ok[w] = ok[w] && inside;         // (a surplus slot shadows the last walker: stores nothing either way)
+        if (MODE == 2) ok[w] = ok[w] && !inside;
     }
+    if (MODE == 1) in_box = true;
+    if (MODE == 2) in_box = false;
     if (threadIdx.x == 0) atomicMax(D.k_live, min((tile + 1) * KT, D.nk));
     // the node rule (first mu_lo and last mu_hi midpoints plus the extra nodes) serves a tile whose wavenumbers are all
     // within its range or negligible (VMX_PK_NEGLIGIBLE) - and whose walkers lie in the box the rule is validated on
@@ -1555,6 +1565,16 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
     }
 }
 
+// the two passes of a block whose walkers disagree on the rule (inlined: as a function of its own it would bring a stack,
+// i.e. scratch memory, to every launch of the kernel)
+template <int KT, int MS, int NW>
+__device__ __forceinline__ void pk_tab2_mixed(const EngineDev& D, const Tab2Group& G, int B)
+{
+    if (G.cross) pk_tab2_body<KT, MS, NW, true, 1>(D, G, B); else pk_tab2_body<KT, MS, NW, false, 1>(D, G, B);
+    __syncthreads();        // (the reduction scratch of the first pass shares its LDS with the second pass's node tables)
+    if (G.cross) pk_tab2_body<KT, MS, NW, true, 2>(D, G, B); else pk_tab2_body<KT, MS, NW, false, 2>(D, G, B);
+}
+
 // waves per SIMD the register allocation aims at (measured: three or four waves of the two-walker shape run the same)
 #ifndef VMX_TAB2_BLOCKS
 #define VMX_TAB2_BLOCKS 4
@@ -1564,6 +1584,16 @@ template <int KT, int MS, int NW>
 __global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : NW == 1 ? VMX_TAB2_BLOCKS : VMX_TAB2_W2) void k_pk_tab2(EngineDev D, Tab2Args A, int B)
 {
     const Tab2Group& G = A.g[blockIdx.y];
+    if constexpr (NW > 1) {
+        // do the walkers of this block agree on the mu rule? (block-uniform: the flags are the prologue's, per walker)
+        bool any_in = false, all_in = true;
+        for (int w = 0; w < NW; ++w) {
+            const int b = min((int)blockIdx.x * NW + w, B - 1);
+            const bool inside = D.scal[((size_t)b * D.n_pipe + G.pipe) * VMX_NS + S_NO_RULE] == 0.0;
+            any_in = any_in || inside; all_in = all_in && inside;
+        }
+        if (any_in && !all_in) { pk_tab2_mixed<KT, MS, NW>(D, G, B); return; }
+    }
     if (G.cross) pk_tab2_body<KT, MS, NW, true>(D, G, B);
     else pk_tab2_body<KT, MS, NW, false>(D, G, B);
 }
@@ -1573,8 +1603,9 @@ __global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : NW == 1 ? VMX_TAB2_BLOCKS :
 // and wavenumber, NW walkers per thread (one entry of the static G table and one (mu^2, mu^4) pair serve all of them), then
 // every member's multipoles (w_members_store).  Block = 64 wavenumbers x 4 mu slices; grid = (ceil(B / NW), groups of the
 // list, k tiles); LDS as k_pk_tab2 (node tables, reused as the [NW][6][256] reduction scratch).
-template <int NW>
-__global__ __launch_bounds__(256, 4) void k_pk_w(EngineDev D, const PkGroup* groups, const int32_t* members, const int32_t* wlist, int B)
+// (MODE: as in pk_tab2_body - 0 the walkers of the block agree on the mu rule, 1 / 2 the two passes of a block whose walkers do not)
+template <int NW, int MODE>
+__device__ __forceinline__ void pk_w_body(const EngineDev& D, const PkGroup* groups, const int32_t* members, const int32_t* wlist, int B)
 {
     extern __shared__ double smem[];
     constexpr int KT = 64, MS = 4;
@@ -1594,12 +1625,13 @@ __global__ __launch_bounds__(256, 4) void k_pk_w(EngineDev D, const PkGroup* gro
     const double inv_nmu = 1.0 / (double)n_mu;
     const double k = D.k[ic], k2 = k * k;
     double e0[NW], e1[NW], k2vd1[NW], k2vd2[NW];
-    bool noexp[NW];
+    bool noexp[NW], keep[NW];
     double e_max = -1e300;
     bool in_box = true;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         int b = blockIdx.x * NW + w;
+        keep[w] = b < B;
         if (b >= B) b = B - 1;                        // a surplus walker slot shadows the last walker and stores nothing
         const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
         const double ga = sc[S_GA], gb = sc[S_GB];
@@ -1607,8 +1639,13 @@ __global__ __launch_bounds__(256, 4) void k_pk_w(EngineDev D, const PkGroup* gro
         noexp[w] = (ga == 0.0) && (gb == 0.0);
         k2vd1[w] = k2 * sc[S_VD1]; k2vd2[w] = k2 * sc[S_VD2];
         e_max = fmax(e_max, e0[w] + fmax(e1[w], 0.0));
-        in_box = in_box && sc[S_NO_RULE] == 0.0;
+        const bool inside = sc[S_NO_RULE] == 0.0;
+        in_box = in_box && inside;
+        if (MODE == 1) keep[w] = keep[w] && inside;
+        if (MODE == 2) keep[w] = keep[w] && !inside;
     }
+    if (MODE == 1) in_box = true;
+    if (MODE == 2) in_box = false;
     const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;
     if (live_block && threadIdx.x == 0) atomicMax(D.k_live, min((tile + 1) * KT, D.nk));
     const bool node_mode = D.n_extra > 0 && in_box && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
@@ -1713,7 +1750,7 @@ __global__ __launch_bounds__(256, 4) void k_pk_w(EngineDev D, const PkGroup* gro
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         const int b = blockIdx.x * NW + w;
-        if (b >= B) continue;
+        if (!keep[w]) continue;
         double tot[6];
         for (int n = 0; n < 6; ++n) {
             double sum = 0.0;
@@ -1722,6 +1759,33 @@ __global__ __launch_bounds__(256, 4) void k_pk_w(EngineDev D, const PkGroup* gro
         }
         w_members_store(D, G, members, b, B, i, k, tot);
     }
+}
+
+template <int NW>
+__device__ __forceinline__ void pk_w_mixed(const EngineDev& D, const PkGroup* groups, const int32_t* members, const int32_t* wlist, int B)
+{
+    pk_w_body<NW, 1>(D, groups, members, wlist, B);
+    __syncthreads();
+    pk_w_body<NW, 2>(D, groups, members, wlist, B);
+}
+
+template <int NW>
+#ifndef VMX_PKW_OCC
+#define VMX_PKW_OCC 4
+#endif
+__global__ __launch_bounds__(256, VMX_PKW_OCC) void k_pk_w(EngineDev D, const PkGroup* groups, const int32_t* members, const int32_t* wlist, int B)
+{
+    if constexpr (NW > 1) {
+        const int p = groups[wlist[blockIdx.y]].pipe;
+        bool any_in = false, all_in = true;
+        for (int w = 0; w < NW; ++w) {
+            const int b = min((int)blockIdx.x * NW + w, B - 1);
+            const bool inside = D.scal[((size_t)b * D.n_pipe + p) * VMX_NS + S_NO_RULE] == 0.0;
+            any_in = any_in || inside; all_in = all_in && inside;
+        }
+        if (any_in && !all_in) { pk_w_mixed<NW>(D, groups, members, wlist, B); return; }
+    }
+    pk_w_body<NW, 0>(D, groups, members, wlist, B);
 }
 
 // Pipelines whose only mu dependence is the Kaiser polynomial times the static G table (metal pairs without

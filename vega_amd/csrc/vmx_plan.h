@@ -25,6 +25,7 @@ struct Tape {
     std::vector<GemmWork> work;     // every block's entries, block after block
     std::vector<int32_t> queue;     // [n_blocks + 1]: block p walks work[queue[p]] .. work[queue[p + 1] - 1]
     std::vector<int32_t> nt_off;    // [tn + 1]: slots of walker tile nt are [nt_off[nt], nt_off[nt + 1])
+    std::vector<int32_t> piece_at;  // [n_pieces]: the piece (in tape order) that position xcd * per_xcd + j of the block grid takes
     int n_blocks = 0, group_size = 1, n_pieces = 0;
     int64_t n_slots = 0;
     double capacity = 0.0;          // cost bound of a piece (K stages + entry charges) the bisection ended on
@@ -37,8 +38,13 @@ struct Tape {
 // the launch has (ranges + blocks - 1) entries at most, every block the same work to a stage, and no last round.
 // The cut is a pure function of (problem shapes, walker tiles, blocks): partial sums are grouped identically on every rank
 // and in every run.  Slots are numbered per walker tile in tape order; k_chi2_parts adds them in that order.
+// `k_bands`: which pieces an XCD takes.  false: runs of consecutive pieces (the same or adjacent row tiles: their K segments
+// tile the rows, so an XCD's blocks read every column of the walker operand at once and it streams through the 4 MB L2).
+// true: the pieces are dealt to the XCDs by where they sit in K - the blocks of an XCD then sweep the same band of the walker
+// operand at the same time and find it in their L2.  The pieces themselves, their cost and the slot numbering are the same
+// either way: which block computes an entry changes, the sums do not (bit for bit).
 inline Tape plan_quad_tape(const std::vector<TapeProblem>& probs, int tn, int blocks, double entry_stages, double skew,
-                           int bm = 64, int bk = 32)
+                           int bm = 64, int bk = 32, bool k_bands = false)
 {
     Tape T;
     const int P = std::max(blocks / 8 * 8, 8);
@@ -122,14 +128,36 @@ inline Tape plan_quad_tape(const std::vector<TapeProblem>& probs, int tn, int bl
     std::vector<int32_t> queue(P + 1, 0);
     std::vector<std::vector<GemmWork>> by_piece(n_pieces);
     for (auto& en : entries) by_piece[en.piece].push_back(en.w);
+    // which piece a grid position takes.  A position's weight (the first half of an XCD's positions belongs to the blocks
+    // dispatched first and carries 1 + skew) must be its piece's: the heavy and the light pieces are dealt separately.
+    std::vector<int32_t> piece_at(n_pieces);
+    for (int pc = 0; pc < n_pieces; ++pc) piece_at[pc] = pc;
+    if (k_bands && n_pieces >= 16) {
+        // a piece's place in K: the stage-weighted mean of its entries' K midpoints
+        std::vector<double> where(n_pieces, 0.0);
+        for (int pc = 0; pc < n_pieces; ++pc) {
+            double wsum = 0.0, ksum = 0.0;
+            for (auto& w : by_piece[pc]) { const double len = w.kend - w.kbeg; wsum += len; ksum += len * 0.5 * (w.kbeg + w.kend); }
+            where[pc] = wsum > 0.0 ? ksum / wsum : 1e300;          // (empty pieces last)
+        }
+        const int half = per_xcd_pieces / 2;
+        std::vector<int32_t> heavy, light;
+        for (int pc = 0; pc < n_pieces; ++pc) ((pc % per_xcd_pieces) < half ? heavy : light).push_back(pc);
+        auto by_k = [&](int32_t a, int32_t b) { return where[a] < where[b]; };
+        std::stable_sort(heavy.begin(), heavy.end(), by_k);
+        std::stable_sort(light.begin(), light.end(), by_k);
+        for (int x = 0; x < 8; ++x)
+            for (int j = 0; j < per_xcd_pieces; ++j)
+                piece_at[x * per_xcd_pieces + j] = j < half ? heavy[(size_t)x * half + j] : light[(size_t)x * (per_xcd_pieces - half) + (j - half)];
+    }
     T.work.reserve(entries.size() * gs);
     for (int p = 0; p < P; ++p) {
         const int xcd = p % 8, i = p / 8, per_xcd = P / 8 / gs;
         const int member = i % gs;
-        const int pcs = xcd * per_xcd + i / gs;
+        const int pos = xcd * per_xcd + i / gs;
         queue[p] = (int32_t)T.work.size();
-        if (pcs < n_pieces && i / gs < per_xcd)
-            for (auto w : by_piece[pcs]) {
+        if (pos < n_pieces && i / gs < per_xcd)
+            for (auto w : by_piece[piece_at[pos]]) {
                 w.nt += member;
                 w.slot += nt_off[w.nt];
                 T.work.push_back(w);
@@ -140,6 +168,7 @@ inline Tape plan_quad_tape(const std::vector<TapeProblem>& probs, int tn, int bl
     T.n_slots = nt_off[tn];
     T.nt_off = std::move(nt_off);
     T.n_blocks = P; T.group_size = gs; T.n_pieces = n_pieces;
+    T.piece_at = std::move(piece_at);
     return T;
 }
 
@@ -197,7 +226,10 @@ inline std::string check_quad_tape(const Tape& T, const std::vector<TapeProblem>
     // (iii) balance and (iv) lock-step
     const int gs = T.group_size, per_xcd = T.n_blocks / 8 / gs, per_xcd_pieces = std::max(T.n_pieces / 8, 1);
     for (int p = 0; p < T.n_blocks; ++p) {
-        const int xcd = p % 8, i = p / 8, pcs = xcd * per_xcd + i / gs;
+        const int xcd = p % 8, i = p / 8, pos = xcd * per_xcd + i / gs;
+        if (i / gs >= per_xcd) { if (T.queue[p + 1] != T.queue[p]) return "a surplus block has work"; continue; }
+        const int pcs = T.piece_at[pos];
+        if ((pcs % per_xcd_pieces < per_xcd_pieces / 2) != (pos % per_xcd_pieces < per_xcd_pieces / 2)) return "a piece sits on a position of the other weight class";
         double cost = 0.0;
         for (int j = T.queue[p]; j < T.queue[p + 1]; ++j) cost += (T.work[j].kend - T.work[j].kbeg) / bk + entry_stages;
         const double w = (pcs % per_xcd_pieces) < per_xcd_pieces / 2 ? 1.0 + skew : 1.0 - skew;
@@ -208,7 +240,8 @@ inline std::string check_quad_tape(const Tape& T, const std::vector<TapeProblem>
             // (only the last non-empty piece may be short)
             bool later = false;
             for (int p2 = 0; p2 < T.n_blocks && !later; ++p2) {
-                const int pcs2 = (p2 % 8) * per_xcd + (p2 / 8) / gs;
+                if ((p2 / 8) / gs >= per_xcd) continue;
+                const int pcs2 = T.piece_at[(p2 % 8) * per_xcd + (p2 / 8) / gs];
                 if (pcs2 > pcs && T.queue[p2 + 1] > T.queue[p2]) later = true;
             }
             if (later) return "a piece before the last is short";

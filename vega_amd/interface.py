@@ -235,9 +235,14 @@ class VegaInterface:
                     raise ValueError(f'monte_carlo is set but data[{name!r}].masked_mc_mock is None')
                 self.engine.set_data(name, view.masked_mc_mock)
                 if view.scaled_inv_masked_cov is not None and not self._use_global_cov:
-                    if self.problem.items[name].marginalize_in_fit:
-                        raise NotImplementedError('a rescaled covariance with marginalize-in-fit is not supported')
-                    self.engine.set_invcov(name, view.scaled_inv_masked_cov)
+                    item = self.problem.items[name]
+                    scaled = np.asarray(view.scaled_inv_masked_cov, dtype=np.float64)
+                    if item.marginalize_in_fit and item.marg_diff2coeff is not None:
+                        # the templates are fitted to the residual against the mock with the map of the UNSCALED covariance
+                        # (reference vega_interface.py:282-292, :546-579), chi2 takes the scaled one (:311-313): Q = P^T C_s^-1 P
+                        P = item.marg_projector()
+                        scaled = P.T.dot(scaled).dot(P)
+                    self.engine.set_invcov(name, scaled)
             else:
                 self.engine.set_data(name, view.masked_data_vec)
                 if self.problem.items[name].cov is not None and not self._use_global_cov:
@@ -567,7 +572,7 @@ class VegaInterface:
             if not self._use_global_cov and item.cov is not None and scales[name] != 1.:
                 # reference data.py:717-719: the mock's covariance scale carries over to the fit (its log-determinant
                 # term as the reference writes it: log(scale) + log det C)
-                view.scaled_inv_masked_cov = item.chi2_matrix / scales[name]
+                view.scaled_inv_masked_cov = item.inv_masked_cov / scales[name]      # (marginalize-in-fit: projected when it is sent)
                 view.scaled_log_cov_det = np.log(scales[name]) + item.log_cov_det
             full = np.full(item.data_vec.size, np.nan)
             full[item.data_mask] = pool[0]

@@ -142,11 +142,14 @@ class _Fit:
     GRAD_NCYCLES, GRAD_STEP_TOL, GRAD_TOL = 3, 0.3, 0.05
     HESS_NCYCLES, HESS_STEP_TOL, HESS_G2_TOL, HESS_GRAD_NCYCLES = 5, 0.3, 0.05, 2
 
-    def __init__(self, ext_start, ext_errors, limits_free, up=1.0, tol=0.1, maxfcn=100000):
+    def __init__(self, ext_start, ext_errors, limits_free, up=1.0, tol=0.1, maxfcn=100000, seed_V=None):
         self.trafo = Transform(limits_free)
         self.n = len(ext_start)
         self.ext_errors = np.asarray(ext_errors, dtype=float)
         self.x0 = np.array([self.trafo.ext2int(i, v) for i, v in enumerate(ext_start)])
+        # a state that carries a covariance (a re-run of iminuit's `iterate` loop): MnSeedGenerator then takes the internal
+        # error matrix as the first metric with dcovar = 0 instead of the diagonal 1 / g2 with dcovar = 1
+        self.seed_V = None if seed_V is None else np.array(seed_V, dtype=float)
         self.up = up
         self.edmval = 0.002 * max(tol * up, EPS2)
         self.maxfcn = maxfcn
@@ -491,12 +494,15 @@ class _Fit:
         fval = (yield from self._eval(x))[0]
         if not np.isfinite(fval):
             self.result = dict(x=x, fval=np.inf, edm=np.inf, V=np.zeros((n, n)), valid=False, hesse_failed=True,
-                               accurate=False, above_max_edm=True)
+                               accurate=False, above_max_edm=True, limit=False)
             return
         grd, g2, gstep = self._initial_gradient(x)
         grd, g2, gstep = yield from self._gradient(x, fval, grd, g2, gstep)
         V = np.diag([1. / g2[i] if abs(g2[i]) > EPS2 else 1. for i in range(n)])
-        state = dict(x=x, fval=fval, grd=grd, g2=g2, gstep=gstep, V=V, dcovar=1., edm=0.5 * float(grd @ V @ grd),
+        dcovar0 = 1.
+        if self.seed_V is not None:
+            V, dcovar0 = self.seed_V.copy(), 0.
+        state = dict(x=x, fval=fval, grd=grd, g2=g2, gstep=gstep, V=V, dcovar=dcovar0, edm=0.5 * float(grd @ V @ grd),
                      made_posdef=False, hesse_failed=False, accurate=False)
         if (g2 <= 0).any():
             state = yield from self._negative_g2(state)
@@ -529,7 +535,7 @@ class _Fit:
                            valid=(not reached_limit) and state['edm'] <= 10 * self.edmval and not hesse_failed
                            and np.isfinite(state['fval']),
                            hesse_failed=hesse_failed, accurate=bool(state.get('accurate')),
-                           above_max_edm=state['edm'] > 10 * self.edmval)
+                           above_max_edm=state['edm'] > 10 * self.edmval, limit=bool(reached_limit))
 
     def _negative_g2(self, state):
         """NegativeG2LineSearch: walk along every direction with a negative second derivative until it turns positive."""
@@ -660,7 +666,12 @@ class MigradMinimizer:
 
     ``evaluate(theta_ext [m, P], fit_index [m]) -> chi2 [m]``."""
 
-    def __init__(self, evaluate, names, start, errors, limits, tol=0.1, errordef=1.0, maxfcn=100000, vectorised=True):
+    def __init__(self, evaluate, names, start, errors, limits, tol=0.1, errordef=1.0, maxfcn=100000, vectorised=True,
+                 iterate=5):
+        # iminuit's Minuit.migrad(ncall, iterate=5) - what the reference calls (vega/minimizer.py:79, :97) - runs MnMigrad again,
+        # up to `iterate` times in all, while the minimum is neither valid nor at the call limit; every re-run starts from the
+        # previous run's state: its values, its parameter errors as step sizes and its error matrix as the first metric
+        self.iterate = int(iterate)
         self.evaluate = evaluate
         self.vectorised = vectorised        # False: one coroutine per fit for every stage (`_Fit.run`, the readable reference)
         self.names = list(names)
@@ -690,11 +701,13 @@ class MigradMinimizer:
             hesse_failed, accurate = S['hesse_failed'].copy(), S['accurate'].copy()
             valid = batch.alive & ~S['limit'] & (edm <= 10 * batch.edmval) & ~hesse_failed & np.isfinite(fval)
             nfcn, n_iter = batch.nfcn.copy(), batch.n_iter.copy()
+            at_limit = S['limit'].copy()
             redo = batch.slow
         else:
             x = np.zeros((F, free.size)); V = np.zeros((F, free.size, free.size)); fval = np.full(F, np.inf); edm = np.full(F, np.inf)
             hesse_failed = np.zeros(F, dtype=bool); accurate = np.zeros(F, dtype=bool); valid = np.zeros(F, dtype=bool)
             nfcn = np.zeros(F, dtype=np.int64); n_iter = np.zeros(F, dtype=int)
+            at_limit = np.zeros(F, dtype=bool)
             redo = list(range(F))
         if redo:
             # the reference implementation, one coroutine per fit: everything when not vectorised, else the fits that left the
@@ -711,6 +724,33 @@ class MigradMinimizer:
                     continue
                 x[f], V[f], fval[f], edm[f] = r['x'], r['V'], r['fval'], r['edm']
                 valid[f], hesse_failed[f], accurate[f] = r['valid'], r['hesse_failed'], r['accurate']
+                at_limit[f] = r['limit']
+        # iminuit's `iterate` loop: the fits that ended neither valid nor at the call limit run again from their last state
+        # (values, parameter errors as steps, error matrix as first metric), up to `iterate` runs in all.  Rare (hard mocks):
+        # the readable one-coroutine-per-fit implementation serves them.
+        for _ in range(max(self.iterate - 1, 0)):
+            again = np.flatnonzero(~valid & ~at_limit & np.isfinite(fval))
+            if not again.size:
+                break
+            vt = Transform(limits)
+            fits = []
+            for f in again:
+                ext_vals = np.array([vt.int2ext(i, x[f, i]) for i in range(free.size)])
+                dxs_f = np.sqrt(np.clip(2. * self.errordef * np.diag(V[f]), 0., None))
+                ext_err = np.array([dxs_f[i] * abs(vt.dint2ext(i, x[f, i])) if vt.has_limits(i) else dxs_f[i] for i in range(free.size)])
+                ext_err = np.where(ext_err > 0, ext_err, self.step[free])
+                fits.append(_Fit(ext_vals, ext_err, limits, up=self.errordef, tol=self.tol, maxfcn=self.maxfcn, seed_V=V[f]))
+            _drive(fits, lambda pts, owner: evaluate_internal(pts, again[owner]))
+            for f, fit in zip(again, fits):
+                r = fit.result
+                nfcn[f] += fit.nfcn
+                n_iter[f] += fit.n_iter
+                if r is None or not np.isfinite(r['fval']):
+                    at_limit[f] = True      # (nothing to restart from: keep the previous state, stop iterating)
+                    continue
+                x[f], V[f], fval[f], edm[f] = r['x'], r['V'], r['fval'], r['edm']
+                valid[f], hesse_failed[f], accurate[f] = r['valid'], r['hesse_failed'], r['accurate']
+                at_limit[f] = r['limit']
         # external values, errors, covariance (MnUserParameterState / MnUserCovariance)
         values = trafo.int2ext(x)
         cov_int = 2. * self.errordef * V

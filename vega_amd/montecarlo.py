@@ -258,8 +258,8 @@ class MonteCarlo:
         for name, pool in mocks.items():
             eng.set_mock_pool(name, pool)
             if scales[name] != 1. and prob.items[name].cov is not None and not vega._use_global_cov:
-                if prob.items[name].marginalize_in_fit:
-                    raise NotImplementedError('a rescaled covariance with marginalize-in-fit is not supported')
+                # (marginalize-in-fit: chi2_matrix is P^T C^-1 P with the projector of the unscaled covariance, which the
+                # reference keeps when the covariance is rescaled - vega_interface.py:282-292, :311-313)
                 eng.set_invcov(name, prob.items[name].chi2_matrix / scales[name])
         fitter = self.minimizer(sample_params, method=method)
         self._mock_rows = np.arange(num_mocks, dtype=np.int32)
