@@ -291,9 +291,28 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
         for (int i = threadIdx.x; i < n_desc; i += blockDim.x) s_dyn[i] = src[i];
     }
     const PipeDev* s_pipes = (const PipeDev*)s_dyn;
-    double* s_theta = s_dyn + n_desc;
+    // ... and the two small lists the walker loops below walk - the slots that must be constant across the batch (with walker
+    // 0's values at them) and the box of the mu rule: read from global memory inside those loops every element is its own
+    // dependent round trip.  Where the kernel's time goes at B = 256 (experiment builds, rocprofv3 kernel trace, round 4): an
+    // empty kernel 4.8 us, + the staging loads and their barrier 8.7, + everything else 16.4 - of which the window's logarithms
+    // and atomics 2.3 and the 40 scalar stores per thread 0.8; the rest is the chain of dependent LDS look-ups descriptor ->
+    // slot -> parameter behind data-dependent branches.
+    const int n_cs = D.n_const_slots, n_ru = D.n_rule;
+    double* s_c0 = s_dyn + n_desc;              // [n_cs] walker 0's values at the constant slots (device entries)
+    double* s_cs = s_c0 + n_cs;                 // [n_cs] the slots
+    double* s_ru = s_cs + n_cs;                 // [3][n_ru] slot, lower and upper bound of the rule's box
+    double* s_theta = s_ru + 3 * n_ru;
     const double* t = D.theta + (size_t)b * D.n_params;
     const double* t0 = D.theta_host ? D.theta_host : D.theta;         // walker 0: table keys and the constant-parameter check
+    const bool t0_in_lds = BYVAL || (D.theta_host && D.src_lds);
+    for (int i = threadIdx.x; i < n_cs; i += blockDim.x) {
+        const int sl = D.const_slots[i];
+        s_cs[i] = (double)sl;
+        if (!t0_in_lds) s_c0[i] = t0[sl];
+    }
+    for (int i = threadIdx.x; i < n_ru; i += blockDim.x) {
+        s_ru[i] = (double)D.rule_slot[i]; s_ru[n_ru + i] = D.rule_lo[i]; s_ru[2 * n_ru + i] = D.rule_hi[i];
+    }
     if (BYVAL || (D.theta_host && D.src_lds)) {
         // zero-copy entry (small batches, one block): one coalesced read of the walkers - from the kernel arguments, or
         // from mapped host memory in a single PCIe round trip - into LDS, and the device copy for later kernels
@@ -444,9 +463,9 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
             // the node rule of the mu sums is trusted inside the parameter box it was validated on; outside (or NaN) the
             // walker's P(k,mu) blocks run the reference's midpoint loop itself
             bool outside = false;
-            for (int q = 0; q < D.n_rule; ++q) {
-                const double v = t[D.rule_slot[q]];
-                outside = outside || !(v >= D.rule_lo[q] && v <= D.rule_hi[q]);
+            for (int q = 0; q < n_ru; ++q) {
+                const double v = t[(int)s_ru[q]];
+                outside = outside || !(v >= s_ru[n_ru + q] && v <= s_ru[2 * n_ru + q]);
             }
             s[S_NO_RULE] = outside ? 1.0 : 0.0;
             if (outside && p == 0) atomicAdd(D.k_live + 4, 1);          // (a statistic: walkers that left the box, cumulative)
@@ -476,8 +495,10 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
     if (slot < D.n_pipe) return;
 
     int st = 0;
-    for (int q = 0; q < D.n_const_slots; ++q)
-        if (t[D.const_slots[q]] != t0[D.const_slots[q]]) st = VMX_STATUS_NOT_CONSTANT;
+    for (int q = 0; q < n_cs; ++q) {
+        const int sl = (int)s_cs[q];
+        if (t[sl] != (t0_in_lds ? t0[sl] : s_c0[q])) st = VMX_STATUS_NOT_CONSTANT;
+    }
     D.status[b] = st;
     D.chi2[b] = 0.0;
 }
