@@ -79,6 +79,26 @@ static void tape_cases()
             }
 }
 
+static void split_cases()
+{
+    // the factored chi2 form at COEFMOD = 2 (fitted bins 3180 and 1590 -> 50 and 25 row tiles; 625 and 313 K stages): the
+    // per-XCD model picks the measured best (4, 2) at B = 256, the one-block-per-CU model leaves it unsplit
+    auto probs = [](int B, int max_split) {
+        const int tn = (B + 63) / 64;
+        return std::vector<SplitProblem>{{50 * tn, 625, (int64_t)B * 3200 * 8, max_split, 50, tn}, {25 * tn, 313, (int64_t)B * 1600 * 8, max_split, 25, tn}};
+    };
+    expect(choose_group_splits(probs(256, 4), true) == std::vector<int>({4, 2}), "per-XCD model: (4, 2) at B = 256");
+    expect(choose_group_splits(probs(256, 4), false) == std::vector<int>({1, 1}), "one-block model: unsplit at B = 256");
+    expect(choose_group_splits(probs(64, 8), true) == std::vector<int>({8, 4}), "per-XCD model: (8, 4) at B = 64");
+    expect(choose_group_splits(probs(1024, 1), true) == std::vector<int>({1, 1}), "no slab room: unsplit");
+    expect(choose_group_splits(probs(256, 4), true) == choose_group_splits(probs(256, 4), true), "deterministic");
+    expect(choose_group_splits({}, true).empty(), "no problems, no splits");
+    for (int B : {9, 64, 256, 512, 4096})
+        for (bool two : {false, true})
+            for (int v : choose_group_splits(probs(B, 4), two)) expect(v == 1 || v == 2 || v == 4, "a split within its bound");
+    std::printf("ok split chooser\n");
+}
+
 static void csr_cases()
 {
     const int64_t ptr_ok[] = {0, 2, 2, 5};
@@ -134,6 +154,7 @@ static void cholesky_cases()
 int main()
 {
     tape_cases();
+    split_cases();
     csr_cases();
     cholesky_cases();
     std::printf(failures ? "FAILED: %d\n" : "all planner checks passed\n", failures);

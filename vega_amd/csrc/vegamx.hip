@@ -216,6 +216,7 @@ struct vmx_engine {
     int g_n = 0, g_ld = 0;
 
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
+    int fact_slab_rows = 0;          // rows of the factored form's slabs of F dx (small rows: up to 4 K splits of a full batch)
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
     // tapes of the quadratic-form launches per number of walker tiles: the blocks' entries, their queues, the partial-sum slots
     struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> queue, nt_off; DevBuf<double> part; int n_blocks = 0; int n_entries = 0; };
@@ -465,45 +466,9 @@ static int plan_gemm(vmx_engine* e, GemmArgs& g, int nbatch, int slab_rows_avail
 // the 256 CUs.  Every combination of 1 / 2 / 4 / 8-way splits is simulated (up to three problems; beyond that the
 // block-count rule of plan_gemm applies) and the shortest makespan wins, extra slabs charged with their write + re-read
 // at ~3 TB/s.
-struct SplitProblem { int tiles; int stages; int64_t slab_bytes; int max_split; };
-static std::vector<int> choose_group_splits(const std::vector<SplitProblem>& probs)
-{
-    const int n = (int)probs.size();
-    std::vector<int> best(n, 0);
-    if (n == 0 || n > 3) return best;
-    constexpr int CUS = 256;
-    constexpr double BLOCK_OVERHEAD = 4.0;                  // pipeline fill + epilogue of a block, in K stages
-    constexpr double STAGE_US = 0.85, SLAB_BYTES_PER_US = 3.0e6;
-    double best_cost = 1e300;
-    std::vector<int> cur(n, 1);
-    std::vector<double> load(CUS);
-    const int combos = 1 << (2 * n);
-    for (int c = 0; c < combos; ++c) {
-        bool ok = true;
-        double penalty = 0.0;
-        for (int i = 0; i < n; ++i) {
-            cur[i] = 1 << ((c >> (2 * i)) & 3);
-            if (cur[i] > probs[i].max_split || probs[i].stages / cur[i] < 4) ok = false;
-            penalty += (cur[i] - 1) * 2.0 * (double)probs[i].slab_bytes / SLAB_BYTES_PER_US / STAGE_US;
-        }
-        if (!ok) continue;
-        std::fill(load.begin(), load.end(), 0.0);
-        std::priority_queue<double, std::vector<double>, std::greater<double>> free_at(load.begin(), load.end());
-        double makespan = 0.0;
-        for (int i = 0; i < n; ++i) {
-            const double cost = (double)((probs[i].stages + cur[i] - 1) / cur[i]) + BLOCK_OVERHEAD;
-            const int blocks = probs[i].tiles * cur[i];
-            for (int b = 0; b < blocks; ++b) {
-                const double t = free_at.top() + cost;
-                free_at.pop(); free_at.push(t);
-                if (t > makespan) makespan = t;
-            }
-        }
-        const double total = makespan + penalty;
-        if (total < best_cost) { best_cost = total; best = cur; }
-    }
-    return best;
-}
+// (vmx_plan::choose_group_splits, vmx_plan.h: both models, run on the CPU by tests/test_planner_host.py)
+using vmx_plan::SplitProblem;
+using vmx_plan::choose_group_splits;
 
 static int gemm_tiles(int M, int N, bool tri)
 {
@@ -1264,6 +1229,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     // split-K slabs are re-read by the consumer kernels: at most 1024 walker rows of slabs per product (measured
     // best in the full chain, where the items overlap on separate streams and fill the chip anyway)
     e->slab_rows = Bm > 1024 ? Bm : 1024;
+    e->fact_slab_rows = std::max(1024, std::min(4 * Bm, 8192));
     if (getenv("VMX_NO_GRAPH")) e->use_graphs = false;
     if (getenv("VMX_TRACE_HOST")) e->trace_host = true;
     {
@@ -2217,10 +2183,11 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                     for (size_t q : by_size) {
                         const ItemDev& d = e->items[q]->dev;
                         int max_split = 1;
-                        while (max_split < 8 && (int64_t)max_split * 2 * B <= e->slab_rows) max_split *= 2;
-                        sp.push_back({gemm_tiles(d.n_masked, B, false), (d.nq_pad + GEMM_BK - 1) / GEMM_BK, (int64_t)B * d.n_masked_pad * 8, max_split});
+                        while (max_split < 8 && (int64_t)max_split * 2 * B <= e->fact_slab_rows) max_split *= 2;
+                        sp.push_back({gemm_tiles(d.n_masked, B, false), (d.nq_pad + GEMM_BK - 1) / GEMM_BK, (int64_t)B * d.n_masked_pad * 8, max_split,
+                                      (d.n_masked + GEMM_BM - 1) / GEMM_BM, (B + GEMM_BN - 1) / GEMM_BN});
                     }
-                    splits = choose_group_splits(sp);
+                    splits = choose_group_splits(sp, true);
                     if (splits.empty()) splits.push_back(0);
                 }
                 size_t gi = 0;
@@ -2233,7 +2200,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                     int per_xcd = 0;
                     const int forced = gi < splits.size() ? splits[gi] : 0;
                     ++gi;
-                    qs.z[q] = plan_gemm(e, g, 1, e->slab_rows, nullptr, false, tiles_total - gemm_tiles(d.n_masked, B, false), &per_xcd, forced);
+                    qs.z[q] = plan_gemm(e, g, 1, e->fact_slab_rows, nullptr, false, tiles_total - gemm_tiles(d.n_masked, B, false), &per_xcd, forced);
                     per_xcd_total += per_xcd;
                     G.p[G.n] = g; G.seq_end[G.n] = per_xcd_total; ++G.n;
                 }
@@ -2244,7 +2211,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                     ItemHost* it = e->items[q];
                     const ItemDev& d = it->dev;
                     qs.z[q] = launch_product(e, KC_QUAD, it->q_f.p, d.nq_pad, 0, d.n_masked, d.nq_pad, it->q_x.p, d.nq_pad, 0, B,
-                                             it->q_y.p, d.n_masked_pad, 0, 1, e->slab_rows);
+                                             it->q_y.p, d.n_masked_pad, 0, 1, e->fact_slab_rows);
                 }
             }
             {
@@ -2371,8 +2338,11 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                     int max_split = 1;
                     while (max_split < 8 && (int64_t)max_split * 2 * B <= e->slab_rows) max_split *= 2;
                     // (a triangular problem pairs its row tiles: every block covers about one full K range)
-                    sp.push_back({gemm_tiles(M, B, stage == 1), (K + GEMM_BK - 1) / GEMM_BK, (int64_t)B * ldd * 8, max_split});
+                    sp.push_back({gemm_tiles(M, B, stage == 1), (K + GEMM_BK - 1) / GEMM_BK, (int64_t)B * ldd * 8, max_split,
+                                  (M + GEMM_BM - 1) / GEMM_BM, (B + GEMM_BN - 1) / GEMM_BN});
                 }
+                // (the one-block-per-CU model: 288 against 317 us for the distortion launch at B = 256 with the per-XCD model's
+                // choice, 101 against 94 at B = 64 - fitted on these shapes in round 2 and kept for them)
                 splits = choose_group_splits(sp);
             }
             if (splits.empty()) splits.push_back(0);
@@ -2657,7 +2627,7 @@ static int quad_build(vmx_engine* e)
             // u0 = U r0 per data vector / mock
             if (it->q_u0.alloc((size_t)rows * nmp, true)) return -2;
             launch_product(e, KC_OTHER, it->q_u.p, nmp, 0, nm, nmp, R0.p, nmp, 0, rows, it->q_u0.p, nmp, 0, 1, rows);
-            if (it->q_y.n < (size_t)e->slab_rows * nmp && it->q_y.alloc((size_t)e->slab_rows * nmp, true)) return -2;
+            if (it->q_y.n < (size_t)e->fact_slab_rows * nmp && it->q_y.alloc((size_t)e->fact_slab_rows * nmp, true)) return -2;
             d.q_u0 = it->q_u0.p; d.q_y = it->q_y.p;
         } else
         launch_product(e, KC_OTHER, it->q_w.p, nmp, 0, nq, nmp, R0.p, nmp, 0, rows, it->q_lin.p, nqp, 0, 1, rows);

@@ -4,12 +4,14 @@
 //
 //   plan_quad_tape     the persistent tape of the quadratic-form launch: cut, slot numbering, block queues
 //   check_quad_tape    the invariants of a tape (coverage, balance, slot order), for the tests and for debug builds
+//   choose_group_splits  K splits of the problems of a grouped product launch (two launch models)
 //   csr_problem        validity / canonical form of a CSR matrix handed over the C ABI
 //   cholesky_lower     in-place Cholesky factor of a symmetric positive-definite matrix (the factored chi2 form)
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -256,6 +258,69 @@ inline std::string check_quad_tape(const Tape& T, const std::vector<TapeProblem>
         }
     }
     return "";
+}
+
+// K splits of the problems of one grouped product launch (the distortion products of all correlation items, the factored chi2
+// form's products): every combination of 1 / 2 / 4 / 8-way splits is simulated (up to three problems) and the shortest makespan
+// wins, extra slabs charged with their write + re-read at ~3 TB/s.  Two models of the launch:
+//   one block per CU (two_per_cu = false): blocks of `stages / split` K stages (+ a fixed start / end cost) handed in launch
+//     order to the first free of 256 CUs - a CU works through short blocks one after the other (the SIMDs issue from the oldest
+//     wave first); fitted on the full chain's distortion products (round 2);
+//   two half-speed blocks per CU, XCD by XCD (two_per_cu = true): two resident blocks share a CU's MFMA pipes for as long as
+//     both are there, and a block that is alone on its CU does NOT run twice as fast (0.55 - 0.65 of the pair's rate: it cannot
+//     cover its own barriers and load latencies); and a K split belongs to whole XCDs (XCD x works on split x % nsplit of the
+//     row tiles of its group, k_gemm_nt44), so an XCD's load is what counts.  For launches of few long blocks this is the
+//     better model: the factored chi2 form at COEFMOD = 2, B = 256 (300 tiles of 313 / 625 stages) - measured 0.976 ms
+//     unsplit, 0.983 (2, 1), 0.806 (2, 2), 0.646 (4, 2), 0.659 (4, 4); this model: 1258, 1273, 964, 662, 677 (round 4).
+struct SplitProblem { int tiles; int stages; int64_t slab_bytes; int max_split; int tm; int tn; };
+inline std::vector<int> choose_group_splits(const std::vector<SplitProblem>& probs, bool two_per_cu = false)
+{
+    const int n = (int)probs.size();
+    std::vector<int> best(n, 0);
+    if (n == 0 || n > 3) return best;
+    constexpr double BLOCK_OVERHEAD = 4.0;                  // pipeline fill + epilogue of a block, in K stages
+    constexpr double STAGE_US = 0.85, SLAB_BYTES_PER_US = 3.0e6;
+    double best_cost = 1e300;
+    std::vector<int> cur(n, 1);
+    const int combos = 1 << (2 * n);
+    auto schedule = [](std::vector<double>& free_at, double cost, int blocks, double& makespan) {
+        // list scheduling: every block goes to the slot that falls free first (free_at is kept as a min-heap)
+        for (int b = 0; b < blocks; ++b) {
+            std::pop_heap(free_at.begin(), free_at.end(), std::greater<double>());
+            const double t = free_at.back() + cost;
+            free_at.back() = t;
+            std::push_heap(free_at.begin(), free_at.end(), std::greater<double>());
+            if (t > makespan) makespan = t;
+        }
+    };
+    for (int c = 0; c < combos; ++c) {
+        bool ok = true;
+        double penalty = 0.0;
+        for (int i = 0; i < n; ++i) {
+            cur[i] = 1 << ((c >> (2 * i)) & 3);
+            if (cur[i] > probs[i].max_split || probs[i].stages / cur[i] < 4) ok = false;
+            penalty += (cur[i] - 1) * 2.0 * (double)probs[i].slab_bytes / SLAB_BYTES_PER_US / STAGE_US;
+        }
+        if (!ok) continue;
+        double makespan = 0.0;
+        if (!two_per_cu) {
+            std::vector<double> free_at(256, 0.0);
+            for (int i = 0; i < n; ++i)
+                schedule(free_at, (double)((probs[i].stages + cur[i] - 1) / cur[i]) + BLOCK_OVERHEAD, probs[i].tiles * cur[i], makespan);
+        } else {
+            for (int x = 0; x < 8; ++x) {
+                std::vector<double> free_at(64, 0.0);           // 32 CUs x 2 resident blocks
+                for (int i = 0; i < n; ++i) {
+                    const int ngroups = 8 / cur[i], group = x / cur[i];
+                    const int rows = probs[i].tm > group ? (probs[i].tm - group + ngroups - 1) / ngroups : 0;      // row tiles group, group + ngroups, ...
+                    schedule(free_at, 2.0 * ((double)((probs[i].stages + cur[i] - 1) / cur[i]) + BLOCK_OVERHEAD), rows * probs[i].tn, makespan);
+                }
+            }
+        }
+        const double total = makespan + penalty;
+        if (total < best_cost) { best_cost = total; best = cur; }
+    }
+    return best;
 }
 
 // A CSR matrix handed over the C ABI (vmx_item_set_matrix_csr): "" or what is wrong.  Canonical form is required: the set-up
