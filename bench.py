@@ -48,6 +48,12 @@ FLOPS_PER_POINT = {'auto': 35, 'cross': 43}
 FLOPS_PER_POINT_TAB2 = {'auto': 26, 'cross': 36}
 
 
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one (the counter passes cannot run inside this process)."""
+    found = sorted((REPO / 'profiles').glob(f'r[0-9][0-9]_{suffix}'))
+    return found[-1] if found else None
+
+
 def build_problem(workload):
     from vega_amd.setup import build_problem as bp
     from vega_amd import synthetic
@@ -129,8 +135,8 @@ def distortion_microbench(engine, torch, n=2500, copies=8, reps=40):
     hot = algo_bytes / (ms_hot / launches_hot * 1e-3) / 1e9
     # (FETCH_SIZE pass of the same product under rocprofv3, scripts/gpu_matvec_only.py: the committed summary)
     traffic = None
-    traffic_file = REPO / 'profiles' / 'r03_distortion_gemv_traffic.json'
-    if traffic_file.exists() and n == 2500:
+    traffic_file = latest_profile('distortion_gemv_traffic.json')
+    if traffic_file is not None and n == 2500:
         for name, rec in json.loads(traffic_file.read_text())['kernels'].items():
             if 'k_gemv1' in name:
                 traffic = rec.get('fetch_bytes_per_launch')
@@ -920,11 +926,11 @@ def main():
         roofline = roofline_for(roof_class, live[roof_class]['ms_per_launch'])
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of `bench.py --core-only` (a counter pass
         # cannot run inside this process): the committed summary of the latest collection is attached when present
-        traffic_file = REPO / 'profiles' / 'r03_bench_core_traffic.json'
-        traffic = json.loads(traffic_file.read_text())['kernels'] if traffic_file.exists() else {}
+        traffic_file = latest_profile('bench_core_traffic.json')
+        traffic = json.loads(traffic_file.read_text())['kernels'] if traffic_file is not None else {}
         if roofline is not None and roof_class in traffic and args.workload == 'joint' and B == 256:
             roofline['traffic'] = traffic[roof_class]['hbm_bytes_per_launch']
-            roofline['traffic_unit'] = 'bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r03_bench_core_traffic.json)'
+            roofline['traffic_unit'] = f'bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_file.name})'
             roofline['algorithmic_bytes_per_launch'] = traffic[roof_class]['algorithmic_bytes_per_launch']
             # the counter passes belong to the kernel as it was when they were collected: their launch duration travels with
             # them, and a live duration that has moved away from it says the file is due for a refresh

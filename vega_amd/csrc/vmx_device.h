@@ -1363,6 +1363,10 @@ struct Tab2Args { Tab2Group g[VMX_TAB2_GROUPS]; };
 // (a sampler's stray point next to an ordinary one) runs the body twice: MODE 1 = the rule, stored for the walkers inside
 // only; MODE 2 = the loop, stored for those outside - so that a walker's arithmetic never depends on its neighbours in the
 // batch: bitwise the same alone, paired, or on another rank (vega_amd/parallel.py).
+// table rows requested ahead of their use (two streams: the pipeline's table and its peak partner's)
+#ifndef VMX_TAB2_PF
+#define VMX_TAB2_PF 4
+#endif
 template <int KT, int MS, int NW, bool CROSS, int MODE = 0>
 __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group& G, int B)
 {
@@ -1480,9 +1484,10 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
         for (int rg = 0; rg < (node_mode ? 2 : 1); ++rg) {
             const int j_lo = rg == 0 ? 0 : hi_beg, j_hi = rg == 0 ? lo_end : n_mu;
             const double* tab = base + (size_t)j_lo * row;
-            double g0 = *tab, g1 = tab[stride], g2 = tab[2 * stride], g3 = tab[3 * stride];
-            double h0 = tab[plane], h1 = tab[plane + stride], h2 = tab[plane + 2 * stride], h3 = tab[plane + 3 * stride];
-            tab += 4 * stride;
+            double gw[VMX_TAB2_PF], hw[VMX_TAB2_PF];
+#pragma unroll
+            for (int u = 0; u < VMX_TAB2_PF; ++u) { gw[u] = tab[u * stride]; hw[u] = tab[plane + u * stride]; }
+            tab += VMX_TAB2_PF * stride;
             for (int j0 = j_lo + ms; j0 < j_hi; j0 += MS * PK_REANCHOR) {
                 // exact anchor of the HCD progression F = exp(-L0 k mu) along this thread's mu sequence
 #pragma unroll
@@ -1499,15 +1504,13 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
                     for (int w = 0; w < NW; ++w) F[w] *= Fq[w];                                                       \
                 }
                 int j = j0;
-                for (int it = 0; it < steps / 4; ++it, j += 4 * MS) {
-                    VMX_TAB2_STEP(g0, h0, j)
-                    VMX_TAB2_STEP(g1, h1, j + MS)
-                    VMX_TAB2_STEP(g2, h2, j + 2 * MS)
-                    VMX_TAB2_STEP(g3, h3, j + 3 * MS)
+                for (int it = 0; it < steps / VMX_TAB2_PF; ++it, j += VMX_TAB2_PF * MS) {
+#pragma unroll
+                    for (int u = 0; u < VMX_TAB2_PF; ++u) VMX_TAB2_STEP(gw[u], hw[u], j + u * MS)
                 }
-                if (steps % 4 > 0) VMX_TAB2_STEP(g0, h0, j)
-                if (steps % 4 > 1) VMX_TAB2_STEP(g1, h1, j + MS)
-                if (steps % 4 > 2) VMX_TAB2_STEP(g2, h2, j + 2 * MS)
+#pragma unroll
+                for (int u = 0; u < VMX_TAB2_PF - 1; ++u)
+                    if (u < steps % VMX_TAB2_PF) VMX_TAB2_STEP(gw[u], hw[u], j + u * MS)
 #undef VMX_TAB2_STEP
             }
         }
@@ -1515,9 +1518,10 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
             // the extra nodes (rows n_mu + jj): not equally spaced, so the HCD factor is exponentiated directly; the table
             // entries run four nodes ahead as above
             const double* tab = base + (size_t)n_mu * row;
-            double g0 = *tab, g1 = tab[stride], g2 = tab[2 * stride], g3 = tab[3 * stride];
-            double h0 = tab[plane], h1 = tab[plane + stride], h2 = tab[plane + 2 * stride], h3 = tab[plane + 3 * stride];
-            tab += 4 * stride;
+            double gw[VMX_TAB2_PF], hw[VMX_TAB2_PF];
+#pragma unroll
+            for (int u = 0; u < VMX_TAB2_PF; ++u) { gw[u] = tab[u * stride]; hw[u] = tab[plane + u * stride]; }
+            tab += VMX_TAB2_PF * stride;
             const int steps = D.n_extra > ms ? (D.n_extra - ms + MS - 1) / MS : 0;
 #define VMX_TAB2_XSTEP(GREG, HREG, JJ)                                                                                \
             {                                                                                                         \
@@ -1530,15 +1534,13 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
                 VMX_TAB2_NODE(nd.y, nd.z, true, g, h)                                                                 \
             }
             int jj = ms;
-            for (int it = 0; it < steps / 4; ++it, jj += 4 * MS) {
-                VMX_TAB2_XSTEP(g0, h0, jj)
-                VMX_TAB2_XSTEP(g1, h1, jj + MS)
-                VMX_TAB2_XSTEP(g2, h2, jj + 2 * MS)
-                VMX_TAB2_XSTEP(g3, h3, jj + 3 * MS)
+            for (int it = 0; it < steps / VMX_TAB2_PF; ++it, jj += VMX_TAB2_PF * MS) {
+#pragma unroll
+                for (int u = 0; u < VMX_TAB2_PF; ++u) VMX_TAB2_XSTEP(gw[u], hw[u], jj + u * MS)
             }
-            if (steps % 4 > 0) VMX_TAB2_XSTEP(g0, h0, jj)
-            if (steps % 4 > 1) VMX_TAB2_XSTEP(g1, h1, jj + MS)
-            if (steps % 4 > 2) VMX_TAB2_XSTEP(g2, h2, jj + 2 * MS)
+#pragma unroll
+            for (int u = 0; u < VMX_TAB2_PF - 1; ++u)
+                if (u < steps % VMX_TAB2_PF) VMX_TAB2_XSTEP(gw[u], hw[u], jj + u * MS)
 #undef VMX_TAB2_XSTEP
         }
 #undef VMX_TAB2_NODE
