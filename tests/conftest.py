@@ -24,7 +24,13 @@ def run_programs(commands, envs, timeout=900):
         return [(p.wait(timeout=timeout), p.stdout.read()) for p in procs]
     _SPAWNER.stdin.write(json.dumps({'commands': commands, 'env': envs, 'cwd': str(REPO), 'timeout': timeout}) + '\n')
     _SPAWNER.stdin.flush()
-    reply = json.loads(_SPAWNER.stdout.readline())
+    # the helper enforces `timeout` on the programs; should the helper itself die or hang, do not wait for its reply for ever
+    import select
+    ready, _, _ = select.select([_SPAWNER.stdout], [], [], timeout + 120)
+    line = _SPAWNER.stdout.readline() if ready else ''
+    if not line:
+        raise RuntimeError(f'tests/helpers/spawn_server.py gave no reply within {timeout + 120} s (exit code {_SPAWNER.poll()})')
+    reply = json.loads(line)
     return [(r['returncode'], r['output']) for r in reply]
 
 

@@ -99,3 +99,50 @@ def test_minimize_scan_and_monte_carlo_against_the_references_drivers(tmp_path):
     np.testing.assert_allclose(bestfits[:, :, 1], exp['mc/bestfits'][:, :, 1], rtol=5e-3)
     np.testing.assert_allclose(mc.mc_chisq, exp['mc/chisq'], rtol=1e-7)
     vega.close()
+
+
+def test_mc_start_from_fit_reads_the_bestfit_table(tmp_path):
+    """`[control] mc_start_from_fit` (reference vega/vega_interface.py:465-472): the Monte-Carlo fiducial takes the best-fit
+    values of an existing fit file - its BESTFIT table with `names` / `values` columns (vega/postprocess/fit_results.py:47-53) -
+    under the [mc parameters]; no initial fit is run."""
+    from vega_amd import VegaInterface, fitslite
+    prob = fits_problem(tmp_path)
+    fit_file = tmp_path / 'previous_fit.fits'
+    fit_names = np.array(['ap', 'at', 'bias_eta_LYA', 'beta_LYA'])
+    fit_values = np.array([1.031, 0.972, -0.2051, 1.71])
+    fitslite.write_tables(str(fit_file), [
+        ('MODEL', [('dummy', 'D', np.zeros(3))]),
+        ('BESTFIT', [('names', '12A', fit_names), ('values', 'D', fit_values), ('errors', 'D', 0.01 * np.ones(4))])], overwrite=True)
+    prob.main_config['control']['mc_start_from_fit'] = str(fit_file)
+    vega = VegaInterface(None, problem=prob, max_batch=8)
+    calls = []
+    vega.minimize = lambda *a, **k: calls.append(1)         # (must not be called: the fit file replaces the initial fit)
+    said = []
+    fid = vega.get_fiducial_for_monte_carlo(print_func=said.append)
+    assert not calls and any('Reading input fit' in s for s in said)
+    want = dict(zip(fit_names, fit_values))
+    want.update(prob.mc_config['params'])                   # [mc parameters] beta_LYA = 1.8 wins over the fit's 1.71
+    assert want['beta_LYA'] == 1.8
+    ref = vega.compute_model(want)
+    for name in prob.items:
+        # (a repeated single-walker call may run against the tables the first one left: the last bit can differ)
+        np.testing.assert_allclose(fid[name], ref[name], rtol=1e-13, atol=1e-16)
+    other = vega.compute_model(dict(zip(fit_names, fit_values)))
+    assert any(np.abs(other[n] - ref[n]).max() > 1e-6 * np.abs(ref[n]).max() for n in prob.items)
+    vega.close()
+
+
+def test_chi2_scan_with_the_vectorised_minimiser(tmp_path):
+    """`chi2_scan(method='bfgs')`: the same grid and pinned parameters through the second minimiser (Minuit's conventions, not
+    its trajectory) - the minima agree with MIGRAD's within a fraction of the reported errors."""
+    from vega_amd import VegaInterface
+    vega = VegaInterface(None, problem=fits_problem(tmp_path), max_batch=256)
+    a = vega.chi2_scan()
+    grids = {k: v.copy() for k, v in vega.analysis.grids.items()}
+    b = vega.chi2_scan(method='bfgs')
+    assert list(vega.analysis.grids) == list(grids) and len(a) == len(b) == 6
+    for ra, rb in zip(a, b):
+        for g in grids:
+            assert ra[g] == rb[g]                           # the pinned grid values
+        assert rb['fval'] == pytest.approx(ra['fval'], rel=1e-3, abs=1e-3)
+    vega.close()
