@@ -133,7 +133,9 @@ typedef struct {
     int32_t amplitude_slot;         /* -1, or a parameter multiplying the contribution: with `no-metal-decomp = False`
                                      * (model.py:120-123, :186) a pair enters twice, its smooth-spectrum pipeline as is
                                      * and its peak-spectrum pipeline times bao_amp */
-    int32_t reserved;
+    int32_t in_direct;              /* 1: the pair is part of a direct_pk evaluation (model.py:188-207 calls _compute_model with
+                                     * the caller's spectrum: with `no-metal-decomp = False` the metal terms are computed on it,
+                                     * :120-123 - the smooth-spectrum entries; with the default decomposition they are left out) */
 } vmx_metal_desc;
 
 typedef struct {
@@ -279,6 +281,11 @@ int vmx_add_prior(vmx_engine* e, int32_t slot, double mean, double sigma);
 /* Allocate the per-batch workspace.  After this the engine is immutable except for
  * vmx_item_set_data / vmx_item_set_matrix(INVCOV) / vmx_set_global_invcov. */
 int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch);
+/* Before vmx_finalize.  enabled = 0: pipelines whose P(k,mu) is the Kaiser polynomial times static factors keep their per-walker
+ * P(k) -> xi path instead of the static spline-coefficient basis derived from the template's spectra (default 1: the basis).
+ * Needed for direct_pk evaluations that include such pipelines (vmx_metal_desc::in_direct): a caller-supplied spectrum has no
+ * static basis; vmx_set_direct_pk refuses them otherwise. */
+int vmx_set_static_poly(vmx_engine* e, int32_t enabled);
 
 /* Total output size per walker: sum of n_dist over items, in item order. */
 int vmx_model_size(vmx_engine* e);

@@ -746,6 +746,33 @@ def dump_direct_pk(VegaInterface):
         print('direct_pk: chi2', out['fid/chi2'], out['chi2'])
 
 
+def dump_direct_pk_metals(VegaInterface):
+    """`direct_pk` together with `no-metal-decomp = False` (reference vega/model.py:188-207 -> :120-123): the metal terms are
+    then part of the direct model, computed on the caller's spectrum (with the default decomposition they are left out:
+    dump_direct_pk).  The auto-correlation with its 15 metal pairs; fiducial point (chi2, model) and two walkers."""
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_lyalya'], True)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(item.read_text().replace('[model]', '[model]\nno-metal-decomp = False'))
+        vega = VegaInterface(main)
+        assert not vega.models['lyalya_lyalya'].no_metal_decomp
+        pk = direct_pk_vector(vega.fiducial['k'], vega.fiducial['pk_full'])
+        out = {'direct_pk': pk, 'fid/chi2': vega.chi2(direct_pk=pk),
+               'fid/model': vega.compute_model(run_init=False, direct_pk=pk)['lyalya_lyalya'],
+               'plain/chi2': vega.chi2()}
+        names, walkers = make_walkers(vega.params, 2, seed=WALKER_SEED + 19)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+        chi2s = []
+        for i, w in enumerate(walkers):
+            _reset_caches(vega)
+            chi2s.append(vega.chi2(w, direct_pk=pk * (1 + 0.01 * (i + 1))))
+        out['chi2'] = np.array(chi2s)
+        np.savez_compressed(HERE / 'expected_direct_pk_metals.npz', **out)
+        print('direct_pk + metals: chi2', out['fid/chi2'], out['chi2'], 'plain', out['plain/chi2'])
+
+
 def dump_fast_metals(VegaInterface):
     """`fast_metals = True` (reference metals.py:53,144-169,280-282): metal x metal correlations are computed at
     the FIRST evaluation and reused for ever after.  Sequence dumped: chi2 at the fiducial point (fills the cache),
@@ -1093,12 +1120,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1145,3 +1172,5 @@ if __name__ == '__main__':
         dump_dmat_file(VI)
     if 'marg_mc' in what:
         dump_marg_mc(VI)
+    if 'direct_pk_metals' in what:
+        dump_direct_pk_metals(VI)

@@ -297,6 +297,25 @@ def test_fits_ingestion_matches_reference(tmp_path):
     assert oc.chi2(prob, pars) == pytest.approx(float(exp['walker0/chi2']), rel=1e-10)
 
 
+def test_direct_pk_with_metal_terms_matches_reference():
+    """`direct_pk` + `no-metal-decomp = False` (reference model.py:188-207 -> :120-123): the metal terms are part of the
+    direct model, on the caller's spectrum (tests/golden/make_golden.py::dump_direct_pk_metals)."""
+    prob = load_problem('auto_metals')
+    prob.items['lyalya_lyalya'].metal_opts['no_metal_decomp'] = False
+    try:
+        exp = np.load(GOLDEN / 'expected_direct_pk_metals.npz')
+        pk = exp['direct_pk']
+        assert oc.chi2(prob, direct_pk=pk) == pytest.approx(float(exp['fid/chi2']), rel=1e-12)
+        model = oc.compute_model(prob, direct_pk=pk)['lyalya_lyalya']
+        assert np.abs(model - exp['fid/model']).max() <= 1e-13 * np.abs(model).max()
+        names = [str(n) for n in exp['param_names']]
+        for i, row in enumerate(exp['theta']):
+            got = oc.chi2(prob, dict(zip(names, row)), direct_pk=pk * (1 + 0.01 * (i + 1)))
+            assert got == pytest.approx(float(exp['chi2'][i]), rel=1e-12)
+    finally:
+        prob.items['lyalya_lyalya'].metal_opts['no_metal_decomp'] = True
+
+
 def test_metal_decomposition_matches_reference():
     """`no-metal-decomp = False` (reference model.py:120-123, :181-186): metals per component."""
     prob = load_problem('auto_metals')

@@ -342,6 +342,30 @@ def test_metal_decomposition():
     vega.close()
 
 
+def test_direct_pk_with_metal_terms():
+    """`direct_pk` + `no-metal-decomp = False` (reference model.py:188-207 -> :120-123): the metal terms are part of the direct
+    model, computed on the caller's spectrum - the smooth-spectrum entries of the pairs (`vmx_metal_desc::in_direct`), on their
+    per-walker pipelines (the interface rebuilds the engine without the static basis of the template's spectra at the first
+    such call).  Against the unmodified reference; ordinary evaluations before and after are untouched."""
+    from vega_amd import VegaInterface
+    prob = _fresh('auto_metals')
+    prob.items['lyalya_lyalya'].metal_opts['no_metal_decomp'] = False
+    exp = np.load(GOLDEN / 'expected_direct_pk_metals.npz')
+    pk = exp['direct_pk']
+    vega = VegaInterface(None, problem=prob, max_batch=4)
+    assert vega.chi2() == pytest.approx(float(exp['plain/chi2']), rel=CHI2_RTOL)
+    assert vega.engine.static_poly
+    assert vega.chi2(direct_pk=pk) == pytest.approx(float(exp['fid/chi2']), rel=CHI2_RTOL)
+    assert not vega.engine.static_poly                  # the engine was rebuilt for the caller's spectrum
+    got = vega.compute_model(direct_pk=pk)['lyalya_lyalya']
+    assert np.abs(got - exp['fid/model']).max() <= XI_RTOL * np.abs(exp['fid/model']).max()
+    names = [str(n) for n in exp['param_names']]
+    for i, row in enumerate(exp['theta']):
+        assert vega.chi2(dict(zip(names, row)), direct_pk=pk * (1 + 0.01 * (i + 1))) == pytest.approx(float(exp['chi2'][i]), rel=CHI2_RTOL)
+    assert vega.chi2() == pytest.approx(float(exp['plain/chi2']), rel=CHI2_RTOL)
+    vega.close()
+
+
 @pytest.mark.parametrize('tag', ['cross', 'auto_rp'])
 def test_new_metals_through_the_engine(tmp_path, tag):
     """`new_metals = True`: metal matrices built at set-up (vega_amd/metal_matrices.py; reference

@@ -256,6 +256,7 @@ struct vmx_engine {
     // quadratic form of chi2: used when only chi2 is asked for (see vmx_set_quadratic_form)
     std::vector<double> theta_ref;
     bool quad_eligible = false, quad_mat_dirty = true, quad_lin_dirty = true, no_fuse = false;
+    bool static_poly = true;         // vmx_set_static_poly
     int quad_kind = 0;               // vmx_set_quadratic_form_kind: 0 = the cheaper form, 1 = Q', 2 = factored
     bool quad_factored = false;      // the form the tensors were built for
     int last_form = 0;               // form of the last evaluation: 0 full chain, 1 Q', 2 factored (vmx_debug_read 4 [8])
@@ -1444,7 +1445,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             e->pk_static.clear();
             for (int p : e->pk_poly) {
                 const vmx_pipe_desc& d = e->pipes[p].d;
-                if (!d.uvb && !d.heii && !(d.damping_scale > 0.0) && !getenv("VMX_NO_STATIC_POLY")) {
+                if (!d.uvb && !d.heii && !(d.damping_scale > 0.0) && e->static_poly && !getenv("VMX_NO_STATIC_POLY")) {
                     PipeDev& pd = e->pipes[p];
                     pd.poly_basis = (int32_t)e->pk_static.size();
                     e->pk_static.push_back(p);
@@ -2829,6 +2830,10 @@ int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk)
     HIP_OK(hipStreamSynchronize(e->stream));
     if (!pk) { e->direct = false; e->dev.pk_direct = nullptr; return 0; }
     REQUIRE(B > 0 && B <= e->max_batch && nk == e->nk, "direct_pk shape: [B <= max_batch][nk]");
+    for (auto* m : e->metals)
+        REQUIRE(!(m->dev.d.in_direct && m->dev.d.pipeline >= 0 && e->pipes[m->dev.d.pipeline].poly_basis >= 0),
+                "direct_pk: a metal pair that enters the direct model sits on a static basis of the template's spectra - build the "
+                "engine with vmx_set_static_poly(e, 0)");
     if (e->pk_direct.n < (size_t)e->max_batch * e->nkp && e->pk_direct.alloc((size_t)e->max_batch * e->nkp, true)) return -2;
     HIP_OK(hipMemcpy2D(e->pk_direct.p, (size_t)e->nkp * sizeof(double), pk, (size_t)nk * sizeof(double),
                        (size_t)nk * sizeof(double), B, hipMemcpyHostToDevice));
@@ -2919,6 +2924,13 @@ int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule)
     e->graphs.clear();
     e->quad_lin_dirty = true;       // the reference point (x0', m0) is re-evaluated with the new rule; Q' and W do not depend on it
     return e->mu_nodes_on ? 1 : 0;
+}
+
+int vmx_set_static_poly(vmx_engine* e, int32_t enabled)
+{
+    REQUIRE(e && !e->finalized, "vmx_set_static_poly (before vmx_finalize)");
+    e->static_poly = enabled != 0;
+    return 0;
 }
 
 int vmx_set_quadratic_form_kind(vmx_engine* e, int32_t kind)

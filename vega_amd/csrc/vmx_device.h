@@ -1073,7 +1073,8 @@ __device__ __forceinline__ void w_members_store(const EngineDev& D, const PkGrou
         for (int m = 0; m < 4; ++m) mm[m] = fma(a2, wm[m + 2], fma(a1, wm[m + 1], a0 * wm[m]));
         double damp = 1.0;
         if (dm.damping_scale > 0.0) damp = exp(-dm.damping_scale * dm.damping_scale * pow(k, (double)dm.damping_power) / 2.0);
-        const double pk = damp * D.pklin[(size_t)dm.pk_lin_kind * D.nkp + i] * inv_nmu;
+        const double pk = damp * ((D.pk_direct && dm.pk_lin_kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i]
+                                                                                      : D.pklin[(size_t)dm.pk_lin_kind * D.nkp + i]) * inv_nmu;
         const size_t col = (size_t)D.pipes[pm].col * B + b;
         D.pl[((size_t)0 * ncols + col) * D.nkp + i] = pk * mm[0];
         D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
@@ -1842,7 +1843,8 @@ __global__ __launch_bounds__(256) void k_pk_poly(EngineDev D, const int32_t* pol
             mm[m] = fma(a2, mg[(size_t)(m + 2) * D.nkp], fma(a1, mg[(size_t)(m + 1) * D.nkp], a0 * mg[(size_t)m * D.nkp]));
         double damp = 1.0;
         if (d.damping_scale > 0.0) damp = exp(-d.damping_scale * d.damping_scale * pow(k, (double)d.damping_power) / 2.0);
-        const double pk = damp * D.pklin[(size_t)d.pk_lin_kind * D.nkp + i] * inv_nmu;
+        const double pk = damp * ((D.pk_direct && d.pk_lin_kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i]
+                                                                                     : D.pklin[(size_t)d.pk_lin_kind * D.nkp + i]) * inv_nmu;
         D.pl[((size_t)0 * ncols + col) * D.nkp + i] = pk * mm[0];
         D.pl[((size_t)1 * ncols + col) * D.nkp + i] = pk * (7.5 * mm[1] - 2.5 * mm[0]);
         D.pl[((size_t)2 * ncols + col) * D.nkp + i] = pk * (39.375 * mm[2] - 33.75 * mm[1] + 3.375 * mm[0]);
@@ -1977,9 +1979,10 @@ __device__ inline double assemble_bin(const EngineDev& D, const ItemDev& it, int
     }
     if (!smooth_in) v += D.xi[Ps.xi_off + (size_t)b * Ps.n_pad + bin];
     if (!direct && !peak_in) v = fma(bao, D.xi[Pp.xi_off + (size_t)b * Pp.n_pad + bin], v);
-    for (int m = 0; m < (direct ? 0 : it.n_metals); ++m) {
+    for (int m = 0; m < it.n_metals; ++m) {
         if ((summed >> m) & 1) continue;
         const MetalDev& md = D.metals[it.metal_begin + m];
+        if (direct && !md.d.in_direct) continue;        // (direct_pk: the metal terms only with `no-metal-decomp = False`, smooth entries)
         const double* mb = D.metal_bias + (size_t)b * 3 * D.n_metals_total + it.metal_begin + m;
         const double f = mb[0];
         double x;

@@ -68,7 +68,7 @@ class MetalDesc(C.Structure):
     _fields_ = [('pipeline', C.c_int32), ('tracer', Tracer * 2), ('same_tracer', C.c_int32),
                 ('growth_rate_slot', C.c_int32), ('growth_rate_default', C.c_double),
                 ('extra_bias_slot', C.c_int32), ('apply_bias', C.c_int32), ('multiplicity', C.c_double),
-                ('amplitude_slot', C.c_int32), ('reserved', C.c_int32)]
+                ('amplitude_slot', C.c_int32), ('in_direct', C.c_int32)]
 
 
 class ItemDesc(C.Structure):
@@ -141,6 +141,7 @@ def load_library():
     lib.vmx_marg_coeff.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32]
     lib.vmx_set_quadratic_form.argtypes = [C.c_void_p, dptr]
     lib.vmx_set_quadratic_form_kind.argtypes = [C.c_void_p, C.c_int32]
+    lib.vmx_set_static_poly.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_mu_quadrature.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_get_mu_nodes.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_set_mu_rule_box.argtypes = [C.c_void_p, C.c_int32, iptr, dptr, dptr]
@@ -177,7 +178,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_static_poly', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -426,9 +427,12 @@ class Engine:
     """One vegamx engine handle on one GPU, built from a Problem."""
 
     def __init__(self, problem, max_batch=256, device=0, extra_names=(), metal_plan=None, kron_metals=True,
-                 csr_threshold=None):
+                 csr_threshold=None, static_poly=True):
         self.lib = load_library()
         self.prob = problem
+        # False: polynomial pipelines keep their per-walker P(k) -> xi path instead of the static spline-coefficient basis of
+        # the template's spectra (include/vegamx.h: vmx_set_static_poly) - what direct_pk needs when metal terms are part of it
+        self.static_poly = bool(static_poly)
         # fast_metals (see fast_metal_plan): per item, per metal pair ('pipeline', None) | ('share', leader index)
         # | ('static', xi vector) | ('basis', [3, n_model] Kaiser basis)
         self.metal_plan = metal_plan or {}
@@ -606,6 +610,9 @@ class Engine:
                         md = MetalDesc()
                         md.pipeline = pid
                         md.amplitude_slot = amplitude_slot
+                        # direct_pk (reference model.py:188-207, :120-123): the metal terms are part of the direct model only with
+                        # `no-metal-decomp = False`, computed on the caller's spectrum - the smooth-spectrum entries here
+                        md.in_direct = int(component == 'smooth')
                         md.tracer[0] = low.tracer(pair.pipeline.tracer1, beta_name=betas[0])
                         md.tracer[1] = low.tracer(pair.pipeline.tracer2, beta_name=betas[1])
                         md.same_tracer = int(n1 == n2)
@@ -729,6 +736,8 @@ class Engine:
             hi = _f64([box[n][1] for n in box])
             self._check(lib.vmx_set_mu_rule_box(self._h, slots.size, _ip(slots), _dp(lo), _dp(hi)))
         self.mu_rule_box = box
+        if not self.static_poly:
+            self._check(lib.vmx_set_static_poly(self._h, 0))
         self._check(lib.vmx_finalize(self._h, self.n_params, self.max_batch))
         self.model_size = self._check(lib.vmx_model_size(self._h))
         # chi2-only evaluations run as a static quadratic form around the configured parameter values when the

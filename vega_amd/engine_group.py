@@ -88,6 +88,7 @@ class EngineGroup:
             raise
         # (fast_metals / static-basis plans are keyed by item name: every engine picks its own items' entries)
         self.metal_plan = kwargs.get('metal_plan') or {}
+        self.static_poly = bool(kwargs.get('static_poly', True))
         first = self.children[0]
         self.lib, self.low, self.names, self.n_params, self.max_batch = first.lib, first.low, first.names, first.n_params, first.max_batch
         assert all(c.names == self.names for c in self.children)

@@ -195,7 +195,6 @@ class VegaInterface:
         """Context: evaluate with the caller's linear spectrum (one [nk] vector, or [B, nk] for a batch) in place of
         the fiducial template - the reference's ``direct_pk`` argument (vega_interface.py:208-248)."""
         import contextlib
-        engine = self.engine
 
         @contextlib.contextmanager
         def ctx():
@@ -203,16 +202,34 @@ class VegaInterface:
                 yield
                 return
             if any(item.metals and not item.metal_opts['no_metal_decomp'] for item in self.problem.items.values()):
-                raise NotImplementedError('direct_pk with no-metal-decomp = False is not accelerated')
+                # the metal terms are then computed on the caller's spectrum too (reference model.py:120-123 through
+                # compute_direct, :188-207): their pipelines cannot sit on the static basis of the template's spectra
+                if getattr(self.engine, 'static_poly', True):
+                    self._rebuild_engine(static_poly=False)
             if any(item.core.xi.relativistic or item.core.xi.asymmetry for item in self.problem.items.values()):
                 raise NotImplementedError('direct_pk with the odd-multipole terms (static splines of the template) '
                                           'is not accelerated')
+            engine = self.engine
             engine.set_direct_pk(direct_pk)
             try:
                 yield
             finally:
                 engine.set_direct_pk(None)
         return ctx()
+
+    def _rebuild_engine(self, **changes):
+        """Replace the engine by one built with other options (the metal plan, blinding offsets and pins carry over; data,
+        mocks and covariances are sent again at the next evaluation)."""
+        old = self.engine
+        plan = old.metal_plan
+        old.close()
+        self._engine_args.update(changes)
+        self.engine = make_engine(self.problem, metal_plan=plan, **self._engine_args)
+        assert self.engine.names == self.param_names
+        self._push_blinding()
+        if self._pinned_names:
+            self._pinned_slots = np.array([self.engine.low.slot[n] for n in self._pinned_names], dtype=np.int64)
+        self._mc_active = False
 
     def _sync_monte_carlo(self):
         """chi2 reads the current mock and the scaled inverse covariance in Monte-Carlo mode
