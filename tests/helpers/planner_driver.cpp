@@ -72,11 +72,32 @@ static void tape_cases()
                 }
                 int64_t want = 0;
                 for (auto& pr : probs)
-                    for (int mt = 0; mt < (pr.nq + 63) / 64; ++mt) want += (int64_t)std::min((mt + 1) * 2, pr.nq_pad / 32) * tn;
+                    for (int mt = 0; mt < (pr.nq + 63) / 64; ++mt) want += (int64_t)tape_tile_stages(pr, mt, 64, 32) * tn;
                 expect(stages == want, "the tape carries every K stage exactly once");
                 std::printf("ok tape nq0=%d items=%zu B=%d blocks=%d: %zu entries, %lld slots, piece cost %.0f..%.0f (cap %.1f)\n",
                             sh[0], sh.size(), B, blocks, a.work.size(), (long long)a.n_slots, lo, hi, a.capacity);
             }
+}
+
+static void tiling_cases()
+{
+    // tiles counted from the bottom of the triangle: the ragged tile is the SHORT one
+    expect(tape_row0(5000, 64) == 8 && tape_row0(2512, 64) == 16 && tape_row0(2560, 64) == 0 && tape_row0(2501, 64) == 0, "row0: nq mod 64 when even");
+    const TapeProblem cross{5000, 5024};
+    expect(tape_tile_stages(cross, 0, 64, 32) == 1 && tape_tile_stages(cross, 1, 64, 32) == 3 && tape_tile_stages(cross, 78, 64, 32) == 157, "stages of the offset tiling");
+    for (int nq : {5000, 2512, 2500, 70, 64, 65, 20000}) {
+        const TapeProblem p{nq, pad32(nq)};
+        const int tm = (nq + 63) / 64, row0 = tape_row0(nq, 64);
+        int covered = 0;
+        for (int mt = 0; mt < tm; ++mt) {
+            const int lo = row0 > 0 ? (mt == 0 ? 0 : row0 + (mt - 1) * 64) : mt * 64, hi = std::min(tape_tile_hi(nq, mt, 64), nq);
+            expect(lo == covered && hi > lo && hi - lo <= 64, "tiles partition the rows");
+            expect(tape_tile_stages(p, mt, 64, 32) * 32 >= hi || tape_tile_stages(p, mt, 64, 32) == p.nq_pad / 32, "a tile's K range reaches its diagonal");
+            covered = hi;
+        }
+        expect(covered == nq, "every row in exactly one tile");
+    }
+    std::printf("ok tiling\n");
 }
 
 static void split_cases()
@@ -154,6 +175,7 @@ static void cholesky_cases()
 int main()
 {
     tape_cases();
+    tiling_cases();
     split_cases();
     csr_cases();
     cholesky_cases();

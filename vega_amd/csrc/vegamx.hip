@@ -1701,6 +1701,7 @@ static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B)
         g.d_slab = (int64_t)B * d.nq_pad;
         g.tm = (d.nq + GEMM_BM - 1) / GEMM_BM; g.tn = (B + GEMM_BN - 1) / GEMM_BN;
         g.part = ql->part.p; g.lin = it->q_lin.p; g.lin_row = e->mock_index.p; g.lin_pool = d.mock_pool ? 1 : 0;
+        g.row0 = vmx_plan::tape_row0(d.nq, GEMM_BM);       // (the tape's K ranges are those of this tiling)
         G.p[G.n++] = g;
     }
     G.work = ql->work.p;

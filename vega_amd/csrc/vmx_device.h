@@ -2276,6 +2276,9 @@ struct GemmArgs {
     // term entering with the tile's first K segment - and leaves one partial sum per walker and wave row in
     // part[(block * 64 + walker in tile) * 2 + wave row]; k_chi2_parts adds them in block order.
     double* part; const double* lin; const int32_t* lin_row; int lin_pool;
+    // ... and count their row tiles from the bottom of the triangle (vmx_plan.h: tape_row0): tile 0 = rows [0, row0), tile
+    // t >= 1 = rows [row0 + 64 (t - 1), row0 + 64 t); 0: the plain tiling
+    int row0;
 };
 #define VMX_TAG_QUAD 12
 #define VMX_TAG_FFTLOG 2
@@ -2639,7 +2642,8 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     // what the K loop and the contraction epilogue read of the current entry's problem: scalars, so that a persistent block
     // (whose entries may belong to different problems) reloads a dozen values per entry - a pointer into the kernel
     // arguments that moves would send the whole GemmGroup to scratch memory
-    int p_M = g.M, p_N = g.N, p_lda = g.lda, p_ldx = g.ldx, p_lin_pool = g.lin_pool;
+    int p_M = g.M, p_N = g.N, p_lda = g.lda, p_ldx = g.ldx, p_lin_pool = g.lin_pool, p_row0 = g.row0;
+    int p_mend = g.M;           // one past the last row of the current tile that counts (a ragged first tile: row0)
     double* p_part = g.part;
     const double* p_lin = g.lin;
     const int32_t* p_lin_row = g.lin_row;
@@ -2670,13 +2674,18 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
             wk = G.work[w_first + pass];
             const GemmArgs& q = G.p[__builtin_amdgcn_readfirstlane(wk.prob)];
             A = (const char*)q.A; X = (const char*)q.X;
-            p_M = q.M; p_N = q.N; p_lda = q.lda; p_ldx = q.ldx; p_lin_pool = q.lin_pool;
+            p_M = q.M; p_N = q.N; p_lda = q.lda; p_ldx = q.ldx; p_lin_pool = q.lin_pool; p_row0 = q.row0;
             p_part = q.part; p_lin = q.lin; p_lin_row = q.lin_row;
             n0 = wk.nt * BN;
             slot = wk.slot;
         }
         const int mt = persist ? wk.mt : pass == 0 ? mt0 : g.tm - 1 - mt0;
         m0 = m_base + mt * BM;
+        p_mend = p_M;
+        if (persist && p_row0 > 0) {            // tiles counted from the bottom of the triangle: the ragged tile is the first
+            m0 = mt == 0 ? 0 : p_row0 + (mt - 1) * BM;
+            if (mt == 0) p_mend = p_row0;
+        }
         if (list) { kbeg = wk.kbeg; kend = wk.kend; }
         else if (g.tri) {
             int kmax = ((mt + 1) * BM + BK - 1) / BK * BK; if (kmax > g.K) kmax = g.K;
@@ -2717,7 +2726,7 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
   for (int pass = 0; pass < npass; ++pass) {
     // (setup(pass + 1) moves the entry's values on before this pass's epilogue: the epilogue reads these copies)
     const int c_m0 = m0, kbeg_c = kbeg, kend_c = kend, c_n0 = n0, c_slot = slot, c_first = first_buf;
-    const int c_M = p_M, c_N = p_N, c_ldx = p_ldx, c_lin_pool = p_lin_pool;
+    const int c_M = p_mend, c_N = p_N, c_ldx = p_ldx, c_lin_pool = p_lin_pool;
     double* const c_part = p_part;
     const double* const c_lin = p_lin;
     const int32_t* const c_lin_row = p_lin_row;

@@ -23,6 +23,20 @@ namespace vmx_plan {
 
 struct TapeProblem { int nq, nq_pad; };       // rows of the half-form matrix and its padded leading dimension (multiple of bk)
 
+// Row tiling of a half-form (lower-triangular) problem.  nq is rarely a multiple of the 64-row tile, and a tile costs its K
+// range whatever its live rows: with the ragged tile at the BOTTOM of the triangle it is the longest row of all (5000 rows: 8
+// live rows, 157 K stages - 2 % of the whole launch; 2512 rows: 16 live rows, 79 stages).  The tiles are therefore counted from
+// the bottom: tile 0 holds the first `row0 = nq mod 64` rows (K range: one stage), tile t >= 1 the rows [row0 + 64 (t - 1),
+// row0 + 64 t).  (Only for an even row0: the contraction epilogue fetches its operands in 16-byte pieces from the tile's first
+// row on; an odd one keeps the plain tiling.)
+inline int tape_row0(int nq, int bm) { const int r = nq % bm; return r % 2 == 0 ? r : 0; }
+inline int tape_tile_hi(int nq, int mt, int bm)            // one past the last row a tile can hold (not clipped to nq)
+{
+    const int row0 = tape_row0(nq, bm);
+    return row0 > 0 ? row0 + mt * bm : (mt + 1) * bm;
+}
+inline int tape_tile_stages(const TapeProblem& p, int mt, int bm, int bk) { return std::min((tape_tile_hi(p.nq, mt, bm) + bk - 1) / bk, p.nq_pad / bk); }
+
 struct Tape {
     std::vector<GemmWork> work;     // every block's entries, block after block
     std::vector<int32_t> queue;     // [n_blocks + 1]: block p walks work[queue[p]] .. work[queue[p + 1] - 1]
@@ -53,8 +67,8 @@ inline Tape plan_quad_tape(const std::vector<TapeProblem>& probs, int tn, int bl
     struct Range { int prob, mt, stages; };
     std::vector<Range> ranges;
     for (size_t q = 0; q < probs.size(); ++q) {
-        const int tm = (probs[q].nq + bm - 1) / bm, kmax_all = probs[q].nq_pad / bk;
-        for (int mt = 0; mt < tm; ++mt) ranges.push_back({(int)q, mt, std::min(((mt + 1) * bm + bk - 1) / bk, kmax_all)});
+        const int tm = (probs[q].nq + bm - 1) / bm;
+        for (int mt = 0; mt < tm; ++mt) ranges.push_back({(int)q, mt, tape_tile_stages(probs[q], mt, bm, bk)});
     }
     std::stable_sort(ranges.begin(), ranges.end(), [](const Range& a, const Range& b) { return a.stages > b.stages; });
     // Blocks work in lock-step groups of `gs` (4 when the walker tiles allow it): the members of a group walk the SAME
@@ -200,12 +214,12 @@ inline std::string check_quad_tape(const Tape& T, const std::vector<TapeProblem>
     }
     for (auto u : slot_used) if (!u) return "slot never written";
     for (size_t q = 0; q < probs.size(); ++q) {
-        const int tm = (probs[q].nq + bm - 1) / bm, kmax_all = probs[q].nq_pad / bk;
+        const int tm = (probs[q].nq + bm - 1) / bm;
         for (int mt = 0; mt < tm; ++mt)
             for (int nt = 0; nt < tn; ++nt) {
                 auto v = seg[q][(size_t)mt * tn + nt];
                 std::sort(v.begin(), v.end());
-                const int want = std::min(((mt + 1) * bm + bk - 1) / bk, kmax_all) * bk;
+                const int want = tape_tile_stages(probs[q], mt, bm, bk) * bk;
                 int at = 0;
                 for (auto& s : v) { if (s.first != at) return "K range has a gap or an overlap"; at = s.second; }
                 if (at != want) return "K range not covered to its end";
@@ -219,8 +233,8 @@ inline std::string check_quad_tape(const Tape& T, const std::vector<TapeProblem>
         for (size_t j = 1; j < mine.size(); ++j) {
             const GemmWork &a = *mine[j - 1], &b = *mine[j];
             if (a.prob == b.prob && a.mt == b.mt) { if (b.kbeg != a.kend) return "segments of a K range out of slot order"; continue; }
-            const int la = std::min(((a.mt + 1) * bm + bk - 1) / bk, probs[a.prob].nq_pad / bk);
-            const int lb = std::min(((b.mt + 1) * bm + bk - 1) / bk, probs[b.prob].nq_pad / bk);
+            const int la = tape_tile_stages(probs[a.prob], a.mt, bm, bk);
+            const int lb = tape_tile_stages(probs[b.prob], b.mt, bm, bk);
             if (lb > la) return "row tiles out of tape order (long rows first)";
             if (b.kbeg != 0) return "a K range starts in the middle";
         }
