@@ -1,4 +1,6 @@
-"""Experiment build (-DVMX_EPI_TRACE): where the contraction epilogue of the quadratic-form launch spends its time."""
+"""Where the contraction epilogue of the quadratic-form launch spends its time.  Needs an experiment build of the library:
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DVMX_EPI_TRACE -o build_exp/libvegamx_epi.so vega_amd/csrc/vegamx.hip
+    VEGAMX_LIBRARY=$PWD/build_exp/libvegamx_epi.so python scripts/gpu_epi_trace.py"""
 import os, sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent

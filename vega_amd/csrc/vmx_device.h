@@ -2595,6 +2595,9 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
     const bool list = persist;
     const unsigned long long t_start = G.trace ? wall_clock64() : 0ull;
     unsigned long long t_first = 0ull, t_loop = 0ull;
+#ifdef VMX_EPI_TRACE
+    unsigned long long t_e1 = 0ull, t_e2 = 0ull;
+#endif
     GemmWork wk{};
     int bx = blockIdx.x, by = blockIdx.y;
     if constexpr (TAG == VMX_TAG_FFTLOG) {
@@ -2848,8 +2851,14 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
             // m = c_m0 + wm + 16 jg + c after the rotations below
             const int c = lane & 15, r = lane >> 4;
             const bool first_seg = kbeg_c == 0;
+#ifdef VMX_EPI_TRACE      /* experiment build (scripts/gpu_epi_trace.py): the block trace then holds the LAST entry's epilogue phases */
+            if (G.trace) t_first = wall_clock64();
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                // E has landed for every wave
+#ifdef VMX_EPI_TRACE
+            if (G.trace) t_e1 = wall_clock64();
+#endif
             if (epi_buf < 0) {              // an empty K range (never a tile's first segment): nothing was multiplied
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -2889,6 +2898,9 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
                 sum = row_sum16(sum);
                 if (c == 0) c_part[((size_t)c_slot * 64 + wn + 4 * i + r) * 2 + (wave & 1)] = n < c_N ? sum : 0.0;
             }
+#ifdef VMX_EPI_TRACE
+            if (G.trace) t_e2 = wall_clock64();
+#endif
             continue;
         }
     }
@@ -2913,7 +2925,11 @@ __global__ __launch_bounds__(GEMM44_THREADS, NBUF == 2 ? GEMM44_THREADS / 128 : 
   }
     if (G.trace && threadIdx.x == 0 && !skip) {
         unsigned long long* tr = G.trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+#ifdef VMX_EPI_TRACE
+        tr[0] = t_loop; tr[1] = t_first; tr[2] = t_e1; tr[3] = t_e2;      // K loop done, epilogue entered, E landed + barrier, reductions done
+#else
         tr[0] = t_start; tr[1] = t_first; tr[2] = t_loop; tr[3] = wall_clock64();
+#endif
     }
 }
 
