@@ -2482,17 +2482,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmGroup G)
   }
 }
 
-// DPP row rotation of a double (two dword moves); CTRL = 0x120 + r is row_ror:r within each 16-lane row
-template <int CTRL>
-__device__ __forceinline__ double dpp_row_rotate(double v)
-{
-    const long long bits = __builtin_bit_cast(long long, v);
-    int lo = (int)bits, hi = (int)(bits >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-
 // v of lane (l ^ MASK), MASK < 32: ds_swizzle in bit mode - an LDS-crossbar instruction (no LDS memory, no VALU slot)
 template <int MASK>
 __device__ __forceinline__ double lane_xor(double v)
@@ -2512,8 +2501,11 @@ __device__ __forceinline__ double dpp_move(double v)
 {
     const long long bits = __builtin_bit_cast(long long, v);
     int lo = (int)bits, hi = (int)(bits >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // (mov_dpp, not update_dpp(lo, lo, ...): every lane is written - full row and bank masks, rotations and permutations have
+    // no invalid source - so there is no "old" value to keep, and without one the compiler needs no copy in front of each move:
+    // 300 of the contraction epilogue's 1500 instructions were such copies)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 // sum over the 16 lanes of a row, the total in every lane: row rotations by 8 and 4 (after the first step lanes l and
