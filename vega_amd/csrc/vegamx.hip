@@ -1424,7 +1424,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
                     t.damping_power = d.damping_power; t.damping_scale = d.damping_scale;
                     e->tab2_groups.push_back(t);          // (col_s / col_q: once the active columns are numbered)
                 }
-            std::vector<double> key((size_t)e->n_xtab * VMX_XTAB_KEY + 1, std::nan(""));
+            std::vector<double> key((size_t)2 * e->n_xtab * VMX_XTAB_KEY + 1, std::nan(""));     // [held][seen by the running evaluation]
             if (e->d_xtab_pipe.upload(xp.data(), xp.size()) || e->d_xtab_partner.upload(xq.data(), xq.size()) ||
                 e->xtab_key.upload(key.data(), key.size())) return -2;
             e->host_key_valid = false; e->pending_key.clear();
@@ -1944,36 +1944,49 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
     D.n_const_slots = tab_mode >= 2 ? (int)e->const_slots2.size() : tab_mode ? (int)e->const_slots.size() : 0;
     if (tab_mode >= 2) D.const_slots = e->d_const_slots2.p;
     if (zero_copy) {
-        D.theta_host = e->dpin_theta; D.theta_copy = e->theta.p; D.src_lds = 1;
+        D.theta_host = e->dpin_theta; D.theta_copy = e->theta.p; D.src_host = 1;
         D.chi2_host = e->dpin_chi2; D.status_host = e->dpin_status;
     } else if (d_theta) {
         // device entry point, eager launches: the first kernel reads the caller's walkers in place and the last one
         // writes the caller's outputs - no staging copies
-        D.theta_host = d_theta; D.theta_copy = e->theta.p; D.src_lds = 0;
+        D.theta_host = d_theta; D.theta_copy = e->theta.p; D.src_host = 0;
         D.chi2_host = d_chi2; D.status_host = d_status;
     }
     if (theta_by_value && zero_copy && B == 1 && e->dpin_done && !e->profiling) { D.done_host = e->dpin_done; D.done_seq = ++e->done_seq; }
     const int n_pipe = D.n_pipe;
+    const bool skip_xtab = e->skip_xtab_once;
+    e->skip_xtab_once = false;
+    bool xtab_launched = !(tab_mode && !skip_xtab);
+    D.xtab_block0 = 0;
     {
         ScopedTimer t(e, KC_PROLOGUE);
-        const int n_thr = B * (n_pipe + 1);
-        // the pipeline descriptors + the constant-slot list with walker 0's values + the mu rule's box, staged in LDS by every block
-        const size_t desc_bytes = (size_t)n_pipe * sizeof(PipeDev) + ((size_t)2 * D.n_const_slots + (size_t)3 * e->rule_slot.size()) * sizeof(double);
+        // grid = (n_pipe + 1 slots) x (chunks of PRO_T walkers) [+ the blocks that check the P(k,mu) tables against walker 0:
+        // k_xtab's grid, flattened]; LDS of a block: the constant-slot list with walker 0's values,
+        // the mu rule's box, its walkers
+        const int n_pro = (n_pipe + 1) * ((B + PRO_T - 1) / PRO_T);
+        const size_t lds = ((size_t)2 * D.n_const_slots + (size_t)3 * e->rule_slot.size() + (size_t)PRO_T * (e->n_params | 1)) * sizeof(double);
+        int n_tab = 0;
+        // (walkers in mapped host memory: a thousand table blocks would each cross PCIe for walker 0 - k_xtab follows instead)
+        if (!xtab_launched && !(zero_copy && !theta_by_value)) {
+            const int rows = XTAB_ROWS * (256 / PRO_T);
+            n_tab = ((e->nkp + PRO_T - 1) / PRO_T) * ((e->n_rows + rows - 1) / rows) * e->n_xtab;
+            D.xtab_block0 = n_pro;
+            xtab_launched = true;
+        }
+#ifdef VMX_EXP_PRO_TRACE
+        if (getenv("VMX_PK_TRACE")) {
+            if (!e->pk_trace.p && e->pk_trace.alloc(65536, true)) return -2;
+            e->pk_trace_blocks = 2 * (size_t)n_pro;
+            D.pk_trace = e->pk_trace.p;
+        }
+#endif
         if (zero_copy && theta_by_value) {
             // (eager launches only: a captured graph would replay the walker it was captured with)
             ThetaArg ta;
             std::memcpy(ta.v, theta_by_value, (size_t)B * e->n_params * sizeof(double));
-            hipLaunchKernelGGL(k_prologue_byval, dim3(1), dim3((n_thr + 63) / 64 * 64), desc_bytes + (size_t)B * e->n_params * sizeof(double), e->stream, D, B, ta);
-        } else if (zero_copy)      // one block holds every walker of the (small) batch in LDS
-            hipLaunchKernelGGL(k_prologue, dim3(1), dim3((n_thr + 63) / 64 * 64), desc_bytes + (size_t)B * e->n_params * sizeof(double), e->stream, D, B);
-        else
-        {
-            // (+ the rows of the block's walkers, staged next to the descriptors when theta is read from a device buffer)
-            // (blocks of PRO_T threads: the descriptors are staged once per block)
-            const int PRO_T = n_pipe >= 8 ? 256 : 64;     // (measured: 19 against 22 us with 5 slots per walker, 40 against 44 with 24)
-            const size_t rows_bytes = (size_t)(PRO_T / (n_pipe + 1) + 2) * e->n_params * sizeof(double);
-            hipLaunchKernelGGL(k_prologue, dim3((n_thr + PRO_T - 1) / PRO_T), dim3(PRO_T), desc_bytes + rows_bytes, e->stream, D, B);
-        }
+            hipLaunchKernelGGL(k_prologue_byval, dim3(n_pro + n_tab), dim3(PRO_T), lds, e->stream, ta, D, B);
+        } else
+            hipLaunchKernelGGL(k_prologue, dim3(n_pro + n_tab), dim3(PRO_T), lds, e->stream, D, B);
     }
     {
         ScopedTimer t(e, KC_PK);
@@ -1990,9 +2003,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         int mu_tab_off = want_mu_tab ? (int)(shmem / sizeof(double)) : -1;
         if (want_mu_tab) shmem += (size_t)2 * e->n_mu * sizeof(double);
         const int n_groups = (int)e->pk_groups.size();
-        const bool skip_xtab = e->skip_xtab_once;
-        e->skip_xtab_once = false;
-        if (tab_mode && !skip_xtab)
+        if (!xtab_launched)
             hipLaunchKernelGGL(k_xtab, dim3((e->nkp + 255) / 256, (e->n_rows + XTAB_ROWS - 1) / XTAB_ROWS, e->n_xtab), dim3(256), 0, e->stream, D);
         if (!e->pk_poly.empty())
             hipLaunchKernelGGL(k_pk_poly, dim3(B, (int)e->pk_poly.size()), dim3(256), 0, e->stream, D, e->d_pk_poly.p, B);
@@ -2002,7 +2013,12 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         if (tab_mode >= 2 && e->n_xtab > 0) {
             n_other = n_groups - e->n_xtab;
             const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
+#ifdef VMX_EXP_PRO_TRACE       // (experiment build: the trace buffer holds k_prologue's stamps, scripts/gpu_pro_trace.py)
+            D.pk_trace = nullptr;
+            if (false) {
+#else
             if (getenv("VMX_PK_TRACE")) {
+#endif
                 e->pk_trace_blocks = (size_t)B * ((e->nk + 7) / 8) * e->tab2_groups.size();     // (an upper bound: unused entries stay zero)
                 if (!e->pk_trace.p && e->pk_trace.alloc(4 * (size_t)e->max_batch * ((e->nk + 7) / 8) * e->tab2_groups.size(), true)) return -2;
                 D.pk_trace = e->pk_trace.p;
@@ -2724,7 +2740,7 @@ static vmx_engine* clone_lane(vmx_engine* e)
         if (L->coef_win.upload(empty_window, 2)) return fail_out();
     }
     if (e->n_xtab > 0) {
-        std::vector<double> key((size_t)e->n_xtab * VMX_XTAB_KEY + 1, std::nan(""));
+        std::vector<double> key((size_t)2 * e->n_xtab * VMX_XTAB_KEY + 1, std::nan(""));
         if (L->xtab.alloc(((size_t)e->n_xtab * 2 * e->n_rows + 128) * e->nkp, true) || L->xtab_k.alloc((size_t)e->n_xtab * 4 * e->nkp, true) ||
             L->xtab_key.upload(key.data(), key.size())) return fail_out();
     }

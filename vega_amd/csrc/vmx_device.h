@@ -171,6 +171,7 @@ struct EngineDev {
     // [tables][VMX_XTAB_KEY], written by the chi2 kernel of the evaluation that built it), recomputes a stale table and
     // leaves a current one alone.  xtab_k [tables][4][nkp]: per wavenumber the Arinyo part of e0, e2, the error flag, the (level-2) bound of the exponents.
     const int32_t* xtab_pipe; const int32_t* xtab_partner; int32_t n_xtab; int32_t xtab_level; double* xtab_key; double* xtab_k;
+    int32_t xtab_block0;        // k_prologue: first of the table blocks behind the walkers' (0: k_xtab is its own launch)
     const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
     int32_t n_gk;
     // fftlog / spline
@@ -201,11 +202,11 @@ struct EngineDev {
     // batch buffers
     int32_t n_params;
     const double* theta;        // [B][n_params]
-    // small host batches skip the staging copies: k_prologue reads the walkers from mapped pinned host memory and
-    // leaves a device copy in `theta_copy` (= theta) for the later kernels; k_chi2 stores its results to host too
+    // theta_host: the walkers are elsewhere - mapped pinned host memory (small host batches skip the staging copies) or the
+    // caller's device buffer, read in place (large batches, eager launches): k_prologue reads them there and leaves a device
+    // copy in `theta_copy` (= theta) for the later kernels; k_chi2 stores its results to chi2_host / status_host too
     const double* theta_host; double* theta_copy; double* chi2_host; int32_t* status_host;
-    int32_t src_lds;            // 1: theta_host is mapped host memory, staged through LDS by one block (tiny batches);
-                                // 0: theta_host is the caller's device buffer, read in place (large batches, eager launches)
+    int32_t src_host;           // theta_host is mapped host memory (a batch of at most 8 walkers)
     double* scal;               // [B][n_pipe][VMX_NS]
     double* metal_bias;         // [B][3][n_metals_total]: bias product x multiplicity, beta1 + beta2, beta1 * beta2
     double beta_override; int32_t beta_override_on;      // set-up hook: betas of the bias-free metal pipelines
@@ -242,10 +243,12 @@ struct SlabInfo { int32_t z[16]; int32_t g; };
 // ------------------------------------------------------------------------------------------------
 // prologue: parameters -> scalars
 // ------------------------------------------------------------------------------------------------
+#define VMX_CAS __attribute__((address_space(4)))      // constant address space: uniform reads become scalar loads
 __device__ inline double th(const double* t, int slot, double dflt) { return slot >= 0 ? t[slot] : dflt; }
 
-__device__ inline void tracer_bias_beta(const double* t, const vmx_tracer& tr, double gr,
-                                        double& bias, double& beta)
+// (TR: vmx_tracer in any address space)
+template <class TR>
+__device__ inline void tracer_bias_beta(const double* t, TR& tr, double gr, double& bias, double& beta)
 {
     // reference vega/utils.py:45-82
     const bool has_bias = tr.bias_slot >= 0, has_eta = tr.bias_eta_slot >= 0, has_beta = tr.beta_slot >= 0;
@@ -270,79 +273,131 @@ __global__ void k_theta_affine(double* theta, const double* tr, int n_params, in
 // A single walker through the host entry point travels in the kernel arguments (no read of mapped host memory over
 // PCIe at the head of a latency-bound chain); up to this many parameters.
 #define VMX_THETA_ARG_MAX 160
+#define PRO_T 64           // threads of a k_prologue block = walkers of one slot
 struct ThetaArg { double v[VMX_THETA_ARG_MAX]; };
 
-template <bool BYVAL>
-__device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const ThetaArg* ta)
+// exponents of the Gaussian factors exp(-k^2 (gb + (ga - gb) mu^2)) of a pipeline: peak broadening (reference
+// power_spectrum.py:395-402), Gaussian smoothing (:526-556) and Gaussian velocity dispersion.  One function for k_prologue's
+// scalars and for the key of the level-2 tables (the table blocks form walker 0's values themselves).
+template <class PD>
+__device__ __forceinline__ void gauss_exponents(const double* t, PD& d, double gr, double& ga, double& gb)
 {
-    // thread = (walker, slot): slots 0 .. n_pipe-1 fill one pipeline's scalars, slot n_pipe the walker-level values
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = gid / (D.n_pipe + 1), slot = gid % (D.n_pipe + 1);
-    __shared__ int s_win[2 * 16];               // per wave: spline-coefficient window of its (walker, pipeline) threads
-    if ((threadIdx.x & 63) == 0) { s_win[2 * (threadIdx.x >> 6)] = 0x7fffffff; s_win[2 * (threadIdx.x >> 6) + 1] = -1; }
-    if (gid == 0) { D.k_live[0] = 0; D.k_live[1] = 0; }
-    // LDS: [pipeline descriptors][walkers of a zero-copy batch].  The descriptors are read dozens of times behind
-    // data-dependent branches; from global memory every such read is its own round trip (~10 us of a single-walker
-    // chain), so the block stages them once.
-    extern __shared__ double s_dyn[];
-    const int n_desc = D.n_pipe * (int)(sizeof(PipeDev) / sizeof(double));
-    {
-        const double* src = (const double*)D.pipes;
-        for (int i = threadIdx.x; i < n_desc; i += blockDim.x) s_dyn[i] = src[i];
+    ga = 0.0; gb = 0.0;
+    if (d.peak_nl) {
+        double sp, st;
+        if (d.sigma_nl_par_slot >= 0 && d.sigma_nl_per_slot >= 0) { sp = t[d.sigma_nl_par_slot]; st = t[d.sigma_nl_per_slot]; }
+        else if (d.sigma_nl_par_slot >= 0) { sp = t[d.sigma_nl_par_slot]; st = sp / (1.0 + gr); }
+        else { st = t[d.sigma_nl_per_slot]; sp = st * (1.0 + gr); }
+        ga += 0.5 * sp * sp; gb += 0.5 * st * st;
     }
-    const PipeDev* s_pipes = (const PipeDev*)s_dyn;
-    // ... and the two small lists the walker loops below walk - the slots that must be constant across the batch (with walker
-    // 0's values at them) and the box of the mu rule: read from global memory inside those loops every element is its own
-    // dependent round trip.  Where the kernel's time goes at B = 256 (experiment builds, rocprofv3 kernel trace, round 4): an
-    // empty kernel 4.8 us, + the staging loads and their barrier 8.7, + everything else 16.4 - of which the window's logarithms
-    // and atomics 2.3 and the 40 scalar stores per thread 0.8; the rest is the chain of dependent LDS look-ups descriptor ->
-    // slot -> parameter behind data-dependent branches.
+    for (int i = 0; i < d.n_smooth; ++i) {
+        const double sp = t[d.smooth_par_slot[i]], st = t[d.smooth_per_slot[i]];
+        ga += d.smooth_weight[i] * sp * sp; gb += d.smooth_weight[i] * st * st;
+    }
+    if (d.vd_kind == VMX_VD_GAUSS)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (d.tracer[q].discrete) { const double sg = t[d.tracer[q].vd_sigma_slot]; ga += 0.25 * sg * sg; }
+}
+
+#define XTAB_ROWS 8         // table rows per 256 threads of a table block
+__device__ __forceinline__ double vmx_log(double x);
+__device__ void xtab_body(const EngineDev& D, int xtab, int bx, int by, int rows_per_block, const double* t0);
+
+template <bool BYVAL>
+__device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
+{
+    // where the walkers are: the kernel arguments (single evaluation), mapped host memory (small host batches: one PCIe round
+    // trip per block, all blocks at once), the caller's device buffer (read in place) or the engine's own copy
+    // (BYVAL: ThetaArg is the kernel's FIRST argument and is read where it lies, at the start of the kernel-argument segment -
+    // global memory; taken by address as a parameter the compiler copies it to scratch, in every wave of the grid)
+    const double* src_all = BYVAL ? (const double*)__builtin_amdgcn_kernarg_segment_ptr() : D.theta_host ? D.theta_host : D.theta;
+    if (D.xtab_block0 > 0 && (int)blockIdx.x >= D.xtab_block0) {
+        // The blocks behind the walkers' own check the level-2 / level-1 tables against walker 0 (k_xtab's work, in this launch:
+        // a launch of its own costs ~5 us of an evaluation whose tables are current nearly always).  They read walker 0 from
+        // the source the walker blocks read it from; nothing of this launch's output.
+        const int rows_per_block = XTAB_ROWS * (256 / PRO_T);
+        const int nbx = (D.nkp + PRO_T - 1) / PRO_T, nby = (D.n_rows + rows_per_block - 1) / rows_per_block;
+        const int q = (int)blockIdx.x - D.xtab_block0;
+        xtab_body(D, q / (nbx * nby), q % nbx, (q / nbx) % nby, rows_per_block, src_all);
+        return;
+    }
+    // block = (slot, 64 walkers): slots 0 .. n_pipe-1 fill one pipeline's scalars, slot n_pipe the walker-level values.  A wave
+    // serves ONE slot: every branch on the pipeline's descriptor is uniform (with the walker's slots side by side in a wave it
+    // walked every pipeline's path in turn), and the descriptor reads are broadcasts.
+#ifdef VMX_EXP_PRO_TRACE
+#define PRO_STAMP(I) do { if (threadIdx.x == 0 && D.pk_trace) D.pk_trace[8 * blockIdx.x + (I)] = wall_clock64(); } while (0)
+#else
+#define PRO_STAMP(I) do {} while (0)
+#endif
+    PRO_STAMP(0);
+    const int n_chunk = (B + PRO_T - 1) / PRO_T;
+    const int slot = (int)blockIdx.x / n_chunk, b_first = ((int)blockIdx.x % n_chunk) * PRO_T;
+    const int b = b_first + (int)threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { D.k_live[0] = 0; D.k_live[1] = 0; }
+    // The slot's pipeline descriptor is read dozens of times ahead of data-dependent branches.  It is static and the slot is
+    // the block's: through the constant address space those reads are scalar loads (batched by the compiler, cached) and the
+    // branches scalar branches - from LDS or global memory every one of them was a vector round trip the next read waited for.
+    const VMX_CAS PipeDev& P = *(const VMX_CAS PipeDev*)(D.pipes + min(slot, D.n_pipe - 1));
+    // LDS: [constant-slot list with walker 0's values][rule box][the block's walkers] - the lists the walker loops below walk
+    // (from global memory every element of theirs is a dependent round trip inside the loop) and the parameters
+    extern __shared__ double s_dyn[];
     const int n_cs = D.n_const_slots, n_ru = D.n_rule;
-    double* s_c0 = s_dyn + n_desc;              // [n_cs] walker 0's values at the constant slots (device entries)
+    double* s_c0 = s_dyn;                       // [n_cs] walker 0's values at the constant slots
     double* s_cs = s_c0 + n_cs;                 // [n_cs] the slots
     double* s_ru = s_cs + n_cs;                 // [3][n_ru] slot, lower and upper bound of the rule's box
-    double* s_theta = s_ru + 3 * n_ru;
-    const double* t = D.theta + (size_t)b * D.n_params;
-    const double* t0 = D.theta_host ? D.theta_host : D.theta;         // walker 0: table keys and the constant-parameter check
-    const bool t0_in_lds = BYVAL || (D.theta_host && D.src_lds);
-    for (int i = threadIdx.x; i < n_cs; i += blockDim.x) {
-        const int sl = D.const_slots[i];
-        s_cs[i] = (double)sl;
-        if (!t0_in_lds) s_c0[i] = t0[sl];
-    }
-    for (int i = threadIdx.x; i < n_ru; i += blockDim.x) {
-        s_ru[i] = (double)D.rule_slot[i]; s_ru[n_ru + i] = D.rule_lo[i]; s_ru[2 * n_ru + i] = D.rule_hi[i];
-    }
-    if (BYVAL || (D.theta_host && D.src_lds)) {
-        // zero-copy entry (small batches, one block): one coalesced read of the walkers - from the kernel arguments, or
-        // from mapped host memory in a single PCIe round trip - into LDS, and the device copy for later kernels
-        const int count = B * D.n_params;
-        for (int i = threadIdx.x; i < count; i += blockDim.x) {
-            const double v = BYVAL ? ta->v[i] : D.theta_host[i];
-            s_theta[i] = v; D.theta_copy[i] = v;
+    double* s_theta = s_ru + 3 * n_ru;          // [PRO_T][n_params | 1] the block's walkers (odd stride: the lanes of a wave read
+    const int t_ld = D.n_params | 1;            // the same parameter of 64 walkers)
+    // This kernel's blocks are single waves that run their code once: its time is the instruction FETCH (every 64 bytes of
+    // straight-line code is an instruction-cache miss, ~2.5 ns per instruction against 0.5 in a hot loop - block time stamps,
+    // round 4), so the loops below stay rolled and short.
+    const int rows = min(B, b_first + PRO_T) - b_first;
+    {
+        // the walkers' rows.  From device memory: direct global -> LDS copies, one wave instruction per row and 64 dwords of it,
+        // all in flight together (no staging registers: a rolled loop).  The few walkers of a batch in the kernel arguments or in
+        // mapped host memory: ordinary loads, four per thread in flight (one trip over PCIe for up to 256 parameters).
+        if (BYVAL || D.src_host) {
+            const int count = rows * D.n_params;
+            const double* src = src_all + (size_t)b_first * D.n_params;
+            for (int i0 = threadIdx.x; i0 < count; i0 += 4 * PRO_T) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * PRO_T; v[u] = i < count ? src[i] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * PRO_T; if (i < count) s_theta[(i / D.n_params) * t_ld + i % D.n_params] = v[u]; }
+            }
+        } else {
+            const int nd = 2 * D.n_params;              // dwords of a row
+            const char* src = (const char*)(src_all + (size_t)b_first * D.n_params);
+            for (int c0 = 0; c0 < nd; c0 += PRO_T)
+                if (c0 + (int)threadIdx.x < nd)
+                    for (int r = 0; r < rows; ++r)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((size_t)r * nd + c0 + threadIdx.x) * 4),
+                                                         (__attribute__((address_space(3))) void*)((char*)(s_theta + r * t_ld) + c0 * 4), 4, 0, 0);
         }
-        t = s_theta + (size_t)b * D.n_params;
-        t0 = s_theta;           // (no second trip over PCIe for walker 0)
+        // the lists (slot n_pipe: the constant slots with walker 0's values; the others: the rule's box)
+        if (slot == D.n_pipe)
+            for (int i = threadIdx.x; i < n_cs; i += PRO_T) { const int q = D.const_slots[i]; s_cs[i] = (double)q; s_c0[i] = src_all[q]; }
+        else
+            for (int i = threadIdx.x; i < n_ru; i += PRO_T) { s_ru[i] = (double)D.rule_slot[i]; s_ru[n_ru + i] = D.rule_lo[i]; s_ru[2 * n_ru + i] = D.rule_hi[i]; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    else if (!BYVAL && D.theta_host && !D.src_lds) {
-        // device entry: the caller's buffer is read in place.  The rows of this block's walkers are requested together with
-        // the descriptors (one round trip instead of two) and land in LDS; the copy the later kernels use leaves from there.
-        const int b_first = (int)(blockIdx.x * blockDim.x) / (D.n_pipe + 1);
-        const int b_last = min(B - 1, (int)(blockIdx.x * blockDim.x + blockDim.x - 1) / (D.n_pipe + 1));
-        const int count = (b_last - b_first + 1) * D.n_params;
-        const double* src = D.theta_host + (size_t)b_first * D.n_params;
-        for (int i = threadIdx.x; i < count; i += blockDim.x) {
-            const double v = src[i];
-            s_theta[i] = v; D.theta_copy[(size_t)b_first * D.n_params + i] = v;
-        }
-        if (b < B) t = s_theta + (size_t)(b - b_first) * D.n_params;
-    }
+    PRO_STAMP(7);
+    // (a surplus lane of the last chunk shadows the chunk's last walker and stores nothing: the wave reductions below see 64 lanes)
+    const bool live = b < B;
+    const double* t = s_theta + (size_t)min((int)threadIdx.x, B - 1 - b_first) * t_ld;
     __syncthreads();
-    if (b >= B) return;
+    PRO_STAMP(1);
+    if (slot == 0 && (BYVAL || D.theta_host)) {
+        // the copy the later kernels use leaves from LDS
+        double* dst = D.theta_copy + (size_t)b_first * D.n_params;
+        for (int r = 0; r < rows; ++r)
+            for (int c = threadIdx.x; c < D.n_params; c += PRO_T) dst[r * D.n_params + c] = s_theta[r * t_ld + c];
+    }
 
     if (slot < D.n_pipe) {
         const int p = slot;
-        const vmx_pipe_desc& d = s_pipes[p].d;
+        const auto& d = P.d;
         // the scalars are collected in registers and stored at the end: with stores in between, the compiler has to keep
         // every parameter load behind the previous store (the pointers may alias) - ~30 dependent L2 round trips
         double s[VMX_NS];
@@ -370,28 +425,17 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
             s[S_HCD_B] = bh; s[S_HCD_BB] = bh * beh; s[S_HCD_L0] = th(t, d.l0_hcd_slot, d.l0_default);
         }
 
-        double ga = 0.0, gb = 0.0;
-        if (d.peak_nl) {
-            // reference power_spectrum.py:395-402
-            double sp, st;
-            if (d.sigma_nl_par_slot >= 0 && d.sigma_nl_per_slot >= 0) { sp = t[d.sigma_nl_par_slot]; st = t[d.sigma_nl_per_slot]; }
-            else if (d.sigma_nl_par_slot >= 0) { sp = t[d.sigma_nl_par_slot]; st = sp / (1.0 + gr); }
-            else { st = t[d.sigma_nl_per_slot]; sp = st * (1.0 + gr); }
-            ga += 0.5 * sp * sp; gb += 0.5 * st * st;
-        }
-        for (int i = 0; i < d.n_smooth; ++i) {
-            const double sp = t[d.smooth_par_slot[i]], st = t[d.smooth_per_slot[i]];
-            ga += d.smooth_weight[i] * sp * sp; gb += d.smooth_weight[i] * st * st;
-        }
+        double ga, gb;
+        gauss_exponents(t, d, gr, ga, gb);
         if (d.exp_par_slot >= 0) { const double a = t[d.exp_par_slot], c = t[d.exp_per_slot]; s[S_EA] = a * a; s[S_EB] = c * c; }
+        if (d.vd_kind != VMX_VD_NONE && d.vd_kind != VMX_VD_GAUSS)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const vmx_tracer& tr = d.tracer[q];
-            if (d.vd_kind == VMX_VD_NONE || !tr.discrete) continue;
-            const double sg = t[tr.vd_sigma_slot];
-            if (d.vd_kind == VMX_VD_GAUSS) ga += 0.25 * sg * sg;
-            else s[q == 0 ? S_VD1 : S_VD2] = sg * sg;
-        }
+            for (int q = 0; q < 2; ++q) {
+                const auto& tr = d.tracer[q];
+                if (!tr.discrete) continue;
+                const double sg = t[tr.vd_sigma_slot];
+                s[q == 0 ? S_VD1 : S_VD2] = sg * sg;
+            }
         s[S_GA] = ga; s[S_GB] = gb;
 
         if (d.nl_model == VMX_NL_ARINYO) {
@@ -412,22 +456,22 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
         }
         s[S_AP] = ap; s[S_AT] = at;
         s[S_DRP] = th(t, d.drp_slot, 0.0);
+        PRO_STAMP(2);
         {
             // Spline coefficients this (walker, pipeline) can read: r'^2 = ap^2 (rp + drp)^2 + at^2 rt^2 over its bins is
             // bounded by the extremes of |rp|, rt (|rp + drp| lies in [max(0, |rp| - |drp|), |rp| + |drp|]); the FFTLog
             // product computes the rows inside the batch's window only.  NaN / out-of-range inputs open the window fully.
-            const PipeDev& P = s_pipes[p];
             const double adrp = fabs(s[S_DRP]);
             const double lo_rp = fmax(P.rp_absmin - adrp, 0.0), hi_rp = P.rp_absmax + adrp;
             const double r2lo = ap * ap * lo_rp * lo_rp + at * at * P.rt_min * P.rt_min;
             const double r2hi = ap * ap * hi_rp * hi_rp + at * at * P.rt_max * P.rt_max;
             int jlo = 0, jhi = D.n_coef - 1;
             if (r2lo > 0.0 && r2hi >= r2lo && r2hi < 1e300) {
-                const double xlo = 0.5 * log(r2lo), xhi = 0.5 * log(r2hi);
+                const double xlo = 0.5 * vmx_log(r2lo), xhi = 0.5 * vmx_log(r2hi);
                 double ulo = 1e300, uhi = -1e300;
                 for (int e = 0; e < d.n_ell; ++e) {
-                    ulo = fmin(ulo, (xlo - D.x0[e]) / D.h[e]);
-                    uhi = fmax(uhi, (xhi - D.x0[e]) / D.h[e]);
+                    ulo = fmin(ulo, (xlo - D.x0[e]) * D.inv_h[e]);
+                    uhi = fmax(uhi, (xhi - D.x0[e]) * D.inv_h[e]);
                 }
                 if (ulo > -1e9 && uhi < 1e9) {
                     jlo = max(0, (int)floor(ulo) - 2);
@@ -435,20 +479,19 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
                 }
             }
             if (P.odd_rel || P.odd_asy || D.extrapolate) { jlo = 0; jhi = D.n_coef - 1; }
-            // one pair of global atomics per wave, not per thread (2 x 1280 atomics on two addresses took ~20 us): the
-            // wave's lanes meet in its own LDS slot first; LDS operations of a wave complete in order
-            int* w_win = s_win + 2 * (threadIdx.x >> 6);
-            atomicMin(&w_win[0], jlo);
-            atomicMax(&w_win[1], jhi);
-            const unsigned long long here = __ballot(1);
-            if ((threadIdx.x & 63) == __ffsll((long long)here) - 1) {
-                atomicMin(&D.coef_win[0], w_win[0]);
-                atomicMax(&D.coef_win[1], w_win[1]);
+            // one pair of global atomics per wave, not per thread (2 x 1280 atomics on two addresses took ~20 us): the lanes'
+            // windows meet in a butterfly first (as LDS atomics the compiler reduces them in a 64-step scalar loop)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { jlo = min(jlo, __shfl_xor(jlo, m)); jhi = max(jhi, __shfl_xor(jhi, m)); }
+            if (threadIdx.x == 0) {
+                atomicMin(&D.coef_win[0], jlo);
+                atomicMax(&D.coef_win[1], jhi);
             }
         }
+        PRO_STAMP(3);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const vmx_tracer& tr = d.tracer[q];
+            const auto& tr = d.tracer[q];
             double a, c = 0.0;
             if (tr.evol_kind == VMX_EVOL_CROOM) { a = t[d.croom_slot[0]]; c = t[d.croom_slot[1]]; }
             else a = t[tr.alpha_slot];
@@ -468,16 +511,20 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
                 outside = outside || !(v >= s_ru[n_ru + q] && v <= s_ru[2 * n_ru + q]);
             }
             s[S_NO_RULE] = outside ? 1.0 : 0.0;
-            if (outside && p == 0) atomicAdd(D.k_live + 4, 1);          // (a statistic: walkers that left the box, cumulative)
+            if (outside && p == 0 && live) atomicAdd(D.k_live + 4, 1);          // (a statistic: walkers that left the box, cumulative)
         }
+        PRO_STAMP(4);
         double* out = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+        if (live)
 #pragma unroll
-        for (int i = 0; i < VMX_NS; ++i) out[i] = s[i];
+            for (int i = 0; i < VMX_NS; ++i) out[i] = s[i];
+        PRO_STAMP(5);
     }
 
     // metal bias products (reference metals.py:295-313, :331-332) and the Kaiser coefficients of the static-basis metals
     // (the walker's n_pipe + 1 threads share the metals: one serial chain of 19 bias / beta look-ups per walker was a third of
     // this kernel at 23 pipelines)
+    if (!live) return;
     for (int m = slot; m < D.n_metals_total; m += D.n_pipe + 1) {
         const vmx_metal_desc& d = D.metals[m].d;
         double f = d.multiplicity;
@@ -495,16 +542,15 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B, const T
     if (slot < D.n_pipe) return;
 
     int st = 0;
-    for (int q = 0; q < n_cs; ++q) {
-        const int sl = (int)s_cs[q];
-        if (t[sl] != (t0_in_lds ? t0[sl] : s_c0[q])) st = VMX_STATUS_NOT_CONSTANT;
-    }
+    for (int q = 0; q < n_cs; ++q)
+        if (t[(int)s_cs[q]] != s_c0[q]) st = VMX_STATUS_NOT_CONSTANT;
     D.status[b] = st;
     D.chi2[b] = 0.0;
+    PRO_STAMP(6);
 }
 
-__global__ void k_prologue(EngineDev D, int B) { prologue_body<false>(D, B, nullptr); }
-__global__ void k_prologue_byval(EngineDev D, int B, ThetaArg ta) { prologue_body<true>(D, B, &ta); }
+__global__ __launch_bounds__(PRO_T) void k_prologue(EngineDev D, int B) { prologue_body<false>(D, B); }
+__global__ __launch_bounds__(PRO_T) void k_prologue_byval(ThetaArg, EngineDev D, int B) { prologue_body<true>(D, B); }
 
 // ------------------------------------------------------------------------------------------------
 // static G(k, mu) table
@@ -824,84 +870,86 @@ __device__ __forceinline__ void pk_w_loop(const PkThread& T, int ms, int j_lo, i
 
 #define VMX_XTAB_KEY 12
 // what the tables of group g depend on: {level, six Arinyo parameters, ga, gb of the pipeline, ga, gb of its peak partner}
-// of the batch's first walker (the scalars of k_prologue)
-__device__ inline void xtab_key_now(const EngineDev& D, int g, double* key)
+// of the batch's first walker t0 (the expressions of k_prologue's scalars)
+__device__ inline void xtab_key_now(const EngineDev& D, int g, double* key, const double* t0)
 {
     const int pipe = D.xtab_pipe[g], partner = D.xtab_partner[g];
     const vmx_pipe_desc& d = D.pipes[pipe].d;
     key[0] = (double)D.xtab_level;
-    for (int i = 0; i < 6; ++i) key[1 + i] = d.arinyo_slot[i] >= 0 ? D.theta[d.arinyo_slot[i]] : 0.0;
+    for (int i = 0; i < 6; ++i) key[1 + i] = d.arinyo_slot[i] >= 0 ? t0[d.arinyo_slot[i]] : 0.0;
     for (int i = 7; i < VMX_XTAB_KEY; ++i) key[i] = 0.0;
     if (D.xtab_level >= 2) {
-        const double* sc = D.scal + (size_t)pipe * VMX_NS;
-        key[7] = sc[S_GA]; key[8] = sc[S_GB];
-        if (partner >= 0) { const double* scp = D.scal + (size_t)partner * VMX_NS; key[9] = scp[S_GA]; key[10] = scp[S_GB]; }
+        gauss_exponents(t0, d, th(t0, d.growth_rate_slot, d.growth_rate_default), key[7], key[8]);
+        if (partner >= 0) {
+            const vmx_pipe_desc& dp = D.pipes[partner].d;
+            gauss_exponents(t0, dp, th(t0, dp.growth_rate_slot, dp.growth_rate_default), key[9], key[10]);
+        }
     }
 }
 
-// the chi2 kernels record what the tables now hold (one thread, after every reader of the old key has finished)
+// xtab_key is [2][tables][VMX_XTAB_KEY]: what the tables hold, and what the table blocks of the running evaluation found for
+// walker 0 (written by one of them whether they rebuild or not).  The chi2 kernels move the second to the first - one thread,
+// after every reader of the old key has finished.
 __device__ inline void xtab_key_store(const EngineDev& D)
 {
     if (D.xtab_level <= 0) return;
-    for (int g = 0; g < D.n_xtab; ++g) {
-        double key[VMX_XTAB_KEY];
-        xtab_key_now(D, g, key);
-        for (int i = 0; i < VMX_XTAB_KEY; ++i) D.xtab_key[g * VMX_XTAB_KEY + i] = key[i];
-    }
+    for (int i = 0; i < D.n_xtab * VMX_XTAB_KEY; ++i) D.xtab_key[i] = D.xtab_key[D.n_xtab * VMX_XTAB_KEY + i];
 }
 
 // The tables of a batch that shares its non-linear (level 1) and Gaussian (level 2) parameters, from the first walker
-// (power_spectrum.py:435-479 D_NL, :526-556 smoothing, :382-417 peak broadening).  grid = (k blocks, row blocks, groups);
-// a launch that finds its tables current costs a few microseconds (~1000 blocks that read the key and leave).
-#define XTAB_ROWS 8
-__global__ __launch_bounds__(256) void k_xtab(EngineDev D)
+// (power_spectrum.py:435-479 D_NL, :526-556 smoothing, :382-417 peak broadening).  blocks = (k blocks, row blocks, groups),
+// as part of k_prologue's grid or as k_xtab; blocks that find their tables current read the key and leave.
+__device__ void xtab_body(const EngineDev& D, int xtab, int bx, int by, int rows_per_block, const double* t0)
 {
-    const int xtab = blockIdx.z, pipe = D.xtab_pipe[xtab];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= D.nkp) return;
+    const int pipe = D.xtab_pipe[xtab];
+    const int i = bx * (int)blockDim.x + threadIdx.x;
     const size_t plane = (size_t)D.n_rows * D.nkp;
     double key[VMX_XTAB_KEY];
-    xtab_key_now(D, xtab, key);
+    xtab_key_now(D, xtab, key, t0);
     bool stale = false;
     for (int q = 0; q < VMX_XTAB_KEY; ++q) stale |= !(D.xtab_key[xtab * VMX_XTAB_KEY + q] == key[q]);      // keys start as NaN
-    if (!stale) return;      // built from the same parameters by an earlier batch
-    for (int j = blockIdx.y * XTAB_ROWS; j < min((int)(blockIdx.y + 1) * XTAB_ROWS, D.n_rows); ++j) {
-    double* cell = D.xtab + (size_t)xtab * 2 * plane + (size_t)j * D.nkp + i;
-    double val = 0.0, val_q = 0.0;
-    if (i < D.nk) {
-        const vmx_pipe_desc& d = D.pipes[pipe].d;
-        const double k = D.k[i], d2 = D.delta2[i];
-        const double g = key[1] * d2 + key[2] * d2 * d2;
-        const double gv = g * pow(k / key[3], key[4]);
-        const double kp = k / key[6];
-        const double gp = g - kp * kp;
-        const double m = vmx_exp(key[5] * D.lnmu[j]);
-        val = exp(fmin(d.arinyo_power * fma(-gv, m, gp), 709.0));
-        if (d.gk_table >= 0) val *= D.gk[((size_t)d.gk_table * D.n_rows + j) * D.nkp + i];
-        if (D.xtab_level >= 2) {
-            const double mu = D.mu[j], mu2 = mu * mu, k2 = k * k;
-            val *= vmx_exp(-k2 * fma(key[7] - key[8], mu2, key[8]));
-            val_q = val * vmx_exp(-k2 * fma((key[9] - key[7]) - (key[10] - key[8]), mu2, key[10] - key[8]));
+    if (bx == 0 && by == 0 && threadIdx.x == 0)
+        for (int q = 0; q < VMX_XTAB_KEY; ++q) D.xtab_key[(D.n_xtab + xtab) * VMX_XTAB_KEY + q] = key[q];
+    if (!stale || i >= D.nkp) return;      // built from the same parameters by an earlier batch
+    for (int j = by * rows_per_block; j < min((by + 1) * rows_per_block, D.n_rows); ++j) {
+        double* cell = D.xtab + (size_t)xtab * 2 * plane + (size_t)j * D.nkp + i;
+        double val = 0.0, val_q = 0.0;
+        if (i < D.nk) {
+            const vmx_pipe_desc& d = D.pipes[pipe].d;
+            const double k = D.k[i], d2 = D.delta2[i];
+            const double g = key[1] * d2 + key[2] * d2 * d2;
+            const double gv = g * pow(k / key[3], key[4]);
+            const double kp = k / key[6];
+            const double gp = g - kp * kp;
+            const double m = vmx_exp(key[5] * D.lnmu[j]);
+            val = exp(fmin(d.arinyo_power * fma(-gv, m, gp), 709.0));
+            if (d.gk_table >= 0) val *= D.gk[((size_t)d.gk_table * D.n_rows + j) * D.nkp + i];
+            if (D.xtab_level >= 2) {
+                const double mu = D.mu[j], mu2 = mu * mu, k2 = k * k;
+                val *= vmx_exp(-k2 * fma(key[7] - key[8], mu2, key[8]));
+                val_q = val * vmx_exp(-k2 * fma((key[9] - key[7]) - (key[10] - key[8]), mu2, key[10] - key[8]));
+            }
+            if (j == 0) {
+                // per wavenumber: the Arinyo part of e0, e2 (the underflow bound of k_pk_multipoles) and VegaArinyoError - NaN or
+                // Inf in exp(growth (1 - pec) - pressure) anywhere on the grid (power_spectrum.py:466-469); the exponent is
+                // monotonic in mu^bv, so its extremes sit at the two ends of the mu grid
+                double* kk = D.xtab_k + (size_t)xtab * 4 * D.nkp + i;
+                kk[0] = d.arinyo_power * gp;
+                kk[D.nkp] = -d.arinyo_power * gv;
+                const double lo = fma(-gv, vmx_exp(key[5] * D.lnmu[0]), gp), hi = fma(-gv, vmx_exp(key[5] * D.lnmu[D.n_mu - 1]), gp);
+                kk[2 * D.nkp] = (!(lo < 709.0) || !(hi < 709.0)) ? 1.0 : 0.0;
+                // level 2: every exponent is shared by the batch - the underflow bound of k_pk_multipoles, per wavenumber
+                const double k2 = k * k, ga = key[7], gb = key[8], dga = key[9] - key[7], dgb = key[10] - key[8];
+                kk[3 * D.nkp] = fma(-k2, gb, kk[0]) + fmax(-k2 * (ga - gb), 0.0) + fmax(kk[D.nkp], 0.0) +
+                                fmax(-k2 * dgb + fmax(-k2 * (dga - dgb), 0.0), 0.0);
+            }
         }
-        if (j == 0) {
-            // per wavenumber: the Arinyo part of e0, e2 (the underflow bound of k_pk_multipoles) and VegaArinyoError - NaN or
-            // Inf in exp(growth (1 - pec) - pressure) anywhere on the grid (power_spectrum.py:466-469); the exponent is
-            // monotonic in mu^bv, so its extremes sit at the two ends of the mu grid
-            double* kk = D.xtab_k + (size_t)xtab * 4 * D.nkp + i;
-            kk[0] = d.arinyo_power * gp;
-            kk[D.nkp] = -d.arinyo_power * gv;
-            const double lo = fma(-gv, vmx_exp(key[5] * D.lnmu[0]), gp), hi = fma(-gv, vmx_exp(key[5] * D.lnmu[D.n_mu - 1]), gp);
-            kk[2 * D.nkp] = (!(lo < 709.0) || !(hi < 709.0)) ? 1.0 : 0.0;
-            // level 2: every exponent is shared by the batch - the underflow bound of k_pk_multipoles, per wavenumber
-            const double k2 = k * k, ga = key[7], gb = key[8], dga = key[9] - key[7], dgb = key[10] - key[8];
-            kk[3 * D.nkp] = fma(-k2, gb, kk[0]) + fmax(-k2 * (ga - gb), 0.0) + fmax(kk[D.nkp], 0.0) +
-                            fmax(-k2 * dgb + fmax(-k2 * (dga - dgb), 0.0), 0.0);
-        }
-    }
-    *cell = val;
-    if (D.xtab_level >= 2) cell[plane] = val_q;
+        *cell = val;
+        if (D.xtab_level >= 2) cell[plane] = val_q;
     }
 }
+
+__global__ __launch_bounds__(256) void k_xtab(EngineDev D) { xtab_body(D, blockIdx.z, blockIdx.x, blockIdx.y, XTAB_ROWS, D.theta); }
 
 // mu loop against the tabulated D_NL * G: no exponential is left in the loop - the HCD factor, the Gaussian
 // smoothing exp(e0 + e1 mu^2) and the peak broadening all advance as geometric progressions (re-anchored exactly
@@ -2162,17 +2210,29 @@ __global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const do
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const int nt = b >> 6, nl = b & 63;
-    double acc = 0.0;
+    // Everything the walker's last additions need is requested FIRST, by every lane (uniform addresses): behind the reduction
+    // each of these was a dependent round trip of lane 0 - eight in a row, most of this kernel's time.
+    constexpr int CHI2_PRE = 4;     // items whose constant is requested ahead
     const int s0 = nt_off[nt], s1 = nt_off[nt + 1];
+    const int mock = D.mock_index[b];
+    int st = D.status[b];
+    double c0[CHI2_PRE];
+#pragma unroll
+    for (int q = 0; q < CHI2_PRE; ++q) {
+        c0[q] = 0.0;
+        if (q < D.n_items) { const ItemDev& it = D.items[q]; c0[q] = it.q_c0[(mock >= 0 && it.mock_pool) ? 1 + mock : 0]; }
+    }
+    double acc = 0.0;
     for (int j = s0 + lane; j < s1; j += 64) {
         const double* pp = part + ((size_t)j * 64 + nl) * 2;
         acc += pp[0] + pp[1];
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane != 0) return;
-    const int mock = D.mock_index[b];
     double c = acc;
-    for (int q = 0; q < D.n_items; ++q) {
+#pragma unroll
+    for (int q = 0; q < CHI2_PRE; ++q) if (q < D.n_items) c += c0[q];
+    for (int q = CHI2_PRE; q < D.n_items; ++q) {
         const ItemDev& it = D.items[q];
         c += it.q_c0[(mock >= 0 && it.mock_pool) ? 1 + mock : 0];
     }
@@ -2181,7 +2241,6 @@ __global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const do
         const double dlt = t[D.prior_slot[q]] - D.prior_mean[q];
         c += dlt * dlt / (D.prior_sigma[q] * D.prior_sigma[q]);
     }
-    int st = D.status[b];
     if (!(c == c) || c > 1e300 || c < -1e300) { st |= VMX_STATUS_NONFINITE; D.status[b] = st; }
     D.chi2[b] = st ? 1e100 : c;
     if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
