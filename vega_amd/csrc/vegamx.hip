@@ -153,7 +153,7 @@ struct vmx_engine {
 
     int nk = 0, nkp = 0, n_mu = 0;
     int n_rows = 0, n_extra = 0, mu_lo = 0, mu_hi = 0;     // node rule of the mu sums (vmx_set_mu_quadrature)
-    DevBuf<double> node_w;
+    DevBuf<double> node_w, mu_img;
     std::vector<int32_t> rule_slot; std::vector<double> rule_lo, rule_hi;     // vmx_set_mu_rule_box
     DevBuf<int32_t> d_rule_slot; DevBuf<double> d_rule_lo, d_rule_hi;
     double k_node_max = 0.0; bool mu_nodes_on = true;
@@ -756,6 +756,17 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
         wl[3 * (size_t)n_mu + j] = dmu * (0.0625 * (((231.0 * m2 - 315.0) * m2 + 105.0) * m2 - 5.0)) * 13.0;
     }
     e->h_mu = mu;
+    {
+        // the LDS image of k_pk_tab2's node tables: {mu^2, mu^4} of the midpoints, {mu, mu^2, mu^4, w} of the extra nodes
+        std::vector<double> img(2 * (size_t)n_mu + 4 * (size_t)e->n_extra);
+        for (int j = 0; j < n_mu; ++j) { const double m2 = mu[j] * mu[j]; img[2 * (size_t)j] = m2; img[2 * (size_t)j + 1] = m2 * m2; }
+        for (int j = 0; j < e->n_extra; ++j) {
+            const double m = mu[n_mu + j], m2 = m * m;
+            double* q = &img[2 * (size_t)n_mu + 4 * (size_t)j];
+            q[0] = m; q[1] = m2; q[2] = m2 * m2; q[3] = node_w[j];
+        }
+        if (e->mu_img.upload(img.data(), img.size())) return -2;
+    }
     if (e->mu.upload(mu.data(), n_rows) || e->sq1mmu2.upload(sq.data(), n_rows) || e->lnmu.upload(lnm.data(), n_rows) || e->wl.upload(wl.data(), wl.size())) return -2;
     return 0;
 }
@@ -1570,7 +1581,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     EngineDev& D = e->dev;
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
-    D.n_rows = e->n_rows; D.n_extra = e->n_extra; D.mu_lo = e->mu_lo; D.mu_hi = e->mu_hi; D.node_w = e->node_w.p;
+    D.n_rows = e->n_rows; D.n_extra = e->n_extra; D.mu_lo = e->mu_lo; D.mu_hi = e->mu_hi; D.node_w = e->node_w.p; D.mu_img = e->mu_img.p;
     {
         // the node rule needs the integrand smooth on the scale of its panels: the binning sincs oscillate with k x bin
         // size, so wavenumbers beyond 24 / (largest bin size) [6 h/Mpc for 4 Mpc/h bins] keep the midpoint loop
@@ -2012,7 +2023,8 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         int n_other = n_groups;
         if (tab_mode >= 2 && e->n_xtab > 0) {
             n_other = n_groups - e->n_xtab;
-            const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
+            // (the node tables' image, + [2 terms][2 walkers][64 wavenumbers] of UV / HeII bias terms behind it)
+            const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra + 256) * sizeof(double);
 #ifdef VMX_EXP_PRO_TRACE       // (experiment build: the trace buffer holds k_prologue's stamps, scripts/gpu_pro_trace.py)
             D.pk_trace = nullptr;
             if (false) {

@@ -156,6 +156,7 @@ struct EngineDev {
     const double* pklin;        // [3][nkp]
     const double* delta2;       // [nkp]
     const double* mu;           // [n_mu]
+    const double* mu_img;       // [n_mu] {mu^2, mu^4}, [n_extra] {mu, mu^2, mu^4, w}: the LDS image of k_pk_tab2's node tables
     const double* sq1mmu2;      // [n_mu] sqrt(1 - mu^2)
     const double* lnmu;         // [n_mu] ln(mu)
     const double* wl;           // [4][n_mu] L_ell(mu) (2 ell + 1) / n_mu
@@ -1436,12 +1437,45 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
     const int ic = valid ? i : D.nk - 1;
     const int n_mu = D.n_mu;
     const double inv_nmu = 1.0 / (double)n_mu;
+    // A block's set-up used to be a third of its life (block phase stamps, round 4: 7 - 9 us of ~20, 15 in the first round of
+    // blocks): seven dependent round trips - the tile's bound, the walkers' scalars, four passes of the (mu^2, mu^4) table
+    // through registers, the extra nodes - each waited for before the next was asked for.  Now everything the set-up reads
+    // is requested at once: the node tables as direct global -> LDS copies of their static image (EngineDev::mu_img:
+    // [n_mu] {mu^2, mu^4}, [n_extra] {mu, mu^2, mu^4, w} - the LDS layout below), the tile's and the walkers' values into
+    // registers; then the block decides.
+    {
+        const unsigned total = (2u * (unsigned)n_mu + 4u * (unsigned)D.n_extra) * 8u;           // bytes, a multiple of 16
+        const char* img = (const char*)D.mu_img;
+        const unsigned wave_off = (threadIdx.x >> 6) * 1024u, lane_off = (threadIdx.x & 63) * 16u;
+        for (unsigned c = 0; c < total; c += (unsigned)NT * 16u) {
+            const unsigned off = c + wave_off;                  // (a wave's 64 x 16 bytes land contiguously at its LDS base)
+            if (off + lane_off < total)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + off + lane_off),
+                                                 (__attribute__((address_space(3))) void*)((char*)smem + off), 16, 0, 0);
+        }
+    }
     // the exponents are shared by the batch at this level: their bound over mu in (0, 1] came with the table (k_xtab).  A
-    // tile whose every value underflows is skipped (as in k_pk_multipoles) before anything else is loaded.
+    // tile whose every value underflows is skipped (as in k_pk_multipoles).
     const double* kx = D.xtab_k + (size_t)xt * 4 * D.nkp + ic;
     const double e_max = kx[3 * D.nkp];
+    const double bad_flag = kx[2 * D.nkp];
+    const double k = D.k[ic], k2 = k * k;
+    bool ok[NW];
+    double raw[NW][14];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        int b = blockIdx.x * NW + w;
+        ok[w] = b < B;
+        if (!ok[w]) b = B - 1;                        // a surplus walker slot shadows the last walker and stores nothing
+        const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
+        raw[w][0] = sc[S_BIAS1]; raw[w][1] = sc[S_BIAS2]; raw[w][2] = sc[S_BB1]; raw[w][3] = sc[S_BB2];
+        raw[w][4] = sc[S_HCD_B]; raw[w][5] = sc[S_HCD_BB]; raw[w][6] = sc[S_HCD_L0]; raw[w][7] = sc[S_VD2]; raw[w][8] = sc[S_NO_RULE];
+        raw[w][9] = G.uvb ? sc[S_UV_LAM] : 0.0; raw[w][10] = G.uvb ? sc[S_UV_BG] : 0.0; raw[w][11] = (G.uvb || G.heii) ? sc[S_UV_BP] : 0.0;
+        raw[w][12] = G.heii ? sc[S_HE_LAM] : 0.0; raw[w][13] = G.heii ? sc[S_HE_BG] : 0.0;
+    }
     const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;
     if (!live_block) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the table copies land before the block's LDS is given up)
         if (threadIdx.x >= KT || !valid) return;
         const size_t ncols = (size_t)B * D.n_active;
         for (int w = 0; w < NW; ++w) {
@@ -1453,32 +1487,34 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
         }
         return;
     }
-    const double k = D.k[ic], k2 = k * k;
     const double dmu = (double)MS * inv_nmu;
-    const bool bad = kx[2 * D.nkp] != 0.0;
+    const bool bad = bad_flag != 0.0;
     double c01[NW], c11[NW], c02[NW], c12[NW], hb[NW], hbb[NW], fk[NW], Fq[NW], k2vd2[NW];
-    bool ok[NW];
     bool in_box = true;
+    // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261): an arctangent and two divisions per (walker,
+    // wavenumber, term) that do not depend on the mu slice - the block's MS slices used to compute each of them MS times
+    // (a sixth of the block's instructions).  Role term NW + w - term `term` of walker w for the tile's wavenumbers - is
+    // computed by slice role % MS; everyone reads it from LDS behind the node tables (after the barrier below).
+    double* s_x = smem + 2 * (size_t)n_mu + 4 * (size_t)D.n_extra;         // [2][NW][KT]
+    if (G.uvb || G.heii) {
+#pragma unroll
+        for (int role = 0; role < 2 * NW; ++role) {
+            if (role % MS != ms) continue;
+            const int term = role / NW, wsel = role % NW;
+            const double lam = term ? raw[wsel][12] : raw[wsel][9], bg = term ? raw[wsel][13] : raw[wsel][10], bp = raw[wsel][11];
+            double v = 0.0;
+            if (term ? G.heii : G.uvb) { const double x = k * lam; const double W = atan(x) / x; v = bg * W / (1.0 + bp * W); }
+            s_x[(size_t)role * KT + kk] = v;
+        }
+    }
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-        int b = blockIdx.x * NW + w;
-        ok[w] = b < B;
-        if (!ok[w]) b = B - 1;                        // a surplus walker slot shadows the last walker and stores nothing
-        const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
-        c01[w] = sc[S_BIAS1]; c02[w] = sc[S_BIAS2]; c11[w] = sc[S_BB1]; c12[w] = sc[S_BB2];
-        if (G.uvb || G.heii) {
-            // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261)
-            double add = 0.0;
-            if (G.uvb) { const double x = k * sc[S_UV_LAM]; const double W = atan(x) / x; add += sc[S_UV_BG] * W / (1.0 + sc[S_UV_BP] * W); }
-            if (G.heii) { const double x = k * sc[S_HE_LAM]; const double W = atan(x) / x; add += sc[S_HE_BG] * W / (1.0 + sc[S_UV_BP] * W); }
-            if (G.lya1) c01[w] += add;
-            if (G.lya2) c02[w] += add;
-        }
-        hb[w] = sc[S_HCD_B]; hbb[w] = sc[S_HCD_BB];
-        fk[w] = -sc[S_HCD_L0] * k;
+        c01[w] = raw[w][0]; c02[w] = raw[w][1]; c11[w] = raw[w][2]; c12[w] = raw[w][3];
+        hb[w] = raw[w][4]; hbb[w] = raw[w][5];
+        fk[w] = -raw[w][6] * k;
         Fq[w] = vmx_exp(fk[w] * dmu);
-        k2vd2[w] = k2 * sc[S_VD2];
-        const bool inside = sc[S_NO_RULE] == 0.0;
+        k2vd2[w] = k2 * raw[w][7];
+        const bool inside = raw[w][8] == 0.0;
         in_box = in_box && inside;
         if (MODE == 1) ok[w] = ok[w] && inside;         // (a surplus slot shadows the last walker: stores nothing either way)
         if (MODE == 2) ok[w] = ok[w] && !inside;
@@ -1491,16 +1527,21 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
     const bool node_mode = D.n_extra > 0 && in_box && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
     if (node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((tile + 1) * KT, D.nk));
     const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
-    {
-        for (int j = threadIdx.x; j < n_mu; j += NT)
-            if (j < lo_end || j >= hi_beg) { const double m = D.mu[j], m2 = m * m; s_mu24[j] = (v2d){m2, m2 * m2}; }
-        if (node_mode)
-            for (int j = threadIdx.x; j < D.n_extra; j += NT) {
-                const double m = D.mu[n_mu + j], m2 = m * m;
-                s_node[j] = (v4d){m, m2, m2 * m2, D.node_w[j]};
-            }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the node tables have landed
     __syncthreads();
+    if (G.uvb || G.heii) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            double add = 0.0;
+            if (G.uvb) add += s_x[(size_t)w * KT + kk];
+            if (G.heii) add += s_x[(size_t)(NW + w) * KT + kk];
+            if (G.lya1) c01[w] += add;
+            if (G.lya2) c02[w] += add;
+        }
+    }
+#ifdef VMX_EXP_PK_PHASE     /* experiment build (scripts/gpu_pk_trace.py): the trace's last two words are phase stamps, not hardware ids */
+    const unsigned long long t_setup = D.pk_trace ? wall_clock64() : 0ull;
+#endif
 
     double s[NW][4], q[NW][4];
 #pragma unroll
@@ -1596,6 +1637,9 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
     }
 
     // moments -> Legendre multipoles  P_ell = (2 ell + 1) / n_mu * sum_n c_{ell n} M_n  (pktoxi.py:37,55,138)
+#ifdef VMX_EXP_PK_PHASE
+    const unsigned long long t_loop = D.pk_trace ? wall_clock64() : 0ull;
+#endif
     __syncthreads();            // every wave is done with the node tables
 #pragma unroll
     for (int w = 0; w < NW; ++w)
@@ -1612,7 +1656,11 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
     if (D.pk_trace && threadIdx.x == 0) {
         unsigned long long* tr = D.pk_trace + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         tr[0] = t_start; tr[1] = wall_clock64();
+#ifdef VMX_EXP_PK_PHASE
+        tr[2] = t_setup; tr[3] = t_loop;
+#else
         tr[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+#endif
     }
     if (threadIdx.x >= KT || !valid) return;
     double damp = 1.0;
@@ -1653,7 +1701,7 @@ __device__ __forceinline__ void pk_tab2_mixed(const EngineDev& D, const Tab2Grou
 #define VMX_TAB2_W2 3
 #endif
 template <int KT, int MS, int NW>
-__global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : NW == 1 ? VMX_TAB2_BLOCKS : VMX_TAB2_W2) void k_pk_tab2(EngineDev D, Tab2Args A, int B)
+__global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : (NW == 1 ? VMX_TAB2_BLOCKS : VMX_TAB2_W2) * (4 / MS)) void k_pk_tab2(EngineDev D, Tab2Args A, int B)
 {
     const Tab2Group& G = A.g[blockIdx.y];
     if constexpr (NW > 1) {
