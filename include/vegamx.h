@@ -90,6 +90,11 @@ typedef struct {
     double  arinyo_power;           /* 1 two Lya tracers, 0.5 one, 0 none (:472-477) */
 
     int32_t gk_table;               /* id from vmx_add_gk_table, -1: no G(k) */
+    int32_t mock_los_slot;          /* -1, or the parameter p a mock's line-of-sight bin follows when p is sampled
+                                     * (`mock-los-smoothing = growth | amplitude`, power_spectrum.py:143-160): one more
+                                     * factor sinc(k_par mock_los_size (1 + theta[p]) / 2) per walker in the mu loop; the
+                                     * static G table then holds the other binning factors only */
+    double  mock_los_size;          /* the mock's bin size (`mock-bin-size`) */
 
     int32_t peak_nl;                /* apply compute_peak_nl (power_spectrum.py:382-417) */
     int32_t sigma_nl_par_slot, sigma_nl_per_slot;

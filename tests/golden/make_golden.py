@@ -411,6 +411,40 @@ def dump_mockbin(VegaInterface):
         print('mockbin: chi2', out['fid/chi2'], out['walker0/chi2'])
 
 
+def dump_mockbin_sampled(VegaInterface):
+    """`mock-bin-size` whose line-of-sight size follows a parameter that VARIES between the walkers (reference
+    power_spectrum.py:143-160, :494-501): `mock-los-smoothing = amplitude` with four values of `los_smooth_amp`, and
+    `= growth` with four growth rates (which also enter the bias relations, utils.py:45-82)."""
+    os.chdir(REF / 'tests')
+    out = {}
+    for mode, name in (('amplitude', 'los_smooth_amp'), ('growth', 'growth_rate')):
+        with tempfile.TemporaryDirectory() as tmp:
+            main = _ref_main(tmp, ['lyalya_lyalya'], False)
+            item = Path(tmp) / 'lyalya_lyalya.ini'
+            item.write_text(item.read_text().replace('[model]', '[model]\nmock-bin-size = 2.0\n'
+                                                     f'mock-los-smoothing = {mode}'))
+            mp = Path(main)
+            if mode == 'amplitude':
+                mp.write_text(mp.read_text().replace('[parameters]', '[parameters]\nlos_smooth_amp = 0.3'))
+            vega = VegaInterface(main)
+            names, walkers = make_walkers(vega.params, 4, seed=WALKER_SEED + 31)
+            for i, w in enumerate(walkers):
+                w['growth_rate'] = vega.params['growth_rate']
+                w[name] = (0.05, 0.3, 0.7, 1.2)[i] if mode == 'amplitude' else vega.params['growth_rate'] * (0.85, 0.95, 1.05, 1.2)[i]
+            out[f'{mode}/param_names'] = np.array(names)
+            out[f'{mode}/theta'] = np.array([[w[n] for n in names] for w in walkers])
+            chi2, models = [], []
+            for w in walkers:
+                _reset_caches(vega)
+                chi2.append(vega.chi2(w))
+                _reset_caches(vega)
+                models.append(np.array(vega.compute_model(w, run_init=False)['lyalya_lyalya']))
+            out[f'{mode}/chi2'] = np.array(chi2)
+            out[f'{mode}/model'] = np.array(models)
+            print('mockbin sampled', mode, chi2)
+    np.savez_compressed(HERE / 'expected_mockbin_sampled.npz', **out)
+
+
 def dump_fits_ingest(VegaInterface):
     """Static-state ingestion (reference vega/data.py:285-473, utils.py:271-298): a data FITS file that carries the
     synthetic distortion matrix (`DM`) and covariance (`CO`) as vector columns - written by
@@ -1125,7 +1159,7 @@ if __name__ == '__main__':
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1174,3 +1208,5 @@ if __name__ == '__main__':
         dump_marg_mc(VI)
     if 'direct_pk_metals' in what:
         dump_direct_pk_metals(VI)
+    if 'mockbin_sampled' in what:
+        dump_mockbin_sampled(VI)

@@ -51,15 +51,22 @@ def test_unsupported_options_fail_loudly():
     prob = load_problem('auto')
     low = E.Lowering(prob)
     core = prob.items['lyalya_lyalya'].core
-    core.pk.mock_bin_size, core.pk.mock_los_smoothing = 2.0, 'amplitude'     # a parameter-dependent binning kernel
+    # a binning kernel that follows a SAMPLED parameter: lowered to a per-walker factor, the table keeps the transverse one
+    core.pk.mock_bin_size, core.pk.mock_los_smoothing = 2.0, 'amplitude'
     prob.params['los_smooth_amp'] = 0.3
     prob.sample_params['limits']['los_smooth_amp'] = (0., 1.)
     try:
-        with pytest.raises(NotImplementedError):
-            low.pipeline(_FakeEngine(), core, 'smooth')
+        low2 = E.Lowering(prob)
+        fake = _FakeEngine()
+        d = low2.pipeline(fake, core, 'smooth')
+        assert d.mock_los_slot == low2.slot['los_smooth_amp'] and d.mock_los_size == 2.0
+        del prob.sample_params['limits']['los_smooth_amp']
+        d = E.Lowering(prob).pipeline(_FakeEngine(), core, 'smooth')
+        assert d.mock_los_slot == -1            # (not sampled: folded into the static table)
     finally:
         core.pk.mock_bin_size, core.pk.mock_los_smoothing = None, None
-        del prob.params['los_smooth_amp'], prob.sample_params['limits']['los_smooth_amp']
+        del prob.params['los_smooth_amp']
+        prob.sample_params['limits'].pop('los_smooth_amp', None)
     core.xi.single_multipole = 3
     try:
         with pytest.raises(ValueError):

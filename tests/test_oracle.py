@@ -276,6 +276,23 @@ def test_mock_binning_matches_reference():
     assert np.abs(model - exp['walker0/model']).max() <= 1e-13 * np.abs(model).max()
 
 
+@pytest.mark.parametrize('mode', ['amplitude', 'growth'])
+def test_mock_binning_that_follows_a_varying_parameter_matches_reference(mode):
+    """`mock-los-smoothing = amplitude | growth` with `los_smooth_amp` / `growth_rate` different from walker to walker
+    (reference power_spectrum.py:143-160): the binning kernel is then a function of the walker."""
+    import copy
+    prob = copy.deepcopy(load_problem('auto_mockbin'))
+    prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = mode
+    exp = np.load(GOLDEN / 'expected_mockbin_sampled.npz')
+    names = [str(n) for n in exp[f'{mode}/param_names']]
+    for i, row in enumerate(exp[f'{mode}/theta']):
+        pars = dict(zip(names, map(float, row)))
+        assert oc.chi2(prob, pars) == pytest.approx(float(exp[f'{mode}/chi2'][i]), rel=1e-12)
+        model = oc.compute_model(prob, pars)['lyalya_lyalya']
+        assert np.abs(model - exp[f'{mode}/model'][i]).max() <= 1e-13 * np.abs(model).max()
+    assert len(set(np.round(exp[f'{mode}/chi2'], 6))) == 4
+
+
 def test_fits_ingestion_matches_reference(tmp_path):
     """Static-state ingestion (reference vega/data.py:285-473, utils.py:271-298): distortion matrix and covariance
     read from vector columns of a FITS data file.  The reference read the same file (same writer, same generator)

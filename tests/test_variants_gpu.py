@@ -311,12 +311,35 @@ def test_mock_binning():
     prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = 'amplitude'
     prob.params['los_smooth_amp'] = 0.4
     _check(prob, n_walkers=1, vary=['bias_eta_LYA', 'beta_LYA', 'ap', 'at', 'bias_hcd'])
+
+
+@pytest.mark.parametrize('mode', ['amplitude', 'growth'])
+def test_mock_binning_that_follows_a_sampled_parameter(mode):
+    """`mock-los-smoothing = amplitude | growth` with a SAMPLED `los_smooth_amp` / `growth_rate` (reference
+    power_spectrum.py:143-160): the line-of-sight factor sinc(k_par L (1 + p) / 2) is the walker's own - a factor of the mu
+    loop (vmx_pipe_desc::mock_los_slot), the static table keeping the transverse one.  Against the unmodified reference,
+    four walkers with four values of the parameter in one batch."""
+    from vega_amd import VegaInterface
     prob = _fresh('auto_mockbin')
-    prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = 'amplitude'
-    prob.params['los_smooth_amp'] = 0.4
-    prob.sample_params['limits']['los_smooth_amp'] = (0., 1.)
-    with pytest.raises(NotImplementedError):
-        VegaInterface(None, problem=prob, max_batch=1)
+    name = 'los_smooth_amp' if mode == 'amplitude' else 'growth_rate'
+    prob.items['lyalya_lyalya'].core.pk.mock_los_smoothing = mode
+    if mode == 'amplitude':
+        prob.params['los_smooth_amp'] = 0.3
+    prob.sample_params['limits'][name] = (0., 2.)
+    exp = np.load(GOLDEN / 'expected_mockbin_sampled.npz')
+    vega = VegaInterface(None, problem=prob, max_batch=4)
+    names = [str(n) for n in exp[f'{mode}/param_names']]
+    theta = np.stack([vega.engine.theta_from_params(dict(zip(names, map(float, row)))) for row in exp[f'{mode}/theta']])
+    chi2, status = vega.chi2_batch(theta, return_status=True)
+    assert not status.any()
+    np.testing.assert_allclose(chi2, exp[f'{mode}/chi2'], rtol=CHI2_RTOL)
+    models = vega.compute_model_batch(theta)['lyalya_lyalya']
+    for i in range(4):
+        ref = exp[f'{mode}/model'][i]
+        assert np.abs(models[i] - ref).max() <= XI_RTOL * np.abs(ref).max(), i
+    # the scalar entry (one walker, its own batch) agrees with the batch
+    assert vega.chi2(dict(zip(names, map(float, exp[f'{mode}/theta'][2])))) == pytest.approx(chi2[2], rel=1e-12)
+    vega.close()
 
 
 def test_metal_decomposition():

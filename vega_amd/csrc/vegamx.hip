@@ -367,6 +367,7 @@ static bool pk_stage_compatible(const vmx_pipe_desc& smooth, const vmx_pipe_desc
 static bool w_stage_compatible(const vmx_pipe_desc& a, const vmx_pipe_desc& b)
 {
     if (a.gk_table != b.gk_table || a.is_peak != b.is_peak || a.peak_nl != b.peak_nl) return false;
+    if (a.mock_los_slot >= 0 || b.mock_los_slot >= 0) return false;        // (a per-walker factor of the mu loop)
     if (a.peak_nl && (a.sigma_nl_par_slot != b.sigma_nl_par_slot || a.sigma_nl_per_slot != b.sigma_nl_per_slot ||
                       a.growth_rate_slot != b.growth_rate_slot || a.growth_rate_default != b.growth_rate_default))
         return false;
@@ -387,6 +388,7 @@ static bool w_stage_compatible(const vmx_pipe_desc& a, const vmx_pipe_desc& b)
 static int pk_variant(const vmx_pipe_desc& d, bool paired)
 {
     const bool rare = d.hcd_model == VMX_HCD_SINC || d.hcd_model == VMX_HCD_FVOIGT || d.nl_model == VMX_NL_MCDONALD || d.exp_par_slot >= 0 ||
+                      d.mock_los_slot >= 0 ||
                       (d.fast_metals && (d.tracer[0].is_lya || d.tracer[1].is_lya) &&
                        (d.uvb || d.heii || d.hcd_model != VMX_HCD_NONE));
     if (rare) return PKV_GENERIC;
@@ -830,6 +832,7 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     if (!e || e->finalized || !desc || n <= 0) return fail(-1, "invalid argument: vmx_add_pipeline");
     if (desc->n_ell < 1 || desc->n_ell > VMX_MAX_ELL) return fail(-1, "invalid argument: n_ell");
     if (desc->gk_table >= (int)e->gk_tables.size()) return fail(-1, "invalid argument: gk_table id");
+    if (desc->mock_los_slot >= 0 && !(desc->mock_los_size > 0.0)) return fail(-1, "invalid argument: mock_los_size");
     if (desc->n_smooth < 0 || desc->n_smooth > VMX_MAX_SMOOTH) return fail(-1, "invalid argument: n_smooth");
     PipeDev p{};
     p.d = *desc;
@@ -1266,7 +1269,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
                              d.lambda_uv_slot, d.bias_gamma_e_slot, d.lambda_heii_slot, d.bias_hcd_slot,
                              d.beta_hcd_slot, d.l0_hcd_slot, d.sigma_nl_par_slot, d.sigma_nl_per_slot,
                              d.exp_par_slot, d.exp_per_slot, d.scale_slot[0], d.scale_slot[1], d.drp_slot,
-                             d.croom_slot[0], d.croom_slot[1]};
+                             d.croom_slot[0], d.croom_slot[1], d.mock_los_slot};
         for (int s : slots) REQUIRE(slot_ok(s), "pipeline slot exceeds n_params");
         for (int i = 0; i < 6; ++i) REQUIRE(slot_ok(d.arinyo_slot[i]), "arinyo slot exceeds n_params");
         for (int i = 0; i < d.n_smooth; ++i)

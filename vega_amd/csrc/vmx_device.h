@@ -695,6 +695,7 @@ struct PkThread {
     // per-thread (one wavenumber) constants of the mu loop
     double k, c0_1, c1_1, c0_2, c1_2, hb, hbb, L0, e0, e1, e2, vd1, vd2, ea, eb, mc_kvel;
     double p0, p1, pq, Fq;
+    double mock_c;              // k / 2 x the walker's line-of-sight mock bin (mock_los), 0: none
     const double* gk;           // this thread's first table entry (row ms of its column)
     size_t gk_stride;           // MS rows
     size_t gk_row;              // one row
@@ -785,6 +786,7 @@ __device__ __forceinline__ void pk_mu_loop(const PkThread& T, const double* s_mu
             }
 
             double val = AA * vmx_exp(E) * g;
+            if (!SPEC && RARE && T.mock_c != 0.0) { const double x = T.mock_c * mu; val *= sin(x) / x; }        // (mu > 0 on the midpoints)
             if (has_vd1 || has_vd2) {
                 const double kpar = T.k * mu;
                 const double kp2 = kpar * kpar;
@@ -1192,6 +1194,8 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
     T.rogers = d.hcd_model == VMX_HCD_ROGERS;
     T.sinc = d.hcd_model == VMX_HCD_SINC;
     T.fvoigt = d.hcd_model == VMX_HCD_FVOIGT;
+    // a mock's line-of-sight bin that follows a sampled parameter: sinc(k_par L (1 + p) / 2) (power_spectrum.py:143-160, :499)
+    T.mock_c = d.mock_los_slot >= 0 ? 0.5 * k * (d.mock_los_size * (1.0 + D.theta[(size_t)b * D.n_params + d.mock_los_slot])) : 0.0;
     T.fv_x = D.fv_x; T.fv_f = D.fv_f; T.fv_n = D.fv_n;
 
     // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261): only the bias changes,
@@ -1345,7 +1349,7 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
             // the run-time-switched loops (rare model options) live in the GENERIC instantiation only: their register
             // footprint would otherwise cap the occupancy of the production loops
             if constexpr (GENERIC) {
-                if (T.sinc || T.fvoigt || T.has_exp || T.mcdonald || T.div1 || T.div2)
+                if (T.sinc || T.fvoigt || T.has_exp || T.mcdonald || T.div1 || T.div2 || T.mock_c != 0.0)
                     pk_mu_loop<MS, WB, false, 0, false, false, 0, true>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q);
                 else
                     pk_mu_loop<MS, WB, false, 0, false, false, 0, false>(T, s_mubv, ms, j_lo, j_hi, inv_nmu, s, q);

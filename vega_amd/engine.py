@@ -52,7 +52,7 @@ class PipeDesc(C.Structure):
         ('hcd_model', C.c_int32), ('bias_hcd_slot', C.c_int32), ('beta_hcd_slot', C.c_int32),
         ('l0_hcd_slot', C.c_int32), ('l0_default', C.c_double),
         ('nl_model', C.c_int32), ('arinyo_slot', C.c_int32 * 6), ('arinyo_power', C.c_double),
-        ('gk_table', C.c_int32),
+        ('gk_table', C.c_int32), ('mock_los_slot', C.c_int32), ('mock_los_size', C.c_double),
         ('peak_nl', C.c_int32), ('sigma_nl_par_slot', C.c_int32), ('sigma_nl_per_slot', C.c_int32),
         ('n_smooth', C.c_int32), ('smooth_par_slot', C.c_int32 * VMX_MAX_SMOOTH),
         ('smooth_per_slot', C.c_int32 * VMX_MAX_SMOOTH), ('smooth_weight', C.c_double * VMX_MAX_SMOOTH),
@@ -342,6 +342,7 @@ class Lowering:
         d.nl_model = NL[nl]
 
         d.gk_table = -1
+        d.mock_los_slot, d.mock_los_size = -1, 0.0
         bs_rp = bs_rt = mock_rp = mock_rt = 0.0
         if pk.use_gk:
             # frozen at the parameters of the first call (reference power_spectrum.py:139-141, :494-495)
@@ -355,9 +356,12 @@ class Lowering:
                 name = 'growth_rate' if pk.mock_los_smoothing == 'growth' else 'los_smooth_amp'
                 sampled = set((self.prob.sample_params or {}).get('limits', {}))
                 if name in sampled:
-                    raise NotImplementedError(f'mock-los-smoothing = {pk.mock_los_smoothing} with a sampled {name} '
-                                              '(a parameter-dependent binning kernel) is not accelerated')
-                mock_rp *= 1 + params[name]
+                    # ... and a factor of its own in the mu loop, per walker, when it is (the plain 1000-point loop: no
+                    # tables, no node rule); the table keeps the transverse factor
+                    d.mock_los_slot, d.mock_los_size = self.need(name), float(pk.mock_bin_size)
+                    mock_rp = 0.0
+                else:
+                    mock_rp *= 1 + params[name]
             elif pk.mock_los_smoothing == 'only-los':
                 mock_rt = 0.0
         if pk.use_gk or pk.mock_bin_size is not None:
