@@ -172,6 +172,13 @@ int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n
                    double x0, double h, int32_t n_knots);
 /* Evaluate the xi splines outside their knot range by polynomial extension instead of flagging the walker
  * (the reference's legacy old_fftlog path uses splev, which extrapolates; pktoxi.py:276-277). */
+/* `fht_extrap = True` (reference vega/pktoxi.py:41,141: mcfit.P2xi(...)(pk_ell, extrap=True)): the FFTLog's input is padded
+ * with power laws through its end segments instead of zeros - n_left samples F[0] (F[1] / F[0])^-t and n_right samples
+ * F[n-1] (F[n-1] / F[n-2])^t, t = 1, 2, ...  Call BEFORE vmx_set_template; the operators of vmx_set_fftlog then have
+ * nk + n_left + n_right columns, [samples | left pads t = 1.. | right pads t = 1..] (vega_amd/fftlog_op.xi_operator(extrap=True)),
+ * and the engine forms the pad samples per walker, multipole and pipeline on the device.  0 / 0 end segments (a spectrum
+ * smoothed to exact zeros at the template's last wavenumbers) give NaN there as in the reference: VMX_STATUS_NONFINITE. */
+int vmx_set_fftlog_padding(vmx_engine* e, int32_t n_left, int32_t n_right);
 int vmx_set_spline_extrapolation(vmx_engine* e, int32_t enabled);
 
 /* Voigt-profile table of model-hcd = fvoigt: F(L0 k_par) by linear interpolation in (x, f), 1 below the table and

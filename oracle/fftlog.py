@@ -75,11 +75,24 @@ class P2xi:
         self.pad_out = (npad - npad // 2, npad // 2)
 
     def __call__(self, F, extrap=False):
-        if extrap:
-            raise NotImplementedError('vega calls P2xi with extrap=False only '
-                                      '(reference vega/pktoxi.py:41,141)')
+        F = np.asarray(F, dtype=float)
         f = np.zeros(self.N)
-        f[self.pad_in[0]:self.pad_in[0] + self.Nin] = self.xfac * np.asarray(F, dtype=float)
+        f[self.pad_in[0]:self.pad_in[0] + self.Nin] = self.xfac * F
+        if extrap:
+            # `fht_extrap = True` (reference vega/pktoxi.py:41,141): mcfit pads the INPUT by power-law extrapolation of its end
+            # segments instead of zeros - left pad end * ratio**(-Npad .. -1) with ratio = F[1] / F[0], right pad
+            # end * ratio**(1 .. Npad) with ratio = F[-1] / F[-2] (`mcfit.mcfit._pad(..., extrap=True, out=False)`) - and
+            # applies its prefactor on the equally extended (geometric) x grid.  0 / 0 end segments give NaN, as there.
+            # PARITY UNPINNED for this option: the reference holds no fixture or test with fht_extrap on; the restatement is
+            # checked against the Hankel integral of a power-law-extended spectrum (tests/test_fftlog_quadrature.py).
+            lo, hi = self.pad_in
+            with np.errstate(all='ignore'):
+                left = F[0] * (F[1] / F[0]) ** np.arange(-lo, 0)
+                right = F[-1] * (F[-1] / F[-2]) ** np.arange(1, hi + 1)
+            x_left = self.x[0] * np.exp(self.delta * np.arange(-lo, 0))
+            x_right = self.x[-1] * np.exp(self.delta * np.arange(1, hi + 1))
+            f[:lo] = x_left**(3 - self.q) / (2 * np.pi)**1.5 * left
+            f[lo + self.Nin:] = x_right**(3 - self.q) / (2 * np.pi)**1.5 * right
         g = np.fft.hfft(np.fft.rfft(f) * self.u, n=self.N) / self.N
         g = g[self.pad_out[0]:self.pad_out[0] + self.Nin]
         return self.y, self.yfac * g

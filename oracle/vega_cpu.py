@@ -360,7 +360,7 @@ def pk_to_xi(pipe, grid, r_grid, mu_grid, pk, taps=None):
     xi_ell_arr = np.zeros([len(ell_vals), len(r_grid)])
     pk_ells = pk_multipoles(grid, pk, ell_vals)
     for i, ell in enumerate(ell_vals):
-        r_fft, xi_fft = _p2xi(grid.k, ell, getattr(pipe.xi, 'fht_lowring', True))(pk_ells[i], extrap=False)
+        r_fft, xi_fft = _p2xi(grid.k, ell, getattr(pipe.xi, 'fht_lowring', True))(pk_ells[i], extrap=getattr(pipe.xi, 'fht_extrap', False))
         if taps is not None:
             taps.setdefault('pk_ell', {})[ell] = pk_ells[i]
             taps.setdefault('xi_fft', {})[ell] = (r_fft, xi_fft)

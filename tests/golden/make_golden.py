@@ -445,6 +445,52 @@ def dump_mockbin_sampled(VegaInterface):
     np.savez_compressed(HERE / 'expected_mockbin_sampled.npz', **out)
 
 
+def dump_fht_extrap(VegaInterface):
+    """`fht_extrap = True` (reference vega/pktoxi.py:41,141): the FFTLog input padded with power laws.  The option only gives
+    numbers for spectra whose last samples are not smoothed to zero: no small-scale non-linear term, no full-shape smoothing,
+    no peak broadening (sigmaNL = 0), no binning kernel - with the test configuration's own model it returns NaN, recorded here as well.
+    (The transform is the repo's restatement of mcfit behind tools/refshim: what this pins is the reference's call path.)"""
+    os.chdir(REF / 'tests')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_lyalya'], False)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        text = item.read_text()
+        item.write_text(text.replace('[model]', '[model]\nfht_extrap = True'))
+        vega = VegaInterface(main)
+        with np.errstate(all='ignore'):
+            out['default_model/chi2'] = vega.chi2()
+        text = re.sub(r'small scale nl *=.*\n', '', text)
+        text = re.sub(r'fullshape smoothing *=.*\n', '', text)
+        # (nor the binning kernel: its sincs change sign from sample to sample at the template's last wavenumbers, and a
+        # power law through two such samples grows like |ratio|^617)
+        text = text.replace('[model]', '[model]\nmodel binning = False')
+        item.write_text(text.replace('[model]', '[model]\nfht_extrap = True'))
+        vega = VegaInterface(main)
+        names, walkers = make_walkers(vega.params, 3, seed=WALKER_SEED + 41)
+        for w in walkers:
+            w['growth_rate'] = vega.params['growth_rate']
+            w['sigmaNL_par'] = 0.0
+            w['sigmaNL_per'] = 0.0
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+        chi2, models = [], []
+        for w in walkers:
+            _reset_caches(vega)
+            chi2.append(vega.chi2(w))
+            _reset_caches(vega)
+            models.append(np.array(vega.compute_model(w, run_init=False)['lyalya_lyalya']))
+        out['chi2'] = np.array(chi2)
+        out['model'] = np.array(models)
+        # the same walkers with zero padding: how much the option moves the model
+        item.write_text(text)
+        vega = VegaInterface(main)
+        _reset_caches(vega)
+        out['zero_pad/chi2_0'] = vega.chi2(walkers[0])
+    print('fht_extrap: chi2', out['chi2'], 'zero padding', out['zero_pad/chi2_0'], 'default model', out['default_model/chi2'])
+    np.savez_compressed(HERE / 'expected_fht_extrap.npz', **out)
+
+
 def dump_fits_ingest(VegaInterface):
     """Static-state ingestion (reference vega/data.py:285-473, utils.py:271-298): a data FITS file that carries the
     synthetic distortion matrix (`DM`) and covariance (`CO`) as vector columns - written by
@@ -1159,7 +1205,7 @@ if __name__ == '__main__':
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1210,3 +1256,5 @@ if __name__ == '__main__':
         dump_direct_pk_metals(VI)
     if 'mockbin_sampled' in what:
         dump_mockbin_sampled(VI)
+    if 'fht_extrap' in what:
+        dump_fht_extrap(VI)

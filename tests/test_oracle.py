@@ -293,6 +293,25 @@ def test_mock_binning_that_follows_a_varying_parameter_matches_reference(mode):
     assert len(set(np.round(exp[f'{mode}/chi2'], 6))) == 4
 
 
+def test_fht_extrap_matches_reference():
+    """`fht_extrap = True` (reference vega/pktoxi.py:41,141) on a model whose spectra keep non-zero end samples; with the test
+    configuration's own model the reference returns NaN (0 / 0 end segments) - so does the oracle."""
+    import copy
+    exp = np.load(GOLDEN / 'expected_fht_extrap.npz')
+    prob = copy.deepcopy(load_problem('auto'))
+    core = prob.items['lyalya_lyalya'].core
+    core.xi.fht_extrap = True
+    with np.errstate(all='ignore'):
+        assert np.isnan(oc.chi2(prob)) and np.isnan(exp['default_model/chi2'])
+    core.pk.small_scale_nl, core.pk.fullshape_smoothing, core.pk.use_gk = None, None, False
+    names = [str(n) for n in exp['param_names']]
+    for i, row in enumerate(exp['theta']):
+        pars = dict(zip(names, map(float, row)))
+        assert oc.chi2(prob, pars) == pytest.approx(float(exp['chi2'][i]), rel=1e-12)
+        model = oc.compute_model(prob, pars)['lyalya_lyalya']
+        assert np.abs(model - exp['model'][i]).max() <= 1e-13 * np.abs(model).max()
+
+
 def test_fits_ingestion_matches_reference(tmp_path):
     """Static-state ingestion (reference vega/data.py:285-473, utils.py:271-298): distortion matrix and covariance
     read from vector columns of a FITS data file.  The reference read the same file (same writer, same generator)

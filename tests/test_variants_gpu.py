@@ -454,3 +454,71 @@ def test_new_bias_evolution_with_a_file_cosmology():
     cross.rel_z_evol_1, cross.rel_z_evol_2 = rel_f, rel_q
     prob.params['alpha_QSO'] = 1.44      # different exponents make the split visible
     _check(prob, n_walkers=2)
+
+
+def _extrap_problem():
+    """The auto-correlation with `fht_extrap = True` on a model whose spectra keep non-zero end samples (no small-scale
+    non-linear term, no full-shape smoothing, no binning kernel; the walkers carry sigmaNL = 0) - tests/golden/make_golden.py:
+    dump_fht_extrap."""
+    prob = _fresh('auto')
+    core = prob.items['lyalya_lyalya'].core
+    core.pk.small_scale_nl, core.pk.fullshape_smoothing, core.pk.use_gk = None, None, False
+    core.xi.fht_extrap = True
+    return prob
+
+
+def test_fht_extrap_against_the_reference():
+    """`fht_extrap = True` (reference vega/pktoxi.py:41,141): power-law pads of the FFTLog input, formed per walker on the
+    device (k_pk_extrap) and multiplied by the padded operator's columns."""
+    from vega_amd import VegaInterface
+    from vega_amd import fftlog_op
+    exp = np.load(GOLDEN / 'expected_fht_extrap.npz')
+    prob = _extrap_problem()
+    vega = VegaInterface(None, problem=prob, max_batch=4)
+    eng = vega.engine
+    assert eng.fht_extrap and eng.fftlog_pads == (617, 617)
+    names = [str(n) for n in exp['param_names']]
+    theta = np.stack([eng.theta_from_params(dict(zip(names, map(float, row)))) for row in exp['theta']])
+    chi2, status = vega.chi2_batch(theta, return_status=True)
+    assert not status.any()
+    np.testing.assert_allclose(chi2, exp['chi2'], rtol=CHI2_RTOL)
+    models = vega.compute_model_batch(theta)['lyalya_lyalya']
+    for i in range(3):
+        assert np.abs(models[i] - exp['model'][i]).max() <= XI_RTOL * np.abs(exp['model'][i]).max(), i
+    # On the radii of this fit the pads are worth 1e-9 of the model (the template reaches 1152 h/Mpc): the stage taps show
+    # them at work.  P_ell rows: the samples, then the pads as numpy forms them; spline coefficients: the padded operator.
+    k = np.asarray(prob.k)
+    nk, (lo, hi) = k.size, eng.fftlog_pads
+    nkp = (nk + lo + hi + 31) // 32 * 32
+    n_cols = len(eng.pk_multipoles(B=3))
+    rows = eng.debug_read(0, 0, 4 * 3 * n_cols * nkp).reshape(4, n_cols * 3, nkp)
+    ncp = (nk + 2 + 31) // 32 * 32
+    coef = eng.debug_read(2, 0, 4 * 3 * n_cols * ncp).reshape(4, n_cols * 3, ncp)
+    moved = 0.0
+    for e, ell in enumerate((0, 2, 4, 6)):
+        op = fftlog_op.xi_operator(k, ell, extrap=True)[0]
+        op0 = fftlog_op.xi_operator(k, ell)[0]
+        for c in range(n_cols * 3):
+            f = rows[e, c, :nk]
+            with np.errstate(all='ignore'):
+                left = f[0] * (f[1] / f[0]) ** (-np.arange(1.0, lo + 1))
+                right = f[-1] * (f[-1] / f[-2]) ** np.arange(1.0, hi + 1)
+            np.testing.assert_allclose(rows[e, c, nk:nk + lo], left, rtol=1e-12, atol=0)
+            np.testing.assert_allclose(rows[e, c, nk + lo:nk + lo + hi], right, rtol=1e-12, atol=0)
+            want = op @ rows[e, c, :nk + lo + hi]
+            got = coef[e, c, :nk + 2]
+            window = got != 0.0             # (the product computes the coefficient rows the batch's bins can read)
+            assert window.sum() > 100
+            assert np.abs(got - want)[window].max() <= 1e-11 * np.abs(want[window]).max()
+            moved = max(moved, np.abs(want - op0 @ f).max() / np.abs(want).max())
+    assert moved > 1e-6            # (the pads do change the transform - at the small radii no bin of this fit reads)
+    vega.close()
+    # the test configuration's own model smooths its spectra to exact zeros at the last wavenumbers: 0 / 0 end segments,
+    # NaN in the reference (recorded in the fixture) - here the non-finite status and the error value
+    assert np.isnan(exp['default_model/chi2'])
+    prob = _fresh('auto')
+    prob.items['lyalya_lyalya'].core.xi.fht_extrap = True
+    vega = VegaInterface(None, problem=prob, max_batch=1)
+    chi2, status = vega.chi2_batch(vega.engine.low.theta0[None, :], return_status=True)
+    assert status[0] != 0 and chi2[0] == 1e100
+    vega.close()

@@ -216,6 +216,7 @@ struct vmx_engine {
     int g_n = 0, g_ld = 0;
 
     int n_params = 0, max_batch = 0, model_size = 0, slab_rows = 0;
+    int pad_l = 0, pad_r = 0;           // vmx_set_fftlog_padding
     int fact_slab_rows = 0;          // rows of the factored form's slabs of F dx (small rows: up to 4 K splits of a full batch)
     std::map<int, std::vector<int>> group_splits;     // K splits of the grouped launches per (stage, batch size)
     // tapes of the quadratic-form launches per number of walker tiles: the blocks' entries, their queues, the partial-sum slots
@@ -645,7 +646,7 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
     REQUIRE(e && !e->finalized, "engine is null or already finalized");
     REQUIRE(nk > 8 && n_mu > 0 && n_mu <= 4096, "bad template sizes");
     HIP_OK(hipSetDevice(e->device));
-    e->nk = nk; e->nkp = vmx_pad(nk); e->n_mu = n_mu;
+    e->nk = nk; e->nkp = vmx_pad(nk + e->pad_l + e->pad_r); e->n_mu = n_mu;      // (the rows of P_ell carry the FFTLog's power-law pads behind the samples)
     const int nkp = e->nkp;
     std::vector<double> buf(nkp, 0.0);
     e->h_k.assign(k, k + nk);
@@ -773,6 +774,14 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
     return 0;
 }
 
+int vmx_set_fftlog_padding(vmx_engine* e, int32_t n_left, int32_t n_right)
+{
+    REQUIRE(e && !e->finalized && e->nk == 0, "vmx_set_fftlog_padding (before vmx_set_template)");
+    REQUIRE(n_left >= 0 && n_right >= 0 && n_left + n_right <= 16384, "vmx_set_fftlog_padding: pad lengths");
+    e->pad_l = n_left; e->pad_r = n_right;
+    return 0;
+}
+
 int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n_coef, double x0, double h,
                    int32_t n_knots)
 {
@@ -786,8 +795,8 @@ int vmx_set_fftlog(vmx_engine* e, int32_t ell_index, const double* op, int32_t n
         if (e->op.alloc((size_t)VMX_MAX_ELL * ncp * e->nkp, true)) return -2;
     }
     REQUIRE(n_coef == e->n_coef, "all multipoles must share the knot count");
-    HIP_OK(hipMemcpy2D(e->op.p + (size_t)ell_index * ncp * e->nkp, (size_t)e->nkp * sizeof(double), op,
-                       (size_t)e->nk * sizeof(double), (size_t)e->nk * sizeof(double), n_coef,
+    const size_t width = (size_t)(e->nk + e->pad_l + e->pad_r) * sizeof(double);       // samples [| left pads | right pads]
+    HIP_OK(hipMemcpy2D(e->op.p + (size_t)ell_index * ncp * e->nkp, (size_t)e->nkp * sizeof(double), op, width, width, n_coef,
                        hipMemcpyHostToDevice));
     e->x0[ell_index] = x0; e->h[ell_index] = h; e->op_set[ell_index] = true;
     return 0;
@@ -1459,7 +1468,8 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
             e->pk_static.clear();
             for (int p : e->pk_poly) {
                 const vmx_pipe_desc& d = e->pipes[p].d;
-                if (!d.uvb && !d.heii && !(d.damping_scale > 0.0) && e->static_poly && !getenv("VMX_NO_STATIC_POLY")) {
+                // (not with fht_extrap: the pads are not linear in P_ell)
+                if (!d.uvb && !d.heii && !(d.damping_scale > 0.0) && e->static_poly && e->pad_l + e->pad_r == 0 && !getenv("VMX_NO_STATIC_POLY")) {
                     PipeDev& pd = e->pipes[p];
                     pd.poly_basis = (int32_t)e->pk_static.size();
                     e->pk_static.push_back(p);
@@ -1584,6 +1594,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     EngineDev& D = e->dev;
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
+    D.pad_l = e->pad_l; D.pad_r = e->pad_r; D.pipe_active = e->d_pipe_active.p;
     D.n_rows = e->n_rows; D.n_extra = e->n_extra; D.mu_lo = e->mu_lo; D.mu_hi = e->mu_hi; D.node_w = e->node_w.p; D.mu_img = e->mu_img.p;
     {
         // the node rule needs the integrand smooth on the scale of its panels: the binning sincs oscillate with k x bin
@@ -2094,10 +2105,16 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
     }
     {
         const int64_t ncols = (int64_t)B * e->n_active;
-        if (ncols > 0)
+        const bool pads = e->pad_l + e->pad_r > 0;
+        if (ncols > 0 && pads) {
+            // fht_extrap: the power-law pads of every (multipole, pipeline, walker) row, behind its samples
+            ScopedTimer t(e, KC_FFTLOG);
+            hipLaunchKernelGGL(k_pk_extrap, dim3((unsigned)(VMX_MAX_ELL * ncols)), dim3(256), 0, e->stream, D, B);
+        }
+        if (ncols > 0)      // (with pads the product runs over the whole row: the live-wavenumber limit is about the samples)
             launch_product(e, KC_FFTLOG, e->op.p, e->nkp, (int64_t)e->ncp * e->nkp, e->n_coef, e->nkp,
                            e->pl.p, e->nkp, ncols * e->nkp, (int)ncols, e->coef.p, e->ncp, ncols * e->ncp,
-                           VMX_MAX_ELL, 0, e->k_live.p, -1, false, e->coef_win.p);
+                           VMX_MAX_ELL, 0, pads ? nullptr : e->k_live.p, -1, false, e->coef_win.p);
     }
     // chi2-only small batches of items without metal terms: bins + quadratic-form entries in one kernel
     bool xi_fused = quad && (size_t)n_pipe == 2 * e->items.size();

@@ -143,6 +143,8 @@ struct ItemSums {
 struct EngineDev {
     // template
     int32_t nk, nkp, n_mu, n_ell;
+    int32_t pad_l, pad_r;       // fht_extrap: power-law pads of the FFTLog input behind the nk samples of a P_ell row
+    const int32_t* pipe_active; // [n_active] the pipeline of a P_ell / coefficient column
     // mu-quadrature nodes appended to every mu-indexed table (mu, lnmu, sq1mmu2, gk, xtab): rows [n_mu, n_rows).  With
     // weights node_w they reproduce the n_mu-point midpoint sums of the reference (power_spectrum.py:76-77, pktoxi.py:138)
     // from the first mu_lo and the last mu_hi midpoints plus n_extra nodes - see vmx_set_mu_quadrature in vegamx.h
@@ -1720,6 +1722,26 @@ __global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : (NW == 1 ? VMX_TAB2_BLOCKS 
     }
     if (G.cross) pk_tab2_body<KT, MS, NW, true>(D, G, B);
     else pk_tab2_body<KT, MS, NW, false>(D, G, B);
+}
+
+// `fht_extrap` (reference pktoxi.py:41,141; mcfit's `_pad(extrap=True)`): behind the nk samples F of every P_ell row the
+// engine writes the FFTLog's power-law pads - F[0] (F[1] / F[0])^-t for t = 1 .. pad_l, then F[nk-1] (F[nk-1] / F[nk-2])^t for
+// t = 1 .. pad_r - which the padded operator's columns multiply (vmx_set_fftlog_padding).  IEEE arithmetic as numpy's:
+// 0 / 0 end segments give NaN.  One block per (multipole, column, walker) row; multipoles a pipeline does not use stay zero.
+__global__ __launch_bounds__(256) void k_pk_extrap(EngineDev D, int B)
+{
+    const size_t ncols = (size_t)B * D.n_active;
+    const int e = (int)(blockIdx.x / ncols);
+    const int col = (int)((blockIdx.x % ncols) / B);
+    double* row = D.pl + (size_t)blockIdx.x * D.nkp;
+    const bool used = e < D.pipes[D.pipe_active[col]].d.n_ell;
+    const double f0 = row[0], f1 = row[1], fm = row[D.nk - 2], fn = row[D.nk - 1];
+    const double ratio_l = f1 / f0, ratio_r = fn / fm;
+    for (int t = threadIdx.x; t < D.pad_l + D.pad_r; t += 256) {
+        double v = 0.0;
+        if (used) v = t < D.pad_l ? f0 * pow(ratio_l, -(double)(t + 1)) : fn * pow(ratio_r, (double)(t - D.pad_l + 1));
+        row[D.nk + t] = v;
+    }
 }
 
 // The shared-W groups (e.g. QSO x every metal line: pipelines that differ in their Kaiser polynomials only) in their own lean

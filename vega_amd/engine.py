@@ -110,6 +110,7 @@ def load_library():
     lib.vmx_add_gk_table.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.vmx_add_gk_table_mock.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
     lib.vmx_set_spline_extrapolation.argtypes = [C.c_void_p, C.c_int32]
+    lib.vmx_set_fftlog_padding.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.vmx_set_fvoigt_table.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_add_pipeline.argtypes = [C.c_void_p, C.POINTER(PipeDesc), C.c_int32, dptr, dptr, dptr, dptr, dptr]
     lib.vmx_add_item.argtypes = [C.c_void_p, C.POINTER(ItemDesc)]
@@ -174,7 +175,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
+    'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_fftlog_padding', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
@@ -537,21 +538,30 @@ class Engine:
             n_mu |= {m.pipeline.pk.n_mu for m in it.metals}
         if len(n_mu) != 1:
             raise NotImplementedError('one engine holds one mu grid: correlations with different num_bins_muk go through engine_group.make_engine')
-        self._check(lib.vmx_set_template(self._h, k.size, _dp(k), _dp(pk_peak), _dp(_f64(prob.pk_smooth)),
-                                         _dp(_f64(prob.pk_full)), _dp(delta2), n_mu.pop()))
-        old = {p.xi.old_fftlog for it in prob.items.values() for p in [it.core] + [m.pipeline for m in it.metals]}
+        pipes = [p for it in prob.items.values() for p in [it.core] + [m.pipeline for m in it.metals]]
+        old = {p.xi.old_fftlog for p in pipes}
         if len(old) != 1:
             raise NotImplementedError('one engine holds one transform: correlations with different old_fftlog go through engine_group.make_engine')
         self.old_fftlog = old.pop()
+        lowring = {p.xi.fht_lowring for p in pipes}
+        extrap = {bool(getattr(p.xi, 'fht_extrap', False)) and not self.old_fftlog for p in pipes}
+        if len(lowring) != 1 or len(extrap) != 1:
+            raise NotImplementedError('one engine holds one operator set: correlations with different fht_lowring / fht_extrap go through engine_group.make_engine')
+        lowring, self.fht_extrap = lowring.pop(), extrap.pop()
+        self.fftlog_pads = (0, 0)
+        if self.fht_extrap:
+            # `fht_extrap = True` (reference pktoxi.py:41,141): the FFTLog's power-law pads ride behind the samples of every
+            # P_ell row and the operators carry their columns (fftlog_op.xi_operator(extrap=True))
+            n_pad = 2 ** int(np.ceil(np.log2(2 * k.size))) - k.size
+            self.fftlog_pads = (n_pad // 2, n_pad - n_pad // 2)
+            self._check(lib.vmx_set_fftlog_padding(self._h, *self.fftlog_pads))
+        self._check(lib.vmx_set_template(self._h, k.size, _dp(k), _dp(pk_peak), _dp(_f64(prob.pk_smooth)),
+                                         _dp(_f64(prob.pk_full)), _dp(delta2), n_mu.pop()))
         if self.old_fftlog:
             self._check(lib.vmx_set_spline_extrapolation(self._h, 1))
-        lowring = {p.xi.fht_lowring for it in prob.items.values() for p in [it.core] + [m.pipeline for m in it.metals]}
-        if len(lowring) != 1:
-            raise NotImplementedError('one engine holds one operator set: correlations with different fht_lowring go through engine_group.make_engine')
-        lowring = lowring.pop()
         for i, ell in enumerate((0, 2, 4, 6)):
             op, x0, h, n_knots = fftlog_op.hamilton_xi_operator(k, ell) if self.old_fftlog else \
-                fftlog_op.xi_operator(k, ell, lowring=lowring)
+                fftlog_op.xi_operator(k, ell, lowring=lowring, extrap=self.fht_extrap)
             op = _f64(op)
             self._check(lib.vmx_set_fftlog(self._h, i, _dp(op), op.shape[0], x0, h, n_knots))
 
@@ -848,7 +858,7 @@ class Engine:
         """P_ell(k) of the last evaluation (batch size B): dict pipeline id -> [B, 4, nk] for the pipelines that form
         their multipoles per walker (the stage tap behind `model_pk`, reference model.py:106-107)."""
         nk = self.prob.k.size
-        nkp = (nk + 31) // 32 * 32
+        nkp = (nk + sum(self.fftlog_pads) + 31) // 32 * 32          # (a row: the samples, then the FFTLog's power-law pads)
         out = {}
         n_cols = None
         for pid in range(self.n_pipelines):

@@ -28,13 +28,14 @@ def _fvoigt_key(pipe):
 
 
 def item_settings(item):
-    """(num_bins_muk, old_fftlog, fht_lowring, Fvoigt table) of a correlation item; its metal pipelines read the same
+    """(num_bins_muk, old_fftlog, fht_lowring, fht_extrap, Fvoigt table) of a correlation item; its metal pipelines read the same
     `[model]` section in the reference (vega/metals.py:60-75), so a disagreement on the transform inside one item is a
     set-up error.  (Pipelines without a Voigt table go with whatever table their item's other pipelines use.)"""
     pipes = [item.core] + [m.pipeline for m in item.metals]
-    keys = {(p.pk.n_mu, bool(p.xi.old_fftlog), bool(p.xi.fht_lowring)) for p in pipes}
+    keys = {(p.pk.n_mu, bool(p.xi.old_fftlog), bool(p.xi.fht_lowring), bool(getattr(p.xi, 'fht_extrap', False)) and not p.xi.old_fftlog)
+            for p in pipes}
     if len(keys) != 1:
-        raise ValueError(f'the pipelines of one correlation item disagree on num_bins_muk / old_fftlog / fht_lowring: {sorted(keys)}')
+        raise ValueError(f'the pipelines of one correlation item disagree on num_bins_muk / old_fftlog / fht_lowring / fht_extrap: {sorted(keys)}')
     tables = {k for k in map(_fvoigt_key, pipes) if k is not None}
     if len(tables) > 1:
         raise NotImplementedError('one correlation item with two different Fvoigt tables')
@@ -49,8 +50,8 @@ def setting_groups(problem):
     # an item without a Voigt table can share an engine with one that has one (same transform settings)
     merged = {}
     for key, names in groups.items():
-        if key[3] is None:
-            host = next((k for k in groups if k[:3] == key[:3] and k[3] is not None), key)
+        if key[-1] is None:
+            host = next((k for k in groups if k[:-1] == key[:-1] and k[-1] is not None), key)
             merged.setdefault(host, []).extend(names)
         else:
             merged.setdefault(key, []).extend(names)

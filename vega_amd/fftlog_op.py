@@ -27,10 +27,14 @@ def _mellin_u(ell, z):
     return np.exp(np.log(2.0) * (z - 1.5) + loggamma(0.5 * (ell + z)) - loggamma(0.5 * (3 + ell - z)))
 
 
-def fftlog_matrix(k, ell, q=1.5, lowring=True):
+def fftlog_matrix(k, ell, q=1.5, lowring=True, pads=False):
     """(H, ln r): xi_ell(r_n) = sum_j H[n, j] P_ell(k_j) for mcfit.P2xi(k, l=ell, lowring=lowring)
     called with extrap=False (zero padding).  ``lowring=False`` (`fht_lowring = False`, reference pktoxi.py:42,53):
-    x y = 1 and a real Nyquist term."""
+    x y = 1 and a real Nyquist term.
+
+    ``pads=True`` (`fht_extrap = True`, reference pktoxi.py:41,141) returns (H, HL, HR, ln r): the operator's columns over
+    the padded input as well - HL[:, t - 1] multiplies the left pad sample F[0] (F[1] / F[0])**(-t), HR[:, t - 1] the right
+    pad sample F[-1] (F[-1] / F[-2])**t (t = 1 .. pad length), prefactor on the extended grid included."""
     k = np.asarray(k, dtype=float)
     n = k.size
     delta = np.log(k[-1] / k[0]) / (n - 1)
@@ -53,7 +57,16 @@ def fftlog_matrix(k, ell, q=1.5, lowring=True):
     ln_r = lnxy - delta - np.log(k[::-1])
     pre = k ** (3 - q) / (2 * np.pi) ** 1.5
     post = (-1.0) ** (ell // 2) * np.exp(-q * ln_r)
-    return post[:, None] * circ * pre[None, :], ln_r
+    H = post[:, None] * circ * pre[None, :]
+    if not pads:
+        return H, ln_r
+    t_left = np.arange(1, pad_in + 1)                   # padded index pad_in - t
+    t_right = np.arange(1, N - pad_in - n + 1)          # padded index pad_in + n + t - 1
+    pre_left = (k[0] * np.exp(-delta * t_left)) ** (3 - q) / (2 * np.pi) ** 1.5
+    pre_right = (k[-1] * np.exp(delta * t_right)) ** (3 - q) / (2 * np.pi) ** 1.5
+    HL = post[:, None] * impulse[(rows + (pad_in - t_left)[None, :]) % N] * pre_left[None, :]
+    HR = post[:, None] * impulse[(rows + (pad_in + n + t_right - 1)[None, :]) % N] * pre_right[None, :]
+    return H, HL, HR, ln_r
 
 
 @functools.lru_cache(maxsize=4)
@@ -76,9 +89,14 @@ def notaknot_bspline_matrix(n):
     return S
 
 
-def xi_operator(k, ell, lowring=True):
-    """(OP, x0, h, n_knots): B-spline coefficients of xi_ell(ln r) from P_ell(k)."""
-    H, ln_r = fftlog_matrix(k, ell, lowring=lowring)
+def xi_operator(k, ell, lowring=True, extrap=False):
+    """(OP, x0, h, n_knots): B-spline coefficients of xi_ell(ln r) from P_ell(k).  ``extrap``: OP has the columns of the
+    power-law pads behind those of the samples, [n_k | left pads t = 1.. | right pads t = 1..] (:func:`fftlog_matrix`)."""
+    if extrap:
+        H, HL, HR, ln_r = fftlog_matrix(k, ell, lowring=lowring, pads=True)
+        H = np.hstack([H, HL, HR])
+    else:
+        H, ln_r = fftlog_matrix(k, ell, lowring=lowring)
     n = ln_r.size
     h = (ln_r[-1] - ln_r[0]) / (n - 1)
     if np.max(np.abs(np.diff(ln_r) - h)) > 1e-10 * h:

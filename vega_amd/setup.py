@@ -221,6 +221,7 @@ class XiOptions:
     uv_shotnoise: bool = False
     rescale_coords_systematics: bool = False
     fht_lowring: bool = True         # [model] fht_lowring (reference pktoxi.py:42,53)
+    fht_extrap: bool = False         # [model] fht_extrap (reference pktoxi.py:41,141): power-law pads of the FFTLog input
     old_growth: bool = False         # [model] old_growth_func (reference correlation_func.py:75-80)
 
 
@@ -509,8 +510,7 @@ def _xi_options(model_section, xi_section, tracers):
     opts = XiOptions()
     opts.ell_max = model_section.getint('ell_max', 6)
     opts.old_fftlog = model_section.getboolean('old_fftlog', False)
-    if model_section.getboolean('fht_extrap', False):
-        raise NotImplementedError('fht_extrap is not supported')
+    opts.fht_extrap = model_section.getboolean('fht_extrap', False)       # (the legacy transform ignores it)
     opts.fht_lowring = model_section.getboolean('fht_lowring', True)
     opts.single_multipole = xi_section.getint('single_multipole', -1)
     opts.rescale_coords_systematics = xi_section.getboolean('rescale-coords-systematics', False)
