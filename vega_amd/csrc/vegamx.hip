@@ -1985,10 +1985,10 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
     D.xtab_block0 = 0;
     {
         ScopedTimer t(e, KC_PROLOGUE);
-        // grid = (n_pipe + 1 slots) x (chunks of PRO_T walkers) [+ the blocks that check the P(k,mu) tables against walker 0:
+        // grid = (2 n_pipe + 1 slots: the P(k,mu) half and the xi half of every pipeline's scalars, the walker-level values) x (chunks of PRO_T walkers) [+ the blocks that check the P(k,mu) tables against walker 0:
         // k_xtab's grid, flattened]; LDS of a block: the constant-slot list with walker 0's values,
         // the mu rule's box, its walkers
-        const int n_pro = (n_pipe + 1) * ((B + PRO_T - 1) / PRO_T);
+        const int n_pro = (2 * n_pipe + 1) * ((B + PRO_T - 1) / PRO_T);
         const size_t lds = ((size_t)2 * D.n_const_slots + (size_t)3 * e->rule_slot.size() + (size_t)PRO_T * (e->n_params | 1)) * sizeof(double);
         int n_tab = 0;
         // (walkers in mapped host memory: a thousand table blocks would each cross PCIe for walker 0 - k_xtab follows instead)

@@ -325,9 +325,12 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
         xtab_body(D, q / (nbx * nby), q % nbx, (q / nbx) % nby, rows_per_block, src_all);
         return;
     }
-    // block = (slot, 64 walkers): slots 0 .. n_pipe-1 fill one pipeline's scalars, slot n_pipe the walker-level values.  A wave
-    // serves ONE slot: every branch on the pipeline's descriptor is uniform (with the walker's slots side by side in a wave it
-    // walked every pipeline's path in turn), and the descriptor reads are broadcasts.
+    // block = (slot, 64 walkers).  Slots 0 .. n_pipe-1 fill the P(k,mu) half of one pipeline's scalars (amplitudes, UV, HCD,
+    // Gaussian exponents, Arinyo, velocity dispersion: S_BIAS1 .. S_VD2), slots n_pipe .. 2 n_pipe-1 its xi half (scale
+    // parameters, the coefficient window, evolution, radiation, the mu rule's guard: S_AP .. S_NO_RULE), slot 2 n_pipe the
+    // walker-level values.  A wave serves ONE slot: every branch on the pipeline's descriptor is uniform (with the walker's
+    // slots side by side in a wave it walked every pipeline's path in turn), the descriptor reads are broadcasts, and a block
+    // fetches the code of its half only (the kernel's time is its instruction fetch).
 #ifdef VMX_EXP_PRO_TRACE
 #define PRO_STAMP(I) do { if (threadIdx.x == 0 && D.pk_trace) D.pk_trace[8 * blockIdx.x + (I)] = wall_clock64(); } while (0)
 #else
@@ -341,7 +344,9 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
     // The slot's pipeline descriptor is read dozens of times ahead of data-dependent branches.  It is static and the slot is
     // the block's: through the constant address space those reads are scalar loads (batched by the compiler, cached) and the
     // branches scalar branches - from LDS or global memory every one of them was a vector round trip the next read waited for.
-    const VMX_CAS PipeDev& P = *(const VMX_CAS PipeDev*)(D.pipes + min(slot, D.n_pipe - 1));
+    const bool half_b = slot >= D.n_pipe && slot < 2 * D.n_pipe, walker_slot = slot == 2 * D.n_pipe;
+    const int p = min(half_b ? slot - D.n_pipe : slot, D.n_pipe - 1);
+    const VMX_CAS PipeDev& P = *(const VMX_CAS PipeDev*)(D.pipes + p);
     // LDS: [constant-slot list with walker 0's values][rule box][the block's walkers] - the lists the walker loops below walk
     // (from global memory every element of theirs is a dependent round trip inside the loop) and the parameters
     extern __shared__ double s_dyn[];
@@ -379,9 +384,9 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
                                                          (__attribute__((address_space(3))) void*)((char*)(s_theta + r * t_ld) + c0 * 4), 4, 0, 0);
         }
         // the lists (slot n_pipe: the constant slots with walker 0's values; the others: the rule's box)
-        if (slot == D.n_pipe)
+        if (walker_slot)
             for (int i = threadIdx.x; i < n_cs; i += PRO_T) { const int q = D.const_slots[i]; s_cs[i] = (double)q; s_c0[i] = src_all[q]; }
-        else
+        else if (half_b)
             for (int i = threadIdx.x; i < n_ru; i += PRO_T) { s_ru[i] = (double)D.rule_slot[i]; s_ru[n_ru + i] = D.rule_lo[i]; s_ru[2 * n_ru + i] = D.rule_hi[i]; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -398,15 +403,16 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
             for (int c = threadIdx.x; c < D.n_params; c += PRO_T) dst[r * D.n_params + c] = s_theta[r * t_ld + c];
     }
 
-    if (slot < D.n_pipe) {
-        const int p = slot;
+    if (!walker_slot) {
         const auto& d = P.d;
         // the scalars are collected in registers and stored at the end: with stores in between, the compiler has to keep
         // every parameter load behind the previous store (the pointers may alias) - ~30 dependent L2 round trips
         double s[VMX_NS];
 #pragma unroll
         for (int i = 0; i < VMX_NS; ++i) s[i] = 0.0;
+        double* out = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
 
+      if (!half_b) {
         const double gr = th(t, d.growth_rate_slot, d.growth_rate_default);
         double b1, be1, b2, be2;
         tracer_bias_beta(t, d.tracer[0], gr, b1, be1);
@@ -446,7 +452,11 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
             s[S_AKV] = t[d.arinyo_slot[2]]; s[S_AAV] = t[d.arinyo_slot[3]];
             s[S_ABV] = t[d.arinyo_slot[4]]; s[S_AKP] = t[d.arinyo_slot[5]];
         }
-
+        PRO_STAMP(2);
+        if (live)
+#pragma unroll
+            for (int i = 0; i < S_AP; ++i) out[i] = s[i];
+      } else {
         // scale parameters (reference scale_parameters.py:162-230)
         double ap = 1.0, at = 1.0;
         if (d.scale_mode == VMX_SCALE_AP_AT) { ap = t[d.scale_slot[0]]; at = t[d.scale_slot[1]]; }
@@ -459,7 +469,6 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
         }
         s[S_AP] = ap; s[S_AT] = at;
         s[S_DRP] = th(t, d.drp_slot, 0.0);
-        PRO_STAMP(2);
         {
             // Spline coefficients this (walker, pipeline) can read: r'^2 = ap^2 (rp + drp)^2 + at^2 rt^2 over its bins is
             // bounded by the extremes of |rp|, rt (|rp + drp| lies in [max(0, |rp| - |drp|), |rp| + |drp|]); the FFTLog
@@ -517,18 +526,18 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
             if (outside && p == 0 && live) atomicAdd(D.k_live + 4, 1);          // (a statistic: walkers that left the box, cumulative)
         }
         PRO_STAMP(4);
-        double* out = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
         if (live)
 #pragma unroll
-            for (int i = 0; i < VMX_NS; ++i) out[i] = s[i];
+            for (int i = S_AP; i < VMX_NS; ++i) out[i] = s[i];
         PRO_STAMP(5);
+      }
     }
 
     // metal bias products (reference metals.py:295-313, :331-332) and the Kaiser coefficients of the static-basis metals
-    // (the walker's n_pipe + 1 threads share the metals: one serial chain of 19 bias / beta look-ups per walker was a third of
+    // (the walker's 2 n_pipe + 1 threads share the metals: one serial chain of 19 bias / beta look-ups per walker was a third of
     // this kernel at 23 pipelines)
     if (!live) return;
-    for (int m = slot; m < D.n_metals_total; m += D.n_pipe + 1) {
+    for (int m = slot; m < D.n_metals_total; m += 2 * D.n_pipe + 1) {
         const vmx_metal_desc& d = D.metals[m].d;
         double f = d.multiplicity;
         const double gr = th(t, d.growth_rate_slot, d.growth_rate_default);
@@ -542,7 +551,7 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
         mb[D.n_metals_total + m] = be1 + be2;
         mb[2 * D.n_metals_total + m] = be1 * be2;
     }
-    if (slot < D.n_pipe) return;
+    if (!walker_slot) return;
 
     int st = 0;
     for (int q = 0; q < n_cs; ++q)
