@@ -1554,7 +1554,7 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
             if (G.lya2) c02[w] += add;
         }
     }
-#ifdef VMX_EXP_PK_PHASE     /* experiment build (scripts/gpu_pk_trace.py): the trace's last two words are phase stamps, not hardware ids */
+#ifdef VMX_EXP_PK_PHASE     /* experiment build (scripts/gpu_pk_phase.py): the trace's last two words are phase stamps, not hardware ids */
     const unsigned long long t_setup = D.pk_trace ? wall_clock64() : 0ull;
 #endif
 
