@@ -21,8 +21,10 @@ eng.sync()
 t = np.fromfile(out, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
 t0 = t[:, 0][t[:, 0] > 0].min()
 np.set_printoptions(linewidth=200, precision=2, suppress=True)
-print('block: entry, then us since entry of: staged, scalars, window, pre-store, stored, walker-slot end, loads arrived')
+print('k_prologue, B = 256: 4 chunks of 64 walkers x (n_pipe P(k,mu)-half slots, n_pipe xi-half slots, 1 walker-level slot), one single-wave block each')
+print('block | entry (us after the first block) | us since entry of: staging barrier passed, P(k,mu) half: scalars done, xi half: window done, '
+      'xi half: all formed, xi half: stored, walker slot: done, staging loads landed')
 for i, row in enumerate(t):
     if row[0] == 0: continue
-    rel = [(x - row[0]) / 100.0 if x else float("nan") for x in row[1:8]]
+    rel = [(x - row[0]) / 100.0 if x >= row[0] else float("nan") for x in row[1:8]]       # (older stamps: another launch's)
     print(i, f'{(row[0] - t0) / 100.0:7.2f}', np.array(rel))
