@@ -551,3 +551,31 @@ def test_rescaled_covariance_with_marginalize_in_fit_through_the_engine(tmp_path
         'errors': {'ap': 0.01, 'at': 0.01}, 'fix': {'ap': False, 'at': False}})
     assert res.is_valid.all() and np.all(res.fval < 3 * 1590)
     vega.close()
+
+
+@pytest.mark.parametrize('n_extra', [70, 170])
+def test_many_parameters(n_extra):
+    """Engines with 130 / 230 parameters (DESI fits with many broadband terms): k_prologue keeps 64 walkers' rows in LDS - more
+    than 64 KB of dynamic LDS beyond ~125 parameters, several 64-dword chunks per row - and the parameters a model does not
+    read change nothing, bit for bit."""
+    from vega_amd import VegaInterface
+    prob = load_problem('joint')
+    base = VegaInterface(None, problem=prob, max_batch=80)
+    wide = VegaInterface(None, problem=prob, max_batch=80, extra_names=[f'zz_unused_{i:03d}' for i in range(n_extra)] +
+                         [f'AA_unused_{i:03d}' for i in range(4)])
+    assert wide.engine.n_params == base.engine.n_params + n_extra + 4 > 125
+    from vega_amd import synthetic
+    theta = synthetic.walkers(base.engine.low.theta0, base.engine.names, 80, seed=77)
+    wide_theta = np.random.default_rng(5).normal(size=(80, wide.engine.n_params))
+    for j, name in enumerate(base.engine.names):
+        wide_theta[:, wide.engine.names.index(name)] = theta[:, j]
+    for B in (1, 3, 80):
+        a, sa = base.chi2_batch(theta[:B], return_status=True)
+        b, sb = wide.chi2_batch(wide_theta[:B], return_status=True)
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(a, b)
+    ma = base.compute_model_batch(theta[:5])
+    mb = wide.compute_model_batch(wide_theta[:5])
+    for name in prob.items:
+        np.testing.assert_array_equal(ma[name], mb[name])
+    base.close(); wide.close()

@@ -2009,6 +2009,20 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             D.pk_trace = e->pk_trace.p;
         }
 #endif
+        if (lds > 160 * 1024 - 256) return fail(-1, "too many parameters for k_prologue's walker rows in LDS (64 x n_params doubles)");
+        if (lds > 64 * 1024) {
+            // beyond ~125 parameters the rows need more than the default 64 KB of dynamic LDS: the function attribute is the
+            // driver's, per device and monotone - the largest request so far is remembered per device
+            static std::mutex mu;
+            static size_t allowed[64] = {};
+            std::lock_guard<std::mutex> lock(mu);
+            size_t& a = allowed[e->device & 63];
+            if (lds > a) {
+                HIP_OK(hipFuncSetAttribute((const void*)k_prologue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_OK(hipFuncSetAttribute((const void*)k_prologue_byval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                a = lds;
+            }
+        }
         if (zero_copy && theta_by_value) {
             // (eager launches only: a captured graph would replay the walker it was captured with)
             ThetaArg ta;
