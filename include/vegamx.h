@@ -160,7 +160,8 @@ void vmx_destroy(vmx_engine* e);
 
 /* Template grids (vega_interface.py:690-696; power_spectrum.py:72-81; pktoxi.py:37,55).
  * pk_peak = pk_full - pk_smooth as formed by the caller (model.py:177);
- * delta2 = k^3 pk_fid / (2 pi^2) (power_spectrum.py:462). */
+ * delta2 = k^3 pk_fid / (2 pi^2) (power_spectrum.py:462).  n_mu = num_bins_muk (power_spectrum.py:52-58; default 1000): at
+ * most 2048 - the mu tables of the P(k,mu) kernels live in LDS. */
 int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* pk_peak,
                      const double* pk_smooth, const double* pk_full, const double* delta2,
                      int32_t n_mu);

@@ -23,7 +23,7 @@ def _mixed(**changes):
 
 
 @pytest.mark.parametrize('changes', [dict(fht_lowring=False), dict(old_fftlog=True), dict(n_mu=400),
-                                     dict(n_mu=400, fht_lowring=False)], ids=str)
+                                     dict(n_mu=400, fht_lowring=False), dict(n_mu=2000)], ids=str)
 def test_mixed_settings_match_the_oracle(changes):
     import torch
     from oracle import vega_cpu as oc

@@ -644,7 +644,8 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
                      const double* pk_smooth, const double* pk_full, const double* delta2, int32_t n_mu)
 {
     REQUIRE(e && !e->finalized, "engine is null or already finalized");
-    REQUIRE(nk > 8 && n_mu > 0 && n_mu <= 4096, "bad template sizes");
+    REQUIRE(nk > 8 && n_mu > 0, "bad template sizes");
+    REQUIRE(n_mu <= 2048, "num_bins_muk above 2048: the mu tables of the P(k,mu) kernels no longer fit a CU's LDS (the reference's default is 1000)");
     HIP_OK(hipSetDevice(e->device));
     e->nk = nk; e->nkp = vmx_pad(nk + e->pad_l + e->pad_r); e->n_mu = n_mu;      // (the rows of P_ell carry the FFTLog's power-law pads behind the samples)
     const int nkp = e->nkp;
@@ -2057,6 +2058,19 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             n_other = n_groups - e->n_xtab;
             // (the node tables' image, + [2 terms][2 walkers][64 wavenumbers] of UV / HeII bias terms behind it)
             const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra + 256) * sizeof(double);
+            if (sh1 > 64 * 1024) {
+                // (num_bins_muk near its limit of 4096: the node tables alone are 64 KB - the driver's per-device attribute, monotone)
+                static std::mutex mu;
+                static size_t allowed[64] = {};
+                std::lock_guard<std::mutex> lock(mu);
+                size_t& a = allowed[e->device & 63];
+                if (sh1 > a) {
+                    HIP_OK(hipFuncSetAttribute((const void*)k_pk_tab2<64, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1));
+                    HIP_OK(hipFuncSetAttribute((const void*)k_pk_tab2<64, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1));
+                    HIP_OK(hipFuncSetAttribute((const void*)k_pk_tab2<16, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1));
+                    a = sh1;
+                }
+            }
 #ifdef VMX_EXP_PRO_TRACE       // (experiment build: the trace buffer holds k_prologue's stamps, scripts/gpu_pro_trace.py)
             D.pk_trace = nullptr;
             if (false) {
