@@ -579,3 +579,24 @@ def test_many_parameters(n_extra):
     for name in prob.items:
         np.testing.assert_array_equal(ma[name], mb[name])
     base.close(); wide.close()
+
+
+def test_a_walkers_model_does_not_depend_on_the_batch_around_it():
+    """129 walkers in one batch and in batches of 64 + 65: the same models bit for bit - k_prologue's 64-walker blocks at their
+    chunk boundaries, the last chunk with a single walker.  One by one (the by-value entry; the streaming products and the
+    16-slice P(k,mu) blocks of a single walker sum in another order): to rounding."""
+    from vega_amd import VegaInterface, synthetic
+    prob = load_problem('joint')
+    vega = VegaInterface(None, problem=prob, max_batch=129)
+    theta = synthetic.walkers(vega.engine.low.theta0, vega.engine.names, 129, seed=131,
+                              varied=['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'drp_QSO', 'bias_hcd', 'L0_hcd'])
+    whole = vega.compute_model_batch(theta)
+    first, rest = vega.compute_model_batch(theta[:64]), vega.compute_model_batch(theta[64:])
+    one_a, one_z = vega.compute_model_batch(theta[:1]), vega.compute_model_batch(theta[128:])
+    for name in prob.items:
+        np.testing.assert_array_equal(whole[name][:64], first[name])
+        np.testing.assert_array_equal(whole[name][64:], rest[name])
+        scale = np.abs(whole[name]).max()
+        np.testing.assert_allclose(whole[name][:1], one_a[name], rtol=0, atol=1e-14 * scale)
+        np.testing.assert_allclose(whole[name][128:], one_z[name], rtol=0, atol=1e-14 * scale)
+    vega.close()
