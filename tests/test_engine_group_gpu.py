@@ -115,3 +115,57 @@ def test_group_with_metals_freezes_static_metals_and_serves_device_walkers():
     dev = vega.chi2_batch_device(torch.as_tensor(theta, device='cuda'))
     np.testing.assert_allclose(dev.cpu().numpy(), before, rtol=1e-9)
     vega.close()
+
+
+def _chi2_models(vega, prob, theta):
+    chi2, status = vega.chi2_batch(theta, return_status=True)
+    assert not status.any()
+    return chi2, vega.compute_model_batch(theta[:2])
+
+
+def test_global_covariance_across_engines():
+    """A global covariance (reference vega/vega_interface.py:295-304) over correlations that sit in different engines:
+    r^T G r = sum_i r_i^T G_ii r_i + 2 sum_{i<j} r_i^T G_ij r_j - every engine with its diagonal block, the cross terms from
+    the engines' models on the device.  (1) The same problem split by hand into two engines against ONE engine; (2) a
+    mixed-setting problem (`fht_lowring = False` on the cross-correlation) against the oracle; device walkers; new data."""
+    import torch
+    from oracle import vega_cpu as oc
+    from vega_amd import VegaInterface, synthetic
+    from vega_amd.engine import Engine
+    from vega_amd.engine_group import EngineGroup
+    prob = synth_joint_problem(with_global_cov=True)
+    names = list(prob.items)
+    one = Engine(prob, max_batch=16)
+    two = EngineGroup(prob, [[names[0]], [names[1]]], max_batch=16)
+    theta = np.vstack([one.low.theta0[None, :], synthetic.walkers(one.low.theta0, one.names, 11, seed=29)])
+    a, sa, ma = one.eval(theta, want_model=True)
+    b, sb, mb = two.eval(theta, want_model=True)
+    assert not sa.any() and not sb.any()
+    np.testing.assert_allclose(b, a, rtol=1e-11)
+    np.testing.assert_allclose(mb, ma, rtol=0, atol=1e-14 * np.abs(ma).max())        # (other launch groupings: other split-K sums)
+    one.close(); two.close()
+
+    prob = _mixed(fht_lowring=False)
+    prob.global_cov = synth_joint_problem(with_global_cov=True).global_cov
+    vega = VegaInterface(None, problem=prob, max_batch=8)
+    assert isinstance(vega.engine, EngineGroup) and vega._use_global_cov
+    theta = theta[:12]
+    chi2, status = vega.chi2_batch(theta, return_status=True)          # (two chunks of max_batch)
+    assert not status.any()
+    for i in (0, 5, 11):
+        pars = dict(zip(vega.engine.names, theta[i]))
+        assert chi2[i] == pytest.approx(oc.chi2(prob, pars), rel=CHI2_RTOL)
+    assert vega.chi2(dict(zip(vega.engine.names, theta[3]))) == pytest.approx(chi2[3], rel=1e-12)
+    assert vega.log_lik(dict(zip(vega.engine.names, theta[3]))) == pytest.approx(oc.log_lik(prob, dict(zip(vega.engine.names, theta[3]))), rel=1e-6)
+    dev = vega.chi2_batch_device(torch.as_tensor(theta, device='cuda'))
+    np.testing.assert_allclose(dev.cpu().numpy(), chi2, rtol=1e-12)
+    # other data (a Monte-Carlo mock installed as data: the cross terms read the engines' current data)
+    import copy
+    name = names[1]
+    prob2 = copy.deepcopy(prob)
+    prob2.items[name].data_vec = prob2.items[name].data_vec * 1.01
+    vega.engine.set_data(name, prob2.items[name].masked_data_vec)
+    moved = vega.chi2_batch(theta[:2])
+    assert moved[1] == pytest.approx(oc.chi2(prob2, dict(zip(vega.engine.names, theta[1]))), rel=CHI2_RTOL)
+    assert abs(moved[1] - chi2[1]) > 1e-5 * abs(chi2[1])             # (the data did change the answer)
+    vega.close()

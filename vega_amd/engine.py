@@ -432,9 +432,11 @@ class Engine:
     """One vegamx engine handle on one GPU, built from a Problem."""
 
     def __init__(self, problem, max_batch=256, device=0, extra_names=(), metal_plan=None, kron_metals=True,
-                 csr_threshold=None, static_poly=True):
+                 csr_threshold=None, static_poly=True, global_chi2_matrix=None):
         self.lib = load_library()
         self.prob = problem
+        # engine_group: this engine's diagonal block of the global inverse covariance of a problem split over several engines
+        self.global_chi2_matrix = None if global_chi2_matrix is None else _f64(global_chi2_matrix)
         # False: polynomial pipelines keep their per-walker P(k) -> xi path instead of the static spline-coefficient basis of
         # the template's spectra (include/vegamx.h: vmx_set_static_poly) - what direct_pk needs when metal terms are part of it
         self.static_poly = bool(static_poly)
@@ -455,6 +457,7 @@ class Engine:
         self.lanes = 1
         self._h = C.c_void_p()
         self._gk = {}
+        self.device = int(device)
         self._check(self.lib.vmx_create(C.byref(self._h), int(device)))
         try:
             self._build()
@@ -729,15 +732,15 @@ class Engine:
                 # best-fit template coefficients = M . residual (reference vega_interface.py:546-579)
                 m = _f64(item.marg_diff2coeff)
                 self._check(lib.vmx_item_set_marg_matrix(self._h, iid, _dp(m), m.shape[0], m.shape[1]))
-            if item.cov is not None and prob.global_cov is None:
+            if item.cov is not None and prob.global_cov is None and self.global_chi2_matrix is None:
                 cinv = _f64(item.chi2_matrix)      # C^-1, or P^T C^-1 P with marginalize-in-fit (setup.py)
                 self._check(lib.vmx_item_set_matrix(self._h, iid, MAT_INVCOV, 0, cinv.shape[0], cinv.shape[1],
                                                     _dp(cinv)))
             self.model_slices[name] = slice(off, off + item.dist_grid.size)
             off += item.dist_grid.size
 
-        if prob.global_cov is not None:
-            g = _f64(prob.global_masks()['chi2_matrix'])
+        if prob.global_cov is not None or self.global_chi2_matrix is not None:
+            g = self.global_chi2_matrix if self.global_chi2_matrix is not None else _f64(prob.global_masks()['chi2_matrix'])
             self._check(lib.vmx_set_global_invcov(self._h, _dp(g), g.shape[0]))
         for pname, (mean, sigma) in prob.priors.items():
             self._check(lib.vmx_add_prior(self._h, low.need(pname), float(mean), float(sigma)))

@@ -6,7 +6,9 @@ In the reference every correlation item owns its operators - `num_bins_muk` size
 chi2 sum (vega/vega_interface.py:232-316).  A vegamx engine holds ONE mu grid, ONE FFTLog operator set and ONE Voigt table
 in HBM, which is what every real configuration needs (the settings come from a shared template); here the rare mixed configuration is served by partitioning the items by setting and giving each part its
 own engine on the same GPU: chi2 is the sum of the parts' chi2 (the priors enter once, through the first part), a model
-is the concatenation of the parts' models in the configured item order.
+is the concatenation of the parts' models in the configured item order.  A global covariance (vega/vega_interface.py:295-304)
+couples the parts: each engine takes its diagonal block of the global inverse, the cross terms are formed from the engines'
+models on the device (`EngineGroup._eval_global_device`).
 
 ``make_engine`` returns a plain ``Engine`` when the settings agree - the group is never on the hot path of BASELINE.json's
 configurations.
@@ -71,19 +73,36 @@ class EngineGroup:
     """The ``Engine`` surface over one engine per setting group (see the module text)."""
 
     def __init__(self, problem, groups, **kwargs):
-        if problem.global_cov is not None:
-            raise NotImplementedError('a global covariance couples correlations with different num_bins_muk / old_fftlog / '
-                                      'fht_lowring: one engine cannot hold them and separate engines cannot share it')
         self.prob = problem
         self.groups = [list(g) for g in groups]
         self.children = []
+        # A global covariance (reference vega/vega_interface.py:295-304: chi2 = r^T G r over the concatenated masked residual)
+        # couples the engines: r^T G r = sum_i r_i^T G_ii r_i + 2 sum_{i<j} r_i^T G_ij r_j with the blocks of G over the
+        # engines' items.  Engine i takes G_ii as ITS global matrix (priors, blinding and status stay where they are); the
+        # cross terms are formed here from the engines' models on the device (`_cross_terms`).
+        blocks = None
+        if problem.global_cov is not None:
+            gm = problem.global_masks()
+            rows, off = {}, 0
+            for name, item in problem.items.items():
+                rows[name] = np.arange(off, off + item.data_size)
+                off += item.data_size
+            blocks = [np.concatenate([rows[n] for n in names]) for names in self.groups]
+            self._global = dict(G=np.asarray(gm['chi2_matrix'], dtype=np.float64), blocks=blocks, dev=None,
+                                data={n: np.asarray(it.masked_data_vec, dtype=np.float64).copy() for n, it in problem.items.items()})
+        else:
+            self._global = None
         try:
             for gi, names in enumerate(self.groups):
                 sub = copy.copy(problem)
                 sub.items = {n: problem.items[n] for n in names}
                 if gi > 0:
                     sub.priors = {}             # (the Gaussian priors are part of the first engine's chi2 only)
-                self.children.append(Engine(sub, **kwargs))
+                extra = {}
+                if blocks is not None:
+                    sub.global_cov, sub._global = None, None
+                    extra['global_chi2_matrix'] = self._global['G'][np.ix_(blocks[gi], blocks[gi])]
+                self.children.append(Engine(sub, **kwargs, **extra))
         except Exception:
             self.close()
             raise
@@ -119,6 +138,8 @@ class EngineGroup:
         theta = np.asarray(theta, dtype=np.float64)
         if theta.ndim == 1:
             theta = theta[None, :]
+        if self._global is not None:
+            return self._eval_global_host(theta, want_model)
         parts = [c.eval(theta, want_model) for c in self.children]
         status = parts[0][1].copy()
         for p in parts[1:]:
@@ -131,11 +152,98 @@ class EngineGroup:
                 model[:, dst] = parts[ci][2][:, src]
         return chi2, status, model
 
+    # ---- a global covariance over the engines
+    def _global_state(self, device):
+        """Device copies of what the cross terms need (made once): per engine the positions of its masked bins in its model
+        vector and its masked data, per pair of engines the zero-padded off-diagonal block of G."""
+        import torch
+        g = self._global
+        if g['dev'] is None:
+            pad = lambda n: (n + 31) // 32 * 32
+            idx, data = [], []
+            for c, names in zip(self.children, self.groups):
+                pos = [c.model_slices[n].start + np.flatnonzero(self.prob.items[n].model_mask) for n in names]
+                idx.append(torch.as_tensor(np.concatenate(pos), device=device, dtype=torch.int64))
+                data.append(torch.as_tensor(np.concatenate([g['data'][n] for n in names]), device=device))
+            cross = {}
+            for i in range(len(self.children)):
+                for j in range(i + 1, len(self.children)):
+                    blk = g['G'][np.ix_(g['blocks'][i], g['blocks'][j])]
+                    m = np.zeros((blk.shape[0], pad(blk.shape[1])))
+                    m[:, :blk.shape[1]] = blk
+                    cross[(i, j)] = torch.as_tensor(m, device=device)
+            g['dev'] = dict(idx=idx, data=data, cross=cross, pad=pad, bufs=None)
+        return g['dev']
+
+    def _eval_global_device(self, theta, out, status=None, models=None):
+        """chi2 with a global covariance for CUDA walkers: every engine evaluates model and its diagonal term (its own
+        stream, ordered by events as in `eval_device_tensor`), then the cross terms 2 r_i^T G_ij r_j - the product G_ij r_j on
+        the first engine's product kernels (`vmx_matvec_device`), residuals and row sums as tensor glue."""
+        import torch
+        st = self._global_state(theta.device)
+        B, n_eng = theta.shape[0], len(self.children)
+        cap = max(B, self.max_batch)
+        if st['bufs'] is None or st['bufs']['chi2'].shape[1] < B:
+            st['bufs'] = dict(
+                chi2=torch.empty((n_eng, cap), dtype=torch.float64, device=theta.device),
+                status=torch.zeros((n_eng, cap), dtype=torch.int32, device=theta.device),
+                model=[torch.empty((cap, c.model_size), dtype=torch.float64, device=theta.device) for c in self.children],
+                res=[torch.zeros((cap, st['pad'](i.numel())), dtype=torch.float64, device=theta.device) for i in st['idx']],
+                z=[torch.empty((cap, st['pad'](i.numel())), dtype=torch.float64, device=theta.device) for i in st['idx']])
+        bufs = st['bufs']
+        mine = torch.cuda.current_stream(theta.device)
+        ready = mine.record_event()
+        done = []
+        for ci, c in enumerate(self.children):
+            stream = self._stream_of(c.stream_handle(), theta.device)
+            stream.wait_event(ready)
+            c.eval_device(theta.data_ptr(), B, bufs['chi2'][ci].data_ptr(), bufs['model'][ci].data_ptr(), bufs['status'][ci].data_ptr())
+            done.append(self._stream_of(c.last_stream_handle(), theta.device).record_event())
+        for ev in done:
+            mine.wait_event(ev)
+        total = bufs['chi2'][:, :B].sum(dim=0)
+        for ci in range(n_eng):
+            n = st['idx'][ci].numel()
+            bufs['res'][ci][:B, :n] = st['data'][ci][None, :] - bufs['model'][ci][:B].index_select(1, st['idx'][ci])
+        first = self.children[0]
+        prod = self._stream_of(first.stream_handle(), theta.device)
+        for (i, j), blk in st['cross'].items():
+            prod.wait_event(mine.record_event())                    # the residuals are formed
+            first.matvec_device(blk.data_ptr(), blk.shape[0], blk.shape[1], bufs['res'][j].data_ptr(), B, bufs['z'][i].data_ptr())
+            mine.wait_event(prod.record_event())
+            n = st['idx'][i].numel()
+            total = total + 2.0 * (bufs['res'][i][:B, :n] * bufs['z'][i][:B, :n]).sum(dim=1)
+        bad = bufs['status'][:, :B].max(dim=0).values != 0
+        out.copy_(torch.where(bad, torch.full_like(total, SENTINEL), total))
+        if status is not None:
+            merged = bufs['status'][0, :B].clone()
+            for ci in range(1, n_eng):
+                merged |= bufs['status'][ci, :B]
+            status.copy_(merged)
+        if models is not None:
+            for ci, src, dst in self._gather:
+                models[:, dst] = bufs['model'][ci][:B, src]
+
+    def _eval_global_host(self, theta, want_model):
+        import torch
+        dev = torch.device('cuda', self.children[0].device)
+        with torch.cuda.device(dev):
+            t = torch.as_tensor(theta, device=dev)
+            B = t.shape[0]
+            out = torch.empty(B, dtype=torch.float64, device=dev)
+            status = torch.empty(B, dtype=torch.int32, device=dev)
+            models = torch.empty((B, self.model_size), dtype=torch.float64, device=dev) if want_model else None
+            self._eval_global_device(t, out, status, models)
+            torch.cuda.current_stream(dev).synchronize()
+        return out.cpu().numpy(), status.cpu().numpy(), (models.cpu().numpy() if want_model else None)
+
     def eval_device_tensor(self, theta, out):
         """``theta`` CUDA float64 [B, n_params] -> ``out`` CUDA float64 [B]: every engine evaluates the walkers on its own
         stream into its own buffer, ordered after the caller's stream by an event; the sum is formed on the caller's stream
         behind one event per engine - no host synchronisation anywhere."""
         import torch
+        if self._global is not None:
+            return self._eval_global_device(theta, out)
         B = theta.shape[0]
         if self._dev_bufs is None or self._dev_bufs.shape[1] < B:
             self._dev_bufs = torch.empty((len(self.children), max(B, self.max_batch)), dtype=torch.float64, device=theta.device)
@@ -181,8 +289,23 @@ class EngineGroup:
     # ---- per item
     def set_data(self, name, masked_data):
         self._owner[name].set_data(name, masked_data)
+        if self._global is not None:
+            self._global['data'][name] = np.asarray(masked_data, dtype=np.float64).copy()
+        if self._global is not None and self._global['dev'] is not None:
+            # (the cross terms' copy of the engine's masked data, in the engine's item order)
+            import torch
+            ci = self.children.index(self._owner[name])
+            off = 0
+            for n in self.groups[ci]:
+                size = self.prob.items[n].data_size
+                if n == name:
+                    d = self._global['dev']['data'][ci]
+                    d[off:off + size] = torch.as_tensor(np.asarray(masked_data, dtype=np.float64), device=d.device)
+                off += size
 
     def set_mock_pool(self, name, pool):
+        if self._global is not None:
+            raise NotImplementedError('mock pools (Monte-Carlo fits in lock-step) with a global covariance across engines')
         self._owner[name].set_mock_pool(name, pool)
 
     def set_invcov(self, name, invcov):
