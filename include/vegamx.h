@@ -212,6 +212,12 @@ int vmx_pipeline_set_tracer_evolution(vmx_engine* e, int32_t pipeline, const dou
 int vmx_pipeline_set_odd_terms(vmx_engine* e, int32_t pipeline, const double* coef, int32_t n_coef, double x0,
                                double h, int32_t relativistic, int32_t asymmetry, const int32_t* slots);
 
+/* The same splines as a linear operator of the component's spectrum, for `direct_pk` (reference vega/model.py:188-207: the
+ * caller's spectrum is then the pk_lin of the odd-multipole terms too, correlation_func.py:491-551): op[4][n_coef][nk], term
+ * order as `coef` above, coef_term = op_term . pk (vega_amd/fftlog_op.hamilton_spline_operator).  vmx_set_direct_pk forms the
+ * walkers' coefficient rows with it (one product per pipeline); without it a pipeline with odd terms refuses direct_pk. */
+int vmx_pipeline_set_odd_operator(vmx_engine* e, int32_t pipeline, const double* op, int32_t n_coef, int32_t nk);
+
 /* A(tau) table of the UV shot-noise term on the uniform grid tau0 + dtau i (correlation_func.py:597-647):
  * np.interp with left = a[0], right = 0. */
 int vmx_set_shotnoise_table(vmx_engine* e, const double* a, int32_t n, double tau0, double dtau);

@@ -522,3 +522,37 @@ def test_fht_extrap_against_the_reference():
     chi2, status = vega.chi2_batch(vega.engine.low.theta0[None, :], return_status=True)
     assert status[0] != 0 and chi2[0] == 1e100
     vega.close()
+
+
+def test_direct_pk_with_the_odd_multipole_terms():
+    """`direct_pk` on a cross-correlation with the relativistic and asymmetry terms (reference model.py:188-207 ->
+    correlation_func.py:491-551: the caller's spectrum is the terms' pk_lin): the Hamilton splines as operators of the
+    spectrum (`vmx_pipeline_set_odd_operator`), the walkers' coefficient rows formed at `vmx_set_direct_pk`.  Against the
+    oracle (as the odd-multipole terms themselves: no reference fixture holds them), two walkers with two spectra; the
+    ordinary evaluation before and after is untouched."""
+    from oracle import vega_cpu as oc
+    from vega_amd import VegaInterface, synthetic
+    prob = _fresh('joint')
+    cross = prob.items['lyalya_qso'].core
+    cross.xi.relativistic = cross.xi.asymmetry = True
+    prob.params.update({'Arel1': -13.5, 'Arel3': 1.0, 'Aasy0': 1.0, 'Aasy2': 1.0, 'Aasy3': 1.0})
+    vega = VegaInterface(None, problem=prob, max_batch=4)
+    names = vega.engine.names
+    theta = synthetic.walkers(vega.engine.low.theta0, names, 2, seed=61, varied=['ap', 'at', 'bias_eta_LYA', 'beta_LYA',
+                                                                                  'beta_QSO', 'drp_QSO', 'Arel1', 'Aasy0', 'Aasy3'])
+    plain = vega.chi2()
+    assert plain == pytest.approx(oc.chi2(prob), rel=CHI2_RTOL)
+    x = np.log(np.asarray(prob.k) / 0.05)
+    for i in range(2):
+        pars = dict(zip(names, theta[i]))
+        pk = np.asarray(prob.pk_full) * (1 + 0.02 * (i + 1) * np.exp(-0.5 * x**2))     # a bump around k = 0.05 h/Mpc
+        ref_model = oc.compute_model(prob, pars, direct_pk=pk)
+        got = vega.compute_model(pars, direct_pk=pk)
+        for name in prob.items:
+            assert np.abs(got[name] - ref_model[name]).max() <= XI_RTOL * np.abs(ref_model[name]).max(), (i, name)
+        assert vega.chi2(pars, direct_pk=pk) == pytest.approx(oc.chi2(prob, pars, direct_pk=pk), rel=CHI2_RTOL)
+        # (the odd terms do depend on the spectrum: with the template's spectrum in their place the model moves)
+        without = oc.compute_model(prob, pars, direct_pk=np.asarray(prob.pk_full))['lyalya_qso']
+        assert np.abs(ref_model['lyalya_qso'] - without).max() > 1e-6 * np.abs(without).max()
+    assert vega.chi2() == plain
+    vega.close()

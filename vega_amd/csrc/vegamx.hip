@@ -203,8 +203,9 @@ struct vmx_engine {
     std::vector<MetalHost*> metals;
     DevBuf<ItemDev> d_items;
     DevBuf<MetalDev> d_metals;
-    std::vector<double> h_bb, h_odd;
-    DevBuf<double> bb_basis, odd_coef, sn_a;
+    std::vector<double> h_bb, h_odd, h_odd_op;
+    std::map<int, int64_t> odd_op_off;        // pipeline -> its odd-multipole operator in odd_op (vmx_pipeline_set_odd_operator)
+    DevBuf<double> bb_basis, odd_coef, odd_op, odd_dyn, sn_a;
     int sn_n = 0; double sn_tau0 = 0.0, sn_dtau = 1.0;
 
     std::vector<int32_t> prior_slot;
@@ -846,7 +847,7 @@ int vmx_add_pipeline(vmx_engine* e, const vmx_pipe_desc* desc, int32_t n, const 
     if (desc->n_smooth < 0 || desc->n_smooth > VMX_MAX_SMOOTH) return fail(-1, "invalid argument: n_smooth");
     PipeDev p{};
     p.d = *desc;
-    p.poly_basis = -1; p.col = -1; p.poly_bins_off = -1;
+    p.poly_basis = -1; p.col = -1; p.poly_bins_off = -1; p.odd_dyn_off = -1;
     // The P(k) stage is symmetric in the two tracers: keep the Lya-like tracer first (and a discrete
     // tracer last) so that the specialised mu loops see one canonical order.
     if (!p.d.same_tracer && ((!p.d.tracer[0].is_lya && p.d.tracer[1].is_lya) ||
@@ -909,7 +910,23 @@ int vmx_pipeline_set_odd_terms(vmx_engine* e, int32_t pipeline, const double* co
         p.odd_slot[i] = slots[i];
     }
     p.odd_off = (int64_t)e->h_odd.size();
+    p.odd_dyn_off = -1; p.odd_dyn_ld = 0;
     e->h_odd.insert(e->h_odd.end(), coef, coef + (size_t)4 * n_coef);
+    return 0;
+}
+
+int vmx_pipeline_set_odd_operator(vmx_engine* e, int32_t pipeline, const double* op, int32_t n_coef, int32_t nk)
+{
+    REQUIRE(e && !e->finalized && op, "vmx_pipeline_set_odd_operator (before vmx_finalize)");
+    REQUIRE(pipeline >= 0 && pipeline < (int)e->pipes.size(), "pipeline id");
+    PipeDev& p = e->pipes[pipeline];
+    REQUIRE((p.odd_rel || p.odd_asy) && n_coef == p.odd_ncoef && nk == e->nk, "vmx_pipeline_set_odd_operator: after vmx_pipeline_set_odd_terms, same shapes");
+    // rows [4 n_coef] of nkp doubles (zero tails): the operand layout of the product kernels
+    const size_t rows = (size_t)4 * n_coef;
+    e->odd_op_off[pipeline] = (int64_t)e->h_odd_op.size();
+    e->h_odd_op.resize(e->h_odd_op.size() + rows * e->nkp, 0.0);
+    double* dst = e->h_odd_op.data() + e->odd_op_off[pipeline];
+    for (size_t r = 0; r < rows; ++r) std::copy(op + r * nk, op + (r + 1) * nk, dst + r * e->nkp);
     return 0;
 }
 
@@ -1367,6 +1384,16 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     for (auto& p : e->pipes) { p.n_pad = vmx_pad(p.n); p.xi_off = xi_off; xi_off += (int64_t)Bm * p.n_pad; }
     e->xi_total = xi_off;
     const int n_pipe = (int)e->pipes.size();
+    {
+        // direct_pk with odd-multipole terms: where a pipeline's per-walker coefficient rows live (EngineDev::odd_dyn)
+        int64_t off = 0;
+        for (auto& kv : e->odd_op_off) {
+            PipeDev& p = e->pipes[kv.first];
+            p.odd_dyn_ld = vmx_pad(4 * p.odd_ncoef);
+            p.odd_dyn_off = off;
+            off += (int64_t)Bm * p.odd_dyn_ld;
+        }
+    }
     if (e->d_pipes.upload(e->pipes.data(), e->pipes.size())) return -2;
 
     // P(k,mu) work groups: an item's peak component rides along with its smooth component when the two
@@ -1569,6 +1596,13 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
 
     if (e->bb_basis.upload(e->h_bb.data(), e->h_bb.size() ? e->h_bb.size() : 0)) return -2;
     if (e->odd_coef.upload(e->h_odd.data(), e->h_odd.size())) return -2;
+    if (!e->h_odd_op.empty()) {
+        // direct_pk with odd-multipole terms: the operators, and the walkers' coefficient rows [pipelines with one][Bm][ld]
+        if (e->odd_op.upload(e->h_odd_op.data(), e->h_odd_op.size())) return -2;
+        int64_t total = 0;
+        for (auto& kv : e->odd_op_off) total += (int64_t)Bm * e->pipes[kv.first].odd_dyn_ld;       // (offsets: set with the descriptors above)
+        if (e->odd_dyn.alloc((size_t)total, true)) return -2;
+    }
     for (auto& p : e->pipes)
         for (int i = 0; i < 5; ++i) REQUIRE(p.odd_slot[i] < n_params, "odd-multipole slot exceeds n_params");
     if (!e->prior_slot.empty()) {
@@ -1627,7 +1661,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.n_items = (int)e->items.size(); D.items = e->d_items.p;
     D.metals = e->d_metals.p; D.n_metals_total = (int)e->metals.size();
     D.bb_basis = e->bb_basis.p;
-    D.odd_coef = e->odd_coef.p;
+    D.odd_coef = e->odd_coef.p; D.odd_dyn = e->odd_dyn.p;
     D.sn_a = e->sn_a.p; D.sn_n = e->sn_n; D.sn_tau0 = e->sn_tau0; D.sn_dtau = e->sn_dtau;
     D.n_priors = (int)e->prior_slot.size();
     D.prior_slot = e->d_prior_slot.p; D.prior_mean = e->d_prior_mean.p; D.prior_sigma = e->d_prior_sigma.p;
@@ -2920,6 +2954,14 @@ int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk)
                        (size_t)nk * sizeof(double), B, hipMemcpyHostToDevice));
     e->direct = true;
     e->dev.pk_direct = e->pk_direct.p;       // every kernel of the chain takes its EngineDev from e->dev
+    // the odd-multipole terms read the caller's spectrum too: the walkers' spline coefficients = operator . spectrum
+    for (auto& p : e->pipes)
+        REQUIRE(!(p.odd_rel || p.odd_asy) || p.odd_dyn_off >= 0,
+                "direct_pk: a pipeline with odd-multipole terms needs their operator form (vmx_pipeline_set_odd_operator)");
+    for (auto& kv : e->odd_op_off) {
+        const PipeDev& p = e->pipes[kv.first];
+        if (vmx_matvec_device(e, e->odd_op.p + kv.second, 4 * p.odd_ncoef, e->nkp, e->pk_direct.p, B, e->odd_dyn.p + p.odd_dyn_off)) return -2;
+    }
     return 0;
 }
 

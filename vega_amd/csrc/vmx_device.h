@@ -70,6 +70,8 @@ struct PipeDev {
     int32_t odd_rel, odd_asy, odd_ncoef;
     int32_t odd_slot[5];
     int64_t odd_off;
+    int64_t odd_dyn_off;  // >= 0: with a caller's spectrum (pk_direct) the walkers' own coefficient rows, EngineDev::odd_dyn
+    int32_t odd_dyn_ld;   // ... [B][odd_dyn_ld] from this offset
     double odd_x0, odd_h;
 };
 
@@ -198,6 +200,7 @@ struct EngineDev {
     int32_t n_metals_total;
     const double* bb_basis;
     const double* odd_coef;
+    const double* odd_dyn;      // direct_pk: per-walker odd-multipole spline coefficients (PipeDev::odd_dyn_off)
     const double* sn_a; int32_t sn_n; double sn_tau0, sn_dtau;     // UV shot-noise A(tau) table
     // priors
     int32_t n_priors;
@@ -3471,7 +3474,9 @@ __device__ __forceinline__ double xi_bin_value(const EngineDev& D, int p, int b,
         const double w0 = omt * omt * omt, w1 = 3.0 * t3 - 6.0 * t2 + 4.0, w2 = -3.0 * t3 + 3.0 * t2 + 3.0 * tt + 1.0;
         double sp[4];
         for (int q = 0; q < 4; ++q) {
-            const double* cf = D.odd_coef + P.odd_off + (size_t)q * P.odd_ncoef + j;
+            const double* cf = (D.pk_direct && P.odd_dyn_off >= 0)
+                                   ? D.odd_dyn + P.odd_dyn_off + (size_t)b * P.odd_dyn_ld + (size_t)q * P.odd_ncoef + j
+                                   : D.odd_coef + P.odd_off + (size_t)q * P.odd_ncoef + j;
             sp[q] = (cf[0] * w0 + cf[1] * w1 + cf[2] * w2 + cf[3] * t3) * (1.0 / 6.0);
         }
         const double l1 = rmu, l3 = 0.5 * (5.0 * rmu * rmu - 3.0) * rmu;

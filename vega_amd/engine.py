@@ -118,6 +118,7 @@ def load_library():
     lib.vmx_item_set_additive_template.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32, C.c_double]
     lib.vmx_pipeline_set_odd_terms.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_double, C.c_double,
                                                C.c_int32, C.c_int32, iptr]
+    lib.vmx_pipeline_set_odd_operator.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32]
     lib.vmx_item_add_metal.argtypes = [C.c_void_p, C.c_int32, C.POINTER(MetalDesc)]
     lib.vmx_item_add_broadband.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, iptr, dptr,
                                            C.c_int32]
@@ -176,7 +177,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_fftlog_padding', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
-    'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_set_shotnoise_table',
+    'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_pipeline_set_odd_operator', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_static_poly', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
@@ -529,6 +530,10 @@ class Engine:
             self._check(self.lib.vmx_pipeline_set_odd_terms(self._h, pid, _dp(coef), coef.shape[1], rows[0][1],
                                                             rows[0][2], int(pipe.xi.relativistic),
                                                             int(pipe.xi.asymmetry), _ip(slots)))
+            # ... and as operators of the spectrum, for `direct_pk` (the caller's spectrum is the terms' pk_lin then)
+            ops = _f64(np.stack([fftlog_op.hamilton_spline_operator(k, ell, kind)
+                                 for kind, ell in (('rel', 1), ('rel', 3), ('asy', 0), ('asy', 2))]))
+            self._check(self.lib.vmx_pipeline_set_odd_operator(self._h, pid, _dp(ops), ops.shape[1], ops.shape[2]))
         return pid
 
     def _build(self):

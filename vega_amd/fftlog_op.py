@@ -135,6 +135,28 @@ def hamilton_spline(k, pk, ell, kind):
     return notaknot_bspline_matrix(n_pts) @ xi, float(x0), float(h)
 
 
+def hamilton_spline_operator(k, ell, kind):
+    """:func:`hamilton_spline` as a matrix: ``coef = OP @ pk`` ([n + 2] x [n]) - the chain is linear in the spectrum, which a
+    caller-supplied spectrum per walker (`direct_pk`) needs; same operations, applied to the columns of the identity."""
+    k = np.asarray(k, dtype=float)
+    n_pts = k.size
+    span = np.log(k.max() / k[0])
+    m = n_pts * np.fft.fftfreq(n_pts)
+    n_pow = 1.0 if kind == 'rel' else 2.0
+    q = 2 - n_pow - 0.5
+    z = q + 2j * np.pi * m / span
+    mu = ell + 0.5
+    um = k[0] ** (-2j * np.pi * m / span) * 2 ** z * np.exp(loggamma((mu + 1 + z) / 2) - loggamma((mu + 1 - z) / 2))
+    um[0] = um[0].real
+    spec = np.fft.ifft(np.fft.fft(np.diag(k ** n_pow * np.sqrt(np.pi / 2)), axis=0) * um[:, None], axis=0)
+    r = np.exp(-m * span / n_pts)
+    order = np.argsort(r)
+    r = r[order]
+    xi = (spec[order] / r[:, None] ** (3 - n_pow)).real
+    xi[-1, :] = 0.0
+    return notaknot_bspline_matrix(n_pts) @ xi
+
+
 def hamilton_xi_operator(k, ell):
     """(OP, x0, h, n_knots) for the reference's legacy transform (``old_fftlog = True``): the Hamilton FFTLog of
     ``PktoXi.Pk2Mp`` (reference vega/pktoxi.py:230-279) applied to a multipole P_ell(k), followed by its cubic

@@ -206,9 +206,6 @@ class VegaInterface:
                 # compute_direct, :188-207): their pipelines cannot sit on the static basis of the template's spectra
                 if getattr(self.engine, 'static_poly', True):
                     self._rebuild_engine(static_poly=False)
-            if any(item.core.xi.relativistic or item.core.xi.asymmetry for item in self.problem.items.values()):
-                raise NotImplementedError('direct_pk with the odd-multipole terms (static splines of the template) '
-                                          'is not accelerated')
             engine = self.engine
             engine.set_direct_pk(direct_pk)
             try:
