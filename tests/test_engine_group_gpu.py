@@ -143,6 +143,18 @@ def test_global_covariance_across_engines():
     assert not sa.any() and not sb.any()
     np.testing.assert_allclose(b, a, rtol=1e-11)
     np.testing.assert_allclose(mb, ma, rtol=0, atol=1e-14 * np.abs(ma).max())        # (other launch groupings: other split-K sums)
+    # mock pools with a per-walker row (Monte-Carlo fits in lock-step): the cross terms take the walker's row of every item
+    rng = np.random.default_rng(3)
+    for eng in (one, two):
+        for name in names:
+            d = np.asarray(prob.items[name].masked_data_vec)
+            eng.set_mock_pool(name, d[None, :] * (1 + 0.01 * np.arange(1, 4)[:, None]))
+        eng.set_mock_index(np.array([0, 2, -1, 1, 1, 0, 2, -1, 0, 1, 2, 0], dtype=np.int32))
+    rng = None
+    a2 = one.eval(theta)[0]
+    b2 = two.eval(theta)[0]
+    np.testing.assert_allclose(b2, a2, rtol=1e-11)
+    assert a2[2] == pytest.approx(a[2], rel=1e-12) and abs(a2[0] - a[0]) > 1e-6 * abs(a[0])     # (row -1: the data)
     one.close(); two.close()
 
     prob = _mixed(fht_lowring=False)

@@ -202,9 +202,20 @@ class EngineGroup:
         for ev in done:
             mine.wait_event(ev)
         total = bufs['chi2'][:, :B].sum(dim=0)
+        rows = None
+        g = self._global
+        if g.get('mock_index') is not None:
+            # Monte-Carlo fits in lock-step: walker b is fitted to row mock_index[b] of every item's mock pool (< 0: the data)
+            if g.get('pool_dev') is None:
+                g['pool_dev'] = [torch.as_tensor(np.concatenate([g['pools'][n] for n in names], axis=1), device=theta.device)
+                                 for names in self.groups]
+            rows = torch.as_tensor(g['mock_index'][:B], device=theta.device)
         for ci in range(n_eng):
             n = st['idx'][ci].numel()
-            bufs['res'][ci][:B, :n] = st['data'][ci][None, :] - bufs['model'][ci][:B].index_select(1, st['idx'][ci])
+            data = st['data'][ci][None, :]
+            if rows is not None:
+                data = torch.where((rows >= 0)[:, None], g['pool_dev'][ci].index_select(0, rows.clamp(min=0)), data)
+            bufs['res'][ci][:B, :n] = data - bufs['model'][ci][:B].index_select(1, st['idx'][ci])
         first = self.children[0]
         prod = self._stream_of(first.stream_handle(), theta.device)
         for (i, j), blk in st['cross'].items():
@@ -304,9 +315,11 @@ class EngineGroup:
                 off += size
 
     def set_mock_pool(self, name, pool):
-        if self._global is not None:
-            raise NotImplementedError('mock pools (Monte-Carlo fits in lock-step) with a global covariance across engines')
         self._owner[name].set_mock_pool(name, pool)
+        if self._global is not None:
+            # (the cross terms read the walker's pool row of every item: kept per item, joined per engine on first use)
+            self._global.setdefault('pools', {})[name] = np.atleast_2d(np.asarray(pool, dtype=np.float64)).copy()
+            self._global['pool_dev'] = None
 
     def set_invcov(self, name, invcov):
         self._owner[name].set_invcov(name, invcov)
@@ -323,6 +336,8 @@ class EngineGroup:
 
     def set_mock_index(self, index=None):
         self._all('set_mock_index', index)
+        if self._global is not None:
+            self._global['mock_index'] = None if index is None else np.ascontiguousarray(index, dtype=np.int64)
 
     def set_constant_nl_hint(self, on=True, gaussian=False):
         self._all('set_constant_nl_hint', on, gaussian)
