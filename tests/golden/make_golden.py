@@ -1200,7 +1200,7 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
