@@ -2091,7 +2091,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         if (tab_mode >= 2 && e->n_xtab > 0) {
             n_other = n_groups - e->n_xtab;
             // (the node tables' image, + [2 terms][2 walkers][64 wavenumbers] of UV / HeII bias terms behind it)
-            const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra + 256) * sizeof(double);
+            const size_t sh1 = std::max<size_t>(2048, (size_t)2 * e->n_mu + 4 * e->n_extra + 256 + 16) * sizeof(double);     // (+ the waves' votes)
             if (sh1 > 64 * 1024) {
                 // (num_bins_muk near its limit of 4096: the node tables alone are 64 KB - the driver's per-device attribute, monotone)
                 static std::mutex mu;

@@ -1491,9 +1491,39 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
         raw[w][9] = G.uvb ? sc[S_UV_LAM] : 0.0; raw[w][10] = G.uvb ? sc[S_UV_BG] : 0.0; raw[w][11] = (G.uvb || G.heii) ? sc[S_UV_BP] : 0.0;
         raw[w][12] = G.heii ? sc[S_HE_LAM] : 0.0; raw[w][13] = G.heii ? sc[S_HE_BG] : 0.0;
     }
-    const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;
+    // ONE barrier for the whole set-up (there were three: the tile's liveness vote, the rule's vote, the tables): every wave
+    // leaves its two votes and its share of the UV / HeII terms in LDS, waits for its table copies, and meets the others once.
+    // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261): an arctangent and two divisions per (walker,
+    // wavenumber, term) that do not depend on the mu slice - the block's MS slices used to compute each of them MS times
+    // (a sixth of the block's instructions).  Role term NW + w - term `term` of walker w for the tile's wavenumbers - is
+    // computed by slice role % MS; everyone reads it from LDS behind the node tables.
+    double* s_x = smem + 2 * (size_t)n_mu + 4 * (size_t)D.n_extra;         // [2][NW][KT]
+    int* s_vote = (int*)(s_x + 2 * NW * KT);                               // [NT / 64][2]
+    if (G.uvb || G.heii) {
+#pragma unroll
+        for (int role = 0; role < 2 * NW; ++role) {
+            if (role % MS != ms) continue;
+            const int term = role / NW, wsel = role % NW;
+            const double lam = term ? raw[wsel][12] : raw[wsel][9], bg = term ? raw[wsel][13] : raw[wsel][10], bp = raw[wsel][11];
+            double v = 0.0;
+            if (term ? G.heii : G.uvb) { const double x = k * lam; const double W = atan(x) / x; v = bg * W / (1.0 + bp * W); }
+            s_x[(size_t)role * KT + kk] = v;
+        }
+    }
+    {
+        const unsigned long long live_v = __ballot(!(e_max < VMX_PK_DEAD));
+        const unsigned long long rule_v = __ballot(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE), all_v = __ballot(true);
+        if ((threadIdx.x & 63) == 0) {
+            s_vote[2 * (threadIdx.x >> 6)] = live_v != 0ull;
+            s_vote[2 * (threadIdx.x >> 6) + 1] = rule_v == all_v;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the node tables have landed
+    __syncthreads();
+    bool live_block = false, rule_ok = true;
+#pragma unroll
+    for (int wv = 0; wv < NT / 64; ++wv) { live_block = live_block || s_vote[2 * wv] != 0; rule_ok = rule_ok && s_vote[2 * wv + 1] != 0; }
     if (!live_block) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the table copies land before the block's LDS is given up)
         if (threadIdx.x >= KT || !valid) return;
         const size_t ncols = (size_t)B * D.n_active;
         for (int w = 0; w < NW; ++w) {
@@ -1509,22 +1539,6 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
     const bool bad = bad_flag != 0.0;
     double c01[NW], c11[NW], c02[NW], c12[NW], hb[NW], hbb[NW], fk[NW], Fq[NW], k2vd2[NW];
     bool in_box = true;
-    // k-dependent effective bias from UV / HeII (power_spectrum.py:224-261): an arctangent and two divisions per (walker,
-    // wavenumber, term) that do not depend on the mu slice - the block's MS slices used to compute each of them MS times
-    // (a sixth of the block's instructions).  Role term NW + w - term `term` of walker w for the tile's wavenumbers - is
-    // computed by slice role % MS; everyone reads it from LDS behind the node tables (after the barrier below).
-    double* s_x = smem + 2 * (size_t)n_mu + 4 * (size_t)D.n_extra;         // [2][NW][KT]
-    if (G.uvb || G.heii) {
-#pragma unroll
-        for (int role = 0; role < 2 * NW; ++role) {
-            if (role % MS != ms) continue;
-            const int term = role / NW, wsel = role % NW;
-            const double lam = term ? raw[wsel][12] : raw[wsel][9], bg = term ? raw[wsel][13] : raw[wsel][10], bp = raw[wsel][11];
-            double v = 0.0;
-            if (term ? G.heii : G.uvb) { const double x = k * lam; const double W = atan(x) / x; v = bg * W / (1.0 + bp * W); }
-            s_x[(size_t)role * KT + kk] = v;
-        }
-    }
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         c01[w] = raw[w][0]; c02[w] = raw[w][1]; c11[w] = raw[w][2]; c12[w] = raw[w][3];
@@ -1542,11 +1556,9 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
     if (threadIdx.x == 0) atomicMax(D.k_live, min((tile + 1) * KT, D.nk));
     // the node rule (first mu_lo and last mu_hi midpoints plus the extra nodes) serves a tile whose wavenumbers are all
     // within its range or negligible (VMX_PK_NEGLIGIBLE) - and whose walkers lie in the box the rule is validated on
-    const bool node_mode = D.n_extra > 0 && in_box && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
+    const bool node_mode = D.n_extra > 0 && in_box && rule_ok;
     if (node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((tile + 1) * KT, D.nk));
     const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the node tables have landed
-    __syncthreads();
     if (G.uvb || G.heii) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
