@@ -153,7 +153,7 @@ struct vmx_engine {
 
     int nk = 0, nkp = 0, n_mu = 0;
     int n_rows = 0, n_extra = 0, mu_lo = 0, mu_hi = 0;     // node rule of the mu sums (vmx_set_mu_quadrature)
-    DevBuf<double> node_w, mu_img;
+    DevBuf<double> node_w, mu_img, mu_img_w;
     std::vector<int32_t> rule_slot; std::vector<double> rule_lo, rule_hi;     // vmx_set_mu_rule_box
     DevBuf<int32_t> d_rule_slot; DevBuf<double> d_rule_lo, d_rule_hi;
     double k_node_max = 0.0; bool mu_nodes_on = true;
@@ -771,6 +771,13 @@ int vmx_set_template(vmx_engine* e, int32_t nk, const double* k, const double* p
             q[0] = m; q[1] = m2; q[2] = m2 * m2; q[3] = node_w[j];
         }
         if (e->mu_img.upload(img.data(), img.size())) return -2;
+        // ... and of k_pk_w's: the same midpoints, {mu^2, mu^4, mu^6, w} of the extra nodes
+        for (int j = 0; j < e->n_extra; ++j) {
+            const double m = mu[n_mu + j], m2 = m * m;
+            double* q = &img[2 * (size_t)n_mu + 4 * (size_t)j];
+            q[0] = m2; q[1] = m2 * m2; q[2] = m2 * m2 * m2; q[3] = node_w[j];
+        }
+        if (e->mu_img_w.upload(img.data(), img.size())) return -2;
     }
     if (e->mu.upload(mu.data(), n_rows) || e->sq1mmu2.upload(sq.data(), n_rows) || e->lnmu.upload(lnm.data(), n_rows) || e->wl.upload(wl.data(), wl.size())) return -2;
     return 0;
@@ -1630,7 +1637,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D = EngineDev{};
     D.nk = e->nk; D.nkp = e->nkp; D.n_mu = e->n_mu; D.n_ell = VMX_MAX_ELL;
     D.pad_l = e->pad_l; D.pad_r = e->pad_r; D.pipe_active = e->d_pipe_active.p;
-    D.n_rows = e->n_rows; D.n_extra = e->n_extra; D.mu_lo = e->mu_lo; D.mu_hi = e->mu_hi; D.node_w = e->node_w.p; D.mu_img = e->mu_img.p;
+    D.n_rows = e->n_rows; D.n_extra = e->n_extra; D.mu_lo = e->mu_lo; D.mu_hi = e->mu_hi; D.node_w = e->node_w.p; D.mu_img = e->mu_img.p; D.mu_img_w = e->mu_img_w.p;
     {
         // the node rule needs the integrand smooth on the scale of its panels: the binning sincs oscillate with k x bin
         // size, so wavenumbers beyond 24 / (largest bin size) [6 h/Mpc for 4 Mpc/h bins] keep the midpoint loop
@@ -2133,7 +2140,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         if (n_w > 0) {
             n_other -= n_w;
             tm |= 32;
-            const size_t shw = std::max<size_t>((size_t)2 * 6 * 256, (size_t)2 * e->n_mu + 4 * e->n_extra) * sizeof(double);
+            const size_t shw = std::max<size_t>((size_t)2 * 6 * 256, (size_t)2 * e->n_mu + 4 * e->n_extra + 16) * sizeof(double);    // (+ the waves' votes)
             if (B >= 64)        // (four walkers per thread: 161 registers, 465 against 426 us for the stage at B = 512)
                 hipLaunchKernelGGL((k_pk_w<2>), dim3((B + 1) / 2, n_w, (e->nk + 63) / 64), dim3(256), shw, e->stream, D, e->d_pk_groups.p, e->d_pk_members.p, e->d_w_groups.p, B);
             else

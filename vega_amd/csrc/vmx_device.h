@@ -161,6 +161,7 @@ struct EngineDev {
     const double* delta2;       // [nkp]
     const double* mu;           // [n_mu]
     const double* mu_img;       // [n_mu] {mu^2, mu^4}, [n_extra] {mu, mu^2, mu^4, w}: the LDS image of k_pk_tab2's node tables
+    const double* mu_img_w;     // ... of k_pk_w's: [n_mu] {mu^2, mu^4}, [n_extra] {mu^2, mu^4, mu^6, w}
     const double* sq1mmu2;      // [n_mu] sqrt(1 - mu^2)
     const double* lnmu;         // [n_mu] ln(mu)
     const double* wl;           // [4][n_mu] L_ell(mu) (2 ell + 1) / n_mu
@@ -1816,21 +1817,35 @@ __device__ __forceinline__ void pk_w_body(const EngineDev& D, const PkGroup* gro
     }
     if (MODE == 1) in_box = true;
     if (MODE == 2) in_box = false;
-    const bool live_block = __syncthreads_or(!(e_max < VMX_PK_DEAD)) != 0;
+    // ONE barrier for the set-up, as in pk_tab2_body: the node tables as direct global -> LDS copies of their static image
+    // (EngineDev::mu_img_w: [n_mu] {mu^2, mu^4}, [n_extra] {mu^2, mu^4, mu^6, w}), the waves' two votes in LDS behind them
+    int* s_vote = (int*)(smem + 2 * (size_t)n_mu + 4 * (size_t)D.n_extra);
+    {
+        const unsigned total = (2u * (unsigned)n_mu + 4u * (unsigned)D.n_extra) * 8u;
+        const char* img = (const char*)D.mu_img_w;
+        const unsigned wave_off = (threadIdx.x >> 6) * 1024u, lane_off = (threadIdx.x & 63) * 16u;
+        for (unsigned c = 0; c < total; c += 256u * 16u) {
+            const unsigned off = c + wave_off;
+            if (off + lane_off < total)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + off + lane_off),
+                                                 (__attribute__((address_space(3))) void*)((char*)smem + off), 16, 0, 0);
+        }
+        const unsigned long long live_v = __ballot(!(e_max < VMX_PK_DEAD));
+        const unsigned long long rule_v = __ballot(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE), all_v = __ballot(true);
+        if ((threadIdx.x & 63) == 0) {
+            s_vote[2 * (threadIdx.x >> 6)] = live_v != 0ull;
+            s_vote[2 * (threadIdx.x >> 6) + 1] = rule_v == all_v;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bool live_block = false, rule_ok = true;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) { live_block = live_block || s_vote[2 * wv] != 0; rule_ok = rule_ok && s_vote[2 * wv + 1] != 0; }
     if (live_block && threadIdx.x == 0) atomicMax(D.k_live, min((tile + 1) * KT, D.nk));
-    const bool node_mode = D.n_extra > 0 && in_box && __syncthreads_and(k <= D.k_node_max || e_max < VMX_PK_NEGLIGIBLE) != 0;
+    const bool node_mode = D.n_extra > 0 && in_box && rule_ok;
     if (live_block && node_mode && threadIdx.x == 0) atomicMax(D.k_live + 1, min((tile + 1) * KT, D.nk));
     const int lo_end = node_mode ? D.mu_lo : n_mu, hi_beg = node_mode ? n_mu - D.mu_hi : n_mu;
-    if (live_block) {
-        for (int j = threadIdx.x; j < n_mu; j += 256)
-            if (j < lo_end || j >= hi_beg) { const double m = D.mu[j], m2 = m * m; s_mu24[j] = (v2d){m2, m2 * m2}; }
-        if (node_mode)
-            for (int j = threadIdx.x; j < D.n_extra; j += 256) {
-                const double m = D.mu[n_mu + j], m2 = m * m;
-                s_node[j] = (v4d){m2, m2 * m2, m2 * m2 * m2, D.node_w[j]};
-            }
-    }
-    __syncthreads();
 
     double wm[NW][6];
 #pragma unroll
