@@ -1658,6 +1658,9 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     for (int i = 0; i < VMX_MAX_ELL; ++i) {
         D.x0[i] = e->x0[i]; D.h[i] = e->h[i]; D.inv_h[i] = 1.0 / e->h[i]; D.xlast[i] = e->x0[i] + e->h[i] * (e->n_knots - 1);
     }
+    D.same_grid = 1;
+    for (int i = 1; i < VMX_MAX_ELL; ++i)
+        if (e->op_set[i] && (!e->op_set[0] || D.x0[i] != D.x0[0] || D.inv_h[i] != D.inv_h[0] || D.xlast[i] != D.xlast[0])) D.same_grid = 0;
     D.n_pipe = n_pipe; D.pipes = e->d_pipes.p;
     D.n_active = e->n_active; D.n_static = (int)e->pk_static.size();
     if (!e->pk_static.empty() && e->poly_coef.alloc((size_t)VMX_MAX_ELL * e->pk_static.size() * 3 * e->ncp, true)) return -2;
@@ -2200,7 +2203,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         XiPlainArgs XA{};
         // (two walkers per thread: 41 us at B = 256 against 53 with one; four measured the same as two)
         if (B > 8 && xi_plain_args(e, XA))
-            hipLaunchKernelGGL(k_xi_quad_plain<2>, dim3((max_nq + 255) / 256, (B + 1) / 2, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, XA, 0, B);
+            hipLaunchKernelGGL((D.same_grid ? k_xi_quad_plain<2, true> : k_xi_quad_plain<2, false>), dim3((max_nq + 255) / 256, (B + 1) / 2, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, XA, 0, B);
         else
         hipLaunchKernelGGL(k_xi_assemble_quad, dim3((max_nq + 255) / 256, B, (unsigned)e->items.size()), dim3(256), 0, e->stream, D, 0, B <= 8 ? 1 : 0);
     } else {
@@ -2214,7 +2217,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         if (sums_on && !e->lean_groups.empty()) {
             // (walkers per thread of the lean kernels: 1 / 2 / 4 measured the same - the stage is bound by its dependent lookups)
             const dim3 grid((max_n + 255) / 256, (unsigned)e->lean_groups.size(), (B + 1) / 2);
-            hipLaunchKernelGGL(k_xi_bins_group<2>, grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
+            hipLaunchKernelGGL((D.same_grid ? k_xi_bins_group<2, true> : k_xi_bins_group<2, false>), grid, dim3(256), 0, e->stream, D, e->d_lean_groups.p, B);
             if (!e->xi_rest_pipes.empty())
                 hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, (unsigned)e->xi_rest_pipes.size(), B), dim3(256), 0, e->stream, D, e->d_xi_rest_pipes.p);
         } else if (B > 8 && !e->direct && !e->xi_lean_pipes.empty()) {
@@ -2226,7 +2229,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                 L.n_ell = P.d.n_ell; L.split_evol = P.split_evol; L.radiation = P.d.is_peak ? 0 : P.d.radiation;
             }
             const dim3 grid((max_n + 255) / 256, (unsigned)e->xi_lean_pipes.size(), (B + 1) / 2);
-            hipLaunchKernelGGL(k_xi_bins_lean<2>, grid, dim3(256), 0, e->stream, D, LA, B);
+            hipLaunchKernelGGL((D.same_grid ? k_xi_bins_lean<2, true> : k_xi_bins_lean<2, false>), grid, dim3(256), 0, e->stream, D, LA, B);
             if (!e->xi_rest_pipes.empty())
                 hipLaunchKernelGGL(k_xi_bins<false>, dim3((max_n + 255) / 256, (unsigned)e->xi_rest_pipes.size(), B), dim3(256), 0, e->stream, D, e->d_xi_rest_pipes.p);
         } else if (e->n_active > 0)

@@ -184,6 +184,7 @@ struct EngineDev {
     int32_t n_coef, ncp;        // coefficients per ell, padded
     int32_t extrapolate;        // splines extend beyond their knots (legacy transform) instead of flagging
     double x0[VMX_MAX_ELL], h[VMX_MAX_ELL], xlast[VMX_MAX_ELL], inv_h[VMX_MAX_ELL];
+    int same_grid;              // the multipoles' ln r grids coincide (x0, h equal over ell)
     // pipelines
     int32_t n_pipe;
     int32_t n_active;           // pipelines with a column in pl / coef (the others carry a static coefficient basis)
@@ -3638,25 +3639,45 @@ struct XiPlainItem { int64_t coord_off; const double* q_x0; double* q_x; int32_t
 struct XiPlainArgs { XiPlainItem it[VMX_MAX_GROUP]; };
 
 // cubic B-spline multipoles of one (walker, pipeline) at ln r' = x, Legendre-summed at mu' = rmu (pktoxi.py:144-162)
+// SAME: every multipole on one ln r grid (EngineDev::same_grid - always, unless fht_lowring moves the grids apart): knot index,
+// offset and with them the four B-spline weights are formed once instead of once per multipole (the same values bit for bit).
+template <bool SAME>
 __device__ __forceinline__ double xi_plain_spline(const EngineDev& D, const double* coef_col, size_t ell_stride, int n_ell, double x,
                                                   double rmu, bool& oob)
 {
     const double* cf[4];
     double tt[4];
     bool on[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int ee = e < n_ell ? e : 0;
-        const bool inside = !(x < D.x0[ee] || x > D.xlast[ee]);     // VegaBoundsError (pktoxi.py:149-152)
-        on[e] = e < n_ell && inside;
-        if (e < n_ell && !inside) oob = true;
-        const double u = (x - D.x0[ee]) * D.inv_h[ee];
+    if (SAME) {
+        const bool inside = !(x < D.x0[0] || x > D.xlast[0]);       // VegaBoundsError (pktoxi.py:149-152)
+        if (!inside) oob = true;
+        const double u = (x - D.x0[0]) * D.inv_h[0];
         int j = (int)floor(u);
         if (j < 0) j = 0;
         if (j > D.n_coef - 4) j = D.n_coef - 4;
         if (!(u == u)) j = 0;
-        tt[e] = u - (double)j;
-        cf[e] = coef_col + (size_t)ee * ell_stride + j;
+        const double t = u - (double)j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            on[e] = e < n_ell && inside;
+            tt[e] = t;
+            cf[e] = coef_col + (size_t)(e < n_ell ? e : 0) * ell_stride + j;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ee = e < n_ell ? e : 0;
+            const bool inside = !(x < D.x0[ee] || x > D.xlast[ee]);
+            on[e] = e < n_ell && inside;
+            if (e < n_ell && !inside) oob = true;
+            const double u = (x - D.x0[ee]) * D.inv_h[ee];
+            int j = (int)floor(u);
+            if (j < 0) j = 0;
+            if (j > D.n_coef - 4) j = D.n_coef - 4;
+            if (!(u == u)) j = 0;
+            tt[e] = u - (double)j;
+            cf[e] = coef_col + (size_t)ee * ell_stride + j;
+        }
     }
     double tap[4][4];
 #pragma unroll
@@ -3680,7 +3701,7 @@ __device__ __forceinline__ double xi_plain_spline(const EngineDev& D, const doub
     return xi;
 }
 
-template <int NW>
+template <int NW, bool SAME>
 __global__ __launch_bounds__(256) void k_xi_quad_plain(EngineDev D, XiPlainArgs A, int item0, int B)
 {
     const XiPlainItem& I = A.it[item0 + blockIdx.z];
@@ -3723,7 +3744,7 @@ __global__ __launch_bounds__(256) void k_xi_quad_plain(EngineDev D, XiPlainArgs 
                 const double rr2 = fma(rrp, rrp, rrt * rrt);
                 if (rr2 != 0.0) {
                     const double* col = D.coef + ((size_t)(half ? I.col_p : I.col_s) * B + b) * D.ncp;
-                    const double v = xi_plain_spline(D, col, ell_stride, I.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), oob[w]);
+                    const double v = xi_plain_spline<SAME>(D, col, ell_stride, I.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), oob[w]);
                     if (half) xp = v * ev; else xs = v * ev;
                 }
             }
@@ -3761,7 +3782,7 @@ struct XiLeanPipe { int64_t coord_off, xi_off, poly_off; int32_t n, n_pad, pipe,
 #define VMX_XI_LEAN_MAX 24
 struct XiLeanArgs { XiLeanPipe p[VMX_XI_LEAN_MAX]; };
 
-template <int NW>
+template <int NW, bool SAME>
 __global__ __launch_bounds__(256) void k_xi_bins_lean(EngineDev D, XiLeanArgs A, int B)
 {
     const XiLeanPipe& P = A.p[blockIdx.y];
@@ -3786,7 +3807,7 @@ __global__ __launch_bounds__(256) void k_xi_bins_lean(EngineDev D, XiLeanArgs A,
             const double rr2 = fma(rrp, rrp, rrt * rrt);
             if (rr2 != 0.0) {
                 const double* col = D.coef + ((size_t)P.col * B + b) * D.ncp;
-                xi = xi_plain_spline(D, col, ell_stride, P.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), oob[w]) * ev;
+                xi = xi_plain_spline<SAME>(D, col, ell_stride, P.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), oob[w]) * ev;
             }
         }
         if (P.radiation) {
@@ -3831,7 +3852,7 @@ __device__ __forceinline__ double xi_member_factor(const EngineDev& D, const XiM
     return 1.0;
 }
 
-template <int NW>
+template <int NW, bool SAME>
 __global__ __launch_bounds__(256) void k_xi_bins_group(EngineDev D, const XiLeanGroup* groups, int B)
 {
     const XiLeanGroup& G = groups[blockIdx.y];
@@ -3863,7 +3884,7 @@ __global__ __launch_bounds__(256) void k_xi_bins_group(EngineDev D, const XiLean
                 if (rr2 != 0.0) {
                     const double* col = D.coef + ((size_t)P.col * B + b) * D.ncp;
                     bool o = false;
-                    xi = xi_plain_spline(D, col, ell_stride, P.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), o) * ev;
+                    xi = xi_plain_spline<SAME>(D, col, ell_stride, P.n_ell, 0.5 * vmx_log(rr2), rrp * vmx_rsqrt(rr2), o) * ev;
                     oob[w] = oob[w] || o;
                 }
             }
