@@ -1193,6 +1193,27 @@ def dump_fits(VegaInterface):
 
 
 
+def dump_fit_stats(VegaInterface):
+    """What the reference's `minimize` leaves next to the fit (vega/vega_interface.py:593-643) on its own test configuration
+    (tests/full_configs/main.ini, the fit tests/test_vega.py:16-18 pins): the best-fit model, every correlation's masked
+    size / chi2 / reduced chi2 / p-value, the totals - the numbers `Output.write_results` puts into the MODEL_<name> headers."""
+    os.chdir(REF / 'tests')
+    vega = VegaInterface('full_configs/main.ini')
+    vega.minimize()
+    out = {'names': np.array(list(vega.corr_items)), 'fval': vega.minimizer.fmin.fval,
+           'chisq': vega.chisq, 'reduced_chisq': vega.reduced_chisq, 'p_value': vega.p_value,
+           'total_data_size': vega.total_data_size,
+           'fit/names': np.array(list(vega.minimizer.values)), 'fit/values': np.array(list(vega.minimizer.values.values()))}
+    for name, st in vega.bestfit_corr_stats.items():
+        for key in ('masked_size', 'chisq', 'reduced_chisq', 'p_value'):
+            out[f'stats/{name}/{key}'] = st[key]
+        assert st['bestfit_marg_coeff'] is None
+        out[f'model/{name}'] = np.array(vega.bestfit_model[name])
+    np.savez_compressed(HERE / 'expected_fit_stats.npz', **out)
+    print('fit stats:', {k: out[k] for k in ('fval', 'chisq', 'reduced_chisq', 'p_value', 'total_data_size')},
+          {n: vega.bestfit_corr_stats[n]['chisq'] for n in vega.bestfit_corr_stats})
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -1200,12 +1221,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1258,3 +1279,5 @@ if __name__ == '__main__':
         dump_mockbin_sampled(VI)
     if 'fht_extrap' in what:
         dump_fht_extrap(VI)
+    if 'fit_stats' in what:
+        dump_fit_stats(VI)

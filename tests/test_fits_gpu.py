@@ -146,3 +146,46 @@ def test_chi2_scan_with_the_vectorised_minimiser(tmp_path):
             assert ra[g] == rb[g]                           # the pinned grid values
         assert rb['fval'] == pytest.approx(ra['fval'], rel=1e-3, abs=1e-3)
     vega.close()
+
+
+def test_bestfit_statistics_and_result_file_against_the_reference(tmp_path):
+    """What the reference's `minimize` leaves next to the fit (vega/vega_interface.py:593-643) and what `run_vega` writes
+    (vega/scripts/run_vega.py:7-51, vega/output.py:37-289) on the reference's own test configuration:
+    `expected_fit_stats.npz` = the unmodified reference's per-correlation sizes / chi2 / reduced chi2 / p-values, totals and
+    best-fit models (make_golden.dump_fit_stats).  The result file is read back as vega/postprocess/fit_results.py reads it."""
+    import vega_amd
+    from vega_amd import fitslite
+    exp = np.load(GOLDEN / 'expected_fit_stats.npz')
+    main = (GOLDEN / 'configs/full4/main.ini').read_text()
+    main = main.replace('filename = lyalya_lyalya__lyalya_lyalyb__lyalya_qso__lyalyb_qso', f'filename = {tmp_path}/fit_result')
+    cfg = tmp_path / 'main.ini'
+    cfg.write_text(main)
+    lines = []
+    vega = vega_amd.run_vega(str(cfg), search_dirs=[GOLDEN], print_func=lines.append, max_batch=64)
+    names = [str(n) for n in exp['names']]
+    assert list(vega.bestfit_corr_stats) == names
+    assert isclose(vega.chisq, float(exp['chisq']), rel_tol=1e-8) and vega.total_data_size == int(exp['total_data_size'])
+    assert isclose(vega.reduced_chisq, float(exp['reduced_chisq']), rel_tol=1e-8) and isclose(vega.p_value, float(exp['p_value']))
+    for name in names:
+        st = vega.bestfit_corr_stats[name]
+        assert st['masked_size'] == int(exp[f'stats/{name}/masked_size']) and st['bestfit_marg_coeff'] is None
+        assert st['chisq'] == pytest.approx(float(exp[f'stats/{name}/chisq']), rel=1e-6, abs=1e-10)
+        assert st['reduced_chisq'] == pytest.approx(float(exp[f'stats/{name}/reduced_chisq']), rel=1e-6, abs=1e-13)
+        assert st['p_value'] == pytest.approx(float(exp[f'stats/{name}/p_value']))
+        ref = exp[f'model/{name}']
+        np.testing.assert_allclose(vega.bestfit_model[name], ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    assert any(line.startswith('Total chi^2/(ndata-nparam): 0.6/(9540-2)') for line in lines)
+
+    hdus = fitslite.open(str(tmp_path / 'fit_result.fits'))
+    by_name = {h.header.get('EXTNAME'): h for h in hdus[1:]}
+    assert list(by_name) == ['MODEL_' + n for n in names] + ['BESTFIT']
+    best = by_name['BESTFIT']
+    assert [str(s).strip() for s in best.data['names']] == [str(n) for n in exp['fit/names']]
+    np.testing.assert_allclose(best.data['values'], exp['fit/values'], rtol=1e-6)
+    assert isclose(best.header['FVAL'], 0.6409716347033996) and best.header['VALID'] is True
+    for name in names:
+        h = by_name['MODEL_' + name]
+        np.testing.assert_array_equal(h.data[name + '_MODEL'], vega.bestfit_model[name])
+        assert h.header['chisq'] == vega.bestfit_corr_stats[name]['chisq'] and h.header['masked_size'] == 1590 * (1 + name.endswith('qso'))
+        assert h.header['bias_eta_LYA'] == vega.bestfit.as_dict()['bias_eta_LYA'] and h.header['ap'] == 1.05
+    vega.close()

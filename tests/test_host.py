@@ -210,7 +210,7 @@ def test_monte_carlo_tables_round_trip_in_the_reference_layout(tmp_path):
     np.testing.assert_array_equal(best['covariance'], cov)
     info = hdul[2].data
     np.testing.assert_array_equal(info['chisq'], analysis.mc_chisq)
-    assert bytes(info['valid_minima'].astype('u1')) == b'TTFTT' and bytes(info['failed_mask'].astype('u1')) == b'FFTFF'
+    assert list(info['valid_minima']) == [True, True, False, True, True] and list(info['failed_mask']) == [False, False, True, False, False]
     np.testing.assert_array_equal(hdul[3].data['lyalya_qso'], analysis.mc_mocks['lyalya_qso'])
     with pytest.raises(OSError):
         output.write_monte_carlo(analysis, tmp_path / 'monte_carlo', cpu_id=3)

@@ -60,7 +60,12 @@ def _read_header(buf, pos):
             if key == 'END':
                 done = True
                 break
-            if card[8:10] == '= ':
+            if key == 'HIERARCH' and '=' in card:
+                # `HIERARCH long or lower-case keyword = value` (the ESO convention astropy writes for `header['hierarch x']`):
+                # kept under the keyword itself, case preserved
+                name, _, raw = card[8:].partition('=')
+                header[name.strip()] = _parse_value(raw)
+            elif card[8:10] == '= ':
                 header[key] = _parse_value(card[10:])
         if done:
             return header, pos
@@ -84,9 +89,10 @@ class _Columns:
 
 
 class _TableData:
-    def __init__(self, rec, names):
+    def __init__(self, rec, names, logical=()):
         self._rec = rec
         self._names = names
+        self._logical = set(logical)
 
     def __getitem__(self, name):
         if name not in self._names:
@@ -94,6 +100,8 @@ class _TableData:
         col = self._rec[name]
         if col.dtype.kind == 'S':
             return np.char.decode(col, 'ascii')
+        if name in self._logical:
+            return col == ord('T')          # TFORM 'L': bool, as astropy hands it out
         # native-endian copy, as astropy hands out
         return np.ascontiguousarray(col.astype(col.dtype.newbyteorder('=')))
 
@@ -146,9 +154,11 @@ def open(path):  # noqa: A001 - mirrors astropy.io.fits.open
         if xt is not None and xt.strip() == 'BINTABLE' and size:
             nrow = header['NAXIS2']
             rowlen = header['NAXIS1']
-            names, formats = [], []
+            names, formats, logical = [], [], []
             for c in range(1, header['TFIELDS'] + 1):
                 repeat, code = _parse_tform(header[f'TFORM{c}'])
+                if code == 'L':
+                    logical.append(header[f'TTYPE{c}'].strip())
                 base, _ = _TFORM_DTYPES[code]
                 if code == 'A':
                     fmt = f'S{repeat}'
@@ -162,7 +172,7 @@ def open(path):  # noqa: A001 - mirrors astropy.io.fits.open
             if dt.itemsize != rowlen:
                 raise ValueError(f'Row length mismatch: {dt.itemsize} vs {rowlen}')
             rec = np.frombuffer(buf, dtype=dt, count=nrow, offset=pos)
-            hdus.append(HDU(header, _TableData(rec, names), names))
+            hdus.append(HDU(header, _TableData(rec, names, logical), names))
         else:
             hdus.append(HDU(header))
         pos += ((size + _BLOCK - 1) // _BLOCK) * _BLOCK
@@ -171,15 +181,37 @@ def open(path):  # noqa: A001 - mirrors astropy.io.fits.open
 
 # ------------------------------------------------------------------------------------------ writer
 def _card(key, value, comment=''):
+    if isinstance(value, tuple):            # (value, comment)
+        value, comment = value
+    if isinstance(value, np.bool_):
+        value = bool(value)
     if isinstance(value, bool):
         v = f"{'T' if value else 'F':>20}"
     elif isinstance(value, (int, np.integer)):
         v = f'{int(value):>20}'
-    elif isinstance(value, float):
-        v = f'{value:>20.13E}'
+    elif isinstance(value, (float, np.floating)):
+        v = f'{float(value):>20.13E}'
     else:
         text = "'" + str(value).replace("'", "''").ljust(8) + "'"
         v = f'{text:<20}'
+    if len(key) > 8 or key != key.upper() or ' ' in key:
+        # HIERARCH card (what astropy makes of `header['hierarch ' + key] = value`, reference vega/output.py:212-228)
+        if isinstance(value, bool):
+            hv = 'T' if value else 'F'
+        elif isinstance(value, (int, np.integer)):
+            hv = str(int(value))
+        elif isinstance(value, (float, np.floating)):
+            hv = repr(float(value)).upper() if np.isfinite(value) else "'" + str(value) + "'"
+            if 'E' not in hv and '.' not in hv:
+                hv += '.0'
+        else:
+            hv = "'" + str(value).replace("'", "''") + "'"
+        card = f'HIERARCH {key} = {hv}'
+        if len(card) > _CARD:
+            card = f'HIERARCH {key}={hv}'
+        if len(card) > _CARD:
+            raise ValueError(f'header keyword {key!r} with its value does not fit one FITS card')
+        return card.ljust(_CARD)
     card = f'{key:<8}= {v}'
     if comment:
         card += f' / {comment}'

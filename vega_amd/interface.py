@@ -33,6 +33,9 @@ class _DataView:
     log_cov_det = property(lambda self: self._item.log_cov_det)
     data_size = property(lambda self: self._item.data_size)
     full_data_size = property(lambda self: self._item.data_vec.size)
+    effective_data_size = property(lambda self: self._item.effective_data_size)
+    variance = property(lambda self: self._item.variance)
+    nb = property(lambda self: self._item.nb)
 
 
 class _ModelView:
@@ -97,6 +100,13 @@ class VegaInterface:
         self._marg_names = [n for n, it in self.problem.items.items() if it.marg_diff2coeff is not None]
         self._random_marg_coeff = None
         self.models = {name: _ModelView(self, name) for name in self.problem.items}
+        # a fit's results (reference vega_interface.py:198, :581-643; written by run_vega through vega.output)
+        from .output import Output
+        self.output = Output(self.main_config['output'] if self.main_config is not None and 'output' in self.main_config
+                             else None, self.problem.items)
+        self.bestfit = self.minimizer = None
+        self.bestfit_model = self.bestfit_corr_stats = None
+        self.chisq = self.reduced_chisq = self.p_value = self.total_data_size = None
 
     # ------------------------------------------------------------------ blinding
     def set_blinding_offsets(self, offsets):
@@ -498,8 +508,56 @@ class VegaInterface:
                 sample[key].update({n: v for n, v in params[key].items() if n in sample['limits']})
         driver = MonteCarlo(self)
         fitter = driver.minimizer(sample, tol=tol, method=method)
-        self.bestfit = fitter.minimize(n_fits=1, fixed=driver._fixed)
+        self.bestfit = self.minimizer = fitter.minimize(n_fits=1, fixed=driver._fixed)
+        self._bestfit_statistics()
         return self.bestfit
+
+    def _bestfit_statistics(self, print_func=None):
+        """What the reference's ``minimize`` leaves behind next to the fit (vega/vega_interface.py:593-643): the best-fit
+        model (through the engine), every correlation's own chi2 / reduced chi2 / p-value on its fitted bins and the best-fit
+        coefficients of its marginalisation templates (added to its best-fit model), and the totals.  The per-correlation
+        chi2 is a statistic of the written result - one product per correlation on the host, once per fit - not the
+        fitted function (that is the engine's, ``self.chisq = fmin.fval``)."""
+        from scipy import stats
+        fit = self.bestfit
+        values = {**self.params, **fit.as_dict(0)}
+        self.bestfit_model = self.compute_model(values, run_init=False)
+        self.total_data_size = 0
+        self.bestfit_corr_stats = {}
+        num_pars = len(self.sample_params['limits'])
+        for name, item in self.problem.items.items():
+            view = self.data[name]
+            size = item.effective_data_size
+            self.total_data_size += size
+            coeff = None
+            if self.monte_carlo and self._use_global_cov:
+                chisq = 0.                                                     # (as the reference: :603-605)
+                diff = None
+            else:
+                if self.monte_carlo:
+                    diff = np.asarray(view.masked_mc_mock) - self.bestfit_model[name][item.model_mask]
+                    inv = view.scaled_inv_masked_cov if view.scaled_inv_masked_cov is not None else item.inv_masked_cov
+                else:
+                    diff = item.masked_data_vec - self.bestfit_model[name][item.model_mask]
+                    inv = item.inv_masked_cov
+                chisq = float(diff.dot(inv.dot(diff)))
+            if item.marg_diff2coeff is not None and diff is not None:
+                coeff = np.asarray(item.marg_diff2coeff.dot(diff))
+                self.bestfit_model[name] = self.bestfit_model[name] + np.asarray(item.marg_templates.dot(coeff)).ravel()
+            dof = size - num_pars
+            self.bestfit_corr_stats[name] = {'masked_size': int(size), 'chisq': chisq, 'reduced_chisq': chisq / dof,
+                                             'p_value': float(1 - stats.chi2.cdf(chisq, dof)), 'bestfit_marg_coeff': coeff}
+            if print_func is not None:
+                print_func(f'{name} chi^2/(ndata-nparam): {chisq:.1f}/({size}-{num_pars}) = {chisq / dof:.3f}')
+        self.chisq = float(fit.fval[0])
+        dof = self.total_data_size - num_pars
+        self.reduced_chisq = self.chisq / dof
+        self.p_value = float(1 - stats.chi2.cdf(self.chisq, dof))
+        if print_func is not None:
+            print_func(f'Total chi^2/(ndata-nparam): {self.chisq:.1f}/({self.total_data_size}-{num_pars}) '
+                       f'= {self.reduced_chisq:.3f}, PTE={self.p_value:.2f}')
+            if not bool(fit.is_valid[0]):
+                print_func('Invalid fit!!! Check data, covariance, model and priors.')
 
     def chi2_scan(self, method='migrad'):
         """``[chi2 scan]`` of the reference (vega/analysis.py:53-122; ``vega.analysis.chi2_scan()`` there): every grid point's

@@ -1,8 +1,18 @@
-"""Monte-Carlo result tables in the reference's FITS layout (reference vega/output.py:442-520,
-``Output.write_monte_carlo``): HDU 'Bestfit' (names, values, errors, covariance), HDU 'FitInfo' (chisq,
-valid_minima, valid_hesse, failed_mask) and HDU 'Mocks' (one vector column per correlation), one file per rank
-(`monte_carlo_<rank>.fits`) as `bin/run_vega_mc_mpi.py:67-71` writes them.
+"""Result files in the reference's FITS layout (reference vega/output.py), written with `fitslite`.
+
+* a fit (`Output.write_results`, reference :37-123): one HDU ``MODEL_<correlation>`` per correlation (columns
+  ``<name>_MODEL / _MODEL_MASK / _MASK / _DATA / _VAR / _RP / _RT / _Z / _NB``, the parameters and the correlation's fit
+  statistics as HIERARCH cards, reference :144-235), HDU ``BESTFIT`` (names, values, errors, covariance; FVAL / VALID /
+  ACCURATE, reference :237-289) and HDU ``SCAN`` (one column per parameter and result of the chi2 scan, reference :291-349) -
+  what `vega.postprocess.fit_results.FitResults` and `mc_start_from_fit` read back;
+* Monte Carlo (`write_monte_carlo`, reference :442-520): HDU 'Bestfit' (names, values, errors, covariance), HDU 'FitInfo'
+  (chisq, valid_minima, valid_hesse, failed_mask) and HDU 'Mocks' (one vector column per correlation), one file per rank
+  (`monte_carlo_<rank>.fits`) as `bin/run_vega_mc_mpi.py:67-71` writes them.
+
+Not written: the ``write_pk`` / ``write_cf`` component HDUs (the engine keeps no per-component P(k) / xi arrays on the host)
+and the hdf flavour (h5py is not a dependency): both raise.
 """
+import os
 from pathlib import Path
 
 import numpy as np
@@ -54,3 +64,122 @@ def write_monte_carlo(analysis, directory, cpu_id=None, overwrite=False):
     path = directory / ('monte_carlo.fits' if cpu_id is None else f'monte_carlo_{cpu_id}.fits')
     fitslite.write_tables(str(path), monte_carlo_tables(analysis), overwrite=overwrite)
     return path
+
+
+# ------------------------------------------------------------------------------------------ a fit's results
+def _pad(array, size, pad_value=np.nan):
+    array = np.asarray(array)
+    return np.pad(array, (0, size - len(array)), constant_values=pad_value)
+
+
+def model_tables(items, corr_funcs, params, bestfit_corr_stats=None):
+    """[(extname, columns, header)] of the MODEL_<name> HDUs (reference vega/output.py:144-235).  ``items``: the problem's
+    correlation items; ``corr_funcs``: {name: model vector} as compute_model returns it."""
+    tables = []
+    for name, cf in corr_funcs.items():
+        it = items[name]
+        cf = np.asarray(cf, dtype=float)
+        n = len(cf)
+        if len(it.data_vec) > n:
+            raise ValueError('Data coordinate grid is larger than the model grid.')
+        variance = it.variance if it.variance is not None else \
+            (np.ones(it.data_vec.size) if it.cov is None else np.diag(it.cov))
+        cols = [(name + '_MODEL', 'D', cf),
+                (name + '_MODEL_MASK', 'L', _pad(it.model_mask, n, False)),
+                (name + '_MASK', 'L', _pad(it.data_mask, n, False)),
+                (name + '_DATA', 'D', _pad(it.data_vec, n)),
+                (name + '_VAR', 'D', _pad(variance, n)),
+                (name + '_RP', 'D', _pad(it.dist_grid.rp, n)),
+                (name + '_RT', 'D', _pad(it.dist_grid.rt, n))]
+        z = None if it.model_grid.z is None else np.atleast_1d(np.asarray(it.model_grid.z, dtype=float))
+        cols.append((name + '_Z', 'D', np.zeros(n) if z is None or n < z.size else _pad(z, n)))        # (reference :199-205)
+        if it.nb is not None:
+            cols.append((name + '_NB', 'K', _pad(np.asarray(it.nb, dtype=np.int64), n, 0)))
+        header = {}
+        for par, val in params.items():
+            header[par] = float(val) if isinstance(val, (float, np.floating)) else val
+        if bestfit_corr_stats is not None:
+            for par, val in bestfit_corr_stats[name].items():
+                if par == 'bestfit_marg_coeff':
+                    if val is not None:
+                        for i, v in enumerate(val):
+                            header[f'marg_coeff_{i}'] = float(v)
+                else:
+                    header[par] = val
+        tables.append(('MODEL_' + name, cols, header))
+    return tables
+
+
+def bestfit_table(names, values, errors, covariance, fval, valid, accurate):
+    """The BESTFIT HDU (reference vega/output.py:237-289)."""
+    names = np.array(list(names))
+    width = max(len(n) for n in names)
+    cov = np.asarray(covariance, dtype=float).reshape(len(names), len(names))
+    cols = [('names', f'{width}A', names), ('values', 'D', np.asarray(values, dtype=float)),
+            ('errors', 'D', np.asarray(errors, dtype=float)), ('covariance', f'{len(names)}D', cov)]
+    header = {'FVAL': (float(fval), 'Bestfit chi^2 value'), 'VALID': (bool(valid), 'Flag for valid fit'),
+              'ACCURATE': (bool(accurate), 'Flag for accurate fit')}
+    return ('BESTFIT', cols, header)
+
+
+def scan_table(scan_results, grids=None):
+    """The SCAN HDU (reference vega/output.py:291-349): ``scan_results`` = one dict per grid point."""
+    names = np.array(list(scan_results[0].keys()))
+    width = max(len(n) for n in names)
+    results = np.array([[res[par] for par in names] for res in scan_results], dtype=float)
+    if len(results) != len(names):
+        # (the reference puts the names column next to the per-point columns, which makes astropy pad the shorter one; the
+        # table here has one row per grid point and the names column padded / cut to that length, as astropy leaves it)
+        pad = np.array([''] * len(results), dtype=names.dtype)
+        pad[:min(len(names), len(results))] = names[:len(results)]
+        name_col = pad
+    else:
+        name_col = names
+    cols = [('names', f'{width}A', name_col)] + [(str(n), 'D', results[:, j]) for j, n in enumerate(names)]
+    header = {}
+    for par, grid in (grids or {}).items():
+        header[par + '_min'] = (float(grid[0]), 'Grid start for ' + par)
+        header[par + '_max'] = (float(grid[-1]), 'Grid end for ' + par)
+        header[par + '_num_bins'] = (int(len(grid)), 'Grid size for ' + par)
+    return ('SCAN', cols, header)
+
+
+class Output:
+    """The reference's ``vega.output`` object for a fit's results (reference vega/output.py:9-123): built from the
+    ``[output]`` section; ``write_results(corr_funcs, params, minimizer, bestfit_corr_stats, scan_results)``."""
+
+    def __init__(self, config, items, analysis=None):
+        get = config.get if config is not None else (lambda key, default=None: default)
+        self.items = items
+        self.analysis = analysis
+        self.type = get('type', 'fits')
+        self.overwrite = str(get('overwrite', False)).lower() in ('true', '1', 'yes')
+        filename = get('filename', None)
+        self.outfile = None if filename is None else os.path.expandvars(filename)
+        flag = (lambda key: config.getboolean(key, False)) if hasattr(config, 'getboolean') else (lambda key: False)
+        self.output_cf, self.output_pk = flag('write_cf'), flag('write_pk')
+        self.mc_output = get('mc_output', None)
+
+    def write_results(self, corr_funcs, params, minimizer=None, bestfit_corr_stats=None, scan_results=None, models=None):
+        """``minimizer``: a `minimizer.FitResult` (fit 0 is written) or None."""
+        if self.type not in ('fits',):
+            raise NotImplementedError(f'output type {self.type!r}: only the fits flavour is written')
+        if self.output_cf or self.output_pk:
+            raise NotImplementedError('write_cf / write_pk: the model components are not kept on the host')
+        if self.outfile is None:
+            raise ValueError('[output] filename is not set')
+        tables = model_tables(self.items, corr_funcs, params, bestfit_corr_stats)
+        if minimizer is not None:
+            accurate = getattr(minimizer, 'has_accurate_covar', None)
+            tables.append(bestfit_table(minimizer.names, minimizer.values[0], minimizer.errors[0], minimizer.covariance[0],
+                                        minimizer.fval[0], minimizer.is_valid[0],
+                                        accurate[0] if accurate is not None else not minimizer.hesse_failed[0]))
+        if scan_results is not None:
+            if minimizer is None:
+                raise ValueError('scan results are written next to a fit')
+            tables.append(scan_table(scan_results, getattr(self.analysis, 'grids', None)))
+        if self.outfile[-5:] != '.fits':
+            self.outfile += '.fits'
+        Path(self.outfile).parent.mkdir(parents=True, exist_ok=True)
+        fitslite.write_tables(self.outfile, tables, overwrite=self.overwrite)
+        return self.outfile

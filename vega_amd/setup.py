@@ -321,6 +321,14 @@ class CorrItem:
     marg_templates = None        # distorted templates [n_dist, n_templates] (sparse)
     marg_diff2coeff = None       # M [n_templates, n_masked]
     marginalize_in_fit = False
+    num_marg_modes = 0           # modes the marginalisation removes (reference data.py:92,825)
+    variance = None              # diagonal of the covariance as read (reference data.py:82-85); None: taken from `cov`
+    nb = None                    # pair counts of the data file (column NB), if any
+
+    @property
+    def effective_data_size(self):
+        """Fitted bins minus the marginalised modes (reference vega/data.py:134)."""
+        return self.data_size - self.num_marg_modes
 
     def marg_projector(self):
         tm = self.marg_templates[self.model_mask, :]
@@ -697,6 +705,7 @@ def marginalization_cov_update(distortion, model_grid, dist_grid, cuts, marg, mo
     u, sv, _ = np.linalg.svd(t, full_matrices=False)
     w = sv > factor * sv[0]
     u, sv = u[:, w], sv[w]
+    marginalization_cov_update.last_modes = int(w.sum())       # the reference's Data.num_marg_modes (data.py:825)
     return np.dot(u * sv**2, u.T)
 
 
@@ -783,6 +792,10 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     rescale = d.getfloat('cov_rescale', None)
     if cov is not None and rescale is not None:
         cov = cov * rescale
+    # what the fit output writes next to the data (reference vega/data.py:82-85, :370): the covariance's diagonal as read,
+    # the pair counts if the file has them
+    variance = np.ones(data_vec.size) if cov is None else np.array(np.diag(cov), dtype=float)
+    nb = np.asarray(t1.data['NB']) if t1.has('NB') else None
     cosmo = None
     if 'OMEGAM' in hdr:     # the picca cosmology of the file: only new-bias-evolution (and new_metals) use it
         cosmo = {'Omega_m': float(hdr['OMEGAM']), 'Omega_k': float(hdr.get('OMEGAK', 0.)),
@@ -979,7 +992,9 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     if marg:
         item.marg_templates, item.marg_diff2coeff = marg_templates, marg_diff2coeff
         item.marginalize_in_fit = bool(marginalize_in_fit)
+        item.num_marg_modes = marginalization_cov_update.last_modes
     item.blind, item.blinding_strat = blind, (blinding if blind else None)
+    item.variance, item.nb = variance, nb
     item.cov_rescale = rescale
     item.cholesky_masked_cov = d.getboolean('cholesky-masked-cov', True)
     return item
