@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Monte-Carlo over mocks, one process per GPU: the reference's ``bin/run_vega_mc_mpi.py`` (:17-71) with torchrun in
-place of mpirun.
+place of mpirun; with ``--fit-mocks`` the reference's ``bin/run_vega_mc_fits_mpi.py`` (:112-163): the global mocks of the
+file ``[control] mc_mocks`` (optionally cut to two slices) are fitted, a contiguous share per rank.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29555 \
         scripts/run_mc_sharded.py main.ini --output-dir out/monte_carlo
@@ -36,7 +37,8 @@ def build_library_once():
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def run(config, output_dir=None, search_dirs=(), max_batch=1024, backend=None, make_vega=None, print_func=None):
+def run(config, output_dir=None, search_dirs=(), max_batch=1024, backend=None, make_vega=None, print_func=None,
+        fit_mocks=None):
     """The body of the launcher; ``make_vega(config, device)`` may replace the interface (CPU tests of the sharding
     logic).  Returns (MonteCarlo driver, FitResult or None, (lo, hi) block of this rank)."""
     import numpy as np
@@ -78,6 +80,33 @@ def run(config, output_dir=None, search_dirs=(), max_batch=1024, backend=None, m
         raise ValueError('Warning: You called "run_mc_sharded.py" without asking for monte carlo. Add '
                          '"run_montecarlo = True" to the "[control]" section.')
     say('Finished initializing Vega')
+    if fit_mocks:
+        # the reference's bin/run_vega_mc_fits_mpi.py (:112-163): fit the global mocks of a file (HDU MOCKS, column
+        # 'global'; `[control] mc_mocks`, optionally cut by slice_start1 / slice_end1 / slice_start2 / slice_end2), a contiguous
+        # share per rank
+        from vega_amd.montecarlo import fit_mocks_sharded
+        from vega_amd.tables import find_file, read_tables
+        if control.get('mc_mocks', None) is None:
+            raise ValueError('--fit-mocks: `[control] mc_mocks` names the file with the mocks')
+        vega.monte_carlo = True
+        table = [t for t in read_tables(find_file(control.get('mc_mocks'), vega.problem.search_dirs))
+                 if str(t.header.get('EXTNAME', '')).strip().upper() == 'MOCKS'][0]
+        mocks = np.asarray(table.data['global'], dtype=float)
+        slices = tuple(control.getint(key, None) for key in ('slice_start1', 'slice_end1', 'slice_start2', 'slice_end2'))
+        if output_dir is None:
+            out = vega.main_config['output'].get('mc_output', None) if 'output' in vega.main_config else None
+            output_dir = out if out is not None else Path(vega.main_config['output']['filename']).parent / 'monte_carlo'
+        t0 = time.perf_counter()
+        mc, res, block = fit_mocks_sharded(vega, mocks, slices, rank=rank, world_size=world, output_dir=output_dir)
+        dt = time.perf_counter() - t0
+        n_valid = int(np.sum(res.is_valid)) if res is not None else 0
+        counts = [(block[1] - block[0], n_valid, dt)]
+        if use_dist:
+            counts = [None] * world
+            dist.all_gather_object(counts, (block[1] - block[0], n_valid, dt))
+        say(f'{sum(c[0] for c in counts)} mocks of {control.get("mc_mocks")} on {world} rank(s): {sum(c[1] for c in counts)} '
+            f'valid fits, slowest rank {max(c[2] for c in counts):.2f} s; results under {output_dir}')
+        return mc, res, block
     fiducial_model = vega.get_fiducial_for_monte_carlo(print_func=say)
     if control.getboolean('forecast', False):
         raise ValueError('You asked to run a forecast. Use a single process instead.')
@@ -110,11 +139,14 @@ def main(argv=None):
     ap.add_argument('--output-dir', default=None, help='directory of monte_carlo_<rank>.fits (default: next to [output] filename)')
     ap.add_argument('--search-dir', action='append', default=[], help='extra directory for relative paths in the configs')
     ap.add_argument('--max-batch', type=int, default=1024, help='walkers per engine call')
+    ap.add_argument('--fit-mocks', action='store_true',
+                    help="fit the global mocks of `[control] mc_mocks` instead of drawing mocks (the reference's "
+                         'bin/run_vega_mc_fits_mpi.py)')
     args = ap.parse_args(argv)
     build_library_once()
     import torch.distributed as dist
     try:
-        run(args.config, args.output_dir, args.search_dir, args.max_batch)
+        run(args.config, args.output_dir, args.search_dir, args.max_batch, fit_mocks=args.fit_mocks)
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()

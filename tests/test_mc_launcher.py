@@ -139,3 +139,42 @@ def test_launcher_refuses_a_config_without_monte_carlo(tmp_path):
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     with pytest.raises(ValueError, match='run_montecarlo'):
         run_mc_sharded.run('unused.ini', output_dir=str(tmp_path), make_vega=make)
+
+
+def test_launcher_fits_the_mocks_of_a_file(tmp_path):
+    """`--fit-mocks` = the reference's bin/run_vega_mc_fits_mpi.py (:112-163): HDU MOCKS / column 'global' of `[control]
+    mc_mocks`, cut by the four slice bounds, this rank's contiguous share fitted and written (one rank here; the share
+    arithmetic has its own test, the fits against the drawn mocks' run on the GPU: tests/test_round2_gpu.py)."""
+    sys.path.insert(0, str(REPO / 'scripts'))
+    import run_mc_sharded
+    from vega_amd import fitslite
+    base = _make_vega(None, 0)
+    prob = base.problem
+    sizes = [it.data_size for it in prob.items.values()]
+    rng = np.random.default_rng(5)
+    mocks = np.concatenate([base.engine.fid[n][None, :] + 1e-4 * rng.standard_normal((4, s))
+                            for n, s in zip(prob.items, sizes)], axis=1)
+    longer = np.concatenate([np.zeros((4, 2)), mocks[:, :sizes[0]], np.ones((4, 5)), mocks[:, sizes[0]:]], axis=1)
+    path = tmp_path / 'mocks.fits'
+    fitslite.write_tables(str(path), [('MOCKS', [('global', f'{longer.shape[1]}D', longer)])])
+
+    def make(config, device):
+        vega = _make_vega(config, device)
+        vega.problem.global_cov = np.eye(sum(sizes))
+        vega.problem.search_dirs = [tmp_path]
+        vega._use_global_cov = True
+        vega.freeze_metals = lambda: None
+        c = vega.main_config['control']
+        c['mc_mocks'] = str(path)
+        c['slice_start1'], c['slice_end1'] = '2', str(2 + sizes[0])
+        c['slice_start2'], c['slice_end2'] = str(2 + sizes[0] + 5), str(longer.shape[1])
+        return vega
+    lines = []
+    mc, res, block = run_mc_sharded.run('unused.ini', output_dir=tmp_path / 'out', make_vega=make, print_func=lines.append,
+                                        fit_mocks=True)
+    assert block == (0, 4) and res.values.shape == (4, 2) and res.is_valid.all()
+    np.testing.assert_array_equal(mc.mc_mocks['global'], mocks)
+    tabs = {h.header['EXTNAME'].upper(): h for h in fitslite.open(tmp_path / 'out' / 'monte_carlo.fits')[1:]}
+    np.testing.assert_array_equal(np.asarray(tabs['MOCKS'].data['global']), mocks)
+    np.testing.assert_allclose(np.asarray(tabs['BESTFIT'].data['values']).T, res.values, rtol=1e-12)
+    assert any('4 mocks of' in line and '4 valid fits' in line for line in lines)

@@ -204,6 +204,52 @@ def test_global_covariance_monte_carlo(tmp_path):
     vega.close()
 
 
+def test_fitting_existing_global_mocks(tmp_path):
+    """`bin/run_vega_mc_fits_mpi.py` (:11-79, :127-163): mocks of the global masked data vector READ from a file (HDU MOCKS,
+    column 'global'), optionally cut to two slices, fitted - here the very mocks `run_monte_carlo` draws for seed 7, written
+    with the driver's own writer inside a longer vector: the fits must be those of the drawn mocks, fit for fit, and a rank's
+    contiguous share must be its rows of them."""
+    from vega_amd import VegaInterface, fitslite
+    from vega_amd.montecarlo import contiguous_share, fit_mocks_sharded
+    prob = synth_joint_problem(with_global_cov=True, tmp_path=tmp_path)
+    names = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA']
+    prob.mc_config = {'params': {}, 'sample': {
+        'limits': {'ap': (0.5, 1.5), 'at': (0.5, 1.5), 'bias_eta_LYA': (-2., 0.), 'beta_LYA': (0., 5.)},
+        'values': {n: prob.params[n] for n in names},
+        'errors': {'ap': 0.01, 'at': 0.01, 'bias_eta_LYA': 0.01, 'beta_LYA': 0.1},
+        'fix': {n: False for n in names}}}
+    vega = VegaInterface(None, problem=prob, max_batch=64)
+    ref = vega.run_monte_carlo(num_mocks=5, seed=7)
+    whole = np.array(vega.analysis.mc_mocks['global'])
+    n1 = next(iter(prob.items.values())).data_size
+    # the mocks inside a longer vector: [7 foreign | item 1 | 11 foreign | item 2 | 3 foreign], through a file
+    rng = np.random.default_rng(0)
+    longer = np.concatenate([rng.standard_normal((5, 7)), whole[:, :n1], rng.standard_normal((5, 11)), whole[:, n1:],
+                             rng.standard_normal((5, 3))], axis=1)
+    path = tmp_path / 'mocks.fits'
+    fitslite.write_tables(str(path), [('MOCKS', [('global', f'{longer.shape[1]}D', longer)])])
+    table = [h for h in fitslite.open(str(path))[1:] if h.header['EXTNAME'] == 'MOCKS'][0]
+    mocks = np.asarray(table.data['global'])
+    np.testing.assert_array_equal(mocks, longer)
+    slices = (7, 7 + n1, 7 + n1 + 11, longer.shape[1] - 3)
+    vega.monte_carlo = True
+    res = vega.analysis.fit_global_mocks(mocks, *slices)
+    np.testing.assert_array_equal(vega.analysis.mc_mocks['global'], whole)
+    np.testing.assert_array_equal(res.values, ref.values)
+    np.testing.assert_array_equal(res.fval, ref.fval)
+    np.testing.assert_array_equal(res.is_valid, ref.is_valid)
+    assert len(vega.analysis.mc_chisq) == 5 and vega.analysis.mc_bestfits['ap'].shape == (5, 2)
+    with pytest.raises(ValueError):
+        vega.analysis.fit_global_mocks(mocks)                  # (uncut: not this problem's vector)
+    # rank 1 of 2: rows 3..4 (the first rank takes the remainder), its own result file
+    assert [contiguous_share(5, 2, r) for r in range(2)] == [(0, 3), (3, 5)]
+    mc, part, block = fit_mocks_sharded(vega, mocks, slices, rank=1, world_size=2, output_dir=tmp_path / 'mc')
+    assert block == (3, 5) and (tmp_path / 'mc' / 'monte_carlo_1.fits').exists()
+    np.testing.assert_allclose(part.values, ref.values[3:5], rtol=1e-9)
+    np.testing.assert_allclose(part.fval, ref.fval[3:5], rtol=1e-9)
+    vega.close()
+
+
 def test_walker_sharding_on_a_real_engine_with_an_rccl_group_of_one():
     """`chi2_sharded` (one all_gather per batch) with backend "nccl" (= RCCL) and device tensors around a real engine;
     more ranks are covered on CPU with gloo (tests/test_parallel.py) and by the round driver's N-GPU bench."""

@@ -230,3 +230,15 @@ def test_oracle_rescaled_covariance_with_marginalize_in_fit(tmp_path):
     np.testing.assert_allclose(coeff['lyalya_lyalya'], exp['fid/coeff'], rtol=0, atol=5e-6 * scale)
     pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
     assert oc.chi2(prob, pars, data_override=mock, cov_scale=float(exp['scale'])) == pytest.approx(float(exp['walker0/chi2']), rel=1e-9)
+
+
+def test_contiguous_share_of_a_mock_file():
+    """reference bin/run_vega_mc_fits_mpi.py:134-141: the first n % size ranks take one more; the shares tile [0, n)"""
+    from vega_amd.montecarlo import contiguous_share
+    for n, size in ((10, 4), (3, 8), (16, 8), (1, 1), (0, 2)):
+        shares = [contiguous_share(n, size, r) for r in range(size)]
+        assert shares[0][0] == 0 and shares[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(shares, shares[1:]))
+        lens = [b - a for a, b in shares]
+        assert max(lens) - min(lens) <= 1 and lens == sorted(lens, reverse=True)
+    assert contiguous_share(10, 4, 1) == (3, 6) and contiguous_share(10, 4, 3) == (8, 10)

@@ -252,6 +252,34 @@ class MonteCarlo:
         if not run_mc_fits:
             self.has_monte_carlo = True
             return None
+        return self._fit_mocks(mocks, num_mocks, scale=scale, sample_params=sample_params, method=method)
+
+    def fit_global_mocks(self, mocks, start1=None, end1=None, start2=None, end2=None, scale=None, sample_params=None,
+                         method='migrad'):
+        """Fit EXISTING mocks of the global masked data vector instead of drawing them (reference
+        bin/run_vega_mc_fits_mpi.py:11-79): ``mocks`` [n, length]; with the four slice bounds every mock is cut to
+        ``r_[mock[start1:end1], mock[start2:end2]]`` first (mocks of a longer joint vector, :41-47).  All fits run in lock-step;
+        results in the attributes of ``run_monte_carlo``, ``mc_mocks = {'global': the (cut) mocks}``."""
+        vega = self.vega
+        prob = vega.problem
+        if prob.global_cov is None:
+            raise ValueError('fit_global_mocks: the mocks are vectors of the global masked data - a `global-cov-file` is needed')
+        whole = np.atleast_2d(np.asarray(mocks, dtype=float))
+        if not (start1 is None or end1 is None or start2 is None or end2 is None):
+            whole = np.concatenate([whole[:, start1:end1], whole[:, start2:end2]], axis=1)
+        n_global = sum(item.data_size for item in prob.items.values())
+        if whole.shape[1] != n_global:
+            raise ValueError(f'the mocks have {whole.shape[1]} entries, the global masked data vector {n_global}')
+        whole = np.ascontiguousarray(whole)
+        self.mc_mocks = {'global': whole}
+        self.current_mc_mock = whole[-1]
+        vega.freeze_metals()
+        return self._fit_mocks(split_global(prob, whole), whole.shape[0], scale=scale, sample_params=sample_params, method=method)
+
+    def _fit_mocks(self, mocks, num_mocks, scale=None, sample_params=None, method='migrad'):
+        vega = self.vega
+        eng = vega.engine
+        prob = vega.problem
         if sample_params is None and prob.mc_config is not None:
             sample_params = prob.mc_config['sample']       # the [monte carlo] section (reference analysis.py:249)
         scales = item_scales(prob, scale)
@@ -289,6 +317,29 @@ class MonteCarlo:
         """`monte_carlo[_<cpu_id>].fits` in the reference's layout (reference vega/output.py:442-520)."""
         from .output import write_monte_carlo
         return write_monte_carlo(self, directory, cpu_id=cpu_id, overwrite=overwrite)
+
+
+def contiguous_share(n, world_size, rank):
+    """[start, stop) of rank's share of n tasks, the first ``n % world_size`` ranks taking one more (reference
+    bin/run_vega_mc_fits_mpi.py:134-141)."""
+    per, rem = divmod(int(n), int(world_size))
+    if rank < rem:
+        start = rank * (per + 1)
+        return start, start + per + 1
+    start = rank * per + rem
+    return start, start + per
+
+
+def fit_mocks_sharded(vega, mocks, slices=(None, None, None, None), rank=0, world_size=1, output_dir=None, **kw):
+    """The rank's contiguous share of a file's global mocks, fitted in lock-step; one result file per rank when
+    ``output_dir`` is given (reference bin/run_vega_mc_fits_mpi.py:127-163)."""
+    lo, hi = contiguous_share(len(mocks), world_size, rank)
+    mc = MonteCarlo(vega)
+    vega.analysis = mc
+    res = mc.fit_global_mocks(mocks[lo:hi], *slices, **kw) if hi > lo else None
+    if output_dir is not None and res is not None:
+        mc.write(output_dir, cpu_id=rank if world_size > 1 else None, overwrite=True)
+    return mc, res, (lo, hi)
 
 
 def run_monte_carlo_sharded(vega, fiducial_model, num_mc_mocks, seed=0, rank=0, world_size=1, output_dir=None,
