@@ -176,16 +176,17 @@ def test_bestfit_statistics_and_result_file_against_the_reference(tmp_path):
         np.testing.assert_allclose(vega.bestfit_model[name], ref, rtol=0, atol=1e-8 * np.abs(ref).max())
     assert any(line.startswith('Total chi^2/(ndata-nparam): 0.6/(9540-2)') for line in lines)
 
-    hdus = fitslite.open(str(tmp_path / 'fit_result.fits'))
-    by_name = {h.header.get('EXTNAME'): h for h in hdus[1:]}
-    assert list(by_name) == ['MODEL_' + n for n in names] + ['BESTFIT']
-    best = by_name['BESTFIT']
-    assert [str(s).strip() for s in best.data['names']] == [str(n) for n in exp['fit/names']]
-    np.testing.assert_allclose(best.data['values'], exp['fit/values'], rtol=1e-6)
-    assert isclose(best.header['FVAL'], 0.6409716347033996) and best.header['VALID'] is True
+    from vega_amd.fit_results import FitResults
+    res = FitResults(tmp_path / 'fit_result.fits')
+    assert list(res.names) == [str(n) for n in exp['fit/names']] and list(res.correlations) == names
+    np.testing.assert_allclose(res.mean, exp['fit/values'], rtol=1e-6)
+    assert isclose(res.chisq, 0.6409716347033996) and res.valid is True
+    assert res.num_data_points == 9540 and isclose(res.reduced_chisq, vega.reduced_chisq) and isclose(res.p_value, vega.p_value)
     for name in names:
-        h = by_name['MODEL_' + name]
-        np.testing.assert_array_equal(h.data[name + '_MODEL'], vega.bestfit_model[name])
-        assert h.header['chisq'] == vega.bestfit_corr_stats[name]['chisq'] and h.header['masked_size'] == 1590 * (1 + name.endswith('qso'))
-        assert h.header['bias_eta_LYA'] == vega.bestfit.as_dict()['bias_eta_LYA'] and h.header['ap'] == 1.05
+        c = res.correlations[name]
+        np.testing.assert_array_equal(c.model, vega.bestfit_model[name])
+        assert c.chisq == vega.bestfit_corr_stats[name]['chisq'] and c.size == 1590 * (1 + name.endswith('qso'))
+    hdus = fitslite.open(str(tmp_path / 'fit_result.fits'))
+    h = [x for x in hdus[1:] if x.header['EXTNAME'] == 'MODEL_LYALYA_QSO'][0]
+    assert h.header['bias_eta_LYA'] == vega.bestfit.as_dict()['bias_eta_LYA'] and h.header['ap'] == 1.05
     vega.close()

@@ -201,7 +201,7 @@ def test_monte_carlo_tables_round_trip_in_the_reference_layout(tmp_path):
     path = output.write_monte_carlo(analysis, tmp_path / 'monte_carlo', cpu_id=3)
     assert path.name == 'monte_carlo_3.fits' and path.stat().st_size % 2880 == 0
     hdul = fitslite.open(path)
-    assert [h.header.get('EXTNAME') for h in hdul[1:]] == ['Bestfit', 'FitInfo', 'Mocks']
+    assert [h.header.get('EXTNAME') for h in hdul[1:]] == ['BESTFIT', 'FITINFO', 'MOCKS']      # (upper case, as astropy stores hdu.name)
     best = hdul[1].data
     assert [s.strip() for s in best['names']] == names
     np.testing.assert_array_equal(best['values'], values.T)

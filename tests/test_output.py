@@ -38,7 +38,7 @@ def test_write_results_layout_and_hierarch_cards(tmp_path):
 
     hdus = fitslite.open(path)
     names = [h.header.get('EXTNAME') for h in hdus[1:]]
-    assert names == ['MODEL_' + n for n in prob.items] + ['BESTFIT', 'SCAN']
+    assert names == ['MODEL_' + n.upper() for n in prob.items] + ['BESTFIT', 'SCAN']       # (upper case, as astropy stores hdu.name)
     for i, (name, item) in enumerate(prob.items.items()):
         h = hdus[1 + i]
         n = item.dist_grid.size
@@ -87,3 +87,33 @@ def test_effective_data_size_counts_the_marginalised_modes():
     prob = load_problem('full4')
     for item in prob.items.values():
         assert item.num_marg_modes == 0 and item.effective_data_size == item.data_size
+
+
+def test_fit_results_reader_round_trip(tmp_path):
+    """vega/postprocess/fit_results.py:33-141 over the written file: correlation names from the (upper-case) HDU names,
+    columns matched without regard to case, `correlations` keyed by the lower-case name"""
+    from vega_amd.fit_results import FitResults
+    from vega_amd.output import Output
+    prob = load_problem('full4')
+    rng = np.random.default_rng(4)
+    models = {name: rng.standard_normal(item.dist_grid.size) for name, item in prob.items.items()}
+    stats = {name: {'masked_size': int(item.data_size), 'chisq': 1.5, 'reduced_chisq': 1e-3, 'p_value': 0.75,
+                    'bestfit_marg_coeff': np.array([2.0]) if name == 'lyalya_qso' else None}
+             for name, item in prob.items.items()}
+    out = Output({'filename': str(tmp_path / 'r.fits')}, prob.items)
+    out.write_results(models, {'ap': 1.0}, _Fit(), stats)
+    res = FitResults(tmp_path / 'r.fits')
+    assert res.chisq == 0.64 and res.valid is True and res.accurate is True and res.num_pars == 2
+    assert list(res.names) == _Fit.names and res.params['beta_LYA'] == 1.67 and res.sigmas['bias_eta_LYA'] == 0.01
+    np.testing.assert_array_equal(res.cov, _Fit.covariance[0])
+    assert list(res.correlations) == list(prob.items)
+    assert res.num_data_points == sum(item.data_size for item in prob.items.values())
+    assert res.reduced_chisq == 0.64 / (res.num_data_points - 2)
+    for name, item in prob.items.items():
+        c = res.correlations[name]
+        np.testing.assert_array_equal(c.model, models[name])
+        np.testing.assert_array_equal(c.model_mask, item.model_mask)
+        np.testing.assert_array_equal(c.data[c.data_mask], item.masked_data_vec)
+        assert (c.size, c.chisq, c.reduced_chisq, c.p_value) == (item.data_size, 1.5, 1e-3, 0.75)
+        np.testing.assert_array_equal(c.bestfit_marg_coeff, [2.0] if name == 'lyalya_qso' else [])
+    assert FitResults(tmp_path / 'r.fits', results_only=True).marg_coeff == {}

@@ -268,7 +268,7 @@ def write_tables(path, tables, overwrite=False):
                  _card('TFIELDS', len(names))]
         for i, (name, tform, _) in enumerate(columns, start=1):
             cards += [_card(f'TTYPE{i}', name), _card(f'TFORM{i}', tform)]
-        cards.append(_card('EXTNAME', extname))
+        cards.append(_card('EXTNAME', str(extname).upper()))          # (astropy stores hdu.name upper case)
         for key, value in extra.items():
             cards.append(_card(key, value))
         data = rec.tobytes()
