@@ -522,6 +522,10 @@ class VegaInterface:
         fit = self.bestfit
         values = {**self.params, **fit.as_dict(0)}
         self.bestfit_model = self.compute_model(values, run_init=False)
+        self.chisq = float(fit.fval[0])
+        if self.model_pk:           # (the models are P_ell(k) there: nothing to compare with the data bins)
+            self.bestfit_corr_stats = None
+            return
         self.total_data_size = 0
         self.bestfit_corr_stats = {}
         num_pars = len(self.sample_params['limits'])
