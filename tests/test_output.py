@@ -117,3 +117,20 @@ def test_fit_results_reader_round_trip(tmp_path):
         assert (c.size, c.chisq, c.reduced_chisq, c.p_value) == (item.data_size, 1.5, 1e-3, 0.75)
         np.testing.assert_array_equal(c.bestfit_marg_coeff, [2.0] if name == 'lyalya_qso' else [])
     assert FitResults(tmp_path / 'r.fits', results_only=True).marg_coeff == {}
+
+
+def test_output_write_monte_carlo_paths(tmp_path):
+    """reference vega/output.py:510-520: [output] mc_output, else monte_carlo/ next to the result file; one file per rank"""
+    from types import SimpleNamespace
+    from vega_amd import fitslite
+    from vega_amd.output import Output
+    prob = load_problem('full4')
+    analysis = SimpleNamespace(has_monte_carlo=True, mc_mocks={'global': np.arange(12.).reshape(3, 4)}, mc_bestfits=None)
+    out = Output({'filename': str(tmp_path / 'fits' / 'result.fits')}, prob.items, analysis)
+    path = out.write_monte_carlo(cpu_id=2)
+    assert path == tmp_path / 'fits' / 'monte_carlo' / 'monte_carlo_2.fits'
+    np.testing.assert_array_equal(fitslite.open(path)[1].data['global'], analysis.mc_mocks['global'])
+    out = Output({'filename': str(tmp_path / 'x.fits'), 'mc_output': str(tmp_path / 'elsewhere')}, prob.items, analysis)
+    assert out.write_monte_carlo() == tmp_path / 'elsewhere' / 'monte_carlo.fits'
+    with pytest.raises(ValueError):
+        Output({'filename': 'x'}, prob.items).write_monte_carlo()

@@ -24,7 +24,6 @@ def run_vega(config_path, search_dirs=(), print_func=print, **engine_args):
     params = dict(vega.params)
     if vega.minimizer is not None:
         params.update(vega.bestfit.as_dict(0))
-    vega.output.analysis = getattr(vega, 'analysis', None)
     vega.output.write_results(vega.bestfit_model if vega.bestfit_model is not None else vega.compute_model(params),
                               params, vega.minimizer, vega.bestfit_corr_stats, scan_results, vega.models)
     return vega

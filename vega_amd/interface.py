@@ -82,6 +82,7 @@ class VegaInterface:
                              and self.main_config['control'].getboolean('model_pk', False))
         self.monte_carlo = False
         self._mc_active = False
+        self._analysis = None
         self._engine_args = dict(max_batch=max_batch, device=device, extra_names=extra_names, kron_metals=kron_metals,
                                  csr_threshold=csr_threshold)
         # parameter-level blinding (reference vega_interface.py:123-127, :853-886): checked before anything is computed
@@ -107,6 +108,17 @@ class VegaInterface:
         self.bestfit = self.minimizer = None
         self.bestfit_model = self.bestfit_corr_stats = None
         self.chisq = self.reduced_chisq = self.p_value = self.total_data_size = None
+
+    @property
+    def analysis(self):
+        """The Monte-Carlo / scan driver (the reference's ``vega.analysis``); ``vega.output`` writes its results."""
+        return self._analysis
+
+    @analysis.setter
+    def analysis(self, driver):
+        self._analysis = driver
+        if getattr(self, 'output', None) is not None:
+            self.output.analysis = driver
 
     # ------------------------------------------------------------------ blinding
     def set_blinding_offsets(self, offsets):

@@ -183,3 +183,16 @@ class Output:
         Path(self.outfile).parent.mkdir(parents=True, exist_ok=True)
         fitslite.write_tables(self.outfile, tables, overwrite=self.overwrite)
         return self.outfile
+
+    def write_monte_carlo(self, cpu_id=None):
+        """``vega.output.write_monte_carlo(rank)`` of the reference's launchers (vega/output.py:442-520,
+        bin/run_vega_mc_mpi.py:67-71): `monte_carlo[_<rank>].fits` under ``[output] mc_output``, or under
+        ``monte_carlo/`` next to the fit's result file."""
+        if self.analysis is None:
+            raise ValueError('Output.write_monte_carlo requires an Analysis object')
+        if not getattr(self.analysis, 'has_monte_carlo', False):
+            raise ValueError('No Monte Carlo results found. Run Analysis.run_monte_carlo() first.')
+        if self.mc_output is None and self.outfile is None:
+            raise ValueError('[output] mc_output / filename are not set')
+        directory = Path(self.outfile).parent / 'monte_carlo' if self.mc_output is None else Path(self.mc_output)
+        return write_monte_carlo(self.analysis, directory, cpu_id=cpu_id, overwrite=self.overwrite)
