@@ -12,6 +12,25 @@ from vega_amd import VegaInterface, synthetic  # noqa: E402
 
 B = 256
 dev = torch.device('cuda', 0)
+if len(sys.argv) > 1 and sys.argv[1] == 'bits':
+    # chi2 of the same walkers on a common grid (fht_lowring = False) - run once with the default library and once with a
+    # -DVMX_EXP_NO_SAME_GRID build (VEGAMX_LIBRARY), the outputs must be equal bit for bit:
+    #   python scripts/gpu_same_grid.py bits > a; VEGAMX_LIBRARY=build_exp/nosame.so python scripts/gpu_same_grid.py bits > b; cmp a b
+    prob = bench.build_problem('joint')
+    for item in prob.items.values():
+        item.core.xi.fht_lowring = False
+    vega = VegaInterface(None, problem=prob, max_batch=B)
+    eng = vega.engine
+    theta = torch.from_numpy(synthetic.walkers(eng.low.theta0, eng.names, B, varied=bench.VARIED, seed=7)).to(dev)
+    out = torch.zeros(B, dtype=torch.float64, device=dev)
+    eng.eval_device(theta.data_ptr(), B, out.data_ptr())
+    eng.sync()
+    chi2_full, _, model = eng.eval(theta.cpu().numpy()[:16], want_model=True)
+    print(out.cpu().numpy().tobytes().hex())
+    print(chi2_full.tobytes().hex())
+    print(model.tobytes().hex()[:4096])
+    vega.close()
+    sys.exit(0)
 for lowring in (True, False, True, False):
     prob = bench.build_problem('joint')
     for item in prob.items.values():

@@ -1661,6 +1661,9 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
     D.same_grid = 1;
     for (int i = 1; i < VMX_MAX_ELL; ++i)
         if (e->op_set[i] && (!e->op_set[0] || D.x0[i] != D.x0[0] || D.inv_h[i] != D.inv_h[0] || D.xlast[i] != D.xlast[0])) D.same_grid = 0;
+#ifdef VMX_EXP_NO_SAME_GRID           // (experiment build: the per-multipole instances on a common grid - scripts/gpu_same_grid.py checks the bits)
+    D.same_grid = 0;
+#endif
     D.n_pipe = n_pipe; D.pipes = e->d_pipes.p;
     D.n_active = e->n_active; D.n_static = (int)e->pk_static.size();
     if (!e->pk_static.empty() && e->poly_coef.alloc((size_t)VMX_MAX_ELL * e->pk_static.size() * 3 * e->ncp, true)) return -2;
