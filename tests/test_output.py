@@ -134,3 +134,16 @@ def test_output_write_monte_carlo_paths(tmp_path):
     assert out.write_monte_carlo() == tmp_path / 'elsewhere' / 'monte_carlo.fits'
     with pytest.raises(ValueError):
         Output({'filename': 'x'}, prob.items).write_monte_carlo()
+
+
+def test_marginalised_modes_reduce_the_effective_data_size(tmp_path):
+    """reference vega/data.py:816-825, :134: the modes the SVD of the masked, prior-scaled templates keeps"""
+    from conftest import marginalization_problem, MARGINALIZATION_CASES
+    prob = marginalization_problem(tmp_path, MARGINALIZATION_CASES['rtmax'])
+    item = prob.items['lyalya_lyalya']
+    tm = item.marg_templates[item.model_mask, :]
+    tm = tm.toarray() if hasattr(tm, 'toarray') else np.asarray(tm)
+    sv = np.linalg.svd(tm * 5.0, compute_uv=False)
+    modes = int((sv > 1e-8 * sv[0]).sum())
+    assert 0 < modes <= tm.shape[1] and item.num_marg_modes == modes
+    assert item.effective_data_size == item.data_size - modes

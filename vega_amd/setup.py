@@ -696,17 +696,22 @@ def marginalization_scale_mask(grid, cuts, marg):
     return mask
 
 
-def marginalization_cov_update(distortion, model_grid, dist_grid, cuts, marg, model_mask, prior_sigma=10.0,
-                               match_data_bins=False, factor=1e-8):
-    """A A^T of the distorted, masked, prior-scaled templates with degenerate modes removed by an SVD
-    (reference vega/data.py:762-828): the matrix added to the masked block of the covariance."""
+def marginalization_modes(distortion, model_grid, dist_grid, cuts, marg, model_mask, prior_sigma=10.0,
+                          match_data_bins=False, factor=1e-8):
+    """(A A^T, number of modes) of the distorted, masked, prior-scaled templates with degenerate modes removed by an SVD
+    (reference vega/data.py:762-828): the matrix added to the masked block of the covariance, and the count the reference
+    keeps as ``Data.num_marg_modes`` (:825) for the effective data size."""
     templates = distortion.dot(marginalization_templates(model_grid, dist_grid, cuts, marg, match_data_bins))
     t = (templates * prior_sigma)[model_mask, :].toarray()
     u, sv, _ = np.linalg.svd(t, full_matrices=False)
     w = sv > factor * sv[0]
     u, sv = u[:, w], sv[w]
-    marginalization_cov_update.last_modes = int(w.sum())       # the reference's Data.num_marg_modes (data.py:825)
-    return np.dot(u * sv**2, u.T)
+    return np.dot(u * sv**2, u.T), int(w.sum())
+
+
+def marginalization_cov_update(*args, **kw):
+    """The covariance update alone (see :func:`marginalization_modes`)."""
+    return marginalization_modes(*args, **kw)[0]
 
 
 # --------------------------------------------------------------------------------------
@@ -835,8 +840,8 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
         if not (fit_marg_scales and match_bins):
             A = A + np.diag(np.full(marg_templates.shape[1], prior_sigma**-2))
         marg_diff2coeff = np.linalg.inv(A).dot(G)
-        update = marginalization_cov_update(distortion, model_grid, dist_grid, cuts, marg, model_mask,
-                                            prior_sigma=prior_sigma, match_data_bins=match_bins)
+        update, num_marg_modes = marginalization_modes(distortion, model_grid, dist_grid, cuts, marg, model_mask,
+                                                       prior_sigma=prior_sigma, match_data_bins=match_bins)
         if not marginalize_in_fit:
             cov[np.ix_(data_mask, data_mask)] += update
 
@@ -992,7 +997,7 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     if marg:
         item.marg_templates, item.marg_diff2coeff = marg_templates, marg_diff2coeff
         item.marginalize_in_fit = bool(marginalize_in_fit)
-        item.num_marg_modes = marginalization_cov_update.last_modes
+        item.num_marg_modes = num_marg_modes
     item.blind, item.blinding_strat = blind, (blinding if blind else None)
     item.variance, item.nb = variance, nb
     item.cov_rescale = rescale
