@@ -1214,6 +1214,33 @@ def dump_fit_stats(VegaInterface):
           {n: vega.bestfit_corr_stats[n]['chisq'] for n in vega.bestfit_corr_stats})
 
 
+SENSITIVITY_NOMINAL = {'bias_eta_LYA': (-0.2, 0.004), 'ap': (1.04, 0.02), 'sigmaNL_par': (6.4, 0.5), 'drp_QSO': (0.2, 0.1)}
+
+
+def dump_sensitivity(VegaInterface):
+    """`VegaInterface.compute_sensitivity` (vega/vega_interface.py:956-1075) of the unmodified reference on its own test
+    configuration: the partial derivatives of the four parts of every correlation (final and raw, peak and smooth) and the
+    Fisher information per bin of every parameter pair, at SENSITIVITY_NOMINAL."""
+    os.chdir(REF / 'tests')
+    # (the auto + cross items WITHOUT their metal terms = tests/golden/configs/joint: with metals the reference's own function
+    # stops at `assert not fast_metals` in Metals.compute_metal_corr_slow, vega/metals.py:242, unless fast_metal_bias is off)
+    with tempfile.TemporaryDirectory() as tmp:
+        vega = VegaInterface(_ref_main(tmp, ['lyalya_lyalya', 'lyalya_qso'], False))
+        vega.compute_sensitivity(nominal=dict(SENSITIVITY_NOMINAL), frac=0.1, verbose=False)
+    sens = vega.sensitivity
+    out = {'names': np.array(list(vega.corr_items)), 'params': np.array(list(SENSITIVITY_NOMINAL)),
+           'nominal': np.array([SENSITIVITY_NOMINAL[p] for p in SENSITIVITY_NOMINAL])}
+    for name in vega.corr_items:
+        for pname, arr in sens['partials'][name].items():
+            out[f'partials/{name}/{pname}'] = arr
+        for (p1, p2), arr in sens['fisher'][name].items():
+            if 'ap' in (p1, p2):            # (the others follow from the partials the same way: kept out of the fixture for its size)
+                out[f'fisher/{name}/{p1}/{p2}'] = arr
+        out[f'fisher_keys/{name}'] = np.array(['/'.join(k) for k in sens['fisher'][name]])
+    np.savez_compressed(HERE / 'expected_sensitivity.npz', **out)
+    print('sensitivity:', {k: float(np.nansum(v)) for k, v in out.items() if k.startswith('fisher/lyalya_lyalya/')})
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -1221,12 +1248,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1281,3 +1308,5 @@ if __name__ == '__main__':
         dump_fht_extrap(VI)
     if 'fit_stats' in what:
         dump_fit_stats(VI)
+    if 'sensitivity' in what:
+        dump_sensitivity(VI)

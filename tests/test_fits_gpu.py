@@ -190,3 +190,39 @@ def test_bestfit_statistics_and_result_file_against_the_reference(tmp_path):
     h = [x for x in hdus[1:] if x.header['EXTNAME'] == 'MODEL_LYALYA_QSO'][0]
     assert h.header['bias_eta_LYA'] == vega.bestfit.as_dict()['bias_eta_LYA'] and h.header['ap'] == 1.05
     vega.close()
+
+
+def test_compute_sensitivity_against_the_reference():
+    """`VegaInterface.compute_sensitivity` (reference vega/vega_interface.py:956-1075; fixture: make_golden.dump_sensitivity, the
+    unmodified reference on the auto + cross items): central differences of the four parts of every correlation - the final
+    and the raw core model of the peak and of the smooth component - and the Fisher information per bin.  Here the 2 P points
+    go through the engine in batches, the components' final models come from the model's being affine in bao_amp, the raw ones from the
+    per-pipeline stage taps.  (Differences of 1e-15-accurate models over a step of 0.1 sigma: compared at 1e-9 of the largest
+    entry of each array.)"""
+    from vega_amd import VegaInterface
+    exp = np.load(GOLDEN / 'expected_sensitivity.npz')
+    nominal = {str(p): (float(v), float(e)) for p, (v, e) in zip(exp['params'], exp['nominal'])}
+    vega = VegaInterface(None, problem=load_problem('joint'), max_batch=64)
+    lines = []
+    sens = vega.compute_sensitivity(nominal=nominal, frac=0.1, print_func=lines.append)
+    assert sens is vega.sensitivity and sens['nominal'] == nominal and len(lines) == len(nominal) + 1
+    for name in (str(n) for n in exp['names']):
+        assert list(sens['partials'][name]) == list(nominal)
+        for pname in nominal:
+            ref = exp[f'partials/{name}/{pname}']
+            got = sens['partials'][name][pname]
+            assert got.shape == ref.shape == (2, 2, vega.problem.items[name].model_grid.size)
+            for i in range(2):
+                for j in range(2):
+                    np.testing.assert_allclose(got[i, j], ref[i, j], rtol=0, atol=1e-9 * max(np.abs(ref[i, j]).max(), 1e-300))
+        assert ['/'.join(k) for k in sens['fisher'][name]] == [str(k) for k in exp[f'fisher_keys/{name}']]
+        mask = vega.problem.items[name].data_mask
+        for key, got in sens['fisher'][name].items():
+            if 'ap' not in key:
+                continue
+            ref = exp[f'fisher/{name}/{key[0]}/{key[1]}']
+            assert np.isnan(got[:, ~mask]).all() and np.isnan(ref[:, ~mask]).all()
+            np.testing.assert_allclose(got[:, mask], ref[:, mask], rtol=0, atol=1e-8 * max(np.abs(ref[:, mask]).max(), 1e-300))
+    # the auto-correlation does not know the quasar parameter: exact zeros there, as in the reference
+    assert not sens['partials']['lyalya_lyalya']['drp_QSO'].any() and exp['partials/lyalya_lyalya/drp_QSO'].any() == False  # noqa: E712
+    vega.close()

@@ -575,6 +575,81 @@ class VegaInterface:
             if not bool(fit.is_valid[0]):
                 print_func('Invalid fit!!! Check data, covariance, model and priors.')
 
+    def compute_sensitivity(self, nominal=None, frac=0.1, verbose=True, print_func=print):
+        """Sensitivity of the model to the floating parameters (reference VegaInterface.compute_sensitivity,
+        vega/vega_interface.py:956-1075): central differences at value +- frac * error of the four parts of every
+        correlation - [0, 0] bao_amp x the peak component's final model, [0, 1] the smooth component's, [1, 0] bao_amp x the
+        raw core correlation of the peak spectrum, [1, 1] that of the smooth one - and the Fisher information per bin of every
+        parameter pair, distorted and not; kept in ``self.sensitivity`` (keys `nominal`, `partials`, `fisher`).
+
+        All 2 P parameter points go through the engine in batches of eight, each twice: the model is affine in ``bao_amp``
+        (model = bao_amp * peak + smooth, reference vega/model.py:157-187), so the two components' final models are
+        model(bao_amp = 1) - model(bao_amp = 0) and model(bao_amp = 0); the raw core correlations are the per-pipeline bins of
+        the same evaluation (the stage taps).  ``nominal``: {name: (value, error)}; default: the last fit's."""
+        from .engine import Engine
+        if nominal is None:
+            if self.bestfit is None:
+                raise RuntimeError('No nominal parameter values provided or saved by minimize()')
+            nominal = {n: (float(v), float(e)) for n, v, e in zip(self.bestfit.names, self.bestfit.values[0], self.bestfit.errors[0])}
+        if self.model_pk or not isinstance(self.engine, Engine):
+            raise NotImplementedError('compute_sensitivity: one engine, correlation-function models')
+        eng = self.engine
+        self.freeze_metals()
+        params = copy.deepcopy(self.params)
+        for pname, (pvalue, _) in nominal.items():
+            params[pname] = pvalue
+        bao_amp = self.params['bao_amp']
+        rows = []
+        for pname, (pvalue, perror) in nominal.items():
+            for sign in (+1, -1):
+                for bao in (0., 1.):
+                    rows.append({**params, pname: pvalue + sign * frac * perror, 'bao_amp': bao})
+        theta = self.theta_matrix(rows)
+        self._check_pinned(theta)
+        sizes = {name: item.model_grid.size for name, item in self.problem.items.items()}
+        model = np.empty((len(rows), eng.model_size))
+        raw = {(name, comp): np.empty((len(rows), sizes[name])) for name in sizes for comp in ('peak', 'smooth')}
+        chunk = min(8, eng.max_batch)       # (up to 8 walkers the engine keeps the per-pipeline bins of a model evaluation: the stage taps)
+        for lo in range(0, len(rows), chunk):
+            hi = min(lo + chunk, len(rows))
+            _, status, model[lo:hi] = eng.eval(theta[lo:hi], want_model=True)
+            if status.any():
+                from .errors import VegaModelError
+                raise VegaModelError(f'model evaluation failed (status {int(status[status != 0][0])})')
+            for (name, comp), out in raw.items():
+                n_pad = (sizes[name] + 31) // 32 * 32
+                out[lo:hi] = eng.debug_read(1, eng.pipe_index[(name, comp)], (hi - lo) * n_pad).reshape(hi - lo, n_pad)[:, :sizes[name]]
+        self.sensitivity = dict(nominal=copy.deepcopy(nominal), partials={n: {} for n in sizes}, fisher={n: {} for n in sizes})
+        for pindex, (pname, (pvalue, perror)) in enumerate(nominal.items()):
+            if verbose:
+                print_func(f'Calculating sensitivity for [{pindex}] {pname} at {pvalue:.4f} ± {perror:.4f}')
+            delta = frac * perror
+            plus0, plus1, minus0, minus1 = (4 * pindex + i for i in range(4))       # (+, bao 0), (+, bao 1), (-, bao 0), (-, bao 1)
+            for name, sl in eng.model_slices.items():
+                dist = model[:, sl]
+                if dist.shape[1] != sizes[name]:
+                    raise ValueError(f'{name}: the distorted and the model grids differ in size (the reference adds both into one array)')
+                part = np.zeros((2, 2, sizes[name]))
+                part[0, 0] = bao_amp * ((dist[plus1] - dist[plus0]) - (dist[minus1] - dist[minus0]))
+                part[0, 1] = dist[plus0] - dist[minus0]
+                part[1, 0] = bao_amp * (raw[(name, 'peak')][plus1] - raw[(name, 'peak')][minus1])
+                part[1, 1] = raw[(name, 'smooth')][plus1] - raw[(name, 'smooth')][minus1]
+                self.sensitivity['partials'][name][pname] = part / (2 * delta)
+        if verbose:
+            print_func('Computing Fisher information for each pair of parameters...')
+        names = list(nominal)
+        for i1, p1 in enumerate(names):
+            for p2 in names[i1:]:
+                for name, item in self.problem.items.items():
+                    mask = item.data_mask
+                    fisher = np.full((2, sizes[name]), np.nan)
+                    for idistort in range(2):
+                        d1 = self.sensitivity['partials'][name][p1][idistort].sum(axis=0)
+                        d2 = self.sensitivity['partials'][name][p2][idistort].sum(axis=0)
+                        fisher[idistort, mask] = d1[mask] * item.inv_masked_cov.dot(d2[mask])
+                    self.sensitivity['fisher'][name][(p1, p2)] = fisher
+        return self.sensitivity
+
     def chi2_scan(self, method='migrad'):
         """``[chi2 scan]`` of the reference (vega/analysis.py:53-122; ``vega.analysis.chi2_scan()`` there): every grid point's
         fit in lock-step - see :meth:`vega_amd.montecarlo.MonteCarlo.chi2_scan`."""
