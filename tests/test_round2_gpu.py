@@ -109,6 +109,10 @@ def test_marginalisation_coefficients_through_the_public_surface(tmp_path, mode)
     assert chi2 == pytest.approx(float(exp[f'{mode}/fid/chi2']), rel=CHI2_RTOL)
     assert set(coeff) == {name}
     close(coeff[name], exp[f'{mode}/fid/coeff'])
+    # ... and the public form on a model the caller holds (reference compute_marg_coeff, vega_interface.py:546-579)
+    held = vega.compute_marg_coeff(vega.compute_model())
+    assert set(held) == {name} and vega.corr_num_marg_modes == {name: vega.problem.items[name].num_marg_modes}
+    np.testing.assert_allclose(held[name], coeff[name], rtol=0, atol=1e-10 * np.abs(coeff[name]).max())
     # the reference's PolyChord closure (vega/samplers/polychord.py:106-113)
     names = list(prob.sample_params['limits'])
 

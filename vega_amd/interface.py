@@ -324,6 +324,36 @@ class VegaInterface:
             self.__dict__.setdefault('_template_cache', {})[name] = dense
         return self.engine.matmul_host(dense, coeff)
 
+    @property
+    def mc_config(self):
+        """The ``[monte carlo]`` set-up ({'params', 'sample'}) or None (reference vega_interface.py:140-150)."""
+        return self.problem.mc_config
+
+    @property
+    def corr_num_marg_modes(self):
+        """Modes the small-scale marginalisation removes, per correlation (reference vega_interface.py:181-184)."""
+        return {name: item.num_marg_modes for name, item in self.problem.items.items()}
+
+    def compute_marg_coeff(self, model_cf):
+        """Best-fit coefficients of the marginalisation templates for given models (reference
+        VegaInterface.compute_marg_coeff, vega/vega_interface.py:546-579): per correlation that has templates, the static
+        map `marg_diff2coeff` applied to the residual of the data - or of the installed Monte-Carlo mock - against the model
+        on the fitted bins.  (A host product on a model the caller already holds; inside chi2 / log_lik the engine forms the
+        coefficients itself: ``return_marg_coeff=True``.)"""
+        out = {}
+        for name, item in self.problem.items.items():
+            if item.marg_diff2coeff is None:
+                continue
+            data = self.data[name].masked_mc_mock if self.monte_carlo else item.masked_data_vec
+            out[name] = np.asarray(item.marg_diff2coeff.dot(np.asarray(data) - np.asarray(model_cf[name])[item.model_mask]))
+        return out
+
+    def set_fast_metals(self):
+        """`fast_metals` is a property of the lowered problem here ([model] fast_metals, frozen at the first evaluation:
+        :meth:`freeze_metals`); the reference's switch (vega/vega_interface.py:657-664, not called by its own drivers any
+        more, :588) has nothing to flip afterwards."""
+        self.freeze_metals()
+
     def _marg_coeff(self, B):
         """dict name -> [B, n_templates] for the items with marginalisation templates, from the residuals of the
         evaluation that has just run (reference vega_interface.py:546-579: per item, ignoring a global covariance)."""
