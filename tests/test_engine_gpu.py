@@ -534,6 +534,21 @@ def test_rescaled_covariance_with_marginalize_in_fit_through_the_engine(tmp_path
     vega = VegaInterface(None, problem=prob, max_batch=4)
     plain = vega.chi2()
     view = vega.data['lyalya_lyalya']
+    # the reference's own call sequence (make_golden.dump_marg_mc): np.random.seed(23), then
+    # analysis.create_monte_carlo_sim(fid, seed=None, scale=4.0) - the generator state goes on, the mock and its scaled inverse
+    # covariance are installed on the data object
+    from vega_amd.montecarlo import MonteCarlo
+    fid = vega.compute_model(run_init=False)
+    np.random.seed(23)
+    vega.analysis = MonteCarlo(vega)
+    full = vega.analysis.create_monte_carlo_sim(fid, seed=None, scale=4.0)['lyalya_lyalya']
+    mask = prob.items['lyalya_lyalya'].data_mask
+    assert np.isnan(full[~mask]).all() and np.array_equal(full[mask], view.masked_mc_mock)
+    np.testing.assert_allclose(view.masked_mc_mock, exp['mock'], rtol=0, atol=1e-9 * np.abs(exp['mock']).max())
+    np.testing.assert_allclose(view.scaled_inv_masked_cov, view.inv_masked_cov / 4.0, rtol=1e-15)
+    vega.monte_carlo = True
+    assert vega.chi2() == pytest.approx(float(exp['fid/chi2']), rel=1e-6)
+    vega.monte_carlo = False
     view.masked_mc_mock = exp['mock']
     view.scaled_inv_masked_cov = view.inv_masked_cov / float(exp['scale'])
     vega.monte_carlo = True

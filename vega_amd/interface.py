@@ -744,7 +744,7 @@ class VegaInterface:
         reads (reference VegaInterface.initialize_monte_carlo, vega/vega_interface.py:505-544).  The ONLY place that
         reads ``[control] global_cov_rescale`` (:531-533) - ``run_monte_carlo`` passes its scale through unchanged, as
         ``Analysis.run_monte_carlo`` -> ``create_global_monte_carlo(scale=None)`` does."""
-        from .montecarlo import MonteCarlo, item_scales
+        from .montecarlo import MonteCarlo
         self.freeze_metals()
         fiducial_model = self.get_fiducial_for_monte_carlo(print_func)
         control = self.main_config['control']
@@ -757,19 +757,7 @@ class VegaInterface:
         self.analysis = MonteCarlo(self)
         mocks = self.analysis.create_mocks(fiducial_model, 1, seed=seed, scale=scale, forecast=forecast,
                                            reseed_per_item=True)
-        out = {}
-        scales = item_scales(self.problem, scale)
-        for name, pool in mocks.items():
-            view, item = self.data[name], self.problem.items[name]
-            view.masked_mc_mock = np.array(pool[0])
-            if not self._use_global_cov and item.cov is not None and scales[name] != 1.:
-                # reference data.py:717-719: the mock's covariance scale carries over to the fit (its log-determinant
-                # term as the reference writes it: log(scale) + log det C)
-                view.scaled_inv_masked_cov = item.inv_masked_cov / scales[name]      # (marginalize-in-fit: projected when it is sent)
-                view.scaled_log_cov_det = np.log(scales[name]) + item.log_cov_det
-            full = np.full(item.data_vec.size, np.nan)
-            full[item.data_mask] = pool[0]
-            out[name] = full
+        out = self.analysis.install_mocks(mocks, scale)
         self.monte_carlo = True
         return out
 

@@ -66,7 +66,8 @@ def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecas
         raise ValueError('this problem has a global covariance: its mocks come from create_global_mocks')
     scales = item_scales(problem, scale)
     matmul = matmul or _default_matmul
-    np.random.seed(seed)
+    if seed is not None:            # (None: the caller's generator state goes on, reference data.py:735-736)
+        np.random.seed(seed)
     chol, fid = {}, {}
     for name, item in problem.items.items():
         fid[name] = _fiducial_on_data_grid(item, fiducial_model[name])
@@ -87,7 +88,7 @@ def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecas
     draws = {name: np.empty((num_mocks, chol[name].shape[0])) for name in problem.items}
     for i in range(num_mocks):
         for name in problem.items:
-            if reseed_per_item:
+            if reseed_per_item and seed is not None:
                 np.random.seed(seed)
             draws[name][i] = np.random.randn(chol[name].shape[0])
     out = {}
@@ -108,7 +109,8 @@ def create_global_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, 
     if gm is None:
         raise ValueError('create_global_mocks requires a global covariance matrix')
     matmul = matmul or _default_matmul
-    np.random.seed(seed)
+    if seed is not None:
+        np.random.seed(seed)
     mask = gm['data_mask']
     fid = np.concatenate([_fiducial_on_data_grid(item, fiducial_model[name])
                           for name, item in problem.items.items()])[mask]
@@ -242,6 +244,47 @@ class MonteCarlo:
                              matmul=vega.engine.matmul_host, reseed_per_item=reseed_per_item)
         self.mc_mocks = mocks
         return mocks
+
+    def install_mocks(self, mocks, scale=None):
+        """Make row 0 of every correlation's mocks the data the following chi2 / fits read in Monte-Carlo mode - what
+        ``Data.create_monte_carlo`` leaves on the reference's Data objects (vega/data.py:711-722, :749-759): ``masked_mc_mock``
+        and, for a rescaled covariance, ``scaled_inv_masked_cov`` / ``scaled_log_cov_det``.  Returns the mocks on the full data
+        grids (NaN outside the masks)."""
+        vega = self.vega
+        scales = item_scales(vega.problem, scale)
+        out = {}
+        for name, pool in mocks.items():
+            view, item = vega.data[name], vega.problem.items[name]
+            view.masked_mc_mock = np.array(pool[0])
+            if not vega._use_global_cov and item.cov is not None and scales[name] != 1.:
+                # reference data.py:717-719: the mock's covariance scale carries over to the fit (its log-determinant
+                # term as the reference writes it: log(scale) + log det C)
+                view.scaled_inv_masked_cov = item.inv_masked_cov / scales[name]      # (marginalize-in-fit: projected when it is sent)
+                view.scaled_log_cov_det = np.log(scales[name]) + item.log_cov_det
+            full = np.full(item.data_vec.size, np.nan)
+            full[item.data_mask] = pool[0]
+            out[name] = full
+        return out
+
+    def create_monte_carlo_sim(self, fiducial_model, seed=None, scale=None, forecast=False):
+        """One mock per correlation, installed as its Monte-Carlo data (reference Analysis.create_monte_carlo_sim,
+        vega/analysis.py:126-162 -> Data.create_monte_carlo, vega/data.py:689-760): every correlation's draw starts from
+        ``seed``; ``seed=None`` goes on with the caller's generator state.  dict name -> mock on the full data grid."""
+        vega = self.vega
+        mocks = create_mocks(vega.problem, fiducial_model, 1, seed=seed, scale=scale, forecast=forecast,
+                             matmul=vega.engine.matmul_host, reseed_per_item=True)
+        self.mc_mocks = mocks
+        return self.install_mocks(mocks, scale)
+
+    def create_global_monte_carlo(self, fiducial_model, seed=None, scale=None, forecast=False):
+        """One mock of the global masked data vector from the global covariance, kept as ``current_mc_mock`` (reference
+        Analysis.create_global_monte_carlo, vega/analysis.py:164-222); returned."""
+        vega = self.vega
+        whole = create_global_mocks(vega.problem, fiducial_model, 1, seed=seed, scale=scale, forecast=forecast,
+                                    matmul=vega.engine.matmul_host)
+        self.mc_mocks = {'global': whole}
+        self.current_mc_mock = whole[-1]
+        return self.current_mc_mock
 
     def run_monte_carlo(self, fiducial_model, num_mocks=1, seed=0, scale=None, forecast=False,
                         run_mc_fits=True, sample_params=None, method='migrad'):
