@@ -175,6 +175,11 @@ def test_bestfit_statistics_and_result_file_against_the_reference(tmp_path):
         ref = exp[f'model/{name}']
         np.testing.assert_allclose(vega.bestfit_model[name], ref, rtol=0, atol=1e-8 * np.abs(ref).max())
     assert any(line.startswith('Total chi^2/(ndata-nparam): 0.6/(9540-2)') for line in lines)
+    # vega.minimizer under the reference's names (vega/minimizer.py:105-187), as run_vega and user scripts read it
+    m = vega.minimizer
+    assert m.fit is vega.bestfit and list(m.values) == [str(n) for n in exp['fit/names']]
+    assert m.values == vega.bestfit.as_dict() and isclose(m.fmin.fval, 0.6409716347033996) and m.fmin.is_valid and m.minuit.valid
+    assert m.covariance.shape == (2, 2) and m.errors['beta_LYA'] == vega.bestfit.errors[0, 1] and m.params[0].name == 'bias_eta_LYA'
 
     from vega_amd.fit_results import FitResults
     res = FitResults(tmp_path / 'fit_result.fits')

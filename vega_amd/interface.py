@@ -550,7 +550,9 @@ class VegaInterface:
                 sample[key].update({n: v for n, v in params[key].items() if n in sample['limits']})
         driver = MonteCarlo(self)
         fitter = driver.minimizer(sample, tol=tol, method=method)
-        self.bestfit = self.minimizer = fitter.minimize(n_fits=1, fixed=driver._fixed)
+        from .minimizer import MinimizerView
+        self.bestfit = fitter.minimize(n_fits=1, fixed=driver._fixed)
+        self.minimizer = MinimizerView(self.bestfit)        # (the reference's names: minimizer.values[par], .fmin.fval, .minuit.valid)
         self._bestfit_statistics()
         return self.bestfit
 

@@ -91,6 +91,27 @@ class FitResult:
         return {n: float(v) for n, v in zip(self.names, self.values[i])}
 
 
+class MinimizerView:
+    """One fit of a :class:`FitResult` behind the attribute names of the reference's ``Minimizer`` after ``minimize()``
+    (vega/minimizer.py:105-187: ``values`` / ``errors`` dictionaries, ``covariance``, ``fmin``, ``minuit``, ``params``) -
+    what ``run_vega``, ``Output`` and user scripts read from ``vega.minimizer``.  ``fit`` is the FitResult itself."""
+
+    def __init__(self, fit, index=0):
+        from types import SimpleNamespace
+        self.fit, self.index = fit, index
+        i = index
+        accurate = getattr(fit, 'has_accurate_covar', None)
+        accurate = bool(accurate[i]) if accurate is not None else not bool(fit.hesse_failed[i])
+        self.values = {n: float(v) for n, v in zip(fit.names, fit.values[i])}
+        self.errors = {n: float(v) for n, v in zip(fit.names, fit.errors[i])}
+        self.covariance = np.array(fit.covariance[i])
+        self.fmin = SimpleNamespace(fval=float(fit.fval[i]), edm=float(fit.edm[i]), is_valid=bool(fit.is_valid[i]),
+                                    hesse_failed=bool(fit.hesse_failed[i]), has_accurate_covar=accurate,
+                                    nfcn=int(fit.nfcn[i]))
+        self.minuit = SimpleNamespace(valid=bool(fit.is_valid[i]), accurate=accurate, fval=float(fit.fval[i]))
+        self.params = [SimpleNamespace(name=n, value=self.values[n], error=self.errors[n]) for n in fit.names]
+
+
 class BatchedMinimizer:
     """Minimise chi2 over the sampled parameters for many data realisations at once.
 

@@ -161,7 +161,7 @@ class Output:
         self.mc_output = get('mc_output', None)
 
     def write_results(self, corr_funcs, params, minimizer=None, bestfit_corr_stats=None, scan_results=None, models=None):
-        """``minimizer``: a `minimizer.FitResult` (fit 0 is written) or None."""
+        """``minimizer``: ``vega.minimizer`` / a `minimizer.FitResult` (fit 0 is written) or None."""
         if self.type not in ('fits',):
             raise NotImplementedError(f'output type {self.type!r}: only the fits flavour is written')
         if self.output_cf or self.output_pk:
@@ -169,6 +169,7 @@ class Output:
         if self.outfile is None:
             raise ValueError('[output] filename is not set')
         tables = model_tables(self.items, corr_funcs, params, bestfit_corr_stats)
+        minimizer = getattr(minimizer, 'fit', minimizer)         # (vega.minimizer: a MinimizerView of the FitResult)
         if minimizer is not None:
             accurate = getattr(minimizer, 'has_accurate_covar', None)
             tables.append(bestfit_table(minimizer.names, minimizer.values[0], minimizer.errors[0], minimizer.covariance[0],
