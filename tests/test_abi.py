@@ -53,3 +53,32 @@ def test_product_never_imports_the_oracle():
         assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), path
     for path in (REPO / 'vega_amd' / 'csrc').iterdir():
         assert 'oracle' not in path.read_text().lower(), path
+
+
+def test_reference_python_surface_is_present():
+    """The names a user of the reference calls on this path (reference vega/vega_interface.py: public methods and the
+    attributes `minimize` leaves; vega/analysis.py; vega/output.py; vega/minimizer.py:105-187; vega/scripts/run_vega.py) exist
+    on their stand-ins.  Class-level: no engine, no GPU.  Not mirrored, by scope: `plots`, `sampler` / `run_sampler`,
+    `read_global_cov` (ingestion happens in vega_amd/setup.py), hdf output."""
+    import vega_amd
+    from vega_amd.interface import VegaInterface
+    from vega_amd.minimizer import MinimizerView
+    from vega_amd.montecarlo import MonteCarlo
+    from vega_amd.output import Output
+    for name in ('compute_model', 'chi2', 'log_lik', 'compute_prior_chi2', 'compute_marg_coeff', 'minimize',
+                 'get_fiducial_for_monte_carlo', 'initialize_monte_carlo', 'set_fast_metals', 'compute_sensitivity',
+                 'mc_config', 'corr_num_marg_modes', 'analysis'):
+        assert hasattr(VegaInterface, name), name
+    for name in ('chi2_scan', 'create_monte_carlo_sim', 'create_global_monte_carlo', 'run_monte_carlo'):
+        assert callable(getattr(MonteCarlo, name)), name
+    for name in ('write_results', 'write_monte_carlo'):
+        assert callable(getattr(Output, name)), name
+    assert callable(vega_amd.run_vega)
+    import numpy as np
+    from vega_amd.minimizer import FitResult
+    fit = FitResult(names=['a'], values=np.ones((1, 1)), errors=np.ones((1, 1)), covariance=np.ones((1, 1, 1)), fval=np.ones(1),
+                    edm=np.zeros(1), is_valid=np.array([True]), hesse_failed=np.array([False]), nfcn=np.array([3]), n_iter=np.array([1]))
+    view = MinimizerView(fit)
+    assert view.values == {'a': 1.0} and view.errors == {'a': 1.0} and view.covariance.shape == (1, 1)
+    assert view.fmin.fval == 1.0 and view.fmin.is_valid and not view.fmin.hesse_failed and view.minuit.valid and view.minuit.accurate
+    assert view.params[0].name == 'a' and view.fit is fit
