@@ -98,6 +98,15 @@ def test_minimize_scan_and_monte_carlo_against_the_references_drivers(tmp_path):
     assert (np.abs(bestfits[:, :, 0] - exp['mc/bestfits'][:, :, 0]) <= 2e-3 * exp['mc/bestfits'][:, :, 1]).all()
     np.testing.assert_allclose(bestfits[:, :, 1], exp['mc/bestfits'][:, :, 1], rtol=5e-3)
     np.testing.assert_allclose(mc.mc_chisq, exp['mc/chisq'], rtol=1e-7)
+    # the launchers' last line: vega.output.write_monte_carlo(rank) (reference bin/run_vega_mc_mpi.py:67-71, output.py:510-520)
+    from vega_amd import fitslite
+    assert vega.output.analysis is mc
+    vega.output.outfile, vega.output.overwrite = str(tmp_path / 'results' / 'fit.fits'), True
+    path = vega.output.write_monte_carlo(cpu_id=3)
+    assert path == tmp_path / 'results' / 'monte_carlo' / 'monte_carlo_3.fits'
+    tabs = {h.header['EXTNAME']: h for h in fitslite.open(path)[1:]}
+    assert set(tabs) == {'BESTFIT', 'FITINFO', 'MOCKS'} and list(tabs['FITINFO'].data['valid_minima']) == [True, True]
+    np.testing.assert_array_equal(np.asarray(tabs['FITINFO'].data['chisq']), mc.mc_chisq)
     vega.close()
 
 
