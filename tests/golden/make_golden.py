@@ -1241,6 +1241,27 @@ def dump_sensitivity(VegaInterface):
     print('sensitivity:', {k: float(np.nansum(v)) for k, v in out.items() if k.startswith('fisher/lyalya_lyalya/')})
 
 
+def dump_components(VegaInterface):
+    """The saved components of the reference's models (`save-components`, vega/model.py:41-45, :113-115, :151-153) on the
+    auto + cross items without metal terms, at one walker: the raw core correlations of the peak / smooth spectrum and the
+    components' final (distorted) models - what `write_cf` puts into the Xi_<name> HDUs (vega/output.py:375-440)."""
+    os.chdir(REF / 'tests')
+    with tempfile.TemporaryDirectory() as tmp:
+        vega = VegaInterface(_ref_main(tmp, ['lyalya_lyalya', 'lyalya_qso'], False))
+        names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 29)
+        vega.fiducial['save-components'] = True
+        full = vega.compute_model(walkers[0], run_init=True)
+        out = {'names': np.array(list(vega.corr_items)), 'param_names': np.array(names),
+               'theta': np.array([[walkers[0][n] for n in names]])}
+        for name, model in vega.models.items():
+            out[f'model/{name}'] = np.array(full[name])
+            for part in ('peak', 'smooth'):
+                out[f'xi/{name}/{part}'] = np.array(model.xi[part]['core'])
+                out[f'xi_distorted/{name}/{part}'] = np.array(model.xi_distorted[part]['core'])
+    np.savez_compressed(HERE / 'expected_components.npz', **out)
+    print('components:', {k: float(np.abs(v).max()) for k, v in out.items() if k.startswith('xi')})
+
+
 def dump_pk_kat(VegaInterface):
     """A few full P(k,mu) grids reduced to the checksums reference tests/test_pk.py uses."""
     # The known answers themselves are constants of the reference's test and live in
@@ -1248,12 +1269,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity', 'components']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity', 'components'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1310,3 +1331,5 @@ if __name__ == '__main__':
         dump_fit_stats(VI)
     if 'sensitivity' in what:
         dump_sensitivity(VI)
+    if 'components' in what:
+        dump_components(VI)

@@ -240,3 +240,47 @@ def test_compute_sensitivity_against_the_reference():
     # the auto-correlation does not know the quasar parameter: exact zeros there, as in the reference
     assert not sens['partials']['lyalya_lyalya']['drp_QSO'].any() and exp['partials/lyalya_lyalya/drp_QSO'].any() == False  # noqa: E712
     vega.close()
+
+
+def test_model_components_and_write_cf_against_the_reference(tmp_path):
+    """`save-components` / `write_cf` (reference vega/model.py:41-45, :113-115, :151-153; vega/output.py:375-440): the raw core
+    correlations of the peak and smooth spectra and the components' final models of the unmodified reference at one walker
+    (make_golden.dump_components) against `VegaInterface.model_components` - one two-walker evaluation, bao_amp = 0 and 1, and
+    the per-pipeline stage taps - and the Xi_<name> HDUs `write_results` makes of them."""
+    from vega_amd import VegaInterface, fitslite
+    from vega_amd.output import Output
+    exp = np.load(GOLDEN / 'expected_components.npz')
+    pars = {str(n): float(v) for n, v in zip(exp['param_names'], exp['theta'][0])}
+    prob = load_problem('joint')
+    vega = VegaInterface(None, problem=prob, max_batch=8)
+    comps = vega.model_components(pars)
+    full = vega.compute_model(pars)
+    names = [str(n) for n in exp['names']]
+    assert list(comps) == names
+    for name in names:
+        np.testing.assert_allclose(full[name], exp[f'model/{name}'], rtol=0, atol=1e-8 * np.abs(exp[f'model/{name}']).max())
+        for key in ('xi', 'xi_distorted'):
+            for part in ('peak', 'smooth'):
+                ref = exp[f'{key}/{name}/{part}']
+                got = comps[name][key][part]['core']
+                assert got.shape == ref.shape
+                np.testing.assert_allclose(got, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+        # the parts add up to the model: bao_amp * peak + smooth (vega/model.py:185)
+        total = pars['bao_amp'] * comps[name]['xi_distorted']['peak']['core'] + comps[name]['xi_distorted']['smooth']['core']
+        np.testing.assert_allclose(total, full[name], rtol=0, atol=1e-14 * np.abs(full[name]).max())
+    out = Output({'filename': str(tmp_path / 'with_cf'), 'write_cf': 'True'}, prob.items)
+    out.output_cf = True
+    path = out.write_results(full, pars, models=comps)
+    hdus = {h.header['EXTNAME']: h for h in fitslite.open(path)[1:]}
+    assert list(hdus) == ['MODEL_' + n.upper() for n in names] + ['XI_' + n.upper() for n in names]
+    h = hdus['XI_LYALYA_QSO']
+    assert list(h.columns.names) == ['raw_peak_core', 'raw_smooth_core', 'distorted_peak_core', 'distorted_smooth_core']
+    np.testing.assert_array_equal(h.data['raw_smooth_core'], comps['lyalya_qso']['xi']['smooth']['core'])
+    np.testing.assert_array_equal(h.data['distorted_peak_core'], comps['lyalya_qso']['xi_distorted']['peak']['core'])
+    with pytest.raises(ValueError):
+        out.write_results(full, pars, models=None)
+    vega.close()
+    metals = VegaInterface(None, problem=load_problem('full4'), max_batch=8)
+    with pytest.raises(NotImplementedError):
+        metals.model_components()
+    metals.close()

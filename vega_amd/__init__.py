@@ -24,6 +24,7 @@ def run_vega(config_path, search_dirs=(), print_func=print, **engine_args):
     params = dict(vega.params)
     if vega.minimizer is not None:
         params.update(vega.bestfit.as_dict(0))
+    models = vega.model_components(params) if vega.output.output_cf else vega.models
     vega.output.write_results(vega.bestfit_model if vega.bestfit_model is not None else vega.compute_model(params),
-                              params, vega.minimizer, vega.bestfit_corr_stats, scan_results, vega.models)
+                              params, vega.minimizer, vega.bestfit_corr_stats, scan_results, models)
     return vega

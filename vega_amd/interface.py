@@ -607,6 +607,38 @@ class VegaInterface:
             if not bool(fit.is_valid[0]):
                 print_func('Invalid fit!!! Check data, covariance, model and priors.')
 
+    def model_components(self, params=None):
+        """The saved components of the reference's models (``save-components``: vega/model.py:41-45, :113-115, :151-153) for
+        correlations without metal terms: dict name -> {'xi': {'peak': {'core': ...}, 'smooth': {'core': ...}},
+        'xi_distorted': {...}} - `xi`: the raw core correlation of the peak / smooth spectrum on the model grid, `xi_distorted`:
+        the component's final model (broadband, distortion).  One evaluation of two walkers, ``bao_amp`` = 0 and 1: the model is
+        affine in it (model = bao_amp * peak + smooth, vega/model.py:157-187) and the raw correlations are the per-pipeline
+        bins of that evaluation (stage taps).  P(k, mu) grids (`write_pk`) are never formed here."""
+        from .engine import Engine
+        if self.model_pk or not isinstance(self.engine, Engine):
+            raise NotImplementedError('model_components: one engine, correlation-function models')
+        for name, item in self.problem.items.items():
+            if item.metals:
+                raise NotImplementedError(f'{name}: the components of correlations with metal terms are not kept apart')
+        eng = self.engine
+        self.freeze_metals(params)
+        base = {**self.params, **(params or {})}
+        theta = self.theta_matrix([{**base, 'bao_amp': 0.}, {**base, 'bao_amp': 1.}])
+        self._check_pinned(theta)
+        _, status, model = eng.eval(theta, want_model=True)
+        if status.any():
+            from .errors import VegaModelError
+            raise VegaModelError(f'model evaluation failed (status {int(status[status != 0][0])})')
+        out = {}
+        for name, sl in eng.model_slices.items():
+            n = self.problem.items[name].model_grid.size
+            n_pad = (n + 31) // 32 * 32
+            raw = {comp: eng.debug_read(1, eng.pipe_index[(name, comp)], 2 * n_pad).reshape(2, n_pad)[1, :n].copy()
+                   for comp in ('peak', 'smooth')}
+            out[name] = {'xi': {'peak': {'core': raw['peak']}, 'smooth': {'core': raw['smooth']}},
+                         'xi_distorted': {'peak': {'core': model[1, sl] - model[0, sl]}, 'smooth': {'core': model[0, sl].copy()}}}
+        return out
+
     def compute_sensitivity(self, nominal=None, frac=0.1, verbose=True, print_func=print):
         """Sensitivity of the model to the floating parameters (reference VegaInterface.compute_sensitivity,
         vega/vega_interface.py:956-1075): central differences at value +- frac * error of the four parts of every

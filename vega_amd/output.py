@@ -9,8 +9,9 @@
   (chisq, valid_minima, valid_hesse, failed_mask) and HDU 'Mocks' (one vector column per correlation), one file per rank
   (`monte_carlo_<rank>.fits`) as `bin/run_vega_mc_mpi.py:67-71` writes them.
 
-Not written: the ``write_pk`` / ``write_cf`` component HDUs (the engine keeps no per-component P(k) / xi arrays on the host)
-and the hdf flavour (h5py is not a dependency): both raise.
+``write_cf``: the ``Xi_<name>`` component HDUs (reference :375-440) from `VegaInterface.model_components` - correlations
+without metal terms.  Not written: the ``write_pk`` HDUs (P(k, mu) grids are never formed: the mu sums are fused into the
+spectrum kernel) and the hdf flavour (h5py is not a dependency): both raise.
 """
 import os
 from pathlib import Path
@@ -144,6 +145,20 @@ def scan_table(scan_results, grids=None):
     return ('SCAN', cols, header)
 
 
+def component_table(name, components):
+    """The ``Xi_<name>`` HDU of `write_cf` (reference vega/output.py:375-440): columns ``raw_<part>_core`` (the model's saved
+    `xi`) and ``distorted_<part>_core`` (`xi_distorted`), parts in the reference's order; shorter columns are zero-padded to
+    the table's length, as astropy pads them."""
+    cols = []
+    for prefix, key in (('raw_', 'xi'), ('distorted_', 'xi_distorted')):
+        for part in ('peak', 'smooth', 'full'):
+            for comp, arr in components.get(key, {}).get(part, {}).items():
+                label = 'core' if comp == 'core' else f'{comp[0]}_{comp[1]}'
+                cols.append((f'{prefix}{part}_{label}', 'D', np.asarray(arr, dtype=float)))
+    rows = max(len(c[2]) for c in cols)
+    return ('Xi_' + name, [(n, f, _pad(a, rows, 0.)) for n, f, a in cols], {})
+
+
 class Output:
     """The reference's ``vega.output`` object for a fit's results (reference vega/output.py:9-123): built from the
     ``[output]`` section; ``write_results(corr_funcs, params, minimizer, bestfit_corr_stats, scan_results)``."""
@@ -164,8 +179,10 @@ class Output:
         """``minimizer``: ``vega.minimizer`` / a `minimizer.FitResult` (fit 0 is written) or None."""
         if self.type not in ('fits',):
             raise NotImplementedError(f'output type {self.type!r}: only the fits flavour is written')
-        if self.output_cf or self.output_pk:
-            raise NotImplementedError('write_cf / write_pk: the model components are not kept on the host')
+        if self.output_pk:
+            raise NotImplementedError('write_pk: P(k, mu) grids are never formed (the mu sums are fused into the spectrum kernel)')
+        if self.output_cf and not isinstance(models, dict):
+            raise ValueError('write_cf: pass the components (VegaInterface.model_components(params)) as `models`')
         if self.outfile is None:
             raise ValueError('[output] filename is not set')
         tables = model_tables(self.items, corr_funcs, params, bestfit_corr_stats)
@@ -175,6 +192,11 @@ class Output:
             tables.append(bestfit_table(minimizer.names, minimizer.values[0], minimizer.errors[0], minimizer.covariance[0],
                                         minimizer.fval[0], minimizer.is_valid[0],
                                         accurate[0] if accurate is not None else not minimizer.hesse_failed[0]))
+        if self.output_cf:
+            for name, components in models.items():
+                if not (isinstance(components, dict) and 'xi' in components):
+                    raise ValueError('write_cf: `models` must be the dictionary VegaInterface.model_components returns')
+                tables.append(component_table(name, components))
         if scan_results is not None:
             if minimizer is None:
                 raise ValueError('scan results are written next to a fit')
