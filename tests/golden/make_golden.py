@@ -1258,8 +1258,26 @@ def dump_components(VegaInterface):
             for part in ('peak', 'smooth'):
                 out[f'xi/{name}/{part}'] = np.array(model.xi[part]['core'])
                 out[f'xi_distorted/{name}/{part}'] = np.array(model.xi_distorted[part]['core'])
+        # ... and the auto-correlation WITH its metal terms (tests/golden/configs/auto_metals): the reference saves components
+        # only with `fast_metal_bias = False` (vega/metals.py:242); with the default `no-metal-decomp = True` the model keeps
+        # the 'core' entries alone, the metal terms sit inside the smooth component's final model (vega/model.py:117-119)
+        main = _ref_main(tmp, ['lyalya_lyalya'], True)
+        item = Path(tmp) / 'lyalya_lyalya.ini'
+        item.write_text(item.read_text().replace('[model]', '[model]\nfast_metal_bias = False'))
+        vega = VegaInterface(main)
+        names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 31)
+        vega.fiducial['save-components'] = True
+        full = vega.compute_model(walkers[0], run_init=True)
+        out['metals/param_names'] = np.array(names)
+        out['metals/theta'] = np.array([[walkers[0][n] for n in names]])
+        model = vega.models['lyalya_lyalya']
+        assert list(model.xi['smooth']) == ['core']
+        out['metals/model'] = np.array(full['lyalya_lyalya'])
+        for part in ('peak', 'smooth'):
+            out[f'metals/xi/{part}'] = np.array(model.xi[part]['core'])
+            out[f'metals/xi_distorted/{part}'] = np.array(model.xi_distorted[part]['core'])
     np.savez_compressed(HERE / 'expected_components.npz', **out)
-    print('components:', {k: float(np.abs(v).max()) for k, v in out.items() if k.startswith('xi')})
+    print('components:', {k: float(np.abs(v).max()) for k, v in out.items() if 'xi' in k})
 
 
 def dump_pk_kat(VegaInterface):

@@ -280,7 +280,15 @@ def test_model_components_and_write_cf_against_the_reference(tmp_path):
     with pytest.raises(ValueError):
         out.write_results(full, pars, models=None)
     vega.close()
-    metals = VegaInterface(None, problem=load_problem('full4'), max_batch=8)
-    with pytest.raises(NotImplementedError):
-        metals.model_components()
+    # with metal terms (default no-metal-decomp = True): the model keeps the 'core' entries alone, the metal terms sit inside the
+    # smooth component's final model - the reference saved these with `fast_metal_bias = False` (vega/metals.py:242)
+    metals = VegaInterface(None, problem=load_problem('auto_metals'), max_batch=8)
+    pars = {str(n): float(v) for n, v in zip(exp['metals/param_names'], exp['metals/theta'][0])}
+    comps = metals.model_components(pars)['lyalya_lyalya']
+    for key in ('xi', 'xi_distorted'):
+        for part in ('peak', 'smooth'):
+            ref = exp[f'metals/{key}/{part}']
+            np.testing.assert_allclose(comps[key][part]['core'], ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    np.testing.assert_allclose(metals.compute_model(pars)['lyalya_lyalya'], exp['metals/model'], rtol=0,
+                               atol=1e-8 * np.abs(exp['metals/model']).max())
     metals.close()

@@ -608,8 +608,8 @@ class VegaInterface:
                 print_func('Invalid fit!!! Check data, covariance, model and priors.')
 
     def model_components(self, params=None):
-        """The saved components of the reference's models (``save-components``: vega/model.py:41-45, :113-115, :151-153) for
-        correlations without metal terms: dict name -> {'xi': {'peak': {'core': ...}, 'smooth': {'core': ...}},
+        """The saved components of the reference's models (``save-components``: vega/model.py:41-45, :113-115, :151-153; metal
+        terms with the default ``no-metal-decomp = True``: inside the smooth component's final model, :117-119): dict name -> {'xi': {'peak': {'core': ...}, 'smooth': {'core': ...}},
         'xi_distorted': {...}} - `xi`: the raw core correlation of the peak / smooth spectrum on the model grid, `xi_distorted`:
         the component's final model (broadband, distortion).  One evaluation of two walkers, ``bao_amp`` = 0 and 1: the model is
         affine in it (model = bao_amp * peak + smooth, vega/model.py:157-187) and the raw correlations are the per-pipeline
@@ -618,8 +618,10 @@ class VegaInterface:
         if self.model_pk or not isinstance(self.engine, Engine):
             raise NotImplementedError('model_components: one engine, correlation-function models')
         for name, item in self.problem.items.items():
-            if item.metals:
-                raise NotImplementedError(f'{name}: the components of correlations with metal terms are not kept apart')
+            if item.metals and not item.metal_opts['no_metal_decomp']:
+                # (`no-metal-decomp = False`: the reference merges every metal pair's saved correlations into the components,
+                # vega/model.py:120-130; with the default the metal terms sit inside the smooth component's final model)
+                raise NotImplementedError(f'{name}: with no-metal-decomp = False the metal pairs are components of their own')
         eng = self.engine
         self.freeze_metals(params)
         base = {**self.params, **(params or {})}

@@ -9,8 +9,7 @@
   (chisq, valid_minima, valid_hesse, failed_mask) and HDU 'Mocks' (one vector column per correlation), one file per rank
   (`monte_carlo_<rank>.fits`) as `bin/run_vega_mc_mpi.py:67-71` writes them.
 
-``write_cf``: the ``Xi_<name>`` component HDUs (reference :375-440) from `VegaInterface.model_components` - correlations
-without metal terms.  Not written: the ``write_pk`` HDUs (P(k, mu) grids are never formed: the mu sums are fused into the
+``write_cf``: the ``Xi_<name>`` component HDUs (reference :375-440) from `VegaInterface.model_components`.  Not written: the ``write_pk`` HDUs (P(k, mu) grids are never formed: the mu sums are fused into the
 spectrum kernel) and the hdf flavour (h5py is not a dependency): both raise.
 """
 import os
