@@ -127,15 +127,11 @@ def scan_table(scan_results, grids=None):
     names = np.array(list(scan_results[0].keys()))
     width = max(len(n) for n in names)
     results = np.array([[res[par] for par in names] for res in scan_results], dtype=float)
-    if len(results) != len(names):
-        # (the reference puts the names column next to the per-point columns, which makes astropy pad the shorter one; the
-        # table here has one row per grid point and the names column padded / cut to that length, as astropy leaves it)
-        pad = np.array([''] * len(results), dtype=names.dtype)
-        pad[:min(len(names), len(results))] = names[:len(results)]
-        name_col = pad
-    else:
-        name_col = names
-    cols = [('names', f'{width}A', name_col)] + [(str(n), 'D', results[:, j]) for j, n in enumerate(names)]
+    # (the reference puts the names column next to the per-point columns: astropy's from_columns makes the table as long as the
+    # longest of them and pads the shorter ones - empty strings, zeros)
+    rows = max(len(names), len(results))
+    name_col = np.array(list(names) + [''] * (rows - len(names)), dtype=f'U{width}')
+    cols = [('names', f'{width}A', name_col)] + [(str(n), 'D', _pad(results[:, j], rows, 0.)) for j, n in enumerate(names)]
     header = {}
     for par, grid in (grids or {}).items():
         header[par + '_min'] = (float(grid[0]), 'Grid start for ' + par)
