@@ -64,6 +64,17 @@ def test_minimize_scan_and_monte_carlo_against_the_references_drivers(tmp_path):
             np.testing.assert_allclose(got[:, c], ref[:, c], rtol=1e-4, atol=1e-8)
         else:
             np.testing.assert_allclose(got[:, c], ref[:, c], rtol=1e-5)
+    # ... and into the result file as run_vega writes it (reference vega/scripts/run_vega.py:32-46, vega/output.py:291-349)
+    from vega_amd import fitslite
+    vega.output.outfile, vega.output.overwrite = str(tmp_path / 'scan_result'), True
+    params = {**vega.params, **res.as_dict()}
+    path = vega.output.write_results(vega.bestfit_model, params, vega.minimizer, vega.bestfit_corr_stats, scan)
+    sc = [h for h in fitslite.open(path)[1:] if h.header['EXTNAME'] == 'SCAN'][0]
+    for c, k in enumerate(keys):
+        np.testing.assert_array_equal(sc.data[k][:len(scan)], got[:, c])
+    for g in grid_names:
+        assert (sc.header[g + '_min'], sc.header[g + '_max'], sc.header[g + '_num_bins']) == \
+            (vega.analysis.grids[g][0], vega.analysis.grids[g][-1], len(vega.analysis.grids[g]))
     vega.close()
 
     # Monte Carlo: fiducial from a fit to the data + [mc parameters], one mock installed as data
