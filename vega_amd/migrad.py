@@ -667,7 +667,12 @@ class MigradMinimizer:
     ``evaluate(theta_ext [m, P], fit_index [m]) -> chi2 [m]``."""
 
     def __init__(self, evaluate, names, start, errors, limits, tol=0.1, errordef=1.0, maxfcn=100000, vectorised=True,
-                 iterate=5):
+                 iterate=5, machine=None):
+        # machine: the fits run where the walkers live - `machine(plan, ext0 [F, P], fit_ids [F]) -> per-stage results` advances
+        # every fit with the state machine of vega_amd/csrc/vmx_migrad.h (the engine's `fit_migrad`: kernels, one thread per fit;
+        # tests/test_migrad_machine.py: the same header on the CPU); `evaluate` is then not called at all.  None: the NumPy
+        # drivers below.
+        self.machine = machine
         # iminuit's Minuit.migrad(ncall, iterate=5) - what the reference calls (vega/minimizer.py:79, :97) - runs MnMigrad again,
         # up to `iterate` times in all, while the minimum is neither valid nor at the call limit; every re-run starts from the
         # previous run's state: its values, its parameter errors as step sizes and its error matrix as the first metric
@@ -751,22 +756,38 @@ class MigradMinimizer:
                 x[f], V[f], fval[f], edm[f] = r['x'], r['V'], r['fval'], r['edm']
                 valid[f], hesse_failed[f], accurate[f] = r['valid'], r['hesse_failed'], r['accurate']
                 at_limit[f] = r['limit']
-        # external values, errors, covariance (MnUserParameterState / MnUserCovariance)
-        values = trafo.int2ext(x)
-        cov_int = 2. * self.errordef * V
-        jac = trafo.dint2ext(x)
-        cov = cov_int * jac[:, :, None] * jac[:, None, :]
-        dxs = np.sqrt(np.clip(np.einsum('fii->fi', cov_int), 0., None))
-        errors = dxs.copy()
-        for i in range(free.size):
-            if trafo.has_limits[i]:
-                du1 = trafo.int2ext_col(i, x[:, i] + dxs[:, i]) - values[:, i]
-                du2 = trafo.int2ext_col(i, x[:, i] - dxs[:, i]) - values[:, i]
-                if trafo.lo[i] is not None and trafo.hi[i] is not None:
-                    du1 = np.where(dxs[:, i] > 1., trafo.hi[i] - trafo.lo[i], du1)
-                errors[:, i] = 0.5 * (np.abs(du1) + np.abs(du2))
+        values, errors, cov = _external_results(trafo, x, V, self.errordef)
         return dict(values=values, errors=errors, cov=cov, fval=fval, edm=edm, valid=valid, hesse_failed=hesse_failed,
                     accurate=accurate, nfcn=nfcn, n_iter=n_iter)
+
+    def plan(self, free_sets):
+        """The Minuit objects of a fit as the state machine takes them (vega_amd/csrc/vmx_migrad.h `Spec`): per stage the free
+        parameters' indices, limits and step sizes; errordef, tolerance, call limit, iminuit's `iterate`."""
+        stages = []
+        for free in free_sets:
+            free = np.asarray(free, dtype=int)
+            stages.append(dict(free=free, limits=[self.limits[j] for j in free], errors=self.step[free].copy()))
+        return dict(stages=stages, n_params=len(self.names), up=self.errordef, tol=self.tol, maxfcn=self.maxfcn,
+                    iterate=max(self.iterate, 1))
+
+    def _minimize_on_machine(self, ext, free_sets, fit_ids):
+        """The fits advanced by the state machine: results of the last Minuit object in `_stage`'s form, call / iteration counts
+        summed over the objects."""
+        plan = self.plan(free_sets)
+        outs = self.machine(plan, ext, fit_ids)
+        nfcn = sum(np.asarray(o['nfcn'], dtype=np.int64) for o in outs)
+        n_iter = sum(np.asarray(o['n_iter'], dtype=int) for o in outs)
+        for stage, o in zip(plan['stages'][:-1], outs[:-1]):
+            ok = np.isfinite(o['fval'])
+            ext[np.ix_(ok, stage['free'])] = o['ext'][ok]          # (what the machine did before it started the next object)
+        last, o = plan['stages'][-1], outs[-1]
+        trafo = _VecTransform(last['limits'])
+        flags = np.asarray(o['flags'])
+        values, errors, cov = _external_results(trafo, o['x'], o['V'], self.errordef)
+        values = np.asarray(o['ext'], dtype=float)                 # (the machine's own transform: what it would start from)
+        res = dict(values=values, errors=errors, cov=cov, fval=np.asarray(o['fval'], dtype=float), edm=np.asarray(o['edm'], dtype=float),
+                   valid=(flags & 1) != 0, hesse_failed=(flags & 2) != 0, accurate=(flags & 4) != 0, nfcn=nfcn, n_iter=n_iter)
+        return res
 
     def minimize(self, n_fits=1, start=None, fixed=(), prefit_bias=True):
         P = len(self.names)
@@ -778,15 +799,21 @@ class MigradMinimizer:
         n_iter = np.zeros(F, dtype=int)
         # the reference first minimises over the bias parameters alone, a Minuit object of its own (vega/minimizer.py:66-86)
         bias = np.array([j for j in free_all if 'bias' in self.names[j]], dtype=int)
-        if prefit_bias and bias.size > 0:
-            pre = self._stage(ext, bias, fit_ids)
-            nfcn += pre['nfcn']
-            n_iter += pre['n_iter']
-            ok = np.isfinite(pre['fval'])
-            ext[np.ix_(ok, bias)] = pre['values'][ok]
-        res = self._stage(ext, free_all, fit_ids)
-        nfcn += res['nfcn']
-        n_iter += res['n_iter']
+        if self.machine is not None and free_all.size > 0:
+            free_sets = ([bias] if prefit_bias and bias.size > 0 else []) + [free_all]
+            res = self._minimize_on_machine(ext, free_sets, fit_ids)
+            nfcn += res['nfcn']
+            n_iter += res['n_iter']
+        else:
+            if prefit_bias and bias.size > 0:
+                pre = self._stage(ext, bias, fit_ids)
+                nfcn += pre['nfcn']
+                n_iter += pre['n_iter']
+                ok = np.isfinite(pre['fval'])
+                ext[np.ix_(ok, bias)] = pre['values'][ok]
+            res = self._stage(ext, free_all, fit_ids)
+            nfcn += res['nfcn']
+            n_iter += res['n_iter']
         ok = np.isfinite(res['fval'])
         values = ext.copy()
         errors = np.zeros((F, P))
@@ -800,6 +827,28 @@ class MigradMinimizer:
                         nfcn=nfcn, n_iter=n_iter)
         out.has_accurate_covar = res['accurate'] & ok
         return out
+
+def _external_results(trafo, x, V, errordef):
+    """External values, errors and covariance of fits at internal points x [F, n] with error matrices V [F, n, n]
+    (MnUserParameterState / MnUserCovariance): 2 up V through the transform's Jacobian; for limited parameters the average of
+    the two one-sided excursions."""
+    x = np.asarray(x, dtype=float)
+    V = np.asarray(V, dtype=float)
+    values = trafo.int2ext(x)
+    cov_int = 2. * errordef * V
+    jac = trafo.dint2ext(x)
+    cov = cov_int * jac[:, :, None] * jac[:, None, :]
+    dxs = np.sqrt(np.clip(np.einsum('fii->fi', cov_int), 0., None))
+    errors = dxs.copy()
+    for i in range(trafo.n):
+        if trafo.has_limits[i]:
+            du1 = trafo.int2ext_col(i, x[:, i] + dxs[:, i]) - values[:, i]
+            du2 = trafo.int2ext_col(i, x[:, i] - dxs[:, i]) - values[:, i]
+            if trafo.lo[i] is not None and trafo.hi[i] is not None:
+                du1 = np.where(dxs[:, i] > 1., trafo.hi[i] - trafo.lo[i], du1)
+            errors[:, i] = 0.5 * (np.abs(du1) + np.abs(du2))
+    return values, errors, cov
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 # The same algorithm, array-oriented: every stage but the line search runs for all fits at once (NumPy over fits), the
