@@ -151,8 +151,8 @@ typedef struct {
 } vmx_item_desc;
 
 const char* vmx_last_error(void);
-/* sizeof() of the descriptor structs as compiled (0 tracer, 1 pipe, 2 metal, 3 item): lets a foreign
- * binding verify its struct layout at load time. */
+/* sizeof() of the structs as compiled (0 tracer, 1 pipe, 2 metal, 3 item, 4 vmx_fit_spec, 5 vmx_fit_options, 6 vmx_fit_result,
+ * 7 vmx_fit_stats): lets a foreign binding verify its struct layout at load time. */
 int vmx_struct_size(int32_t which);
 
 int vmx_create(vmx_engine** out, int device);
@@ -324,6 +324,67 @@ int vmx_eval(vmx_engine* e, const double* theta, int32_t B, double* chi2, double
 int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2,
                     double* d_model, int32_t* d_status);
 int vmx_sync(vmx_engine* e);
+/* vmx_eval_device for walkers that bring their own Monte-Carlo mock rows: d_mock_index [B] (device memory) holds, per walker, the
+ * row of the items' mock pools it is compared with (-1: the item's data vector) - what vmx_set_mock_index states from the host
+ * for the calls that follow, stated per call from HBM here, so that two batches with different rows can be in flight (lanes).
+ * chi2 only; always eager launches (no captured graph: the batch size is expected to change from call to call).  The rows must
+ * lie inside the pools (the caller wrote them; the fit driver below checks its own on the host). */
+int vmx_eval_device_mocks(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2, int32_t* d_status,
+                          const int32_t* d_mock_index);
+
+/* Fits where the walkers live.  The reference minimises chi2 one MIGRAD after the other - vega/minimizer.py:66-97 per fit
+ * (iminuit.Minuit(chi2, ...).migrad(ncall): a bias-only pre-fit, then the full fit from its result), vega/analysis.py:224-308 per
+ * Monte-Carlo mock, bin/run_vega_mc_mpi.py:52-71 per rank.  vmx_fit_migrad runs n_fits such fits together ON THE DEVICE: every
+ * fit is a resumable MIGRAD state machine (vega_amd/csrc/vmx_migrad.h - Minuit2 strategy 1 restated decision for decision:
+ * internal coordinates, seed, two-point gradient, line search, Davidon update, HESSE, iminuit's `iterate` re-runs - tested on the
+ * CPU under sanitizers against the per-fit reference coroutine of vega_amd/migrad.py) advanced by one thread; a round = one
+ * kernel that consumes the chi2 values of every fit's last request and runs its bookkeeping up to the next one, a scan, one
+ * kernel that writes the requested points as parameter rows (Minuit's transforms in the kernel), and the engine's chain over
+ * those rows in chunks on alternating lanes.  Parameter rows, chi2 values and the fits' states never leave HBM; the host reads
+ * ONE integer per round (the number of rows) and the results at the end.  A fit's sequence of function values is Minuit's own;
+ * the fits advance at their own pace (a fit that converges goes on to HESSE / its next object while others iterate).
+ *
+ *   spec      the Minuit objects of a fit (1 or 2 stages; stage 1 starts from stage 0's result): free parameter columns, limits,
+ *             step sizes; errordef `up`, tolerance, call limit, iminuit's `iterate` (reference: 1.0, 0.1, 100000, 5)
+ *   theta0    [n_fits][n_params] host: start values and the values of the columns held fixed, per fit
+ *   mock_row  [n_fits] host or NULL: the pool row (vmx_item_set_mock_pool) fit f is fitted to; NULL: the items' data
+ *   opt       const_hint = vmx_set_constant_nl_hint's level for the rows of a round, or -1: derived here (a column varies when a
+ *             stage frees it or the fits' rows differ in it - what vmx_eval derives from host walkers); NULL: -1, 512, 2;
+ *             chunk = rows per engine call (0: 512); lanes = batches in flight (0: 2)
+ *   results   [n_stages] host arrays the caller owns: x [n_fits][n] internal minimum, ext [n_fits][n] its external values,
+ *             V [n_fits][n][n] internal error matrix, fval, edm, flags (VMX_FIT_* bits), nfcn (function calls of the stage, re-runs
+ *             included), n_iter
+ * Synchronous; calls on a handle stay serialised by the caller. */
+#define VMX_FIT_MAXN 32
+#define VMX_FIT_MAX_STAGES 2
+enum { VMX_FIT_VALID = 1, VMX_FIT_HESSE_FAILED = 2, VMX_FIT_ACCURATE = 4, VMX_FIT_AT_CALL_LIMIT = 8, VMX_FIT_MADE_POSDEF = 16 };
+typedef struct {
+    int32_t n;
+    int32_t col[VMX_FIT_MAXN];
+    int32_t has_lo[VMX_FIT_MAXN], has_hi[VMX_FIT_MAXN];
+    double lo[VMX_FIT_MAXN], hi[VMX_FIT_MAXN];
+    double err[VMX_FIT_MAXN];
+} vmx_fit_stage;
+typedef struct {
+    int32_t n_stages, n_params, iterate, maxfcn;
+    double up, tol;
+    vmx_fit_stage stage[VMX_FIT_MAX_STAGES];
+} vmx_fit_spec;
+typedef struct { int32_t const_hint, chunk, lanes, reserved; } vmx_fit_options;
+typedef struct {
+    double* x; double* ext; double* V; double* fval; double* edm;
+    int32_t* flags; int64_t* nfcn; int32_t* n_iter;
+} vmx_fit_result;
+typedef struct {
+    int64_t rounds, evaluations, engine_calls, fits_unfinished;
+    int64_t calls_by_batch[8];          /* engine calls with 1, 2-4, 5-16, 17-64, 65-256, 257-1024, 1025-4096, more rows */
+    int64_t evaluations_by_batch[8];
+    double seconds, seconds_setup, seconds_rounds;
+    double seconds_host_waiting;        /* of seconds_rounds: the host blocked on the stream (the GPU working) */
+    double gpu_idle_seconds_between_rounds;     /* HIP events around the host's turn of every round: the stream empty */
+} vmx_fit_stats;
+int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, const double* theta0, const int32_t* mock_row,
+                   const vmx_fit_options* opt, vmx_fit_result* results, vmx_fit_stats* stats);
 /* direct_pk (vega_interface.py:208-248 -> model.py:188-207): while set, every item's model is its smooth pipeline
  * (no peak component, no metals with the default no-metal-decomp; additive broadband terms enter once) evaluated with
  * the linear spectrum pk[b][nk] of walker b (host pointer, e.g. the output of a Boltzmann code per parameter point)

@@ -3,6 +3,7 @@
 // and run without a GPU.  It plays the role of the library's fit kernels (vmx_fit.h): every round it advances all fits,
 // prints the parameter rows they ask for, and reads the function values back - the function itself lives in the test.
 //
+// argv[1]: capacity N of the fit state (4, 8, 16 or 32; default 32)
 // stdin:  n_stages n_params iterate maxfcn up tol
 //         per stage: n, then n lines "col has_lo has_hi lo hi err"
 //         n_fits, then n_fits rows of n_params start values
@@ -25,7 +26,8 @@ static double read_double()
 }
 static long read_int() { return (long)read_double(); }
 
-int main()
+template <int N>
+static int run()
 {
     Spec sp{};
     sp.n_stages = (int32_t)read_int(); sp.n_params = (int32_t)read_int(); sp.iterate = (int32_t)read_int();
@@ -34,7 +36,7 @@ int main()
     for (int s = 0; s < sp.n_stages; ++s) {
         StageSpec& st = sp.stage[s];
         st.n = (int32_t)read_int();
-        if (st.n < 1 || st.n > MAXN) { std::printf("FAIL n\n"); return 2; }
+        if (st.n < 1 || st.n > N) { std::printf("FAIL n\n"); return 2; }
         for (int i = 0; i < st.n; ++i) {
             st.col[i] = (int32_t)read_int(); st.has_lo[i] = (int32_t)read_int(); st.has_hi[i] = (int32_t)read_int();
             st.lo[i] = read_double(); st.hi[i] = read_double(); st.err[i] = read_double();
@@ -44,8 +46,8 @@ int main()
     std::vector<double> base((size_t)F * P);
     for (auto& v : base) v = read_double();
 
-    std::vector<FitState> state(F);
-    for (auto& s : state) { s = FitState{}; reset(s); }
+    std::vector<FitStateT<N>> state(F);
+    for (auto& s : state) { s = FitStateT<N>{}; reset(s); }
     std::vector<std::vector<double>> ox(sp.n_stages), oext(sp.n_stages), oV(sp.n_stages), ofval(sp.n_stages), oedm(sp.n_stages);
     std::vector<std::vector<int32_t>> oflags(sp.n_stages), oiter(sp.n_stages);
     std::vector<std::vector<int64_t>> onfcn(sp.n_stages);
@@ -79,6 +81,8 @@ int main()
             std::vector<double> row(P);
             for (int q = 0; q < count[f]; ++q) {
                 request_point(state[f], st.n, q, pt);
+                for (int i = 0; i < st.n; ++i)
+                    if (request_coord(state[f], st.n, q, i) != pt[i]) { std::printf("FAIL request_coord\n"); return 2; }
                 for (int c = 0; c < P; ++c) row[c] = base[(size_t)f * P + c];
                 for (int i = 0; i < st.n; ++i) row[st.col[i]] = int2ext(st, i, pt[i]);
                 std::printf("%d", f);
@@ -104,4 +108,18 @@ int main()
     }
     std::printf("END %ld\n", rounds);
     return 0;
+}
+
+// argv[1]: capacity of the fit state (free parameters per Minuit object) the machine is instantiated with - the library picks
+// the smallest of 4 / 8 / 16 / 32 that holds the stages (vmx_fit.h)
+int main(int argc, char** argv)
+{
+    const int cap = argc > 1 ? std::atoi(argv[1]) : MAXN;
+    switch (cap) {
+    case 4: return run<4>();
+    case 8: return run<8>();
+    case 16: return run<16>();
+    case 32: return run<32>();
+    default: std::printf("FAIL capacity\n"); return 2;
+    }
 }

@@ -28,7 +28,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_struct_layouts_match(lib):
     from vega_amd import engine
-    for which, struct in enumerate((engine.Tracer, engine.PipeDesc, engine.MetalDesc, engine.ItemDesc)):
+    for which, struct in enumerate((engine.Tracer, engine.PipeDesc, engine.MetalDesc, engine.ItemDesc, engine.FitSpec, engine.FitOptions,
+                                   engine.FitResultArrays, engine.FitStats)):
         assert lib.vmx_struct_size(which) == C.sizeof(struct)
 
 

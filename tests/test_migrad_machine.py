@@ -30,7 +30,7 @@ def driver(tmp_path_factory):
     return exe
 
 
-def machine_on_cpu(exe, evaluate, log=None):
+def machine_on_cpu(exe, evaluate, log=None, capacity=None):
     """`machine(plan, ext0, fit_ids)` for MigradMinimizer: the driver process advances the fits, `evaluate(theta, fit)` answers."""
     def fmt(v):
         return repr(float(v))
@@ -47,7 +47,8 @@ def machine_on_cpu(exe, evaluate, log=None):
                 head += [str(int(j)), str(int(lo is not None)), str(int(hi is not None)), fmt(lo or 0.), fmt(hi or 0.), fmt(err)]
         head.append(str(F))
         head += [fmt(v) for v in ext0.ravel()]
-        proc = subprocess.Popen([str(exe)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+        cap = capacity or next(c for c in (4, 8, 16, 32) if c >= max(len(st['free']) for st in plan['stages']))
+        proc = subprocess.Popen([str(exe), str(cap)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                 env={'ASAN_OPTIONS': 'detect_leaks=1', 'UBSAN_OPTIONS': 'print_stacktrace=1'})
         proc.stdin.write(' '.join(head) + '\n')
         proc.stdin.flush()
@@ -151,6 +152,12 @@ def test_bias_prefit_chained_into_the_full_fit_with_every_kind_of_limit(driver):
     ref, got, pr, pg, rounds = both(driver, evaluate, names, [0.] * n, [0.05] * n, limits, 48)
     assert_same(ref, got, pr, pg)
     assert got.is_valid.all()
+    # the library instantiates the machine for 4, 8, 16 or 32 free parameters (the smallest that holds the stages: 8 above);
+    # the capacity is storage only
+    m32 = MigradMinimizer(None, names, [0.] * n, [0.05] * n, limits, machine=machine_on_cpu(driver, evaluate, capacity=32)).minimize(48)
+    np.testing.assert_array_equal(m32.nfcn, got.nfcn)
+    np.testing.assert_array_equal(m32.values, got.values)
+    np.testing.assert_array_equal(m32.covariance, got.covariance)
     # the fits run at their own pace: the machine needs as many rounds as its slowest fit, not the sum of the stages' maxima
     assert rounds < 150
 
@@ -228,6 +235,6 @@ def test_iterate_reruns_and_the_call_limit(driver):
 def test_the_library_compiles_the_tested_header():
     """libvegamx's fit kernels advance the fits with the header the driver tests - no second copy of the algorithm."""
     fit = (REPO / 'vega_amd' / 'csrc' / 'vmx_fit.h').read_text()
-    assert '#include "vmx_migrad.h"' in fit and 'vmx_migrad::advance(' in fit
+    assert '#include "vmx_migrad.h"' in fit and 'vmx_migrad::advance<N>(' in fit
     head = (REPO / 'vega_amd' / 'csrc' / 'vmx_migrad.h').read_text()
     assert 'hip/' not in head and 'hipLaunch' not in head

@@ -5,6 +5,7 @@
 // and a per-batch workspace sized at vmx_finalize.  vmx_eval* enqueues the kernel chain of
 // vmx_device.h on the engine stream.
 #include "vmx_device.h"
+#include "vmx_fit.h"
 
 #include <cmath>
 #include <chrono>
@@ -18,6 +19,10 @@
 #include <utility>
 #include <string>
 #include <vector>
+
+#ifndef VMX_MAX_LANES
+#define VMX_MAX_LANES 2             // (three lanes measured at the end of round 4 with an experiment build: no gain over two, DESIGN section 5)
+#endif
 
 static thread_local std::string g_err;
 
@@ -133,6 +138,27 @@ struct ItemHost {
     bool lean_pair = false;             // k_xi_quad_plain applies: plain_pair, or that but for a radiation term on the smooth component
 };
 
+// Device-resident fits (vmx_fit_migrad): buffers kept between calls, grown on demand
+struct FitWorkspace {
+    DevBuf<double> state;               // [F] vmx_migrad::FitStateT<N> (N: vmx_fit_migrad picks the capacity)
+    DevBuf<vmx_migrad::Spec> spec;
+    DevBuf<double> base, theta, chi2;
+    DevBuf<int32_t> mock_row, count, offset, done, mock, status;
+    DevBuf<double> ox[vmx_migrad::MAX_STAGES], oext[vmx_migrad::MAX_STAGES], oV[vmx_migrad::MAX_STAGES], ofval[vmx_migrad::MAX_STAGES], oedm[vmx_migrad::MAX_STAGES];
+    DevBuf<int32_t> oflags[vmx_migrad::MAX_STAGES], oiter[vmx_migrad::MAX_STAGES];
+    DevBuf<int64_t> onfcn[vmx_migrad::MAX_STAGES];
+    int32_t* pin_word = nullptr; int32_t* dpin_word = nullptr;       // mapped host memory: rows of the round, fits still running
+    hipEvent_t ev_lane = nullptr;
+    std::vector<hipEvent_t> ev_gap;                                   // pairs around the host's turn of a round (GPU idle time)
+    ~FitWorkspace() {
+        if (pin_word) (void)hipHostFree(pin_word);
+        if (ev_lane) (void)hipEventDestroy(ev_lane);
+        for (auto& ev : ev_gap) (void)hipEventDestroy(ev);
+    }
+};
+template <typename T>
+static int ensure(DevBuf<T>& b, size_t count) { return b.n >= count && b.p ? 0 : b.alloc(count, false); }
+
 }  // namespace
 
 struct vmx_engine {
@@ -150,6 +176,8 @@ struct vmx_engine {
     int n_lanes = 1;
     int64_t lane_calls = 0;
     hipStream_t last_stream = nullptr;      // the stream the last vmx_eval_device ran on
+    const int32_t* call_mock = nullptr;     // per-call mock rows of the walkers (device pointer; vmx_eval_device_mocks, vmx_fit_migrad)
+    FitWorkspace* fitws = nullptr;
 
     int nk = 0, nkp = 0, n_mu = 0;
     int n_rows = 0, n_extra = 0, mu_lo = 0, mu_hi = 0;     // node rule of the mu sums (vmx_set_mu_quadrature)
@@ -297,6 +325,7 @@ struct vmx_engine {
         for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
         for (auto& q : quad_lists) delete q.second;
+        delete fitws;
         if (pin_theta) (void)hipHostFree(pin_theta);
         if (pin_chi2) (void)hipHostFree(pin_chi2);
         if (pin_status) (void)hipHostFree(pin_status);
@@ -599,6 +628,41 @@ static int launch_product(vmx_engine* e, int kc, const double* A, int lda, int64
 
 }  // namespace
 
+// capacity N of the fit states and fits per block T: N = the smallest of 4 / 8 / 16 / 32 that holds the stages; T x the state's
+// size fits a CU's LDS (vmx_fit.h).  One fit per block: the threads of a wave are in different phases of their fits and a wave
+// executes the union of its threads' paths (vmx_fit.h)
+template <int N, int T>
+static int fit_launch_round(const FitDev& D, hipStream_t st, size_t emit_lds, bool set_attr)
+{
+    constexpr size_t lds = (size_t)T * fit_lds_stride<N>() * sizeof(double);
+    static_assert(lds <= 160 * 1024 - 1024, "fit states of a block must fit a CU's LDS");
+    if (set_attr && lds > 64 * 1024)
+        HIP_OK(hipFuncSetAttribute((const void*)k_fit_advance<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (set_attr) return 0;
+    hipLaunchKernelGGL((k_fit_advance<N, T>), dim3((D.F + T - 1) / T), dim3(FIT_THREADS), lds, st, D);
+    hipLaunchKernelGGL(k_fit_scan, dim3(1), dim3(1024), 0, st, D);
+    hipLaunchKernelGGL((k_fit_emit<N>), dim3(D.F), dim3(64), emit_lds, st, D);
+    return 0;
+}
+static int fit_round(int cap, const FitDev& D, hipStream_t st, size_t emit_lds, bool set_attr)
+{
+    switch (cap) {
+    case 4: return fit_launch_round<4, 1>(D, st, emit_lds, set_attr);
+    case 8: return fit_launch_round<8, 1>(D, st, emit_lds, set_attr);
+    case 16: return fit_launch_round<16, 1>(D, st, emit_lds, set_attr);
+    default: return fit_launch_round<32, 1>(D, st, emit_lds, set_attr);
+    }
+}
+static size_t fit_state_bytes(int cap)
+{
+    switch (cap) {
+    case 4: return sizeof(vmx_migrad::FitStateT<4>);
+    case 8: return sizeof(vmx_migrad::FitStateT<8>);
+    case 16: return sizeof(vmx_migrad::FitStateT<16>);
+    default: return sizeof(vmx_migrad::FitStateT<32>);
+    }
+}
+
 extern "C" {
 
 int vmx_struct_size(int32_t which)
@@ -608,6 +672,10 @@ int vmx_struct_size(int32_t which)
         case 1: return (int)sizeof(vmx_pipe_desc);
         case 2: return (int)sizeof(vmx_metal_desc);
         case 3: return (int)sizeof(vmx_item_desc);
+        case 4: return (int)sizeof(vmx_fit_spec);
+        case 5: return (int)sizeof(vmx_fit_options);
+        case 6: return (int)sizeof(vmx_fit_result);
+        case 7: return (int)sizeof(vmx_fit_stats);
         default: return -1;
     }
 }
@@ -1777,7 +1845,7 @@ static void quad_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B)
         g.M = d.nq; g.N = B; g.K = d.nq_pad; g.tri = 1; g.nsplit = 1; g.klen = d.nq_pad;
         g.d_slab = (int64_t)B * d.nq_pad;
         g.tm = (d.nq + GEMM_BM - 1) / GEMM_BM; g.tn = (B + GEMM_BN - 1) / GEMM_BN;
-        g.part = ql->part.p; g.lin = it->q_lin.p; g.lin_row = e->mock_index.p; g.lin_pool = d.mock_pool ? 1 : 0;
+        g.part = ql->part.p; g.lin = it->q_lin.p; g.lin_row = e->call_mock ? e->call_mock : e->mock_index.p; g.lin_pool = d.mock_pool ? 1 : 0;
         g.row0 = vmx_plan::tape_row0(d.nq, GEMM_BM);       // (the tape's K ranges are those of this tiling)
         G.p[G.n++] = g;
     }
@@ -2015,6 +2083,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                      const double* theta_by_value = nullptr)
 {
     EngineDev D = e->dev;
+    if (e->call_mock) D.mock_index = e->call_mock;      // (this call's walkers bring their own mock rows)
     // tab_mode: table level of the P(k,mu) stage (EngineDev::xtab_level)
     D.xtab_level = tab_mode;
     e->last_tab_level = tab_mode;
@@ -2811,6 +2880,7 @@ static vmx_engine* clone_lane(vmx_engine* e)
     auto* L = new vmx_engine(*e);
     // what the copy must not share (or free)
     L->lanes.clear(); L->n_lanes = 1; L->lane_calls = 0;
+    L->fitws = nullptr; L->call_mock = nullptr;
     L->stream = nullptr; L->cur = nullptr; L->aux.clear(); L->ev_join.clear(); L->ev_fork = nullptr;
     L->graphs.clear(); L->quad_lists.clear(); L->spans.clear(); L->span_used = 0; L->profiling = false;
     L->pin_theta = nullptr; L->pin_chi2 = nullptr; L->pin_status = nullptr; L->pin_done = nullptr; L->pin_part = nullptr;
@@ -2879,12 +2949,12 @@ static vmx_engine* clone_lane(vmx_engine* e)
     return L;
 }
 
-int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2, double* d_model,
-                    int32_t* d_status)
+// vmx_eval_device and its variants.  d_mock: this call's walkers are compared with those rows of the mock pools (device
+// pointer, [B]; nullptr: the rows of vmx_set_mock_index); eager: no captured graph for small batches (a caller whose batch size
+// changes from call to call - the fit driver - would capture one per size).
+static int eval_device_impl(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2, double* d_model, int32_t* d_status,
+                            const int32_t* d_mock, bool eager)
 {
-    REQUIRE(e && e->finalized && d_theta, "vmx_eval_device");
-    REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
-    HIP_OK(hipSetDevice(e->device));
     e->host_key_valid = false;          // (device-resident walkers may rebuild the tables: the host no longer knows their key)
     bool quad = false;
     if (!d_model && quad_ready(e, &quad, B)) return -2;
@@ -2894,6 +2964,9 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     // chain spends 20 - 30 % of its launch there).  Anything else waits for the second lane first.
     const bool two_lanes = e->n_lanes > 1 && quad && !d_model && e->blind_scale.empty() && B >= 64 && !e->direct &&
                            !(e->profiling && e->prof_mask == 0xffffffffu);
+    struct MockScope {          // the per-call rows apply to the engine (or lane) that runs this call, and to this call only
+        vmx_engine* x; MockScope(vmx_engine* x_, const int32_t* m) : x(x_) { x->call_mock = m; } ~MockScope() { x->call_mock = nullptr; }
+    };
     if (!two_lanes) wait_lane(e);
     else if (const int which = (int)(e->lane_calls++ % e->n_lanes)) {
         while ((int)e->lanes.size() < which) {
@@ -2907,19 +2980,22 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
         if (quad_ready(L, &lq, B)) return -2;       // (its work lists: the tensors are the borrowed ones)
         if (!lq) return fail(-2, "the second lane cannot take the quadratic form");
         const int tab = (B >= 16 && L->n_xtab > 0) ? L->const_hint : 0;
+        MockScope scope(L, d_mock);
         if (run_chain(L, B, tab, false, d_theta, d_chi2, d_status, true)) return -2;
         e->last_stream = L->stream;
         return 0;
     }
+    MockScope scope(e, d_mock);
     if (!e->blind_scale.empty()) {
         // parameter-level blinding: the walkers are transformed in the engine's own copy
         HIP_OK(hipMemcpyAsync(e->theta.p, d_theta, (size_t)B * e->n_params * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         const int n = B * e->n_params;
         hipLaunchKernelGGL(k_theta_affine, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->theta.p, e->d_blind.p, e->n_params, n);
-        if (run_chain_cached(e, B, B >= 16 ? e->const_hint : 0, false, quad)) return -2;
+        const int tab = (B >= 16 && e->n_xtab > 0) ? e->const_hint : 0;
+        if (eager ? run_chain(e, B, tab, false, nullptr, nullptr, nullptr, quad) : run_chain_cached(e, B, B >= 16 ? e->const_hint : 0, false, quad)) return -2;
         if (d_chi2) HIP_OK(hipMemcpyAsync(d_chi2, e->chi2.p, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         if (d_status) HIP_OK(hipMemcpyAsync(d_status, e->status.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
-    } else if (B >= 64 || !e->use_graphs || e->profiling) {
+    } else if (B >= 64 || !e->use_graphs || e->profiling || eager) {
         // large batches: eager launches cost nothing next to the kernels, and they let the chain read / write the
         // caller's buffers directly (a captured graph would pin their addresses)
         const int tab = (B >= 16 && e->n_xtab > 0) ? e->const_hint : 0;
@@ -2934,14 +3010,193 @@ int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_c
     return 0;
 }
 
+int vmx_eval_device(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2, double* d_model,
+                    int32_t* d_status)
+{
+    REQUIRE(e && e->finalized && d_theta, "vmx_eval_device");
+    REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
+    HIP_OK(hipSetDevice(e->device));
+    return eval_device_impl(e, d_theta, B, d_chi2, d_model, d_status, nullptr, false);
+}
+
+int vmx_eval_device_mocks(vmx_engine* e, const double* d_theta, int32_t B, double* d_chi2, int32_t* d_status,
+                          const int32_t* d_mock_index)
+{
+    REQUIRE(e && e->finalized && d_theta && d_mock_index, "vmx_eval_device_mocks");
+    REQUIRE(B > 0 && B <= e->max_batch, "batch exceeds max_batch");
+    HIP_OK(hipSetDevice(e->device));
+    return eval_device_impl(e, d_theta, B, d_chi2, nullptr, d_status, d_mock_index, true);
+}
+
+// ---- fits where the walkers live (vmx_fit.h)
+static_assert(sizeof(vmx_fit_stage) == sizeof(vmx_migrad::StageSpec) && sizeof(vmx_fit_spec) == sizeof(vmx_migrad::Spec),
+              "include/vegamx.h and vmx_migrad.h describe the same fit");
+static_assert(VMX_FIT_MAXN == vmx_migrad::MAXN && VMX_FIT_MAX_STAGES == vmx_migrad::MAX_STAGES, "fit limits");
+
+int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, const double* theta0, const int32_t* mock_row,
+                   const vmx_fit_options* opt, vmx_fit_result* results, vmx_fit_stats* stats)
+{
+    REQUIRE(e && e->finalized && spec && theta0 && results && n_fits > 0, "vmx_fit_migrad");
+    REQUIRE(spec->n_stages >= 1 && spec->n_stages <= VMX_FIT_MAX_STAGES && spec->n_params == e->n_params, "vmx_fit_migrad: stages / parameter columns");
+    REQUIRE(spec->iterate >= 1 && spec->maxfcn > 0 && spec->up > 0.0 && spec->tol > 0.0, "vmx_fit_migrad: iterate, maxfcn, up, tol");
+    int max_req = 1, n_max = 1;
+    for (int s = 0; s < spec->n_stages; ++s) {
+        const vmx_fit_stage& st = spec->stage[s];
+        n_max = std::max(n_max, (int)st.n);
+        REQUIRE(st.n >= 1 && st.n <= VMX_FIT_MAXN, "vmx_fit_migrad: 1 .. 32 free parameters per stage");
+        for (int i = 0; i < st.n; ++i) {
+            REQUIRE(st.col[i] >= 0 && st.col[i] < e->n_params, "vmx_fit_migrad: parameter column");
+            for (int j = 0; j < i; ++j) REQUIRE(st.col[j] != st.col[i], "vmx_fit_migrad: a column is listed twice");
+            REQUIRE(!(st.has_lo[i] && st.has_hi[i]) || st.hi[i] > st.lo[i], "vmx_fit_migrad: limits");
+            REQUIRE(st.err[i] > 0.0, "vmx_fit_migrad: step sizes must be positive");
+        }
+        max_req = std::max(max_req, vmx_migrad::max_request(st.n));
+    }
+    if (mock_row)
+        for (int f = 0; f < n_fits; ++f)
+            for (auto* it : e->items) REQUIRE(mock_row[f] < 0 || mock_row[f] < it->n_mocks, "vmx_fit_migrad: mock row exceeds the pool");
+    const int chunk = std::max(1, std::min(opt && opt->chunk > 0 ? opt->chunk : 512, e->max_batch));
+    const int want_lanes = opt && opt->lanes > 0 ? std::min(opt->lanes, VMX_MAX_LANES) : 2;
+    int hint = opt ? opt->const_hint : -1;
+    REQUIRE(hint >= -1 && hint <= 2, "vmx_fit_migrad: const_hint -1 (derive it), 0, 1 or 2");
+    if (hint < 0) {
+        // the table level the rows of a round allow (vmx_set_constant_nl_hint), as vmx_eval derives it from host walkers: a column
+        // varies when a stage frees it or the fits' rows differ in it
+        std::vector<char> varies(e->n_params, 0);
+        for (int s = 0; s < spec->n_stages; ++s)
+            for (int i = 0; i < spec->stage[s].n; ++i) varies[spec->stage[s].col[i]] = 1;
+        for (int f = 1; f < n_fits; ++f)
+            for (int c = 0; c < e->n_params; ++c)
+                if (theta0[(size_t)f * e->n_params + c] != theta0[c]) varies[c] = 1;
+        hint = e->n_xtab > 0 ? (e->no_tab2 ? 1 : 2) : 0;
+        for (int slot : e->const_slots) if (varies[slot]) hint = 0;
+        for (int slot : e->const_slots2) if (hint == 2 && varies[slot]) hint = 1;
+    }
+    HIP_OK(hipSetDevice(e->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    wait_lane(e);
+    HIP_OK(hipStreamSynchronize(e->stream));
+
+    const int F = n_fits, P = e->n_params;
+    const size_t cap = (size_t)F * max_req;
+    if (!e->fitws) e->fitws = new FitWorkspace();
+    FitWorkspace& W = *e->fitws;
+    const int fit_cap = n_max <= 4 ? 4 : n_max <= 8 ? 8 : n_max <= 16 ? 16 : 32;
+    const size_t state_bytes = fit_state_bytes(fit_cap);
+    if (ensure(W.state, (size_t)F * state_bytes / sizeof(double)) || ensure(W.done, F) || ensure(W.spec, 1) || ensure(W.base, (size_t)F * P) || ensure(W.theta, cap * P) || ensure(W.chi2, cap) ||
+        ensure(W.mock_row, F) || ensure(W.count, F) || ensure(W.offset, (size_t)F + 1) || ensure(W.mock, cap) || ensure(W.status, cap)) return -2;
+    for (int s = 0; s < spec->n_stages; ++s) {
+        const size_t n = spec->stage[s].n;
+        if (ensure(W.ox[s], F * n) || ensure(W.oext[s], F * n) || ensure(W.oV[s], F * n * n) || ensure(W.ofval[s], F) || ensure(W.oedm[s], F) ||
+            ensure(W.oflags[s], F) || ensure(W.oiter[s], F) || ensure(W.onfcn[s], F)) return -2;
+    }
+    if (!W.pin_word) {
+        HIP_OK(hipHostMalloc((void**)&W.pin_word, 16 * sizeof(int32_t), hipHostMallocMapped));
+        HIP_OK(hipHostGetDevicePointer((void**)&W.dpin_word, W.pin_word, 0));
+        HIP_OK(hipEventCreateWithFlags(&W.ev_lane, hipEventDisableTiming));
+    }
+    hipStream_t st = e->stream;
+    HIP_OK(hipMemsetAsync(W.state.p, 0, (size_t)F * state_bytes, st));       // (all zeros = a fit at its start)
+    HIP_OK(hipMemsetAsync(W.done.p, 0, (size_t)F * sizeof(int32_t), st));
+    HIP_OK(hipMemsetAsync(W.offset.p, 0, ((size_t)F + 1) * sizeof(int32_t), st));
+    HIP_OK(hipMemcpyAsync(W.spec.p, spec, sizeof(vmx_fit_spec), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(W.base.p, theta0, (size_t)F * P * sizeof(double), hipMemcpyHostToDevice, st));
+    if (mock_row) HIP_OK(hipMemcpyAsync(W.mock_row.p, mock_row, (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice, st));
+
+    FitDev D{};
+    D.state = W.state.p; D.spec = W.spec.p; D.base = W.base.p; D.mock_row = mock_row ? W.mock_row.p : nullptr;
+    for (int s = 0; s < spec->n_stages; ++s)
+        D.out[s] = vmx_migrad::StageOut{W.ox[s].p, W.oext[s].p, W.oV[s].p, W.ofval[s].p, W.oedm[s].p, W.oflags[s].p, W.onfcn[s].p, W.oiter[s].p};
+    D.count = W.count.p; D.offset = W.offset.p; D.done = W.done.p; D.theta = W.theta.p; D.mock = W.mock.p; D.chi2 = W.chi2.p;
+    D.host_word = W.dpin_word; D.F = F; D.P = P; D.admitted = F;
+
+    // the engine as the fits' objective: chi2-only device evaluations of the round's rows, eager launches, two lanes when the
+    // quadratic form serves them; the table level the caller vouches for
+    const int saved_hint = e->const_hint, saved_lanes = e->n_lanes;
+    const bool saved_ring = e->ring_allowed;
+    e->const_hint = hint;
+    if (want_lanes > e->n_lanes) { e->n_lanes = want_lanes; e->ring_allowed = false; }
+    struct Restore {
+        vmx_engine* e; int hint, lanes; bool ring;
+        ~Restore() { wait_lane(e); e->const_hint = hint; e->n_lanes = lanes; e->ring_allowed = ring; e->lane_calls = 0; e->last_stream = e->stream; }
+    } restore{e, saved_hint, saved_lanes, saved_ring};
+
+    vmx_fit_stats S{};
+    const size_t emit_lds = (size_t)((P + 1) & ~1) * sizeof(int32_t) + vmx_migrad::MAXN * sizeof(double);
+    if (fit_round(fit_cap, D, st, emit_lds, true)) return -2;
+    const auto t_loop = std::chrono::steady_clock::now();
+    double wait_s = 0.0;
+    size_t gap_used = 0;
+    for (;;) {
+        if (fit_round(fit_cap, D, st, emit_lds, false)) return -2;
+        if (gap_used + 2 > W.ev_gap.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+            W.ev_gap.push_back(a); W.ev_gap.push_back(b);
+        }
+        HIP_OK(hipEventRecord(W.ev_gap[gap_used], st));
+        const auto t_w0 = std::chrono::steady_clock::now();
+        HIP_OK(hipStreamSynchronize(st));
+        wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
+        const int total = W.pin_word[0];
+        if (total <= 0) break;
+        REQUIRE((size_t)total <= cap, "vmx_fit_migrad: a round asked for more rows than its buffers hold");
+        HIP_OK(hipEventRecord(W.ev_gap[gap_used + 1], st));
+        gap_used += 2;
+        S.rounds += 1;
+        S.evaluations += total;
+        bool lane_used = false;
+        hipStream_t lane_stream = nullptr;
+        for (int off = 0; off < total; off += chunk) {
+            const int B = std::min(chunk, total - off);
+            if (eval_device_impl(e, W.theta.p + (size_t)off * P, B, W.chi2.p + off, nullptr, W.status.p + off, mock_row ? W.mock.p + off : nullptr, true)) return -2;
+            if (e->last_stream != st) { lane_used = true; lane_stream = e->last_stream; }
+            S.engine_calls += 1;
+            int bin = 0;
+            while (bin < 7 && B > (1 << (2 * bin))) ++bin;          // 1, 2..4, 5..16, 17..64, 65..256, 257..1024, 1025..4096, more
+            S.calls_by_batch[bin] += 1;
+            S.evaluations_by_batch[bin] += B;
+        }
+        if (lane_used) {        // the next round's bookkeeping reads every chunk's chi2
+            HIP_OK(hipEventRecord(W.ev_lane, lane_stream));
+            HIP_OK(hipStreamWaitEvent(st, W.ev_lane, 0));
+        }
+    }
+    S.fits_unfinished = W.pin_word[1];
+    const auto t_done = std::chrono::steady_clock::now();
+    for (int s = 0; s < spec->n_stages; ++s) {
+        const size_t n = spec->stage[s].n;
+        const vmx_fit_result& r = results[s];
+        REQUIRE(r.x && r.ext && r.V && r.fval && r.edm && r.flags && r.nfcn && r.n_iter, "vmx_fit_migrad: result arrays");
+        HIP_OK(hipMemcpy(r.x, W.ox[s].p, F * n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(r.ext, W.oext[s].p, F * n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(r.V, W.oV[s].p, F * n * n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(r.fval, W.ofval[s].p, F * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(r.edm, W.oedm[s].p, F * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(r.flags, W.oflags[s].p, F * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(r.nfcn, W.onfcn[s].p, F * sizeof(int64_t), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(r.n_iter, W.oiter[s].p, F * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    double idle_ms = 0.0;
+    for (size_t i = 0; i + 1 < gap_used; i += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, W.ev_gap[i], W.ev_gap[i + 1]) == hipSuccess) idle_ms += t;
+    }
+    const auto t_end = std::chrono::steady_clock::now();
+    S.seconds = std::chrono::duration<double>(t_end - t_begin).count();
+    S.seconds_setup = std::chrono::duration<double>(t_loop - t_begin).count();
+    S.seconds_rounds = std::chrono::duration<double>(t_done - t_loop).count();
+    S.seconds_host_waiting = wait_s;
+    S.gpu_idle_seconds_between_rounds = idle_ms * 1e-3;
+    if (stats) *stats = S;
+    return 0;
+}
+
 void* vmx_stream(vmx_engine* e) { return e ? (void*)e->stream : nullptr; }
 void* vmx_last_stream(vmx_engine* e) { return e ? (void*)(e->last_stream ? e->last_stream : e->stream) : nullptr; }
 
 int vmx_set_lanes(vmx_engine* e, int32_t lanes)
 {
-#ifndef VMX_MAX_LANES
-#define VMX_MAX_LANES 2             // (three lanes measured at the end of round 4 with an experiment build: no gain over two, DESIGN section 5)
-#endif
     REQUIRE(e && e->finalized && lanes >= 1 && lanes <= VMX_MAX_LANES, "vmx_set_lanes: 1 or 2 (after vmx_finalize)");
     HIP_OK(hipSetDevice(e->device));
     if (lanes < e->n_lanes) drop_lane(e);

@@ -73,7 +73,8 @@ enum Phase : int32_t {
     PH_H_OFF_VALS, PH_H_FINAL, PH_AFTER_HESSE, PH_OUTER_TAIL, PH_FINISH, PH_DONE
 };
 
-struct FitState {
+template <int N>
+struct FitStateT {
     // control
     int32_t phase, stage, rerun, done;
     int32_t seeded, ipass, iterate_again, reached_limit;
@@ -82,19 +83,19 @@ struct FitState {
     int64_t nfcn, maxfcn_eff;
     // the request being served
     int32_t req_kind, req_m;
-    int32_t req_idx[MAXN];
-    double req_step[MAXN], req_x[MAXN];
+    int32_t req_idx[N];
+    double req_step[N], req_x[N];
     // the minimisation state (MinimumState): internal point, value, gradient, metric
-    double x[MAXN], grd[MAXN], g2[MAXN], gstep[MAXN], err[MAXN];
+    double x[N], grd[N], g2[N], gstep[N], err[N];
     double fval, dcovar, edm;
     // two-point gradient (Numerical2PGradientCalculator)
     int32_t g_ret, g_cycle;
     uint32_t g_active, pad1;
     double g_fval, g_dfmin;
-    double g_x[MAXN], g_grd[MAXN], g_g2[MAXN], g_gstep[MAXN], g_stepb4[MAXN];
+    double g_x[N], g_grd[N], g_g2[N], g_gstep[N], g_stepb4[N];
     // line search (MnLineSearch)
     int32_t ls_ret, ls_niter;
-    double ls_x[MAXN], ls_step[MAXN];
+    double ls_x[N], ls_step[N];
     double ls_f0, ls_gdel, ls_overal, ls_undral, ls_toler8, ls_slamax, ls_slamin, ls_flast, ls_slam, ls_f2;
     double ls_p0x, ls_p0y, ls_p1x, ls_p1y, ls_p2x, ls_p2y, ls_fvmin, ls_xvmin;
     double ls_lam, ls_fmin;
@@ -104,11 +105,13 @@ struct FitState {
     int32_t h_ret, h_j, h_failed;
     uint32_t h_open;
     double h_amin, h_aimsag, h_dfmin;
-    double h_g2[MAXN], h_gst[MAXN], h_grd[MAXN], h_dirin[MAXN], h_yy[MAXN], h_d[MAXN], h_dmin[MAXN], h_chgold[MAXN];
-    int32_t h_cyc[MAXN], h_mult[MAXN];
-    // metric and two work matrices (row stride MAXN)
-    double V[MAXN * MAXN], M1[MAXN * MAXN], M2[MAXN * MAXN];
+    double h_g2[N], h_gst[N], h_grd[N], h_dirin[N], h_yy[N], h_d[N], h_dmin[N], h_chgold[N];
+    int32_t h_cyc[N], h_mult[N];
+    // metric and two work matrices (row stride N)
+    double V[N * N], M1[N * N], M2[N * N];
 };
+using FitState = FitStateT<MAXN>;
+
 
 VMX_HD inline bool finite_(double v) { return __builtin_isfinite(v); }
 VMX_HD inline double value_(const double* vals, int k)
@@ -152,7 +155,8 @@ VMX_HD inline double dint2ext(const StageSpec& st, int i, double value)
     return 1.;
 }
 
-VMX_HD inline int request_count(const FitState& s, int n)
+template <int N>
+VMX_HD inline int request_count(const FitStateT<N>& s, int n)
 {
     switch (s.req_kind) {
     case REQ_POINT: return 1;
@@ -165,7 +169,8 @@ VMX_HD inline int request_count(const FitState& s, int n)
 VMX_HD inline int max_request(int n) { const int a = 2 * n, b = n * (n - 1) / 2; return a > b ? (a > 1 ? a : 1) : b; }
 
 // internal coordinates of point q of the current request
-VMX_HD inline void request_point(const FitState& s, int n, int q, double* pt)
+template <int N>
+VMX_HD inline void request_point(const FitStateT<N>& s, int n, int q, double* pt)
 {
     for (int i = 0; i < n; ++i) pt[i] = s.req_x[i];
     if (s.req_kind == REQ_PAIRS) {
@@ -180,53 +185,71 @@ VMX_HD inline void request_point(const FitState& s, int n, int q, double* pt)
     }
 }
 
-// ---- small dense linear algebra on row-stride-MAXN matrices
+// coordinate i of point q of the current request (what request_point leaves in pt[i]): a thread per coordinate on the device
+template <int N>
+VMX_HD inline double request_coord(const FitStateT<N>& s, int n, int q, int i)
+{
+    double v = s.req_x[i];
+    if (s.req_kind == REQ_PAIRS) {
+        if (s.req_idx[q >> 1] == i) { if (q & 1) v -= s.req_step[q >> 1]; else v += s.req_step[q >> 1]; }
+    } else if (s.req_kind == REQ_OFFDIAG) {
+        int a = 0, left = q;
+        while (left >= n - 1 - a) { left -= n - 1 - a; ++a; }
+        if (i == a || i == a + 1 + left) v += s.req_step[i];
+    }
+    return v;
+}
+
+// ---- small dense linear algebra on row-stride-N matrices
+template <int N>
 VMX_HD inline double quad_form(const double* V, const double* g, int n)      // g^T V g
 {
     double t = 0.;
     for (int i = 0; i < n; ++i) {
         double r = 0.;
-        for (int j = 0; j < n; ++j) r += V[i * MAXN + j] * g[j];
+        for (int j = 0; j < n; ++j) r += V[i * N + j] * g[j];
         t += g[i] * r;
     }
     return t;
 }
 
 // extreme eigenvalues of the symmetric matrix A (destroyed): cyclic Jacobi rotations
+template <int N>
 VMX_HD inline void eig_extremes(double* A, int n, double* emin, double* emax)
 {
     for (int sweep = 0; sweep < 64; ++sweep) {
         double off = 0., diag = 0.;
         for (int i = 0; i < n; ++i) {
-            diag += A[i * MAXN + i] * A[i * MAXN + i];
-            for (int j = i + 1; j < n; ++j) off += A[i * MAXN + j] * A[i * MAXN + j];
+            diag += A[i * N + i] * A[i * N + i];
+            for (int j = i + 1; j < n; ++j) off += A[i * N + j] * A[i * N + j];
         }
         if (!(off > 1e-32 * diag)) break;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * MAXN + q];
+                const double apq = A[p * N + q];
                 if (apq == 0.) continue;
-                const double theta = (A[q * MAXN + q] - A[p * MAXN + p]) / (2. * apq);
+                const double theta = (A[q * N + q] - A[p * N + p]) / (2. * apq);
                 const double t = (theta >= 0. ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
                 const double c = 1. / sqrt(t * t + 1.), sn = t * c;
                 for (int k = 0; k < n; ++k) {       // columns p, q
-                    const double akp = A[k * MAXN + p], akq = A[k * MAXN + q];
-                    A[k * MAXN + p] = c * akp - sn * akq;
-                    A[k * MAXN + q] = sn * akp + c * akq;
+                    const double akp = A[k * N + p], akq = A[k * N + q];
+                    A[k * N + p] = c * akp - sn * akq;
+                    A[k * N + q] = sn * akp + c * akq;
                 }
                 for (int k = 0; k < n; ++k) {       // rows p, q
-                    const double apk = A[p * MAXN + k], aqk = A[q * MAXN + k];
-                    A[p * MAXN + k] = c * apk - sn * aqk;
-                    A[q * MAXN + k] = sn * apk + c * aqk;
+                    const double apk = A[p * N + k], aqk = A[q * N + k];
+                    A[p * N + k] = c * apk - sn * aqk;
+                    A[q * N + k] = sn * apk + c * aqk;
                 }
             }
     }
     double lo = A[0], hi = A[0];
-    for (int i = 1; i < n; ++i) { const double d = A[i * MAXN + i]; if (d < lo) lo = d; if (d > hi) hi = d; }
+    for (int i = 1; i < n; ++i) { const double d = A[i * N + i]; if (d < lo) lo = d; if (d > hi) hi = d; }
     *emin = lo; *emax = hi;
 }
 
 // MnPosDef on M (in place; W: work matrix).  Returns whether the matrix had to be changed to become positive definite.
+template <int N>
 VMX_HD inline bool make_posdef(double* M, int n, double* W)
 {
     if (n == 1) {
@@ -235,62 +258,97 @@ VMX_HD inline bool make_posdef(double* M, int n, double* W)
     }
     const double epspdf = 1e-6;          // max(1e-6, Eps2)
     double dgmin = M[0];
-    for (int i = 1; i < n; ++i) if (M[i * MAXN + i] < dgmin) dgmin = M[i * MAXN + i];
+    for (int i = 1; i < n; ++i) if (M[i * N + i] < dgmin) dgmin = M[i * N + i];
     const double dg = dgmin <= 0 ? 0.5 + epspdf - dgmin : 0.;
     for (int i = 0; i < n; ++i) {
-        double d = M[i * MAXN + i] + dg;
+        double d = M[i * N + i] + dg;
         if (d < 0.) d = 1.;
-        M[i * MAXN + i] = d;
+        M[i * N + i] = d;
     }
     for (int i = 0; i < n; ++i) {
-        const double si = 1. / sqrt(M[i * MAXN + i]);
-        for (int j = 0; j < n; ++j) W[i * MAXN + j] = M[i * MAXN + j] * si * (1. / sqrt(M[j * MAXN + j]));
+        const double si = 1. / sqrt(M[i * N + i]);
+        for (int j = 0; j < n; ++j) W[i * N + j] = M[i * N + j] * si * (1. / sqrt(M[j * N + j]));
+    }
+    // MnPosDef asks whether pmin > epspdf * max(|pmax|, 1) for the extreme eigenvalues of the scaled matrix W (unit diagonal).
+    // Almost always it is, by orders of magnitude, and that can be SHOWN without eigenvalues: |pmax| <= R, the largest absolute row
+    // sum (Gershgorin), and pmin > tau whenever W - tau I has a Cholesky factor.  With tau = 2 epspdf max(R, 1) + 1e-9 and every
+    // pivot > 1e-9 the answer stands whatever the rounding (a Jacobi sweep costs a thread thousands of dependent instructions:
+    // 80 us of the 290 us a round's bookkeeping took).  Anything closer goes through the eigenvalues.
+    {
+        double R = 0.;
+        for (int i = 0; i < n; ++i) {
+            double r = 0.;
+            for (int j = 0; j < n; ++j) r += fabs(W[i * N + j]);
+            if (r > R) R = r;
+        }
+        const double tau = 2. * epspdf * (R > 1. ? R : 1.) + 1e-9;
+        bool clear = finite_(R);
+        // in-place Cholesky of the lower triangle of a copy is not needed: the factor's entries go to the strict upper triangle of W
+        // (W is symmetric and is destroyed by the eigenvalue path anyway, which reads it only if this test fails - so work on the
+        // upper triangle and restore it from the lower one afterwards)
+        for (int j = 0; j < n && clear; ++j) {
+            double d = W[j * N + j] - tau;
+            for (int k = 0; k < j; ++k) d -= W[k * N + j] * W[k * N + j];
+            if (!(d > 1e-9)) { clear = false; break; }
+            const double l = sqrt(d);
+            for (int i = j + 1; i < n; ++i) {
+                double v = W[i * N + j];                        // (lower triangle: untouched original)
+                for (int k = 0; k < j; ++k) v -= W[k * N + i] * W[k * N + j];
+                W[j * N + i] = v / l;                           // L[i][j] kept at the mirrored position
+            }
+        }
+        if (clear) return false;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) W[i * N + j] = W[j * N + i];
     }
     double pmin, pmax;
-    eig_extremes(W, n, &pmin, &pmax);
+    eig_extremes<N>(W, n, &pmin, &pmax);
     pmax = fabs(pmax) > 1. ? fabs(pmax) : 1.;
     if (pmin > epspdf * pmax) return false;
     const double padd = 0.001 * pmax - pmin;
-    for (int i = 0; i < n; ++i) M[i * MAXN + i] *= (1. + padd);
+    for (int i = 0; i < n; ++i) M[i * N + i] *= (1. + padd);
     return true;
 }
 
 // in-place inverse (Gauss-Jordan, partial pivoting); false for an exactly singular matrix
+template <int N>
 VMX_HD inline bool invert(double* A, int n)
 {
-    int piv[MAXN];
+    int piv[N];
     for (int c = 0; c < n; ++c) {
         int p = c;
-        double best = fabs(A[c * MAXN + c]);
-        for (int r = c + 1; r < n; ++r) if (fabs(A[r * MAXN + c]) > best) { best = fabs(A[r * MAXN + c]); p = r; }
+        double best = fabs(A[c * N + c]);
+        for (int r = c + 1; r < n; ++r) if (fabs(A[r * N + c]) > best) { best = fabs(A[r * N + c]); p = r; }
         if (!(best > 0.)) return false;
         piv[c] = p;
-        if (p != c) for (int k = 0; k < n; ++k) { const double t = A[c * MAXN + k]; A[c * MAXN + k] = A[p * MAXN + k]; A[p * MAXN + k] = t; }
-        const double d = 1. / A[c * MAXN + c];
-        A[c * MAXN + c] = 1.;
-        for (int k = 0; k < n; ++k) A[c * MAXN + k] *= d;
+        if (p != c) for (int k = 0; k < n; ++k) { const double t = A[c * N + k]; A[c * N + k] = A[p * N + k]; A[p * N + k] = t; }
+        const double d = 1. / A[c * N + c];
+        A[c * N + c] = 1.;
+        for (int k = 0; k < n; ++k) A[c * N + k] *= d;
         for (int r = 0; r < n; ++r) {
             if (r == c) continue;
-            const double f = A[r * MAXN + c];
+            const double f = A[r * N + c];
             if (f == 0.) continue;
-            A[r * MAXN + c] = 0.;
-            for (int k = 0; k < n; ++k) A[r * MAXN + k] -= f * A[c * MAXN + k];
+            A[r * N + c] = 0.;
+            for (int k = 0; k < n; ++k) A[r * N + k] -= f * A[c * N + k];
         }
     }
     for (int c = n - 1; c >= 0; --c)
-        if (piv[c] != c) for (int r = 0; r < n; ++r) { const double t = A[r * MAXN + c]; A[r * MAXN + c] = A[r * MAXN + piv[c]]; A[r * MAXN + piv[c]] = t; }
+        if (piv[c] != c) for (int r = 0; r < n; ++r) { const double t = A[r * N + c]; A[r * N + c] = A[r * N + piv[c]]; A[r * N + piv[c]] = t; }
     return true;
 }
 
-VMX_HD inline void set_diag_metric(FitState& s, int n)
+template <int N>
+VMX_HD inline void set_diag_metric(FitStateT<N>& s, int n)
 {
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) s.V[i * MAXN + j] = 0.;
-    for (int i = 0; i < n; ++i) s.V[i * MAXN + i] = fabs(s.g2[i]) > EPS2 ? 1. / s.g2[i] : 1.;
+        for (int j = 0; j < n; ++j) s.V[i * N + j] = 0.;
+    for (int i = 0; i < n; ++i) s.V[i * N + i] = fabs(s.g2[i]) > EPS2 ? 1. / s.g2[i] : 1.;
 }
 
 // sub-machine entries
-VMX_HD inline void begin_gradient(FitState& s, int n, const double* x, double fval, const double* grd, const double* g2,
+template <int N>
+VMX_HD inline void begin_gradient(FitStateT<N>& s, int n, const double* x, double fval, const double* grd, const double* g2,
                                   const double* gstep, double up, int32_t ret)
 {
     for (int i = 0; i < n; ++i) { s.g_x[i] = x[i]; s.g_grd[i] = grd[i]; s.g_g2[i] = g2[i]; s.g_gstep[i] = gstep[i]; s.g_stepb4[i] = 0.; }
@@ -301,14 +359,16 @@ VMX_HD inline void begin_gradient(FitState& s, int n, const double* x, double fv
     s.g_ret = ret;
     s.phase = PH_GRAD_BEGIN;
 }
-VMX_HD inline void begin_line_search(FitState& s, int n, const double* x, double f0, double gdel, int32_t ret)
+template <int N>
+VMX_HD inline void begin_line_search(FitStateT<N>& s, int n, const double* x, double f0, double gdel, int32_t ret)
 {
     // (s.ls_step holds the direction)
     for (int i = 0; i < n; ++i) s.ls_x[i] = x[i];
     s.ls_f0 = f0; s.ls_gdel = gdel; s.ls_ret = ret;
     s.phase = PH_LS_BEGIN;
 }
-VMX_HD inline void emit_line_point(FitState& s, int n, double slam)
+template <int N>
+VMX_HD inline void emit_line_point(FitStateT<N>& s, int n, double slam)
 {
     for (int i = 0; i < n; ++i) s.req_x[i] = s.ls_x[i] + slam * s.ls_step[i];
     s.req_kind = REQ_POINT;
@@ -317,7 +377,8 @@ VMX_HD inline void emit_line_point(FitState& s, int n, double slam)
 // Advance fit `fit` until its next request.  `vals`: the chi2 values of the points of its previous request (in request
 // order); `base`: the fit's parameter row (read for start values, written with a stage's result before the next stage starts);
 // `outs`: result arrays of the stages.  Returns the number of points requested; 0: the fit is done.
-VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, double* base, const StageOut* outs, int64_t fit)
+template <int N>
+VMX_HD inline int advance(FitStateT<N>& s, const Spec& sp, const double* vals, double* base, const StageOut* outs, int64_t fit)
 {
     const double up = sp.up;
     const double edmval = 0.002 * (sp.tol * up > EPS2 ? sp.tol * up : EPS2);
@@ -343,7 +404,7 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
                     if (!(e > 0.)) e = st.err[i];
                     s.err[i] = e;
                     s.x[i] = ext2int(st, i, ext);
-                    for (int j = 0; j < n; ++j) s.V[i * MAXN + j] = Vs[i * n + j];
+                    for (int j = 0; j < n; ++j) s.V[i * N + j] = Vs[i * n + j];
                 }
                 s.seeded = 1;
             }
@@ -429,7 +490,7 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
             for (int i = 0; i < n; ++i) { s.grd[i] = s.g_grd[i]; s.g2[i] = s.g_g2[i]; s.gstep[i] = s.g_gstep[i]; }
             if (s.seeded) s.dcovar = 0.;
             else { set_diag_metric(s, n); s.dcovar = 1.; }
-            s.edm = 0.5 * quad_form(s.V, s.grd, n);
+            s.edm = 0.5 * quad_form<N>(s.V, s.grd, n);
             bool negative = false;
             for (int i = 0; i < n; ++i) if (s.g2[i] <= 0.) negative = true;
             s.ng_iter = 0;
@@ -451,7 +512,7 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
             if (pick < 0) {
                 set_diag_metric(s, n);
                 s.dcovar = 1.;
-                s.edm = 0.5 * quad_form(s.V, s.grd, n);
+                s.edm = 0.5 * quad_form<N>(s.V, s.grd, n);
                 s.phase = PH_OUTER_BEGIN;
                 break;
             }
@@ -488,18 +549,18 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
             double gdel = 0.;
             for (int i = 0; i < n; ++i) {
                 double r = 0.;
-                for (int j = 0; j < n; ++j) r += s.V[i * MAXN + j] * s.grd[j];
+                for (int j = 0; j < n; ++j) r += s.V[i * N + j] * s.grd[j];
                 s.ls_step[i] = -r;
                 gdel += s.ls_step[i] * s.grd[i];
             }
             if (gdel > 0.) {
-                for (int i = 0; i < n * MAXN; ++i) s.M1[i] = s.V[i];
-                make_posdef(s.M1, n, s.M2);
-                for (int i = 0; i < n * MAXN; ++i) s.V[i] = s.M1[i];
+                for (int i = 0; i < n * N; ++i) s.M1[i] = s.V[i];
+                make_posdef<N>(s.M1, n, s.M2);
+                for (int i = 0; i < n * N; ++i) s.V[i] = s.M1[i];
                 gdel = 0.;
                 for (int i = 0; i < n; ++i) {
                     double r = 0.;
-                    for (int j = 0; j < n; ++j) r += s.V[i * MAXN + j] * s.grd[j];
+                    for (int j = 0; j < n; ++j) r += s.V[i * N + j] * s.grd[j];
                     s.ls_step[i] = -r;
                     gdel += s.ls_step[i] * s.grd[i];
                 }
@@ -520,22 +581,22 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
             break;
         }
         case PH_IT_GRAD_DONE: {
-            double edm = 0.5 * quad_form(s.V, s.g_grd, n);
+            double edm = 0.5 * quad_form<N>(s.V, s.g_grd, n);
             if (edm != edm) { s.reached_limit = 0; s.phase = PH_IT_END; break; }
             if (edm < 0.) {
-                for (int i = 0; i < n * MAXN; ++i) s.M1[i] = s.V[i];
-                make_posdef(s.M1, n, s.M2);
-                for (int i = 0; i < n * MAXN; ++i) s.V[i] = s.M1[i];
-                edm = 0.5 * quad_form(s.V, s.g_grd, n);
+                for (int i = 0; i < n * N; ++i) s.M1[i] = s.V[i];
+                make_posdef<N>(s.M1, n, s.M2);
+                for (int i = 0; i < n * N; ++i) s.V[i] = s.M1[i];
+                edm = 0.5 * quad_form<N>(s.V, s.g_grd, n);
                 if (edm < 0.) { s.reached_limit = 0; s.phase = PH_IT_END; break; }
             }
             // Davidon's update (DavidonErrorUpdator): dx -> M1 row 0, dg -> row 1, vg -> row 2 (scratch)
-            double* dx = s.M1; double* dg = s.M1 + MAXN; double* vg = s.M1 + 2 * MAXN;
+            double* dx = s.M1; double* dg = s.M1 + N; double* vg = s.M1 + 2 * N;
             double delgam = 0., gvg = 0.;
             for (int i = 0; i < n; ++i) { dx[i] = s.g_x[i] - s.x[i]; dg[i] = s.g_grd[i] - s.grd[i]; delgam += dx[i] * dg[i]; }
             for (int i = 0; i < n; ++i) {
                 double r = 0.;
-                for (int j = 0; j < n; ++j) r += s.V[i * MAXN + j] * dg[j];
+                for (int j = 0; j < n; ++j) r += s.V[i * N + j] * dg[j];
                 vg[i] = r;
             }
             for (int i = 0; i < n; ++i) gvg += dg[i] * vg[i];
@@ -547,12 +608,12 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
                     for (int j = 0; j < n; ++j) {
                         double u = dx[i] * dx[j] / delgam - vg[i] * vg[j] / gvg;
                         if (rank1) u += gvg * ((dx[i] / delgam - vg[i] / gvg) * (dx[j] / delgam - vg[j] / gvg));
-                        const double v = s.V[i * MAXN + j] + u;
-                        s.M2[i * MAXN + j] = v;
+                        const double v = s.V[i * N + j] + u;
+                        s.M2[i * N + j] = v;
                         if (j >= i) { sum_upd += fabs(u); sum_v += fabs(v); }
                     }
                 for (int i = 0; i < n; ++i)
-                    for (int j = 0; j < n; ++j) s.V[i * MAXN + j] = s.M2[i * MAXN + j];
+                    for (int j = 0; j < n; ++j) s.V[i * N + j] = s.M2[i * N + j];
                 dcov = 0.5 * (s.dcovar + sum_upd / sum_v);
             }
             for (int i = 0; i < n; ++i) { s.x[i] = s.g_x[i]; s.grd[i] = s.g_grd[i]; s.g2[i] = s.g_g2[i]; s.gstep[i] = s.g_gstep[i]; }
@@ -717,7 +778,7 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
                 s.h_dmin[i] = 8. * EPS2 * (fabs(s.x[i]) + EPS2);
                 s.h_d[i] = fabs(s.gstep[i]) > s.h_dmin[i] ? fabs(s.gstep[i]) : s.h_dmin[i];
                 s.h_cyc[i] = 0; s.h_mult[i] = 0;
-                for (int j = 0; j < n; ++j) s.M1[i * MAXN + j] = 0.;
+                for (int j = 0; j < n; ++j) s.M1[i * N + j] = 0.;
             }
             s.h_open = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
             s.h_failed = 0;
@@ -767,7 +828,7 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
                 if (dn < s.h_dmin[i]) dn = s.h_dmin[i];
                 s.h_cyc[i] += 1;
                 if (fabs((dn - d) / dn) < HESS_STEP_TOL || fabs((s.h_g2[i] - g2bfor) / s.h_g2[i]) < HESS_G2_TOL || s.h_cyc[i] >= HESS_NCYCLES) {
-                    s.M1[i * MAXN + i] = s.h_g2[i];
+                    s.M1[i * N + i] = s.h_g2[i];
                     s.h_open &= ~(1u << i);
                     continue;
                 }
@@ -842,23 +903,23 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
             for (int i = 0; i < n; ++i)
                 for (int j = i + 1; j < n; ++j, ++q) {
                     const double el = (value_(vals, q) + s.h_amin - s.h_yy[i] - s.h_yy[j]) / (s.h_dirin[i] * s.h_dirin[j]);
-                    s.M1[i * MAXN + j] = el;
-                    s.M1[j * MAXN + i] = el;
+                    s.M1[i * N + j] = el;
+                    s.M1[j * N + i] = el;
                 }
             s.phase = PH_H_FINAL;
             break;
         }
         case PH_H_FINAL: {
-            const bool made = make_posdef(s.M1, n, s.M2);
+            const bool made = make_posdef<N>(s.M1, n, s.M2);
             for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) s.M2[i * MAXN + j] = s.M1[i * MAXN + j];
-            if (!invert(s.M2, n)) { s.hesse_failed = 1; s.fval = s.h_amin; s.phase = s.h_ret; break; }
+                for (int j = 0; j < n; ++j) s.M2[i * N + j] = s.M1[i * N + j];
+            if (!invert<N>(s.M2, n)) { s.hesse_failed = 1; s.fval = s.h_amin; s.phase = s.h_ret; break; }
             for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) s.V[i * MAXN + j] = s.M2[i * MAXN + j];
+                for (int j = 0; j < n; ++j) s.V[i * N + j] = s.M2[i * N + j];
             for (int i = 0; i < n; ++i) { s.grd[i] = s.h_grd[i]; s.g2[i] = s.h_g2[i]; s.gstep[i] = s.h_gst[i]; }
             s.fval = s.h_amin;
             s.dcovar = 0.;
-            s.edm = 0.5 * quad_form(s.V, s.grd, n);
+            s.edm = 0.5 * quad_form<N>(s.V, s.grd, n);
             s.made_posdef = made ? 1 : 0; s.hesse_failed = 0; s.accurate = made ? 0 : 1;
             s.phase = s.h_ret;
             break;
@@ -896,7 +957,7 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
             if (s.rerun == 0 || !bad) {
                 for (int i = 0; i < n; ++i) {
                     o.x[fit * n + i] = s.x[i];
-                    for (int j = 0; j < n; ++j) o.V[(fit * n + i) * n + j] = bad ? 0. : s.V[i * MAXN + j];
+                    for (int j = 0; j < n; ++j) o.V[(fit * n + i) * n + j] = bad ? 0. : s.V[i * N + j];
                 }
                 o.fval[fit] = bad ? __builtin_inf() : s.fval;
                 o.edm[fit] = bad ? __builtin_inf() : s.edm;
@@ -931,7 +992,8 @@ VMX_HD inline int advance(FitState& s, const Spec& sp, const double* vals, doubl
     }
 }
 
-VMX_HD inline void reset(FitState& s)
+template <int N>
+VMX_HD inline void reset(FitStateT<N>& s)
 {
     s.phase = PH_INIT; s.stage = 0; s.rerun = 0; s.done = 0; s.req_kind = REQ_NONE; s.req_m = 0;
     s.nfcn = 0; s.n_iter = 0;

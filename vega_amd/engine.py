@@ -76,6 +76,40 @@ class ItemDesc(C.Structure):
                 ('pipe_smooth', C.c_int32), ('bao_amp_slot', C.c_int32)]
 
 
+VMX_FIT_MAXN, VMX_FIT_MAX_STAGES = 32, 2
+
+
+class FitStage(C.Structure):
+    _fields_ = [('n', C.c_int32), ('col', C.c_int32 * VMX_FIT_MAXN), ('has_lo', C.c_int32 * VMX_FIT_MAXN),
+                ('has_hi', C.c_int32 * VMX_FIT_MAXN), ('lo', C.c_double * VMX_FIT_MAXN), ('hi', C.c_double * VMX_FIT_MAXN),
+                ('err', C.c_double * VMX_FIT_MAXN)]
+
+
+class FitSpec(C.Structure):
+    _fields_ = [('n_stages', C.c_int32), ('n_params', C.c_int32), ('iterate', C.c_int32), ('maxfcn', C.c_int32),
+                ('up', C.c_double), ('tol', C.c_double), ('stage', FitStage * VMX_FIT_MAX_STAGES)]
+
+
+class FitOptions(C.Structure):
+    _fields_ = [('const_hint', C.c_int32), ('chunk', C.c_int32), ('lanes', C.c_int32), ('reserved', C.c_int32)]
+
+
+class FitResultArrays(C.Structure):
+    _fields_ = [('x', C.POINTER(C.c_double)), ('ext', C.POINTER(C.c_double)), ('V', C.POINTER(C.c_double)),
+                ('fval', C.POINTER(C.c_double)), ('edm', C.POINTER(C.c_double)), ('flags', C.POINTER(C.c_int32)),
+                ('nfcn', C.POINTER(C.c_int64)), ('n_iter', C.POINTER(C.c_int32))]
+
+
+class FitStats(C.Structure):
+    _fields_ = [('rounds', C.c_int64), ('evaluations', C.c_int64), ('engine_calls', C.c_int64), ('fits_unfinished', C.c_int64),
+                ('calls_by_batch', C.c_int64 * 8), ('evaluations_by_batch', C.c_int64 * 8),
+                ('seconds', C.c_double), ('seconds_setup', C.c_double), ('seconds_rounds', C.c_double),
+                ('seconds_host_waiting', C.c_double), ('gpu_idle_seconds_between_rounds', C.c_double)]
+
+
+FIT_BATCH_BINS = ('1', '2..4', '5..16', '17..64', '65..256', '257..1024', '1025..4096', '4097..')
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -136,6 +170,9 @@ def load_library():
     lib.vmx_eval.argtypes = [C.c_void_p, dptr, C.c_int32, dptr, dptr, iptr]
     lib.vmx_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vmx_sync.argtypes = [C.c_void_p]
+    lib.vmx_eval_device_mocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vmx_fit_migrad.argtypes = [C.c_void_p, C.POINTER(FitSpec), C.c_int32, dptr, iptr, C.POINTER(FitOptions),
+                                   C.POINTER(FitResultArrays), C.POINTER(FitStats)]
     lib.vmx_set_constant_nl_hint.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_set_direct_pk.argtypes = [C.c_void_p, dptr, C.c_int32, C.c_int32]
     lib.vmx_set_linear_spectra.argtypes = [C.c_void_p, dptr, dptr, dptr, C.c_int32]
@@ -167,7 +204,7 @@ def load_library():
     lib.vmx_set_profiling_mask.argtypes = [C.c_void_p, C.c_uint32]
     lib.vmx_get_timings.argtypes = [C.c_void_p, dptr, C.POINTER(C.c_int64), C.c_int32]
     lib.vmx_struct_size.argtypes = [C.c_int32]
-    for which, struct in enumerate((Tracer, PipeDesc, MetalDesc, ItemDesc)):
+    for which, struct in enumerate((Tracer, PipeDesc, MetalDesc, ItemDesc, FitSpec, FitOptions, FitResultArrays, FitStats)):
         if lib.vmx_struct_size(which) != C.sizeof(struct):
             raise EngineError(f'ABI mismatch: {struct.__name__} is {C.sizeof(struct)} bytes here, '
                               f'{lib.vmx_struct_size(which)} in libvegamx.so')
@@ -180,7 +217,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_pipeline_set_odd_operator', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_static_poly', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_eval_device_mocks', 'vmx_fit_migrad', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_static_poly', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -810,6 +847,58 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.vmx_sync(self._h))
+
+    def eval_device_mocks(self, d_theta_ptr, B, d_chi2_ptr, d_mock_ptr, d_status_ptr=None):
+        """``eval_device`` for walkers that bring their own mock rows: ``d_mock_ptr`` int32 [B] in device memory, per walker the
+        pool row it is compared with (include/vegamx.h: vmx_eval_device_mocks)."""
+        self._check(self.lib.vmx_eval_device_mocks(self._h, d_theta_ptr, B, d_chi2_ptr, d_status_ptr, d_mock_ptr))
+
+    def fit_migrad(self, plan, theta0, mock_rows=None, const_hint=-1, chunk=0, lanes=0):
+        """MIGRAD fits of ``theta0.shape[0]`` parameter rows on the device (include/vegamx.h: vmx_fit_migrad).  ``plan``:
+        :meth:`vega_amd.migrad.MigradMinimizer.plan` with ``free`` = indices into the engine's parameter columns; ``mock_rows``:
+        the pool row every fit is fitted to (None: the items' data).  Returns (per-stage result dicts, statistics of the run)."""
+        stages = plan['stages']
+        if not 1 <= len(stages) <= VMX_FIT_MAX_STAGES:
+            raise ValueError(f'1 .. {VMX_FIT_MAX_STAGES} Minuit objects per fit')
+        theta0 = _f64(theta0)
+        F = theta0.shape[0]
+        if theta0.ndim != 2 or theta0.shape[1] != self.n_params:
+            raise ValueError(f'theta0 must have {self.n_params} columns')
+        spec = FitSpec()
+        spec.n_stages, spec.n_params = len(stages), self.n_params
+        spec.iterate, spec.maxfcn, spec.up, spec.tol = int(plan['iterate']), int(plan['maxfcn']), float(plan['up']), float(plan['tol'])
+        for k, st in enumerate(stages):
+            free = np.asarray(st['free'], dtype=int)
+            if not 1 <= free.size <= VMX_FIT_MAXN:
+                raise NotImplementedError(f'{free.size} free parameters: the device-resident fits take 1 .. {VMX_FIT_MAXN} per Minuit object')
+            cs = spec.stage[k]
+            cs.n = free.size
+            for i, (j, lim, err) in enumerate(zip(free, st['limits'], st['errors'])):
+                lo, hi = (None, None) if lim is None else lim
+                lo = None if lo is None or not np.isfinite(lo) else float(lo)
+                hi = None if hi is None or not np.isfinite(hi) else float(hi)
+                cs.col[i], cs.has_lo[i], cs.has_hi[i] = int(j), int(lo is not None), int(hi is not None)
+                cs.lo[i], cs.hi[i], cs.err[i] = lo or 0., hi or 0., float(err)
+        outs, res = [], (FitResultArrays * len(stages))()
+        for k, st in enumerate(stages):
+            n = len(st['free'])
+            o = dict(x=np.zeros((F, n)), ext=np.zeros((F, n)), V=np.zeros((F, n, n)), fval=np.zeros(F), edm=np.zeros(F),
+                     flags=np.zeros(F, dtype=np.int32), nfcn=np.zeros(F, dtype=np.int64), n_iter=np.zeros(F, dtype=np.int32))
+            outs.append(o)
+            r = res[k]
+            r.x, r.ext, r.V, r.fval, r.edm = _dp(o['x']), _dp(o['ext']), _dp(o['V']), _dp(o['fval']), _dp(o['edm'])
+            r.flags, r.nfcn, r.n_iter = _ip(o['flags']), o['nfcn'].ctypes.data_as(C.POINTER(C.c_int64)), _ip(o['n_iter'])
+        rows = None if mock_rows is None else np.ascontiguousarray(mock_rows, dtype=np.int32)
+        if rows is not None and rows.shape != (F,):
+            raise ValueError('mock_rows: one pool row per fit')
+        opt = FitOptions(int(const_hint), int(chunk), int(lanes), 0)
+        stats = FitStats()
+        self._check(self.lib.vmx_fit_migrad(self._h, C.byref(spec), F, _dp(theta0), None if rows is None else _ip(rows),
+                                            C.byref(opt), res, C.byref(stats)))
+        info = {name: getattr(stats, name) for name, _ in FitStats._fields_ if not name.endswith('by_batch')}
+        info['calls_by_batch'] = dict(zip(FIT_BATCH_BINS, list(stats.calls_by_batch)))
+        info['evaluations_by_batch'] = dict(zip(FIT_BATCH_BINS, list(stats.evaluations_by_batch)))
+        return outs, info
 
     def set_constant_nl_hint(self, on=True, gaussian=False):
         """For ``eval_device``: the caller asserts that the Arinyo parameters - with ``gaussian`` also the smoothing,

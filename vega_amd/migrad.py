@@ -820,8 +820,7 @@ class MigradMinimizer:
         cov = np.zeros((F, P, P))
         values[np.ix_(ok, free_all)] = res['values'][ok]
         errors[np.ix_(ok, free_all)] = res['errors'][ok]
-        for f in np.flatnonzero(ok):
-            cov[f][np.ix_(free_all, free_all)] = res['cov'][f]
+        cov[np.ix_(np.flatnonzero(ok), free_all, free_all)] = res['cov'][ok]
         out = FitResult(names=self.names, values=values, errors=errors, covariance=cov, fval=np.where(ok, res['fval'], np.inf),
                         edm=np.where(ok, res['edm'], np.inf), is_valid=res['valid'] & ok, hesse_failed=res['hesse_failed'] | ~ok,
                         nfcn=nfcn, n_iter=n_iter)

@@ -14,6 +14,8 @@ instead of one MIGRAD after another, all mocks of a rank are minimised in lock-s
 :class:`vega_amd.minimizer.BatchedMinimizer`, each batch of trial points being one engine call with a per-walker mock
 index (``vmx_set_mock_index``).
 """
+import os
+
 import numpy as np
 
 from .minimizer import BatchedMinimizer
@@ -86,11 +88,20 @@ def create_mocks(problem, fiducial_model, num_mocks, seed=0, scale=None, forecas
     # the legacy global generator is consumed mock by mock, item by item (reference vega/data.py:748-757): n_masked
     # numbers per item, or the full data size with `cholesky-masked-cov = False`
     draws = {name: np.empty((num_mocks, chol[name].shape[0])) for name in problem.items}
-    for i in range(num_mocks):
-        for name in problem.items:
-            if reseed_per_item and seed is not None:
+    if reseed_per_item and seed is not None:
+        for i in range(num_mocks):
+            for name in problem.items:
                 np.random.seed(seed)
-            draws[name][i] = np.random.randn(chol[name].shape[0])
+                draws[name][i] = np.random.randn(chol[name].shape[0])
+    else:
+        # (the legacy generator's stream does not depend on how it is cut into calls - its cached second Gaussian of a pair goes on
+        # to the next call - so all draws come from ONE call and are dealt out in the reference's order: a mock's items side by side)
+        sizes = [chol[name].shape[0] for name in problem.items]
+        flat = np.random.randn(num_mocks * sum(sizes)).reshape(num_mocks, sum(sizes))
+        lo = 0
+        for name, n in zip(problem.items, sizes):
+            draws[name] = np.ascontiguousarray(flat[:, lo:lo + n])
+            lo += n
     out = {}
     for name, item in problem.items.items():
         noise = matmul(chol[name], draws[name])
@@ -142,6 +153,12 @@ class MonteCarlo:
         self.vega = vega
         self.has_monte_carlo = False
         self.current_mc_mock = None
+        # who advances the MIGRAD fits: 'device' - the state machines of vega_amd/csrc/vmx_migrad.h in the engine's fit kernels
+        # (parameter rows, chi2 and the fits' states stay in HBM, include/vegamx.h: vmx_fit_migrad) - or 'python' - the NumPy
+        # lock-step drivers of vega_amd/migrad.py through the engine's host entry (the readable reference; the only one for
+        # engine groups and for method='bfgs')
+        self.driver = os.environ.get('VEGA_AMD_FIT_DRIVER', 'device')
+        self.driver_stats = None
 
     def minimizer(self, sample_params=None, tol=0.1, method='migrad'):
         """Minimiser over ``sample_params`` (default: the interface's [sample] section) - ``method='migrad'``: MIGRAD's own
@@ -178,7 +195,16 @@ class MonteCarlo:
         self._fixed = tuple(n for n in names if sp.get('fix', {}).get(n, False))
         if method == 'migrad':
             from .migrad import MigradMinimizer
-            return MigradMinimizer(evaluate, names, start, errors, limits, tol=tol)
+            machine = None
+            if self.driver == 'device' and hasattr(eng, 'fit_migrad'):
+                def machine(plan, ext0, fit_ids):
+                    theta = np.tile(theta0, (ext0.shape[0], 1))
+                    theta[:, cols] = ext0
+                    on_engine = dict(plan, stages=[dict(st, free=cols[st['free']]) for st in plan['stages']])
+                    rows = None if self._mock_rows is None else self._mock_rows[np.asarray(fit_ids)]
+                    outs, self.driver_stats = eng.fit_migrad(on_engine, theta, rows)
+                    return outs
+            return MigradMinimizer(evaluate, names, start, errors, limits, tol=tol, machine=machine)
         if method != 'bfgs':
             raise ValueError("method: 'migrad' or 'bfgs'")
         return BatchedMinimizer(evaluate, names, start, errors, limits, tol=tol)
@@ -337,12 +363,14 @@ class MonteCarlo:
         try:
             res = fitter.minimize(n_fits=num_mocks, fixed=self._fixed)
         finally:
-            eng.set_mock_index(None)
+            if fitter.machine is None:          # (the device-resident fits state their rows per call, nothing is left on the engine)
+                eng.set_mock_index(None)
             self._mock_rows = None
             for name, item in prob.items.items():
                 if scales[name] != 1. and item.cov is not None and not vega._use_global_cov:
                     eng.set_invcov(name, item.chi2_matrix)
         self.fit_result = res
+        res.driver_stats = self.driver_stats if self.driver == 'device' else None
         # a fit that could not run has no Bestfit / covariance row and chisq = NaN (reference analysis.py:279-297)
         failed = ~np.isfinite(res.fval)
         ok = ~failed
