@@ -319,8 +319,11 @@ def coefmod_throughput(device, batch=256, steps=10, coef=2):
 
 def monte_carlo_fits(prob, device, n_mocks=1024):
     """One GPU's share of BASELINE configs[4] (8192 mocks over 8 GPUs): n_mocks Monte-Carlo realisations of the
-    bench workload, each fitted over (ap, at, bias_eta_LYA, beta_LYA, beta_QSO, bias_hcd) by the batched minimiser,
-    all in lock-step; mock generation (Cholesky factor x normal draws) included."""
+    bench workload, each fitted over (ap, at, bias_eta_LYA, beta_LYA, beta_QSO, bias_hcd) by MIGRAD - the bias pre-fit, then the
+    full fit, HESSE (reference vega/analysis.py:224-308 -> vega/minimizer.py:66-97) - all at once; mock generation (Cholesky
+    factor x normal draws) included.  `migrad`: the fits advanced on the device (vmx_fit_migrad); `migrad_numpy_driver`: the
+    same fits advanced in lock-step by the NumPy driver through the host entry (round 4's path); `bfgs`: the vectorised
+    variable-metric minimiser (Minuit's conventions, not its trajectory)."""
     from vega_amd import VegaInterface
     vega = VegaInterface(None, problem=prob, max_batch=4096, device=device)
     vega.chi2()
@@ -333,18 +336,38 @@ def monte_carlo_fits(prob, device, n_mocks=1024):
     truth = np.array([vega.params[n] for n in names])
     out = {'workload': f'{n_mocks} mocks x {len(names)}-parameter fits (mock generation + minimisation + Hessian), after an untimed '
                        '128-mock run of the same call (buffers of the mock pool, clocks)'}
-    vega.run_monte_carlo(num_mocks=128, seed=5, sample_params=sample, method='migrad')
-    # 'migrad': MIGRAD's own sequence of steps per fit (vega_amd/migrad.py - what the reference runs through iminuit), the fits
-    # advancing in lock-step; 'bfgs': the vectorised variable-metric minimiser (Minuit's conventions, not its trajectory)
-    for method in ('migrad', 'bfgs'):
-        t0 = time.perf_counter()
-        res = vega.run_monte_carlo(num_mocks=n_mocks, seed=11, sample_params=sample, method=method)
-        dt = time.perf_counter() - t0
-        pulls = (res.values - truth) / res.errors
-        out[method] = {'fits_per_s': n_mocks / dt, 'seconds': dt, 'chi2_evaluations': int(res.nfcn.sum()),
-                       'evals_per_fit': float(res.nfcn.mean()), 'valid_fraction': float(res.is_valid.mean()),
-                       'pull_rms': [float(v) for v in pulls.std(axis=0)]}
+    saved = os.environ.get('VEGA_AMD_FIT_DRIVER')
+    try:
+        for label, method, driver in (('migrad', 'migrad', 'device'), ('migrad_numpy_driver', 'migrad', 'python'), ('bfgs', 'bfgs', 'python')):
+            os.environ['VEGA_AMD_FIT_DRIVER'] = driver
+            vega.run_monte_carlo(num_mocks=128, seed=5, sample_params=sample, method=method)
+            t0 = time.perf_counter()
+            res = vega.run_monte_carlo(num_mocks=n_mocks, seed=11, sample_params=sample, method=method)
+            dt = time.perf_counter() - t0
+            pulls = (res.values - truth) / res.errors
+            out[label] = {'fits_per_s': n_mocks / dt, 'seconds': dt, 'chi2_evaluations': int(res.nfcn.sum()),
+                          'evals_per_fit': float(res.nfcn.mean()), 'valid_fraction': float(res.is_valid.mean()),
+                          'pull_rms': [float(v) for v in pulls.std(axis=0)]}
+            st = getattr(res, 'driver_stats', None)
+            if st:
+                # the driver's own account: the GPU is idle while the host takes its turn of a round (HIP events around it) and
+                # outside the rounds (mock generation, the quadratic form's linear terms of the new pool, results)
+                idle = st['gpu_idle_seconds_between_rounds'] + (dt - st['seconds_rounds'])
+                out[label].update({'rounds': st['rounds'], 'engine_calls': st['engine_calls'],
+                                   'seconds_in_rounds': st['seconds_rounds'], 'gpu_idle_seconds_between_rounds': st['gpu_idle_seconds_between_rounds'],
+                                   'evals_per_s_in_rounds': st['evaluations'] / st['seconds_rounds'],
+                                   'engine_calls_by_batch_size': st['calls_by_batch'], 'evaluations_by_batch_size': st['evaluations_by_batch'],
+                                   'host_fraction': idle / dt})
+    finally:
+        if saved is None:
+            os.environ.pop('VEGA_AMD_FIT_DRIVER', None)
+        else:
+            os.environ['VEGA_AMD_FIT_DRIVER'] = saved
     out['fits_per_s'] = out['migrad']['fits_per_s']
+    out['host_fraction'] = out['migrad'].get('host_fraction')
+    out['host_fraction_note'] = ('share of the run during which the GPU had nothing of it to do: everything outside the rounds of the '
+                                 'device-resident fits + the host\'s turn of every round (HIP events on the stream); the kernel-trace '
+                                 'view of the same run: profiles/r05_mc_fits_timeline.txt')
     vega.close()
     return out
 
@@ -419,7 +442,8 @@ def cpu_baseline(workload, names, theta, repeats=7, warmups=2, extra_theta=None)
             'one_core_value': single,
             'sample': f'{workers} worker processes (1 BLAS thread each) x 1 walker per repeat, median of {repeats} repeats '
                       f'after {warmups} warm-ups ({med * 1e3:.0f} ms per repeat), {len(done)} distinct walkers of the same '
-                      f'workload, oracle/vega_cpu.py chi2; {total:.1f} s in all'}, done, [vals[i] for i in done], extra_vals
+                      f'workload, oracle/vega_cpu.py chi2; {total:.1f} s in all; {workers} of the host\'s {cores} cores: a one-GPU box of the '
+                      'pool allows 16 worker processes (more are killed by its process guard)'}, done, [vals[i] for i in done], extra_vals
 
 
 def launch_ranks(args):
@@ -444,16 +468,26 @@ def launch_ranks(args):
         env.setdefault('OMP_NUM_THREADS', '1')
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env, cwd=str(REPO),
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    # rank 0's stdout is drained by a reader thread while the ranks are polled: the other ranks sit in the final barrier until rank
+    # 0 has written its line, and a line larger than the pipe's buffer (64 KB; it is ~15 KB today and grows) must not block it
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     failed = None
-    while failed is None and any(p.poll() is None for p in procs[1:]):
+    deadline = time.time() + float(os.environ.get('VEGA_BENCH_RANKS_TIMEOUT', 3300))
+    while failed is None and any(p.poll() is None for p in procs):
         for r, p in enumerate(procs):
             if p.poll() not in (None, 0):
                 failed = r
-        # (rank 0 writes one line: the pipe cannot fill up while it is not read)
+        if failed is None and time.time() > deadline:
+            sys.stderr.write('bench.py: the ranks did not finish in time\n')
+            failed = next(r for r, p in enumerate(procs) if p.poll() is None)
         time.sleep(0.2)
     line = b''
     if failed is None:
-        line, _ = procs[0].communicate()
+        reader.join(timeout=30)
+        line = b''.join(chunks)
         failed = next((r for r, p in enumerate(procs) if p.wait() != 0), None)
     if failed is not None:
         for p in procs:
@@ -466,7 +500,7 @@ def launch_ranks(args):
                 p.kill()
                 p.wait()
         sys.stderr.write(f'bench.py: rank {failed} exited with code {procs[failed].returncode}\n')
-        return procs[failed].returncode or 1
+        return procs[failed].returncode or 1        # (a rank ended for running too long has a negative code: 1 is returned)
     sys.stdout.write(line.decode())
     sys.stdout.flush()
     return 0
@@ -932,6 +966,7 @@ def main():
             roofline['traffic'] = traffic[roof_class]['hbm_bytes_per_launch']
             roofline['traffic_unit'] = f'bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_file.name})'
             roofline['algorithmic_bytes_per_launch'] = traffic[roof_class]['algorithmic_bytes_per_launch']
+            roofline['traffic_over_algorithmic'] = roofline['traffic'] / roofline['algorithmic_bytes_per_launch']
             # the counter passes belong to the kernel as it was when they were collected: their launch duration travels with
             # them, and a live duration that has moved away from it says the file is due for a refresh
             collected_us = traffic[roof_class].get('avg_us_kernel_trace_run')
@@ -978,6 +1013,13 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': WORKLOAD_TEXT[args.workload].format(B=B, total=B * world),
                        'batch_per_gpu': B, 'batches_in_flight': L, 'pipelines_per_eval': len(eng.pipe_index),
+                       'chi2_only': True, 'walkers_share_nl_parameters': True,
+                       'full_chain_evals_per_s': ((other_paths or {}).get('full_chain') or {}).get('evals_per_s'),
+                       'general_walkers_evals_per_s': ((other_paths or {}).get('general_walkers') or {}).get('evals_per_s'),
+                       'single_lane_evals_per_s': (single_lane or {}).get('value'),
+                       'fine_print': '`value`: chi2 only (static quadratic form, no model vector written), two independent batches in flight, walkers '
+                                     'sharing their Arinyo / smoothing parameters; the same workload with the model written: full_chain_evals_per_s; '
+                                     'with walkers that vary those parameters too: general_walkers_evals_per_s; one batch in flight: single_lane_evals_per_s',
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': communicator if use_dist else 'none',
                        'steady_state': f'untimed before the timed region: {args.ramp_steps} ramp steps, a calibration pass, 20-step '

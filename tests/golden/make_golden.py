@@ -688,11 +688,15 @@ def dump_marginalization(VegaInterface):
             out[f'{tag}/log_lik'] = vega.log_lik()
             out[f'{tag}/num_marg_modes'] = data.num_marg_modes
             out[f'{tag}/cov_update_trace'] = np.trace(data.cov_marg_update)
+            # what the result file writes as <name>_VAR (vega/output.py:197): `Data.variance` is a live view of the covariance's
+            # diagonal (data.py:85), so the update added in place at data.py:107 shows in it
+            out[f'{tag}/variance'] = np.array(data.variance)
             print('marginalization', tag, out[f'{tag}/chi2'], out[f'{tag}/log_lik'], data.num_marg_modes)
             # the same templates fitted on the fly instead (control: marginalize-in-fit)
             mp = Path(main)
             mp.write_text(mp.read_text().replace('[control]', '[control]\nmarginalize-in-fit = True'))
             vega = VegaInterface(main)
+            out[f'{tag}/infit/variance'] = np.array(vega.data['lyalya_lyalya'].variance)
             out[f'{tag}/infit/chi2'] = vega.chi2()
             out[f'{tag}/infit/log_lik'] = vega.log_lik()
             names, walkers = make_walkers(vega.params, 1, seed=WALKER_SEED + 4)

@@ -457,6 +457,8 @@ def test_small_scale_marginalization_matches_reference(tmp_path, tag):
     exp = np.load(GOLDEN / 'expected_marginalization.npz')
     item = prob.items['lyalya_lyalya']
     assert np.trace(item.cov_marg_update) == pytest.approx(float(exp[f'{tag}/cov_update_trace']), rel=1e-10)
+    # the variance the result file writes (<name>_VAR): the reference's is a live view of the UPDATED covariance's diagonal
+    np.testing.assert_allclose(item.variance, exp[f'{tag}/variance'], rtol=1e-9)
     assert oc.chi2(prob) == pytest.approx(float(exp[f'{tag}/chi2']), rel=1e-8)
     assert oc.log_lik(prob) == pytest.approx(float(exp[f'{tag}/log_lik']), rel=1e-8)
 
@@ -469,6 +471,7 @@ def test_marginalize_in_fit_matches_reference(tmp_path, tag):
     from conftest import marginalization_problem, MARGINALIZATION_CASES
     prob = marginalization_problem(tmp_path, MARGINALIZATION_CASES[tag], in_fit=True)
     exp = np.load(GOLDEN / 'expected_marginalization.npz')
+    np.testing.assert_allclose(prob.items['lyalya_lyalya'].variance, exp[f'{tag}/infit/variance'], rtol=1e-12)      # (no update in fit)
     assert oc.chi2(prob) == pytest.approx(float(exp[f'{tag}/infit/chi2']), rel=1e-9)
     assert oc.log_lik(prob) == pytest.approx(float(exp[f'{tag}/infit/log_lik']), rel=1e-9)
     pars = {str(n): float(v) for n, v in zip(exp[f'{tag}/infit/param_names'], exp[f'{tag}/infit/theta'][0])}

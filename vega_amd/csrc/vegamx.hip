@@ -3220,19 +3220,23 @@ int vmx_set_direct_pk(vmx_engine* e, const double* pk, int32_t B, int32_t nk)
         REQUIRE(!(m->dev.d.in_direct && m->dev.d.pipeline >= 0 && e->pipes[m->dev.d.pipeline].poly_basis >= 0),
                 "direct_pk: a metal pair that enters the direct model sits on a static basis of the template's spectra - build the "
                 "engine with vmx_set_static_poly(e, 0)");
-    if (e->pk_direct.n < (size_t)e->max_batch * e->nkp && e->pk_direct.alloc((size_t)e->max_batch * e->nkp, true)) return -2;
-    HIP_OK(hipMemcpy2D(e->pk_direct.p, (size_t)e->nkp * sizeof(double), pk, (size_t)nk * sizeof(double),
-                       (size_t)nk * sizeof(double), B, hipMemcpyHostToDevice));
-    e->direct = true;
-    e->dev.pk_direct = e->pk_direct.p;       // every kernel of the chain takes its EngineDev from e->dev
-    // the odd-multipole terms read the caller's spectrum too: the walkers' spline coefficients = operator . spectrum
+    // (every check before any state changes: a refused call leaves the engine as it was)
     for (auto& p : e->pipes)
         REQUIRE(!(p.odd_rel || p.odd_asy) || p.odd_dyn_off >= 0,
                 "direct_pk: a pipeline with odd-multipole terms needs their operator form (vmx_pipeline_set_odd_operator)");
+    if (e->pk_direct.n < (size_t)e->max_batch * e->nkp && e->pk_direct.alloc((size_t)e->max_batch * e->nkp, true)) return -2;
+    HIP_OK(hipMemcpy2D(e->pk_direct.p, (size_t)e->nkp * sizeof(double), pk, (size_t)nk * sizeof(double),
+                       (size_t)nk * sizeof(double), B, hipMemcpyHostToDevice));
+    // the odd-multipole terms read the caller's spectrum too: the walkers' spline coefficients = operator . spectrum
     for (auto& kv : e->odd_op_off) {
         const PipeDev& p = e->pipes[kv.first];
-        if (vmx_matvec_device(e, e->odd_op.p + kv.second, 4 * p.odd_ncoef, e->nkp, e->pk_direct.p, B, e->odd_dyn.p + p.odd_dyn_off)) return -2;
+        if (vmx_matvec_device(e, e->odd_op.p + kv.second, 4 * p.odd_ncoef, e->nkp, e->pk_direct.p, B, e->odd_dyn.p + p.odd_dyn_off)) {
+            e->direct = false; e->dev.pk_direct = nullptr;      // (a failed product: back to the template)
+            return -2;
+        }
     }
+    e->direct = true;
+    e->dev.pk_direct = e->pk_direct.p;       // every kernel of the chain takes its EngineDev from e->dev
     return 0;
 }
 

@@ -229,8 +229,8 @@ class VegaInterface:
                 if getattr(self.engine, 'static_poly', True):
                     self._rebuild_engine(static_poly=False)
             engine = self.engine
-            engine.set_direct_pk(direct_pk)
             try:
+                engine.set_direct_pk(direct_pk)
                 yield
             finally:
                 engine.set_direct_pk(None)

@@ -287,6 +287,11 @@ class MonteCarlo:
                 # term as the reference writes it: log(scale) + log det C)
                 view.scaled_inv_masked_cov = item.inv_masked_cov / scales[name]      # (marginalize-in-fit: projected when it is sent)
                 view.scaled_log_cov_det = np.log(scales[name]) + item.log_cov_det
+            elif not vega._use_global_cov and item.cov is not None and getattr(view, 'scaled_inv_masked_cov', None) is not None:
+                # (the reference resets both on every call, data.py:711-722: a scale of 1 after another scale must not keep the
+                # other scale's matrix on the view - _sync_monte_carlo would leave it on the engine)
+                view.scaled_inv_masked_cov = item.inv_masked_cov
+                view.scaled_log_cov_det = item.log_cov_det
             full = np.full(item.data_vec.size, np.nan)
             full[item.data_mask] = pool[0]
             out[name] = full

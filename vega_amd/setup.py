@@ -844,6 +844,9 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
                                                        prior_sigma=prior_sigma, match_data_bins=match_bins)
         if not marginalize_in_fit:
             cov[np.ix_(data_mask, data_mask)] += update
+            # (the reference's `variance` is a live view of the covariance's diagonal, vega/data.py:85: the in-place update of
+            # data.py:107 shows in what the result file writes as <name>_VAR)
+            variance = np.array(np.diag(cov), dtype=float)
 
     # the reference injects the data bin sizes into the [model] / [metals] sections
     # (reference vega/model.py:38-39, vega/metals.py:119-123)
