@@ -290,6 +290,12 @@ int vmx_item_set_data(vmx_engine* e, int32_t item, const double* masked_data, in
  * vmx_finalize; the index array applies to the following vmx_eval* calls. */
 int vmx_item_set_mock_pool(vmx_engine* e, int32_t item, const double* pool, int32_t n_mocks, int32_t n_masked);
 int vmx_set_mock_index(vmx_engine* e, const int32_t* index, int32_t B);
+/* Mocks made on the device: the lower Cholesky factor L [n_masked][n_masked] of the (scaled) masked covariance and the fiducial
+ * model on the masked bins - a mock is fiducial + L . (standard-normal draws), reference vega/data.py:737-753.  Kept until replaced;
+ * used by vmx_fit_migrad with a mock stream.  vmx_item_get_mock_pool copies the first n_mocks rows of an item's pool to the host
+ * (the MOCKS table of the result file, reference vega/output.py:442-520). */
+int vmx_item_set_mock_factor(vmx_engine* e, int32_t item, const double* chol, const double* fiducial, int32_t n_masked);
+int vmx_item_get_mock_pool(vmx_engine* e, int32_t item, double* pool, int32_t n_mocks, int32_t n_masked);
 
 /* Global-covariance mode (vega_interface.py:295-304): inverse of the masked global covariance over
  * the concatenation of all items' masked bins, in item order. */
@@ -350,7 +356,8 @@ int vmx_eval_device_mocks(vmx_engine* e, const double* d_theta, int32_t B, doubl
  *   mock_row  [n_fits] host or NULL: the pool row (vmx_item_set_mock_pool) fit f is fitted to; NULL: the items' data
  *   opt       const_hint = vmx_set_constant_nl_hint's level for the rows of a round, or -1: derived here (a column varies when a
  *             stage frees it or the fits' rows differ in it - what vmx_eval derives from host walkers); NULL: -1, 512, 2;
- *             chunk = rows per engine call (0: 512); lanes = batches in flight (0: 2)
+ *             chunk = rows per engine call (0: 512); lanes = batches in flight (0: 2); mocks: see vmx_mock_stream (NULL: the
+ *             pools hold the mocks already)
  *   results   [n_stages] host arrays the caller owns: x [n_fits][n] internal minimum, ext [n_fits][n] its external values,
  *             V [n_fits][n][n] internal error matrix, fval, edm, flags (VMX_FIT_* bits), nfcn (function calls of the stage, re-runs
  *             included), n_iter
@@ -370,7 +377,21 @@ typedef struct {
     double up, tol;
     vmx_fit_stage stage[VMX_FIT_MAX_STAGES];
 } vmx_fit_spec;
-typedef struct { int32_t const_hint, chunk, lanes, reserved; } vmx_fit_options;
+/* Mocks made while their fits run (vmx_fit_migrad): the normal draws arrive from a producer on the host - the reference draws them
+ * from NumPy's legacy global generator, mock after mock, a mock's correlations in turn (vega/data.py:748-757), and that stream is
+ * sequential by construction - while everything else of a mock happens on the device, wave by wave: mock = fiducial + L . draws
+ * with the chain's product kernels (L, fiducial: vmx_item_set_mock_factor), its row of every item's pool, its rows of the
+ * quadratic form's linear terms.  Wave w (mocks [w wave, (w + 1) wave)) joins the fits at round w - a fixed schedule: what a round
+ * evaluates never depends on how fast the draws arrive; the host waits for the producer when it is behind. */
+typedef struct {
+    int32_t n_mocks;                    /* = n_fits: fit f is fitted to mock f */
+    int32_t wave;                       /* mocks per wave (0: 64) */
+    const double* draws;                /* host [n_mocks][stride]: a mock's standard-normal draws, its items' side by side in item order */
+    int64_t stride;
+    const volatile int32_t* n_drawn;    /* host: mocks whose draws are complete (the producer counts up, release order) */
+    double timeout_seconds;             /* give up when the producer stalls (0: 600) */
+} vmx_mock_stream;
+typedef struct { int32_t const_hint, chunk, lanes, reserved; const vmx_mock_stream* mocks; } vmx_fit_options;
 typedef struct {
     double* x; double* ext; double* V; double* fval; double* edm;
     int32_t* flags; int64_t* nfcn; int32_t* n_iter;
@@ -382,6 +403,8 @@ typedef struct {
     double seconds, seconds_setup, seconds_rounds;
     double seconds_host_waiting;        /* of seconds_rounds: the host blocked on the stream (the GPU working) */
     double gpu_idle_seconds_between_rounds;     /* HIP events around the host's turn of every round: the stream empty */
+    double seconds_waiting_for_draws;   /* mock stream: the host waiting for the producer at a wave's round */
+    double seconds_enqueuing_waves;     /* mock stream: host time of the waves' copies and launches */
 } vmx_fit_stats;
 int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, const double* theta0, const int32_t* mock_row,
                    const vmx_fit_options* opt, vmx_fit_result* results, vmx_fit_stats* stats);

@@ -24,7 +24,8 @@ def _run_mc(vega, n_mocks, seed, driver, **kw):
     from vega_amd.montecarlo import MonteCarlo
     vega.freeze_metals()
     mc = MonteCarlo(vega)
-    mc.driver = driver
+    mc.driver = 'python' if driver == 'python' else 'device'
+    mc.stream_mocks = driver == 'streamed'          # (the mocks made while their fits run: include/vegamx.h vmx_mock_stream)
     vega.analysis = mc
     if id(vega) not in _FID:        # (one fiducial model for both drivers: a single walker's path through the engine depends on
         _FID[id(vega)] = vega.compute_model()       # what the tables hold from earlier calls - equal to 1e-16, not bitwise)
@@ -78,10 +79,51 @@ def test_device_fits_equal_the_numpy_driver_on_monte_carlo_mocks():
     assert sum(st['evaluations_by_batch'].values()) == st['evaluations']
     assert st['gpu_idle_seconds_between_rounds'] < 0.25 * st['seconds_rounds']
     assert a.driver_stats is None
-    # a rescaled covariance, rows handed out of order (fit i <- pool row i all the same), chunks smaller than a round
+    # a rescaled covariance
     mc_c, c = _run_mc(vega, 20, 5, 'python', scale=1.7)
     mc_d, d = _run_mc(vega, 20, 5, 'device', scale=1.7)
     _assert_same_fits(c, d)
+    vega.close()
+
+
+def test_mocks_made_while_their_fits_run():
+    """`run_monte_carlo` with the mock stream (the default of the device driver): the normal draws come from a host thread in the
+    reference's order (vega/data.py:748-757), the mocks are formed on the device wave by wave and join the fits on a fixed
+    schedule.  Same mocks as `create_mocks` to rounding, same fits, the same results again (nothing depends on how fast the
+    draws arrive), waves that do not divide the number of mocks, a rescaled covariance."""
+    from vega_amd import VegaInterface
+    prob = synth_joint_problem()
+    names = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'bias_hcd']
+    _sample(prob, names, [(0.5, 1.5), (0.5, 1.5), (-2., 0.), (0., 5.), (0., 1.), (-0.5, 0.)], [0.01, 0.01, 0.01, 0.1, 0.1, 0.01])
+    vega = VegaInterface(None, problem=prob, max_batch=256)
+    n = 150                     # (two full waves of 64 and one of 22)
+    mc_a, a = _run_mc(vega, n, 3, 'python')
+    mc_b, b = _run_mc(vega, n, 3, 'streamed')
+    for name in prob.items:
+        assert mc_b.mc_mocks[name].shape == mc_a.mc_mocks[name].shape
+        scale = np.abs(mc_a.mc_mocks[name]).max()
+        np.testing.assert_allclose(mc_b.mc_mocks[name], mc_a.mc_mocks[name], rtol=0, atol=1e-13 * scale)
+    _assert_same_fits(a, b, flips=1)
+    st = b.driver_stats
+    assert st['evaluations'] == int(b.nfcn.sum()) and st['fits_unfinished'] == 0 and st['rounds'] < 110
+    assert st['seconds_waiting_for_draws'] < 0.5 * st['seconds']
+    mc_c, c = _run_mc(vega, n, 3, 'streamed')
+    for name in prob.items:
+        np.testing.assert_array_equal(mc_c.mc_mocks[name], mc_b.mc_mocks[name])
+    np.testing.assert_array_equal(c.nfcn, b.nfcn)
+    np.testing.assert_array_equal(c.values, b.values)
+    np.testing.assert_array_equal(c.fval, b.fval)
+    # the mocks read back are the data the fits saw: chi2 of a best fit against its mock through the host entry
+    eng = vega.engine
+    for f in (0, 70, 149):
+        for name in prob.items:
+            eng.set_data(name, mc_b.mc_mocks[name][f])
+        assert vega.chi2(dict(zip(b.names, b.values[f]))) == pytest.approx(b.fval[f], rel=1e-10)
+    for name, item in prob.items.items():
+        eng.set_data(name, item.masked_data_vec)
+    _, d = _run_mc(vega, 40, 8, 'python', scale=2.5)
+    _, e = _run_mc(vega, 40, 8, 'streamed', scale=2.5)
+    _assert_same_fits(d, e, flips=1)
     vega.close()
 
 

@@ -7,8 +7,10 @@
 #include "vmx_device.h"
 #include "vmx_fit.h"
 
+#include <atomic>
 #include <cmath>
 #include <chrono>
+#include <thread>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -125,6 +127,11 @@ struct ItemHost {
     // ... in its factored form (vmx_set_quadratic_form_kind): U with C^-1 = U^T U [n_masked][n_masked_pad], F = U S DM'
     // [n_masked][nq_pad], u0 = U r0 per data vector / mock [rows][n_masked_pad], slabs of F dx [slab_rows][n_masked_pad]
     DevBuf<double> q_u, q_f, q_u0, q_y;
+    // mocks made on the device (vmx_item_set_mock_factor, vmx_fit_migrad with a mock stream): Cholesky factor [n_masked][pad] and
+    // fiducial [pad]; the full C^-1 and the masked reference model of the quadratic form, kept for the per-wave linear terms;
+    // per-wave scratch (draws, noise, residual rows, C^-1 rows)
+    DevBuf<double> mc_chol, mc_fid, q_cfull, q_m0, mc_z, mc_noise, mc_r0, mc_t;
+    bool has_factor = false;
     std::vector<double> h_q_c0;         // host copy of q_c0 (the single-walker chain adds the constants on the host)
     DevBuf<int64_t> q_basis_off;
     int q_rows = 0;                     // rows of q_lin / q_c0 (1 + mocks)
@@ -1284,6 +1291,34 @@ int vmx_item_set_mock_pool(vmx_engine* e, int32_t item, const double* pool, int3
     it->dev.mock_pool = it->mock_pool.p;
     // the item table lives in device memory: patch this item's entry
     HIP_OK(hipMemcpy(e->d_items.p + item, &it->dev, sizeof(ItemDev), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int vmx_item_set_mock_factor(vmx_engine* e, int32_t item, const double* chol, const double* fiducial, int32_t n_masked)
+{
+    REQUIRE(e && e->finalized && chol && fiducial, "vmx_item_set_mock_factor (after vmx_finalize)");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(n_masked == it->dev.n_masked, "mock factor: [n_masked][n_masked]");
+    HIP_OK(hipSetDevice(e->device));
+    wait_lane(e);
+    HIP_OK(hipStreamSynchronize(e->stream));
+    const int nmp = it->dev.n_masked_pad;
+    if (upload_padded(it->mc_chol, chol, n_masked, n_masked, nmp) || upload_padded(it->mc_fid, fiducial, 1, n_masked, nmp)) return -2;
+    it->has_factor = true;
+    return 0;
+}
+
+int vmx_item_get_mock_pool(vmx_engine* e, int32_t item, double* pool, int32_t n_mocks, int32_t n_masked)
+{
+    REQUIRE(e && e->finalized && pool, "vmx_item_get_mock_pool");
+    REQUIRE(item >= 0 && item < (int)e->items.size(), "item id");
+    ItemHost* it = e->items[item];
+    REQUIRE(n_mocks > 0 && n_mocks <= it->n_mocks && n_masked == it->dev.n_masked && it->mock_pool.p, "mock pool shape");
+    HIP_OK(hipSetDevice(e->device));
+    wait_lane(e);
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipMemcpy(pool, it->mock_pool.p, (size_t)n_mocks * n_masked * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -2749,11 +2784,13 @@ static int quad_build(vmx_engine* e)
 
         DevBuf<int32_t> midx;
         if (midx.upload(it->mask_idx.data(), it->mask_idx.size())) return -2;
-        DevBuf<double> cfull;
+        DevBuf<double>& cfull = it->q_cfull;       // (kept: the linear terms of mocks that arrive later need it, vmx_fit_migrad)
         if (it->has_cinv) {
-            if (cfull.alloc((size_t)nm * nmp, true)) return -2;
+            if (cfull.n < (size_t)nm * nmp && cfull.alloc((size_t)nm * nmp, true)) return -2;
             hipLaunchKernelGGL(k_sym_from_half, dim3((nm + 255) / 256, nm), dim3(256), 0, e->stream, cfull.p, it->cinv.p, nm, nmp);
         }
+        if (it->q_m0.n < (size_t)nmp && it->q_m0.alloc((size_t)nmp, true)) return -2;
+        hipLaunchKernelGGL(k_mask_gather, dim3((nm + 255) / 256), dim3(256), 0, e->stream, it->q_m0.p, (const double*)(e->model.p + d.model_off), midx.p, nm);
         if (e->quad_factored && (e->quad_mat_dirty || it->q_f.p == nullptr)) {
             // F = U X^T with C^-1 = U^T U: the Cholesky factor of the inverse covariance on the host (vmx_plan.h; n^3 / 3 flops,
             // a second for n = 3180 - set-up, redone only when the covariance changes)
@@ -3052,7 +3089,24 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
         }
         max_req = std::max(max_req, vmx_migrad::max_request(st.n));
     }
-    if (mock_row)
+    const vmx_mock_stream* ms = opt ? opt->mocks : nullptr;
+    int wave = 0, n_waves = 0;
+    std::vector<int64_t> draw_off;          // column of every item's draws in a mock's row
+    if (ms) {
+        // mocks made while the fits run: fit f is fitted to pool row f, admitted with its wave
+        REQUIRE(ms->n_mocks == n_fits && ms->draws && ms->n_drawn && !e->gcinv.p, "vmx_fit_migrad: a mock stream makes one mock per fit (no global covariance)");
+        int64_t off = 0;
+        for (auto* it : e->items) {
+            REQUIRE(it->has_factor && it->has_mask, "vmx_fit_migrad: vmx_item_set_mock_factor for every item first");
+            draw_off.push_back(off);
+            off += it->dev.n_masked;
+        }
+        REQUIRE(ms->stride >= off, "vmx_fit_migrad: the draws of a mock are its items' side by side");
+        wave = ms->wave > 0 ? ms->wave : 64;
+        n_waves = (n_fits + wave - 1) / wave;
+        if (mock_row) for (int f = 0; f < n_fits; ++f) REQUIRE(mock_row[f] == f, "vmx_fit_migrad: with a mock stream fit f takes pool row f");
+    }
+    else if (mock_row)
         for (int f = 0; f < n_fits; ++f)
             for (auto* it : e->items) REQUIRE(mock_row[f] < 0 || mock_row[f] < it->n_mocks, "vmx_fit_migrad: mock row exceeds the pool");
     const int chunk = std::max(1, std::min(opt && opt->chunk > 0 ? opt->chunk : 512, e->max_batch));
@@ -3079,6 +3133,29 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
 
     const int F = n_fits, P = e->n_params;
     const size_t cap = (size_t)F * max_req;
+    std::vector<int32_t> own_rows;
+    if (ms) {
+        // pools of n_fits rows, to be filled wave by wave (rows that have not arrived are zeros: nothing reads them before their
+        // fits are admitted); the quadratic form's per-mock terms are sized for them by the build the first evaluation triggers
+        drop_lane(e);
+        for (size_t q = 0; q < e->items.size(); ++q) {
+            ItemHost* it = e->items[q];
+            const size_t need = (size_t)n_fits * it->dev.n_masked;
+            if (it->mock_pool.n < need || it->n_mocks != n_fits) {
+                if (it->mock_pool.n < need && it->mock_pool.alloc(need, true)) return -2;
+                it->n_mocks = n_fits;
+                it->dev.mock_pool = it->mock_pool.p;
+                HIP_OK(hipMemcpy(e->d_items.p + q, &it->dev, sizeof(ItemDev), hipMemcpyHostToDevice));
+            }
+            e->quad_lin_dirty = true;
+            const size_t rows = (size_t)wave * it->dev.n_masked_pad;
+            if (ensure(it->mc_z, rows) || ensure(it->mc_noise, rows) || ensure(it->mc_r0, rows) || ensure(it->mc_t, rows)) return -2;
+            HIP_OK(hipMemset(it->mc_z.p, 0, rows * sizeof(double)));       // (the pad columns of the draws stay zero)
+        }
+        own_rows.resize(n_fits);
+        for (int f = 0; f < n_fits; ++f) own_rows[f] = f;
+        mock_row = own_rows.data();
+    }
     if (!e->fitws) e->fitws = new FitWorkspace();
     FitWorkspace& W = *e->fitws;
     const int fit_cap = n_max <= 4 ? 4 : n_max <= 8 ? 8 : n_max <= 16 ? 16 : 32;
@@ -3108,7 +3185,7 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
     for (int s = 0; s < spec->n_stages; ++s)
         D.out[s] = vmx_migrad::StageOut{W.ox[s].p, W.oext[s].p, W.oV[s].p, W.ofval[s].p, W.oedm[s].p, W.oflags[s].p, W.onfcn[s].p, W.oiter[s].p};
     D.count = W.count.p; D.offset = W.offset.p; D.done = W.done.p; D.theta = W.theta.p; D.mock = W.mock.p; D.chi2 = W.chi2.p;
-    D.host_word = W.dpin_word; D.F = F; D.P = P; D.admitted = F;
+    D.host_word = W.dpin_word; D.F = F; D.P = P; D.admitted = ms ? 0 : F;
 
     // the engine as the fits' objective: chi2-only device evaluations of the round's rows, eager launches, two lanes when the
     // quadratic form serves them; the table level the caller vouches for
@@ -3127,7 +3204,55 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
     const auto t_loop = std::chrono::steady_clock::now();
     double wait_s = 0.0;
     size_t gap_used = 0;
+    int next_wave = 0;
+    double producer_wait_s = 0.0, wave_host_s = 0.0;
+    bool quad_form = false;
+    if (ms && quad_ready(e, &quad_form, chunk)) return -2;       // (the form's tensors, with room for every mock's terms)
     for (;;) {
+        if (ms && next_wave < n_waves) {
+            // Wave `next_wave` joins at this round - a fixed schedule (one wave per round from the start), so that the rounds'
+            // batches, hence every bit of every chi2, do not depend on how fast the draws arrive; the host waits for the producer
+            // when it is behind.  The wave's mocks = fiducial + L . draws with the chain's product kernels (reference
+            // vega/data.py:751-753), then their rows of the quadratic form's linear terms and constants, all on the stream
+            // ahead of the round's bookkeeping.
+            const int a = next_wave * wave, b = std::min(n_fits, a + wave), cnt = b - a;
+            const auto t_p0 = std::chrono::steady_clock::now();
+            const double limit = ms->timeout_seconds > 0.0 ? ms->timeout_seconds : 600.0;
+            while (*ms->n_drawn < b) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count() > limit)
+                    return fail(-2, "vmx_fit_migrad: the producer of the mock draws stalled");
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            producer_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count();
+            std::atomic_thread_fence(std::memory_order_acquire);
+            e->cur = st;
+            for (size_t q = 0; q < e->items.size(); ++q) {
+                ItemHost* it = e->items[q];
+                const ItemDev& d = it->dev;
+                const int nm = d.n_masked, nmp = d.n_masked_pad;
+                HIP_OK(hipMemcpy2DAsync(it->mc_z.p, (size_t)nmp * sizeof(double), ms->draws + (size_t)a * ms->stride + draw_off[q],
+                                        (size_t)ms->stride * sizeof(double), (size_t)nm * sizeof(double), cnt, hipMemcpyHostToDevice, st));
+                launch_product(e, KC_OTHER, it->mc_chol.p, nmp, 0, nm, nmp, it->mc_z.p, nmp, 0, cnt, it->mc_noise.p, nmp, 0, 1, cnt);
+                hipLaunchKernelGGL(k_mock_rows, dim3((nm + 255) / 256, cnt), dim3(256), 0, st, it->mock_pool.p + (size_t)a * nm,
+                                   quad_form ? it->mc_r0.p : (double*)nullptr, nmp, (const double*)it->mc_noise.p, (const double*)it->mc_fid.p,
+                                   (const double*)it->q_m0.p, nm, cnt);
+                if (!quad_form) continue;
+                if (e->quad_factored)
+                    launch_product(e, KC_OTHER, it->q_u.p, nmp, 0, nm, nmp, it->mc_r0.p, nmp, 0, cnt, it->q_u0.p + (size_t)(1 + a) * nmp, nmp, 0, 1, cnt);
+                else {
+                    launch_product(e, KC_OTHER, it->q_w.p, nmp, 0, d.nq, nmp, it->mc_r0.p, nmp, 0, cnt, it->q_lin.p + (size_t)(1 + a) * d.nq_pad, d.nq_pad, 0, 1, cnt);
+                    if (it->has_cinv) {
+                        launch_product(e, KC_OTHER, it->q_cfull.p, nmp, 0, nm, nmp, it->mc_r0.p, nmp, 0, cnt, it->mc_t.p, nmp, 0, 1, cnt);
+                        hipLaunchKernelGGL(k_rowdot, dim3(cnt), dim3(256), 0, st, it->q_c0.p + 1 + a, (const double*)it->mc_r0.p, (const double*)it->mc_t.p, nmp, nm);
+                    } else
+                        hipLaunchKernelGGL(k_rowdot, dim3(cnt), dim3(256), 0, st, it->q_c0.p + 1 + a, (const double*)it->mc_r0.p, (const double*)it->mc_r0.p, nmp, nm);
+                }
+            }
+            HIP_OK(hipGetLastError());
+            next_wave += 1;
+            D.admitted = b;
+            wave_host_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count();
+        }
         if (fit_round(fit_cap, D, st, emit_lds, false)) return -2;
         if (gap_used + 2 > W.ev_gap.size()) {
             hipEvent_t a = nullptr, b = nullptr;
@@ -3139,7 +3264,8 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
         HIP_OK(hipStreamSynchronize(st));
         wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
         const int total = W.pin_word[0];
-        if (total <= 0) break;
+        if (total <= 0 && (!ms || next_wave >= n_waves)) break;
+        if (total <= 0) { HIP_OK(hipEventRecord(W.ev_gap[gap_used + 1], st)); gap_used += 2; continue; }      // (nothing asked for yet: the next wave joins)
         REQUIRE((size_t)total <= cap, "vmx_fit_migrad: a round asked for more rows than its buffers hold");
         HIP_OK(hipEventRecord(W.ev_gap[gap_used + 1], st));
         gap_used += 2;
@@ -3163,6 +3289,12 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
         }
     }
     S.fits_unfinished = W.pin_word[1];
+    S.seconds_waiting_for_draws = producer_wait_s;
+    S.seconds_enqueuing_waves = wave_host_s - producer_wait_s;
+    if (ms && quad_form)        // (the host copy of the constants serves the single-walker chain of vmx_eval)
+        for (auto* it : e->items)
+            if (!e->quad_factored && it->h_q_c0.size() == (size_t)it->q_rows)
+                HIP_OK(hipMemcpy(it->h_q_c0.data(), it->q_c0.p, it->h_q_c0.size() * sizeof(double), hipMemcpyDeviceToHost));
     const auto t_done = std::chrono::steady_clock::now();
     for (int s = 0; s < spec->n_stages; ++s) {
         const size_t n = spec->stage[s].n;

@@ -2410,6 +2410,24 @@ __global__ void k_quad_rows(double* R0, int ld, const double* model0, const int3
     R0[(size_t)k * ld + i] = d - model0[mask_idx[i]];
 }
 
+// masked bins of the reference model (kept for the linear terms of mocks that arrive later)
+__global__ void k_mask_gather(double* out, const double* model0, const int32_t* mask_idx, int n_masked)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_masked) out[i] = model0[mask_idx[i]];
+}
+
+// Monte-Carlo mocks made on the device: pool row = fiducial + noise (noise = cholesky(C) . normal draws, a product of the chain's
+// kernels; reference vega/data.py:751-753), and the residual of the quadratic form's reference point for the same rows
+__global__ void k_mock_rows(double* pool, double* R0, int ld, const double* noise, const double* fid, const double* m0, int n_masked, int n_rows)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (i >= n_masked || k >= n_rows) return;
+    const double v = fid[i] + noise[(size_t)k * ld + i];
+    pool[(size_t)k * n_masked + i] = v;
+    if (R0) R0[(size_t)k * ld + i] = v - m0[i];
+}
+
 // out[k] = sum_i a[k][i] b[k][i]   (one block per row, fixed-order reduction)
 __global__ __launch_bounds__(256) void k_rowdot(double* out, const double* a, const double* b, int ld, int n)
 {

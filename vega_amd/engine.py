@@ -90,8 +90,14 @@ class FitSpec(C.Structure):
                 ('up', C.c_double), ('tol', C.c_double), ('stage', FitStage * VMX_FIT_MAX_STAGES)]
 
 
+class MockStream(C.Structure):
+    _fields_ = [('n_mocks', C.c_int32), ('wave', C.c_int32), ('draws', C.POINTER(C.c_double)), ('stride', C.c_int64),
+                ('n_drawn', C.POINTER(C.c_int32)), ('timeout_seconds', C.c_double)]
+
+
 class FitOptions(C.Structure):
-    _fields_ = [('const_hint', C.c_int32), ('chunk', C.c_int32), ('lanes', C.c_int32), ('reserved', C.c_int32)]
+    _fields_ = [('const_hint', C.c_int32), ('chunk', C.c_int32), ('lanes', C.c_int32), ('reserved', C.c_int32),
+                ('mocks', C.POINTER(MockStream))]
 
 
 class FitResultArrays(C.Structure):
@@ -104,7 +110,8 @@ class FitStats(C.Structure):
     _fields_ = [('rounds', C.c_int64), ('evaluations', C.c_int64), ('engine_calls', C.c_int64), ('fits_unfinished', C.c_int64),
                 ('calls_by_batch', C.c_int64 * 8), ('evaluations_by_batch', C.c_int64 * 8),
                 ('seconds', C.c_double), ('seconds_setup', C.c_double), ('seconds_rounds', C.c_double),
-                ('seconds_host_waiting', C.c_double), ('gpu_idle_seconds_between_rounds', C.c_double)]
+                ('seconds_host_waiting', C.c_double), ('gpu_idle_seconds_between_rounds', C.c_double),
+                ('seconds_waiting_for_draws', C.c_double), ('seconds_enqueuing_waves', C.c_double)]
 
 
 FIT_BATCH_BINS = ('1', '2..4', '5..16', '17..64', '65..256', '257..1024', '1025..4096', '4097..')
@@ -163,6 +170,8 @@ def load_library():
     lib.vmx_set_global_invcov.argtypes = [C.c_void_p, dptr, C.c_int32]
     lib.vmx_item_set_mock_pool.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32]
     lib.vmx_set_mock_index.argtypes = [C.c_void_p, iptr, C.c_int32]
+    lib.vmx_item_set_mock_factor.argtypes = [C.c_void_p, C.c_int32, dptr, dptr, C.c_int32]
+    lib.vmx_item_get_mock_pool.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32]
     lib.vmx_add_prior.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double]
     lib.vmx_finalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.vmx_model_size.argtypes = [C.c_void_p]
@@ -216,7 +225,7 @@ EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_fftlog_padding', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_pipeline_set_odd_operator', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
-    'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
+    'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_item_set_mock_factor', 'vmx_item_get_mock_pool', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_eval_device_mocks', 'vmx_fit_migrad', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_static_poly', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
@@ -853,7 +862,22 @@ class Engine:
         pool row it is compared with (include/vegamx.h: vmx_eval_device_mocks)."""
         self._check(self.lib.vmx_eval_device_mocks(self._h, d_theta_ptr, B, d_chi2_ptr, d_status_ptr, d_mock_ptr))
 
-    def fit_migrad(self, plan, theta0, mock_rows=None, const_hint=-1, chunk=0, lanes=0):
+    def set_mock_factor(self, name, chol, fiducial_masked):
+        """Cholesky factor of item ``name``'s (scaled) masked covariance and its fiducial model on the masked bins: the mocks of a
+        ``fit_migrad(..., mock_stream=...)`` run are made from them on the device (include/vegamx.h: vmx_item_set_mock_factor)."""
+        qi = self.item_names.index(name)
+        chol, fid = _f64(chol), _f64(fiducial_masked)
+        self._check(self.lib.vmx_item_set_mock_factor(self._h, qi, _dp(chol), _dp(fid), fid.size))
+
+    def get_mock_pool(self, name, n_mocks):
+        """The first ``n_mocks`` rows of item ``name``'s mock pool, as the device holds them."""
+        qi = self.item_names.index(name)
+        n = self.prob.items[name].data_size
+        out = np.empty((n_mocks, n))
+        self._check(self.lib.vmx_item_get_mock_pool(self._h, qi, _dp(out), n_mocks, n))
+        return out
+
+    def fit_migrad(self, plan, theta0, mock_rows=None, const_hint=-1, chunk=0, lanes=0, mock_stream=None):
         """MIGRAD fits of ``theta0.shape[0]`` parameter rows on the device (include/vegamx.h: vmx_fit_migrad).  ``plan``:
         :meth:`vega_amd.migrad.MigradMinimizer.plan` with ``free`` = indices into the engine's parameter columns; ``mock_rows``:
         the pool row every fit is fitted to (None: the items' data).  Returns (per-stage result dicts, statistics of the run)."""
@@ -891,7 +915,16 @@ class Engine:
         rows = None if mock_rows is None else np.ascontiguousarray(mock_rows, dtype=np.int32)
         if rows is not None and rows.shape != (F,):
             raise ValueError('mock_rows: one pool row per fit')
-        opt = FitOptions(int(const_hint), int(chunk), int(lanes), 0)
+        opt = FitOptions(int(const_hint), int(chunk), int(lanes), 0, None)
+        if mock_stream is not None:
+            # the mocks are made while the fits run: `draws` [F, stride] float64 filled by a producer thread, `counter` int32 [1]
+            # counting the complete rows (include/vegamx.h: vmx_mock_stream)
+            draws, counter = mock_stream['draws'], mock_stream['counter']
+            if draws.dtype != np.float64 or not draws.flags.c_contiguous or draws.shape[0] != F or counter.dtype != np.int32:
+                raise ValueError('mock_stream: draws float64 [n_fits, stride] C-contiguous, counter int32')
+            ms = MockStream(F, int(mock_stream.get('wave', 0)), _dp(draws), draws.shape[1], _ip(counter),
+                            float(mock_stream.get('timeout', 0.)))
+            opt.mocks = C.pointer(ms)
         stats = FitStats()
         self._check(self.lib.vmx_fit_migrad(self._h, C.byref(spec), F, _dp(theta0), None if rows is None else _ip(rows),
                                             C.byref(opt), res, C.byref(stats)))

@@ -159,6 +159,11 @@ class MonteCarlo:
         # engine groups and for method='bfgs')
         self.driver = os.environ.get('VEGA_AMD_FIT_DRIVER', 'device')
         self.driver_stats = None
+        # with the device driver the mocks of `run_monte_carlo` are made while their fits run (the normal draws on a host thread -
+        # NumPy's legacy generator is sequential -, everything else on the device, wave by wave: include/vegamx.h vmx_mock_stream);
+        # False: all mocks first, as the reference's loop reads (same numbers to rounding)
+        self.stream_mocks = os.environ.get('VEGA_AMD_STREAM_MOCKS', '1') != '0'
+        self._mock_stream = None
 
     def minimizer(self, sample_params=None, tol=0.1, method='migrad'):
         """Minimiser over ``sample_params`` (default: the interface's [sample] section) - ``method='migrad'``: MIGRAD's own
@@ -202,7 +207,7 @@ class MonteCarlo:
                     theta[:, cols] = ext0
                     on_engine = dict(plan, stages=[dict(st, free=cols[st['free']]) for st in plan['stages']])
                     rows = None if self._mock_rows is None else self._mock_rows[np.asarray(fit_ids)]
-                    outs, self.driver_stats = eng.fit_migrad(on_engine, theta, rows)
+                    outs, self.driver_stats = eng.fit_migrad(on_engine, theta, rows, mock_stream=self._mock_stream)
                     return outs
             return MigradMinimizer(evaluate, names, start, errors, limits, tol=tol, machine=machine)
         if method != 'bfgs':
@@ -322,11 +327,78 @@ class MonteCarlo:
         vega = self.vega
         eng = vega.engine
         prob = vega.problem
+        if (run_mc_fits and method == 'migrad' and self.driver == 'device' and self.stream_mocks and hasattr(eng, 'fit_migrad')
+                and prob.global_cov is None and not vega._use_global_cov and not forecast
+                and all(item.cov is not None and item.cholesky_masked_cov for item in prob.items.values())):
+            return self._fit_streamed_mocks(fiducial_model, num_mocks, seed=seed, scale=scale, sample_params=sample_params)
         mocks = self.create_mocks(fiducial_model, num_mocks, seed=seed, scale=scale, forecast=forecast)
         if not run_mc_fits:
             self.has_monte_carlo = True
             return None
         return self._fit_mocks(mocks, num_mocks, scale=scale, sample_params=sample_params, method=method)
+
+    def _fit_streamed_mocks(self, fiducial_model, num_mocks, seed=0, scale=None, sample_params=None, wave=64):
+        """`run_monte_carlo` with the mocks made WHILE their fits run.  The reference draws a mock's numbers from NumPy's legacy
+        global generator, mock after mock, a mock's correlations in turn (vega/data.py:748-757) - a sequential stream, ~10 ns per
+        number, a fifth of the whole run when it comes first.  Here a host thread produces exactly that stream (the generator's
+        output does not depend on how it is cut into calls) wave by wave into a buffer the fit driver reads; everything else of a
+        mock - fiducial + cholesky . draws, its row of the pools, its terms of the quadratic form - happens on the device when
+        its wave joins the fits (include/vegamx.h: vmx_mock_stream).  Same mocks as `create_mocks` to rounding."""
+        import threading
+        vega = self.vega
+        eng = vega.engine
+        prob = vega.problem
+        if sample_params is None and prob.mc_config is not None:
+            sample_params = prob.mc_config['sample']
+        scales = item_scales(prob, scale)
+        sizes = []
+        for name, item in prob.items.items():
+            cache = item.__dict__.setdefault('_cholesky', {})
+            key = (scales[name], True)
+            if key not in cache:
+                cache[key] = np.linalg.cholesky(scales[name] * item.cov[:, item.data_mask][item.data_mask, :])
+            fid = _fiducial_on_data_grid(item, fiducial_model[name])[item.data_mask]
+            sent = eng.__dict__.setdefault('_mock_factor_sent', {})
+            if name not in sent or sent[name][0] is not cache[key] or not np.array_equal(sent[name][1], fid):
+                eng.set_mock_factor(name, cache[key], fid)         # (kept on the device until another factor / fiducial comes)
+                sent[name] = (cache[key], fid.copy())
+            sizes.append(item.data_size)
+            if scales[name] != 1.:
+                eng.set_invcov(name, item.chi2_matrix / scales[name])
+        stride = int(sum(sizes))
+        draws = np.empty((num_mocks, stride))
+        counter = np.zeros(1, dtype=np.int32)
+        failure = []
+
+        def produce():
+            try:
+                if seed is not None:
+                    np.random.seed(seed)
+                for a in range(0, num_mocks, wave):
+                    b = min(a + wave, num_mocks)
+                    draws[a:b] = np.random.randn((b - a) * stride).reshape(b - a, stride)
+                    counter[0] = b
+            except BaseException as exc:        # (the consumer must not wait for ever)
+                failure.append(exc)
+                counter[0] = num_mocks
+        producer = threading.Thread(target=produce, name='mock-draws', daemon=True)
+        fitter = self.minimizer(sample_params, method='migrad')
+        self._mock_rows = np.arange(num_mocks, dtype=np.int32)
+        self._mock_stream = dict(draws=draws, counter=counter, wave=wave, timeout=300.)
+        producer.start()
+        try:
+            res = fitter.minimize(n_fits=num_mocks, fixed=self._fixed)
+        finally:
+            producer.join()
+            self._mock_rows = None
+            self._mock_stream = None
+            for name, item in prob.items.items():
+                if scales[name] != 1.:
+                    eng.set_invcov(name, item.chi2_matrix)
+        if failure:
+            raise failure[0]
+        self.mc_mocks = {name: eng.get_mock_pool(name, num_mocks) for name in prob.items}
+        return self._keep_results(res)
 
     def fit_global_mocks(self, mocks, start1=None, end1=None, start2=None, end2=None, scale=None, sample_params=None,
                          method='migrad'):
@@ -374,6 +446,9 @@ class MonteCarlo:
             for name, item in prob.items.items():
                 if scales[name] != 1. and item.cov is not None and not vega._use_global_cov:
                     eng.set_invcov(name, item.chi2_matrix)
+        return self._keep_results(res)
+
+    def _keep_results(self, res):
         self.fit_result = res
         res.driver_stats = self.driver_stats if self.driver == 'device' else None
         # a fit that could not run has no Bestfit / covariance row and chisq = NaN (reference analysis.py:279-297)
