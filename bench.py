@@ -446,6 +446,44 @@ def cpu_baseline(workload, names, theta, repeats=7, warmups=2, extra_theta=None)
                       'pool allows 16 worker processes (more are killed by its process guard)'}, done, [vals[i] for i in done], extra_vals
 
 
+def set_rank_affinity(local_rank):
+    """Pin this rank to the CPUs of its GPU's NUMA node - before any GPU call, from sysfs alone: the AMD display devices of
+    /sys/class/drm in card order, the local_rank-th one's `numa_node`, that node's cpulist (eight Python drivers on one socket
+    would otherwise share whatever cores the scheduler picks).  Returns what was done, for the bench line."""
+    info = {'cpus_before': len(os.sched_getaffinity(0))}
+    try:
+        cards = []
+        for card in sorted(Path('/sys/class/drm').glob('card[0-9]*'), key=lambda c: int(c.name[4:])):
+            if '-' in card.name:
+                continue
+            vendor = card / 'device' / 'vendor'
+            if vendor.is_file() and vendor.read_text().strip() == '0x1002':
+                cards.append(card)
+        if local_rank >= len(cards):
+            info['set'] = False
+            info['reason'] = f'{len(cards)} AMD devices in /sys/class/drm'
+            return info
+        node = int((cards[local_rank] / 'device' / 'numa_node').read_text().strip())
+        info['numa_node'] = node
+        if node < 0:
+            info['set'] = False
+            info['reason'] = 'the device reports no NUMA node'
+            return info
+        cpus = set()
+        for part in Path(f'/sys/devices/system/node/node{node}/cpulist').read_text().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        info['set'] = bool(cpus)
+        info['cpus'] = len(os.sched_getaffinity(0))
+    except (OSError, ValueError) as exc:
+        info['set'] = False
+        info['reason'] = str(exc)
+    return info
+
+
 def launch_ranks(args):
     """`--gpus N`, N > 1, and no WORLD_SIZE in the environment: start the N ranks here - fresh child processes of a parent
     that has made NO GPU call (no torch import, the library only compiled, never loaded), one per GPU, the environment
@@ -546,6 +584,8 @@ def main():
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: start it as `python bench.py --gpus N` (it '
                          'launches its own ranks) or under torchrun with --nproc-per-node equal to --gpus')
 
+    affinity = set_rank_affinity(local_rank) if world > 1 and not args.ranks_share_gpu else {'set': False, 'cpus_before': len(os.sched_getaffinity(0)), 'reason': 'one rank, or ranks sharing a GPU'}
+
     # torch bundles its own HIP runtime: it has to be loaded before libvegamx.so brings in the system one (importing it
     # does not touch the GPU; the first CUDA call below does, after the CPU baseline has finished)
     import torch
@@ -635,12 +675,18 @@ def main():
             ext_streams[h] = torch.cuda.ExternalStream(h, device=dev)
         return ext_streams[h]
 
+    gather_clock = {'on': False, 'events': [], 'host_s': 0.0, 'n': 0}
+
     def finish_gathers(keep=0):
         """gloo: run the host gathers of all but the last `keep` enqueued steps (the copy's event first)."""
         while len(pending) > keep:
             slot, copied = pending.pop(0)
             copied.synchronize()
+            tg = time.perf_counter()
             dist.all_gather_into_tensor(gathered[slot], staged[slot])
+            if gather_clock['on']:
+                gather_clock['host_s'] += time.perf_counter() - tg
+                gather_clock['n'] += 1
 
     def sync_all():
         for e in engines:
@@ -658,7 +704,14 @@ def main():
             comm_stream.wait_event(stream_of_last_eval().record_event())
             with torch.cuda.stream(comm_stream):
                 if on_rccl:
+                    if gather_clock['on']:
+                        ga = torch.cuda.Event(enable_timing=True)
+                        ga.record(comm_stream)
                     dist.all_gather_into_tensor(gathered[slot], chi2_bufs[slot])
+                    if gather_clock['on']:
+                        gb = torch.cuda.Event(enable_timing=True)
+                        gb.record(comm_stream)
+                        gather_clock['events'].append((ga, gb))
                     comm_done[slot] = comm_stream.record_event()
                 else:
                     # the host gather of step i runs once step i + 1 is enqueued: the lanes stay busy while the host waits
@@ -722,14 +775,17 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    gather_clock['on'] = use_dist
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     sync_all()
     torch.cuda.synchronize()
+    elapsed_own = time.perf_counter() - t0         # this rank's own K steps (the contract's time, below, ends behind the barrier)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gather_clock['on'] = False
     timings = eng.timings(reset=True)
     eng.set_profiling(False)
 
@@ -877,7 +933,33 @@ def main():
         # what the communicator itself reports
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, (rank, local_rank, torch.cuda.get_device_properties(dev).name))
+        # what every rank measured by itself: its own time over the K steps (before the closing barrier), the gather's own time per
+        # step (HIP events on the communication stream around the collective; gloo: the host call), the event-timed kernel classes
+        # of the timed region, the CPUs it ran on - so that a shortfall at N > 1 can be read off the line: one slow rank, the
+        # gather, or the hosts' share
+        if on_rccl:
+            gather_us = [a.elapsed_time(b) * 1e3 for a, b in gather_clock['events']]
+        else:
+            gather_us = [gather_clock['host_s'] / max(gather_clock['n'], 1) * 1e6] * max(gather_clock['n'], 1)
+        mine = {'rank': rank, 'elapsed_s': elapsed_own, 'gather_us_per_step': float(np.mean(gather_us)) if gather_us else None,
+                'gather_us_max': float(np.max(gather_us)) if gather_us else None,
+                'kernel_ms_in_timed_region': {k: {'ms': v[0], 'launches': v[1]} for k, v in timings.items() if v[1]},
+                'cpu_affinity': affinity}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        own = sorted(r['elapsed_s'] for r in per_rank)
+        slowest = max(per_rank, key=lambda r: r['elapsed_s'])
+        gathers = [r['gather_us_per_step'] for r in per_rank if r['gather_us_per_step'] is not None]
         communicator = {'op': 'one all_gather_into_tensor of chi2 [B] per rank and step', 'backend': dist.get_backend(),
+                        'rank_elapsed_s': {'min': own[0], 'median': own[len(own) // 2], 'max': own[-1], 'all': [r['elapsed_s'] for r in per_rank],
+                                           'note': 'each rank\'s own K steps, before the closing barrier; `value` uses the time behind it'},
+                        'gather_us_per_step': {'mean_over_ranks': float(np.mean(gathers)) if gathers else None,
+                                               'max_over_ranks': max(gathers) if gathers else None,
+                                               'how': 'HIP events on the communication stream around the collective' if on_rccl else 'host clock around the gloo call'},
+                        'slowest_rank': {'rank': slowest['rank'], 'elapsed_s': slowest['elapsed_s'],
+                                         'kernel_ms_in_timed_region': slowest['kernel_ms_in_timed_region'],
+                                         'gather_us_per_step': slowest['gather_us_per_step']},
+                        'cpu_affinity': [r['cpu_affinity'] for r in per_rank],
                         'world_size': dist.get_world_size(), 'ranks': [r[0] for r in ranks_seen],
                         'devices': [r[1] for r in ranks_seen], 'device_name': ranks_seen[0][2],
                         'distinct_rank_blocks_in_last_gather': distinct, 'ranks_share_gpu': bool(args.ranks_share_gpu),

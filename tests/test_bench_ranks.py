@@ -57,5 +57,13 @@ def test_two_ranks_on_one_gpu_over_gloo():
     assert coll['backend'] == 'gloo' and coll['world_size'] == 2 and coll['ranks'] == [0, 1]
     assert coll['distinct_rank_blocks_in_last_gather'] == 2 and coll['ranks_share_gpu'] is True
     assert line['value'] > 0 and line['config']['batches_in_flight'] == 2
+    # the line explains itself at N > 1: every rank's own time, the gather's own time, the slowest rank's kernels, the CPUs
+    own = coll['rank_elapsed_s']
+    assert len(own['all']) == 2 and own['min'] <= own['median'] <= own['max'] <= line['ms_per_step'] * 4e-3 * 1.001
+    assert coll['gather_us_per_step']['mean_over_ranks'] > 0 and coll['gather_us_per_step']['max_over_ranks'] >= coll['gather_us_per_step']['mean_over_ranks']
+    slow = coll['slowest_rank']
+    assert slow['rank'] in (0, 1) and slow['elapsed_s'] == own['max'] and slow['kernel_ms_in_timed_region']
+    assert all(v['launches'] > 0 and v['ms'] > 0 for v in slow['kernel_ms_in_timed_region'].values())
+    assert len(coll['cpu_affinity']) == 2 and all('cpus_before' in a for a in coll['cpu_affinity'])
     # whole-job aggregate: both ranks' walkers over the slowest rank's time
     assert abs(line['value'] - 2 * line['config']['batch_per_gpu'] * 4 / (line['ms_per_step'] * 4e-3)) < 1e-6 * line['value']
