@@ -237,6 +237,26 @@ def synth_joint_problem(with_global_cov=False, tmp_path=None):
     return prob
 
 
+def model_only_problem(tmp_path):
+    """The joint auto + cross config with `has_datafile = False` in both correlations and the coordinates handed in by the caller
+    - what tests/golden/make_golden.py::dump_model_only gave the reference (vega/correlation_item.py:40-42, :120-136)."""
+    import re
+    import numpy as np
+    from vega_amd import Coordinates
+    from vega_amd.setup import build_problem
+    cfg = tmp_path / 'configs' / 'modelonly'
+    cfg.mkdir(parents=True)
+    main = (GOLDEN / 'configs' / 'joint' / 'main.ini').read_text()
+    (cfg / 'main.ini').write_text(re.sub(r'ini files = .*', 'ini files = configs/modelonly/lyalya_lyalya.ini configs/modelonly/lyalya_qso.ini', main))
+    for it in ('lyalya_lyalya', 'lyalya_qso'):
+        text = (GOLDEN / 'configs' / 'joint' / f'{it}.ini').read_text()
+        (cfg / f'{it}.ini').write_text(re.sub(r'filename = .*', 'has_datafile = False', text, count=1))
+    exp = np.load(GOLDEN / 'expected_model_only.npz')
+    coordinates = {'lyalya_lyalya': Coordinates(0., 120., 100., 30, 25),                 # (z: the effective redshift)
+                   'lyalya_qso': Coordinates(-80., 80., 80., 40, 20, z=exp['cross/z'])}
+    return build_problem('configs/modelonly/main.ini', search_dirs=[tmp_path, GOLDEN], coordinates=coordinates), coordinates
+
+
 def config1_problem():
     """BASELINE configs[1] as stated: Lya x Lya auto-correlation only, ell = 0, 2, 4, dense synthetic 2500^2
     distortion matrix and covariance."""

@@ -708,6 +708,43 @@ def dump_marginalization(VegaInterface):
     np.savez_compressed(HERE / 'expected_marginalization.npz', **out)
 
 
+def dump_model_only(VegaInterface):
+    """Correlations WITHOUT a data file (reference vega/correlation_item.py:40-42, :120-136, vega/vega_interface.py:110-137,
+    :208-235): `has_datafile = False`, the caller hands the coordinates to every correlation item, `compute_model` builds
+    the models on them - no distortion matrix, no mask, no chi2.  The auto-correlation on a 30 x 25 grid of 4 Mpc/h bins with a
+    constant redshift (`Coordinates(..., z_eff=...)`) and the cross-correlation on a 40 x 20 grid with its own redshifts;
+    fiducial point and three walkers."""
+    from vega.coordinates import Coordinates
+    os.chdir(REF / 'tests')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        main = _ref_main(tmp, ['lyalya_lyalya', 'lyalya_qso'], False)
+        for it in ('lyalya_lyalya', 'lyalya_qso'):
+            item = Path(tmp) / f'{it}.ini'
+            item.write_text(re.sub(r'filename = .*', 'has_datafile = False', item.read_text(), count=1))
+        vega = VegaInterface(main)
+        assert not vega._has_data and vega.data['lyalya_lyalya'] is None
+        z_eff = vega.fiducial['z_eff']
+        auto = Coordinates(0., 120., 100., 30, 25, z_eff=z_eff)
+        rng = np.random.default_rng(77)
+        cross = Coordinates(-80., 80., 80., 40, 20)
+        cross = Coordinates(-80., 80., 80., 40, 20, z_grid=z_eff + 0.05 * rng.standard_normal(cross.rp_grid.size))
+        vega.corr_items['lyalya_lyalya'].init_coordinates(auto)
+        vega.corr_items['lyalya_qso'].init_coordinates(cross)
+        out['cross/z'] = np.asarray(cross.z_grid)
+        fid = vega.compute_model()
+        for name, xi in fid.items():
+            out[f'fid/{name}'] = np.asarray(xi)
+        names, walkers = make_walkers(vega.params, 3, seed=WALKER_SEED + 21)
+        out['param_names'] = np.array(names)
+        out['theta'] = np.array([[w[n] for n in names] for w in walkers])
+        for i, w in enumerate(walkers):
+            for name, xi in vega.compute_model(w).items():
+                out[f'walker{i}/{name}'] = np.asarray(xi)
+        print('model only:', {n: (v.shape, float(np.abs(v).max())) for n, v in fid.items()})
+    np.savez_compressed(HERE / 'expected_model_only.npz', **out)
+
+
 def dump_dmat_file(VegaInterface):
     """The ingestion branch DESI production files use (reference vega/data.py:441-473): the distortion matrix in its own
     file with a model grid COEFMOD = 2 times finer than the data grid (DM is 2500 x 10000, HDU 2 carries the 100 x 100
@@ -1291,12 +1328,12 @@ def dump_pk_kat(VegaInterface):
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity', 'components']
+    what = sys.argv[1:] or ['inputs', 'configs', 'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity', 'components', 'model_only']
     if 'inputs' in what:
         convert_inputs()
     if 'configs' in what:
         derive_configs()
-    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity', 'components'} else None
+    VI = _reference() if set(what) & {'full4', 'joint', 'picca', 'mc', 'extras', 'fast_metals', 'mockbin', 'fits_ingest', 'marginalization', 'direct_pk', 'blinding', 'metal_decomp', 'new_metals', 'new_bias_evol', 'config1', 'marg_coeff', 'global_mc', 'model_compute', 'options2', 'fits', 'dmat_file', 'marg_mc', 'direct_pk_metals', 'mockbin_sampled', 'fht_extrap', 'fit_stats', 'sensitivity', 'components', 'model_only'} else None
     if 'full4' in what:
         dump_full4(VI)
     if 'joint' in what:
@@ -1355,3 +1392,5 @@ if __name__ == '__main__':
         dump_sensitivity(VI)
     if 'components' in what:
         dump_components(VI)
+    if 'model_only' in what:
+        dump_model_only(VI)

@@ -345,3 +345,33 @@ def test_sharded_monte_carlo_launcher_on_a_real_engine(tmp_path):
         want = truth.get(n, vega.params[n])
         assert np.abs((res.values[:, j] - want) / res.errors[:, j]).max() < 5, n
     vega.close()
+
+
+def test_model_only_correlations_on_the_engine(tmp_path):
+    """Correlations without a data file (reference vega/correlation_item.py:40-42, :120-136, vega/vega_interface.py:110-137,
+    :208-235): `VegaInterface(main, coordinates={name: Coordinates(...)})` computes the models on the caller's coordinates - no
+    distortion matrix, no mask - and refuses chi2, as the reference asserts.  Against the unmodified reference at 1e-8."""
+    from conftest import model_only_problem
+    from vega_amd import VegaInterface
+    _, coordinates = model_only_problem(tmp_path)
+    exp = np.load(GOLDEN / 'expected_model_only.npz')
+    vega = VegaInterface('configs/modelonly/main.ini', search_dirs=[tmp_path, GOLDEN], max_batch=8, coordinates=coordinates)
+    assert not vega._has_data and all(view is None for view in vega.data.values())
+    fid = vega.compute_model()
+    names = [str(n) for n in exp['param_names']]
+    for name in vega.corr_items:
+        ref = exp[f'fid/{name}']
+        assert fid[name].shape == ref.shape
+        np.testing.assert_allclose(fid[name], ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    walkers = [dict(zip(names, row)) for row in exp['theta']]
+    batch = vega.compute_model_batch(walkers)
+    for i, w in enumerate(walkers):
+        one = vega.compute_model(w)
+        for name in vega.corr_items:
+            ref = exp[f'walker{i}/{name}']
+            np.testing.assert_allclose(one[name], ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+            np.testing.assert_allclose(batch[name][i], ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    for call in (vega.chi2, vega.log_lik, vega.minimize):
+        with pytest.raises(AssertionError, match='data'):
+            call()
+    vega.close()

@@ -242,3 +242,28 @@ def test_contiguous_share_of_a_mock_file():
         lens = [b - a for a, b in shares]
         assert max(lens) - min(lens) <= 1 and lens == sorted(lens, reverse=True)
     assert contiguous_share(10, 4, 1) == (3, 6) and contiguous_share(10, 4, 3) == (8, 10)
+
+
+def test_model_only_correlations_match_the_reference(tmp_path):
+    """Correlations without a data file (reference vega/correlation_item.py:40-42, :120-136, vega/vega_interface.py:110-137,
+    :208-235): the caller's coordinates, no distortion matrix, no mask - the oracle on the lowered problem against the
+    unmodified reference (expected_model_only.npz: fiducial point and three walkers, a constant and a per-bin redshift)."""
+    from conftest import model_only_problem
+    from oracle import vega_cpu as oc
+    prob, _ = model_only_problem(tmp_path)
+    exp = np.load(GOLDEN / 'expected_model_only.npz')
+    assert all(not item.has_data and item.distortion is None for item in prob.items.values())
+    fid = oc.compute_model(prob)
+    names = [str(n) for n in exp['param_names']]
+    for name in prob.items:
+        ref = exp[f'fid/{name}']
+        np.testing.assert_allclose(fid[name], ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+    for i, row in enumerate(exp['theta']):
+        got = oc.compute_model(prob, dict(zip(names, row)))
+        for name in prob.items:
+            ref = exp[f'walker{i}/{name}']
+            np.testing.assert_allclose(got[name], ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+    # without coordinates the constructor says what it needs
+    from vega_amd.setup import build_problem
+    with pytest.raises(NotImplementedError, match='coordinates'):
+        build_problem('configs/modelonly/main.ini', search_dirs=[tmp_path, GOLDEN])

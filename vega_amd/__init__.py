@@ -1,5 +1,6 @@
 """vega_amd - MI355X-native model + chi2 engine behind Vega's VegaInterface surface."""
 from .interface import VegaInterface  # noqa: F401
+from .setup import Grid as Coordinates  # noqa: F401  (reference vega/coordinates.py: the grids a caller hands to a model-only correlation)
 from .errors import VegaModelError, VegaBoundsError, VegaArinyoError  # noqa: F401
 
 

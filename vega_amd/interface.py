@@ -65,14 +65,18 @@ class VegaInterface:
     """GPU-backed stand-in for ``vega.VegaInterface`` restricted to the model + chi2 hot path."""
 
     def __init__(self, main_path, search_dirs=(), max_batch=256, device=0, problem=None,
-                 extra_names=(), kron_metals=True, csr_threshold=None):
-        self.problem = problem if problem is not None else build_problem(main_path, search_dirs)
+                 extra_names=(), kron_metals=True, csr_threshold=None, coordinates=None):
+        # coordinates: {name: vega_amd.Coordinates(...)} for correlations WITHOUT a data file - the reference's
+        # `corr_item.init_coordinates(...)` (vega/correlation_item.py:120-136); such a problem computes models only
+        self.problem = problem if problem is not None else build_problem(main_path, search_dirs, coordinates=coordinates)
+        # (reference vega_interface.py:110-118: one correlation without data switches every `data[name]` to None)
+        self._has_data = all(getattr(item, 'has_data', True) for item in self.problem.items.values())
         self.main_config = self.problem.main_config
         self.params = self.problem.params
         self.sample_params = self.problem.sample_params
         self.priors = self.problem.priors
         self.corr_items = self.problem.items
-        self.data = {name: _DataView(item) for name, item in self.problem.items.items()}
+        self.data = {name: _DataView(item) if self._has_data else None for name, item in self.problem.items.items()}
         self.fiducial = {'k': self.problem.k, 'pk_full': self.problem.pk_full,
                          'pk_smooth': self.problem.pk_smooth, 'z_eff': self.problem.z_eff,
                          'z_fiducial': self.problem.z_fid, 'Omega_m': self.problem.omega_m,
@@ -253,6 +257,8 @@ class VegaInterface:
     def _sync_monte_carlo(self):
         """chi2 reads the current mock and the scaled inverse covariance in Monte-Carlo mode
         (reference vega/vega_interface.py:296-297, :311-313)."""
+        # (reference vega_interface.py:265, :342: `assert self._has_data` - a correlation without a data file has no chi2)
+        assert self._has_data, 'a correlation without a data file: models only (chi2, log_lik and fits need data)'
         if self.monte_carlo == self._mc_active and not self.monte_carlo:
             return
         if self.monte_carlo and self._use_global_cov:

@@ -323,6 +323,7 @@ class CorrItem:
     marginalize_in_fit = False
     num_marg_modes = 0           # modes the marginalisation removes (reference data.py:92,825)
     variance = None              # diagonal of the covariance as read (reference data.py:82-85); None: taken from `cov`
+    has_data = True              # False: a correlation without a data file - model only, on the caller's coordinates
     nb = None                    # pair counts of the data file (column NB), if any
 
     @property
@@ -717,7 +718,7 @@ def marginalization_cov_update(*args, **kw):
 # --------------------------------------------------------------------------------------
 # one correlation item
 # --------------------------------------------------------------------------------------
-def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
+def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False, coordinates=None):
     d = cfg['data']
     name = d.get('name')
     tr1 = Tracer(d.get('tracer1'), d.get('tracer1-type'))
@@ -734,11 +735,26 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
         marg['all-rmin'] = True
     fit_marg_scales = bool(marg) and model_sec.getboolean('fit-marginalized-scales', False)
     new_metals = model_sec.getboolean('new_metals', False)
-    if 'filename' not in d or not d.getboolean('has_datafile', True):
-        raise NotImplementedError('correlation items without a data file are not supported')
-
-    # ---- data file (reference vega/data.py:285-421)
-    tabs = read_tables(find_file(d.get('filename'), search_dirs))
+    has_data = 'filename' in d and d.getboolean('has_datafile', True)
+    if not has_data:
+        # A correlation without a data file (reference vega/correlation_item.py:40-42): the model alone, on coordinates the caller
+        # hands in (reference: `corr_item.init_coordinates(Coordinates(...))` before `compute_model`, correlation_item.py:120-136,
+        # vega_interface.py:110-137 - `data[name] = None`, no distortion matrix, model on the model coordinates, chi2 refused).
+        # Here the coordinates come with the constructor: VegaInterface(main, coordinates={name: Grid(...)}).
+        if coordinates is None:
+            raise NotImplementedError(f'{name}: a correlation without a data file computes its model on coordinates the caller '
+                                      'hands in - VegaInterface(main, coordinates={name: vega_amd.Coordinates(rp_min, rp_max, rt_max, '
+                                      'rp_nbins, rt_nbins)})')
+        if 'metals' in cfg and not new_metals:
+            raise NotImplementedError(f'{name}: metal matrices come with a data file; a model-only correlation has no metal terms')
+        g = coordinates
+        z = np.full(g.rp.size, consts[1]) if g.z is None else np.broadcast_to(np.asarray(g.z, dtype=float), g.rp.shape)
+        from .tables import Table
+        tabs = [Table({'RPMIN': g.rp_min, 'RPMAX': g.rp_max, 'RTMAX': g.rt_max, 'NP': g.n_rp, 'NT': g.n_rt, 'BLINDING': 'none'},
+                      {'DA': np.zeros(g.rp.size), 'RP': g.rp, 'RT': g.rt, 'Z': z})]
+    else:
+        # ---- data file (reference vega/data.py:285-421)
+        tabs = read_tables(find_file(d.get('filename'), search_dirs))
     t1 = tabs[0]
     hdr = t1.header
     # blinding strategy of the file (reference vega/data.py:305-339): `desi_dr3` data are blinded (DA_BLIND must be
@@ -1005,6 +1021,7 @@ def _build_item(cfg, consts, search_dirs, marginalize_in_fit=False):
     item.variance, item.nb = variance, nb
     item.cov_rescale = rescale
     item.cholesky_masked_cov = d.getboolean('cholesky-masked-cov', True)
+    item.has_data = has_data
     return item
 
 
@@ -1047,7 +1064,7 @@ def _read_sample(section, params):
     return out
 
 
-def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
+def build_problem(main_path, search_dirs=(), fiducial_overrides=None, coordinates=None):
     """Parse ``main.ini`` and everything it names into a :class:`Problem`.
 
     ``fiducial_overrides`` may replace ``Omega_m`` / ``Omega_de`` read from the template
@@ -1082,7 +1099,7 @@ def build_problem(main_path, search_dirs=(), fiducial_overrides=None):
         cfg = _parser(find_file(os.path.expandvars(path), dirs))
         cfgs[cfg['data'].get('name')] = cfg
     for name, cfg in cfgs.items():
-        items[name] = _build_item(cfg, consts, dirs, marginalize_in_fit)
+        items[name] = _build_item(cfg, consts, dirs, marginalize_in_fit, coordinates=(coordinates or {}).get(name))
 
     # parameters: component configs first, main config wins (reference :705-736)
     params = {}
