@@ -447,17 +447,6 @@ int vmx_set_mu_quadrature(vmx_engine* e, int32_t node_rule);
  * loop itself, decided per walker on the device (k_prologue), so a sampler that wanders off gets slower, never different.
  * vmx_debug_read(what = 4)[7] counts such walkers since vmx_finalize.  n = 0: no guard. */
 int vmx_set_mu_rule_box(vmx_engine* e, int32_t n, const int32_t* slots, const double* lo, const double* hi);
-/* Level-3 tables for the auto-correlation core groups (after vmx_finalize).  Once a batch shares every Gaussian factor (level 2)
- * the auto spectrum is T(k, mu) [p0(mu^2) + F p1(mu^2)]^2 with F = exp(-L0 k mu), the HCD scale L0 (Rogers 2018,
- * power_spectrum.py:263-297) the one parameter left that is not a polynomial coefficient.  Its mu sums are tabulated once per
- * level-2 table, K_{m,j}(k; L0_c) = sum over the reference's n_mu midpoints of mu^2m F_c^j T, at 13 Chebyshev nodes L0_c of the box
- * l0_centre (1 +- rel_half_width), and a walker's moments are those values interpolated in its L0 (barycentric; 6e-16 of the
- * unsuppressed sums at rel_half_width = 0.125, 6e-13 at 0.25: tests/test_mu_quadrature.py) times its nine coefficients - ~400 FMAs
- * per walker and wavenumber in place of 178 nodes.  l0_slot: the parameter column of L0 (-1: the pipelines' constant default, one
- * node).  The box is a property of the engine, not of a batch: a walker's arithmetic never depends on its neighbours; a walker
- * whose L0 lies outside the box keeps the node rule / the plain loop.  rel_half_width = 0 with l0_slot >= 0: only walkers AT the
- * centre.  Tables are built on the device when a level-2 table has been the same for two evaluations in a row. */
-int vmx_set_hcd_level3(vmx_engine* e, int32_t l0_slot, double l0_centre, double rel_half_width);
 /* The extra nodes of that rule as the engine built them: mu[n], w[n] (weights in units of one midpoint); returns n
  * (also when the buffers are NULL or too small, without writing). */
 int vmx_get_mu_nodes(vmx_engine* e, double* mu, double* w, int32_t capacity);
@@ -519,8 +508,7 @@ void* vmx_stream(vmx_engine* e);
  * 4 = {live wavenumbers of the P(k,mu) stage in the last evaluation, k up to which the mu node rule applies (0: off),
  * nodes per wavenumber of that rule, leading wavenumbers whose tiles took the rule in the last evaluation, table level of
  * the last evaluation (vmx_set_constant_nl_hint), first and last spline-coefficient row the last evaluation's bins read,
- * walkers that left the mu rule's box since vmx_finalize, form of the last evaluation (vmx_set_quadratic_form_kind),
- * (walker, group) pairs the level-3 tables served in the last evaluation (vmx_set_hcd_level3)}.
+ * walkers that left the mu rule's box since vmx_finalize, form of the last evaluation (vmx_set_quadratic_form_kind)}.
  * Returns the number of doubles written (<= capacity) or a negative error. */
 int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, int64_t capacity);
 

@@ -208,10 +208,6 @@ struct vmx_engine {
     bool no_pk_w = false;                    // VMX_NO_PK_W: the shared-W groups stay in k_pk_multipoles
     std::vector<Tab2Group> tab2_groups;      // the groups with tables, as k_pk_tab2 takes them (cross groups first)
     DevBuf<double> xtab_key;
-    // level-3 tables of the auto-correlation core groups (vmx_set_hcd_level3; EngineDev::l3_tab)
-    DevBuf<double> l3_tab, l3_key, l3_node;
-    int n_l3 = 0, l3_n = 0; double l3_lo = 0.0, l3_hi = 0.0; int l3_slot = -2;
-    int64_t step_seq = 0;
     int n_xtab = 0;
     int const_hint = 0;              // vmx_set_constant_nl_hint: table level the caller vouches for (device-resident theta)
     int fv_n = 0;
@@ -2123,7 +2119,6 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
 {
     EngineDev D = e->dev;
     if (e->call_mock) D.mock_index = e->call_mock;      // (this call's walkers bring their own mock rows)
-    D.step_seq = ++e->step_seq;
     // tab_mode: table level of the P(k,mu) stage (EngineDev::xtab_level)
     D.xtab_level = tab_mode;
     e->last_tab_level = tab_mode;
@@ -2248,22 +2243,6 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                         hipLaunchKernelGGL((k_pk_tab2<64, 4, 1>), dim3(B, n, (e->nk + 63) / 64), dim3(256), sh1, e->stream, D, A, B);
                 } else      // (8 x 32 blocks for a single walker measured the same: 12 us)
                     hipLaunchKernelGGL((k_pk_tab2<16, 16, 1>), dim3(B, n, (e->nk + 15) / 16), dim3(256), sh1, e->stream, D, A, B);
-            }
-        }
-        // the auto-correlation core groups whose level-3 tables are current: their walkers' multipoles from the tabulated mu sums
-        // (k_pk_tab2 left those walkers out); the same launch checks / rebuilds the tables
-        if (tab_mode >= 2 && e->n_l3 > 0) {
-            Tab2Args A{};
-            int n = 0;
-            for (auto& t : e->tab2_groups) if (t.l3 > 0 && n < VMX_TAB2_GROUPS / 2) A.g[n++] = t;
-            if (n > 0) {
-                // the check-and-rebuild launch is not part of every step (a launch costs ~5 us even when every block leaves at
-                // once): the first steps of an engine / lane, then every 32nd - a table that went stale in between sends its
-                // walkers to k_pk_tab2 until then (slower, never different), and the schedule is a function of the step count
-                if (e->step_seq <= 8 || (e->step_seq & 31) == 0)
-                    hipLaunchKernelGGL(k_pk_l3_build, dim3(1, n, e->nkp / 16), dim3(256), 0, e->stream, D, A);
-                hipLaunchKernelGGL(k_pk_l3, dim3((B + 63) / 64, n, (e->nk + VMX_L3_KB - 1) / VMX_L3_KB), dim3(256),
-                                   (size_t)(VMX_L3_KB * VMX_L3_ROW + 16 * 64) * sizeof(double), e->stream, D, A, B);
             }
         }
         // the shared-W groups in their own kernel (large batches)
@@ -2969,7 +2948,6 @@ static vmx_engine* clone_lane(vmx_engine* e)
                     &L->xtab_key, &L->gres, &L->gz, &L->mv_part, &L->pk_direct}) b->forget();
     for (auto* b : {&L->status, &L->k_live, &L->coef_win}) b->forget();
     L->gemm_trace.forget(); L->pk_trace.forget(); L->d_items.forget();
-    L->l3_tab.forget(); L->l3_key.forget();
     if (L->theta.alloc((size_t)Bm * e->n_params) || L->scal.alloc(ncols * VMX_NS) ||
         L->metal_bias.alloc((size_t)Bm * 3 * (e->metals.size() + 1)) ||
         L->pl.alloc((size_t)VMX_MAX_ELL * acols * e->nkp) || L->coef.alloc((size_t)VMX_MAX_ELL * acols * e->ncp) ||
@@ -2985,11 +2963,6 @@ static vmx_engine* clone_lane(vmx_engine* e)
             L->xtab_key.upload(key.data(), key.size())) return fail_out();
     }
     if (e->gcinv.p && (L->gres.alloc((size_t)Bm * e->g_ld, true) || L->gz.alloc((size_t)e->slab_rows * e->g_ld, true))) return fail_out();
-    if (e->n_l3 > 0) {
-        const size_t chunks = (size_t)e->nkp / 16;
-        std::vector<double> key((size_t)e->n_l3 * chunks * 16, std::nan(""));
-        if (L->l3_tab.alloc((size_t)e->n_l3 * e->nkp * VMX_L3_ROW, true) || L->l3_key.upload(key.data(), key.size())) return fail_out();
-    }
     std::vector<ItemDev> items;
     for (auto* it : L->items) {
         ItemDev& d = it->dev;
@@ -3004,7 +2977,6 @@ static vmx_engine* clone_lane(vmx_engine* e)
     if (L->d_items.upload(items.data(), items.size())) return fail_out();
     EngineDev& D = L->dev;
     D.xtab = L->xtab.p; D.xtab_key = L->xtab_key.p; D.xtab_k = L->xtab_k.p;
-    D.l3_tab = L->l3_tab.p; D.l3_key = L->l3_key.p;
     D.items = L->d_items.p;
     D.theta = L->theta.p; D.scal = L->scal.p; D.metal_bias = L->metal_bias.p; D.pl = L->pl.p; D.coef = L->coef.p;
     D.xi = L->xi.p; D.xim = L->xim.p; D.model = L->model.p; D.chi2 = L->chi2.p; D.status = L->status.p; D.k_live = L->k_live.p;
@@ -3459,47 +3431,6 @@ int vmx_get_mu_nodes(vmx_engine* e, double* mu, double* w, int32_t capacity)
     return e->n_extra;
 }
 
-int vmx_set_hcd_level3(vmx_engine* e, int32_t l0_slot, double l0_centre, double rel_half_width)
-{
-    REQUIRE(e && e->finalized && rel_half_width >= 0.0 && rel_half_width <= 0.25, "vmx_set_hcd_level3 (after vmx_finalize; half width 0 .. 0.25)");
-    HIP_OK(hipSetDevice(e->device));
-    drop_lane(e);
-    HIP_OK(hipStreamSynchronize(e->stream));
-    // the groups it serves: auto-correlation core groups (level-2 tables, Rogers HCD on both tracers) whose L0 is that parameter
-    int n = 0;
-    for (auto& t : e->tab2_groups) {
-        const vmx_pipe_desc& d = e->pipes[t.pipe].d;
-        t.l3 = 0;
-        if (t.cross || d.hcd_model != VMX_HCD_ROGERS || d.l0_hcd_slot != l0_slot || n >= VMX_TAB2_GROUPS / 2) continue;
-        if (l0_slot < 0) l0_centre = d.l0_default;
-        t.l3 = ++n;
-    }
-    e->n_l3 = (rel_half_width >= 0.0 && l0_centre > 0.0) ? n : 0;
-    if (l0_slot < 0) rel_half_width = 0.0;
-    e->l3_slot = l0_slot;
-    EngineDev& D = e->dev;
-    D.n_l3 = e->n_l3;
-    if (e->n_l3 == 0) { for (auto& t : e->tab2_groups) t.l3 = 0; return 0; }
-    // Chebyshev nodes of the first kind on [centre (1 - w), centre (1 + w)], the middle one the centre itself, and their
-    // barycentric weights (-1)^c sin((2 c + 1) pi / (2 n)); one node when the box has no width
-    const int nn = rel_half_width > 0.0 ? VMX_L3_NODES : 1;
-    std::vector<double> node(32, 0.0);
-    const double hw = rel_half_width * l0_centre, pi = 3.14159265358979323846;
-    for (int c = 0; c < nn; ++c) {
-        node[c] = nn == 1 ? l0_centre : l0_centre + hw * std::cos((2 * c + 1) * pi / (2.0 * nn));
-        node[16 + c] = nn == 1 ? 1.0 : ((c & 1) ? -1.0 : 1.0) * std::sin((2 * c + 1) * pi / (2.0 * nn));
-    }
-    node[nn / 2] = l0_centre;
-    e->l3_n = nn; e->l3_lo = l0_centre - hw; e->l3_hi = l0_centre + hw;
-    const size_t chunks = (size_t)e->nkp / 16;
-    std::vector<double> key((size_t)e->n_l3 * chunks * 16, std::nan(""));
-    if (e->l3_node.upload(node.data(), node.size()) || e->l3_tab.alloc((size_t)e->n_l3 * e->nkp * VMX_L3_ROW, true) ||
-        e->l3_key.upload(key.data(), key.size())) return -2;
-    D.l3_tab = e->l3_tab.p; D.l3_key = e->l3_key.p; D.l3_node = e->l3_node.p;
-    D.l3_n = nn; D.l3_lo = e->l3_lo; D.l3_hi = e->l3_hi;
-    return 0;
-}
-
 int vmx_set_mu_rule_box(vmx_engine* e, int32_t n, const int32_t* slots, const double* lo, const double* hi)
 {
     REQUIRE(e && !e->finalized && n >= 0 && (n == 0 || (slots && lo && hi)), "vmx_set_mu_rule_box (before vmx_finalize)");
@@ -3746,8 +3677,7 @@ int64_t vmx_debug_read(vmx_engine* e, int32_t what, int32_t index, double* out, 
         if (capacity >= 5) out[4] = e->last_tab_level;
         if (capacity >= 7) { out[5] = live[2]; out[6] = live[3]; }
         if (capacity >= 9) out[8] = e->last_form;               // 0: full chain, 1: the quadratic form Q', 2: its factored form
-        if (capacity >= 10) out[9] = live[5];                   // (walker, group) pairs the level-3 tables served
-        if (capacity >= 8) { out[7] = live[4]; return capacity >= 10 ? 10 : capacity >= 9 ? 9 : 8; }       // walkers that left the mu rule's box since vmx_finalize
+        if (capacity >= 8) { out[7] = live[4]; return capacity >= 9 ? 9 : 8; }       // walkers that left the mu rule's box since vmx_finalize
         return capacity >= 7 ? 7 : capacity >= 5 ? 5 : capacity >= 4 ? 4 : 3;
     }
     else { fail(-1, "invalid argument: what"); return -1; }

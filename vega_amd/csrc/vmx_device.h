@@ -178,19 +178,6 @@ struct EngineDev {
     // leaves a current one alone.  xtab_k [tables][4][nkp]: per wavenumber the Arinyo part of e0, e2, the error flag, the (level-2) bound of the exponents.
     const int32_t* xtab_pipe; const int32_t* xtab_partner; int32_t n_xtab; int32_t xtab_level; double* xtab_key; double* xtab_k;
     int32_t xtab_block0;        // k_prologue: first of the table blocks behind the walkers' (0: k_xtab is its own launch)
-    // Level 3 (auto-correlation core groups, vmx_set_hcd_level3): with every Gaussian factor in the level-2 table T(k, mu) the
-    // auto spectrum is T [p0(mu^2) + F p1(mu^2)]^2 with F = exp(-L0 k mu) - the HCD scale L0 the one parameter left that is not
-    // a polynomial coefficient.  Its mu sums are tabulated ONCE per level-2 table: K_{m,j}(k; L0_c) = sum_mu mu^2m F_c^j T over
-    // the n_mu midpoints (the reference's sum itself, not the node rule) at l3_n Chebyshev nodes L0_c of a fixed box around the
-    // configured L0, and a walker's moments are 36 of those values interpolated in L0 (barycentric, exact to 1e-15 inside the
-    // box) times its nine coefficients: ~400 FMAs per walker and wavenumber instead of 178 nodes (k_pk_l3).  A walker outside
-    // the box keeps k_pk_tab2.  l3_tab [groups][nkp][VMX_L3_ROW]: per wavenumber [2 tables][2 j][6 m][16] and the j = 0 sums [2][8];
-    // l3_key [groups][nkp / 16][16]: the level-2 key a chunk of 16 wavenumbers was built for + the step it was built in.
-    double* l3_tab; double* l3_key;
-    const double* l3_node;      // [16] nodes, [16] barycentric weights
-    int32_t n_l3, l3_n;
-    double l3_lo, l3_hi;
-    int64_t step_seq;           // counts the chains of this engine: tables built in the running step are not read in it
     const double* gk_mom;       // [tables + 1][6][nkp]  sum_j mu_j^(2n) G(k, mu_j); last table: G = 1
     int32_t n_gk;
     // fftlog / spline
@@ -246,7 +233,6 @@ struct EngineDev {
     int32_t* k_live;            // [0] wavenumbers >= *k_live have P_ell = 0 for every walker and pipeline of the batch;
                                 // [1] wavenumbers < k_live[1] sat in tiles that took the mu node rule (a statistic);
                                 // [2], [3] the spline-coefficient window of the last evaluation (a statistic)
-                                // [5] (walker, group) pairs the level-3 tables served in the last evaluation (a statistic)
     unsigned long long* pk_trace;   // debugging aid (VMX_PK_TRACE): per block of k_pk_tab2 {start, end (100 MHz ticks), hw id, xcc id}
     int32_t* coef_win;          // [2] first / last spline coefficient any bin of the batch reads (k_prologue; reset by k_chi2)
     const int32_t* mock_index;  // [B] row of the mock pool used as data by walker b, -1: the item's data vector
@@ -359,7 +345,7 @@ __device__ __forceinline__ void prologue_body(const EngineDev& D, int B)
     const int n_chunk = (B + PRO_T - 1) / PRO_T;
     const int slot = (int)blockIdx.x / n_chunk, b_first = ((int)blockIdx.x % n_chunk) * PRO_T;
     const int b = b_first + (int)threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { D.k_live[0] = 0; D.k_live[1] = 0; D.k_live[5] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { D.k_live[0] = 0; D.k_live[1] = 0; }
     // The slot's pipeline descriptor is read dozens of times ahead of data-dependent branches.  It is static and the slot is
     // the block's: through the constant address space those reads are scalar loads (batched by the compiler, cached) and the
     // branches scalar branches - from LDS or global memory every one of them was a vector round trip the next read waited for.
@@ -1437,8 +1423,8 @@ __global__ __launch_bounds__(256, GENERIC ? 1 : VMX_PK_WAVES) void k_pk_multipol
 // grid = (ceil(B / NW), level-2 groups - the costlier cross groups first -, k tiles: the launch ends on the dead tiles); LDS: (mu^2, mu^4) of the midpoints and {mu, mu^2, mu^4, w} of the extra
 // nodes, reused as the [NW][8][KT MS] reduction scratch.
 // what k_pk_tab2 needs to know about a group, passed in the kernel arguments (no descriptor loads ahead of the set-up)
-struct Tab2Group { int32_t pipe, partner, xtab, cross, kind_s, kind_q, col_s, col_q, uvb, heii, lya1, lya2, damping_power, l3;
-                   double damping_scale; };       // l3: 1 + index of the group's level-3 tables (0: none)
+struct Tab2Group { int32_t pipe, partner, xtab, cross, kind_s, kind_q, col_s, col_q, uvb, heii, lya1, lya2, damping_power, pad;
+                   double damping_scale; };
 #define VMX_TAB2_GROUPS 8
 struct Tab2Args { Tab2Group g[VMX_TAB2_GROUPS]; };
 
@@ -1452,7 +1438,7 @@ struct Tab2Args { Tab2Group g[VMX_TAB2_GROUPS]; };
 #define VMX_TAB2_PF 4
 #endif
 template <int KT, int MS, int NW, bool CROSS, int MODE = 0>
-__device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group& G, int B, unsigned skip = 0u)
+__device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group& G, int B)
 {
     extern __shared__ double smem[];
     constexpr int NT = KT * MS;
@@ -1499,8 +1485,8 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         int b = blockIdx.x * NW + w;
-        ok[w] = b < B && !((skip >> w) & 1u);         // (skip: level 3 serves this walker, k_pk_l3)
-        if (b >= B) b = B - 1;                        // a surplus walker slot shadows the last walker and stores nothing
+        ok[w] = b < B;
+        if (!ok[w]) b = B - 1;                        // a surplus walker slot shadows the last walker and stores nothing
         const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
         raw[w][0] = sc[S_BIAS1]; raw[w][1] = sc[S_BIAS2]; raw[w][2] = sc[S_BB1]; raw[w][3] = sc[S_BB2];
         raw[w][4] = sc[S_HCD_B]; raw[w][5] = sc[S_HCD_BB]; raw[w][6] = sc[S_HCD_L0]; raw[w][7] = sc[S_VD2]; raw[w][8] = sc[S_NO_RULE];
@@ -1734,30 +1720,11 @@ __device__ __forceinline__ void pk_tab2_body(const EngineDev& D, const Tab2Group
 // the two passes of a block whose walkers disagree on the rule (inlined: as a function of its own it would bring a stack,
 // i.e. scratch memory, to every launch of the kernel)
 template <int KT, int MS, int NW>
-__device__ __forceinline__ void pk_tab2_mixed(const EngineDev& D, const Tab2Group& G, int B, unsigned skip)
+__device__ __forceinline__ void pk_tab2_mixed(const EngineDev& D, const Tab2Group& G, int B)
 {
-    if (G.cross) pk_tab2_body<KT, MS, NW, true, 1>(D, G, B, skip); else pk_tab2_body<KT, MS, NW, false, 1>(D, G, B, skip);
+    if (G.cross) pk_tab2_body<KT, MS, NW, true, 1>(D, G, B); else pk_tab2_body<KT, MS, NW, false, 1>(D, G, B);
     __syncthreads();        // (the reduction scratch of the first pass shares its LDS with the second pass's node tables)
-    if (G.cross) pk_tab2_body<KT, MS, NW, true, 2>(D, G, B, skip); else pk_tab2_body<KT, MS, NW, false, 2>(D, G, B, skip);
-}
-
-// Are the level-3 tables of group table `l3` (level-2 table xt) usable for the 64 wavenumbers of tile `tile64` in THIS step:
-// built for the level-2 key the running evaluation found, and not in this very step (a block must not read what another block
-// of the same launch may still be writing: the XCDs' L2s are not coherent inside a launch).  Wave-uniform.
-__device__ inline bool l3_valid(const EngineDev& D, int l3, int xt, int tile64)
-{
-    if (D.xtab_level < 2) return false;
-    // the tile's four records are 64 consecutive doubles: one load per lane (a chain of dependent loads here - compare, then
-    // load the next - cost every block 50 us)
-    const int lane = threadIdx.x & 63, c = lane >> 4, q = lane & 15;
-    const int chunk = tile64 * 4 + c;
-    bool ok = true;
-    if (chunk * 16 < D.nkp && q <= VMX_XTAB_KEY) {
-        const double rec = D.l3_key[((size_t)l3 * (D.nkp / 16) + chunk) * 16 + q];
-        if (q < VMX_XTAB_KEY) ok = rec == D.xtab_key[(size_t)(D.n_xtab + xt) * VMX_XTAB_KEY + q];
-        else ok = rec != (double)D.step_seq;
-    }
-    return __all(ok) != 0;
+    if (G.cross) pk_tab2_body<KT, MS, NW, true, 2>(D, G, B); else pk_tab2_body<KT, MS, NW, false, 2>(D, G, B);
 }
 
 // waves per SIMD the register allocation aims at (measured: three or four waves of the two-walker shape run the same)
@@ -1769,18 +1736,6 @@ template <int KT, int MS, int NW>
 __global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : (NW == 1 ? VMX_TAB2_BLOCKS : VMX_TAB2_W2) * (4 / MS)) void k_pk_tab2(EngineDev D, Tab2Args A, int B)
 {
     const Tab2Group& G = A.g[blockIdx.y];
-    // walkers whose HCD scale lies in the box of the group's level-3 tables are k_pk_l3's (block-uniform)
-    unsigned skip = 0u;
-    if (G.l3 > 0 && D.n_l3 > 0 && l3_valid(D, G.l3 - 1, G.xtab, (int)(blockIdx.z * KT) / 64)) {
-        bool all = true;
-        for (int w = 0; w < NW; ++w) {
-            const int b = (int)blockIdx.x * NW + w;
-            if (b >= B) continue;
-            const double L0 = D.scal[((size_t)b * D.n_pipe + G.pipe) * VMX_NS + S_HCD_L0];
-            if (L0 >= D.l3_lo && L0 <= D.l3_hi) skip |= 1u << w; else all = false;
-        }
-        if (all) return;
-    }
     if constexpr (NW > 1) {
         // do the walkers of this block agree on the mu rule? (block-uniform: the flags are the prologue's, per walker)
         bool any_in = false, all_in = true;
@@ -1789,301 +1744,10 @@ __global__ __launch_bounds__(KT * MS, KT != 64 ? 4 : (NW == 1 ? VMX_TAB2_BLOCKS 
             const bool inside = D.scal[((size_t)b * D.n_pipe + G.pipe) * VMX_NS + S_NO_RULE] == 0.0;
             any_in = any_in || inside; all_in = all_in && inside;
         }
-        if (any_in && !all_in) { pk_tab2_mixed<KT, MS, NW>(D, G, B, skip); return; }
+        if (any_in && !all_in) { pk_tab2_mixed<KT, MS, NW>(D, G, B); return; }
     }
-    if (G.cross) pk_tab2_body<KT, MS, NW, true>(D, G, B, skip);
-    else pk_tab2_body<KT, MS, NW, false>(D, G, B, skip);
-}
-
-// ---- level 3: the auto-correlation core groups from tabulated mu sums (EngineDev::l3_tab)
-// k_pk_l3_build, grid (1, groups, chunks of 16 wavenumbers): the chunk's tables are checked against the level-2 key of the
-// running evaluation and rebuilt when the level-2 table has been the same for two steps in a row (a sampler that changes the
-// shared parameters every step never pays for tables it would not use).  k_pk_l3, grid (blocks of 64 walkers, groups, chunks
-// of VMX_L3_KB wavenumbers): the walkers' multipoles.
-#define VMX_L3_NODES 13
-#define VMX_L3_ROW 400             // doubles per wavenumber of l3_tab: [2 tables][2 j][6 m][16 nodes], then the j = 0 sums [2][8]
-#ifndef VMX_L3_KB
-#define VMX_L3_KB 4               // wavenumbers per consumer block (one per wave)
-#endif
-__global__ __launch_bounds__(256) void k_pk_l3_build(EngineDev D, Tab2Args A)
-{
-    const Tab2Group& G = A.g[blockIdx.y];
-    const int l3 = G.l3 - 1, xt = G.xtab, p = G.pipe;
-    const int chunk = blockIdx.z;               // build blocks: chunk of 16 wavenumbers; consumer blocks: 4 waves x VMX_L3_KPW wavenumbers
-    const size_t plane = (size_t)D.n_rows * D.nkp;
-    const double* found = D.xtab_key + (size_t)(D.n_xtab + xt) * VMX_XTAB_KEY;
-    {
-        if (chunk * 16 >= D.nkp) return;
-        const double* held = D.xtab_key + (size_t)xt * VMX_XTAB_KEY;
-        double* rec = D.l3_key + ((size_t)l3 * (D.nkp / 16) + chunk) * 16;
-        // (one key entry per thread: a chain of compare-then-load would cost this block a dozen round trips in every step)
-        const int kq_ = threadIdx.x & 15;
-        bool st_q = true, cur_q = true;
-        if (kq_ < VMX_XTAB_KEY) {
-            const double f = found[kq_];
-            st_q = held[kq_] == f && (kq_ != 0 || f == 2.0);
-            cur_q = rec[kq_] == f;
-        }
-        const bool stable = __syncthreads_and(st_q) != 0, current = __syncthreads_and(cur_q) != 0;
-        if (!stable || current) return;
-        const int kk = threadIdx.x & 15, slot = threadIdx.x >> 4, i = chunk * 16 + kk;
-        const bool node = slot < D.l3_n, fixed = slot == D.l3_n;
-        if (node || fixed) {
-            double acc[2][2][6];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) acc[t][j][m] = 0.0;
-            if (i < D.nk) {
-                const double k = D.k[i];
-                const double fk = node ? -D.l3_node[slot] * k : 0.0;
-                const double* tab = D.xtab + (size_t)xt * 2 * plane + i;
-                for (int j = 0; j < D.n_mu; ++j) {
-                    const double g = tab[(size_t)j * D.nkp], h = tab[plane + (size_t)j * D.nkp];
-                    const double mu = D.mu[j], mu2 = mu * mu;
-                    const double F = node ? vmx_exp(fk * mu) : 1.0;
-                    double pw = 1.0;
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) {
-                        const double a = pw * F, b = a * F;
-                        acc[0][0][m] = fma(a, g, acc[0][0][m]); acc[0][1][m] = fma(b, g, acc[0][1][m]);
-                        acc[1][0][m] = fma(a, h, acc[1][0][m]); acc[1][1][m] = fma(b, h, acc[1][1][m]);
-                        pw *= mu2;
-                    }
-                }
-            }
-            if (node) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int m = 0; m < 6; ++m)
-                            D.l3_tab[((size_t)l3 * D.nkp + i) * VMX_L3_ROW + ((t * 2 + j) * 6 + m) * 16 + slot] = acc[t][j][m];
-            } else {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int m = 0; m < 6; ++m)
-                        D.l3_tab[((size_t)l3 * D.nkp + i) * VMX_L3_ROW + 384 + t * 8 + m] = acc[t][0][m];     // (F = 1: the j = 0 sums)
-            }
-        }
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int q = 0; q < VMX_XTAB_KEY; ++q) rec[q] = found[q];
-            rec[12] = (double)D.step_seq;
-        }
-        }
-}
-
-__global__ __launch_bounds__(256, 4) void k_pk_l3(EngineDev D, Tab2Args A, int B)
-{
-    const Tab2Group& G = A.g[blockIdx.y];
-    const int l3 = G.l3 - 1, xt = G.xtab, p = G.pipe;
-    const int chunk = blockIdx.z;
-    const double* found = D.xtab_key + (size_t)(D.n_xtab + xt) * VMX_XTAB_KEY;
-    // ---- the walkers' multipoles: a block = 64 walkers (lanes) x VMX_L3_KB wavenumbers (4 waves x VMX_L3_KB / 4).  The block
-    // copies its wavenumbers' table rows into LDS with all its threads (one coalesced stream), the interpolation's FMAs then
-    // take the table value as a broadcast LDS read (the same for the whole wave) and the walker's weight from a register.
-    // (Measured before this form: the same loop with the table values as scalar loads - 48 dependent round trips per wavenumber
-    // and less than one wave per SIMD to hide them - took 60 - 80 us, more than the k_pk_tab2 blocks it replaces.)
-    extern __shared__ double l3_lds[];
-    constexpr int KB = VMX_L3_KB, ROW = VMX_L3_ROW;
-    const int k_first = chunk * KB;
-    if (k_first >= D.nk) return;
-#ifdef VMX_EXP_L3_STAMP
-    unsigned long long stamp[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0};
-#endif
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b0 = blockIdx.x * 64 + lane;
-    const bool mine = b0 < B;
-    const int b = mine ? b0 : B - 1;
-    // Everything the block reads from global memory is requested up front, before the first value is looked at: with about one
-    // wave per SIMD nothing hides a round trip, and a chain of them (is the table valid? -> the walker's scalars -> the nodes ->
-    // per wavenumber its bound, its flag, k, the linear spectra) cost 50 us where the arithmetic is worth 5.
-    const int n = D.l3_n;
-    // ... the validity record of the tile (as l3_valid) and the level-2 key it must match
-    const int vc = lane >> 4, vq = lane & 15, vchunk = (k_first / 64) * 4 + vc;
-    const bool vload = vchunk * 16 < D.nkp && vq <= VMX_XTAB_KEY;
-    const double v_rec = vload ? D.l3_key[((size_t)l3 * (D.nkp / 16) + vchunk) * 16 + vq] : 0.0;
-    const double v_found = (vload && vq < VMX_XTAB_KEY) ? found[vq] : 0.0;
-    // ... the walker
-    const double* sc = D.scal + ((size_t)b * D.n_pipe + p) * VMX_NS;
-    const double c01 = sc[S_BIAS1], c11 = sc[S_BB1], hb = sc[S_HCD_B], hbb = sc[S_HCD_BB], L0 = sc[S_HCD_L0];
-    const double uv_lam = G.uvb ? sc[S_UV_LAM] : 0.0, uv_bg = G.uvb ? sc[S_UV_BG] : 0.0, uv_bp = (G.uvb || G.heii) ? sc[S_UV_BP] : 0.0;
-    const double he_lam = G.heii ? sc[S_HE_LAM] : 0.0, he_bg = G.heii ? sc[S_HE_BG] : 0.0;
-    // ... the nodes and their barycentric weights (lane c holds node c)
-    const double node_l = lane < n ? D.l3_node[lane] : 0.0, lam_l = lane < n ? D.l3_node[16 + lane] : 0.0;
-    // ... the wave's wavenumbers: bound of the exponents, error flag, k, the two linear spectra
-    constexpr int KW = (KB + 3) / 4;
-    static_assert(KW <= 2, "the rolled loop below selects the pre-loaded values of at most two wavenumbers per wave");
-    double pre_e[KW], pre_bad[KW], pre_k[KW], pre_ps[KW], pre_pq[KW];
-#pragma unroll
-    for (int u = 0; u < KW; ++u) {
-        const int i = min(k_first + wv + 4 * u, D.nk - 1);
-        const double* kx = D.xtab_k + (size_t)xt * 4 * D.nkp + i;
-        pre_e[u] = kx[3 * D.nkp]; pre_bad[u] = kx[2 * D.nkp]; pre_k[u] = D.k[i];
-        pre_ps[u] = D.pklin[(size_t)G.kind_s * D.nkp + i]; pre_pq[u] = D.pklin[(size_t)G.kind_q * D.nkp + i];
-    }
-    // ... its table rows into LDS
-    double* s_tab = l3_lds;                                     // [KB][ROW]
-    double* s_w = l3_lds + KB * ROW;                            // [16][64] lambda_c / (L0 - L0_c) per walker
-    {
-        // (direct global -> LDS copies, all in flight at once: a copy loop through registers waited for every load before its
-        // LDS write - twelve round trips, 12 us of this kernel's first 14)
-        const unsigned total = (unsigned)min(KB, D.nk - k_first) * ROW * 8u;           // bytes, a multiple of 16
-        const char* img = (const char*)(D.l3_tab + ((size_t)l3 * D.nkp + k_first) * ROW);
-        const unsigned wave_off = (threadIdx.x >> 6) * 1024u, lane_off = (threadIdx.x & 63) * 16u;
-        for (unsigned c = 0; c < total; c += 256u * 16u) {
-            const unsigned off = c + wave_off;                  // (a wave's 64 x 16 bytes land contiguously at its LDS base)
-            if (off + lane_off < total)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + off + lane_off),
-                                                 (__attribute__((address_space(3))) void*)((char*)s_tab + off), 16, 0, 0);
-        }
-    }
-    bool v_ok = true;
-    if (vload) v_ok = vq < VMX_XTAB_KEY ? v_rec == v_found : v_rec != (double)D.step_seq;
-    const bool valid = D.xtab_level >= 2 && __all(v_ok) != 0;
-    const bool use = valid && mine && L0 >= D.l3_lo && L0 <= D.l3_hi;
-    // the four waves hold the same walkers and share the divisions of the barycentric terms
-    for (int c = wv; c < n; c += 4) {
-        const double node_c = __shfl(node_l, c, 64), lam_c = __shfl(lam_l, c, 64);
-        s_w[c * 64 + lane] = lam_c / (L0 - node_c);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the table rows have landed
-    if (__syncthreads_or(use) == 0) return;         // (also the barrier behind the LDS copies)
-#ifdef VMX_EXP_L3_STAMP
-    stamp[1] = wall_clock64();
-#endif
-    {
-        const unsigned long long users = __ballot(use);
-        if (blockIdx.z == 0 && wv == 0 && lane == 0) atomicAdd(D.k_live + 5, (int)__popcll(users));       // (a statistic: vmx_debug_read 4 [9])
-    }
-    double wgt[VMX_L3_NODES];
-    bool centre_only;
-    {
-        int hit = -1;
-        double sum = 0.0;
-#pragma unroll
-        for (int c = 0; c < VMX_L3_NODES; ++c) {
-            wgt[c] = c < n ? s_w[c * 64 + lane] : 0.0;
-            if (c < n && L0 == __shfl(node_l, c, 64)) hit = c;
-            sum += wgt[c];
-        }
-        const double inv = 1.0 / sum;
-#pragma unroll
-        for (int c = 0; c < VMX_L3_NODES; ++c) wgt[c] = hit >= 0 ? (c == hit ? 1.0 : 0.0) : wgt[c] * inv;
-        if (!use) {
-#pragma unroll
-            for (int c = 0; c < VMX_L3_NODES; ++c) wgt[c] = c == n / 2 ? 1.0 : 0.0;      // (a lane that stores nothing: finite numbers)
-            hit = n / 2;
-        }
-        centre_only = __all(hit == n / 2);          // the wave's walkers share the configured L0 (a fit that keeps it fixed): one node
-#ifdef VMX_EXP_L3_CENTRE
-        centre_only = true;
-#endif
-    }
-#ifdef VMX_EXP_L3_STAMP
-    stamp[2] = wall_clock64();
-#endif
-    const int mid = D.l3_n / 2;
-    const double inv_nmu = 1.0 / (double)D.n_mu;
-    const size_t ncols = (size_t)B * D.n_active;
-    // The loops over the wavenumbers, the two tables and the six powers stay ROLLED (the thirteen nodes of a row are unrolled:
-    // the weights are registers): a wave runs a ~100-instruction body two dozen times instead of 3000 instructions once - code
-    // that runs once is fetched at ~2.5 ns per instruction, which made the unrolled form 15 us per wavenumber.
-    bool any_live = false;
-#pragma unroll 1
-    for (int u = 0; u < KW; ++u) {
-        const int kq = wv + 4 * u;
-        const int i = k_first + kq;
-        if (i >= D.nk) break;
-        const double e_u = u == 0 ? pre_e[0] : pre_e[KW - 1], bad_u = u == 0 ? pre_bad[0] : pre_bad[KW - 1], k = u == 0 ? pre_k[0] : pre_k[KW - 1];
-        const double ps_u = u == 0 ? pre_ps[0] : pre_ps[KW - 1], pq_u = u == 0 ? pre_pq[0] : pre_pq[KW - 1];
-        const bool live = !(e_u < VMX_PK_DEAD);                 // (dead: every value underflows - exact zeros, as k_pk_tab2's dead tiles)
-        double a01 = c01, damp = 1.0;
-        if (live) {
-            any_live = true;
-            if (bad_u != 0.0 && use) atomicOr(&D.status[b], VMX_STATUS_ARINYO);
-            if (G.lya1) {       // k-dependent effective bias from UV / HeII fluctuations (power_spectrum.py:224-261), as k_pk_tab2
-                if (G.uvb) { const double x = k * uv_lam; const double W = atan(x) / x; a01 += uv_bg * W / (1.0 + uv_bp * W); }
-                if (G.heii) { const double x = k * he_lam; const double W = atan(x) / x; a01 += he_bg * W / (1.0 + uv_bp * W); }
-            }
-            if (G.damping_scale > 0.0) damp = exp(-G.damping_scale * G.damping_scale * pow(k, (double)G.damping_power) / 2.0);
-        }
-        // [p0 + F p1]^2 = p0^2 + 2 F p0 p1 + F^2 p1^2, p0 = a01 + c11 mu^2, p1 = hb + hbb mu^2: coefficients of mu^0, mu^2, mu^4
-        const double q00 = a01 * a01, q01 = 2.0 * a01 * c11, q02 = c11 * c11;
-        const double q10 = 2.0 * a01 * hb, q11 = 2.0 * (a01 * hbb + c11 * hb), q12 = 2.0 * c11 * hbb;
-        const double q20 = hb * hb, q21 = 2.0 * hb * hbb, q22 = hbb * hbb;
-#ifdef VMX_EXP_L3_STAMP
-        if (u == 0) stamp[3] = wall_clock64();
-#endif
-        const double* tb = s_tab + kq * ROW;
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t) {
-            double M0 = 0.0, M1 = 0.0, M2 = 0.0, M3 = 0.0;
-            if (live) {
-#pragma unroll 1
-                for (int m = 0; m < 6; ++m) {
-                    const double* r1 = tb + ((t * 2 + 0) * 6 + m) * 16;
-                    const double* r2 = r1 + 6 * 16;
-                    double K1, K2;
-                    if (centre_only) { K1 = r1[mid]; K2 = r2[mid]; }
-                    else {
-                        // both rows into registers first (fourteen 16-byte LDS reads in flight), then the FMAs: read-then-use one
-                        // value at a time left every FMA behind its own LDS round trip
-                        v2d a[7];
-#pragma unroll
-                        for (int h = 0; h < 7; ++h) a[h] = ((const v2d*)r1)[h];
-                        double s1 = 0.0, u1 = 0.0, s2 = 0.0, u2 = 0.0;          // (two chains per row: the FMAs of a chain are dependent)
-#pragma unroll
-                        for (int h = 0; h < 7; ++h) {
-                            s1 = fma(wgt[2 * h], a[h].x, s1);
-                            if (2 * h + 1 < VMX_L3_NODES) u1 = fma(wgt[2 * h + 1], a[h].y, u1);
-                        }
-#pragma unroll
-                        for (int h = 0; h < 7; ++h) a[h] = ((const v2d*)r2)[h];
-#pragma unroll
-                        for (int h = 0; h < 7; ++h) {
-                            s2 = fma(wgt[2 * h], a[h].x, s2);
-                            if (2 * h + 1 < VMX_L3_NODES) u2 = fma(wgt[2 * h + 1], a[h].y, u2);
-                        }
-                        K1 = s1 + u1; K2 = s2 + u2;
-                    }
-                    const double K0 = tb[384 + t * 8 + m];
-                    // moment n takes power m = n + i with the coefficient of mu^(2 i)
-                    const double t0 = fma(q00, K0, fma(q10, K1, q20 * K2)), t1 = fma(q01, K0, fma(q11, K1, q21 * K2)), t2 = fma(q02, K0, fma(q12, K1, q22 * K2));
-                    M0 += m == 0 ? t0 : m == 1 ? t1 : m == 2 ? t2 : 0.0;
-                    M1 += m == 1 ? t0 : m == 2 ? t1 : m == 3 ? t2 : 0.0;
-                    M2 += m == 2 ? t0 : m == 3 ? t1 : m == 4 ? t2 : 0.0;
-                    M3 += m == 3 ? t0 : m == 4 ? t1 : m == 5 ? t2 : 0.0;
-                }
-            }
-            const int kind = t ? G.kind_q : G.kind_s;
-            const double pk = damp * ((D.pk_direct && kind == VMX_PKLIN_SMOOTH) ? D.pk_direct[(size_t)b * D.nkp + i] : (t ? pq_u : ps_u));
-            if (use) {
-                // moments -> Legendre multipoles, as k_pk_tab2 (pktoxi.py:37,55,138)
-                const size_t col = (size_t)(t ? G.col_q : G.col_s) * B + b;
-                double* dst = D.pl + col * D.nkp + i;
-                const size_t es = ncols * D.nkp;
-                dst[0] = pk * (M0 * inv_nmu);
-                if (D.n_ell > 1) dst[es] = pk * ((7.5 * M1 - 2.5 * M0) * inv_nmu);
-                if (D.n_ell > 2) dst[2 * es] = pk * ((39.375 * M2 - 33.75 * M1 + 3.375 * M0) * inv_nmu);
-                if (D.n_ell > 3) dst[3 * es] = pk * ((187.6875 * M3 - 255.9375 * M2 + 85.3125 * M1 - 4.0625 * M0) * inv_nmu);
-            }
-        }
-    }
-    if (any_live && lane == 0) atomicMax(D.k_live, min(((k_first >> 6) + 1) * 64, D.nk));
-#ifdef VMX_EXP_L3_STAMP
-    if (D.pk_trace && lane == 0 && wv == 0) {
-        unsigned long long* tr = D.pk_trace + 8 * (20000 + (size_t)blockIdx.z * gridDim.x + blockIdx.x);
-        stamp[4] = wall_clock64();
-        for (int q = 0; q < 5; ++q) tr[q] = stamp[q];
-    }
-#endif
+    if (G.cross) pk_tab2_body<KT, MS, NW, true>(D, G, B);
+    else pk_tab2_body<KT, MS, NW, false>(D, G, B);
 }
 
 // `fht_extrap` (reference pktoxi.py:41,141; mcfit's `_pad(extrap=True)`): behind the nk samples F of every P_ell row the

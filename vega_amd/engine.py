@@ -193,7 +193,6 @@ def load_library():
     lib.vmx_set_mu_quadrature.argtypes = [C.c_void_p, C.c_int32]
     lib.vmx_get_mu_nodes.argtypes = [C.c_void_p, dptr, dptr, C.c_int32]
     lib.vmx_set_mu_rule_box.argtypes = [C.c_void_p, C.c_int32, iptr, dptr, dptr]
-    lib.vmx_set_hcd_level3.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double]
     lib.vmx_stream.argtypes = [C.c_void_p]
     lib.vmx_stream.restype = C.c_void_p
     lib.vmx_last_stream.argtypes = [C.c_void_p]
@@ -227,7 +226,7 @@ EXPORTED_SYMBOLS = [
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_pipeline_set_odd_operator', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
     'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_item_set_mock_factor', 'vmx_item_get_mock_pool', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
-    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_eval_device_mocks', 'vmx_fit_migrad', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_static_poly', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_set_hcd_level3', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
+    'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_eval_device_mocks', 'vmx_fit_migrad', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_static_poly', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
 
@@ -809,12 +808,6 @@ class Engine:
             self._check(lib.vmx_set_static_poly(self._h, 0))
         self._check(lib.vmx_finalize(self._h, self.n_params, self.max_batch))
         self.model_size = self._check(lib.vmx_model_size(self._h))
-        # level-3 tables of the auto-correlation core groups: the box of the HCD scale around its configured value
-        # (include/vegamx.h: vmx_set_hcd_level3; VEGA_AMD_LEVEL3=0 switches them off)
-        self.level3_half_width = float(os.environ.get('VEGA_AMD_LEVEL3', '0.125'))
-        if self.level3_half_width > 0:
-            slot = low.s('L0_hcd')
-            self._check(lib.vmx_set_hcd_level3(self._h, slot, float(low.theta0[slot]) if slot >= 0 else 0.0, self.level3_half_width))
         # chi2-only evaluations run as a static quadratic form around the configured parameter values when the
         # configuration allows it (include/vegamx.h: vmx_set_quadratic_form)
         self.quadratic_form = bool(self._check(lib.vmx_set_quadratic_form(self._h, _dp(_f64(low.theta0)))))
@@ -1040,10 +1033,6 @@ class Engine:
     def last_form(self):
         """Form the last evaluation took: 'full' (distortion + C^-1 products), 'q' or 'factored'."""
         return ('full', 'q', 'factored')[int(self.debug_read(4, 0, 9)[8])]
-
-    def level3_served(self):
-        """(walker, group) pairs whose P_ell came from the level-3 tables in the last evaluation (vmx_set_hcd_level3)."""
-        return int(self.debug_read(4, 0, 10)[9])
 
     def set_quadratic_form(self, on=True):
         """Switch the quadratic form of chi2-only evaluations on (expansion point: the configured parameter values) or
