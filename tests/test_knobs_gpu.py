@@ -1,13 +1,20 @@
 """Every alternative path the library can be switched to (the VMX_* environment knobs read at vmx_finalize / at the first
 chi2-only call) is run against the same references as the default path: a fallback that is never exercised rots.
 
-Per knob an engine is built with the variable set and checked on
+The knobs are read once per engine, so they are exercised in three sets of knobs that act on different stages and do
+not mask each other (a set per engine, two fixtures: six engines instead of one per knob and fixture; with
+VEGA_TEST_SINGLE_KNOBS=1 every knob gets its own engine - the way to find the culprit when a set fails).  What masks what:
+without the quadratic form (VMX_NO_QUAD) or without the mapped buffers (VMX_NO_ZERO_COPY) a single walker's chi2 is never
+added up on the host, and the done word is only waited on when it is not - so VMX_NO_HOST_REDUCE runs once with the done
+word and once without.  Per set an engine is built with the variables set and checked on
   (a) the reference's 8 golden walkers of the dense-matrix joint fixture and of the joint + metals fixture, tiled to 64
       (walkers that differ in every parameter: the per-walker loops, the MFMA products, the streaming kernels at B = 1 / 8);
   (b) a batch that shares its Arinyo / smoothing parameters, as a sampler's does (the table levels, two walkers per thread,
       the shared-W kernel, the FFTLog ring at B = 256), against the default engine and - three walkers - the CPU oracle.
 Bars: chi2 1e-6, xi 1e-8 of the vector's scale (BASELINE.json north_star).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -18,11 +25,13 @@ pytestmark = pytest.mark.gpu
 XI_RTOL = 1e-8
 CHI2_RTOL = 1e-6
 
-KNOBS = [
-    ('VMX_NO_QUAD', '1'), ('VMX_NO_TAB2', '1'), ('VMX_EXACT_MU', '1'), ('VMX_NO_GRAPH', '1'), ('VMX_NO_ZERO_COPY', '1'),
-    ('VMX_NO_DONE_WORD', '1'), ('VMX_NO_HOST_REDUCE', '1'), ('VMX_NO_STATIC_POLY', '1'), ('VMX_NO_STATIC_BINS', '1'),
-    ('VMX_NO_PK_W', '1'), ('VMX_NO_XI_LEAN', '1'), ('VMX_NO_XI_SUMS', '1'),
+KNOB_SETS = [
+    ('VMX_NO_TAB2', 'VMX_NO_GRAPH', 'VMX_NO_HOST_REDUCE', 'VMX_NO_XI_LEAN'),
+    ('VMX_EXACT_MU', 'VMX_NO_HOST_REDUCE', 'VMX_NO_DONE_WORD', 'VMX_NO_STATIC_POLY', 'VMX_NO_XI_SUMS'),
+    ('VMX_NO_QUAD', 'VMX_NO_ZERO_COPY', 'VMX_NO_PK_W', 'VMX_NO_STATIC_BINS'),
 ]
+if os.environ.get('VEGA_TEST_SINGLE_KNOBS', '0') not in ('', '0'):
+    KNOB_SETS = [(k,) for k in sorted({k for ks in KNOB_SETS for k in ks})]
 SHARED_VARIED = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'sigma_velo_disp_lorentz_QSO', 'drp_QSO', 'bias_hcd',
                  'beta_hcd', 'L0_hcd', 'bias_eta_SiII(1190)', 'bias_eta_SiII(1193)', 'bias_eta_SiIII(1207)',
                  'bias_eta_SiII(1260)', 'bias_eta_CIV(eff)', 'bao_amp']
@@ -63,13 +72,15 @@ def _assert_xi(got, ref, what):
     assert np.abs(got - ref).max() <= XI_RTOL * scale, what
 
 
-@pytest.mark.parametrize('knob,value', KNOBS, ids=[f'{k}={v}' for k, v in KNOBS])
+@pytest.mark.parametrize('knobs', KNOB_SETS, ids=['+'.join(k[4:] for k in ks) for ks in KNOB_SETS])
 @pytest.mark.parametrize('tag', ['joint_synth', 'joint_metals'])
-def test_every_fallback_path_against_the_fixtures(monkeypatch, tag, knob, value):
+def test_every_fallback_path_against_the_fixtures(monkeypatch, tag, knobs):
     from vega_amd import VegaInterface
     n_shared = 256 if tag == 'joint_synth' else 64
     theta_s, chi2_s, pick, models_s = _default_results(tag, n_shared)
-    monkeypatch.setenv(knob, value)
+    for k in knobs:
+        monkeypatch.setenv(k, '1')
+    knob = '+'.join(knobs)
     exp = np.load(GOLDEN / f'expected_{tag}.npz')
     vega = VegaInterface(None, problem=_problem(tag), max_batch=n_shared)
     eng = vega.engine
