@@ -60,8 +60,7 @@ def test_mocks_are_the_references_mocks_and_per_walker_data():
     vega.close()
 
 
-def test_batched_mock_fits_are_unbiased_and_match_scipy_on_the_oracle():
-    from scipy import optimize
+def test_batched_mock_fits_are_unbiased_and_sit_at_the_oracles_minimum():
     from oracle import vega_cpu as oc
     from vega_amd import VegaInterface
     prob = _synth_problem()
@@ -87,17 +86,23 @@ def test_batched_mock_fits_are_unbiased_and_match_scipy_on_the_oracle():
     assert mc.mc_bestfits['ap'].shape == (n_mocks, 2) and len(mc.mc_chisq) == n_mocks
     assert all(mc.mc_valid_minima) and all(mc.mc_valid_hesse)
 
-    # one mock, same objective on the CPU oracle with SciPy: best fits agree within a fraction of the errors
+    # one mock, same objective on the CPU oracle: the engine's best fit is a stationary point of the ORACLE's chi2 - the value
+    # there is the engine's, no neighbour half an error away along an axis lies lower, and the vertex of the parabola through the
+    # three points of every axis is within a tenth of the error of the fit (9 evaluations of the ~0.4 s oracle; the Nelder-Mead
+    # run that used to stand here took 110 for the same statement)
     mock = {name: mc.mc_mocks[name][0] for name in prob.items}
 
     def objective(x):
         return oc.chi2(prob, dict(zip(names, x)), data_override=mock)
-    # (a simplex of one reported error per parameter around the fit: every evaluation of the ~0.25 s oracle then probes the
-    # neighbourhood that matters, where the default 5 % simplex spent its first hundred calls contracting from 5 sigma)
-    simplex = np.vstack([res.values[0]] + [res.values[0] + res.errors[0][i] * np.eye(len(names))[i] for i in range(len(names))])
-    ref = optimize.minimize(objective, res.values[0], method='Nelder-Mead',
-                            options={'xatol': 1e-5, 'fatol': 1e-4, 'maxfev': 110, 'initial_simplex': simplex})
-    assert ref.fun <= res.fval[0] + 1e-3
-    assert res.fval[0] - ref.fun < 2e-3
-    assert np.all(np.abs(ref.x - res.values[0]) < 0.1 * res.errors[0])
+    x0, err = res.values[0], res.errors[0]
+    f0 = objective(x0)
+    assert f0 == pytest.approx(res.fval[0], rel=1e-6)
+    for i in range(len(names)):
+        h = 0.5 * err[i]
+        fp, fm = objective(x0 + h * np.eye(len(names))[i]), objective(x0 - h * np.eye(len(names))[i])
+        assert min(fp, fm) > f0 - 1e-3
+        curv = fp - 2 * f0 + fm
+        assert curv > 0
+        assert abs(0.5 * h * (fp - fm) / curv) < 0.1 * err[i], names[i]
+        assert curv / h ** 2 >= 2.0 / err[i] ** 2 * 0.9       # (an error is never below the conditional one, 2 up / f''; Minuit's matrix is good to a few per cent)
     vega.close()

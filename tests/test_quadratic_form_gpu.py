@@ -103,13 +103,6 @@ def test_quadratic_form_with_mocks_rescaled_covariance_and_new_data(kind):
     df = eng.eval(base, want_model=True)[0]
     assert np.abs((dq - dq[0]) - (df - df[0])).max() < 1e-7      # differences of ~1e-3 reproduced to 1e-7 absolute
     eng.set_mock_index(None)
-    # rescaled inverse covariance (Monte-Carlo `scale`): the matrices are rebuilt
-    for name, item in prob.items.items():
-        eng.set_invcov(name, item.chi2_matrix / 4.0)
-    np.testing.assert_allclose(eng.eval(theta)[0], full_scaled := eng.eval(theta, want_model=True)[0], rtol=1e-10)
-    np.testing.assert_allclose(full_scaled[5], full[5] / 4.0, rtol=1e-9)
-    for name, item in prob.items.items():
-        eng.set_invcov(name, item.chi2_matrix)
     # new data vectors through the reference's Monte-Carlo switch: the linear terms are refreshed
     for name, view in vega.data.items():
         view.masked_mc_mock = mocks[name][1]
@@ -117,6 +110,12 @@ def test_quadratic_form_with_mocks_rescaled_covariance_and_new_data(kind):
     assert vega.chi2() == pytest.approx(oc.chi2(prob, data_override={n: mocks[n][1] for n in mocks}), rel=CHI2_RTOL)
     vega.monte_carlo = False
     assert vega.chi2() == pytest.approx(oc.chi2(prob), rel=CHI2_RTOL)
+    # rescaled inverse covariance (Monte-Carlo `scale`): the matrices are rebuilt (last: every rebuild factors the
+    # covariances again on the host in the factored form)
+    for name, item in prob.items.items():
+        eng.set_invcov(name, item.chi2_matrix / 4.0)
+    np.testing.assert_allclose(eng.eval(theta)[0], full_scaled := eng.eval(theta, want_model=True)[0], rtol=1e-10)
+    np.testing.assert_allclose(full_scaled[5], full[5] / 4.0, rtol=1e-9)
     vega.close()
 
 

@@ -2175,6 +2175,13 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
                 a = lds;
             }
         }
+#ifdef VMX_EXP_SKIP_SMALL
+        // experiment build (timing only, results are wrong): what the step costs without this launch - the bound of what folding
+        // it into its neighbour can give
+        static const int exp_skip = getenv("VMX_EXP_SKIP") ? atoi(getenv("VMX_EXP_SKIP")) : 0;
+        static int exp_calls = 0;
+        if ((exp_skip & 2) && ++exp_calls > 64) goto exp_no_prologue;
+#endif
         if (zero_copy && theta_by_value) {
             // (eager launches only: a captured graph would replay the walker it was captured with)
             ThetaArg ta;
@@ -2182,6 +2189,9 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             hipLaunchKernelGGL(k_prologue_byval, dim3(n_pro + n_tab), dim3(PRO_T), lds, e->stream, ta, D, B);
         } else
             hipLaunchKernelGGL(k_prologue, dim3(n_pro + n_tab), dim3(PRO_T), lds, e->stream, D, B);
+#ifdef VMX_EXP_SKIP_SMALL
+        exp_no_prologue:;
+#endif
     }
     {
         ScopedTimer t(e, KC_PK);
@@ -2468,6 +2478,11 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             }
             // the launch left contraction partials instead of the product: a small kernel adds them up
             ScopedTimer t(e, KC_CHI2);
+#ifdef VMX_EXP_SKIP_SMALL
+            static const int exp_skip1 = getenv("VMX_EXP_SKIP") ? atoi(getenv("VMX_EXP_SKIP")) : 0;
+            static int exp_calls1 = 0;
+            if (!((exp_skip1 & 1) && ++exp_calls1 > 64))
+#endif
             hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, (const double*)ql->part.p,
                                (const int32_t*)ql->nt_off.p);
             HIP_OK(hipGetLastError());

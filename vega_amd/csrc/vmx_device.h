@@ -2359,6 +2359,9 @@ __global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const do
     D.chi2[b] = st ? 1e100 : c;
     if (D.chi2_host) D.chi2_host[b] = st ? 1e100 : c;
     if (D.status_host) D.status_host[b] = st;
+#ifdef VMX_EXP_SKIP_SMALL
+    if (b == 0) { D.k_live[2] = D.coef_win[0]; D.k_live[3] = D.coef_win[1]; xtab_key_store(D); return; }      // (experiment: the window is never reset)
+#endif
     if (b == 0) {
         D.k_live[2] = D.coef_win[0]; D.k_live[3] = D.coef_win[1]; D.coef_win[0] = 0x7fffffff; D.coef_win[1] = -1;
         xtab_key_store(D);
