@@ -356,12 +356,14 @@ int vmx_eval_device_mocks(vmx_engine* e, const double* d_theta, int32_t B, doubl
  *   mock_row  [n_fits] host or NULL: the pool row (vmx_item_set_mock_pool) fit f is fitted to; NULL: the items' data
  *   opt       const_hint = vmx_set_constant_nl_hint's level for the rows of a round, or -1: derived here (a column varies when a
  *             stage frees it or the fits' rows differ in it - what vmx_eval derives from host walkers); NULL: -1, 512, 2;
- *             chunk = rows per engine call (0: 512); lanes = batches in flight (0: 2); mocks: see vmx_mock_stream (NULL: the
- *             pools hold the mocks already)
+ *             chunk = rows per engine call (0: 512); lanes = batches in flight (0: 2); mocks: see vmx_mock_stream - NULL: the
+ *             pools hold the mocks already
  *   results   [n_stages] host arrays the caller owns: x [n_fits][n] internal minimum, ext [n_fits][n] its external values,
  *             V [n_fits][n][n] internal error matrix, fval, edm, flags (VMX_FIT_* bits), nfcn (function calls of the stage, re-runs
  *             included), n_iter
- * Synchronous; calls on a handle stay serialised by the caller. */
+ * Synchronous; calls on a handle stay serialised by the caller.  Every argument is checked before anything runs (-1 and
+ * vmx_last_error, the engine untouched).  A run that fails later (-2: a HIP error, a stalled producer of a mock stream) leaves the
+ * engine usable with its hint / lanes restored; `results` and, with a mock stream, the items' mock pools then hold unspecified rows. */
 #define VMX_FIT_MAXN 32
 #define VMX_FIT_MAX_STAGES 2
 enum { VMX_FIT_VALID = 1, VMX_FIT_HESSE_FAILED = 2, VMX_FIT_ACCURATE = 4, VMX_FIT_AT_CALL_LIMIT = 8, VMX_FIT_MADE_POSDEF = 16 };

@@ -3094,6 +3094,8 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
     int max_req = 1, n_max = 1;
     for (int s = 0; s < spec->n_stages; ++s) {
         const vmx_fit_stage& st = spec->stage[s];
+        const vmx_fit_result& r = results[s];
+        REQUIRE(r.x && r.ext && r.V && r.fval && r.edm && r.flags && r.nfcn && r.n_iter, "vmx_fit_migrad: result arrays of every stage");
         n_max = std::max(n_max, (int)st.n);
         REQUIRE(st.n >= 1 && st.n <= VMX_FIT_MAXN, "vmx_fit_migrad: 1 .. 32 free parameters per stage");
         for (int i = 0; i < st.n; ++i) {
@@ -3281,7 +3283,7 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
         const int total = W.pin_word[0];
         if (total <= 0 && (!ms || next_wave >= n_waves)) break;
         if (total <= 0) { HIP_OK(hipEventRecord(W.ev_gap[gap_used + 1], st)); gap_used += 2; continue; }      // (nothing asked for yet: the next wave joins)
-        REQUIRE((size_t)total <= cap, "vmx_fit_migrad: a round asked for more rows than its buffers hold");
+        if ((size_t)total > cap) return fail(-2, "vmx_fit_migrad: a round asked for more rows than its buffers hold");
         HIP_OK(hipEventRecord(W.ev_gap[gap_used + 1], st));
         gap_used += 2;
         S.rounds += 1;
@@ -3314,7 +3316,6 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
     for (int s = 0; s < spec->n_stages; ++s) {
         const size_t n = spec->stage[s].n;
         const vmx_fit_result& r = results[s];
-        REQUIRE(r.x && r.ext && r.V && r.fval && r.edm && r.flags && r.nfcn && r.n_iter, "vmx_fit_migrad: result arrays");
         HIP_OK(hipMemcpy(r.x, W.ox[s].p, F * n * sizeof(double), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(r.ext, W.oext[s].p, F * n * sizeof(double), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(r.V, W.oV[s].p, F * n * n * sizeof(double), hipMemcpyDeviceToHost));
