@@ -178,7 +178,7 @@ VMX_HD inline void request_point(const FitStateT<N>& s, int n, int q, double* pt
         if (q & 1) pt[i] -= s.req_step[q >> 1]; else pt[i] += s.req_step[q >> 1];
     } else if (s.req_kind == REQ_OFFDIAG) {
         int i = 0, left = q;
-        while (left >= n - 1 - i) { left -= n - 1 - i; ++i; }
+        while (i < n - 2 && left >= n - 1 - i) { left -= n - 1 - i; ++i; }      // (bounded whatever q is)
         const int j = i + 1 + left;
         pt[i] += s.req_step[i];
         pt[j] += s.req_step[j];
@@ -194,7 +194,7 @@ VMX_HD inline double request_coord(const FitStateT<N>& s, int n, int q, int i)
         if (s.req_idx[q >> 1] == i) { if (q & 1) v -= s.req_step[q >> 1]; else v += s.req_step[q >> 1]; }
     } else if (s.req_kind == REQ_OFFDIAG) {
         int a = 0, left = q;
-        while (left >= n - 1 - a) { left -= n - 1 - a; ++a; }
+        while (a < n - 2 && left >= n - 1 - a) { left -= n - 1 - a; ++a; }
         if (i == a || i == a + 1 + left) v += s.req_step[i];
     }
     return v;
