@@ -63,7 +63,8 @@ def build_problem(workload):
     prob = bp(cfg, search_dirs=[REPO / 'tests' / 'golden'])
     for item in prob.items.values():
         item.distortion = synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt)
-        item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt))
+        item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt),
+                            inv_masked_cov=synthetic.inverse_masked_covariance(item.data_grid.rp, item.data_grid.rt, item.data_mask))
     return prob
 
 
@@ -357,7 +358,9 @@ def monte_carlo_fits(prob, device, n_mocks=1024):
                                    'seconds_in_rounds': st['seconds_rounds'], 'gpu_idle_seconds_between_rounds': st['gpu_idle_seconds_between_rounds'],
                                    'evals_per_s_in_rounds': st['evaluations'] / st['seconds_rounds'],
                                    'engine_calls_by_batch_size': st['calls_by_batch'], 'evaluations_by_batch_size': st['evaluations_by_batch'],
-                                   'host_fraction': idle / dt})
+                                   'host_fraction': idle / dt,
+                                   'driver_seconds': {k: st[k] for k in ('seconds', 'seconds_setup', 'seconds_rounds', 'seconds_host_waiting',
+                                                                        'seconds_waiting_for_draws', 'seconds_enqueuing_waves') if k in st}})
     finally:
         if saved is None:
             os.environ.pop('VEGA_AMD_FIT_DRIVER', None)
@@ -446,24 +449,15 @@ def cpu_baseline(workload, names, theta, repeats=7, warmups=2, extra_theta=None)
                       'pool allows 16 worker processes (more are killed by its process guard)'}, done, [vals[i] for i in done], extra_vals
 
 
-def set_rank_affinity(local_rank):
-    """Pin this rank to the CPUs of its GPU's NUMA node - before any GPU call, from sysfs alone: the AMD display devices of
-    /sys/class/drm in card order, the local_rank-th one's `numa_node`, that node's cpulist (eight Python drivers on one socket
-    would otherwise share whatever cores the scheduler picks).  Returns what was done, for the bench line."""
-    info = {'cpus_before': len(os.sched_getaffinity(0))}
+def set_rank_affinity(pci_address):
+    """Pin this rank to the CPUs of its GPU's NUMA node: sysfs `numa_node` of the PCI function HIP reports for the rank's device
+    (the order of /sys/class/drm cards is not HIP's device order: on the pool's 8-GPU hosts card0 sits on node 0 while the one
+    visible device may be on node 1), then that node's cpulist.  Launch latency through the far socket costs 1 - 2 % of the
+    latency-bound figures (single evaluation 47.5 against 46.0 us, Monte-Carlo fits 3400 against 3475 / s); eight Python drivers
+    on one socket would otherwise share whatever cores the scheduler picks.  Returns what was done, for the bench line."""
+    info = {'cpus_before': len(os.sched_getaffinity(0)), 'pci': pci_address}
     try:
-        cards = []
-        for card in sorted(Path('/sys/class/drm').glob('card[0-9]*'), key=lambda c: int(c.name[4:])):
-            if '-' in card.name:
-                continue
-            vendor = card / 'device' / 'vendor'
-            if vendor.is_file() and vendor.read_text().strip() == '0x1002':
-                cards.append(card)
-        if local_rank >= len(cards):
-            info['set'] = False
-            info['reason'] = f'{len(cards)} AMD devices in /sys/class/drm'
-            return info
-        node = int((cards[local_rank] / 'device' / 'numa_node').read_text().strip())
+        node = int((Path('/sys/bus/pci/devices') / pci_address / 'numa_node').read_text().strip())
         info['numa_node'] = node
         if node < 0:
             info['set'] = False
@@ -584,8 +578,6 @@ def main():
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: start it as `python bench.py --gpus N` (it '
                          'launches its own ranks) or under torchrun with --nproc-per-node equal to --gpus')
 
-    affinity = set_rank_affinity(local_rank) if world > 1 and not args.ranks_share_gpu else {'set': False, 'cpus_before': len(os.sched_getaffinity(0)), 'reason': 'one rank, or ranks sharing a GPU'}
-
     # torch bundles its own HIP runtime: it has to be loaded before libvegamx.so brings in the system one (importing it
     # does not touch the GPU; the first CUDA call below does, after the CPU baseline has finished)
     import torch
@@ -619,6 +611,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the vegamx engine has no CPU fallback')
     torch.cuda.set_device(local_rank)
+    # (after the CPU baseline, which uses every core it may: the rank's driver threads next to its GPU)
+    if args.ranks_share_gpu:
+        affinity = {'set': False, 'cpus_before': len(os.sched_getaffinity(0)), 'reason': 'ranks sharing a GPU'}
+    else:
+        props = torch.cuda.get_device_properties(local_rank)
+        affinity = set_rank_affinity(f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0')
     use_dist = world > 1 or args.force_dist
     on_rccl = args.dist_backend == 'nccl'
     if use_dist:
@@ -1104,6 +1102,7 @@ def main():
                                      'with walkers that vary those parameters too: general_walkers_evals_per_s; one batch in flight: single_lane_evals_per_s',
                        'varied_parameters': [v for v in VARIED if v in eng.low.slot],
                        'collective': communicator if use_dist else 'none',
+                       'cpu_affinity': affinity,
                        'steady_state': f'untimed before the timed region: {args.ramp_steps} ramp steps, a calibration pass, 20-step '
                                        f'blocks until two agree to 1 % (clock ramp), then the {args.warmup} warm-up steps - '
                                        '`value` is a warmed steady state'},

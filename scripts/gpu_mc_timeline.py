@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--method', default='migrad')
     ap.add_argument('--python-driver', action='store_true', help='the NumPy lock-step driver (vega_amd/migrad.py) instead of the device-resident one')
     ap.add_argument('--marker', action='store_true')
+    ap.add_argument('--like-bench', type=int, default=0, help='1: a second engine with two lanes alive (as in bench.py), 2: the same, closed again')
     ap.add_argument('--trace', default=None)
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
@@ -77,6 +78,20 @@ def main():
     import bench
     from vega_amd import VegaInterface
     prob = bench.build_problem('joint')
+    if args.like_bench:
+        # what bench.py has done before its Monte-Carlo leg: torch on the device, a second engine with two lanes that has run steps
+        import torch
+        from vega_amd import synthetic
+        other = VegaInterface(None, problem=prob, max_batch=256, device=0)
+        other.engine.set_constant_nl_hint(True, gaussian=True)
+        other.engine.set_lanes(2)
+        pool = torch.from_numpy(synthetic.walkers(other.engine.low.theta0, other.engine.names, 256, varied=bench.VARIED)).to('cuda:0')
+        out = torch.zeros(256, dtype=torch.float64, device='cuda:0')
+        for _ in range(300):
+            other.engine.eval_device(pool.data_ptr(), 256, out.data_ptr())
+        other.engine.sync()
+        if args.like_bench > 1:
+            other.close()
     vega = VegaInterface(None, problem=prob, max_batch=4096, device=0)
     vega.chi2()
     names = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO', 'bias_hcd']

@@ -230,7 +230,8 @@ def synth_joint_problem(with_global_cov=False, tmp_path=None):
     prob = build_problem(main, search_dirs=dirs)
     for item in prob.items.values():
         item.distortion = synthetic.distortion_matrix(item.model_grid.rp, item.model_grid.rt)
-        item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt))
+        item.set_covariance(synthetic.covariance(item.data_grid.rp, item.data_grid.rt),
+                            inv_masked_cov=synthetic.inverse_masked_covariance(item.data_grid.rp, item.data_grid.rt, item.data_mask))
     if with_global_cov and tmp_path is None:
         prob.global_cov = synthetic.global_covariance([(it.data_grid.rp, it.data_grid.rt)
                                                        for it in prob.items.values()])

@@ -615,3 +615,42 @@ def test_a_walkers_model_does_not_depend_on_the_batch_around_it():
         np.testing.assert_allclose(whole[name][:1], one_a[name], rtol=0, atol=1e-14 * scale)
         np.testing.assert_allclose(whole[name][128:], one_z[name], rtol=0, atol=1e-14 * scale)
     vega.close()
+
+
+@pytest.mark.parametrize('global_cov', [False, True], ids=['per-item covariances', 'global covariance'])
+def test_full_chain_chi2_by_the_covariance_tape(monkeypatch, global_cov):
+    """chi2 of the full chain (a model is asked for; reference vega_interface.py:295-319: r^T C^-1 r) at more than 8 walkers is
+    the quadratic-form launch over the inverse covariances - the half-triangle tape with the residuals as walker vectors -
+    instead of the C^-1 products + k_chi2.  Against the oracle, against the product path (VMX_NO_CINV_TAPE), at ragged batch
+    sizes, twice (the same bits), and with a mock as data."""
+    from conftest import synth_joint_problem
+    from oracle import vega_cpu as oc
+    from vega_amd import VegaInterface, synthetic
+    prob = synth_joint_problem(with_global_cov=global_cov)
+    vega = VegaInterface(None, problem=prob, max_batch=256)
+    eng = vega.engine
+    theta = synthetic.walkers(eng.low.theta0, eng.names, 256, seed=21)
+    chi2, status, model = eng.eval(theta, want_model=True)
+    assert not status.any()
+    for b in (0, 100, 255):
+        assert chi2[b] == pytest.approx(oc.chi2(prob, dict(zip(eng.names, theta[b]))), rel=1e-9)
+    again = eng.eval(theta, want_model=True)[0]
+    np.testing.assert_array_equal(again, chi2)
+    for n in (9, 65, 130):                       # ragged walker tiles; a walker's chi2 depends on the batch's tile count only in its last bits
+        np.testing.assert_allclose(eng.eval(theta[:n], want_model=True)[0], chi2[:n], rtol=1e-12)
+    if not global_cov:
+        from vega_amd.montecarlo import create_mocks
+        mocks = create_mocks(prob, vega.compute_model(), 2, seed=5)
+        for name, pool in mocks.items():
+            eng.set_mock_pool(name, pool)
+        eng.set_mock_index(np.ones(256, dtype=np.int32))
+        with_mock = eng.eval(theta, want_model=True)[0]
+        assert with_mock[3] == pytest.approx(oc.chi2(prob, dict(zip(eng.names, theta[3])), data_override={n: mocks[n][1] for n in mocks}), rel=1e-9)
+        eng.set_mock_index(None)
+    vega.close()
+    monkeypatch.setenv('VMX_NO_CINV_TAPE', '1')
+    vega = VegaInterface(None, problem=prob, max_batch=256)
+    products, _, model2 = vega.engine.eval(theta, want_model=True)
+    np.testing.assert_allclose(chi2, products, rtol=1e-12)
+    np.testing.assert_array_equal(model, model2)
+    vega.close()

@@ -6,7 +6,8 @@ not mask each other (a set per engine, two fixtures: six engines instead of one 
 VEGA_TEST_SINGLE_KNOBS=1 every knob gets its own engine - the way to find the culprit when a set fails).  What masks what:
 without the quadratic form (VMX_NO_QUAD) or without the mapped buffers (VMX_NO_ZERO_COPY) a single walker's chi2 is never
 added up on the host, and the done word is only waited on when it is not - so VMX_NO_HOST_REDUCE runs once with the done
-word and once without.  Per set an engine is built with the variables set and checked on
+word and once without; VMX_NO_CINV_TAPE (the full chain's chi2 by the C^-1 products instead of the tape) sits with VMX_NO_QUAD,
+where every chi2 of a large batch comes from the full chain.  Per set an engine is built with the variables set and checked on
   (a) the reference's 8 golden walkers of the dense-matrix joint fixture and of the joint + metals fixture, tiled to 64
       (walkers that differ in every parameter: the per-walker loops, the MFMA products, the streaming kernels at B = 1 / 8);
   (b) a batch that shares its Arinyo / smoothing parameters, as a sampler's does (the table levels, two walkers per thread,
@@ -28,7 +29,7 @@ CHI2_RTOL = 1e-6
 KNOB_SETS = [
     ('VMX_NO_TAB2', 'VMX_NO_GRAPH', 'VMX_NO_HOST_REDUCE', 'VMX_NO_XI_LEAN'),
     ('VMX_EXACT_MU', 'VMX_NO_HOST_REDUCE', 'VMX_NO_DONE_WORD', 'VMX_NO_STATIC_POLY', 'VMX_NO_XI_SUMS'),
-    ('VMX_NO_QUAD', 'VMX_NO_ZERO_COPY', 'VMX_NO_PK_W', 'VMX_NO_STATIC_BINS'),
+    ('VMX_NO_QUAD', 'VMX_NO_CINV_TAPE', 'VMX_NO_ZERO_COPY', 'VMX_NO_PK_W', 'VMX_NO_STATIC_BINS'),
 ]
 if os.environ.get('VEGA_TEST_SINGLE_KNOBS', '0') not in ('', '0'):
     KNOB_SETS = [(k,) for k in sorted({k for ks in KNOB_SETS for k in ks})]

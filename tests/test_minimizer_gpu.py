@@ -86,6 +86,16 @@ def test_batched_mock_fits_are_unbiased_and_sit_at_the_oracles_minimum():
     assert mc.mc_bestfits['ap'].shape == (n_mocks, 2) and len(mc.mc_chisq) == n_mocks
     assert all(mc.mc_valid_minima) and all(mc.mc_valid_hesse)
 
+    # the second minimiser through the same driver (`method='bfgs'`, what bench.py's `monte_carlo_fits.bfgs` runs): the same mocks
+    # (same seed), minima within Minuit's EDM tolerance of MIGRAD's
+    first_mocks = {name: np.array(mc.mc_mocks[name]) for name in prob.items}
+    other = vega.run_monte_carlo(num_mocks=n_mocks, seed=3, method='bfgs')
+    assert other.is_valid.all()
+    assert np.abs(other.fval - res.fval).max() < 2e-3
+    assert np.abs((other.values - res.values) / res.errors).max() < 0.1
+    for name in prob.items:
+        # (MIGRAD's mocks were made on the device while their fits ran, these on the host: L . draws in another order of additions)
+        np.testing.assert_allclose(vega.analysis.mc_mocks[name], first_mocks[name], rtol=1e-13, atol=1e-16)
     # one mock, same objective on the CPU oracle: the engine's best fit is a stationary point of the ORACLE's chi2 - the value
     # there is the engine's, no neighbour half an error away along an axis lies lower, and the vertex of the parabola through the
     # three points of every axis is within a tenth of the error of the fit (9 evaluations of the ~0.4 s oracle; the Nelder-Mead

@@ -258,6 +258,8 @@ struct vmx_engine {
     // tapes of the quadratic-form launches per number of walker tiles: the blocks' entries, their queues, the partial-sum slots
     struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> queue, nt_off; DevBuf<double> part; int n_blocks = 0; int n_entries = 0; };
     std::map<int, QuadList*> quad_lists;     // by number of walker tiles
+    std::map<int, QuadList*> cinv_lists;     // the same tape over the inverse covariances (chi2 of the full chain), by walker tiles
+    DevBuf<double> zero_row;                 // zeros, as long as the longest padded residual: that contraction has no linear term
     int quad_blocks = 0;             // persistent blocks of the quadratic-form launch: 2 per CU
     std::vector<double> host_key, pending_key;   // vmx_eval: shared parameters the level-2 tables hold / seen in the last call
     bool host_key_valid = false, skip_xtab_once = false;
@@ -278,6 +280,7 @@ struct vmx_engine {
     bool ring_allowed = true;        // one batch in flight only: a 128 KB block leaves the other lane's kernels no room on its CU
     int last_tab_level = 0;          // table level of the last chain (vmx_debug_read what = 4)
     bool no_tab2 = false;            // VMX_NO_TAB2: level-1 tables only (the Gaussian factors stay in the mu loop)
+    bool no_cinv_tape = false;       // VMX_NO_CINV_TAPE: chi2 of the full chain by the C^-1 products + k_chi2 at every batch size
     bool pk_small_attr = false;      // the single-walker P(k) shape asked for its > 64 KB of LDS
     bool kron_attr = false;          // k_metal_kron asked for its dynamic LDS
     DevBuf<double> mv_part;          // split-K slabs of the stand-alone product
@@ -332,6 +335,7 @@ struct vmx_engine {
         for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
         for (auto& q : quad_lists) delete q.second;
+        for (auto& q : cinv_lists) delete q.second;
         delete fitws;
         if (pin_theta) (void)hipHostFree(pin_theta);
         if (pin_chi2) (void)hipHostFree(pin_chi2);
@@ -1390,6 +1394,7 @@ int vmx_finalize(vmx_engine* e, int32_t n_params, int32_t max_batch)
         e->quad_blocks = 2 * cus;
     }
     if (getenv("VMX_NO_TAB2")) e->no_tab2 = true;
+    if (getenv("VMX_NO_CINV_TAPE")) e->no_cinv_tape = true;
     if (getenv("VMX_NO_PK_W")) e->no_pk_w = true;
     if (getenv("VMX_NO_HOST_REDUCE")) e->no_host_reduce = true;
     if (getenv("VMX_NO_XI_LEAN")) e->xi_lean = false;
@@ -1904,6 +1909,60 @@ static vmx_engine::QuadList* quad_work_list(vmx_engine* e, int B)
     vmx_engine::QuadList* ql = quad_build_tape(e, B);
     if (ql) e->quad_lists[tn] = ql;
     return ql;
+}
+
+// chi2 of the full chain, r^T C^-1 r = 2 r^T (L r) with the half-form inverse covariance L, is the same contraction as the
+// quadratic form's: the tape over the items' covariances (or over the global one), the residuals as walker vectors, no linear
+// term.  (Round 5: the 16x16x4 product + slabs + k_chi2 took 98 us at B = 256 where this launch takes ~30.)
+static bool cinv_tape_applies(const vmx_engine* e, int B)
+{
+    if (B <= 8 || e->no_cinv_tape) return false;
+    if (e->gcinv.p) return true;
+    if (e->items.size() > VMX_MAX_GROUP) return false;
+    for (auto* it : e->items) if (!it->has_cinv) return false;
+    return true;
+}
+
+static vmx_engine::QuadList* cinv_work_list(vmx_engine* e, int B)
+{
+    const int tn = (B + GEMM_BN - 1) / GEMM_BN;
+    auto found = e->cinv_lists.find(tn);
+    if (found != e->cinv_lists.end()) return found->second;
+    std::vector<vmx_plan::TapeProblem> probs;
+    int longest = 0;
+    if (e->gcinv.p) { probs.push_back({e->g_n, e->g_ld}); longest = e->g_ld; }
+    else for (auto* it : e->items) { probs.push_back({it->dev.n_masked, it->dev.n_masked_pad}); longest = std::max(longest, (int)it->dev.n_masked_pad); }
+    if (e->zero_row.n < (size_t)longest && e->zero_row.alloc((size_t)longest, true)) return nullptr;
+    vmx_plan::Tape T = vmx_plan::plan_quad_tape(probs, tn, e->quad_blocks, QUAD_ENTRY_STAGES, QUAD_SKEW, GEMM_BM, GEMM_BK, QUAD_K_BANDS);
+    auto* ql = new vmx_engine::QuadList();
+    ql->n_blocks = T.n_blocks;
+    ql->n_entries = (int)T.n_slots;
+    if (T.work.empty()) T.work.push_back(GemmWork{-1, 0, 0, 0, 0, 0, 0, 0});
+    if (ql->work.upload(T.work.data(), T.work.size()) || ql->queue.upload(T.queue.data(), T.queue.size()) ||
+        ql->nt_off.upload(T.nt_off.data(), T.nt_off.size()) ||
+        ql->part.alloc(std::max<size_t>((size_t)T.n_slots, 1) * 128, true)) { delete ql; return nullptr; }
+    e->cinv_lists[tn] = ql;
+    return ql;
+}
+
+static void cinv_launch_list(vmx_engine* e, vmx_engine::QuadList* ql, int B)
+{
+    GemmGroup G{};
+    auto add = [&](const double* A, const double* X, int n, int ld) {
+        GemmArgs g{};
+        g.A = A; g.lda = ld; g.X = X; g.ldx = ld; g.D = nullptr; g.ldd = ld;
+        g.M = n; g.N = B; g.K = ld; g.tri = 1; g.nsplit = 1; g.klen = ld;
+        g.d_slab = (int64_t)B * ld;
+        g.tm = (n + GEMM_BM - 1) / GEMM_BM; g.tn = (B + GEMM_BN - 1) / GEMM_BN;
+        g.part = ql->part.p; g.lin = e->zero_row.p; g.lin_row = nullptr; g.lin_pool = 0;
+        g.row0 = vmx_plan::tape_row0(n, GEMM_BM);
+        G.p[G.n++] = g;
+    };
+    if (e->gcinv.p) add(e->gcinv.p, e->gres.p, e->g_n, e->g_ld);
+    else for (auto* it : e->items) add(it->cinv.p, it->res.p, it->dev.n_masked, it->dev.n_masked_pad);
+    G.work = ql->work.p;
+    G.queue = ql->queue.p;
+    hipLaunchKernelGGL((k_gemm_nt44<KC_QUAD>), dim3(ql->n_blocks, 1), dim3(GEMM44_THREADS), 0, e->cur, G);
 }
 
 // static spline-coefficient basis of the polynomial pipelines: C[ell][basis][i] = OP_ell . V_i[ell] (k_poly_basis), with the
@@ -2484,7 +2543,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
             if (!((exp_skip1 & 1) && ++exp_calls1 > 64))
 #endif
             hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, (const double*)ql->part.p,
-                               (const int32_t*)ql->nt_off.p);
+                               (const int32_t*)ql->nt_off.p, 1);
             HIP_OK(hipGetLastError());
             e->last_B = B;
             e->last_full = false;
@@ -2559,7 +2618,7 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
         SlabInfo dslabs{};
         for (size_t q = 0; q < e->items.size(); ++q) dslabs.z[q] = 1;
         for (int stage = 0; stage < 2; ++stage) {       // 0: distortion products, 1: C^-1 products
-            if (stage == 1 && e->gcinv.p) break;
+            if (stage == 1 && (e->gcinv.p || cinv_tape_applies(e, B))) break;
             GemmGroup G{};
             int tiles_total = 0, per_xcd_total = 0;
             for (auto* it : e->items) {
@@ -2669,6 +2728,21 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
     for (size_t q = 1; q < e->items.size(); ++q) HIP_OK(hipStreamWaitEvent(e->stream, e->ev_join[q - 1], 0));
     }
     e->cur = e->stream;
+    if (grouped && cinv_tape_applies(e, B)) {
+        vmx_engine::QuadList* ql = cinv_work_list(e, B);
+        if (!ql) return -2;
+        {
+            ScopedTimer t(e, KC_INVCOV);
+            cinv_launch_list(e, ql, B);
+        }
+        ScopedTimer t(e, KC_CHI2);
+        hipLaunchKernelGGL(k_chi2_parts, dim3((B + 3) / 4), dim3(256), 0, e->stream, D, B, (const double*)ql->part.p,
+                           (const int32_t*)ql->nt_off.p, 0);
+        HIP_OK(hipGetLastError());
+        e->last_B = B;
+        e->last_full = true;
+        return 0;
+    }
     slabs.g = 1;
     if (e->gcinv.p)
         slabs.g = launch_product(e, KC_INVCOV, e->gcinv.p, e->g_ld, 0, e->g_n, e->g_ld, e->gres.p, e->g_ld, 0, B,
@@ -2687,6 +2761,8 @@ static int run_chain(vmx_engine* e, int B, int tab_mode, bool zero_copy = false,
 static int run_chain_cached(vmx_engine* e, int B, int tab_mode, bool zero_copy = false, bool quad = false)
 {
     if (e->n_xtab == 0) tab_mode = 0;
+    // (the covariance tape of the full chain is built - allocations, uploads - outside any stream capture)
+    if (!quad && B > 8 && e->items.size() <= VMX_MAX_GROUP && cinv_tape_applies(e, B) && !cinv_work_list(e, B)) return -2;
     if (!e->use_graphs || e->profiling) return run_chain(e, B, tab_mode, zero_copy, nullptr, nullptr, nullptr, quad);
     const int key = (((B * 4 + tab_mode) * 2 + (zero_copy ? 1 : 0)) * 2 + (e->direct ? 1 : 0)) * 2 + (quad ? 1 : 0);
     auto it = e->graphs.find(key);
@@ -2934,7 +3010,7 @@ static vmx_engine* clone_lane(vmx_engine* e)
     L->lanes.clear(); L->n_lanes = 1; L->lane_calls = 0;
     L->fitws = nullptr; L->call_mock = nullptr;
     L->stream = nullptr; L->cur = nullptr; L->aux.clear(); L->ev_join.clear(); L->ev_fork = nullptr;
-    L->graphs.clear(); L->quad_lists.clear(); L->spans.clear(); L->span_used = 0; L->profiling = false;
+    L->graphs.clear(); L->quad_lists.clear(); L->cinv_lists.clear(); L->spans.clear(); L->span_used = 0; L->profiling = false;
     L->pin_theta = nullptr; L->pin_chi2 = nullptr; L->pin_status = nullptr; L->pin_done = nullptr; L->pin_part = nullptr;
     L->dpin_theta = nullptr; L->dpin_chi2 = nullptr; L->dpin_status = nullptr; L->dpin_done = nullptr; L->dpin_part = nullptr;
     L->host_key_valid = false; L->pending_key.clear();

@@ -2319,7 +2319,7 @@ __global__ __launch_bounds__(CHI2_THREADS) void k_chi2_quad(EngineDev D, int B, 
 // chi2 from the contraction partials of the quadratic-form launch (GemmArgs::part): the slots of a persistent launch are
 // numbered per walker tile in tape order, [nt_off[nt], nt_off[nt + 1]); walker b of tile nt adds the two wave-row sums of
 // every slot of its tile in that order - an order that does not depend on which block computed what.  One wave per walker.
-__global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const double* part, const int32_t* nt_off)
+__global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const double* part, const int32_t* nt_off, int with_c0)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
@@ -2328,13 +2328,15 @@ __global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const do
     // each of these was a dependent round trip of lane 0 - eight in a row, most of this kernel's time.
     constexpr int CHI2_PRE = 4;     // items whose constant is requested ahead
     const int s0 = nt_off[nt], s1 = nt_off[nt + 1];
-    const int mock = D.mock_index[b];
+    // (with_c0 = 0: the contraction was r^T C^-1 r of the full chain itself - no constants of a quadratic form to add)
+    const int n_c0 = with_c0 ? D.n_items : 0;
+    const int mock = with_c0 ? D.mock_index[b] : -1;
     int st = D.status[b];
     double c0[CHI2_PRE];
 #pragma unroll
     for (int q = 0; q < CHI2_PRE; ++q) {
         c0[q] = 0.0;
-        if (q < D.n_items) { const ItemDev& it = D.items[q]; c0[q] = it.q_c0[(mock >= 0 && it.mock_pool) ? 1 + mock : 0]; }
+        if (q < n_c0) { const ItemDev& it = D.items[q]; c0[q] = it.q_c0[(mock >= 0 && it.mock_pool) ? 1 + mock : 0]; }
     }
     double acc = 0.0;
     for (int j = s0 + lane; j < s1; j += 64) {
@@ -2345,8 +2347,8 @@ __global__ __launch_bounds__(256) void k_chi2_parts(EngineDev D, int B, const do
     if (lane != 0) return;
     double c = acc;
 #pragma unroll
-    for (int q = 0; q < CHI2_PRE; ++q) if (q < D.n_items) c += c0[q];
-    for (int q = CHI2_PRE; q < D.n_items; ++q) {
+    for (int q = 0; q < CHI2_PRE; ++q) if (q < n_c0) c += c0[q];
+    for (int q = CHI2_PRE; q < n_c0; ++q) {
         const ItemDev& it = D.items[q];
         c += it.q_c0[(mock >= 0 && it.mock_pool) ? 1 + mock : 0];
     }

@@ -207,7 +207,8 @@ class MonteCarlo:
                     theta[:, cols] = ext0
                     on_engine = dict(plan, stages=[dict(st, free=cols[st['free']]) for st in plan['stages']])
                     rows = None if self._mock_rows is None else self._mock_rows[np.asarray(fit_ids)]
-                    outs, self.driver_stats = eng.fit_migrad(on_engine, theta, rows, mock_stream=self._mock_stream)
+                    outs, self.driver_stats = eng.fit_migrad(on_engine, theta, rows, mock_stream=self._mock_stream,
+                                                             chunk=int(os.environ.get('VEGA_AMD_FIT_CHUNK', '0')))
                     return outs
             return MigradMinimizer(evaluate, names, start, errors, limits, tol=tol, machine=machine)
         if method != 'bfgs':
@@ -440,7 +441,7 @@ class MonteCarlo:
         try:
             res = fitter.minimize(n_fits=num_mocks, fixed=self._fixed)
         finally:
-            if fitter.machine is None:          # (the device-resident fits state their rows per call, nothing is left on the engine)
+            if getattr(fitter, 'machine', None) is None:     # (the device-resident fits state their rows per call, nothing is left on the engine)
                 eng.set_mock_index(None)
             self._mock_rows = None
             for name, item in prob.items.items():

@@ -357,9 +357,15 @@ class CorrItem:
                 self._log_cov_det = float(np.linalg.slogdet(masked)[1])
         return self._log_cov_det
 
-    def set_covariance(self, cov):
+    def set_covariance(self, cov, inv_masked_cov=None):
+        """`inv_masked_cov`: the inverse of the masked covariance when the caller holds it already (it is computed at first use
+        otherwise - a second and a half at 3180 bins)."""
         self.cov = None if cov is None else np.asarray(cov, dtype=float)
-        self._inv_masked_cov = None
+        if inv_masked_cov is not None:
+            inv_masked_cov = np.asarray(inv_masked_cov, dtype=float)
+            if cov is None or inv_masked_cov.shape != (self.data_size, self.data_size):
+                raise ValueError('inv_masked_cov must be the [data_size, data_size] inverse of the masked covariance')
+        self._inv_masked_cov = inv_masked_cov
         self._log_cov_det = None
         self._chi2_matrix = None
 

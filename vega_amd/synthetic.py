@@ -6,15 +6,40 @@ benchmark configs therefore use the seeded generators below; the same arrays are
 the reference when the golden fixtures are made (tests/golden/make_golden.py) so that engine,
 oracle and reference all see identical inputs.
 """
+import hashlib
+
 import numpy as np
 
 SEED = 20260803
+
+# The dense generators are pure functions of their grids and cost seconds at 5000 bins; bench.py and the test suites build the same
+# problems dozens of times per process.  Results are kept per (function, grid, arguments) and handed out READ-ONLY (a caller that
+# wants to change one copies it); a few hundred MB per process at the benchmark's sizes.
+_KEPT = {}
+
+
+def _kept(tag, arrays, args, make):
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        a = np.ascontiguousarray(a, dtype=float)
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    key = (tag, h.hexdigest(), args)
+    if key not in _KEPT:
+        out = make()
+        out.flags.writeable = False
+        _KEPT[key] = out
+    return _KEPT[key]
 
 
 def distortion_matrix(rp, rt, seed=SEED, dense_fraction=0.65):
     """``DM = I - W``: W couples bins at similar rt, falls off with |d rp|; rows of W sum to 0.3;
     35 % of the far-off-band (|d rt| > 24) entries are zeroed so a CSR twin is meaningfully
-    sparse."""
+    sparse.  (Kept per grid; the array is read-only.)"""
+    return _kept('dm', (rp, rt), (seed, dense_fraction), lambda: _distortion_matrix(rp, rt, seed, dense_fraction))
+
+
+def _distortion_matrix(rp, rt, seed, dense_fraction):
     rp = np.asarray(rp, dtype=float)
     rt = np.asarray(rt, dtype=float)
     n = rp.size
@@ -152,7 +177,18 @@ def dmat_file_configs(directory, golden, config='auto', coef=2, item_options=Non
 
 
 def covariance(rp, rt):
-    """SPD covariance: variance ~ 1/r^2, Kronecker-exponential correlations in (rp, rt)."""
+    """SPD covariance: variance ~ 1/r^2, Kronecker-exponential correlations in (rp, rt).  (Kept per grid; read-only.)"""
+    return _kept('cov', (rp, rt), (), lambda: _covariance(rp, rt))
+
+
+def inverse_masked_covariance(rp, rt, mask):
+    """``inv(covariance(rp, rt)[mask][:, mask])`` - what `CorrItem.inv_masked_cov` computes (reference vega/utils.py:271-298) -
+    kept per (grid, mask), read-only: `item.set_covariance(cov, inv_masked_cov=...)`."""
+    mask = np.asarray(mask, dtype=bool)
+    return _kept('icov', (rp, rt, mask), (), lambda: np.linalg.inv(covariance(rp, rt)[:, mask][mask, :]))
+
+
+def _covariance(rp, rt):
     rp = np.asarray(rp, dtype=float)
     rt = np.asarray(rt, dtype=float)
     r = np.sqrt(rp**2 + rt**2)
