@@ -38,7 +38,9 @@ def test_launcher_reports_a_failed_rank_and_does_not_hang():
                           '--core-only', '--steps', '2'], cwd=str(REPO), text=True, capture_output=True, timeout=600)
     assert out.returncode != 0
     assert out.stdout == ''                                 # no JSON line from a failed job
-    assert out.stderr.count('needs a GPU') == 2             # both ranks were started and said why they stopped
+    # (a rank says why it stopped; the launcher ends the other one as soon as the first has failed - whether that one got to say
+    # it too is a matter of timing)
+    assert 1 <= out.stderr.count('needs a GPU') <= 2 and 'exited with code 1' in out.stderr
     assert 'exited with code' in out.stderr
 
 
