@@ -360,7 +360,8 @@ def monte_carlo_fits(prob, device, n_mocks=1024):
                                    'engine_calls_by_batch_size': st['calls_by_batch'], 'evaluations_by_batch_size': st['evaluations_by_batch'],
                                    'host_fraction': idle / dt,
                                    'driver_seconds': {k: st[k] for k in ('seconds', 'seconds_setup', 'seconds_rounds', 'seconds_host_waiting',
-                                                                        'seconds_waiting_for_draws', 'seconds_enqueuing_waves') if k in st}})
+                                                                        'seconds_waiting_for_draws', 'seconds_enqueuing_waves', 'seconds_enqueuing_rounds',
+                                                                        'seconds_enqueuing_calls') if k in st}})
     finally:
         if saved is None:
             os.environ.pop('VEGA_AMD_FIT_DRIVER', None)

@@ -407,6 +407,8 @@ typedef struct {
     double gpu_idle_seconds_between_rounds;     /* HIP events around the host's turn of every round: the stream empty */
     double seconds_waiting_for_draws;   /* mock stream: the host waiting for the producer at a wave's round */
     double seconds_enqueuing_waves;     /* mock stream: host time of the waves' copies and launches */
+    double seconds_enqueuing_rounds;    /* host time of the rounds' own launches (advance, scan, emit) */
+    double seconds_enqueuing_calls;     /* host time of the engine calls' launches */
 } vmx_fit_stats;
 int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, const double* theta0, const int32_t* mock_row,
                    const vmx_fit_options* opt, vmx_fit_result* results, vmx_fit_stats* stats);

@@ -3346,7 +3346,11 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
             D.admitted = b;
             wave_host_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count();
         }
-        if (fit_round(fit_cap, D, st, emit_lds, false)) return -2;
+        {
+            const auto t_r0 = std::chrono::steady_clock::now();
+            if (fit_round(fit_cap, D, st, emit_lds, false)) return -2;
+            S.seconds_enqueuing_rounds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count();
+        }
         if (gap_used + 2 > W.ev_gap.size()) {
             hipEvent_t a = nullptr, b = nullptr;
             HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
@@ -3366,6 +3370,7 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
         S.evaluations += total;
         bool lane_used = false;
         hipStream_t lane_stream = nullptr;
+        const auto t_c0 = std::chrono::steady_clock::now();
         for (int off = 0; off < total; off += chunk) {
             const int B = std::min(chunk, total - off);
             if (eval_device_impl(e, W.theta.p + (size_t)off * P, B, W.chi2.p + off, nullptr, W.status.p + off, mock_row ? W.mock.p + off : nullptr, true)) return -2;
@@ -3376,6 +3381,7 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
             S.calls_by_batch[bin] += 1;
             S.evaluations_by_batch[bin] += B;
         }
+        S.seconds_enqueuing_calls += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
         if (lane_used) {        // the next round's bookkeeping reads every chunk's chi2
             HIP_OK(hipEventRecord(W.ev_lane, lane_stream));
             HIP_OK(hipStreamWaitEvent(st, W.ev_lane, 0));

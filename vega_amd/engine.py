@@ -111,7 +111,8 @@ class FitStats(C.Structure):
                 ('calls_by_batch', C.c_int64 * 8), ('evaluations_by_batch', C.c_int64 * 8),
                 ('seconds', C.c_double), ('seconds_setup', C.c_double), ('seconds_rounds', C.c_double),
                 ('seconds_host_waiting', C.c_double), ('gpu_idle_seconds_between_rounds', C.c_double),
-                ('seconds_waiting_for_draws', C.c_double), ('seconds_enqueuing_waves', C.c_double)]
+                ('seconds_waiting_for_draws', C.c_double), ('seconds_enqueuing_waves', C.c_double),
+                ('seconds_enqueuing_rounds', C.c_double), ('seconds_enqueuing_calls', C.c_double)]
 
 
 FIT_BATCH_BINS = ('1', '2..4', '5..16', '17..64', '65..256', '257..1024', '1025..4096', '4097..')
