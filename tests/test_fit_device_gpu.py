@@ -231,3 +231,26 @@ def test_device_fits_with_a_global_covariance_and_with_metals():
     # over such a fit without changing a decision - seen between boxes, whose host BLAS the NumPy driver's arithmetic follows)
     _assert_same_fits(a, b, rtol_err=1e-4, flips=1, rtol_fval=1e-8, max_pull=1e-4)
     vega.close()
+
+
+def test_seventeen_free_parameters_take_the_largest_state_record():
+    """More than 16 free parameters: the fit kernels' 32-parameter instantiation (k_fit_advance<32, 1>, k_fit_emit<32>: a 22 KB
+    state record per fit, gradients of 34 points, HESSE's 136 off-diagonal points) against the NumPy driver: five physical
+    parameters and the twelve coefficients of the additive post-distortion broadband (chi2 is exactly quadratic in those)."""
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, str(REPO))
+    from bench import build_problem
+    from vega_amd import VegaInterface
+    prob = build_problem('joint_metals')
+    bb = sorted(n for n in prob.params if n.startswith('BB-') and 'add post' in n)
+    names = ['ap', 'at', 'bias_eta_LYA', 'beta_LYA', 'beta_QSO'] + bb
+    assert len(names) == 17
+    _sample(prob, names, [(0.5, 1.5), (0.5, 1.5), (-2., 0.), (0., 5.), (0., 1.)] + [(-1., 1.)] * 12, [0.01, 0.01, 0.01, 0.1, 0.1] + [1e-4] * 12)
+    vega = VegaInterface(None, problem=prob, max_batch=256)
+    _, a = _run_mc(vega, 3, 21, 'python')
+    mc, b = _run_mc(vega, 3, 21, 'device')
+    # (fits of 960 - 1340 calls each; call for call the same on the boxes seen so far)
+    _assert_same_fits(a, b, rtol_err=1e-3, flips=1, rtol_fval=1e-8, max_pull=1e-3)
+    assert a.is_valid.all() and mc.driver_stats['fits_unfinished'] == 0
+    vega.close()
