@@ -254,3 +254,39 @@ def test_seventeen_free_parameters_take_the_largest_state_record():
     _assert_same_fits(a, b, rtol_err=1e-3, flips=1, rtol_fval=1e-8, max_pull=1e-3)
     assert a.is_valid.all() and mc.driver_stats['fits_unfinished'] == 0
     vega.close()
+
+
+def test_refused_fit_requests_leave_the_engine_as_it_was():
+    """include/vegamx.h: every argument of vmx_fit_migrad is checked before anything runs."""
+    from vega_amd import VegaInterface
+    prob = synth_joint_problem()
+    vega = VegaInterface(None, problem=prob, max_batch=64)
+    eng = vega.engine
+    before = vega.chi2()
+    col = {n: eng.low.slot[n] for n in ('ap', 'at', 'beta_LYA')}
+    theta = np.tile(eng.low.theta0, (4, 1))
+    good = dict(free=[col['ap'], col['at']], limits=[(0.5, 1.5), (0.5, 1.5)], errors=[0.01, 0.01])
+    base = dict(iterate=5, maxfcn=100000, up=1.0, tol=0.1)
+
+    def plan(**stage):
+        return dict(base, stages=[dict(good, **stage)])
+    refused = [
+        (plan(free=[col['ap'], col['ap']]), 'twice'),
+        (plan(free=[col['ap'], eng.n_params]), 'column'),
+        (plan(limits=[(1.5, 0.5), (0.5, 1.5)]), 'limits'),
+        (plan(errors=[0.0, 0.01]), 'step'),
+        (dict(base, iterate=0, stages=[good]), 'iterate'),
+        (dict(base, up=-1.0, stages=[good]), 'up'),
+    ]
+    for p, word in refused:
+        with pytest.raises(Exception, match=word):
+            eng.fit_migrad(p, theta)
+    with pytest.raises(Exception, match='const_hint'):
+        eng.fit_migrad(plan(), theta, const_hint=7)
+    with pytest.raises(Exception, match='pool'):
+        eng.fit_migrad(plan(), theta, mock_rows=np.array([0, 0, 0, 3], dtype=np.int32))      # (no mock pool installed)
+    assert vega.chi2() == before
+    outs, stats = eng.fit_migrad(plan(), theta)                 # ... and the same request, valid, runs
+    assert stats['fits_unfinished'] == 0 and (outs[0]['flags'] & 1).all()
+    assert vega.chi2() == before
+    vega.close()
