@@ -616,8 +616,11 @@ def main():
     if args.ranks_share_gpu:
         affinity = {'set': False, 'cpus_before': len(os.sched_getaffinity(0)), 'reason': 'ranks sharing a GPU'}
     else:
-        props = torch.cuda.get_device_properties(local_rank)
-        affinity = set_rank_affinity(f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0')
+        try:
+            props = torch.cuda.get_device_properties(local_rank)
+            affinity = set_rank_affinity(f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0')
+        except (AttributeError, RuntimeError) as exc:      # (a torch without the PCI fields: no pinning, said so in the line)
+            affinity = {'set': False, 'cpus_before': len(os.sched_getaffinity(0)), 'reason': f'no PCI address of the device: {exc}'}
     use_dist = world > 1 or args.force_dist
     on_rccl = args.dist_backend == 'nccl'
     if use_dist:

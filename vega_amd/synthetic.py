@@ -32,6 +32,11 @@ def _kept(tag, arrays, args, make):
     return _KEPT[key]
 
 
+def forget():
+    """Drops the kept arrays (a process that has built many different grids and wants the memory back)."""
+    _KEPT.clear()
+
+
 def distortion_matrix(rp, rt, seed=SEED, dense_fraction=0.65):
     """``DM = I - W``: W couples bins at similar rt, falls off with |d rp|; rows of W sum to 0.3;
     35 % of the far-off-band (|d rt| > 24) entries are zeroed so a CSR twin is meaningfully
