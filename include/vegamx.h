@@ -296,6 +296,11 @@ int vmx_set_mock_index(vmx_engine* e, const int32_t* index, int32_t B);
  * (the MOCKS table of the result file, reference vega/output.py:442-520). */
 int vmx_item_set_mock_factor(vmx_engine* e, int32_t item, const double* chol, const double* fiducial, int32_t n_masked);
 int vmx_item_get_mock_pool(vmx_engine* e, int32_t item, double* pool, int32_t n_mocks, int32_t n_masked);
+/* Page-locked host memory for buffers the library reads asynchronously - the `draws` of a vmx_mock_stream above all: from
+ * pageable memory every wave's upload is staged (and, behind some runtimes, pinned page by page while the producer is still
+ * first-touching the buffer: 20 ms of a 290-ms run).  Owned by the engine: vmx_host_free, or vmx_destroy at the latest. */
+int vmx_host_alloc(vmx_engine* e, void** out, int64_t bytes);
+int vmx_host_free(vmx_engine* e, void* p);
 
 /* Global-covariance mode (vega_interface.py:295-304): inverse of the masked global covariance over
  * the concatenation of all items' masked bins, in item order. */

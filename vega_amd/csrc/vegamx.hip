@@ -258,6 +258,7 @@ struct vmx_engine {
     // tapes of the quadratic-form launches per number of walker tiles: the blocks' entries, their queues, the partial-sum slots
     struct QuadList { DevBuf<GemmWork> work; DevBuf<int32_t> queue, nt_off; DevBuf<double> part; int n_blocks = 0; int n_entries = 0; };
     std::map<int, QuadList*> quad_lists;     // by number of walker tiles
+    std::vector<void*> host_allocs;          // vmx_host_alloc: pinned host buffers handed to the caller, freed with the engine at the latest
     std::map<int, QuadList*> cinv_lists;     // the same tape over the inverse covariances (chi2 of the full chain), by walker tiles
     DevBuf<double> zero_row;                 // zeros, as long as the longest padded residual: that contraction has no linear term
     int quad_blocks = 0;             // persistent blocks of the quadratic-form launch: 2 per CU
@@ -336,6 +337,7 @@ struct vmx_engine {
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
         for (auto& q : quad_lists) delete q.second;
         for (auto& q : cinv_lists) delete q.second;
+        for (void* p : host_allocs) (void)hipHostFree(p);
         delete fitws;
         if (pin_theta) (void)hipHostFree(pin_theta);
         if (pin_chi2) (void)hipHostFree(pin_chi2);
@@ -1323,6 +1325,30 @@ int vmx_item_get_mock_pool(vmx_engine* e, int32_t item, double* pool, int32_t n_
     wait_lane(e);
     HIP_OK(hipStreamSynchronize(e->stream));
     HIP_OK(hipMemcpy(pool, it->mock_pool.p, (size_t)n_mocks * n_masked * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int vmx_host_alloc(vmx_engine* e, void** out, int64_t bytes)
+{
+    REQUIRE(e && out && bytes > 0, "vmx_host_alloc");
+    HIP_OK(hipSetDevice(e->device));
+    void* p = nullptr;
+    HIP_OK(hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
+    e->host_allocs.push_back(p);
+    *out = p;
+    return 0;
+}
+
+int vmx_host_free(vmx_engine* e, void* p)
+{
+    REQUIRE(e && p, "vmx_host_free");
+    auto it = std::find(e->host_allocs.begin(), e->host_allocs.end(), p);
+    REQUIRE(it != e->host_allocs.end(), "vmx_host_free: not a buffer of vmx_host_alloc on this engine");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->stream));       // (no copy out of it may still be queued)
+    wait_lane(e);
+    e->host_allocs.erase(it);
+    HIP_OK(hipHostFree(p));
     return 0;
 }
 
@@ -3010,7 +3036,7 @@ static vmx_engine* clone_lane(vmx_engine* e)
     L->lanes.clear(); L->n_lanes = 1; L->lane_calls = 0;
     L->fitws = nullptr; L->call_mock = nullptr;
     L->stream = nullptr; L->cur = nullptr; L->aux.clear(); L->ev_join.clear(); L->ev_fork = nullptr;
-    L->graphs.clear(); L->quad_lists.clear(); L->cinv_lists.clear(); L->spans.clear(); L->span_used = 0; L->profiling = false;
+    L->graphs.clear(); L->quad_lists.clear(); L->cinv_lists.clear(); L->host_allocs.clear(); L->spans.clear(); L->span_used = 0; L->profiling = false;
     L->pin_theta = nullptr; L->pin_chi2 = nullptr; L->pin_status = nullptr; L->pin_done = nullptr; L->pin_part = nullptr;
     L->dpin_theta = nullptr; L->dpin_chi2 = nullptr; L->dpin_status = nullptr; L->dpin_done = nullptr; L->dpin_part = nullptr;
     L->host_key_valid = false; L->pending_key.clear();

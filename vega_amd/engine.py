@@ -173,6 +173,8 @@ def load_library():
     lib.vmx_set_mock_index.argtypes = [C.c_void_p, iptr, C.c_int32]
     lib.vmx_item_set_mock_factor.argtypes = [C.c_void_p, C.c_int32, dptr, dptr, C.c_int32]
     lib.vmx_item_get_mock_pool.argtypes = [C.c_void_p, C.c_int32, dptr, C.c_int32, C.c_int32]
+    lib.vmx_host_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int64]
+    lib.vmx_host_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.vmx_add_prior.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double]
     lib.vmx_finalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.vmx_model_size.argtypes = [C.c_void_p]
@@ -226,7 +228,7 @@ EXPORTED_SYMBOLS = [
     'vmx_last_error', 'vmx_struct_size', 'vmx_create', 'vmx_destroy', 'vmx_set_template', 'vmx_set_fftlog', 'vmx_set_fftlog_padding', 'vmx_set_spline_extrapolation', 'vmx_set_fvoigt_table', 'vmx_add_gk_table', 'vmx_add_gk_table_mock',
     'vmx_add_pipeline', 'vmx_pipeline_set_tracer_evolution', 'vmx_pipeline_set_odd_terms', 'vmx_pipeline_set_odd_operator', 'vmx_set_shotnoise_table',
     'vmx_item_set_additive_template', 'vmx_add_item', 'vmx_item_add_metal', 'vmx_item_set_metal_static', 'vmx_item_set_metal_basis', 'vmx_item_set_metal_kron', 'vmx_set_metal_beta_override', 'vmx_item_add_broadband', 'vmx_item_set_matrix', 'vmx_item_set_matrix_csr',
-    'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_item_set_mock_factor', 'vmx_item_get_mock_pool', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
+    'vmx_item_set_mask', 'vmx_item_set_data', 'vmx_item_set_mock_pool', 'vmx_set_mock_index', 'vmx_item_set_mock_factor', 'vmx_item_get_mock_pool', 'vmx_host_alloc', 'vmx_host_free', 'vmx_set_global_invcov', 'vmx_add_prior', 'vmx_finalize',
     'vmx_model_size', 'vmx_pipeline_column', 'vmx_eval', 'vmx_eval_device', 'vmx_eval_device_mocks', 'vmx_fit_migrad', 'vmx_sync', 'vmx_set_constant_nl_hint', 'vmx_set_direct_pk', 'vmx_set_linear_spectra', 'vmx_item_set_marg_matrix', 'vmx_marg_coeff', 'vmx_set_quadratic_form', 'vmx_set_quadratic_form_kind', 'vmx_set_static_poly', 'vmx_set_mu_quadrature', 'vmx_set_mu_rule_box', 'vmx_get_mu_nodes', 'vmx_set_parameter_transform', 'vmx_stream', 'vmx_last_stream', 'vmx_set_lanes', 'vmx_debug_read', 'vmx_matvec_device', 'vmx_matmul_host',
     'vmx_set_profiling', 'vmx_set_profiling_mask', 'vmx_get_timings', 'vmx_kernel_name']
 
@@ -869,6 +871,22 @@ class Engine:
         qi = self.item_names.index(name)
         chol, fid = _f64(chol), _f64(fiducial_masked)
         self._check(self.lib.vmx_item_set_mock_factor(self._h, qi, _dp(chol), _dp(fid), fid.size))
+
+    def pinned_empty(self, shape):
+        """A float64 array of ``shape`` in page-locked host memory (include/vegamx.h: vmx_host_alloc) - for buffers the library
+        copies from asynchronously.  Kept per engine and reused while it is large enough; the memory lives until `close()`, so the
+        array must not be used after that."""
+        count = int(np.prod(shape))
+        kept = self.__dict__.get('_pinned')
+        if kept is None or kept[1] < count:
+            if kept is not None:
+                self._check(self.lib.vmx_host_free(self._h, kept[0]))
+                self._pinned = None
+            ptr = C.c_void_p()
+            self._check(self.lib.vmx_host_alloc(self._h, C.byref(ptr), count * 8))
+            self._pinned = kept = (ptr, count)
+        flat = np.ctypeslib.as_array(C.cast(kept[0], C.POINTER(C.c_double)), shape=(kept[1],))
+        return flat[:count].reshape(shape)
 
     def get_mock_pool(self, name, n_mocks):
         """The first ``n_mocks`` rows of item ``name``'s mock pool, as the device holds them."""

@@ -352,22 +352,9 @@ class MonteCarlo:
         if sample_params is None and prob.mc_config is not None:
             sample_params = prob.mc_config['sample']
         scales = item_scales(prob, scale)
-        sizes = []
-        for name, item in prob.items.items():
-            cache = item.__dict__.setdefault('_cholesky', {})
-            key = (scales[name], True)
-            if key not in cache:
-                cache[key] = np.linalg.cholesky(scales[name] * item.cov[:, item.data_mask][item.data_mask, :])
-            fid = _fiducial_on_data_grid(item, fiducial_model[name])[item.data_mask]
-            sent = eng.__dict__.setdefault('_mock_factor_sent', {})
-            if name not in sent or sent[name][0] is not cache[key] or not np.array_equal(sent[name][1], fid):
-                eng.set_mock_factor(name, cache[key], fid)         # (kept on the device until another factor / fiducial comes)
-                sent[name] = (cache[key], fid.copy())
-            sizes.append(item.data_size)
-            if scales[name] != 1.:
-                eng.set_invcov(name, item.chi2_matrix / scales[name])
-        stride = int(sum(sizes))
-        draws = np.empty((num_mocks, stride))
+        stride = int(sum(item.data_size for item in prob.items.values()))
+        # (page-locked: the waves' uploads are plain DMA, and the producer below does not first-touch pages the runtime is pinning)
+        draws = eng.pinned_empty((num_mocks, stride)) if hasattr(eng, 'pinned_empty') else np.empty((num_mocks, stride))
         counter = np.zeros(1, dtype=np.int32)
         failure = []
 
@@ -383,10 +370,26 @@ class MonteCarlo:
                 failure.append(exc)
                 counter[0] = num_mocks
         producer = threading.Thread(target=produce, name='mock-draws', daemon=True)
+        producer.start()        # (first thing: the stream is the one sequential part, everything below runs next to it)
+        try:
+            for name, item in prob.items.items():
+                cache = item.__dict__.setdefault('_cholesky', {})
+                key = (scales[name], True)
+                if key not in cache:
+                    cache[key] = np.linalg.cholesky(scales[name] * item.cov[:, item.data_mask][item.data_mask, :])
+                fid = _fiducial_on_data_grid(item, fiducial_model[name])[item.data_mask]
+                sent = eng.__dict__.setdefault('_mock_factor_sent', {})
+                if name not in sent or sent[name][0] is not cache[key] or not np.array_equal(sent[name][1], fid):
+                    eng.set_mock_factor(name, cache[key], fid)         # (kept on the device until another factor / fiducial comes)
+                    sent[name] = (cache[key], fid.copy())
+                if scales[name] != 1.:
+                    eng.set_invcov(name, item.chi2_matrix / scales[name])
+        except BaseException:
+            producer.join()
+            raise
         fitter = self.minimizer(sample_params, method='migrad')
         self._mock_rows = np.arange(num_mocks, dtype=np.int32)
         self._mock_stream = dict(draws=draws, counter=counter, wave=wave, timeout=300.)
-        producer.start()
         try:
             res = fitter.minimize(n_fits=num_mocks, fixed=self._fixed)
         finally:
