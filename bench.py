@@ -342,13 +342,16 @@ def monte_carlo_fits(prob, device, n_mocks=1024):
         for label, method, driver in (('migrad', 'migrad', 'device'), ('migrad_numpy_driver', 'migrad', 'python'), ('bfgs', 'bfgs', 'python')):
             os.environ['VEGA_AMD_FIT_DRIVER'] = driver
             vega.run_monte_carlo(num_mocks=128, seed=5, sample_params=sample, method=method)
-            t0 = time.perf_counter()
-            res = vega.run_monte_carlo(num_mocks=n_mocks, seed=11, sample_params=sample, method=method)
-            dt = time.perf_counter() - t0
+            runs = []
+            for _ in range(2):          # (the same run twice, the faster one reported, both listed: one-off stalls of a shared host)
+                t0 = time.perf_counter()
+                res_i = vega.run_monte_carlo(num_mocks=n_mocks, seed=11, sample_params=sample, method=method)
+                runs.append((time.perf_counter() - t0, res_i))
+            dt, res = min(runs, key=lambda r: r[0])
             pulls = (res.values - truth) / res.errors
             out[label] = {'fits_per_s': n_mocks / dt, 'seconds': dt, 'chi2_evaluations': int(res.nfcn.sum()),
                           'evals_per_fit': float(res.nfcn.mean()), 'valid_fraction': float(res.is_valid.mean()),
-                          'pull_rms': [float(v) for v in pulls.std(axis=0)]}
+                          'pull_rms': [float(v) for v in pulls.std(axis=0)], 'seconds_of_both_runs': [r[0] for r in runs]}
             st = getattr(res, 'driver_stats', None)
             if st:
                 # the driver's own account: the GPU is idle while the host takes its turn of a round (HIP events around it) and
