@@ -135,6 +135,19 @@ def test_synthetic_tensors_are_deterministic_and_well_formed():
     assert np.allclose(cov, cov.T) and np.linalg.eigvalsh(cov).min() > 0
     theta = synthetic.walkers(np.array([1.0, 0.0, 9e99]), ['ap', 'x', 'qso_rad_lifetime'], 5)
     assert theta.shape == (5, 3) and np.all(theta[:, 2] == 9e99) and np.ptp(theta[:, 0]) > 0
+    # the generators keep their results per grid (read-only, the same object again; another grid or argument is another entry;
+    # the kept inverse is the item's own inverse), and a fresh generation after forget() gives the same bits
+    assert synthetic.distortion_matrix(grid.rp[:400], grid.rt[:400]) is dm and not dm.flags.writeable
+    assert synthetic.distortion_matrix(grid.rp[:400], grid.rt[:400], dense_fraction=0.5) is not dm
+    with pytest.raises(ValueError):
+        dm[0, 0] = 1.0
+    mask = np.arange(300) % 3 != 0
+    inv = synthetic.inverse_masked_covariance(grid.rp[:300], grid.rt[:300], mask)
+    np.testing.assert_array_equal(inv, np.linalg.inv(cov[:, mask][mask, :]))
+    kept = dm.copy()
+    synthetic.forget()
+    again = synthetic.distortion_matrix(grid.rp[:400], grid.rt[:400])
+    assert again is not dm and np.array_equal(again, kept)
 
 
 def test_table_bundle_round_trip(tmp_path):
