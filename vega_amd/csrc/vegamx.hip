@@ -3256,17 +3256,22 @@ int vmx_fit_migrad(vmx_engine* e, const vmx_fit_spec* spec, int32_t n_fits, cons
     if (ms) {
         // pools of n_fits rows, to be filled wave by wave (rows that have not arrived are zeros: nothing reads them before their
         // fits are admitted); the quadratic form's per-mock terms are sized for them by the build the first evaluation triggers
-        drop_lane(e);
+        // (a run of the same size as the last one finds its pools, the form's per-mock rows and the second lane as they are: the
+        // waves overwrite the rows their fits read, nothing reads a row before its wave has come)
+        bool resized = false;
+        for (auto* it : e->items)
+            if (it->mock_pool.n < (size_t)n_fits * it->dev.n_masked || it->n_mocks != n_fits || !it->dev.mock_pool) resized = true;
+        if (resized) drop_lane(e);
         for (size_t q = 0; q < e->items.size(); ++q) {
             ItemHost* it = e->items[q];
             const size_t need = (size_t)n_fits * it->dev.n_masked;
-            if (it->mock_pool.n < need || it->n_mocks != n_fits) {
+            if (resized) {
                 if (it->mock_pool.n < need && it->mock_pool.alloc(need, true)) return -2;
                 it->n_mocks = n_fits;
                 it->dev.mock_pool = it->mock_pool.p;
                 HIP_OK(hipMemcpy(e->d_items.p + q, &it->dev, sizeof(ItemDev), hipMemcpyHostToDevice));
+                e->quad_lin_dirty = true;
             }
-            e->quad_lin_dirty = true;
             const size_t rows = (size_t)wave * it->dev.n_masked_pad;
             if (ensure(it->mc_z, rows) || ensure(it->mc_noise, rows) || ensure(it->mc_r0, rows) || ensure(it->mc_t, rows)) return -2;
             HIP_OK(hipMemset(it->mc_z.p, 0, rows * sizeof(double)));       // (the pad columns of the draws stay zero)
