@@ -3,7 +3,8 @@ chi2-only call) is run against the same references as the default path: a fallba
 
 The knobs are read once per engine, so they are exercised in three sets of knobs that act on different stages and do
 not mask each other (a set per engine, two fixtures: six engines instead of one per knob and fixture; with
-VEGA_TEST_SINGLE_KNOBS=1 every knob gets its own engine - the way to find the culprit when a set fails).  What masks what:
+VEGA_TEST_SINGLE_KNOBS=1 every knob gets its own engine - 26 cases, ~10 s on an MI355X box since the synthetic matrices are
+kept per session - the way to find the culprit when a set fails).  What masks what:
 without the quadratic form (VMX_NO_QUAD) or without the mapped buffers (VMX_NO_ZERO_COPY) a single walker's chi2 is never
 added up on the host, and the done word is only waited on when it is not - so VMX_NO_HOST_REDUCE runs once with the done
 word and once without; VMX_NO_CINV_TAPE (the full chain's chi2 by the C^-1 products instead of the tape) sits with VMX_NO_QUAD,
